@@ -1,0 +1,283 @@
+"""Generate golden vectors by running the REFERENCE (pySDC, /root/reference) in the build container.
+
+Usage (build container only; the reference never travels to the GPU box):
+
+    cd /tmp && PYTHONDONTWRITEBYTECODE=1 \
+      PYTHONPATH=/root/repo/oracle/qmat_shim:/root/repo:/root/reference \
+      python /root/repo/tests/golden/gen_golden.py
+
+``qmat`` (third-party, absent here) is replaced by oracle/qmat_shim, which forwards to
+pysdc_amd.coeffs; the coefficient matrices that were actually used are stored with every case.
+Outputs: tests/golden/*.npz (inputs + expected outputs only - data, no reference source).
+"""
+import json
+import os
+
+import numpy as np
+
+from pySDC.core.step import Step
+from pySDC.implementations.problem_classes.HeatEquation_ND_FD import heatNd_unforced, heatNd_forced
+from pySDC.implementations.problem_classes.AdvectionEquation_ND_FD import advectionNd
+from pySDC.implementations.problem_classes.Van_der_Pol_implicit import vanderpol
+from pySDC.implementations.sweeper_classes.generic_implicit import generic_implicit
+from pySDC.implementations.sweeper_classes.imex_1st_order import imex_1st_order
+from pySDC.implementations.controller_classes.controller_nonMPI import controller_nonMPI
+from pySDC.implementations.datatype_classes.mesh import mesh, imex_mesh
+from pySDC.core.problem import Problem
+from pySDC.helpers.stats_helper import get_sorted
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+class advdiff_composite(Problem):
+    """test-only composite: impl part / solve delegate to a reference
+    heatNd_unforced, expl part to a reference advectionNd."""
+
+    dtype_u = mesh
+    dtype_f = imex_mesh
+
+    def __init__(self, nvars=64, nu=0.02, c=1.0, freq=2, order=2, stencil_type='center', bc='periodic',
+                 solver_type='direct', lintol=1e-12, liniter=10000):
+        self.diff = heatNd_unforced(nvars=nvars, nu=nu, freq=freq, order=order, bc=bc, solver_type=solver_type,
+                                    lintol=lintol, liniter=liniter)
+        self.adv = advectionNd(nvars=nvars, c=c, freq=freq, order=order, stencil_type=stencil_type, bc=bc)
+        super().__init__(init=self.diff.init)
+        self.nvars = self.diff.nvars
+        self.work_counters = self.diff.work_counters
+
+    def eval_f(self, u, t):
+        f = self.dtype_f(self.init)
+        f.impl[:] = self.diff.eval_f(u, t)
+        f.expl[:] = self.adv.eval_f(u, t)
+        return f
+
+    def solve_system(self, rhs, factor, u0, t):
+        return self.diff.solve_system(rhs, factor, u0, t)
+
+    def u_exact(self, t):
+        return self.diff.u_exact(0.0)
+
+
+PROBS = {'heat_unforced': heatNd_unforced, 'heat_forced': heatNd_forced, 'advection': advectionNd,
+         'advdiff': advdiff_composite, 'vanderpol': vanderpol}
+SWEEPERS = {'generic_implicit': generic_implicit, 'imex_1st_order': imex_1st_order}
+
+
+def coll_dict(sw):
+    d = dict(nodes=sw.coll.nodes, weights=sw.coll.weights, Qmat=sw.coll.Qmat, QI=sw.QI,
+             right_is_node=np.array(sw.coll.right_is_node), left_is_node=np.array(sw.coll.left_is_node))
+    if hasattr(sw, 'QE'):
+        d['QE'] = sw.QE
+    return d
+
+
+def fstack(f):
+    return np.asarray(f) if not hasattr(f, 'impl') else np.stack([np.asarray(f.impl), np.asarray(f.expl)])
+
+
+def sweep_case(name, prob, prob_params, sweeper, sweeper_params, dt, t0=0.1, nsweeps=3, seed=0, tau_seed=None,
+               u0_kind='randn'):
+    """one level: predict, then nsweeps x (update_nodes, compute_residual for all four residual types,
+    compute_end_point for both do_coll_update values)."""
+    desc = dict(problem_class=PROBS[prob], problem_params=dict(prob_params), sweeper_class=SWEEPERS[sweeper],
+                sweeper_params=dict(sweeper_params), level_params=dict(dt=dt), step_params=dict(maxiter=50))
+    S = Step(desc)
+    L = S.levels[0]
+    P = L.prob
+    M = L.sweep.coll.num_nodes
+    rng = np.random.default_rng(seed)
+    if prob == 'vanderpol':
+        u0 = np.asarray(prob_params.get('u0', (2.0, 0.0)), dtype=float)
+    elif u0_kind == 'randn':
+        u0 = rng.standard_normal(P.init[0])
+    else:
+        u0 = np.asarray(P.u_exact(0.0)) + 1e-3 * rng.standard_normal(P.init[0])
+    L.status.time = t0
+    L.u[0] = P.dtype_u(P.init)
+    L.u[0][:] = u0
+    out = {'u0': np.array(u0)}
+    if tau_seed is not None:
+        trng = np.random.default_rng(tau_seed)
+        for m in range(M):
+            L.tau[m] = P.dtype_u(P.init)
+            L.tau[m][:] = 1e-2 * trng.standard_normal(P.init[0])
+        out['tau'] = np.stack([np.asarray(t) for t in L.tau])
+    L.sweep.predict()
+
+    def snap(tag):
+        out[f'{tag}_u'] = np.stack([np.asarray(x) for x in L.u])
+        out[f'{tag}_f'] = np.stack([fstack(x) for x in L.f])
+        for rt in ('full_abs', 'last_abs', 'full_rel', 'last_rel'):
+            L.params.residual_type = rt
+            L.sweep.compute_residual()
+            out[f'{tag}_res_{rt}'] = np.array(L.status.residual)
+        L.params.residual_type = 'full_abs'
+        for dcu in (False, True):
+            L.sweep.params.do_coll_update = dcu
+            L.sweep.compute_end_point()
+            out[f'{tag}_uend_{int(dcu)}'] = np.asarray(L.uend).copy()
+        L.sweep.params.do_coll_update = False
+
+    snap('k0')
+    wc = {k: [] for k in P.work_counters}
+    for k in range(1, nsweeps + 1):
+        L.sweep.updateVariableCoeffs(k)
+        if getattr(L.sweep.genQI, 'isKDependent', lambda: False)():
+            out[f'k{k}_QI'] = L.sweep.QI.copy()
+        L.sweep.update_nodes()
+        snap(f'k{k}')
+        for key in wc:
+            wc[key].append(P.work_counters[key].niter)
+    for key in wc:
+        out[f'work_{key}'] = np.array(wc[key])
+    for k_, v in coll_dict(L.sweep).items():
+        out[f'coll_{k_}'] = np.asarray(v)
+    meta = dict(name=name, prob=prob, prob_params=prob_params, sweeper=sweeper, sweeper_params=sweeper_params,
+                dt=dt, t0=t0, nsweeps=nsweeps, has_tau=tau_seed is not None)
+    out['meta'] = np.array(json.dumps(meta))
+    return out
+
+
+def run_case(name, prob, prob_params, sweeper, sweeper_params, level_params, maxiter, t0, Tend, num_procs=1,
+             controller_params=None, seed=None):
+    desc = dict(problem_class=PROBS[prob], problem_params=dict(prob_params), sweeper_class=SWEEPERS[sweeper],
+                sweeper_params=dict(sweeper_params), level_params=dict(level_params),
+                step_params=dict(maxiter=maxiter))
+    cp = dict(logger_level=40)
+    cp.update(controller_params or {})
+    C = controller_nonMPI(num_procs, cp, desc)
+    P = C.MS[0].levels[0].prob
+    u0 = P.u_exact(t0)
+    if seed is not None:
+        u0 = u0 + 1e-3 * np.random.default_rng(seed).standard_normal(np.shape(u0))
+        u0 = P.dtype_u(P.init) + u0
+    uend, stats = C.run(u0, t0, Tend)
+    out = {'u0': np.asarray(u0).copy(), 'uend': np.asarray(uend).copy()}
+    niter = get_sorted(stats, type='niter', sortby='time')
+    out['niter_t'] = np.array([t for t, _ in niter])
+    out['niter'] = np.array([v for _, v in niter])
+    res = get_sorted(stats, type='residual_post_iteration', sortby='time')
+    out['res_t'] = np.array([t for t, _ in res])
+    out['res'] = np.array([v for _, v in res])
+    for k_, v in coll_dict(C.MS[0].levels[0].sweep).items():
+        out[f'coll_{k_}'] = np.asarray(v)
+    if seed is None:
+        out['err'] = np.array(abs(uend - P.u_exact(Tend)))
+    meta = dict(name=name, prob=prob, prob_params=prob_params, sweeper=sweeper, sweeper_params=sweeper_params,
+                level_params=level_params, maxiter=maxiter, t0=t0, Tend=Tend, num_procs=num_procs,
+                controller_params=controller_params or {}, seed=seed)
+    out['meta'] = np.array(json.dumps(meta))
+    return out
+
+
+def save(fname, cases):
+    flat = {}
+    for c in cases:
+        name = json.loads(str(c['meta']))['name']
+        for k, v in c.items():
+            flat[f'{name}/{k}'] = v
+    np.savez_compressed(os.path.join(OUT, fname), **flat)
+    print(fname, len(cases), 'cases', os.path.getsize(os.path.join(OUT, fname)) // 1024, 'KiB')
+
+
+def main():
+    RR = dict(quad_type='RADAU-RIGHT')
+    # ---- G2: single sweeps, heat, generic_implicit ----
+    cases = []
+    for nv, tag in ((64, '1d'), ((16, 16), '2d'), ((8, 8, 8), '3d')):
+        for order in (2, 4):
+            for M, QI, dt in ((3, 'IE', 1e-3), (5, 'LU', 1e-1), (5, 'IE', 1e-1)):
+                cases.append(sweep_case(f'heat{tag}_o{order}_M{M}_{QI}_dt{dt:g}', 'heat_unforced',
+                                        dict(nvars=nv, nu=0.1, freq=2, order=order, bc='periodic'),
+                                        'generic_implicit', dict(num_nodes=M, QI=QI, **RR), dt))
+    cases.append(sweep_case('heat3d_tau', 'heat_unforced', dict(nvars=(8, 8, 8), nu=0.1, freq=2, bc='periodic'),
+                            'generic_implicit', dict(num_nodes=5, QI='IE', **RR), 1e-2, tau_seed=7))
+    cases.append(sweep_case('heat1d_tau_LU', 'heat_unforced', dict(nvars=64, nu=0.1, freq=2, bc='periodic'),
+                            'generic_implicit', dict(num_nodes=3, QI='LU', **RR), 1e-2, tau_seed=8))
+    cases.append(sweep_case('heat2d_gauss', 'heat_unforced', dict(nvars=(16, 16), nu=0.1, freq=2, bc='periodic'),
+                            'generic_implicit', dict(num_nodes=3, QI='LU', quad_type='GAUSS'), 1e-2))
+    cases.append(sweep_case('heat2d_lobatto', 'heat_unforced', dict(nvars=(16, 16), nu=0.1, freq=2, bc='periodic'),
+                            'generic_implicit', dict(num_nodes=4, QI='IE', quad_type='LOBATTO'), 1e-2))
+    for QI in ('MIN-SR-S', 'MIN-SR-NS', 'IEpar', 'MIN-SR-FLEX', 'Qpar', 'PIC'):
+        cases.append(sweep_case(f'heat3d_diag_{QI}', 'heat_unforced',
+                                dict(nvars=(8, 8, 8), nu=0.1, freq=2, bc='periodic'),
+                                'generic_implicit', dict(num_nodes=5, QI=QI, **RR), 1e-2, nsweeps=6 if 'FLEX' in QI else 3))
+    cases.append(sweep_case('heat3d_cg', 'heat_unforced',
+                            dict(nvars=(8, 8, 8), nu=0.1, freq=2, bc='periodic', solver_type='CG', lintol=1e-12),
+                            'generic_implicit', dict(num_nodes=5, QI='IE', **RR), 1e-2))
+    cases.append(sweep_case('heat1d_dirichlet', 'heat_unforced',
+                            dict(nvars=63, nu=0.1, freq=1, bc='dirichlet-zero'),
+                            'generic_implicit', dict(num_nodes=3, QI='LU', **RR), 1e-2))
+    for ig in ('zero', 'copy'):
+        cases.append(sweep_case(f'heat1d_guess_{ig}', 'heat_unforced', dict(nvars=64, nu=0.1, freq=2, bc='periodic'),
+                                'generic_implicit', dict(num_nodes=3, QI='IE', initial_guess=ig, **RR), 1e-2))
+    save('sweeps_heat.npz', cases)
+
+    # ---- G2 IMEX ----
+    cases = []
+    for nv, tag in ((64, '1d'), ((16, 16), '2d'), ((8, 8, 8), '3d')):
+        cases.append(sweep_case(f'forced{tag}_M3', 'heat_forced', dict(nvars=nv, nu=0.1, freq=2, bc='periodic'),
+                                'imex_1st_order', dict(num_nodes=3, QI='LU', QE='EE', **RR), 1e-2, u0_kind='exact'))
+        cases.append(sweep_case(f'advdiff{tag}_M5', 'advdiff', dict(nvars=nv, nu=0.02, c=1.0, freq=2, order=2),
+                                'imex_1st_order', dict(num_nodes=5, QI='IE', QE='EE', **RR), 1e-3))
+        cases.append(sweep_case(f'advdiff{tag}_M3_LU_PIC', 'advdiff', dict(nvars=nv, nu=0.02, c=1.0, freq=2, order=4),
+                                'imex_1st_order', dict(num_nodes=3, QI='LU', QE='PIC', **RR), 1e-2))
+    cases.append(sweep_case('forced1d_dirichlet', 'heat_forced', dict(nvars=63, nu=0.1, freq=1, bc='dirichlet-zero'),
+                            'imex_1st_order', dict(num_nodes=3, QI='LU', QE='EE', **RR), 1e-2, u0_kind='exact'))
+    cases.append(sweep_case('advdiff3d_tau', 'advdiff', dict(nvars=(8, 8, 8), nu=0.02, c=1.0, freq=2, order=2),
+                            'imex_1st_order', dict(num_nodes=5, QI='IE', QE='EE', **RR), 1e-3, tau_seed=3))
+    cases.append(sweep_case('advdiff1d_upwind', 'advdiff',
+                            dict(nvars=64, nu=0.02, c=1.0, freq=2, order=3, stencil_type='upwind'),
+                            'imex_1st_order', dict(num_nodes=3, QI='IE', QE='EE', **RR), 1e-3))
+    save('sweeps_imex.npz', cases)
+
+    # ---- implicit advection (complex symbol) ----
+    cases = []
+    cases.append(sweep_case('adv1d_impl', 'advection', dict(nvars=64, c=1.0, freq=2, order=2, bc='periodic'),
+                            'generic_implicit', dict(num_nodes=3, QI='IE', **RR), 1e-2))
+    cases.append(sweep_case('adv2d_impl_up', 'advection',
+                            dict(nvars=(16, 16), c=0.5, freq=2, order=3, stencil_type='upwind', bc='periodic'),
+                            'generic_implicit', dict(num_nodes=3, QI='LU', **RR), 1e-2))
+    save('sweeps_adv.npz', cases)
+
+    # ---- G4 van der Pol ----
+    cases = []
+    cases.append(sweep_case('vdp_mu5', 'vanderpol', dict(u0=(2.0, 0.0), mu=5.0, newton_tol=1e-9),
+                            'generic_implicit', dict(num_nodes=5, QI='LU', **RR), 0.05, t0=0.0, nsweeps=4))
+    rng = np.random.default_rng(0)
+    for i in range(8):
+        u0 = tuple(float(x) for x in rng.uniform(-2, 2, 2))
+        cases.append(sweep_case(f'vdp_rand{i}', 'vanderpol', dict(u0=u0, mu=5.0, newton_tol=1e-9),
+                                'generic_implicit', dict(num_nodes=5, QI='LU', **RR), 0.05, t0=0.0, nsweeps=4))
+    save('sweeps_vdp.npz', cases)
+
+    # ---- G3 runs ----
+    cases = []
+    cfg1 = dict(prob='heat_unforced', prob_params=dict(nvars=1024, nu=0.1, freq=2, bc='periodic'),
+                sweeper='generic_implicit', sweeper_params=dict(num_nodes=3, QI='IE', **RR),
+                level_params=dict(dt=0.01, restol=1e-10), maxiter=50, t0=0.0, Tend=0.1)
+    cases.append(run_case('config1', **cfg1))
+    small = dict(prob='heat_unforced', prob_params=dict(nvars=(16, 16), nu=0.1, freq=2, bc='periodic'),
+                 sweeper='generic_implicit', sweeper_params=dict(num_nodes=3, QI='LU', **RR),
+                 level_params=dict(dt=0.02, restol=1e-9), maxiter=50, t0=0.0, Tend=0.16)
+    for P_ in (1, 2, 4):
+        for jac in (True, False):
+            if P_ == 1 and not jac:
+                continue
+            cases.append(run_case(f'mssdc_P{P_}_{"jac" if jac else "gs"}', num_procs=P_,
+                                  controller_params=dict(mssdc_jac=jac), seed=5, **small))
+    fixedk = dict(prob='heat_unforced', prob_params=dict(nvars=(8, 8, 8), nu=0.1, freq=2, bc='periodic'),
+                  sweeper='generic_implicit', sweeper_params=dict(num_nodes=5, QI='IE', **RR),
+                  level_params=dict(dt=1e-3, restol=-1), maxiter=4, t0=0.0, Tend=3e-3)
+    cases.append(run_case('fixedK_3d', seed=0, **fixedk))
+    cases.append(run_case('fixedK_3d_P2', seed=0, num_procs=2, **fixedk))
+    imex = dict(prob='heat_forced', prob_params=dict(nvars=(16, 16), nu=0.1, freq=2, bc='periodic'),
+                sweeper='imex_1st_order', sweeper_params=dict(num_nodes=3, QI='LU', QE='EE', **RR),
+                level_params=dict(dt=0.05, restol=1e-9, nsweeps=2), maxiter=50, t0=0.0, Tend=0.2)
+    cases.append(run_case('forced2d_run', **imex))
+    cases.append(run_case('forced2d_run_P2', num_procs=2, **imex))
+    save('runs.npz', cases)
+
+
+if __name__ == '__main__':
+    main()

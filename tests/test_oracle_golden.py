@@ -1,0 +1,126 @@
+"""CPU: the oracle (oracle/sdc_oracle.py) replayed against golden vectors produced by the reference
+itself (tests/golden/gen_golden.py).  This is what pins the oracle."""
+import numpy as np
+import pytest
+
+from oracle import sdc_oracle as O
+from tests._cases import load_cases, make_oracle_problem, make_oracle_coll, rel_err
+
+# the oracle follows the reference's arithmetic order; direct sparse solves are deterministic, so the
+# agreement is at rounding level (Newton / CG paths included)
+TOL = 1e-13
+
+SWEEP_FILES = ['sweeps_heat.npz', 'sweeps_imex.npz', 'sweeps_adv.npz', 'sweeps_vdp.npz']
+SWEEP_CASES = [(f, n) for f in SWEEP_FILES for n in load_cases(f)]
+
+
+@pytest.mark.parametrize('fname,name', SWEEP_CASES)
+def test_sweep_case(fname, name):
+    case = load_cases(fname)[name]
+    meta = case['meta']
+    prob = make_oracle_problem(meta['prob'], meta['prob_params'])
+    coll = make_oracle_coll(case)
+    L = O.Level(prob, coll, meta['dt'])
+    L.time = meta['t0']
+    L.u[0] = np.array(case['u0'], dtype=float).reshape(prob.nvars)
+    if meta['has_tau']:
+        for m in range(coll.num_nodes):
+            L.tau[m] = np.array(case['tau'][m])
+    ig = meta['sweeper_params'].get('initial_guess', 'spread')
+    O.predict(L, ig)
+
+    def check(tag):
+        got_u = np.stack(L.u)
+        got_f = np.stack(L.f)
+        assert rel_err(got_u, case[f'{tag}_u']) < TOL, tag
+        assert rel_err(got_f, case[f'{tag}_f']) < TOL * 10, tag
+        for rt in ('full_abs', 'last_abs', 'full_rel', 'last_rel'):
+            L.residual_type = rt
+            O.compute_residual(L)
+            ref = float(case[f'{tag}_res_{rt}'])
+            assert abs(L.status_residual - ref) <= 1e-11 * max(abs(ref), 1e-3) + 1e-15, (tag, rt)
+        for dcu in (False, True):
+            O.compute_end_point(L, dcu or not coll.right_is_node)
+            assert rel_err(L.uend, case[f'{tag}_uend_{int(dcu)}']) < TOL, (tag, dcu)
+
+    check('k0')
+    for k in range(1, meta['nsweeps'] + 1):
+        if f'k{k}_QI' in case:
+            L.coll = make_oracle_coll(case, QI=case[f'k{k}_QI'])
+        O.sweep(L)
+        check(f'k{k}')
+    for key, counter in prob.work_counters.items():
+        assert counter.niter == int(case[f'work_{key}'][-1]), key
+
+
+RUN_CASES = list(load_cases('runs.npz'))
+
+
+@pytest.mark.parametrize('name', RUN_CASES)
+def test_run_case(name):
+    case = load_cases('runs.npz')[name]
+    meta = case['meta']
+    lp = meta['level_params']
+    coll = make_oracle_coll(case)
+
+    def make_level():
+        prob = make_oracle_problem(meta['prob'], meta['prob_params'])
+        return O.Level(prob, coll, lp['dt'], restol=lp.get('restol', -1.0), nsweeps=lp.get('nsweeps', 1))
+
+    shape = make_level().prob.nvars
+    uend, stats = O.run_sdc(make_level, np.array(case['u0']).reshape(shape), meta['t0'], meta['Tend'],
+                            num_procs=meta['num_procs'], maxiter=meta['maxiter'],
+                            mssdc_jac=meta['controller_params'].get('mssdc_jac', True))
+    assert [n for _, n in stats['niter']] == list(case['niter'])            # bit-exact iteration counts
+    np.testing.assert_allclose([t for t, _ in stats['niter']], case['niter_t'], rtol=0, atol=1e-14)
+    assert rel_err(uend, case['uend']) < TOL
+    res = [r for _, hist in stats['residuals'] for r in hist]
+    np.testing.assert_allclose(res, case['res'], rtol=1e-9, atol=1e-16)
+
+
+def test_config1_known_answers():
+    """SURVEY 3.5 / BASELINE.md: 5 iterations every step, err 1.14e-11."""
+    case = load_cases('runs.npz')['config1']
+    assert list(case['niter']) == [5] * 10
+    assert abs(float(case['err']) - 1.1398e-11) < 1e-14
+
+
+def test_solver_equivalence_budget():
+    """FFT-symbol solve vs SuperLU vs CG(1e-12) on a 3-D 16^3 random rhs at the
+    benchmark stiffness; documents the <=1e-10 budget the GPU parity tests use."""
+    for order in (2, 4):
+        P = O.HeatUnforced((16, 16, 16), 0.1, 2, order=order)
+        rhs = np.random.default_rng(1).standard_normal(P.nvars)
+        lam_max = 12.0 / P.dx**2 * P.nu
+        factor = 63.0 / lam_max
+        direct = P.solve_system(rhs, factor, rhs, 0.0)
+        spec = O.spectral_solve(P, rhs, factor)
+        assert rel_err(spec, direct) < 1e-13
+        Pcg = O.HeatUnforced((16, 16, 16), 0.1, 2, order=order, solver_type='CG')
+        cgsol = Pcg.solve_system(rhs, factor, np.zeros_like(rhs), 0.0)
+        assert rel_err(cgsol, direct) < 1e-10
+        assert 20 < Pcg.work_counters['CG'].niter < 200
+    A = O.Advection((16, 16), 0.7, 2, order=3, stencil_type='upwind')
+    rhs = np.random.default_rng(2).standard_normal(A.nvars)
+    assert rel_err(O.spectral_solve(A, rhs, 0.01), A.solve_system(rhs, 0.01, rhs, 0.0)) < 1e-13
+
+
+def test_fd_stencil_known_answers():
+    """literal stencils the reference pins in tests/test_helpers/test_problem_helper.py:6-135."""
+    c, s = O.fd_stencil(2, 2, 'center')
+    np.testing.assert_allclose(c, [1, -2, 1], atol=1e-14)
+    c, s = O.fd_stencil(2, 4, 'center')
+    np.testing.assert_allclose(c, [-1 / 12, 4 / 3, -5 / 2, 4 / 3, -1 / 12], atol=1e-14)
+    c, s = O.fd_stencil(2, 6, 'center')
+    np.testing.assert_allclose(c, [1 / 90, -3 / 20, 3 / 2, -49 / 18, 3 / 2, -3 / 20, 1 / 90], atol=1e-14)
+    c, s = O.fd_stencil(1, 2, 'center')
+    np.testing.assert_allclose(c, [-0.5, 0, 0.5], atol=1e-14)
+    c, s = O.fd_stencil(1, 4, 'center')
+    np.testing.assert_allclose(c, [1 / 12, -2 / 3, 0, 2 / 3, -1 / 12], atol=1e-14)
+    c, s = O.fd_stencil(1, 1, 'upwind')
+    np.testing.assert_allclose(c, [-1, 1], atol=1e-14)
+    c, s = O.fd_stencil(1, 2, 'upwind')
+    np.testing.assert_allclose(c, [0.5, -2, 1.5], atol=1e-14)
+    c, s = O.fd_stencil(1, 3, 'upwind')
+    np.testing.assert_allclose(c, [1 / 6, -1, 1 / 2, 1 / 3], atol=1e-14)
+    np.testing.assert_array_equal(s, [-2, -1, 0, 1])
