@@ -1,0 +1,132 @@
+/* sdcmi.h - C-ABI of libsdcmi.so, the MI355X (gfx950) SDC sweep engine.
+ *
+ * The reference (pySDC) has no FFI on this path: its plug-in boundary is two Python classes named in the
+ * description dict (sweeper_class / problem_class, pySDC/core/level.py:87-88) plus the datatype the problem
+ * names (pySDC/implementations/problem_classes/generic_ND_FD.py:81-82).  The entry points below are what the
+ * host-side mirror of those classes (pysdc_amd/) binds through ctypes; each one cites the reference method
+ * it replaces.  Plain pointers and sizes only; every function returns 0 on success and a negative
+ * sdc_status otherwise, with text from sdc_last_error().
+ *
+ * State of one level lives on the device as slabs (f64, C order, spatial index fastest):
+ *   U[(M+1)][N]  F[(M+1)][ncomp][N]  TAU[M][N]  UEND[N]        N = n^ndim, M = collocation nodes
+ * replacing the reference's Python lists u[], f[], tau[] (pySDC/core/level.py:96-106).
+ */
+#ifndef SDCMI_H
+#define SDCMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sdc_ctx sdc_ctx;
+
+enum sdc_status {
+    SDC_OK = 0,
+    SDC_ERR_PARAM = -1,    /* -> ParameterError / ProblemError */
+    SDC_ERR_HIP = -2,      /* HIP runtime failure */
+    SDC_ERR_STATE = -3,    /* level not unlocked, coefficients / operator not set (assert L.status.unlocked) */
+    SDC_ERR_UNSUPPORTED = -4,
+    SDC_ERR_NOMEM = -5,
+    SDC_ERR_NEWTON = -6    /* Newton failure: pySDC raises ProblemError (Van_der_Pol_implicit.py:179-186) */
+};
+
+enum sdc_slot { SDC_SLOT_U = 0, SDC_SLOT_F = 1, SDC_SLOT_TAU = 2, SDC_SLOT_UEND = 3, SDC_SLOT_WORK = 4 };
+enum sdc_residual_type { SDC_RES_FULL_ABS = 0, SDC_RES_LAST_ABS = 1, SDC_RES_FULL_REL = 2, SDC_RES_LAST_REL = 3 };
+enum sdc_guess { SDC_GUESS_SPREAD = 0, SDC_GUESS_COPY = 1, SDC_GUESS_ZERO = 2, SDC_GUESS_CONST = 3 };
+enum sdc_expl_kind {
+    SDC_EXPL_NONE = 0,    /* fully implicit problem (generic_implicit) */
+    SDC_EXPL_STENCIL = 1, /* f.expl = B u with a periodic FD stencil (advection part of config 3) */
+    SDC_EXPL_FORCING = 2  /* f.expl = P(x) g(t), independent of u (heatNd_forced, HeatEquation_ND_FD.py:162-204) */
+};
+
+/* ---- context ----------------------------------------------------------------------------------------- */
+/* ndim in 1..3, n points per dimension (square grid as generic_ND_FD.py:131-132 requires), num_nodes = M,
+ * ncomp = 1 (dtype_f = mesh) or 2 (dtype_f = imex_mesh).  `stream` is a hipStream_t (0 = default stream).
+ * Allocates the slabs.  Replaces Level.__init__ container set-up (pySDC/core/level.py:96-106). */
+int sdc_ctx_create(sdc_ctx** out, int device, int ndim, int n, int num_nodes, int ncomp, void* stream);
+int sdc_ctx_destroy(sdc_ctx* ctx);
+const char* sdc_last_error(const sdc_ctx* ctx); /* ctx may be NULL: error of the last failed create */
+size_t sdc_ctx_bytes(const sdc_ctx* ctx);       /* device bytes held by the context */
+
+/* Collocation and Q-Delta matrices in pySDC layout: (M+1)x(M+1) row-major with zero first row/column
+ * (pySDC/core/collocation.py:88-97, pySDC/core/sweeper.py:100-123).  QE may be NULL when ncomp == 1.
+ * Called again by updateVariableCoeffs (pySDC/core/sweeper.py:262-276). */
+int sdc_set_coeffs(sdc_ctx* ctx, const double* Qmat, const double* QI, const double* QE, const double* nodes,
+                   const double* weights);
+
+/* Periodic finite-difference operator A = sum over axes of the 1-D stencil sum_s w[s] u[i+off[s]]
+ * (weights already carry coeff / dx^derivative): the matrix generic_ND_FD.py:140-149 assembles through
+ * helpers/problem_helper.py:83-242.  which = 0: implicit part (solved), 1: explicit part (SDC_EXPL_STENCIL). */
+int sdc_set_stencil(sdc_ctx* ctx, int which, int npts, const int* offsets, const double* weights);
+/* Explicit part = profile[N] * g(t) with the profile given on the host (SDC_EXPL_FORCING). */
+int sdc_set_expl_kind(sdc_ctx* ctx, int kind);
+int sdc_set_forcing_profile(sdc_ctx* ctx, const double* host_profile);
+/* g(t) at the left point and at the M node times of the current step: g[0..M] (host). */
+int sdc_set_forcing_values(sdc_ctx* ctx, const double* g);
+
+/* ---- slab access -------------------------------------------------------------------------------------- */
+/* Device pointer of one field: U[m] (m = 0..M), F[m][comp], TAU[m] (m = 0..M-1), UEND.  Non-owning; valid
+ * until sdc_ctx_destroy.  These back the L.u[m] / L.f[m] views (SURVEY 8b "Level/data surface"). */
+void* sdc_slot_ptr(sdc_ctx* ctx, int slot, int m, int comp);
+int sdc_upload(sdc_ctx* ctx, int slot, int m, int comp, const double* host);
+int sdc_download(sdc_ctx* ctx, int slot, int m, int comp, double* host);
+int sdc_set_tau_active(sdc_ctx* ctx, int active); /* L.tau[m] is None  <->  0 */
+
+/* ---- the sweep path ----------------------------------------------------------------------------------- */
+/* Sweeper.predict (pySDC/core/sweeper.py:125-162): F[0] = f(U[0], t); nodes filled per `guess`;
+ * fill_u / fill_f are the constants for SDC_GUESS_CONST ('random' draws them on the host). */
+int sdc_predict(sdc_ctx* ctx, double t, double dt, int guess, double fill_u, double fill_f);
+/* One sweep over all nodes: generic_implicit.update_nodes (generic_implicit.py:51-103) when ncomp == 1,
+ * imex_1st_order.update_nodes (imex_1st_order.py:57-108) when ncomp == 2, including the M implicit solves
+ * (generic_ND_FD.py:208-264, solver_type 'direct') and the M right-hand side evaluations (:188-206). */
+int sdc_sweep(sdc_ctx* ctx, double t, double dt);
+/* Sweeper.compute_residual (pySDC/core/sweeper.py:164-215).  node_norms[M] receives abs(residual[m]),
+ * *residual the value stored in L.status.residual for `type`.  Synchronises the stream. */
+int sdc_residual(sdc_ctx* ctx, double dt, int type, double* node_norms, double* residual);
+/* compute_end_point (generic_implicit.py:105-131 / imex_1st_order.py:110-137) into UEND. */
+int sdc_end_point(sdc_ctx* ctx, double dt, int do_coll_update);
+/* integrate() (generic_implicit.py:29-49 / imex_1st_order.py:37-55): dst[m] = dt sum_j Q[m+1][j] f[j],
+ * dst = M device pointers (called by BaseTransfer.restrict, pySDC/core/base_transfer.py:134,137). */
+int sdc_integrate(sdc_ctx* ctx, double dt, double* const* dst);
+
+/* ---- problem-level operations on raw device fields (the non-fused plug-in path) ------------------------ */
+/* eval_f (generic_ND_FD.py:188-206; HeatEquation_ND_FD.py:162-204 for the IMEX variant).  g_t is the value
+ * of the forcing's time factor g(t) (only read for SDC_EXPL_FORCING); f_expl may be NULL. */
+int sdc_eval_f(sdc_ctx* ctx, const double* u, double g_t, double* f_impl, double* f_expl);
+/* solve_system (generic_ND_FD.py:208-264, 'direct'): (I - factor*A) out = rhs. */
+int sdc_solve(sdc_ctx* ctx, const double* rhs, double factor, double* out);
+
+/* ---- datatype operations (mesh arithmetic, datatype_classes/mesh.py:12-125) ---------------------------- */
+int sdc_vec_copy(sdc_ctx* ctx, size_t n, const double* x, double* y);
+int sdc_vec_fill(sdc_ctx* ctx, size_t n, double a, double* y);
+int sdc_vec_axpby(sdc_ctx* ctx, size_t n, double a, const double* x, double b, const double* y, double* z);
+int sdc_vec_amax(sdc_ctx* ctx, size_t n, const double* x, double* out); /* abs(): max-norm, synchronises */
+
+/* ---- van der Pol ensemble (BASELINE config 4; Van_der_Pol_implicit.py:106-201) ------------------------- */
+/* ntraj independent trajectories, SoA state x1[ntraj], x2[ntraj] on the device; `nsweeps` sweeps of
+ * generic_implicit with Newton per node, all nodes kept in registers.  counters[0] = Newton iterations,
+ * counters[1] = rhs evaluations (summed over trajectories); *max_residual = max over trajectories of the
+ * full_abs collocation residual after the last sweep.  Uses the ctx coefficient matrices (M <= 8). */
+int sdc_vdp_step(sdc_ctx* ctx, size_t ntraj, double* x1, double* x2, double mu, double dt, int nsweeps,
+                 double newton_tol, int newton_maxiter, unsigned long long* counters, double* max_residual);
+
+/* ---- stream / timing ------------------------------------------------------------------------------------ */
+int sdc_sync(sdc_ctx* ctx);
+/* hipEvent timing on the context's stream (GPUTimings analogue, hooks/log_timings.py:328-342):
+ * begin records an event, end records another, synchronises and returns elapsed milliseconds. */
+int sdc_timer_begin(sdc_ctx* ctx);
+int sdc_timer_end(sdc_ctx* ctx, double* ms);
+/* Per-kernel accumulated device time since the last reset, measured with events around every launch when
+ * profiling is enabled (adds launch serialisation; off by default).  names/ms/calls arrays of length cap. */
+int sdc_profile_enable(sdc_ctx* ctx, int on);
+int sdc_profile_read(sdc_ctx* ctx, int cap, const char** names, double* ms, int* calls, int* count);
+
+int sdc_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDCMI_H */

@@ -1,0 +1,211 @@
+// In-register / LDS Stockham FFT building blocks for f64 complex lines of length N = 2^p (2 <= N <= 1024)
+// on gfx950.  One line is spread over P = N/E threads with E = min(16, N) elements per thread; element i of
+// thread j is line index j + i*P.  Every stage reads that same strided set (so loads/stores to global memory
+// keep one pattern for all N) and scatters through LDS to the Stockham output position.  Real and imaginary
+// planes go through LDS one after the other, which halves the LDS footprint (N*8 bytes per line).
+#pragma once
+#include <hip/hip_runtime.h>
+
+typedef double2 cd;
+#define DEVI __device__ __forceinline__
+
+DEVI cd cadd(cd a, cd b) { return cd{a.x + b.x, a.y + b.y}; }
+DEVI cd csub(cd a, cd b) { return cd{a.x - b.x, a.y - b.y}; }
+DEVI cd cmul(cd a, cd b) { return cd{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+DEVI cd cscale(cd a, double s) { return cd{a.x * s, a.y * s}; }
+DEVI cd cconj(cd a) { return cd{a.x, -a.y}; }
+DEVI cd cfma(cd a, cd b, cd c) {  // a*b + c
+    return cd{fma(a.x, b.x, fma(-a.y, b.y, c.x)), fma(a.x, b.y, fma(a.y, b.x, c.y))};
+}
+DEVI cd cinv(cd d) {  // 1/d
+    double m = 1.0 / (d.x * d.x + d.y * d.y);
+    return cd{d.x * m, -d.y * m};
+}
+
+// DIR = -1: forward transform exp(-2 pi i jk/N); DIR = +1: inverse (unnormalised)
+template <int DIR>
+DEVI cd mul_dir_i(cd a) {  // a * (DIR * i)
+    return DIR < 0 ? cd{a.y, -a.x} : cd{-a.y, a.x};
+}
+template <int DIR>
+DEVI cd tw_dir(cd w) {  // tables hold the forward twiddle
+    return DIR < 0 ? w : cd{w.x, -w.y};
+}
+
+// cos(2 pi m/16), sin(2 pi m/16), m = 0..7
+__device__ static const double kC16[8] = {1.0,
+                                          0.92387953251128673848,
+                                          0.70710678118654752440,
+                                          0.38268343236508977173,
+                                          0.0,
+                                          -0.38268343236508977173,
+                                          -0.70710678118654752440,
+                                          -0.92387953251128673848};
+__device__ static const double kS16[8] = {0.0,
+                                          0.38268343236508977173,
+                                          0.70710678118654752440,
+                                          0.92387953251128673848,
+                                          1.0,
+                                          0.92387953251128673848,
+                                          0.70710678118654752440,
+                                          0.38268343236508977173};
+
+template <int DIR, int M16>
+DEVI cd mul_w16(cd a) {  // a * W16^(M16) in direction DIR, 0 <= M16 < 16
+    constexpr int m = M16 & 15;
+    if constexpr (m == 0) return a;
+    else if constexpr (m == 4) return mul_dir_i<DIR>(a);
+    else if constexpr (m == 8) return cd{-a.x, -a.y};
+    else if constexpr (m == 12) return mul_dir_i<-DIR>(a);
+    else if constexpr (m > 8) { cd b = mul_w16<DIR, m - 8>(a); return cd{-b.x, -b.y}; }
+    else {
+        const double c = kC16[m], s = (DIR < 0 ? -kS16[m] : kS16[m]);
+        return cd{a.x * c - a.y * s, a.x * s + a.y * c};
+    }
+}
+
+template <int DIR>
+DEVI void bf2(cd& a, cd& b) {
+    cd t = a;
+    a = cadd(t, b);
+    b = csub(t, b);
+}
+template <int DIR>
+DEVI void bf4(cd& a0, cd& a1, cd& a2, cd& a3) {
+    cd t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = mul_dir_i<DIR>(csub(a1, a3));
+    a0 = cadd(t0, t2);
+    a1 = cadd(t1, t3);
+    a2 = csub(t0, t2);
+    a3 = csub(t1, t3);
+}
+
+// R-point DFT of x[0..R-1] (natural order in, natural order out)
+template <int R, int DIR>
+DEVI void dft(cd (&x)[R]) {
+    if constexpr (R == 2) {
+        bf2<DIR>(x[0], x[1]);
+    } else if constexpr (R == 4) {
+        bf4<DIR>(x[0], x[1], x[2], x[3]);
+    } else if constexpr (R == 8) {
+        // 8 = 4 (n1) x 2 (n2): x[2*n1 + n2]
+        bf4<DIR>(x[0], x[2], x[4], x[6]);
+        bf4<DIR>(x[1], x[3], x[5], x[7]);  // A[k1][n2] at x[2*k1 + n2]
+        x[3] = mul_w16<DIR, 2>(x[3]);
+        x[5] = mul_w16<DIR, 4>(x[5]);
+        x[7] = mul_w16<DIR, 6>(x[7]);
+        bf2<DIR>(x[0], x[1]);
+        bf2<DIR>(x[2], x[3]);
+        bf2<DIR>(x[4], x[5]);
+        bf2<DIR>(x[6], x[7]);  // X[k1 + 4*k2] at x[2*k1 + k2]
+        cd y[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) y[k] = x[2 * (k & 3) + (k >> 2)];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] = y[k];
+    } else {
+        static_assert(R == 16, "radix");
+        // 16 = 4 (n1) x 4 (n2): x[4*n1 + n2]
+        bf4<DIR>(x[0], x[4], x[8], x[12]);
+        bf4<DIR>(x[1], x[5], x[9], x[13]);
+        bf4<DIR>(x[2], x[6], x[10], x[14]);
+        bf4<DIR>(x[3], x[7], x[11], x[15]);  // A[k1][n2] at x[4*k1 + n2]
+        x[5] = mul_w16<DIR, 1>(x[5]);
+        x[6] = mul_w16<DIR, 2>(x[6]);
+        x[7] = mul_w16<DIR, 3>(x[7]);
+        x[9] = mul_w16<DIR, 2>(x[9]);
+        x[10] = mul_w16<DIR, 4>(x[10]);
+        x[11] = mul_w16<DIR, 6>(x[11]);
+        x[13] = mul_w16<DIR, 3>(x[13]);
+        x[14] = mul_w16<DIR, 6>(x[14]);
+        x[15] = mul_w16<DIR, 9>(x[15]);
+        bf4<DIR>(x[0], x[1], x[2], x[3]);
+        bf4<DIR>(x[4], x[5], x[6], x[7]);
+        bf4<DIR>(x[8], x[9], x[10], x[11]);
+        bf4<DIR>(x[12], x[13], x[14], x[15]);  // X[k1 + 4*k2] at x[4*k1 + k2]
+        cd y[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) y[k] = x[4 * (k & 3) + (k >> 2)];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) x[k] = y[k];
+    }
+}
+
+constexpr int fft_elems(int N) { return N < 16 ? N : 16; }
+
+// LDS index maps (in doubles).  The skew (pos >> 4) breaks the power-of-two strides of the stage-1 scatter.
+template <int N>
+struct LayContig {  // lines are separate: [col][pos]
+    static constexpr int kLine = N + (N >> 4);
+    DEVI static int idx(int col, int pos) { return col * kLine + pos + (pos >> 4); }
+    static constexpr int doubles(int cols) { return cols * kLine; }
+};
+template <int N, int T>
+struct LayStrided {  // T columns interleaved: [pos][col]
+    DEVI static int idx(int col, int pos) { return (pos + (pos >> 4)) * T + col; }
+    static constexpr int doubles(int) { return (N + (N >> 4)) * T; }
+};
+
+// one Stockham stage on the registers of one thread: radix R, NS = product of the previous radices
+template <int N, int R, int NS, int DIR>
+DEVI void fft_butterflies(cd (&r)[fft_elems(N)], int j, const cd* __restrict__ tw) {
+    constexpr int E = fft_elems(N), P = N / E, NB = E / R;
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+        cd x[R];
+#pragma unroll
+        for (int t = 0; t < R; ++t) x[t] = r[q + t * NB];
+        if constexpr (NS > 1) {
+            const int k = (j + q * P) & (NS - 1);
+            constexpr int step = N / (NS * R);
+#pragma unroll
+            for (int t = 1; t < R; ++t) x[t] = cmul(x[t], tw_dir<DIR>(tw[t * k * step]));
+        }
+        dft<R, DIR>(x);
+#pragma unroll
+        for (int t = 0; t < R; ++t) r[q + t * NB] = x[t];
+    }
+}
+
+// scatter the stage output through LDS and read back the strided set of the next stage
+template <int N, int R, int NS, class LAY>
+DEVI void fft_exchange(cd (&r)[fft_elems(N)], int j, int col, double* lds) {
+    constexpr int E = fft_elems(N), P = N / E, NB = E / R;
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const int b = j + q * P;
+            const int k = b & (NS - 1);
+            const int base = (b - k) * R + k;
+#pragma unroll
+            for (int t = 0; t < R; ++t)
+                lds[LAY::idx(col, base + t * NS)] = part == 0 ? r[q + t * NB].x : r[q + t * NB].y;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            const double v = lds[LAY::idx(col, j + i * P)];
+            if (part == 0) r[i].x = v;
+            else r[i].y = v;
+        }
+        __syncthreads();
+    }
+}
+
+template <int N, int NS, int DIR, class LAY>
+DEVI void fft_stages(cd (&r)[fft_elems(N)], int j, int col, double* lds, const cd* __restrict__ tw) {
+    constexpr int REM = N / NS;
+    constexpr int R = REM >= 16 ? 16 : REM;
+    fft_butterflies<N, R, NS, DIR>(r, j, tw);
+    if constexpr (NS * R < N) {
+        fft_exchange<N, R, NS, LAY>(r, j, col, lds);
+        fft_stages<N, NS * R, DIR, LAY>(r, j, col, lds, tw);
+    }
+}
+
+// Full length-N transform of the line held as r[i] <-> index j + i*P; result in the same arrangement.
+// All threads of the block must call this (it contains barriers when N > 16).
+template <int N, int DIR, class LAY>
+DEVI void fft_line(cd (&r)[fft_elems(N)], int j, int col, double* lds, const cd* __restrict__ tw) {
+    fft_stages<N, 1, DIR, LAY>(r, j, col, lds, tw);
+}

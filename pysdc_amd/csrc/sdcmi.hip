@@ -1,0 +1,1369 @@
+// libsdcmi: SDC sweep engine for MI355X (gfx950).  Kernels + the C-ABI declared in include/sdcmi.h.
+//
+// Data layout (all f64, spatial index fastest):
+//   U[(M+1)][N]   F[(M+1)][ncomp][N]   TAU[M][N]   UEND[N]   W[M][Nc] (complex half spectrum, work)
+// Sweep pipeline for the periodic FD problems (DESIGN.md "kernels"):
+//   gather (Q-weighted sums, all nodes, one pass)            -> R[m] stored in U[1+m]
+//   r2c FFT along axis 0 (strided tiles, LDS)                -> W
+//   c2c FFT along axis 1 (3-D only, in place)
+//   c2c FFT along the contiguous axis + node-coupled solve + inverse, all M nodes of one line per workgroup
+//   inverse axis 1, inverse axis 0 (c2r)                     -> U[1..M]
+//   stencil A*U[m] (+ explicit stencil)                      -> F[1..M]
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/sdcmi.h"
+#include "fft.hpp"
+
+#define MAXM 8
+#define MAXSTEN 12
+
+// ------------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------------
+struct Stencil {
+    int npts = 0;
+    int off[MAXSTEN];
+    double w[MAXSTEN];
+};
+
+struct ProfEntry {
+    double ms = 0;
+    int calls = 0;
+};
+
+struct sdc_ctx {
+    int device = 0, ndim = 0, n = 0, M = 0, ncomp = 1;
+    size_t N = 0;       // n^ndim
+    size_t Nc = 0;      // complex entries of one spectrum field
+    hipStream_t stream = nullptr;
+    double *U = nullptr, *F = nullptr, *TAU = nullptr, *UEND = nullptr, *profile = nullptr;
+    cd* W = nullptr;
+    cd *tw = nullptr, *lamI = nullptr, *lamE = nullptr;
+    unsigned long long* red = nullptr;  // reduction slots (device)
+    unsigned long long* red_host = nullptr;
+    bool tau_active = false, have_coeffs = false, have_stencil[2] = {false, false}, unlocked = false;
+    int expl_kind = SDC_EXPL_NONE;
+    double Q[MAXM + 1][MAXM + 1], QI[MAXM + 1][MAXM + 1], QE[MAXM + 1][MAXM + 1], nodes[MAXM], weights[MAXM];
+    double gvals[MAXM + 1];
+    Stencil st[2];
+    size_t bytes = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, pev0 = nullptr, pev1 = nullptr;
+    bool profiling = false;
+    std::map<std::string, ProfEntry> prof;
+    std::vector<std::string> prof_names;
+    std::string err;
+};
+
+static thread_local std::string g_create_err;
+
+static int fail(sdc_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    else g_create_err = buf;
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                              \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess)                                                                        \
+            return fail(c, e_ == hipErrorOutOfMemory ? SDC_ERR_NOMEM : SDC_ERR_HIP, "%s: %s", #call, \
+                        hipGetErrorString(e_));                                                      \
+    } while (0)
+
+struct LaunchTimer {
+    sdc_ctx* c;
+    const char* name;
+    LaunchTimer(sdc_ctx* c_, const char* n) : c(c_), name(n) {
+        if (c->profiling) (void)hipEventRecord(c->pev0, c->stream);
+    }
+    ~LaunchTimer() {
+        if (c->profiling) {
+            (void)hipEventRecord(c->pev1, c->stream);
+            (void)hipEventSynchronize(c->pev1);
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, c->pev0, c->pev1);
+            ProfEntry& e = c->prof[name];
+            e.ms += ms;
+            e.calls += 1;
+        }
+    }
+};
+
+static inline int is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
+
+// ------------------------------------------------------------------------------------------------------
+// elementwise kernels
+// ------------------------------------------------------------------------------------------------------
+struct QuadArgs {
+    const double* u0;    // may be null
+    const double* F;     // F slab base; field (j, comp) at F + (j*ncomp + comp)*N
+    const double* tau;   // TAU base or null
+    const double* Usub;  // U slab base for the residual (subtract U[mo+1]) or null
+    double* out[MAXM];   // MODE 0 outputs
+    double cI[MAXM][MAXM];  // [mo][j-1]
+    double cE[MAXM][MAXM];
+    unsigned long long* norms;  // MODE 1: per-node max |.| as ordered bit patterns
+    size_t N;
+    int nout;  // number of output rows (M, or 1 for the end point)
+    int tau_row0;  // tau row used for output 0 (end point uses the last row)
+};
+
+__device__ inline void atomic_max_abs(unsigned long long* slot, double v) {
+    // |v| >= 0: IEEE order == unsigned order of the bit pattern; NaN (0x7ff8...) wins, like np.max
+    atomicMax(slot, (unsigned long long)__double_as_longlong(fabs(v)));
+}
+
+__device__ inline double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        double w = __shfl_xor(v, o, 64);
+        v = (v > w || v != v) ? v : w;  // propagate NaN
+    }
+    return v;
+}
+
+// out[mo] = u0 + sum_j cI[mo][j] F_impl[j] (+ cE[mo][j] F_expl[j]) (+ tau[mo]) (- U[mo+1], max-norm)
+template <int M, int NCOMP, int MODE>
+__global__ __launch_bounds__(256) void k_quad(QuadArgs a) {
+    const size_t n2 = a.N >> 1;
+    double nmax[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) nmax[m] = 0.0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x * blockDim.x) {
+        double2 fi[M], fe[M];
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            fi[j] = reinterpret_cast<const double2*>(a.F + ((size_t)(j + 1) * NCOMP) * a.N)[i];
+            if (NCOMP == 2) fe[j] = reinterpret_cast<const double2*>(a.F + ((size_t)(j + 1) * NCOMP + 1) * a.N)[i];
+        }
+        double2 u0 = a.u0 ? reinterpret_cast<const double2*>(a.u0)[i] : double2{0.0, 0.0};
+#pragma unroll
+        for (int mo = 0; mo < M; ++mo) {
+            if (mo < a.nout) {
+                double2 acc = double2{0.0, 0.0};
+#pragma unroll
+                for (int j = 0; j < M; ++j) {
+                    if (NCOMP == 2) {
+                        // same grouping as imex_1st_order.py:52: Q * (impl + expl) when both weights agree
+                        acc.x += a.cI[mo][j] * fi[j].x + a.cE[mo][j] * fe[j].x;
+                        acc.y += a.cI[mo][j] * fi[j].y + a.cE[mo][j] * fe[j].y;
+                    } else {
+                        acc.x += a.cI[mo][j] * fi[j].x;
+                        acc.y += a.cI[mo][j] * fi[j].y;
+                    }
+                }
+                acc.x += u0.x;
+                acc.y += u0.y;
+                if (a.tau) {
+                    double2 t = reinterpret_cast<const double2*>(a.tau + (size_t)(a.tau_row0 + mo) * a.N)[i];
+                    acc.x += t.x;
+                    acc.y += t.y;
+                }
+                if (MODE == 0) {
+                    reinterpret_cast<double2*>(a.out[mo])[i] = acc;
+                } else {
+                    double2 us = reinterpret_cast<const double2*>(a.Usub + (size_t)(mo + 1) * a.N)[i];
+                    double r0 = fabs(acc.x - us.x), r1 = fabs(acc.y - us.y);
+                    double r = (r0 > r1 || r0 != r0) ? r0 : r1;
+                    nmax[mo] = (nmax[mo] > r || nmax[mo] != nmax[mo]) ? nmax[mo] : r;
+                }
+            }
+        }
+    }
+    if (MODE == 1) {
+#pragma unroll
+        for (int mo = 0; mo < M; ++mo) {
+            double v = wave_max(nmax[mo]);
+            if ((threadIdx.x & 63) == 0 && mo < a.nout) atomic_max_abs(a.norms + mo, v);
+        }
+    }
+}
+
+__global__ void k_amax(const double* __restrict__ x, size_t n, unsigned long long* slot) {
+    double m = 0.0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        double v = fabs(x[i]);
+        m = (m > v || m != m) ? m : v;
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomic_max_abs(slot, m);
+}
+
+__global__ void k_axpby(size_t n, double a, const double* __restrict__ x, double b, const double* __restrict__ y,
+                        double* __restrict__ z) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        double v = 0.0;
+        if (x) v = a * x[i];
+        if (y) v += b * y[i];
+        z[i] = v;
+    }
+}
+
+__global__ void k_fill(size_t n, double a, double* __restrict__ y) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = a;
+}
+
+struct SpreadArgs {
+    const double* u0;       // U[0]
+    const double* f0;       // F[0] base (ncomp fields)
+    const double* profile;  // forcing profile or null
+    double* U;              // slab
+    double* F;              // slab
+    double g[MAXM + 1];     // forcing scalars at t and the node times
+    size_t N;
+    int M, ncomp, guess, forcing;
+    double fill_u, fill_f;
+};
+
+// predictor fill of the node values; core/sweeper.py:140-158
+__global__ __launch_bounds__(256) void k_spread(SpreadArgs a) {
+    const size_t n2 = a.N >> 1;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x * blockDim.x) {
+        double2 u = reinterpret_cast<const double2*>(a.u0)[i];
+        double2 fi = reinterpret_cast<const double2*>(a.f0)[i];
+        double2 fe = double2{0.0, 0.0}, pr = double2{0.0, 0.0};
+        if (a.ncomp == 2) fe = reinterpret_cast<const double2*>(a.f0 + a.N)[i];
+        if (a.forcing) pr = reinterpret_cast<const double2*>(a.profile)[i];
+        for (int m = 1; m <= a.M; ++m) {
+            double2 um = u, fim = fi, fem = fe;
+            if (a.guess == SDC_GUESS_SPREAD) {
+                if (a.forcing) fem = double2{pr.x * a.g[m], pr.y * a.g[m]};
+            } else if (a.guess == SDC_GUESS_ZERO) {
+                um = fim = fem = double2{0.0, 0.0};
+            } else if (a.guess == SDC_GUESS_CONST) {
+                um = double2{a.fill_u, a.fill_u};
+                fim = fem = double2{a.fill_f, a.fill_f};
+            }
+            reinterpret_cast<double2*>(a.U + (size_t)m * a.N)[i] = um;
+            reinterpret_cast<double2*>(a.F + ((size_t)m * a.ncomp) * a.N)[i] = fim;
+            if (a.ncomp == 2) reinterpret_cast<double2*>(a.F + ((size_t)m * a.ncomp + 1) * a.N)[i] = fem;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// periodic finite-difference operator (eval_f), any stencil width, 1-3 dimensions
+// ------------------------------------------------------------------------------------------------------
+struct StencilArgs {
+    const double* in[MAXM];
+    double* outI[MAXM];  // implicit-operator result or null
+    double* outE[MAXM];  // explicit-stencil result or null
+    const double* profile;  // forcing profile (outE = profile * g[f]) or null
+    double g[MAXM];
+    Stencil sI, sE;
+    int nf, ndim, n;
+    int useE;  // 0 none, 1 stencil, 2 forcing
+};
+
+__device__ inline int wrapi(int i, int n) { return i < 0 ? i + n : (i >= n ? i - n : i); }
+
+__global__ __launch_bounds__(256) void k_stencil(StencilArgs a) {
+    const int n = a.n;
+    const size_t N = a.ndim == 1 ? (size_t)n : (a.ndim == 2 ? (size_t)n * n : (size_t)n * n * n);
+    const size_t n2 = N >> 1;
+    const int f = blockIdx.y;
+    const double* __restrict__ u = a.in[f];
+    for (size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x; p < n2; p += (size_t)gridDim.x * blockDim.x) {
+        const size_t i0 = p * 2;
+        const int z = (int)(i0 % n);
+        const size_t rest = i0 / n;
+        const int y = a.ndim >= 2 ? (int)(rest % n) : 0;
+        const int x = a.ndim == 3 ? (int)(rest / n) : 0;
+        const size_t line = i0 - z;  // start of the contiguous line
+        for (int which = 0; which < 2; ++which) {
+            double* out = which == 0 ? a.outI[f] : a.outE[f];
+            if (!out) continue;
+            if (which == 1 && a.useE == 2) {
+                double2 pr = reinterpret_cast<const double2*>(a.profile)[p];
+                reinterpret_cast<double2*>(out)[p] = double2{pr.x * a.g[f], pr.y * a.g[f]};
+                continue;
+            }
+            const Stencil& s = which == 0 ? a.sI : a.sE;
+            double r0 = 0.0, r1 = 0.0;
+            // axis order follows the Kronecker sum of problem_helper.py:226-235: slowest axis first
+            if (a.ndim == 3) {
+                for (int k = 0; k < s.npts; ++k) {
+                    const size_t q = ((size_t)wrapi(x + s.off[k], n) * n + y) * n + z;
+                    double2 v = *reinterpret_cast<const double2*>(u + q);
+                    r0 += s.w[k] * v.x;
+                    r1 += s.w[k] * v.y;
+                }
+            }
+            if (a.ndim >= 2) {
+                for (int k = 0; k < s.npts; ++k) {
+                    const size_t q = ((size_t)x * n + wrapi(y + s.off[k], n)) * n + z;
+                    double2 v = *reinterpret_cast<const double2*>(u + q);
+                    r0 += s.w[k] * v.x;
+                    r1 += s.w[k] * v.y;
+                }
+            }
+            for (int k = 0; k < s.npts; ++k) {
+                r0 += s.w[k] * u[line + wrapi(z + s.off[k], n)];
+                r1 += s.w[k] * u[line + wrapi(z + 1 + s.off[k], n)];
+            }
+            reinterpret_cast<double2*>(out)[p] = double2{r0, r1};
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// FFT kernels
+// ------------------------------------------------------------------------------------------------------
+struct FieldPtrs {
+    const double* in[MAXM];
+    double* out[MAXM];
+};
+
+// 1-D problems: promote the real line to complex / take the real part back
+__global__ void k_promote(FieldPtrs p, cd* W, size_t N) {
+    const int f = blockIdx.y;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < N; i += (size_t)gridDim.x * blockDim.x)
+        W[(size_t)f * N + i] = cd{p.in[f][i], 0.0};
+}
+__global__ void k_realpart(FieldPtrs p, const cd* W, size_t N) {
+    const int f = blockIdx.y;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < N; i += (size_t)gridDim.x * blockDim.x)
+        p.out[f][i] = W[(size_t)f * N + i].x;
+}
+
+// r2c along axis 0: real field [N][rest] seen as complex pairs [N][rest/2]; two real columns per complex
+// column ("two for one"), unpacked to the half spectra W[k][rest], k = 0..N/2.
+template <int N, int T>
+__global__ __launch_bounds__((N / fft_elems(N)) * T) void k_fftx_fwd(FieldPtrs p, cd* __restrict__ W, size_t fstride,
+                                                                      int rest, const cd* __restrict__ tw) {
+    constexpr int E = fft_elems(N), P = N / E;
+    using LAY = LayStrided<N, T>;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int col = threadIdx.x % T, j = threadIdx.x / T;
+    const int ncol = rest >> 1;  // complex columns
+    const int c = blockIdx.x * T + col;
+    const bool ok = c < ncol;
+    const double* __restrict__ in = p.in[blockIdx.y];
+    cd r[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i)
+        r[i] = ok ? *reinterpret_cast<const cd*>(in + (size_t)(j + i * P) * rest + 2 * (size_t)c) : cd{0.0, 0.0};
+    fft_line<N, -1, LAY>(r, j, col, lds, tw);
+    // unpack: A[k] = (C[k] + conj C[N-k]) / 2, B[k] = (C[k] - conj C[N-k]) / (2i)
+    cd A[E], B[E];
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+#pragma unroll
+        for (int i = 0; i < E; ++i) lds[LAY::idx(col, j + i * P)] = part == 0 ? r[i].x : r[i].y;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            const int k = j + i * P;
+            const double v = lds[LAY::idx(col, (N - k) & (N - 1))];
+            if (part == 0) {
+                A[i].x = 0.5 * (r[i].x + v);
+                B[i].y = -0.5 * (r[i].x - v);
+            } else {
+                A[i].y = 0.5 * (r[i].y - v);
+                B[i].x = 0.5 * (r[i].y + v);
+            }
+        }
+        __syncthreads();
+    }
+    cd* __restrict__ Wf = W + blockIdx.y * fstride;
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+        const int k = j + i * P;
+        if (ok && k <= N / 2) {
+            cd* dst = Wf + (size_t)k * rest + 2 * (size_t)c;
+            dst[0] = A[i];
+            dst[1] = B[i];
+        }
+    }
+}
+
+// c2r along axis 0 (inverse of the above, unnormalised)
+template <int N, int T>
+__global__ __launch_bounds__((N / fft_elems(N)) * T) void k_fftx_inv(FieldPtrs p, const cd* __restrict__ W,
+                                                                      size_t fstride, int rest,
+                                                                      const cd* __restrict__ tw) {
+    constexpr int E = fft_elems(N), P = N / E;
+    using LAY = LayStrided<N, T>;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int col = threadIdx.x % T, j = threadIdx.x / T;
+    const int ncol = rest >> 1;
+    const int c = blockIdx.x * T + col;
+    const bool ok = c < ncol;
+    const cd* __restrict__ Wf = W + blockIdx.y * fstride;
+    cd A[E], B[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+        const int k = j + i * P;
+        if (ok && k <= N / 2) {
+            const cd* src = Wf + (size_t)k * rest + 2 * (size_t)c;
+            A[i] = src[0];
+            B[i] = src[1];
+        } else {
+            A[i] = B[i] = cd{0.0, 0.0};
+        }
+    }
+    cd r[E];
+    // C[k] = A[k] + i B[k] (k <= N/2), C[N-k] = conj A[k] + i conj B[k]
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            const int k = j + i * P;
+            if (k <= N / 2) {
+                const bool edge = (k == 0) || (k == N / 2);
+                double own, mir;
+                if (part == 0) {
+                    own = edge ? A[i].x : A[i].x - B[i].y;
+                    mir = A[i].x + B[i].y;
+                } else {
+                    own = edge ? B[i].x : A[i].y + B[i].x;
+                    mir = -A[i].y + B[i].x;
+                }
+                lds[LAY::idx(col, k)] = own;
+                if (!edge) lds[LAY::idx(col, N - k)] = mir;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            const double v = lds[LAY::idx(col, j + i * P)];
+            if (part == 0) r[i].x = v;
+            else r[i].y = v;
+        }
+        __syncthreads();
+    }
+    fft_line<N, +1, LAY>(r, j, col, lds, tw);
+    double* __restrict__ out = p.out[blockIdx.y];
+    if (ok) {
+#pragma unroll
+        for (int i = 0; i < E; ++i) *reinterpret_cast<cd*>(out + (size_t)(j + i * P) * rest + 2 * (size_t)c) = r[i];
+    }
+}
+
+// c2c in place along the middle axis of W[f][kx][y][z] (3-D only): tile = all y x T z-columns
+template <int N, int T, int DIR>
+__global__ __launch_bounds__((N / fft_elems(N)) * T) void k_ffty(cd* __restrict__ W, size_t fstride,
+                                                                  const cd* __restrict__ tw) {
+    constexpr int E = fft_elems(N), P = N / E;
+    using LAY = LayStrided<N, T>;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int col = threadIdx.x % T, j = threadIdx.x / T;
+    const int c = blockIdx.x * T + col;
+    const bool ok = c < N;
+    cd* __restrict__ base = W + blockIdx.z * fstride + (size_t)blockIdx.y * N * N + c;
+    cd r[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i) r[i] = ok ? base[(size_t)(j + i * P) * N] : cd{0.0, 0.0};
+    fft_line<N, DIR, LAY>(r, j, col, lds, tw);
+    if (ok) {
+#pragma unroll
+        for (int i = 0; i < E; ++i) base[(size_t)(j + i * P) * N] = r[i];
+    }
+}
+
+struct ZArgs {
+    cd* W;
+    size_t fstride;
+    const cd *tw, *lamI, *lamE;  // lamE may be null
+    double cI[MAXM][MAXM];       // strictly lower: dt*QI[m+1][j+1], j < m
+    double cE[MAXM][MAXM];       // strictly lower: dt*QE[m+1][j+1]
+    double alpha[MAXM];          // dt*QI[m+1][m+1]
+    double invN;
+    int nf, ndim, coupled;
+};
+
+// forward FFT along the contiguous axis, node-coupled implicit solve in Fourier space, inverse FFT.
+// One workgroup = all nf fields of one line; field f occupies threads [f*P, (f+1)*P).
+template <int N>
+__global__ __launch_bounds__((N / fft_elems(N)) * MAXM) void k_fftz_solve(ZArgs a) {
+    constexpr int E = fft_elems(N), P = N / E;
+    using LAY = LayContig<N>;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int f = threadIdx.x / P, j = threadIdx.x % P;
+    const size_t line = blockIdx.x;
+    cd* __restrict__ Wl = a.W + f * a.fstride + line * N;
+    cd r[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i) r[i] = Wl[j + i * P];
+    fft_line<N, -1, LAY>(r, j, f, lds, a.tw);
+
+    // symbol of the other axes for this line
+    cd lI0 = cd{0.0, 0.0}, lE0 = cd{0.0, 0.0};
+    if (a.ndim == 3) {
+        const int kx = (int)(line / N), ky = (int)(line % N);
+        lI0 = cadd(a.lamI[kx], a.lamI[ky]);
+        if (a.lamE) lE0 = cadd(a.lamE[kx], a.lamE[ky]);
+    } else if (a.ndim == 2) {
+        lI0 = a.lamI[line];
+        if (a.lamE) lE0 = a.lamE[line];
+    }
+    double* re = lds;
+    double* im = lds + N + (N >> 4);
+#pragma unroll 1
+    for (int jf = 0; jf < a.nf; ++jf) {
+        if (f == jf) {
+            const double al = a.alpha[jf];
+#pragma unroll
+            for (int i = 0; i < E; ++i) {
+                const cd lam = cadd(lI0, a.lamI[j + i * P]);
+                r[i] = cmul(r[i], cinv(cd{1.0 - al * lam.x, -al * lam.y}));
+            }
+        }
+        if (a.coupled && jf + 1 < a.nf) {
+            if (f == jf) {
+#pragma unroll
+                for (int i = 0; i < E; ++i) {
+                    const int k = j + i * P;
+                    re[k + (k >> 4)] = r[i].x;
+                    im[k + (k >> 4)] = r[i].y;
+                }
+            }
+            __syncthreads();
+            if (f > jf) {
+                const double ci = a.cI[f][jf], ce = a.cE[f][jf];
+                if (ci != 0.0 || ce != 0.0) {
+#pragma unroll
+                    for (int i = 0; i < E; ++i) {
+                        const int k = j + i * P;
+                        const cd u = cd{re[k + (k >> 4)], im[k + (k >> 4)]};
+                        const cd lam = cadd(lI0, a.lamI[k]);
+                        cd coef = cd{ci * lam.x, ci * lam.y};
+                        if (a.lamE) {
+                            const cd mu = cadd(lE0, a.lamE[k]);
+                            coef.x += ce * mu.x;
+                            coef.y += ce * mu.y;
+                        }
+                        r[i] = cfma(coef, u, r[i]);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < E; ++i) r[i] = cscale(r[i], a.invN);
+    fft_line<N, +1, LAY>(r, j, f, lds, a.tw);
+#pragma unroll
+    for (int i = 0; i < E; ++i) Wl[j + i * P] = r[i];
+}
+
+// ------------------------------------------------------------------------------------------------------
+// van der Pol ensemble: one trajectory per lane, all node values in registers
+// ------------------------------------------------------------------------------------------------------
+struct VdpArgs {
+    double* x1;
+    double* x2;
+    size_t ntraj;
+    double mu, dt, tol;
+    int nsweeps, maxiter;
+    double Q[MAXM][MAXM], QI[MAXM][MAXM];  // inner MxM blocks
+    unsigned long long* counters;          // [0] newton, [1] rhs, [2] failures
+    unsigned long long* resmax;
+};
+
+template <int M>
+__global__ __launch_bounds__(256) void k_vdp(VdpArgs a) {
+#pragma clang fp contract(off)  // keep the reference's separate multiply / add roundings (Newton counts)
+    unsigned long long newton = 0, rhs = 0, failed = 0;
+    double resmax = 0.0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < a.ntraj; i += (size_t)gridDim.x * blockDim.x) {
+        const double mu = a.mu, dt = a.dt;
+        const double u00 = a.x1[i], u01 = a.x2[i];
+        double u0[M], u1[M], f0[M], f1[M];
+        // predict: spread (core/sweeper.py:140-143); f[0] evaluation counted like the reference does
+        rhs += 1;
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            u0[m] = u00;
+            u1[m] = u01;
+            f0[m] = u01;
+            f1[m] = mu * (1 - u00 * u00) * u01 - u00;
+            rhs += 1;
+        }
+        for (int k = 0; k < a.nsweeps; ++k) {
+            double g0[M], g1[M];
+#pragma unroll
+            for (int m = 0; m < M; ++m) {  // integral[m] = dt*(Q - QI) f + u0 (generic_implicit.py:72-82)
+                double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                for (int j = 0; j < M; ++j) {
+                    s0 += dt * a.Q[m][j] * f0[j];
+                    s1 += dt * a.Q[m][j] * f1[j];
+                }
+#pragma unroll
+                for (int j = 0; j < M; ++j) {
+                    s0 -= dt * a.QI[m][j] * f0[j];
+                    s1 -= dt * a.QI[m][j] * f1[j];
+                }
+                g0[m] = s0 + u00;
+                g1[m] = s1 + u01;
+            }
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                double r0 = g0[m], r1 = g1[m];
+#pragma unroll
+                for (int j = 0; j < M; ++j) {
+                    if (j < m) {
+                        r0 += dt * a.QI[m][j] * f0[j];
+                        r1 += dt * a.QI[m][j] * f1[j];
+                    }
+                }
+                const double h = dt * a.QI[m][m];
+                double x1 = u0[m], x2 = u1[m];
+                if (h == 0.0) {
+                    x1 = r0;
+                    x2 = r1;
+                } else {
+                    // Newton with the closed-form 2x2 inverse (Van_der_Pol_implicit.py:159-201)
+                    int it = 0;
+                    double res = 99.0;
+                    while (it < a.maxiter) {
+                        const double e0 = x1 - h * x2 - r0;
+                        const double e1 = x2 - h * (mu * (1 - x1 * x1) * x2 - x1) - r1;
+                        res = fmax(fabs(e0), fabs(e1));
+                        if (res < a.tol || res != res) break;
+                        const double c = 1.0 / (-2 * h * h * mu * x1 * x2 - h * h - 1 + h * mu * (1 - x1 * x1));
+                        const double d00 = c * (h * mu * (1 - x1 * x1) - 1), d01 = c * (-h);
+                        const double d10 = c * (2 * h * mu * x1 * x2 + h), d11 = c * (-1.0);
+                        const double nx1 = x1 - (d00 * e0 + d01 * e1);
+                        const double nx2 = x2 - (d10 * e0 + d11 * e1);
+                        x1 = nx1;
+                        x2 = nx2;
+                        ++it;
+                        ++newton;
+                    }
+                    if (res != res || it == a.maxiter) failed += 1;
+                }
+                u0[m] = x1;
+                u1[m] = x2;
+                f0[m] = x2;
+                f1[m] = mu * (1 - x1 * x1) * x2 - x1;
+                rhs += 1;
+            }
+        }
+        // full_abs collocation residual (core/sweeper.py:186-199)
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                s0 += dt * a.Q[m][j] * f0[j];
+                s1 += dt * a.Q[m][j] * f1[j];
+            }
+            const double r = fmax(fabs(s0 + (u00 - u0[m])), fabs(s1 + (u01 - u1[m])));
+            resmax = (resmax > r || resmax != resmax) ? resmax : r;
+        }
+        a.x1[i] = u0[M - 1];
+        a.x2[i] = u1[M - 1];
+    }
+    // wave-level reductions, one atomic per wave
+    for (int o = 32; o > 0; o >>= 1) {
+        newton += __shfl_xor(newton, o, 64);
+        rhs += __shfl_xor(rhs, o, 64);
+        failed += __shfl_xor(failed, o, 64);
+    }
+    resmax = wave_max(resmax);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(a.counters + 0, newton);
+        atomicAdd(a.counters + 1, rhs);
+        atomicAdd(a.counters + 2, failed);
+        atomic_max_abs(a.resmax, resmax);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------
+static inline int grid_for(size_t work, int block) {
+    size_t g = (work + block - 1) / block;
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+static double* slot_ptr(sdc_ctx* c, int slot, int m, int comp) {
+    switch (slot) {
+        case SDC_SLOT_U: return (m >= 0 && m <= c->M) ? c->U + (size_t)m * c->N : nullptr;
+        case SDC_SLOT_F:
+            return (m >= 0 && m <= c->M && comp >= 0 && comp < c->ncomp) ? c->F + ((size_t)m * c->ncomp + comp) * c->N
+                                                                         : nullptr;
+        case SDC_SLOT_TAU: return (m >= 0 && m < c->M) ? c->TAU + (size_t)m * c->N : nullptr;
+        case SDC_SLOT_UEND: return c->UEND;
+        default: return nullptr;
+    }
+}
+
+template <int MODE>
+static int launch_quad(sdc_ctx* c, const QuadArgs& a, const char* name) {
+    LaunchTimer lt(c, name);
+    const int grid = grid_for(c->N / 2, 256);
+#define QCASE(MM)                                                                                   \
+    case MM:                                                                                        \
+        if (c->ncomp == 2) hipLaunchKernelGGL((k_quad<MM, 2, MODE>), dim3(grid), dim3(256), 0, c->stream, a); \
+        else hipLaunchKernelGGL((k_quad<MM, 1, MODE>), dim3(grid), dim3(256), 0, c->stream, a);     \
+        break;
+    switch (c->M) {
+        QCASE(1) QCASE(2) QCASE(3) QCASE(4) QCASE(5) QCASE(6) QCASE(7) QCASE(8)
+        default: return fail(c, SDC_ERR_PARAM, "num_nodes %d > %d", c->M, MAXM);
+    }
+#undef QCASE
+    HIPCHK(c, hipGetLastError());
+    return SDC_OK;
+}
+
+static void quad_base(sdc_ctx* c, QuadArgs& a) {
+    memset(&a, 0, sizeof a);
+    a.F = c->F;
+    a.N = c->N;
+    a.nout = c->M;
+}
+
+static int run_stencil(sdc_ctx* c, int nf, const double* const* in, double* const* outI, double* const* outE,
+                       const double* g) {
+    StencilArgs a;
+    memset(&a, 0, sizeof a);
+    a.nf = nf;
+    a.ndim = c->ndim;
+    a.n = c->n;
+    a.sI = c->st[0];
+    a.sE = c->st[1];
+    a.useE = c->expl_kind;
+    a.profile = c->profile;
+    for (int f = 0; f < nf; ++f) {
+        a.in[f] = in[f];
+        a.outI[f] = outI ? outI[f] : nullptr;
+        a.outE[f] = (outE && c->expl_kind != SDC_EXPL_NONE) ? outE[f] : nullptr;
+        a.g[f] = g ? g[f] : 0.0;
+    }
+    LaunchTimer lt(c, "stencil");
+    hipLaunchKernelGGL(k_stencil, dim3(grid_for(c->N / 2, 256), nf), dim3(256), 0, c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    return SDC_OK;
+}
+
+template <int N>
+static int fft_pipeline_n(sdc_ctx* c, int nf, const FieldPtrs& p, ZArgs& z) {
+    constexpr int E = fft_elems(N), P = N / E;
+    constexpr int T = 8;  // complex columns per strided tile = 128 bytes per row
+    const size_t lds_str = (size_t)LayStrided<N, T>::doubles(T) * sizeof(double);
+    const int n = c->n;
+    z.W = c->W;
+    z.fstride = c->Nc;
+    z.tw = c->tw;
+    z.lamI = c->lamI;
+    z.nf = nf;
+    z.ndim = c->ndim;
+    z.invN = 1.0 / (double)c->N;
+    size_t lines;
+    if (c->ndim == 1) {
+        LaunchTimer lt(c, "promote");
+        hipLaunchKernelGGL(k_promote, dim3(grid_for(c->N, 256), nf), dim3(256), 0, c->stream, p, c->W, c->N);
+        lines = 1;
+    } else {
+        const int rest = (int)(c->N / n);
+        const int tiles = (rest / 2 + T - 1) / T;
+        {
+            LaunchTimer lt(c, "fft_x_fwd");
+            hipLaunchKernelGGL((k_fftx_fwd<N, T>), dim3(tiles, nf), dim3(P * T), lds_str, c->stream, p, c->W, c->Nc,
+                               rest, c->tw);
+        }
+        if (c->ndim == 3) {
+            LaunchTimer lt(c, "fft_y_fwd");
+            hipLaunchKernelGGL((k_ffty<N, T, -1>), dim3((n + T - 1) / T, n / 2 + 1, nf), dim3(P * T), lds_str,
+                               c->stream, c->W, c->Nc, c->tw);
+        }
+        lines = (size_t)(n / 2 + 1) * (c->ndim == 3 ? n : 1);
+    }
+    {
+        LaunchTimer lt(c, "fft_z_solve");
+        size_t ldsz = (size_t)LayContig<N>::doubles(nf < 2 ? 2 : nf) * sizeof(double);
+        hipLaunchKernelGGL((k_fftz_solve<N>), dim3((unsigned)lines), dim3(P * nf), ldsz, c->stream, z);
+    }
+    if (c->ndim == 1) {
+        LaunchTimer lt(c, "realpart");
+        hipLaunchKernelGGL(k_realpart, dim3(grid_for(c->N, 256), nf), dim3(256), 0, c->stream, p, c->W, c->N);
+    } else {
+        const int rest = (int)(c->N / n);
+        const int tiles = (rest / 2 + T - 1) / T;
+        if (c->ndim == 3) {
+            LaunchTimer lt(c, "fft_y_inv");
+            hipLaunchKernelGGL((k_ffty<N, T, +1>), dim3((n + T - 1) / T, n / 2 + 1, nf), dim3(P * T), lds_str,
+                               c->stream, c->W, c->Nc, c->tw);
+        }
+        LaunchTimer lt(c, "fft_x_inv");
+        hipLaunchKernelGGL((k_fftx_inv<N, T>), dim3(tiles, nf), dim3(P * T), lds_str, c->stream, p, c->W, c->Nc, rest,
+                           c->tw);
+    }
+    HIPCHK(c, hipGetLastError());
+    return SDC_OK;
+}
+
+// (I - alpha_f A) out_f = in_f + sum_{j<f} (cI[f][j] A + cE[f][j] B) out_j for f = 0..nf-1
+static int fft_pipeline(sdc_ctx* c, int nf, const FieldPtrs& p, ZArgs& z) {
+    if (!c->have_stencil[0]) return fail(c, SDC_ERR_STATE, "implicit operator not set (sdc_set_stencil)");
+    if (!is_pow2(c->n) || c->n > 1024)
+        return fail(c, SDC_ERR_UNSUPPORTED, "spectral solve needs n = 2^p <= 1024 per dimension, got %d", c->n);
+    switch (c->n) {
+        case 2: return fft_pipeline_n<2>(c, nf, p, z);
+        case 4: return fft_pipeline_n<4>(c, nf, p, z);
+        case 8: return fft_pipeline_n<8>(c, nf, p, z);
+        case 16: return fft_pipeline_n<16>(c, nf, p, z);
+        case 32: return fft_pipeline_n<32>(c, nf, p, z);
+        case 64: return fft_pipeline_n<64>(c, nf, p, z);
+        case 128: return fft_pipeline_n<128>(c, nf, p, z);
+        case 256: return fft_pipeline_n<256>(c, nf, p, z);
+        case 512: return fft_pipeline_n<512>(c, nf, p, z);
+        case 1024: return fft_pipeline_n<1024>(c, nf, p, z);
+    }
+    return fail(c, SDC_ERR_UNSUPPORTED, "n = %d", c->n);
+}
+
+static int build_symbol(sdc_ctx* c, int which) {
+    const int n = c->n;
+    std::vector<cd> lam(n);
+    const Stencil& s = c->st[which];
+    for (int k = 0; k < n; ++k) {
+        long double re = 0, im = 0;
+        for (int q = 0; q < s.npts; ++q) {
+            // exact argument reduction: (k*off) mod n
+            long long kk = ((long long)k * s.off[q]) % n;
+            if (kk < 0) kk += n;
+            const long double ang = 2.0L * 3.14159265358979323846264338327950288L * (long double)kk / (long double)n;
+            re += (long double)s.w[q] * cosl(ang);
+            im += (long double)s.w[q] * sinl(ang);
+        }
+        lam[k] = cd{(double)re, (double)im};
+    }
+    cd** dst = which == 0 ? &c->lamI : &c->lamE;
+    if (!*dst) {
+        HIPCHK(c, hipMalloc((void**)dst, sizeof(cd) * n));
+        c->bytes += sizeof(cd) * n;
+    }
+    HIPCHK(c, hipMemcpyAsync(*dst, lam.data(), sizeof(cd) * n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SDC_OK;
+}
+
+extern "C" {
+
+int sdc_version(void) { return 100; }
+
+const char* sdc_last_error(const sdc_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+size_t sdc_ctx_bytes(const sdc_ctx* ctx) { return ctx ? ctx->bytes : 0; }
+
+int sdc_ctx_create(sdc_ctx** out, int device, int ndim, int n, int num_nodes, int ncomp, void* stream) {
+    if (!out) return fail(nullptr, SDC_ERR_PARAM, "out is null");
+    *out = nullptr;
+    if (ndim < 1 || ndim > 3) return fail(nullptr, SDC_ERR_PARAM, "can work with up to three dimensions, got %d", ndim);
+    if (n < 2 || (n & 1)) return fail(nullptr, SDC_ERR_PARAM, "need an even number of points per dimension, got %d", n);
+    if (num_nodes < 1 || num_nodes > MAXM) return fail(nullptr, SDC_ERR_PARAM, "num_nodes must be in 1..%d", MAXM);
+    if (ncomp != 1 && ncomp != 2) return fail(nullptr, SDC_ERR_PARAM, "ncomp must be 1 or 2");
+    sdc_ctx* c = new sdc_ctx();
+    c->device = device;
+    c->ndim = ndim;
+    c->n = n;
+    c->M = num_nodes;
+    c->ncomp = ncomp;
+    c->stream = (hipStream_t)stream;
+    c->N = 1;
+    for (int d = 0; d < ndim; ++d) c->N *= (size_t)n;
+    c->Nc = ndim == 1 ? c->N : (size_t)(n / 2 + 1) * (c->N / n);
+    memset(c->Q, 0, sizeof c->Q);
+    memset(c->QI, 0, sizeof c->QI);
+    memset(c->QE, 0, sizeof c->QE);
+    memset(c->gvals, 0, sizeof c->gvals);
+    int rc = [&]() -> int {
+        HIPCHK(nullptr, hipSetDevice(device));
+        const size_t fb = c->N * sizeof(double);
+        HIPCHK(nullptr, hipMalloc((void**)&c->U, fb * (c->M + 1)));
+        HIPCHK(nullptr, hipMalloc((void**)&c->F, fb * (c->M + 1) * ncomp));
+        HIPCHK(nullptr, hipMalloc((void**)&c->UEND, fb));
+        HIPCHK(nullptr, hipMalloc((void**)&c->W, sizeof(cd) * c->Nc * c->M));
+        HIPCHK(nullptr, hipMalloc((void**)&c->red, sizeof(unsigned long long) * 16));
+        HIPCHK(nullptr, hipHostMalloc((void**)&c->red_host, sizeof(unsigned long long) * 16));
+        c->bytes = fb * (c->M + 1) * (1 + ncomp) + fb + sizeof(cd) * c->Nc * c->M;
+        HIPCHK(nullptr, hipMemsetAsync(c->U, 0, fb * (c->M + 1), c->stream));
+        HIPCHK(nullptr, hipMemsetAsync(c->F, 0, fb * (c->M + 1) * ncomp, c->stream));
+        HIPCHK(nullptr, hipMemsetAsync(c->UEND, 0, fb, c->stream));
+        HIPCHK(nullptr, hipEventCreate(&c->ev0));
+        HIPCHK(nullptr, hipEventCreate(&c->ev1));
+        HIPCHK(nullptr, hipEventCreate(&c->pev0));
+        HIPCHK(nullptr, hipEventCreate(&c->pev1));
+        if (is_pow2(n)) {
+            std::vector<cd> tw(n);
+            for (int m = 0; m < n; ++m) {
+                const long double ang = 2.0L * 3.14159265358979323846264338327950288L * (long double)m / (long double)n;
+                tw[m] = cd{(double)cosl(ang), (double)(-sinl(ang))};
+            }
+            HIPCHK(nullptr, hipMalloc((void**)&c->tw, sizeof(cd) * n));
+            HIPCHK(nullptr, hipMemcpyAsync(c->tw, tw.data(), sizeof(cd) * n, hipMemcpyHostToDevice, c->stream));
+        }
+        HIPCHK(nullptr, hipStreamSynchronize(c->stream));
+        return SDC_OK;
+    }();
+    if (rc != SDC_OK) {
+        sdc_ctx_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return SDC_OK;
+}
+
+int sdc_ctx_destroy(sdc_ctx* c) {
+    if (!c) return SDC_OK;
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(c->U);
+    (void)hipFree(c->F);
+    (void)hipFree(c->TAU);
+    (void)hipFree(c->UEND);
+    (void)hipFree(c->W);
+    (void)hipFree(c->tw);
+    (void)hipFree(c->lamI);
+    (void)hipFree(c->lamE);
+    (void)hipFree(c->profile);
+    (void)hipFree(c->red);
+    if (c->red_host) (void)hipHostFree(c->red_host);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->pev0) (void)hipEventDestroy(c->pev0);
+    if (c->pev1) (void)hipEventDestroy(c->pev1);
+    delete c;
+    return SDC_OK;
+}
+
+int sdc_set_coeffs(sdc_ctx* c, const double* Qmat, const double* QI, const double* QE, const double* nodes,
+                   const double* weights) {
+    if (!c || !Qmat || !QI || !nodes || !weights) return fail(c, SDC_ERR_PARAM, "null coefficient pointer");
+    if (c->ncomp == 2 && !QE) return fail(c, SDC_ERR_PARAM, "QE required for the IMEX sweeper");
+    const int M1 = c->M + 1;
+    for (int i = 0; i < M1; ++i)
+        for (int j = 0; j < M1; ++j) {
+            c->Q[i][j] = Qmat[i * M1 + j];
+            c->QI[i][j] = QI[i * M1 + j];
+            c->QE[i][j] = QE ? QE[i * M1 + j] : 0.0;
+            if (j > i && c->QI[i][j] != 0.0) return fail(c, SDC_ERR_PARAM, "Lower triangular matrix expected!");
+            if (j >= i && j > 0 && c->QE[i][j] != 0.0)
+                return fail(c, SDC_ERR_PARAM, "Strictly lower triangular matrix expected!");
+        }
+    for (int m = 0; m < c->M; ++m) {
+        c->nodes[m] = nodes[m];
+        c->weights[m] = weights[m];
+    }
+    c->have_coeffs = true;
+    return SDC_OK;
+}
+
+int sdc_set_stencil(sdc_ctx* c, int which, int npts, const int* offsets, const double* weights) {
+    if (!c || which < 0 || which > 1 || npts < 1 || npts > MAXSTEN || !offsets || !weights)
+        return fail(c, SDC_ERR_PARAM, "bad stencil (npts must be 1..%d)", MAXSTEN);
+    Stencil& s = c->st[which];
+    s.npts = npts;
+    for (int k = 0; k < npts; ++k) {
+        if (offsets[k] <= -c->n || offsets[k] >= c->n) return fail(c, SDC_ERR_PARAM, "stencil offset exceeds grid");
+        s.off[k] = offsets[k];
+        s.w[k] = weights[k];
+    }
+    c->have_stencil[which] = true;
+    if (which == 1) c->expl_kind = SDC_EXPL_STENCIL;
+    return build_symbol(c, which);
+}
+
+int sdc_set_expl_kind(sdc_ctx* c, int kind) {
+    if (!c || kind < 0 || kind > 2) return fail(c, SDC_ERR_PARAM, "bad explicit kind");
+    if (kind != SDC_EXPL_NONE && c->ncomp != 2) return fail(c, SDC_ERR_PARAM, "explicit part needs ncomp == 2");
+    c->expl_kind = kind;
+    return SDC_OK;
+}
+
+int sdc_set_forcing_profile(sdc_ctx* c, const double* host_profile) {
+    if (!c || !host_profile) return fail(c, SDC_ERR_PARAM, "null profile");
+    if (c->ncomp != 2) return fail(c, SDC_ERR_PARAM, "forcing needs ncomp == 2");
+    if (!c->profile) {
+        HIPCHK(c, hipMalloc((void**)&c->profile, c->N * sizeof(double)));
+        c->bytes += c->N * sizeof(double);
+    }
+    HIPCHK(c, hipMemcpyAsync(c->profile, host_profile, c->N * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->expl_kind = SDC_EXPL_FORCING;
+    return SDC_OK;
+}
+
+int sdc_set_forcing_values(sdc_ctx* c, const double* g) {
+    if (!c || !g) return fail(c, SDC_ERR_PARAM, "null forcing values");
+    for (int m = 0; m <= c->M; ++m) c->gvals[m] = g[m];
+    return SDC_OK;
+}
+
+static int ensure_tau(sdc_ctx* c) {
+    if (!c->TAU) {
+        HIPCHK(c, hipMalloc((void**)&c->TAU, c->N * sizeof(double) * c->M));
+        HIPCHK(c, hipMemsetAsync(c->TAU, 0, c->N * sizeof(double) * c->M, c->stream));
+        c->bytes += c->N * sizeof(double) * c->M;
+    }
+    return SDC_OK;
+}
+
+void* sdc_slot_ptr(sdc_ctx* c, int slot, int m, int comp) {
+    if (!c) return nullptr;
+    if (slot == SDC_SLOT_TAU && ensure_tau(c) != SDC_OK) return nullptr;
+    if (slot == SDC_SLOT_WORK) return c->W;
+    return slot_ptr(c, slot, m, comp);
+}
+
+int sdc_set_tau_active(sdc_ctx* c, int active) {
+    if (!c) return SDC_ERR_PARAM;
+    if (active) {
+        int rc = ensure_tau(c);
+        if (rc != SDC_OK) return rc;
+    }
+    c->tau_active = active != 0;
+    return SDC_OK;
+}
+
+int sdc_upload(sdc_ctx* c, int slot, int m, int comp, const double* host) {
+    if (!c || !host) return fail(c, SDC_ERR_PARAM, "null pointer");
+    double* d = (double*)sdc_slot_ptr(c, slot, m, comp);
+    if (!d) return fail(c, SDC_ERR_PARAM, "bad slot (%d, %d, %d)", slot, m, comp);
+    HIPCHK(c, hipMemcpyAsync(d, host, c->N * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SDC_OK;
+}
+
+int sdc_download(sdc_ctx* c, int slot, int m, int comp, double* host) {
+    if (!c || !host) return fail(c, SDC_ERR_PARAM, "null pointer");
+    double* d = (double*)sdc_slot_ptr(c, slot, m, comp);
+    if (!d) return fail(c, SDC_ERR_PARAM, "bad slot (%d, %d, %d)", slot, m, comp);
+    HIPCHK(c, hipMemcpyAsync(host, d, c->N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SDC_OK;
+}
+
+int sdc_eval_f(sdc_ctx* c, const double* u, double g_t, double* f_impl, double* f_expl) {
+    if (!c || !u || !f_impl) return fail(c, SDC_ERR_PARAM, "null pointer");
+    if (!c->have_stencil[0]) return fail(c, SDC_ERR_STATE, "implicit operator not set (sdc_set_stencil)");
+    if (c->expl_kind == SDC_EXPL_FORCING && !c->profile) return fail(c, SDC_ERR_STATE, "forcing profile not set");
+    const double* in[1] = {u};
+    double* oi[1] = {f_impl};
+    double* oe[1] = {f_expl};
+    double g[1] = {g_t};
+    return run_stencil(c, 1, in, oi, f_expl ? oe : nullptr, g);
+}
+
+int sdc_predict(sdc_ctx* c, double t, double dt, int guess, double fill_u, double fill_f) {
+    (void)t;
+    (void)dt;
+    if (!c) return SDC_ERR_PARAM;
+    if (!c->have_coeffs) return fail(c, SDC_ERR_STATE, "coefficients not set (sdc_set_coeffs)");
+    if (guess < 0 || guess > 3) return fail(c, SDC_ERR_PARAM, "initial_guess option %d not implemented", guess);
+    int rc = sdc_eval_f(c, c->U, c->gvals[0], c->F, c->ncomp == 2 ? c->F + c->N : nullptr);
+    if (rc != SDC_OK) return rc;
+    SpreadArgs a;
+    memset(&a, 0, sizeof a);
+    a.u0 = c->U;
+    a.f0 = c->F;
+    a.profile = c->profile;
+    a.U = c->U;
+    a.F = c->F;
+    a.N = c->N;
+    a.M = c->M;
+    a.ncomp = c->ncomp;
+    a.guess = guess;
+    a.forcing = c->expl_kind == SDC_EXPL_FORCING;
+    a.fill_u = fill_u;
+    a.fill_f = fill_f;
+    for (int m = 0; m <= c->M; ++m) a.g[m] = c->gvals[m];
+    {
+        LaunchTimer lt(c, "spread");
+        hipLaunchKernelGGL(k_spread, dim3(grid_for(c->N / 2, 256)), dim3(256), 0, c->stream, a);
+    }
+    HIPCHK(c, hipGetLastError());
+    c->unlocked = true;
+    return SDC_OK;
+}
+
+int sdc_sweep(sdc_ctx* c, double t, double dt) {
+    (void)t;
+    if (!c) return SDC_ERR_PARAM;
+    if (!c->have_coeffs) return fail(c, SDC_ERR_STATE, "coefficients not set (sdc_set_coeffs)");
+    if (!c->unlocked) return fail(c, SDC_ERR_STATE, "level is locked: predict first (assert L.status.unlocked)");
+    const int M = c->M;
+    // 1. gather u0 + dt (Q - QI) F_impl + dt (Q - QE) F_expl (+ tau) for all nodes into U[1..M]
+    QuadArgs q;
+    quad_base(c, q);
+    q.u0 = c->U;
+    q.tau = c->tau_active ? c->TAU : nullptr;
+    const bool forcing = c->expl_kind == SDC_EXPL_FORCING;
+    for (int m = 0; m < M; ++m) {
+        q.out[m] = c->U + (size_t)(m + 1) * c->N;
+        for (int j = 0; j < M; ++j) {
+            q.cI[m][j] = dt * (c->Q[m + 1][j + 1] - c->QI[m + 1][j + 1]);
+            // u-independent forcing: the new explicit values equal the old ones, so the strictly lower
+            // QE add-back of imex_1st_order.py:94 folds into the gather
+            q.cE[m][j] = forcing ? dt * c->Q[m + 1][j + 1] : dt * (c->Q[m + 1][j + 1] - c->QE[m + 1][j + 1]);
+        }
+    }
+    int rc = launch_quad<0>(c, q, "gather");
+    if (rc != SDC_OK) return rc;
+    // 2. node-coupled spectral solve
+    FieldPtrs p;
+    memset(&p, 0, sizeof p);
+    ZArgs z;
+    memset(&z, 0, sizeof z);
+    bool coupled = false;
+    for (int m = 0; m < M; ++m) {
+        p.in[m] = c->U + (size_t)(m + 1) * c->N;
+        p.out[m] = c->U + (size_t)(m + 1) * c->N;
+        z.alpha[m] = dt * c->QI[m + 1][m + 1];
+        for (int j = 0; j < m; ++j) {
+            z.cI[m][j] = dt * c->QI[m + 1][j + 1];
+            z.cE[m][j] = (c->expl_kind == SDC_EXPL_STENCIL) ? dt * c->QE[m + 1][j + 1] : 0.0;
+            if (z.cI[m][j] != 0.0 || z.cE[m][j] != 0.0) coupled = true;
+        }
+    }
+    z.coupled = coupled;
+    z.lamE = c->expl_kind == SDC_EXPL_STENCIL ? c->lamE : nullptr;
+    if (c->expl_kind == SDC_EXPL_STENCIL && !c->have_stencil[1])
+        return fail(c, SDC_ERR_STATE, "explicit operator not set (sdc_set_stencil which=1)");
+    rc = fft_pipeline(c, M, p, z);
+    if (rc != SDC_OK) return rc;
+    // 3. F[m] = f(U[m]) for the new values
+    const double* in[MAXM];
+    double* oi[MAXM];
+    double* oe[MAXM];
+    double g[MAXM];
+    for (int m = 0; m < M; ++m) {
+        in[m] = c->U + (size_t)(m + 1) * c->N;
+        oi[m] = c->F + ((size_t)(m + 1) * c->ncomp) * c->N;
+        oe[m] = (c->ncomp == 2 && c->expl_kind == SDC_EXPL_STENCIL) ? oi[m] + c->N : nullptr;
+        g[m] = c->gvals[m + 1];
+    }
+    return run_stencil(c, M, in, oi, c->expl_kind == SDC_EXPL_STENCIL ? oe : nullptr, g);
+}
+
+int sdc_solve(sdc_ctx* c, const double* rhs, double factor, double* out) {
+    if (!c || !rhs || !out) return fail(c, SDC_ERR_PARAM, "null pointer");
+    FieldPtrs p;
+    memset(&p, 0, sizeof p);
+    ZArgs z;
+    memset(&z, 0, sizeof z);
+    p.in[0] = rhs;
+    p.out[0] = out;
+    z.alpha[0] = factor;
+    z.coupled = 0;
+    z.lamE = nullptr;
+    return fft_pipeline(c, 1, p, z);
+}
+
+int sdc_residual(sdc_ctx* c, double dt, int type, double* node_norms, double* residual) {
+    if (!c || !residual) return fail(c, SDC_ERR_PARAM, "null pointer");
+    if (!c->have_coeffs) return fail(c, SDC_ERR_STATE, "coefficients not set (sdc_set_coeffs)");
+    if (type < 0 || type > 3)
+        return fail(c, SDC_ERR_PARAM,
+                    "residual_type = %d not implemented, choose full_abs, last_abs, full_rel or last_rel instead", type);
+    const int M = c->M;
+    HIPCHK(c, hipMemsetAsync(c->red, 0, sizeof(unsigned long long) * 16, c->stream));
+    QuadArgs q;
+    quad_base(c, q);
+    q.u0 = c->U;
+    q.tau = c->tau_active ? c->TAU : nullptr;
+    q.Usub = c->U;
+    q.norms = c->red;
+    for (int m = 0; m < M; ++m)
+        for (int j = 0; j < M; ++j) q.cI[m][j] = q.cE[m][j] = dt * c->Q[m + 1][j + 1];
+    int rc = launch_quad<1>(c, q, "residual");
+    if (rc != SDC_OK) return rc;
+    if (type >= SDC_RES_FULL_REL) {
+        LaunchTimer lt(c, "amax");
+        hipLaunchKernelGGL(k_amax, dim3(grid_for(c->N, 256)), dim3(256), 0, c->stream, c->U, c->N, c->red + 8);
+    }
+    HIPCHK(c, hipMemcpyAsync(c->red_host, c->red, sizeof(unsigned long long) * 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    double norms[MAXM], mx = 0.0;
+    for (int m = 0; m < M; ++m) {
+        memcpy(&norms[m], &c->red_host[m], sizeof(double));
+        if (node_norms) node_norms[m] = norms[m];
+        mx = (norms[m] > mx || norms[m] != norms[m]) ? norms[m] : mx;
+    }
+    double u0n;
+    memcpy(&u0n, &c->red_host[8], sizeof(double));
+    switch (type) {
+        case SDC_RES_FULL_ABS: *residual = mx; break;
+        case SDC_RES_LAST_ABS: *residual = norms[M - 1]; break;
+        case SDC_RES_FULL_REL: *residual = mx / u0n; break;
+        default: *residual = norms[M - 1] / u0n; break;
+    }
+    return SDC_OK;
+}
+
+int sdc_end_point(sdc_ctx* c, double dt, int do_coll_update) {
+    if (!c) return SDC_ERR_PARAM;
+    if (!c->have_coeffs) return fail(c, SDC_ERR_STATE, "coefficients not set (sdc_set_coeffs)");
+    if (!do_coll_update) return sdc_vec_copy(c, c->N, c->U + (size_t)c->M * c->N, c->UEND);
+    QuadArgs q;
+    quad_base(c, q);
+    q.u0 = c->U;
+    q.tau = c->tau_active ? c->TAU : nullptr;
+    q.tau_row0 = c->M - 1;
+    q.nout = 1;
+    q.out[0] = c->UEND;
+    for (int j = 0; j < c->M; ++j) q.cI[0][j] = q.cE[0][j] = dt * c->weights[j];
+    return launch_quad<0>(c, q, "end_point");
+}
+
+int sdc_integrate(sdc_ctx* c, double dt, double* const* dst) {
+    if (!c || !dst) return fail(c, SDC_ERR_PARAM, "null pointer");
+    if (!c->have_coeffs) return fail(c, SDC_ERR_STATE, "coefficients not set (sdc_set_coeffs)");
+    QuadArgs q;
+    quad_base(c, q);
+    for (int m = 0; m < c->M; ++m) {
+        if (!dst[m]) return fail(c, SDC_ERR_PARAM, "null destination %d", m);
+        q.out[m] = dst[m];
+        for (int j = 0; j < c->M; ++j) q.cI[m][j] = q.cE[m][j] = dt * c->Q[m + 1][j + 1];
+    }
+    return launch_quad<0>(c, q, "integrate");
+}
+
+int sdc_vec_copy(sdc_ctx* c, size_t n, const double* x, double* y) {
+    if (!c || !x || !y) return fail(c, SDC_ERR_PARAM, "null pointer");
+    LaunchTimer lt(c, "copy");
+    HIPCHK(c, hipMemcpyAsync(y, x, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    return SDC_OK;
+}
+
+int sdc_vec_fill(sdc_ctx* c, size_t n, double a, double* y) {
+    if (!c || !y) return fail(c, SDC_ERR_PARAM, "null pointer");
+    LaunchTimer lt(c, "fill");
+    hipLaunchKernelGGL(k_fill, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, n, a, y);
+    HIPCHK(c, hipGetLastError());
+    return SDC_OK;
+}
+
+int sdc_vec_axpby(sdc_ctx* c, size_t n, double a, const double* x, double b, const double* y, double* z) {
+    if (!c || !z) return fail(c, SDC_ERR_PARAM, "null pointer");
+    LaunchTimer lt(c, "axpby");
+    hipLaunchKernelGGL(k_axpby, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, n, a, x, b, y, z);
+    HIPCHK(c, hipGetLastError());
+    return SDC_OK;
+}
+
+int sdc_vec_amax(sdc_ctx* c, size_t n, const double* x, double* out) {
+    if (!c || !x || !out) return fail(c, SDC_ERR_PARAM, "null pointer");
+    HIPCHK(c, hipMemsetAsync(c->red + 9, 0, sizeof(unsigned long long), c->stream));
+    {
+        LaunchTimer lt(c, "amax");
+        hipLaunchKernelGGL(k_amax, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, x, n, c->red + 9);
+    }
+    HIPCHK(c, hipMemcpyAsync(c->red_host + 9, c->red + 9, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    memcpy(out, &c->red_host[9], sizeof(double));
+    return SDC_OK;
+}
+
+int sdc_vdp_step(sdc_ctx* c, size_t ntraj, double* x1, double* x2, double mu, double dt, int nsweeps,
+                 double newton_tol, int newton_maxiter, unsigned long long* counters, double* max_residual) {
+    if (!c || !x1 || !x2) return fail(c, SDC_ERR_PARAM, "null pointer");
+    if (!c->have_coeffs) return fail(c, SDC_ERR_STATE, "coefficients not set (sdc_set_coeffs)");
+    VdpArgs a;
+    memset(&a, 0, sizeof a);
+    a.x1 = x1;
+    a.x2 = x2;
+    a.ntraj = ntraj;
+    a.mu = mu;
+    a.dt = dt;
+    a.tol = newton_tol;
+    a.nsweeps = nsweeps;
+    a.maxiter = newton_maxiter;
+    for (int m = 0; m < c->M; ++m)
+        for (int j = 0; j < c->M; ++j) {
+            a.Q[m][j] = c->Q[m + 1][j + 1];
+            a.QI[m][j] = c->QI[m + 1][j + 1];
+        }
+    HIPCHK(c, hipMemsetAsync(c->red, 0, sizeof(unsigned long long) * 16, c->stream));
+    a.counters = c->red;
+    a.resmax = c->red + 4;
+    const int grid = grid_for(ntraj, 256);
+    {
+        LaunchTimer lt(c, "vdp_step");
+#define VCASE(MM) \
+    case MM: hipLaunchKernelGGL((k_vdp<MM>), dim3(grid), dim3(256), 0, c->stream, a); break;
+        switch (c->M) {
+            VCASE(1) VCASE(2) VCASE(3) VCASE(4) VCASE(5) VCASE(6) VCASE(7) VCASE(8)
+            default: return fail(c, SDC_ERR_PARAM, "num_nodes %d > %d", c->M, MAXM);
+        }
+#undef VCASE
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->red_host, c->red, sizeof(unsigned long long) * 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (counters) {
+        counters[0] = c->red_host[0];
+        counters[1] = c->red_host[1];
+    }
+    if (max_residual) memcpy(max_residual, &c->red_host[4], sizeof(double));
+    if (c->red_host[2] != 0)
+        return fail(c, SDC_ERR_NEWTON, "Newton did not converge (or got nan) for %llu trajectories", c->red_host[2]);
+    return SDC_OK;
+}
+
+int sdc_sync(sdc_ctx* c) {
+    if (!c) return SDC_ERR_PARAM;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SDC_OK;
+}
+
+int sdc_timer_begin(sdc_ctx* c) {
+    if (!c) return SDC_ERR_PARAM;
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    return SDC_OK;
+}
+
+int sdc_timer_end(sdc_ctx* c, double* ms) {
+    if (!c || !ms) return SDC_ERR_PARAM;
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    float f = 0;
+    HIPCHK(c, hipEventElapsedTime(&f, c->ev0, c->ev1));
+    *ms = f;
+    return SDC_OK;
+}
+
+int sdc_profile_enable(sdc_ctx* c, int on) {
+    if (!c) return SDC_ERR_PARAM;
+    c->profiling = on != 0;
+    c->prof.clear();
+    return SDC_OK;
+}
+
+int sdc_profile_read(sdc_ctx* c, int cap, const char** names, double* ms, int* calls, int* count) {
+    if (!c || !count) return SDC_ERR_PARAM;
+    c->prof_names.clear();
+    int i = 0;
+    for (auto& kv : c->prof) {
+        if (i < cap) {
+            c->prof_names.push_back(kv.first);
+            if (ms) ms[i] = kv.second.ms;
+            if (calls) calls[i] = kv.second.calls;
+        }
+        ++i;
+    }
+    for (int k = 0; k < (int)c->prof_names.size(); ++k)
+        if (names) names[k] = c->prof_names[k].c_str();
+    *count = i < cap ? i : cap;
+    return SDC_OK;
+}
+
+}  // extern "C"

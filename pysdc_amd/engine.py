@@ -1,0 +1,183 @@
+"""Thin object wrapper around one libsdcmi context = the device state of one pySDC Level."""
+import ctypes as C
+
+import numpy as np
+
+from pysdc_amd import lib as L
+from pysdc_amd.errors import ParameterError
+
+
+def _dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class SweepEngine:
+    """Device slabs U[(M+1)][N], F[(M+1)][ncomp][N], TAU[M][N], UEND[N] plus the sweep entry points.
+
+    nvars: tuple of equal even ints (ndim <= 3); ncomp: 1 (implicit) or 2 (IMEX)."""
+
+    def __init__(self, nvars, num_nodes, ncomp=1, device=0, stream=0):
+        self.lib = L.load()
+        nvars = (nvars,) if isinstance(nvars, int) else tuple(int(v) for v in nvars)
+        if len(set(nvars)) != 1:
+            raise ParameterError('need a square domain, got %s' % (nvars,))
+        self.nvars, self.ndim, self.n = nvars, len(nvars), nvars[0]
+        self.N = int(np.prod(nvars))
+        self.M, self.ncomp, self.device = int(num_nodes), int(ncomp), int(device)
+        self.ctx = C.c_void_p()
+        L.check(self.lib.sdc_ctx_create(C.byref(self.ctx), device, self.ndim, self.n, self.M, self.ncomp,
+                                        C.c_void_p(stream)))
+        self.tau_active = False
+
+    def close(self):
+        if getattr(self, 'ctx', None):
+            self.lib.sdc_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        L.check(rc, self.ctx)
+
+    # ---- setup ----
+    def set_coeffs(self, Qmat, QI, QE, nodes, weights):
+        Qm = np.ascontiguousarray(Qmat, dtype=np.float64)
+        qi = np.ascontiguousarray(QI, dtype=np.float64)
+        qe = None if QE is None else np.ascontiguousarray(QE, dtype=np.float64)
+        nd = np.ascontiguousarray(nodes, dtype=np.float64)
+        w = np.ascontiguousarray(weights, dtype=np.float64)
+        if Qm.shape != (self.M + 1, self.M + 1) or qi.shape != Qm.shape:
+            raise ParameterError(f'coefficient matrices must be {(self.M + 1, self.M + 1)}')
+        self._chk(self.lib.sdc_set_coeffs(self.ctx, _dptr(Qm), _dptr(qi), None if qe is None else _dptr(qe),
+                                          _dptr(nd), _dptr(w)))
+
+    def set_stencil(self, which, offsets, weights):
+        off = (C.c_int * len(offsets))(*[int(o) for o in offsets])
+        w = np.ascontiguousarray(weights, dtype=np.float64)
+        self._chk(self.lib.sdc_set_stencil(self.ctx, which, len(offsets), off, _dptr(w)))
+
+    def set_forcing_profile(self, profile):
+        p = np.ascontiguousarray(profile, dtype=np.float64).reshape(-1)
+        assert p.size == self.N
+        self._chk(self.lib.sdc_set_forcing_profile(self.ctx, _dptr(p)))
+
+    def set_forcing_values(self, g):
+        g = np.ascontiguousarray(g, dtype=np.float64)
+        assert g.size == self.M + 1
+        self._chk(self.lib.sdc_set_forcing_values(self.ctx, _dptr(g)))
+
+    def set_tau_active(self, active):
+        self._chk(self.lib.sdc_set_tau_active(self.ctx, int(bool(active))))
+        self.tau_active = bool(active)
+
+    # ---- data ----
+    def ptr(self, slot, m=0, comp=0):
+        p = self.lib.sdc_slot_ptr(self.ctx, slot, m, comp)
+        if not p:
+            raise ParameterError(f'bad slot ({slot}, {m}, {comp})')
+        return p
+
+    def upload(self, slot, m, host, comp=0):
+        h = np.ascontiguousarray(host, dtype=np.float64).reshape(-1)
+        if h.size != self.N:
+            raise ParameterError(f'expected {self.N} values, got {h.size}')
+        self._chk(self.lib.sdc_upload(self.ctx, slot, m, comp, _dptr(h)))
+
+    def download(self, slot, m=0, comp=0):
+        out = np.empty(self.N, dtype=np.float64)
+        self._chk(self.lib.sdc_download(self.ctx, slot, m, comp, _dptr(out)))
+        return out.reshape(self.nvars)
+
+    def download_u(self):
+        return np.stack([self.download(L.SLOT_U, m) for m in range(self.M + 1)])
+
+    def download_f(self):
+        if self.ncomp == 1:
+            return np.stack([self.download(L.SLOT_F, m) for m in range(self.M + 1)])
+        return np.stack([np.stack([self.download(L.SLOT_F, m, c) for c in range(2)]) for m in range(self.M + 1)])
+
+    # ---- sweep path ----
+    def predict(self, t, dt, guess='spread', fill_u=0.0, fill_f=0.0):
+        self._chk(self.lib.sdc_predict(self.ctx, t, dt, L.GUESS[guess], fill_u, fill_f))
+
+    def sweep(self, t, dt):
+        self._chk(self.lib.sdc_sweep(self.ctx, t, dt))
+
+    def residual(self, dt, residual_type='full_abs'):
+        if residual_type not in L.RES_TYPES:
+            raise ParameterError(
+                f'residual_type = {residual_type} not implemented, choose '
+                f'full_abs, last_abs, full_rel or last_rel instead'
+            )
+        norms = np.zeros(self.M)
+        res = C.c_double()
+        self._chk(self.lib.sdc_residual(self.ctx, dt, L.RES_TYPES[residual_type], _dptr(norms), C.byref(res)))
+        return res.value, norms
+
+    def end_point(self, dt, do_coll_update):
+        self._chk(self.lib.sdc_end_point(self.ctx, dt, int(bool(do_coll_update))))
+
+    def integrate(self, dt, dst_ptrs):
+        arr = (C.c_void_p * self.M)(*dst_ptrs)
+        self._chk(self.lib.sdc_integrate(self.ctx, dt, arr))
+
+    # ---- problem-level ----
+    def eval_f(self, u_ptr, g_t, fi_ptr, fe_ptr=None):
+        self._chk(self.lib.sdc_eval_f(self.ctx, u_ptr, g_t, fi_ptr, fe_ptr))
+
+    def solve(self, rhs_ptr, factor, out_ptr):
+        self._chk(self.lib.sdc_solve(self.ctx, rhs_ptr, factor, out_ptr))
+
+    # ---- vectors ----
+    def vec_copy(self, n, x, y):
+        self._chk(self.lib.sdc_vec_copy(self.ctx, n, x, y))
+
+    def vec_fill(self, n, a, y):
+        self._chk(self.lib.sdc_vec_fill(self.ctx, n, a, y))
+
+    def vec_axpby(self, n, a, x, b, y, z):
+        self._chk(self.lib.sdc_vec_axpby(self.ctx, n, a, x, b, y, z))
+
+    def vec_amax(self, n, x):
+        out = C.c_double()
+        self._chk(self.lib.sdc_vec_amax(self.ctx, n, x, C.byref(out)))
+        return out.value
+
+    # ---- misc ----
+    def sync(self):
+        self._chk(self.lib.sdc_sync(self.ctx))
+
+    def timer_begin(self):
+        self._chk(self.lib.sdc_timer_begin(self.ctx))
+
+    def timer_end(self):
+        ms = C.c_double()
+        self._chk(self.lib.sdc_timer_end(self.ctx, C.byref(ms)))
+        return ms.value
+
+    def profile_enable(self, on=True):
+        self._chk(self.lib.sdc_profile_enable(self.ctx, int(on)))
+
+    def profile_read(self):
+        cap = 64
+        names = (C.c_char_p * cap)()
+        ms = np.zeros(cap)
+        calls = (C.c_int * cap)()
+        count = C.c_int()
+        self._chk(self.lib.sdc_profile_read(self.ctx, cap, names, _dptr(ms), calls, C.byref(count)))
+        return {names[i].decode(): (float(ms[i]), int(calls[i])) for i in range(count.value)}
+
+    @property
+    def device_bytes(self):
+        return int(self.lib.sdc_ctx_bytes(self.ctx))
+
+    def vdp_step(self, ntraj, x1_ptr, x2_ptr, mu, dt, nsweeps, newton_tol=1e-9, newton_maxiter=100):
+        counters = (C.c_ulonglong * 2)()
+        res = C.c_double()
+        self._chk(self.lib.sdc_vdp_step(self.ctx, ntraj, x1_ptr, x2_ptr, mu, dt, nsweeps, newton_tol,
+                                        newton_maxiter, counters, C.byref(res)))
+        return dict(newton=int(counters[0]), rhs=int(counters[1]), residual=res.value)

@@ -1,0 +1,106 @@
+"""ctypes binding of libsdcmi.so (C-ABI: include/sdcmi.h).  No fallback: if the HIP library is missing or a
+call fails this raises - the product path never computes on the CPU."""
+import ctypes as C
+import os
+
+from pysdc_amd.errors import EngineError, ParameterError, ProblemError, UnlockError
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libsdcmi.so')
+
+SLOT_U, SLOT_F, SLOT_TAU, SLOT_UEND, SLOT_WORK = 0, 1, 2, 3, 4
+RES_TYPES = {'full_abs': 0, 'last_abs': 1, 'full_rel': 2, 'last_rel': 3}
+GUESS = {'spread': 0, 'copy': 1, 'zero': 2, 'random': 3}
+EXPL_NONE, EXPL_STENCIL, EXPL_FORCING = 0, 1, 2
+
+ERR_PARAM, ERR_HIP, ERR_STATE, ERR_UNSUPPORTED, ERR_NOMEM, ERR_NEWTON = -1, -2, -3, -4, -5, -6
+
+_dp = C.POINTER(C.c_double)
+_vp = C.c_void_p
+
+# name -> (restype, argtypes); must list every symbol include/sdcmi.h declares (tests/test_abi.py checks)
+PROTOTYPES = {
+    'sdc_version': (C.c_int, []),
+    'sdc_ctx_create': (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    'sdc_ctx_destroy': (C.c_int, [_vp]),
+    'sdc_last_error': (C.c_char_p, [_vp]),
+    'sdc_ctx_bytes': (C.c_size_t, [_vp]),
+    'sdc_set_coeffs': (C.c_int, [_vp, _dp, _dp, _dp, _dp, _dp]),
+    'sdc_set_stencil': (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_int), _dp]),
+    'sdc_set_expl_kind': (C.c_int, [_vp, C.c_int]),
+    'sdc_set_forcing_profile': (C.c_int, [_vp, _dp]),
+    'sdc_set_forcing_values': (C.c_int, [_vp, _dp]),
+    'sdc_slot_ptr': (_vp, [_vp, C.c_int, C.c_int, C.c_int]),
+    'sdc_upload': (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _dp]),
+    'sdc_download': (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _dp]),
+    'sdc_set_tau_active': (C.c_int, [_vp, C.c_int]),
+    'sdc_predict': (C.c_int, [_vp, C.c_double, C.c_double, C.c_int, C.c_double, C.c_double]),
+    'sdc_sweep': (C.c_int, [_vp, C.c_double, C.c_double]),
+    'sdc_residual': (C.c_int, [_vp, C.c_double, C.c_int, _dp, _dp]),
+    'sdc_end_point': (C.c_int, [_vp, C.c_double, C.c_int]),
+    'sdc_integrate': (C.c_int, [_vp, C.c_double, C.POINTER(_vp)]),
+    'sdc_eval_f': (C.c_int, [_vp, _vp, C.c_double, _vp, _vp]),
+    'sdc_solve': (C.c_int, [_vp, _vp, C.c_double, _vp]),
+    'sdc_vec_copy': (C.c_int, [_vp, C.c_size_t, _vp, _vp]),
+    'sdc_vec_fill': (C.c_int, [_vp, C.c_size_t, C.c_double, _vp]),
+    'sdc_vec_axpby': (C.c_int, [_vp, C.c_size_t, C.c_double, _vp, C.c_double, _vp, _vp]),
+    'sdc_vec_amax': (C.c_int, [_vp, C.c_size_t, _vp, _dp]),
+    'sdc_vdp_step': (C.c_int, [_vp, C.c_size_t, _vp, _vp, C.c_double, C.c_double, C.c_int, C.c_double, C.c_int,
+                               C.POINTER(C.c_ulonglong), _dp]),
+    'sdc_sync': (C.c_int, [_vp]),
+    'sdc_timer_begin': (C.c_int, [_vp]),
+    'sdc_timer_end': (C.c_int, [_vp, _dp]),
+    'sdc_profile_enable': (C.c_int, [_vp, C.c_int]),
+    'sdc_profile_read': (C.c_int, [_vp, C.c_int, C.POINTER(C.c_char_p), _dp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libsdcmi.so (once).  torch, when installed, is imported first so that the library binds to the
+    one HIP runtime already in the process (same SONAME, libamdhip64.so.7)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EngineError(
+            f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            '(hipcc --offload-arch=gfx950).  There is no CPU fallback.'
+        )
+    try:
+        import torch  # noqa: F401  (plumbing only: shares the HIP runtime / streams)
+    except Exception:  # pragma: no cover
+        pass
+    try:
+        lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    except OSError as e:
+        raise EngineError(f'cannot load {LIB_PATH}: {e}') from e
+    for name, (res, args) in PROTOTYPES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise EngineError(f'{LIB_PATH} does not export {name}') from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, ctx=None):
+    if rc == 0:
+        return
+    lib = load()
+    msg = lib.sdc_last_error(ctx)
+    msg = msg.decode() if msg else f'libsdcmi error {rc}'
+    if rc == ERR_PARAM:
+        raise ParameterError(msg)
+    if rc == ERR_STATE:
+        raise UnlockError(msg)
+    if rc == ERR_NEWTON:
+        raise ProblemError(msg)
+    if rc == ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    if rc == ERR_NOMEM:
+        raise MemoryError(msg)
+    raise EngineError(msg)

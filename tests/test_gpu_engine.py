@@ -1,0 +1,131 @@
+"""GPU parity: the HIP engine (through the C-ABI) against golden vectors of the reference and against the
+oracle on seeded inputs.  Tolerance: <= 1e-10 relative on f64 state (BASELINE.json north_star); residual
+values to 1e-8 relative (they are differences of O(1) quantities)."""
+import numpy as np
+import pytest
+
+from pysdc_amd import lib as L
+from tests._cases import load_cases, make_oracle_problem, make_oracle_coll, rel_err
+from tests import _gpu as G
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def supported(case):
+    meta = case['meta']
+    pp = meta['prob_params']
+    if meta['prob'] == 'vanderpol':
+        return False
+    if pp.get('bc', 'periodic') != 'periodic':
+        return False
+    n = G.norm_nvars(pp['nvars'])[0]
+    return n & (n - 1) == 0
+
+
+SWEEP_FILES = ['sweeps_heat.npz', 'sweeps_imex.npz', 'sweeps_adv.npz']
+SWEEP_CASES = [(f, n) for f in SWEEP_FILES for n, c in load_cases(f).items() if supported(c)]
+
+
+@pytest.mark.parametrize('fname,name', SWEEP_CASES)
+def test_sweep_vs_golden(fname, name):
+    case = load_cases(fname)[name]
+    meta = case['meta']
+    M = len(case['coll_nodes'])
+    dt, t0 = meta['dt'], meta['t0']
+    e = G.engine_for(meta['prob'], meta['prob_params'], M)
+    G.set_case_coeffs(e, case)
+    G.set_forcing_times(e, meta, t0, dt, case['coll_nodes'])
+    e.upload(L.SLOT_U, 0, case['u0'])
+    if meta['has_tau']:
+        e.set_tau_active(True)
+        for m in range(M):
+            e.upload(L.SLOT_TAU, m, case['tau'][m])
+    e.predict(t0, dt, meta['sweeper_params'].get('initial_guess', 'spread'))
+    right = bool(case['coll_right_is_node'])
+
+    def check(tag):
+        assert rel_err(e.download_u(), case[f'{tag}_u']) < TOL, tag
+        assert rel_err(e.download_f(), case[f'{tag}_f']) < TOL, tag
+        for rt in ('full_abs', 'last_abs', 'full_rel', 'last_rel'):
+            res, _ = e.residual(dt, rt)
+            ref = float(case[f'{tag}_res_{rt}'])
+            scale = max(1.0, float(np.max(np.abs(case[f'{tag}_u'])))) if 'abs' in rt else 1.0
+            assert abs(res - ref) <= 1e-8 * abs(ref) + 1e-11 * scale, (tag, rt, res, ref)
+        for dcu in (False, True):
+            e.end_point(dt, dcu or not right)
+            assert rel_err(e.download(L.SLOT_UEND), case[f'{tag}_uend_{int(dcu)}']) < TOL, (tag, dcu)
+
+    check('k0')
+    for k in range(1, meta['nsweeps'] + 1):
+        if f'k{k}_QI' in case:
+            G.set_case_coeffs(e, case, QI=case[f'k{k}_QI'])
+        e.sweep(t0, dt)
+        check(f'k{k}')
+    e.close()
+
+
+@pytest.mark.parametrize('nvars,order', [((32,), 2), ((64, 64), 4), ((16, 16, 16), 2), ((32, 32, 32), 6),
+                                         ((128,), 8), ((256, 256), 2)])
+def test_eval_f_and_solve_vs_oracle(nvars, order):
+    from oracle import sdc_oracle as O
+
+    P = O.HeatUnforced(nvars if len(nvars) > 1 else nvars[0], 0.1, 2, order=order)
+    e = G.engine_for('heat_unforced', dict(nvars=nvars, nu=0.1, order=order), 3)
+    rng = np.random.default_rng(11)
+    u = rng.standard_normal(nvars)
+    e.upload(L.SLOT_U, 0, u)
+    e.eval_f(e.ptr(L.SLOT_U, 0), 0.0, e.ptr(L.SLOT_F, 0))
+    assert rel_err(e.download(L.SLOT_F, 0), P.eval_f(u, 0.0)) < 1e-13
+    factor = 63.0 / (4.0 * len(nvars) * 0.1 / P.dx**2)
+    e.solve(e.ptr(L.SLOT_U, 0), factor, e.ptr(L.SLOT_U, 1))
+    got = e.download(L.SLOT_U, 1)
+    ref = O.spectral_solve(P, u, factor) if np.prod(nvars) > 40000 else P.solve_system(u, factor, u, 0.0)
+    assert rel_err(got, ref) < 1e-12
+    # in place is allowed
+    e.solve(e.ptr(L.SLOT_U, 0), factor, e.ptr(L.SLOT_U, 0))
+    assert rel_err(e.download(L.SLOT_U, 0), ref) < 1e-12
+    e.close()
+
+
+def test_vector_ops():
+    e = G.engine_for('heat_unforced', dict(nvars=(16, 16), nu=0.1), 2)
+    rng = np.random.default_rng(3)
+    x, y = rng.standard_normal((16, 16)), rng.standard_normal((16, 16))
+    e.upload(L.SLOT_U, 0, x)
+    e.upload(L.SLOT_U, 1, y)
+    e.vec_axpby(e.N, 2.5, e.ptr(L.SLOT_U, 0), -0.5, e.ptr(L.SLOT_U, 1), e.ptr(L.SLOT_U, 2))
+    assert np.array_equal(e.download(L.SLOT_U, 2), 2.5 * x + (-0.5) * y)
+    assert e.vec_amax(e.N, e.ptr(L.SLOT_U, 0)) == float(np.max(np.abs(x)))
+    e.vec_fill(e.N, 3.25, e.ptr(L.SLOT_U, 2))
+    assert np.all(e.download(L.SLOT_U, 2) == 3.25)
+    e.vec_copy(e.N, e.ptr(L.SLOT_U, 1), e.ptr(L.SLOT_U, 2))
+    assert np.array_equal(e.download(L.SLOT_U, 2), y)
+    xn = x.copy()
+    xn[3, 4] = np.nan
+    e.upload(L.SLOT_U, 0, xn)
+    assert np.isnan(e.vec_amax(e.N, e.ptr(L.SLOT_U, 0)))   # np.max propagates NaN; so does abs()
+    e.close()
+
+
+def test_error_paths():
+    from pysdc_amd.engine import SweepEngine
+    from pysdc_amd.errors import ParameterError, UnlockError
+
+    with pytest.raises(ParameterError):
+        SweepEngine((7, 7), 3)
+    with pytest.raises(ParameterError):
+        SweepEngine((8, 8, 8, 8), 3)
+    e = SweepEngine((8, 8), 3)
+    with pytest.raises(UnlockError):
+        e.sweep(0.0, 0.1)          # coefficients not set
+    bad = np.zeros((4, 4))
+    bad[1, 2] = 1.0
+    with pytest.raises(ParameterError):
+        e.set_coeffs(np.zeros((4, 4)), bad, None, np.ones(3), np.ones(3))
+    e.close()
+    e = SweepEngine((12, 12), 3)   # even but not 2^p: operator works, spectral solve refuses
+    e.set_stencil(0, [-1, 0, 1], [1.0, -2.0, 1.0])
+    with pytest.raises(NotImplementedError):
+        e.solve(e.ptr(L.SLOT_U, 0), 0.1, e.ptr(L.SLOT_U, 1))
+    e.close()
