@@ -1,0 +1,206 @@
+"""Benchmark of the SDC sweep path (BASELINE.json metric): time-steps/s and SDC-iterations/s of the 3-D heat
+equation, finite differences, M=5 Gauss-Radau nodes, implicit (generic_implicit) sweeps, f64.
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+One "step" = one block of N time steps (one time-slice per GPU; N = 1: one time step): predict, then 4 SDC
+iterations (update_nodes + compute_residual + convergence check each) and the end point, all through the
+drop-in plug-in path  controller -> sweeper_class/problem_class -> C-ABI -> HIP kernels.  Inputs are generated
+on the device and are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def kernel_bytes(name, n, M, ncomp=1):
+    """ALGORITHMIC bytes of one launch of each kernel of the sweep (DESIGN.md 'kernels'): fields read + written
+    once, f64; spectra have (n/2+1)/n * 2 words per real word."""
+    N = n**3
+    field = 8.0 * N
+    spec = 16.0 * (n // 2 + 1) * n * n
+    table = {
+        'gather': (1 + M * ncomp + M) * field,          # u0 + F[1..M] -> R[1..M]
+        'fft_x_fwd': M * (field + spec),                # real tiles in, half spectra out
+        'fft_y_fwd': 2 * M * spec,
+        'fft_z_solve': 2 * M * spec,
+        'fft_y_inv': 2 * M * spec,
+        'fft_x_inv': M * (field + spec),
+        'stencil': 2 * M * field * ncomp if ncomp == 1 else M * field * 3,
+        'residual': (1 + M * ncomp + M) * field,        # u0, F[1..M], U[1..M] -> M norms
+        'spread': (2 + 2 * M) * field,
+        'copy': 2 * field,
+    }
+    return table.get(name)
+
+
+def cpu_baseline(M, dt_ref_n, sample_n=64, target_n=1024, nsweeps=4):
+    """The oracle (NumPy/SciPy restatement of the reference's path, oracle/sdc_oracle.py) timed on one host
+    core on a bounded sample: heat 3-D sample_n^3, M nodes, 1 time step = 4 sweeps, CG(rtol 1e-12) like the
+    reference's feasible 3-D configuration.  kind = "port"."""
+    import numpy as np
+
+    from oracle import sdc_oracle as O
+    from pysdc_amd.coeffs import CollBase, QDELTA_GENERATORS
+    from pysdc_amd.synth import init_field
+
+    c = CollBase(M, 0, 1, 'LEGENDRE', 'RADAU-RIGHT')
+    QI = np.zeros_like(c.Qmat)
+    QI[1:, 1:] = QDELTA_GENERATORS['IE'](qGen=c.generator, tLeft=0).genCoeffs()
+    coll = O.Coll(c.nodes, c.weights, c.Qmat, QI)
+    nv = (sample_n,) * 3
+    dt = dt_ref_n * (target_n / sample_n) ** 2  # same dt*nu/dx^2 stiffness as the GPU workload
+    t0 = time.perf_counter()
+    prob = O.HeatUnforced(nv, 0.1, 2, solver_type='CG', lintol=1e-12)
+    setup = time.perf_counter() - t0
+    u0 = init_field(nv, 2, 1e-3, 0)
+    t0 = time.perf_counter()
+    O.run_sdc(lambda: O.Level(prob, coll, dt, restol=-1.0), u0, 0.0, dt, maxiter=nsweeps)
+    el = time.perf_counter() - t0
+    raw = 1.0 / el
+    scale = (sample_n / target_n) ** 3
+    return {
+        'value': raw * scale, 'unit': 'time-steps/s', 'cores': 1, 'kind': 'port',
+        'sample': f'heat 3-D {sample_n}^3 f64, M={M}, 1 time step = {nsweeps} sweeps, CG rtol 1e-12 '
+                  f'({prob.work_counters["CG"].niter} CG iterations), {el:.1f} s on 1 core (+{setup:.1f} s matrix '
+                  f'setup, not counted); value = measured {raw:.4f} steps/s x ({sample_n}/{target_n})^3 '
+                  f'(linear-in-DOF extrapolation, optimistic for the CPU)',
+        'raw_value': raw, 'raw_unit': f'time-steps/s at {sample_n}^3',
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--n', type=int, default=1024, help='grid points per dimension (1024 = BASELINE metric)')
+    ap.add_argument('--nodes', type=int, default=5)
+    ap.add_argument('--sweeps', type=int, default=4)
+    ap.add_argument('--qi', default='IE')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    import ctypes as C
+
+    from pysdc_amd import lib as Lb
+    from pysdc_amd.controller import controller_nonMPI, controller_dist
+    from pysdc_amd.problems import heatNd_unforced
+    from pysdc_amd.sweepers import generic_implicit
+    from pysdc_amd.stats import get_sorted
+
+    n, M, K = args.n, args.nodes, args.sweeps
+    dt = 1e-3 * (512.0 / n) ** 2  # dt*nu*12/dx^2 ~ 315 at every size
+    desc = dict(problem_class=heatNd_unforced, problem_params=dict(nvars=(n, n, n), nu=0.1, freq=2, order=2),
+                sweeper_class=generic_implicit,
+                sweeper_params=dict(num_nodes=M, quad_type='RADAU-RIGHT', QI=args.qi),
+                level_params=dict(dt=dt, restol=-1.0, nsweeps=1), step_params=dict(maxiter=K))
+    if world == 1:
+        ctrl = controller_nonMPI(1, dict(logger_level=40), desc)
+        step = ctrl.MS[0]
+    else:
+        ctrl = controller_dist(dict(logger_level=40), desc)
+        step = ctrl.S
+    L = step.levels[0]
+    eng = L.engine  # allocates the device slabs
+    # synthetic input on the device: sin mode (freq 2) + 1e-3 * seeded noise
+    u0 = L.prob.u_init
+    freq = (C.c_int * 3)(2, 2, 2)
+    Lb.check(eng.lib.sdc_init_field(eng.ctx, u0.ptr, freq, 1e-3, 0), eng.ctx)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    block = dt * world  # one bench step advances `world` time steps
+    uend, _ = ctrl.run(u0, 0.0, block * args.warmup) if args.warmup > 0 else (u0, None)
+    sync()
+    eng.profile_enable(True)
+    t0 = time.perf_counter()
+    uend, stats = ctrl.run(uend, block * args.warmup, block * (args.warmup + args.steps))
+    sync()
+    el = time.perf_counter() - t0
+    prof = eng.profile_read()
+    eng.profile_enable(False)
+
+    elt = torch.tensor([el], dtype=torch.float64, device='cuda')
+    if world > 1:
+        dist.all_reduce(elt, op=dist.ReduceOp.MAX)
+    el = float(elt.item())
+    niter = [v for _, v in get_sorted(stats, type='niter')]
+    assert niter == [K] * len(niter), niter
+    finite = bool(np.isfinite(abs(uend)))
+
+    if rank == 0:
+        steps_total = args.steps * world
+        sweeps_total = steps_total * K
+        # dominant kernel of the timed region, from HIP events on the engine's stream
+        dom = max(prof.items(), key=lambda kv: kv[1][0]) if prof else (None, (0.0, 0))
+        kern = {k: {'ms_per_launch': v[0] / v[1], 'launches': v[1],
+                    'gbs': (kernel_bytes(k, n, M) or 0) / (v[0] / v[1]) / 1e6}
+                for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0]) if v[1] > 0}
+        roof = None
+        if dom[0] is not None and kernel_bytes(dom[0], n, M):
+            ach = kernel_bytes(dom[0], n, M) / (dom[1][0] / dom[1][1]) / 1e6
+            traffic = None
+            tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
+            if os.path.exists(tfile):
+                tr = json.load(open(tfile)).get(f'{dom[0]}@{n}')
+                traffic = tr
+            roof = {'kernel': dom[0], 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': ach / HBM_PEAK_GBS, 'traffic': traffic,
+                    'algorithmic_bytes_per_launch': kernel_bytes(dom[0], n, M),
+                    'ms_per_launch': dom[1][0] / dom[1][1]}
+        sweep_ms = sum(v[0] for k, v in prof.items()
+                       if k in ('gather', 'fft_x_fwd', 'fft_y_fwd', 'fft_z_solve', 'fft_y_inv', 'fft_x_inv', 'stencil')
+                       ) / max(1, sweeps_total // world)
+        out = {
+            'metric': 'time-steps/s (HeatND 3-D FD, M=5, implicit SDC sweeps)', 'value': steps_total / el,
+            'unit': 'time-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': 1e3 * el / args.steps, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': f'heatNd_unforced {n}^3 periodic order-2 FD, nu=0.1, M={M} LEGENDRE RADAU-RIGHT, '
+                                   f'QI={args.qi}, generic_implicit, {K} sweeps/step (restol=-1, maxiter={K}), '
+                                   f'dt={dt:g}, solver=direct (Fourier)',
+                       'time_parallel': f'{world} time-slice(s), one per GPU, multi-step SDC (Jacobi)'},
+            'sdc_iters_per_s': sweeps_total / el,
+            'sweep_kernels_ms': sweep_ms,
+            'sweep_floor_gbs': 8.0 * n**3 * (3 * M + 1) / sweep_ms / 1e6 if sweep_ms else None,
+            'roofline': roof, 'kernels': kern, 'finite': finite,
+            'device_bytes_per_gpu': eng.device_bytes,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out['cpu_baseline'] = cpu_baseline(M, dt, target_n=n)
+            except Exception as e:  # pragma: no cover
+                out['cpu_baseline'] = {'error': repr(e)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

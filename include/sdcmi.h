@@ -74,6 +74,10 @@ void* sdc_slot_ptr(sdc_ctx* ctx, int slot, int m, int comp);
 int sdc_upload(sdc_ctx* ctx, int slot, int m, int comp, const double* host);
 int sdc_download(sdc_ctx* ctx, int slot, int m, int comp, double* host);
 int sdc_set_tau_active(sdc_ctx* ctx, int active); /* L.tau[m] is None  <->  0 */
+/* Synthetic input generated on the device (no multi-GB host arrays): dst[i] = prod_d sin(pi*freq[d]*x_d) on
+ * the grid of generic_ND_FD.py:171-180 (the u_exact(0) of HeatEquation_ND_FD.py:103-132) + amp * g(i), g a
+ * standard normal from splitmix64(seed, i) + Box-Muller; host equivalent: pysdc_amd.synth.init_field. */
+int sdc_init_field(sdc_ctx* ctx, double* dst, const int* freq, double amp, unsigned long long seed);
 
 /* ---- the sweep path ----------------------------------------------------------------------------------- */
 /* Sweeper.predict (pySDC/core/sweeper.py:125-162): F[0] = f(U[0], t); nodes filled per `guess`;
@@ -99,7 +103,8 @@ int sdc_eval_f(sdc_ctx* ctx, const double* u, double g_t, double* f_impl, double
 /* solve_system (generic_ND_FD.py:208-264, 'direct'): (I - factor*A) out = rhs. */
 int sdc_solve(sdc_ctx* ctx, const double* rhs, double factor, double* out);
 
-/* ---- datatype operations (mesh arithmetic, datatype_classes/mesh.py:12-125) ---------------------------- */
+/* ---- datatype operations (mesh arithmetic, datatype_classes/mesh.py:12-125) ----------------------------
+ * ctx may be NULL: the operation then runs on the null stream of the current device. */
 int sdc_vec_copy(sdc_ctx* ctx, size_t n, const double* x, double* y);
 int sdc_vec_fill(sdc_ctx* ctx, size_t n, double a, double* y);
 int sdc_vec_axpby(sdc_ctx* ctx, size_t n, double a, const double* x, double b, const double* y, double* z);

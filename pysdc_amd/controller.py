@@ -1,0 +1,454 @@
+"""Controllers: the caller of the sweep path.
+
+``controller_nonMPI`` reproduces the stage machine of the reference's serial controller
+(pySDC/implementations/controller_classes/controller_nonMPI.py:85-689) for single-level SDC and multi-step
+SDC (``num_procs`` time steps handled in one process; Jacobi-like ``mssdc_jac=True`` or Gauss-Seidel-like):
+same call order, same iteration counting (``iter`` only incremented in it_check, :523), same convergence rule
+(convergence_controller_classes/check_convergence.py:72-82) and the ``Tend - 10*eps`` time guard (:112,163).
+
+``controller_dist`` is the same algorithm with ONE time step per process / GPU
+(pySDC/implementations/controller_classes/controller_MPI.py:71-168 run, :218-305 send_full / recv_full,
+:634-768 stages): the forward transfer ``uend -> u[0]`` of the next time-rank is a point-to-point message
+through ``torch.distributed`` (RCCL over xGMI on GPUs, gloo in the CPU tests); the end-of-block value is
+broadcast from the last rank (controller_MPI.py:125-130).  Convergence flags travel on the host side."""
+import itertools
+import logging
+
+import numpy as np
+
+from pysdc_amd.errors import CommunicationError, ControllerError, ParameterError
+from pysdc_amd.hooks import DefaultHooks, Hooks, Timings
+from pysdc_amd.level import Step
+
+
+class _Pars:
+    """pySDC/core/controller.py:15-29."""
+
+    def __init__(self, params):
+        self.mssdc_jac = True
+        self.predict_type = None
+        self.all_to_done = False
+        self.logger_level = 20
+        self.log_to_file = False
+        self.dump_setup = True
+        self.fname = 'run_pid.log'
+        self.use_iteration_estimator = False
+        for k, v in params.items():
+            setattr(self, k, v)
+
+
+def check_convergence(S):
+    """check_convergence.py:60-92 (residual / maxiter rule; e_tol belongs to an optional plug-in)."""
+    L = S.levels[0]
+    iter_converged = S.status.iter >= S.params.maxiter
+    res_converged = L.status.residual <= L.params.restol and (S.status.iter > 0 or L.status.sweep > 0)
+    converged = (iter_converged or res_converged or bool(S.status.force_done)) and not S.status.force_continue
+    return bool(converged)
+
+
+class _ControllerBase:
+    def __init__(self, controller_params, description):
+        self.params = _Pars(dict(controller_params))
+        self.logger = logging.getLogger('controller')
+        self.hooks = [DefaultHooks(), Timings()]
+        hook_class = controller_params.get('hook_class', [])
+        if not isinstance(hook_class, list):
+            hook_class = [hook_class]
+        for h in hook_class:
+            self.add_hook(h)
+        if description.get('convergence_controllers'):
+            raise ParameterError('optional convergence controllers are host-side pySDC plug-ins outside this engine')
+
+    def add_hook(self, hook):
+        if hook not in [type(h) for h in self.hooks]:
+            self.hooks.append(hook())
+
+    def return_stats(self):
+        stats = {}
+        for hook in self.hooks:
+            stats = {**stats, **hook.return_stats()}
+        return stats
+
+    def _hook(self, name, S, level=0, **kw):
+        for hook in self.hooks:
+            getattr(hook, name)(step=S, level_number=level, **kw)
+
+
+class controller_nonMPI(_ControllerBase):
+    def __init__(self, num_procs, controller_params, description):
+        super().__init__(controller_params, description)
+        self.MS = [Step(description) for _ in range(num_procs)]
+        if self.params.dump_setup and False:
+            pass
+        self.nsweeps = [L.params.nsweeps for L in self.MS[0].levels]
+        self.nlevels = len(self.MS[0].levels)
+
+    # controller_nonMPI.py:85-167
+    def run(self, u0, t0, Tend):
+        uend = None
+        num_procs = len(self.MS)
+        for hook in self.hooks:
+            hook.reset_stats()
+        slots = list(range(num_procs))
+        time = [t0 + sum(self.MS[j].dt for j in range(p)) for p in slots]
+        active = [time[p] < Tend - 10 * np.finfo(float).eps for p in slots]
+        if not any(active):
+            raise ControllerError('Nothing to do, check t0, dt and Tend.')
+        active_slots = list(itertools.compress(slots, active))
+        self.restart_block(active_slots, time, u0)
+        for hook in self.hooks:
+            hook.post_setup(step=None, level_number=None)
+        for S in self.MS:
+            self._hook('pre_run', S)
+        while any(active):
+            MS_active = [self.MS[p] for p in active_slots]
+            done = False
+            while not done:
+                done = self.pfasst(MS_active)
+            uend = self.MS[active_slots[-1]].levels[0].uend
+            time[active_slots[0]] = time[active_slots[-1]] + self.MS[active_slots[-1]].dt
+            for i in range(1, len(active_slots)):
+                time[active_slots[i]] = time[active_slots[i] - 1] + self.MS[active_slots[i] - 1].dt
+            active = [time[p] < Tend - 10 * np.finfo(float).eps for p in slots]
+            active_slots = list(itertools.compress(slots, active))
+            if active_slots:
+                # the views into the last step's UEND slab are about to be reset: keep an owning copy
+                uend = type(uend)(uend)
+            self.restart_block(active_slots, time, uend)
+        for S in self.MS:
+            self._hook('post_run', S)
+        return uend, self.return_stats()
+
+    # controller_nonMPI.py:169-224
+    def restart_block(self, active_slots, time, u0):
+        for j in range(len(active_slots)):
+            p = active_slots[j]
+            S = self.MS[p]
+            S.status.slot = p
+            S.prev = self.MS[active_slots[j - 1]]
+            S.reset_step()
+            S.status.first = active_slots.index(p) == 0
+            S.status.last = active_slots.index(p) == len(active_slots) - 1
+            S.init_step(u0)
+            S.status.done = False
+            S.status.prev_done = False
+            S.status.iter = 0
+            S.status.stage = 'SPREAD'
+            S.status.force_done = False
+            S.status.time_size = len(active_slots)
+            for l in S.levels:
+                l.tag = None
+                l.status.sweep = 1
+        for p in active_slots:
+            for lvl in self.MS[p].levels:
+                lvl.status.time = time[p]
+
+    # controller_nonMPI.py:226-295
+    def send_full(self, S, level=None, add_to_stats=False):
+        self._hook('pre_comm', S, level)
+        if not S.status.last:
+            S.levels[level].sweep.compute_end_point()
+            S.levels[level].tag = (level, S.status.iter, S.status.slot)
+        self._hook('post_comm', S, level, add_to_stats=add_to_stats)
+
+    def recv_full(self, S, level=None, add_to_stats=False):
+        self._hook('pre_comm', S, level)
+        if not S.status.prev_done and not S.status.first:
+            target, source = S.levels[level], S.prev.levels[level]
+            tag = (level, S.status.iter, S.prev.status.slot)
+            if source.tag != tag:
+                raise CommunicationError('source and target tag are not the same, got %s and %s' % (source.tag, tag))
+            target.u[0] = source.uend
+            target.f[0] = target.prob.eval_f(target.u[0], target.time)
+        self._hook('post_comm', S, level, add_to_stats=add_to_stats)
+
+    # controller_nonMPI.py:297-332
+    def pfasst(self, local_MS_active):
+        stages = [S.status.stage for S in local_MS_active if S.status.stage != 'DONE']
+        if stages[1:] == stages[:-1]:
+            stage = stages[0]
+        else:
+            raise ControllerError('not all stages are equal')
+        MS_running = [S for S in local_MS_active if S.status.stage != 'DONE']
+        switcher = {'SPREAD': self.spread, 'IT_CHECK': self.it_check, 'IT_FINE': self.it_fine,
+                    'IT_COARSE': self.it_coarse}
+        if stage not in switcher:
+            raise ControllerError('Unknown stage, got %s' % stage)
+        switcher[stage](MS_running)
+        return all(S.status.done for S in local_MS_active)
+
+    def spread(self, local_MS_running):
+        for S in local_MS_running:
+            self._hook('pre_step', S)
+            S.levels[0].sweep.predict()
+            S.status.stage = 'IT_CHECK'
+
+    # controller_nonMPI.py:479-543
+    def it_check(self, local_MS_running):
+        for S in local_MS_running:
+            self.send_full(S, level=0)
+            self.recv_full(S, level=0)
+            S.levels[0].sweep.compute_residual(stage='IT_CHECK')
+        for S in local_MS_running:
+            if S.status.iter > 0:
+                self._hook('post_iteration', S)
+            S.status.done = check_convergence(S)
+            S.status.force_continue = False
+        for S in local_MS_running:
+            if not S.status.first:
+                S.status.prev_done = S.prev.status.done
+                S.status.done = S.status.done and S.status.prev_done
+            if self.params.all_to_done:
+                S.status.done = all(T.status.done for T in local_MS_running)
+            if not S.status.done:
+                S.status.iter += 1
+                self._hook('pre_iteration', S)
+                if len(local_MS_running) == 1 or self.params.mssdc_jac:
+                    S.status.stage = 'IT_FINE'
+                else:
+                    S.status.stage = 'IT_COARSE'
+            else:
+                S.levels[0].sweep.compute_end_point()
+                self._hook('post_step', S)
+                S.status.stage = 'DONE'
+
+    # controller_nonMPI.py:545-582
+    def it_fine(self, local_MS_running):
+        for S in local_MS_running:
+            S.levels[0].status.sweep = 0
+        for k in range(self.nsweeps[0]):
+            for S in local_MS_running:
+                S.levels[0].status.sweep += 1
+            for S in local_MS_running:
+                self.send_full(S, level=0)
+                self.recv_full(S, level=0, add_to_stats=(k == self.nsweeps[0] - 1))
+            for S in local_MS_running:
+                self._hook('pre_sweep', S)
+                S.levels[0].sweep.updateVariableCoeffs(k + 1)
+                S.levels[0].sweep.update_nodes()
+                S.levels[0].sweep.compute_residual(stage='IT_FINE')
+                self._hook('post_sweep', S)
+        for S in local_MS_running:
+            S.status.stage = 'IT_CHECK'
+
+    # controller_nonMPI.py:636-666 (single level: serial multi-step SDC)
+    def it_coarse(self, local_MS_running):
+        for S in local_MS_running:
+            self.recv_full(S, level=0)
+            self._hook('pre_sweep', S)
+            S.levels[0].sweep.update_nodes()
+            S.levels[0].sweep.compute_residual(stage='IT_COARSE')
+            self._hook('post_sweep', S)
+            self.send_full(S, level=0, add_to_stats=True)
+            S.status.stage = 'IT_CHECK'
+
+
+class controller_dist(_ControllerBase):
+    """One time step per rank (= per GPU).  ``comm``: torch.distributed group carrying the state vectors
+    (RCCL on GPUs); 1-byte convergence flags and step counts use a gloo side group so they never touch the
+    device.  ``description['step_class']`` may replace the Step implementation (CPU tests use an
+    oracle-backed step under gloo)."""
+
+    def __init__(self, controller_params, description, comm=None):
+        import torch.distributed as dist
+
+        super().__init__(controller_params, description)
+        self.dist = dist
+        self.comm = comm
+        self.rank = dist.get_rank(comm)
+        self.size = dist.get_world_size(comm)
+        if dist.get_backend(comm) == 'gloo':
+            self.host_comm = comm
+        else:
+            self.host_comm = dist.new_group(backend='gloo')
+        self.S = description.get('step_class', Step)(description)
+        self.S.status.slot = self.rank
+        self.nsweeps = [L.params.nsweeps for L in self.S.levels]
+        self.req_send = None
+
+    # ---- host-side scalars (check_convergence.py:105-160; controller_MPI.py:90,120,142) ---------------------
+    def _send_flag(self, value, dst):
+        import torch
+
+        self.dist.send(torch.tensor([1 if value else 0], dtype=torch.int32), dst=dst, group=self.host_comm)
+
+    def _recv_flag(self, src):
+        import torch
+
+        t = torch.zeros(1, dtype=torch.int32)
+        self.dist.recv(t, src=src, group=self.host_comm)
+        return bool(t.item())
+
+    def _all_sum(self, value):
+        import torch
+
+        t = torch.tensor([int(value)], dtype=torch.int64)
+        self.dist.all_reduce(t, group=self.host_comm)
+        return int(t.item())
+
+    # controller_MPI.py:71-168
+    def run(self, u0, t0, Tend):
+        for hook in self.hooks:
+            hook.reset_stats()
+        S = self.S
+        dt = S.dt
+        eps10 = 10 * np.finfo(float).eps
+        time = t0 + dt * self.rank
+        active = time < Tend - eps10
+        num_active = self._all_sum(active)
+        if num_active == 0:
+            raise ControllerError('Nothing to do, check t0, dt and Tend!')
+        P = S.levels[0].prob
+        uend = P.dtype_u(u0)
+        self.restart_block(num_active, time, uend, active)
+        self._hook('pre_run', S)
+        while num_active > 0:
+            if active:
+                while not S.status.done:
+                    self.pfasst(num_active)
+            # end value of the block travels from its last active rank to everybody (controller_MPI.py:125-130)
+            root = num_active - 1
+            if self.rank == root:
+                uend[:] = S.levels[0].uend
+            uend.bcast(root=root, comm=self.comm)
+            time = time + dt * num_active
+            active = time < Tend - eps10
+            num_active = self._all_sum(active)
+            if num_active > 0:
+                self.restart_block(num_active, time, uend, active)
+        self._hook('post_run', S)
+        return uend, self.return_stats()
+
+    # controller_MPI.py:170-216
+    def restart_block(self, size, time, u0, active):
+        S = self.S
+        if not active:
+            S.status.done = True
+            return
+        S.status.slot = self.rank
+        S.reset_step()
+        S.status.first = self.rank == 0
+        S.status.last = self.rank == size - 1
+        S.init_step(u0)
+        S.status.done = False
+        S.status.prev_done = False
+        S.status.iter = 0
+        S.status.stage = 'SPREAD'
+        S.status.force_done = False
+        S.status.time_size = size
+        for lvl in S.levels:
+            lvl.tag = None
+            lvl.status.sweep = 1
+            lvl.status.time = time
+        self.req_send = None
+
+    # controller_MPI.py:235-305.  send_full followed by recv_full is issued as ONE batched P2P group
+    # (ncclGroupStart/End under RCCL) so that the send to rank+1 and the receive from rank-1 progress
+    # concurrently instead of unwinding rank by rank.
+    def exchange(self, level=0, send=True, recv=True, blocking_send=False):
+        S = self.S
+        L = S.levels[level]
+        self._hook('pre_comm', S, level)
+        ops = []
+        tag = level * 100 + S.status.iter
+        if send:
+            if self.req_send is not None:
+                self.req_send.wait()  # the previous message still reads UEND
+                self.req_send = None
+            L.sweep.compute_end_point()
+            if not S.status.last:
+                ops.append(self.dist.P2POp(self.dist.isend, L.uend.as_torch(), self.rank + 1, self.comm, tag))
+        do_recv = recv and not S.status.first and not S.status.prev_done
+        if do_recv:
+            ops.append(self.dist.P2POp(self.dist.irecv, L.u[0].as_torch(), self.rank - 1, self.comm, tag))
+        if ops:
+            reqs = self.dist.batch_isend_irecv(ops)
+            if send and not S.status.last:
+                # with a batched launch all requests complete together
+                self.req_send = reqs[0]
+                if blocking_send or len(reqs) == 1 and not do_recv:
+                    pass
+            for r in reqs[(1 if (send and not S.status.last) else 0):]:
+                r.wait()
+            if blocking_send and self.req_send is not None:
+                self.req_send.wait()
+                self.req_send = None
+        if do_recv:
+            L._touched()
+            L.f[0] = L.prob.eval_f(L.u[0], L.time)
+        self._hook('post_comm', S, level)
+
+    def pfasst(self, size):
+        S = self.S
+        stage = S.status.stage
+        if stage == 'SPREAD':
+            self._hook('pre_step', S)
+            S.levels[0].sweep.predict()
+            S.status.stage = 'IT_CHECK'
+        elif stage == 'IT_CHECK':
+            self.it_check(size)
+        elif stage == 'IT_FINE':
+            self.it_fine()
+        elif stage == 'IT_COARSE':
+            self.it_coarse()
+        else:
+            raise ControllerError('Unknown stage, got %s' % stage)
+
+    # controller_MPI.py:574-664
+    def it_check(self, size):
+        S = self.S
+        L = S.levels[0]
+        self.exchange(0)
+        L.sweep.compute_residual(stage='IT_CHECK')
+        if S.status.iter > 0:
+            self._hook('post_iteration', S)
+        S.status.done = check_convergence(S)
+        S.status.force_continue = False
+        if self.params.all_to_done:
+            S.status.done = self._all_sum(S.status.done) == size
+        else:
+            if not S.status.first and not S.status.prev_done:
+                S.status.prev_done = self._recv_flag(self.rank - 1)
+                S.status.done = S.status.done and S.status.prev_done
+            if not S.status.last:
+                self._send_flag(S.status.done, self.rank + 1)
+        if not S.status.done:
+            S.status.iter += 1
+            self._hook('pre_iteration', S)
+            if size == 1 or self.params.mssdc_jac:
+                S.status.stage = 'IT_FINE'
+            else:
+                S.status.stage = 'IT_COARSE'
+        else:
+            if self.req_send is not None:
+                self.req_send.wait()
+                self.req_send = None
+            self._hook('post_step', S)
+            S.status.stage = 'DONE'
+
+    # controller_MPI.py:666-700
+    def it_fine(self):
+        S = self.S
+        L = S.levels[0]
+        L.status.sweep = 0
+        for k in range(self.nsweeps[0]):
+            L.status.sweep += 1
+            self.exchange(0)
+            self._hook('pre_sweep', S)
+            L.sweep.updateVariableCoeffs(k + 1)
+            L.sweep.update_nodes()
+            L.sweep.compute_residual(stage='IT_FINE')
+            self._hook('post_sweep', S)
+        S.status.stage = 'IT_CHECK'
+
+    # controller_MPI.py:736-768 (single level: Gauss-Seidel-like multi-step SDC)
+    def it_coarse(self):
+        S = self.S
+        L = S.levels[0]
+        self.exchange(0, send=False, recv=True)
+        self._hook('pre_sweep', S)
+        L.sweep.update_nodes()
+        L.sweep.compute_residual(stage='IT_COARSE')
+        self._hook('post_sweep', S)
+        self.exchange(0, send=True, recv=False, blocking_send=True)
+        S.status.stage = 'IT_CHECK'

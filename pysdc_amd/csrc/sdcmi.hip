@@ -57,6 +57,9 @@ struct sdc_ctx {
     size_t bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, pev0 = nullptr, pev1 = nullptr;
     bool profiling = false;
+    std::vector<hipEvent_t> pool;            // event pairs recorded around launches while profiling
+    std::vector<const char*> pool_names;
+    size_t pool_used = 0;                    // pairs in flight
     std::map<std::string, ProfEntry> prof;
     std::vector<std::string> prof_names;
     std::string err;
@@ -83,22 +86,42 @@ static int fail(sdc_ctx* c, int code, const char* fmt, ...) {
                         hipGetErrorString(e_));                                                      \
     } while (0)
 
-struct LaunchTimer {
-    sdc_ctx* c;
-    const char* name;
-    LaunchTimer(sdc_ctx* c_, const char* n) : c(c_), name(n) {
-        if (c->profiling) (void)hipEventRecord(c->pev0, c->stream);
-    }
-    ~LaunchTimer() {
-        if (c->profiling) {
-            (void)hipEventRecord(c->pev1, c->stream);
-            (void)hipEventSynchronize(c->pev1);
-            float ms = 0;
-            (void)hipEventElapsedTime(&ms, c->pev0, c->pev1);
-            ProfEntry& e = c->prof[name];
+// Per-kernel device time: a pair of events from a pool is recorded around every launch on the context's
+// stream; nothing synchronises until the pool is full or the profile is read, so the timed region of bench.py
+// is not perturbed.
+static void prof_flush(sdc_ctx* c) {
+    if (c->pool_used == 0) return;
+    (void)hipEventSynchronize(c->pool[2 * c->pool_used - 1]);
+    for (size_t i = 0; i < c->pool_used; ++i) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, c->pool[2 * i], c->pool[2 * i + 1]) == hipSuccess) {
+            ProfEntry& e = c->prof[c->pool_names[i]];
             e.ms += ms;
             e.calls += 1;
         }
+    }
+    c->pool_used = 0;
+}
+
+struct LaunchTimer {
+    sdc_ctx* c;
+    size_t slot = 0;
+    bool on;
+    LaunchTimer(sdc_ctx* c_, const char* n) : c(c_), on(c_->profiling) {
+        if (!on) return;
+        constexpr size_t kPairs = 2048;
+        if (c->pool.empty()) {
+            c->pool.resize(2 * kPairs);
+            c->pool_names.resize(kPairs);
+            for (auto& e : c->pool) (void)hipEventCreate(&e);
+        }
+        if (c->pool_used == kPairs) prof_flush(c);
+        slot = c->pool_used++;
+        c->pool_names[slot] = n;
+        (void)hipEventRecord(c->pool[2 * slot], c->stream);
+    }
+    ~LaunchTimer() {
+        if (on) (void)hipEventRecord(c->pool[2 * slot + 1], c->stream);
     }
 };
 
@@ -342,7 +365,7 @@ __global__ void k_realpart(FieldPtrs p, const cd* W, size_t N) {
 // r2c along axis 0: real field [N][rest] seen as complex pairs [N][rest/2]; two real columns per complex
 // column ("two for one"), unpacked to the half spectra W[k][rest], k = 0..N/2.
 template <int N, int T>
-__global__ __launch_bounds__((N / fft_elems(N)) * T) void k_fftx_fwd(FieldPtrs p, cd* __restrict__ W, size_t fstride,
+__global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_fwd(FieldPtrs p, cd* __restrict__ W, size_t fstride,
                                                                       int rest, const cd* __restrict__ tw) {
     constexpr int E = fft_elems(N), P = N / E;
     using LAY = LayStrided<N, T>;
@@ -392,7 +415,7 @@ __global__ __launch_bounds__((N / fft_elems(N)) * T) void k_fftx_fwd(FieldPtrs p
 
 // c2r along axis 0 (inverse of the above, unnormalised)
 template <int N, int T>
-__global__ __launch_bounds__((N / fft_elems(N)) * T) void k_fftx_inv(FieldPtrs p, const cd* __restrict__ W,
+__global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_inv(FieldPtrs p, const cd* __restrict__ W,
                                                                       size_t fstride, int rest,
                                                                       const cd* __restrict__ tw) {
     constexpr int E = fft_elems(N), P = N / E;
@@ -455,7 +478,7 @@ __global__ __launch_bounds__((N / fft_elems(N)) * T) void k_fftx_inv(FieldPtrs p
 
 // c2c in place along the middle axis of W[f][kx][y][z] (3-D only): tile = all y x T z-columns
 template <int N, int T, int DIR>
-__global__ __launch_bounds__((N / fft_elems(N)) * T) void k_ffty(cd* __restrict__ W, size_t fstride,
+__global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_ffty(cd* __restrict__ W, size_t fstride,
                                                                   const cd* __restrict__ tw) {
     constexpr int E = fft_elems(N), P = N / E;
     using LAY = LayStrided<N, T>;
@@ -486,78 +509,87 @@ struct ZArgs {
 };
 
 // forward FFT along the contiguous axis, node-coupled implicit solve in Fourier space, inverse FFT.
-// One workgroup = all nf fields of one line; field f occupies threads [f*P, (f+1)*P).
+// One workgroup = LPB lines x all nf fields; column c = f*LPB + l occupies threads [c*P, (c+1)*P).
+// After the forward transform the spectra go through LDS once more so that one thread holds ALL nf node
+// values of a mode: the lower-triangular node coupling is then a register recurrence with wave-uniform
+// coefficient indices (scalar kernarg loads, no per-lane table look-ups).
 template <int N>
-__global__ __launch_bounds__((N / fft_elems(N)) * MAXM) void k_fftz_solve(ZArgs a) {
-    constexpr int E = fft_elems(N), P = N / E;
+constexpr int z_lines_per_block() {
+    constexpr int P = N / fft_elems(N);
+    return P >= 64 ? 1 : 64 / P;
+}
+
+template <int N>
+__global__ __launch_bounds__(z_lines_per_block<N>() * (N / fft_elems(N)) * MAXM, 3) void k_fftz_solve(ZArgs a, unsigned nlines) {
+    constexpr int E = fft_elems(N), P = N / E, LPB = z_lines_per_block<N>();
+    constexpr int NCH = E == 16 ? 2 : 1;  // the solve buffer holds N/NCH modes per column at a time
+    constexpr int CH = N / NCH, ECH = E / NCH;
     using LAY = LayContig<N>;
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int f = threadIdx.x / P, j = threadIdx.x % P;
-    const size_t line = blockIdx.x;
+    const int c = threadIdx.x / P, j = threadIdx.x % P;
+    const int f = c / LPB, l = c % LPB;
+    const size_t line = (size_t)blockIdx.x * LPB + l;
+    const bool ok = line < nlines;
     cd* __restrict__ Wl = a.W + f * a.fstride + line * N;
     cd r[E];
 #pragma unroll
-    for (int i = 0; i < E; ++i) r[i] = Wl[j + i * P];
-    fft_line<N, -1, LAY>(r, j, f, lds, a.tw);
+    for (int i = 0; i < E; ++i) r[i] = ok ? Wl[j + i * P] : cd{0.0, 0.0};
+    fft_line<N, -1, LAY>(r, j, c, lds, a.tw);
 
-    // symbol of the other axes for this line
-    cd lI0 = cd{0.0, 0.0}, lE0 = cd{0.0, 0.0};
-    if (a.ndim == 3) {
-        const int kx = (int)(line / N), ky = (int)(line % N);
-        lI0 = cadd(a.lamI[kx], a.lamI[ky]);
-        if (a.lamE) lE0 = cadd(a.lamE[kx], a.lamE[ky]);
-    } else if (a.ndim == 2) {
-        lI0 = a.lamI[line];
-        if (a.lamE) lE0 = a.lamE[line];
-    }
-    double* re = lds;
-    double* im = lds + N + (N >> 4);
-#pragma unroll 1
-    for (int jf = 0; jf < a.nf; ++jf) {
-        if (f == jf) {
-            const double al = a.alpha[jf];
+    cd* buf = reinterpret_cast<cd*>(lds);  // [column][CH]
+    const int nthreads = a.nf * LPB * P;
 #pragma unroll
-            for (int i = 0; i < E; ++i) {
-                const cd lam = cadd(lI0, a.lamI[j + i * P]);
-                r[i] = cmul(r[i], cinv(cd{1.0 - al * lam.x, -al * lam.y}));
+    for (int ph = 0; ph < NCH; ++ph) {
+#pragma unroll
+        for (int i = 0; i < ECH; ++i) buf[c * CH + j + i * P] = r[ph * ECH + i];
+        __syncthreads();
+        for (int item = threadIdx.x; item < LPB * CH; item += nthreads) {
+            const int ll = item / CH, kk = item % CH;
+            const size_t ln = (size_t)blockIdx.x * LPB + ll;
+            const int kz = ph * CH + kk;
+            cd lam = a.lamI[kz], mu = cd{0.0, 0.0};
+            if (a.lamE) mu = a.lamE[kz];
+            if (a.ndim == 3) {
+                const int kx = (int)(ln / N), ky = (int)(ln % N);
+                lam = cadd(lam, cadd(a.lamI[kx], a.lamI[ky]));
+                if (a.lamE) mu = cadd(mu, cadd(a.lamE[kx], a.lamE[ky]));
+            } else if (a.ndim == 2) {
+                lam = cadd(lam, a.lamI[ln]);
+                if (a.lamE) mu = cadd(mu, a.lamE[ln]);
             }
-        }
-        if (a.coupled && jf + 1 < a.nf) {
-            if (f == jf) {
+            cd u[MAXM];
 #pragma unroll
-                for (int i = 0; i < E; ++i) {
-                    const int k = j + i * P;
-                    re[k + (k >> 4)] = r[i].x;
-                    im[k + (k >> 4)] = r[i].y;
-                }
-            }
-            __syncthreads();
-            if (f > jf) {
-                const double ci = a.cI[f][jf], ce = a.cE[f][jf];
-                if (ci != 0.0 || ce != 0.0) {
+            for (int m = 0; m < MAXM; ++m) {
+                if (m < a.nf) {
+                    cd acc = buf[(m * LPB + ll) * CH + kk];
+                    if (a.coupled) {
 #pragma unroll
-                    for (int i = 0; i < E; ++i) {
-                        const int k = j + i * P;
-                        const cd u = cd{re[k + (k >> 4)], im[k + (k >> 4)]};
-                        const cd lam = cadd(lI0, a.lamI[k]);
-                        cd coef = cd{ci * lam.x, ci * lam.y};
-                        if (a.lamE) {
-                            const cd mu = cadd(lE0, a.lamE[k]);
-                            coef.x += ce * mu.x;
-                            coef.y += ce * mu.y;
+                        for (int q = 0; q < m; ++q) {
+                            const double ci = a.cI[m][q], ce = a.cE[m][q];
+                            const cd coef = cd{ci * lam.x + ce * mu.x, ci * lam.y + ce * mu.y};
+                            acc = cfma(coef, u[q], acc);
                         }
-                        r[i] = cfma(coef, u, r[i]);
                     }
+                    const double al = a.alpha[m];
+                    u[m] = cmul(acc, cinv(cd{1.0 - al * lam.x, -al * lam.y}));
+                    buf[(m * LPB + ll) * CH + kk] = cscale(u[m], a.invN);
                 }
             }
-            __syncthreads();
         }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < ECH; ++i) r[ph * ECH + i] = buf[c * CH + j + i * P];
+        __syncthreads();
     }
+    // opaque copy of the lane index: without it the forward transform's twiddles stay live (~100 VGPRs)
+    // through the whole kernel for reuse in the inverse
+    int j2 = j;
+    asm volatile("" : "+v"(j2));
+    fft_line<N, +1, LAY>(r, j2, c, lds, a.tw);
+    if (ok) {
 #pragma unroll
-    for (int i = 0; i < E; ++i) r[i] = cscale(r[i], a.invN);
-    fft_line<N, +1, LAY>(r, j, f, lds, a.tw);
-#pragma unroll
-    for (int i = 0; i < E; ++i) Wl[j + i * P] = r[i];
+        for (int i = 0; i < E; ++i) Wl[j2 + i * P] = r[i];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -789,8 +821,13 @@ static int fft_pipeline_n(sdc_ctx* c, int nf, const FieldPtrs& p, ZArgs& z) {
     }
     {
         LaunchTimer lt(c, "fft_z_solve");
-        size_t ldsz = (size_t)LayContig<N>::doubles(nf < 2 ? 2 : nf) * sizeof(double);
-        hipLaunchKernelGGL((k_fftz_solve<N>), dim3((unsigned)lines), dim3(P * nf), ldsz, c->stream, z);
+        constexpr int LPB = z_lines_per_block<N>();
+        constexpr int NCH = fft_elems(N) == 16 ? 2 : 1;
+        size_t ldsz = (size_t)LayContig<N>::doubles(nf * LPB) * sizeof(double);  // FFT exchange planes
+        const size_t solve_sz = (size_t)nf * LPB * (N / NCH) * sizeof(cd);         // node-coupling buffer
+        if (solve_sz > ldsz) ldsz = solve_sz;
+        hipLaunchKernelGGL((k_fftz_solve<N>), dim3((unsigned)((lines + LPB - 1) / LPB)), dim3(P * LPB * nf), ldsz,
+                           c->stream, z, (unsigned)lines);
     }
     if (c->ndim == 1) {
         LaunchTimer lt(c, "realpart");
@@ -857,9 +894,73 @@ static int build_symbol(sdc_ctx* c, int which) {
     return SDC_OK;
 }
 
+static inline int grid_for(size_t work, int block);
+// context-less datatype operations (ctx == NULL) run on the null stream of the current device
+static sdc_ctx* default_ctx() {
+    static thread_local sdc_ctx* d = nullptr;
+    if (d) return d;
+    sdc_ctx* c = new sdc_ctx();
+    if (hipMalloc((void**)&c->red, sizeof(unsigned long long) * 16) != hipSuccess ||
+        hipHostMalloc((void**)&c->red_host, sizeof(unsigned long long) * 16) != hipSuccess ||
+        hipEventCreate(&c->pev0) != hipSuccess || hipEventCreate(&c->pev1) != hipSuccess) {
+        g_create_err = "cannot set up the default context (no GPU?)";
+        delete c;
+        return nullptr;
+    }
+    d = c;
+    return d;
+}
+#define CTX_OR_DEFAULT(c)                 \
+    if (!(c)) {                           \
+        (c) = default_ctx();              \
+        if (!(c)) return SDC_ERR_HIP;     \
+    }
+
+// deterministic synthetic field: prod_d sin(pi*freq_d*x_d) + amp * N(0,1) from a counter-based hash
+__device__ inline unsigned long long splitmix64(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__global__ void k_init_field(double* __restrict__ out, int ndim, int n, int f0, int f1, int f2, double amp,
+                             unsigned long long seed) {
+    const size_t N = ndim == 1 ? (size_t)n : (ndim == 2 ? (size_t)n * n : (size_t)n * n * n);
+    const double dx = 1.0 / n, pi = 3.14159265358979323846;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < N; i += (size_t)gridDim.x * blockDim.x) {
+        const int i2 = (int)(i % n);
+        const size_t rest = i / n;
+        const int i1 = ndim >= 2 ? (int)(rest % n) : 0;
+        const int i0 = ndim == 3 ? (int)(rest / n) : 0;
+        double v;
+        // grid orientation of generic_ND_FD.py:171-180: 2-D x on axis 1, y on axis 0; 3-D x on axis 1, y on
+        // axis 0, z on axis 2
+        if (ndim == 1) v = sin(pi * f0 * (i2 * dx));
+        else if (ndim == 2) v = sin(pi * f0 * (i2 * dx)) * sin(pi * f1 * (i1 * dx));
+        else v = sin(pi * f0 * (i1 * dx)) * sin(pi * f1 * (i0 * dx)) * sin(pi * f2 * (i2 * dx));
+        if (amp != 0.0) {
+            const unsigned long long h1 = splitmix64(seed * 0x100000001B3ull + 2 * i);
+            const unsigned long long h2 = splitmix64(seed * 0x100000001B3ull + 2 * i + 1);
+            const double u1 = ((double)(h1 >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+            const double u2 = ((double)(h2 >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+            v += amp * sqrt(-2.0 * log(u1)) * cos(2.0 * pi * u2);
+        }
+        out[i] = v;
+    }
+}
+
 extern "C" {
 
 int sdc_version(void) { return 100; }
+
+int sdc_init_field(sdc_ctx* c, double* dst, const int* freq, double amp, unsigned long long seed) {
+    if (!c || !dst || !freq) return fail(c, SDC_ERR_PARAM, "null pointer");
+    LaunchTimer lt(c, "init_field");
+    hipLaunchKernelGGL(k_init_field, dim3(grid_for(c->N, 256)), dim3(256), 0, c->stream, dst, c->ndim, c->n, freq[0],
+                       c->ndim > 1 ? freq[1] : 0, c->ndim > 2 ? freq[2] : 0, amp, seed);
+    HIPCHK(c, hipGetLastError());
+    return SDC_OK;
+}
 
 const char* sdc_last_error(const sdc_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
@@ -941,6 +1042,7 @@ int sdc_ctx_destroy(sdc_ctx* c) {
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->pev0) (void)hipEventDestroy(c->pev0);
     if (c->pev1) (void)hipEventDestroy(c->pev1);
+    for (auto& e : c->pool) (void)hipEventDestroy(e);
     delete c;
     return SDC_OK;
 }
@@ -1238,14 +1340,16 @@ int sdc_integrate(sdc_ctx* c, double dt, double* const* dst) {
 }
 
 int sdc_vec_copy(sdc_ctx* c, size_t n, const double* x, double* y) {
-    if (!c || !x || !y) return fail(c, SDC_ERR_PARAM, "null pointer");
+    CTX_OR_DEFAULT(c);
+    if (!x || !y) return fail(c, SDC_ERR_PARAM, "null pointer");
     LaunchTimer lt(c, "copy");
     HIPCHK(c, hipMemcpyAsync(y, x, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     return SDC_OK;
 }
 
 int sdc_vec_fill(sdc_ctx* c, size_t n, double a, double* y) {
-    if (!c || !y) return fail(c, SDC_ERR_PARAM, "null pointer");
+    CTX_OR_DEFAULT(c);
+    if (!y) return fail(c, SDC_ERR_PARAM, "null pointer");
     LaunchTimer lt(c, "fill");
     hipLaunchKernelGGL(k_fill, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, n, a, y);
     HIPCHK(c, hipGetLastError());
@@ -1253,7 +1357,8 @@ int sdc_vec_fill(sdc_ctx* c, size_t n, double a, double* y) {
 }
 
 int sdc_vec_axpby(sdc_ctx* c, size_t n, double a, const double* x, double b, const double* y, double* z) {
-    if (!c || !z) return fail(c, SDC_ERR_PARAM, "null pointer");
+    CTX_OR_DEFAULT(c);
+    if (!z) return fail(c, SDC_ERR_PARAM, "null pointer");
     LaunchTimer lt(c, "axpby");
     hipLaunchKernelGGL(k_axpby, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, n, a, x, b, y, z);
     HIPCHK(c, hipGetLastError());
@@ -1261,7 +1366,8 @@ int sdc_vec_axpby(sdc_ctx* c, size_t n, double a, const double* x, double b, con
 }
 
 int sdc_vec_amax(sdc_ctx* c, size_t n, const double* x, double* out) {
-    if (!c || !x || !out) return fail(c, SDC_ERR_PARAM, "null pointer");
+    CTX_OR_DEFAULT(c);
+    if (!x || !out) return fail(c, SDC_ERR_PARAM, "null pointer");
     HIPCHK(c, hipMemsetAsync(c->red + 9, 0, sizeof(unsigned long long), c->stream));
     {
         LaunchTimer lt(c, "amax");
@@ -1343,13 +1449,15 @@ int sdc_timer_end(sdc_ctx* c, double* ms) {
 
 int sdc_profile_enable(sdc_ctx* c, int on) {
     if (!c) return SDC_ERR_PARAM;
+    if (c->profiling) prof_flush(c);
     c->profiling = on != 0;
-    c->prof.clear();
+    if (on) c->prof.clear();
     return SDC_OK;
 }
 
 int sdc_profile_read(sdc_ctx* c, int cap, const char** names, double* ms, int* calls, int* count) {
     if (!c || !count) return SDC_ERR_PARAM;
+    prof_flush(c);
     c->prof_names.clear();
     int i = 0;
     for (auto& kv : c->prof) {

@@ -1,0 +1,311 @@
+"""Device datatype: the behaviour of pySDC's ``mesh`` / ``imex_mesh``
+(/root/reference/pySDC/implementations/datatype_classes/mesh.py:12-190) on an MI355X buffer.
+
+A ``hip_mesh`` either owns its storage (a torch float64 tensor used purely as a device allocation) or is a
+non-owning *view* of one field of a SweepEngine slab (``L.u[m]`` / ``L.f[m]``, SURVEY.md 8b "Ownership").
+Arithmetic runs in HIP kernels through the C-ABI (``sdc_vec_*``); ``abs()`` is the global max norm returned
+as a Python float exactly like ``mesh.__abs__`` (mesh.py:65-83), including NaN propagation."""
+import ctypes as C
+
+import numpy as np
+
+from pysdc_amd import lib as L
+from pysdc_amd.errors import DataError
+
+_F64 = np.dtype('float64')
+
+
+def _torch():
+    import torch
+
+    return torch
+
+
+class _CAI:
+    """holder exposing __cuda_array_interface__ so torch can wrap library-owned device memory (RCCL P2P)."""
+
+    def __init__(self, ptr, n, keep):
+        self.__cuda_array_interface__ = {'shape': (int(n),), 'typestr': '<f8', 'data': (int(ptr), False),
+                                         'version': 2, 'strides': None}
+        self._keep = keep
+
+
+class hip_mesh:
+    comm = None
+    xp = None
+    __array_priority__ = 1000  # ndarray * hip_mesh -> hip_mesh.__rmul__
+
+    def __init__(self, init=None, val=0.0, *, _ptr=None, _shape=None, _keep=None, _on_write=None):
+        self._buf = None
+        self._keep = _keep
+        self._on_write = _on_write  # slab views tell their level that device state changed
+        if _ptr is not None:  # non-owning view
+            self.shape = tuple(_shape)
+            self.size = int(np.prod(self.shape))
+            self.ptr = int(_ptr)
+            return
+        if isinstance(init, hip_mesh):
+            self.shape = init.shape
+            self.size = init.size
+            self._alloc()
+            _chk(L.load().sdc_vec_copy(None, self.size, init.ptr, self.ptr))
+        elif isinstance(init, tuple) and len(init) == 3 and isinstance(init[2], np.dtype):
+            if init[2] != _F64:
+                raise DataError(f'hip_mesh holds float64 data, got {init[2]}')
+            shape = init[0]
+            self.shape = (int(shape),) if np.isscalar(shape) else tuple(int(s) for s in shape)
+            self.size = int(np.prod(self.shape))
+            self._alloc()
+            _chk(L.load().sdc_vec_fill(None, self.size, float(val), self.ptr))
+            type(self).comm = init[1]
+        else:
+            raise NotImplementedError(type(init))
+
+    def _alloc(self):
+        torch = _torch()
+        self._buf = torch.empty(self.size, dtype=torch.float64, device='cuda')
+        self.ptr = self._buf.data_ptr()
+
+    # ---- views / host access -------------------------------------------------------------------------
+    @classmethod
+    def view(cls, ptr, shape, keep=None, on_write=None):
+        return cls(_ptr=ptr, _shape=shape, _keep=keep, _on_write=on_write)
+
+    def _wrote(self):
+        if self._on_write is not None:
+            self._on_write()
+
+    @property
+    def dtype(self):
+        return _F64
+
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    def get(self):
+        """host copy (cupy_mesh idiom: ``uend.get()``, projects/GPU/heat.py:61-94)."""
+        torch = _torch()
+        torch.cuda.synchronize()
+        out = np.empty(self.size, dtype=np.float64)
+        _check_hip(_hip().hipMemcpy(out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr), self.size * 8, 2))
+        return out.reshape(self.shape)
+
+    def set(self, host):
+        h = np.ascontiguousarray(host, dtype=np.float64).reshape(-1)
+        if h.size != self.size:
+            raise DataError(f'size mismatch: {h.size} vs {self.size}')
+        _check_hip(_hip().hipMemcpy(C.c_void_p(self.ptr), h.ctypes.data_as(C.c_void_p), self.size * 8, 1))
+        self._wrote()
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.get()
+        return a if dtype is None else a.astype(dtype)
+
+    def flatten(self):
+        return hip_mesh.view(self.ptr, (self.size,), keep=self)
+
+    def as_torch(self):
+        """torch tensor aliasing this buffer (for torch.distributed send/recv over RCCL)."""
+        if self._buf is not None:
+            return self._buf
+        torch = _torch()
+        return torch.as_tensor(_CAI(self.ptr, self.size, self), device='cuda')
+
+    # ---- assignment ----------------------------------------------------------------------------------
+    def __setitem__(self, key, value):
+        if not (key is Ellipsis or (isinstance(key, slice) and key == slice(None))):
+            raise NotImplementedError('hip_mesh supports whole-field assignment only: x[:] = value')
+        if isinstance(value, hip_mesh):
+            if value.size != self.size:
+                raise DataError(f'size mismatch: {value.size} vs {self.size}')
+            if value.ptr != self.ptr:
+                _chk(L.load().sdc_vec_copy(None, self.size, value.ptr, self.ptr))
+        elif np.isscalar(value):
+            _chk(L.load().sdc_vec_fill(None, self.size, float(value), self.ptr))
+        else:
+            self.set(np.broadcast_to(np.asarray(value, dtype=np.float64), self.shape))
+        self._wrote()
+
+    def __getitem__(self, key):
+        if key is Ellipsis or (isinstance(key, slice) and key == slice(None)):
+            return self
+        raise NotImplementedError('hip_mesh supports whole-field access only; use .get() for host indexing')
+
+    # ---- arithmetic (mesh.py:49-63: results keep the datatype) ------------------------------------------
+    def _new_like(self):
+        out = hip_mesh.__new__(type(self))
+        out._keep = None
+        out._on_write = None
+        out.shape, out.size = self.shape, self.size
+        hip_mesh._alloc(out)
+        return out
+
+    def _axpby(self, a, x, b, y, out):
+        _chk(L.load().sdc_vec_axpby(None, self.size, float(a), None if x is None else x.ptr, float(b),
+                                    None if y is None else y.ptr, out.ptr))
+        return out
+
+    def _coerce(self, other):
+        if isinstance(other, hip_mesh):
+            if other.size != self.size:
+                raise DataError(f'size mismatch: {other.size} vs {self.size}')
+            return other
+        tmp = self._new_like()
+        tmp[:] = other
+        return tmp
+
+    def __add__(self, o):
+        if np.isscalar(o):
+            o = self._coerce(np.full(self.shape, float(o)))
+        return self._axpby(1.0, self, 1.0, self._coerce(o), self._new_like())
+
+    __radd__ = __add__
+
+    def __sub__(self, o):
+        if np.isscalar(o):
+            o = self._coerce(np.full(self.shape, float(o)))
+        return self._axpby(1.0, self, -1.0, self._coerce(o), self._new_like())
+
+    def __rsub__(self, o):
+        if np.isscalar(o):
+            o = self._coerce(np.full(self.shape, float(o)))
+        return self._axpby(-1.0, self, 1.0, self._coerce(o), self._new_like())
+
+    def __mul__(self, a):
+        if not np.isscalar(a):
+            raise NotImplementedError('hip_mesh * non-scalar')
+        return self._axpby(float(a), self, 0.0, None, self._new_like())
+
+    __rmul__ = __mul__
+
+    def __truediv__(self, a):
+        if not np.isscalar(a):
+            raise NotImplementedError('hip_mesh / non-scalar')
+        return self._axpby(1.0 / float(a), self, 0.0, None, self._new_like())
+
+    def __neg__(self):
+        return self._axpby(-1.0, self, 0.0, None, self._new_like())
+
+    def __iadd__(self, o):
+        self._wrote()
+        return self._axpby(1.0, self, 1.0, self._coerce(o), self)
+
+    def __isub__(self, o):
+        self._wrote()
+        return self._axpby(1.0, self, -1.0, self._coerce(o), self)
+
+    def __imul__(self, a):
+        self._wrote()
+        return self._axpby(float(a), self, 0.0, None, self)
+
+    def __abs__(self):
+        out = C.c_double()
+        _chk(L.load().sdc_vec_amax(None, self.size, self.ptr, C.byref(out)))
+        return float(out.value)
+
+    def copy(self):
+        return type(self)(self) if type(self) is hip_mesh else hip_mesh(self)
+
+    # ---- communication (mesh.py:85-125) through torch.distributed (RCCL on GPUs) -----------------------
+    def isend(self, dest=None, tag=None, comm=None):
+        import torch.distributed as dist
+
+        return dist.isend(self.as_torch(), dst=dest, group=comm, tag=tag or 0)
+
+    def irecv(self, source=None, tag=None, comm=None):
+        import torch.distributed as dist
+
+        return dist.irecv(self.as_torch(), src=source, group=comm, tag=tag or 0)
+
+    def bcast(self, root=None, comm=None):
+        import torch.distributed as dist
+
+        dist.broadcast(self.as_torch(), src=root, group=comm)
+        return self
+
+    def __reduce__(self):
+        # controller_nonMPI clones steps with dill.copy and only falls back to re-instantiation on
+        # PicklingError / TypeError / ValueError (controller_nonMPI.py:37-45): device buffers do not pickle
+        raise TypeError('hip_mesh holds device memory and cannot be pickled')
+
+
+class hip_imex_mesh:
+    """two components ``impl`` / ``expl`` in one buffer (datatype_classes/mesh.py:166-173)."""
+
+    components = ['impl', 'expl']
+
+    def __init__(self, init=None, val=0.0, *, _parts=None):
+        if _parts is not None:
+            self.impl, self.expl = _parts
+        elif isinstance(init, hip_imex_mesh):
+            self.impl, self.expl = hip_mesh(init.impl), hip_mesh(init.expl)
+        elif isinstance(init, tuple):
+            self.impl, self.expl = hip_mesh(init, val), hip_mesh(init, val)
+        else:
+            raise NotImplementedError(type(init))
+        self.shape = (2,) + self.impl.shape
+
+    @classmethod
+    def view(cls, ptr_impl, ptr_expl, shape, keep=None, on_write=None):
+        return cls(_parts=(hip_mesh.view(ptr_impl, shape, keep, on_write),
+                           hip_mesh.view(ptr_expl, shape, keep, on_write)))
+
+    def get(self):
+        return np.stack([self.impl.get(), self.expl.get()])
+
+    def __array__(self, dtype=None, copy=None):
+        return self.get()
+
+    def __setitem__(self, key, value):
+        if isinstance(value, hip_imex_mesh):
+            self.impl[:] = value.impl
+            self.expl[:] = value.expl
+        elif np.isscalar(value):
+            self.impl[:] = value
+            self.expl[:] = value
+        else:
+            v = np.asarray(value)
+            self.impl[:] = v[0]
+            self.expl[:] = v[1]
+
+    def __getitem__(self, key):
+        if key == 0:
+            return self.impl
+        if key == 1:
+            return self.expl
+        return self
+
+
+# ---- raw HIP runtime access for host copies (same runtime instance the engine uses) ---------------------
+_hiprt = None
+
+
+def _hip():
+    global _hiprt
+    if _hiprt is None:
+        L.load()
+        for name in ('libamdhip64.so.7', 'libamdhip64.so'):
+            try:
+                _hiprt = C.CDLL(name, mode=C.RTLD_GLOBAL)
+                break
+            except OSError:
+                continue
+        if _hiprt is None:
+            from pysdc_amd.errors import EngineError
+
+            raise EngineError('cannot find the HIP runtime (libamdhip64)')
+        _hiprt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        _hiprt.hipMemcpy.restype = C.c_int
+    return _hiprt
+
+
+def _check_hip(rc):
+    if rc != 0:
+        from pysdc_amd.errors import EngineError
+
+        raise EngineError(f'HIP runtime error {rc}')
+
+
+def _chk(rc):
+    L.check(rc, None)

@@ -1,0 +1,315 @@
+"""Level and Step containers with the reference's surface (pySDC/core/level.py:42-191, pySDC/core/step.py:24-331)
+on top of device slabs: ``L.u[m]``, ``L.f[m]``, ``L.tau[m]``, ``L.uend`` are views into the SweepEngine's
+U / F / TAU / UEND slabs; assigning to them copies into the slab (SURVEY.md 8b "Level/data surface")."""
+import logging
+
+import numpy as np
+
+from pysdc_amd import lib as Lb
+from pysdc_amd.engine import SweepEngine
+from pysdc_amd.errors import ParameterError
+from pysdc_amd.hip_mesh import hip_mesh, hip_imex_mesh
+
+
+class _Frozen:
+    def get(self, key, default=None):
+        return self.__dict__.get(key, default)
+
+
+class LevelParams(_Frozen):
+    """pySDC/core/level.py:9-21."""
+
+    def __init__(self, params):
+        self.dt = None
+        self.dt_initial = None
+        self.restol = -1.0
+        self.nsweeps = 1
+        self.residual_type = 'full_abs'
+        for k, v in params.items():
+            setattr(self, k, v)
+        self.dt_initial = self.dt * 1.0 if self.dt is not None else None
+
+
+class LevelStatus(_Frozen):
+    """pySDC/core/level.py:24-39."""
+
+    def __init__(self):
+        self.residual = None
+        self.unlocked = False
+        self.updated = False
+        self.time = None
+        self.dt_new = None
+        self.sweep = None
+
+
+class SlabList:
+    """list-like over the fields of one engine slab.  get -> view or None; set -> copy into the slab."""
+
+    def __init__(self, level, slot, length, imex=False):
+        self._L, self._slot, self._len, self._imex = level, slot, length, imex
+        self._valid = [False] * length
+        self._views = [None] * length
+
+    def __len__(self):
+        return self._len
+
+    def _norm(self, m):
+        if m < 0:
+            m += self._len
+        if not 0 <= m < self._len:
+            raise IndexError(m)
+        return m
+
+    def _view(self, m):
+        if self._views[m] is None:
+            e = self._L.engine
+            shape = e.nvars
+            if self._imex:
+                self._views[m] = hip_imex_mesh.view(e.ptr(self._slot, m, 0), e.ptr(self._slot, m, 1), shape, keep=e,
+                                                    on_write=self._L._touched)
+            else:
+                self._views[m] = hip_mesh.view(e.ptr(self._slot, m, 0), shape, keep=e, on_write=self._L._touched)
+        return self._views[m]
+
+    def __getitem__(self, m):
+        if isinstance(m, slice):
+            return [self[i] for i in range(*m.indices(self._len))]
+        m = self._norm(m)
+        return self._view(m) if self._valid[m] else None
+
+    def __setitem__(self, m, value):
+        m = self._norm(m)
+        if value is None:
+            self._valid[m] = False
+        else:
+            if self._slot == Lb.SLOT_TAU and not any(self._valid):
+                self._L._activate_tau()
+            v = self._view(m)
+            if value is not v:
+                v[:] = value
+            self._valid[m] = True
+        if self._slot == Lb.SLOT_TAU and not any(self._valid):
+            self._L.engine.set_tau_active(False)
+        self._L._touched()
+
+    def __iter__(self):
+        return (self[m] for m in range(self._len))
+
+    def mark(self, ms, valid=True):
+        for m in ms:
+            self._valid[m] = valid
+
+    def invalidate(self):
+        self._valid = [False] * self._len
+
+
+class Level:
+    """pySDC/core/level.py:42-191."""
+
+    def __init__(self, problem_class, problem_params, sweeper_class, sweeper_params, level_params, level_index):
+        self.params = LevelParams(level_params)
+        self.status = LevelStatus()
+        self.__sweep = sweeper_class(sweeper_params, self)
+        self.__prob = problem_class(**problem_params)
+        self.level_index = level_index
+        M = self.__sweep.coll.num_nodes
+        self.__engine = None
+        self._u = self._f = self._tau = None
+        self._uend_valid = False
+        self._uend_view = None
+        self.uold = [None] * (M + 1)
+        self.fold = [None] * (M + 1)
+        self.u_avg = [None] * M
+        self.residual = [None] * M
+        self.increment = [None] * M
+        self.__tag = None
+        self._res_cache = None
+
+    # ---- device state ----------------------------------------------------------------------------------
+    @property
+    def engine(self):
+        if self.__engine is None:
+            P, M = self.__prob, self.__sweep.coll.num_nodes
+            nvars = getattr(P, 'nvars', None)
+            if nvars is None:
+                raise ParameterError('problem does not define nvars: cannot create device slabs')
+            self.__engine = SweepEngine(nvars, M, getattr(P, 'ncomp', 1))
+            P.bind_engine(self.__engine)
+            self.__sweep.push_coeffs(self.__engine)
+        return self.__engine
+
+    def _lists(self):
+        if self._u is None:
+            M = self.__sweep.coll.num_nodes
+            imex = getattr(self.__prob, 'ncomp', 1) == 2
+            self._u = SlabList(self, Lb.SLOT_U, M + 1)
+            self._f = SlabList(self, Lb.SLOT_F, M + 1, imex=imex)
+            self._tau = SlabList(self, Lb.SLOT_TAU, M)
+
+    @property
+    def u(self):
+        self._lists()
+        return self._u
+
+    @property
+    def f(self):
+        self._lists()
+        return self._f
+
+    @property
+    def tau(self):
+        self._lists()
+        return self._tau
+
+    @property
+    def uend(self):
+        if not self._uend_valid:
+            return None
+        if self._uend_view is None:
+            e = self.engine
+            self._uend_view = hip_mesh.view(e.ptr(Lb.SLOT_UEND), e.nvars, keep=e)
+        return self._uend_view
+
+    @uend.setter
+    def uend(self, value):
+        if value is None:
+            self._uend_valid = False
+            return
+        self._uend_valid = True
+        v = self.uend
+        if value is not v:
+            v[:] = value
+
+    def _activate_tau(self):
+        e = self.engine
+        e.set_tau_active(True)
+        e.vec_fill(e.N * e.M, 0.0, e.ptr(Lb.SLOT_TAU, 0))
+
+    def _touched(self):
+        self._res_cache = None
+
+    def reset_level(self, reset_status=True):
+        """pySDC/core/level.py:110-131."""
+        self._lists()
+        M = self.__sweep.coll.num_nodes
+        self.uend = None
+        self._u.invalidate()
+        self._f.invalidate()
+        self._tau.invalidate()
+        if self.__engine is not None:
+            self.__engine.set_tau_active(False)
+        self.uold = [None] * (M + 1)
+        self.fold = [None] * (M + 1)
+        self.u_avg = [None] * M
+        self.residual = [None] * M
+        self.increment = [None] * M
+        self._res_cache = None
+        if reset_status:
+            self.status = LevelStatus()
+
+    # ---- the rest of the reference's surface -------------------------------------------------------------
+    @property
+    def sweep(self):
+        return self.__sweep
+
+    @property
+    def prob(self):
+        return self.__prob
+
+    @property
+    def time(self):
+        return self.status.time
+
+    @property
+    def dt(self):
+        return self.params.dt
+
+    @property
+    def tag(self):
+        return self.__tag
+
+    @tag.setter
+    def tag(self, t):
+        self.__tag = t
+
+
+class StepParams(_Frozen):
+    def __init__(self, params):
+        self.maxiter = None
+        for k, v in params.items():
+            setattr(self, k, v)
+
+
+class StepStatus(_Frozen):
+    """pySDC/core/step.py:21-44."""
+
+    def __init__(self):
+        self.iter = None
+        self.stage = None
+        self.slot = None
+        self.first = None
+        self.last = None
+        self.pred_cnt = None
+        self.done = None
+        self.force_done = None
+        self.force_continue = False
+        self.prev_done = None
+        self.time_size = None
+        self.diff_old_loc = None
+        self.diff_first_loc = None
+        self.restart = False
+
+
+class Step:
+    """pySDC/core/step.py:47-331: one time step with its level hierarchy (single level in this round)."""
+
+    def __init__(self, description):
+        self.logger = logging.getLogger('step')
+        self.params = StepParams(description.get('step_params', {}))
+        self.status = StepStatus()
+        self.levels = []
+        self.__prev = None
+        self.__next = None
+        essential = ['problem_class', 'sweeper_class', 'sweeper_params', 'level_params']
+        for key in essential:
+            if key not in description:
+                raise ParameterError('need %s to instantiate step, only got %s' % (key, str(description.keys())))
+        pp = dict(description.get('problem_params', {}))
+        sp = dict(description['sweeper_params'])
+        lp = dict(description['level_params'])
+        for name, d in (('problem_params', pp), ('sweeper_params', sp), ('level_params', lp)):
+            for k, v in d.items():
+                if isinstance(v, list) and len(v) > 1:
+                    raise ParameterError(
+                        f'{name}[{k!r}] is a list: lists mean one entry per level (pySDC/core/step.py:175-199) and '
+                        'multi-level hierarchies are not part of this engine yet; pass tuples / arrays for values'
+                    )
+                if isinstance(v, list) and len(v) == 1:
+                    d[k] = v[0]
+        self.levels.append(Level(description['problem_class'], pp, description['sweeper_class'], sp, lp, 0))
+
+    @property
+    def time(self):
+        return self.levels[0].time
+
+    @property
+    def dt(self):
+        return self.levels[0].dt
+
+    @property
+    def prev(self):
+        return self.__prev
+
+    @prev.setter
+    def prev(self, p):
+        self.__prev = p
+
+    def reset_step(self):
+        for l in self.levels:
+            l.reset_level()
+
+    def init_step(self, u0):
+        """pySDC/core/step.py:256-271."""
+        assert len(self.levels) >= 1
+        assert len(self.levels[0].u) >= 1
+        self.levels[0].u[0] = u0

@@ -1,0 +1,327 @@
+"""Problem classes with the reference's plug-in surface (SURVEY.md 8b "Problem surface"):
+``init, dtype_u, dtype_f, u_init, f_init, eval_f(u, t), solve_system(rhs, factor, u0, t), u_exact(t),
+work_counters, nvars, dx, get_default_sweeper_class()`` - computing on the MI355X through libsdcmi.
+
+Mirrors (behaviour, parameter names, error messages):
+  GenericNDimFinDiff  /root/reference/pySDC/implementations/problem_classes/generic_ND_FD.py:17-264
+  heatNd_unforced/_forced  .../HeatEquation_ND_FD.py:9-230
+  advectionNd         .../AdvectionEquation_ND_FD.py:8-132
+plus ``advectiondiffusionNd_imex`` (BASELINE config 3; the reference has no ND finite-difference IMEX
+advection-diffusion class)."""
+import logging
+
+import numpy as np
+
+from pysdc_amd import fd
+from pysdc_amd import lib as L
+from pysdc_amd.errors import ProblemError, ReadOnlyError
+from pysdc_amd.hip_mesh import hip_mesh, hip_imex_mesh
+
+
+class WorkCounter:
+    """pySDC/core/problem.py:16-40."""
+
+    def __init__(self):
+        self.niter = 0
+
+    def __call__(self, *args, **kwargs):
+        self.niter += 1
+
+    def decrement(self):
+        self.niter -= 1
+
+    def __str__(self):
+        return f'{self.niter}'
+
+
+class _Params(dict):
+    __getattr__ = dict.get
+
+
+class Problem:
+    """pySDC/core/problem.py:43-215 (interface part)."""
+
+    dtype_u = hip_mesh
+    dtype_f = hip_mesh
+    logger = logging.getLogger('problem')
+    fused = False  # set by classes whose sweep can run as one fused engine call
+
+    def __init__(self, init):
+        object.__setattr__(self, '_readonly', set())
+        self.work_counters = {}
+        self.init = init
+        self.params = _Params()
+        self._engine = None
+
+    def _makeAttributeAndRegister(self, *names, localVars=None, readOnly=False):
+        for name in names:
+            object.__setattr__(self, name, localVars[name])
+            self.params[name] = localVars[name]
+            if readOnly:
+                self._readonly.add(name)
+
+    def __setattr__(self, name, value):
+        if name in getattr(self, '_readonly', ()):
+            raise ReadOnlyError(name)
+        object.__setattr__(self, name, value)
+
+    @property
+    def u_init(self):
+        return self.dtype_u(self.init)
+
+    @property
+    def f_init(self):
+        return self.dtype_f(self.init)
+
+    def eval_f(self, u, t):
+        raise NotImplementedError('ERROR: problem has to implement eval_f(self, u, t)')
+
+    def solve_system(self, rhs, factor, u0, t):
+        raise NotImplementedError('ERROR: problem has to implement solve_system(self, rhs, factor, u0, t)')
+
+    def u_exact(self, t):
+        raise NotImplementedError('ERROR: problem has to implement u_exact(self, t)')
+
+    # ---- engine binding: the level's SweepEngine also serves eval_f / solve_system ------------------------
+    ncomp = 1
+
+    def bind_engine(self, engine):
+        self._engine = engine
+        self.configure_engine(engine)
+
+    def configure_engine(self, engine):
+        pass
+
+    @property
+    def engine(self):
+        if self._engine is None:
+            from pysdc_amd.engine import SweepEngine
+
+            self.bind_engine(SweepEngine(self.nvars, 1, self.ncomp))
+        return self._engine
+
+
+class GenericNDimFinDiff(Problem):
+    """du/dt = A u, A a periodic finite-difference operator applied matrix-free on the device."""
+
+    fused = True
+
+    def __init__(self, nvars=512, coeff=1.0, derivative=1, freq=2, stencil_type='center', order=2, lintol=1e-12,
+                 liniter=10000, solver_type='direct', bc='periodic', bcParams=None):
+        if type(nvars) not in [int, tuple]:
+            raise ProblemError('nvars should be either tuple or int')
+        if type(freq) not in [int, tuple]:
+            raise ProblemError('freq should be either tuple or int')
+        if type(nvars) is int:
+            nvars = (nvars,)
+        ndim = len(nvars)
+        if ndim > 3:
+            raise ProblemError(f'can work with up to three dimensions, got {ndim}')
+        if type(freq) is int:
+            freq = (freq,) * ndim
+        if len(freq) != ndim:
+            raise ProblemError(f'len(freq)={len(freq)}, different to ndim={ndim}')
+        for f in freq:
+            if ndim == 1 and f == -1:
+                bc = 'periodic'
+                break
+            if f % 2 != 0 and bc == 'periodic':
+                raise ProblemError('need even number of frequencies due to periodic BCs')
+        for nvar in nvars:
+            if nvar % 2 != 0 and bc == 'periodic':
+                raise ProblemError('the setup requires nvars = 2^p per dimension')
+            if (nvar + 1) % 2 != 0 and bc == 'dirichlet-zero':
+                raise ProblemError('setup requires nvars = 2^p - 1')
+        if ndim > 1 and nvars[1:] != nvars[:-1]:
+            raise ProblemError('need a square domain, got %s' % (nvars,))
+        if bc != 'periodic':
+            raise ProblemError(f'the MI355X engine implements periodic boundary conditions only, got bc={bc!r}')
+        if solver_type != 'direct':
+            raise ProblemError(
+                f"solver_type {solver_type!r} is not available on the MI355X engine: the periodic operator is "
+                "solved exactly in Fourier space (solver_type='direct')"
+            )
+        super().__init__(init=(nvars[0] if ndim == 1 else nvars, None, np.dtype('float64')))
+        dx, xvalues = fd.get_1d_grid(size=nvars[0], bc=bc, left_boundary=0.0, right_boundary=1.0)
+        self._stencil = fd.periodic_operator_stencil(derivative, order, stencil_type, dx, coeff)
+        self.xvalues = xvalues
+        self._makeAttributeAndRegister('nvars', 'stencil_type', 'order', 'bc', localVars=locals(), readOnly=True)
+        self._makeAttributeAndRegister('freq', 'lintol', 'liniter', 'solver_type', localVars=locals())
+
+    @property
+    def ndim(self):
+        return len(self.nvars)
+
+    @property
+    def dx(self):
+        return self.xvalues[1] - self.xvalues[0]
+
+    @property
+    def grids(self):
+        x = self.xvalues
+        if self.ndim == 1:
+            return x
+        if self.ndim == 2:
+            return x[None, :], x[:, None]
+        return x[None, :, None], x[:, None, None], x[None, None, :]
+
+    @classmethod
+    def get_default_sweeper_class(cls):
+        from pysdc_amd.sweepers import generic_implicit
+
+        return generic_implicit
+
+    def configure_engine(self, engine):
+        engine.set_stencil(0, *self._stencil)
+
+    def eval_f(self, u, t):
+        f = self.f_init
+        self.engine.eval_f(u.ptr, 0.0, f.ptr)
+        return f
+
+    def solve_system(self, rhs, factor, u0, t):
+        sol = self.u_init
+        self.engine.solve(rhs.ptr, float(factor), sol.ptr)
+        return sol
+
+    def _from_host(self, values):
+        sol = self.u_init
+        sol[:] = values
+        return sol
+
+
+class heatNd_unforced(GenericNDimFinDiff):
+    def __init__(self, nvars=512, nu=0.1, freq=2, stencil_type='center', order=2, lintol=1e-12, liniter=10000,
+                 solver_type='direct', bc='periodic', sigma=6e-2):
+        super().__init__(nvars, nu, 2, freq, stencil_type, order, lintol, liniter, solver_type, bc)
+        self._makeAttributeAndRegister('nu', localVars=locals(), readOnly=True)
+        self._makeAttributeAndRegister('sigma', localVars=locals())
+
+    def u_exact(self, t, **kwargs):
+        """HeatEquation_ND_FD.py:84-132 verbatim in its arithmetic, including the 3-D expression whose middle
+        term of rho has no '/ dx**2' (SURVEY.md F8); evaluated on the host, returned on the device."""
+        ndim, freq, nu, sigma, dx = self.ndim, self.freq, self.nu, self.sigma, self.dx
+        if ndim == 1:
+            x = self.grids
+            rho = (2.0 - 2.0 * np.cos(np.pi * freq[0] * dx)) / dx**2
+            if freq[0] > 0:
+                sol = np.sin(np.pi * freq[0] * x) * np.exp(-t * nu * rho)
+            else:
+                sol = np.exp(-0.5 * ((x - 0.5) / sigma) ** 2) * np.exp(-t * nu * rho)
+        elif ndim == 2:
+            rho = (2.0 - 2.0 * np.cos(np.pi * freq[0] * dx)) / dx**2 + (
+                2.0 - 2.0 * np.cos(np.pi * freq[1] * dx)
+            ) / dx**2
+            x, y = self.grids
+            sol = np.sin(np.pi * freq[0] * x) * np.sin(np.pi * freq[1] * y) * np.exp(-t * nu * rho)
+        else:
+            rho = (
+                (2.0 - 2.0 * np.cos(np.pi * freq[0] * dx)) / dx**2
+                + (2.0 - 2.0 * np.cos(np.pi * freq[1] * dx))
+                + (2.0 - 2.0 * np.cos(np.pi * freq[2] * dx)) / dx**2
+            )
+            x, y, z = self.grids
+            sol = (np.sin(np.pi * freq[0] * x) * np.sin(np.pi * freq[1] * y) * np.sin(np.pi * freq[2] * z)
+                   * np.exp(-t * nu * rho))
+        return self._from_host(sol)
+
+
+class heatNd_forced(heatNd_unforced):
+    dtype_f = hip_imex_mesh
+    ncomp = 2
+    expl_kind = L.EXPL_FORCING
+
+    def _profile(self):
+        g = self.grids
+        if self.ndim == 1:
+            return np.sin(np.pi * self.freq[0] * g)
+        p = np.sin(np.pi * self.freq[0] * g[0])
+        for i in range(1, self.ndim):
+            p = p * np.sin(np.pi * self.freq[i] * g[i])
+        return np.broadcast_to(p, self.nvars)
+
+    def forcing_g(self, t):
+        """time factor of the forcing term, HeatEquation_ND_FD.py:176-204."""
+        return self.nu * np.pi**2 * sum([freq**2 for freq in self.freq]) * np.cos(t) - np.sin(t)
+
+    def configure_engine(self, engine):
+        super().configure_engine(engine)
+        engine.set_forcing_profile(self._profile())
+
+    @classmethod
+    def get_default_sweeper_class(cls):
+        from pysdc_amd.sweepers import imex_1st_order
+
+        return imex_1st_order
+
+    def eval_f(self, u, t):
+        f = self.f_init
+        self.engine.eval_f(u.ptr, float(self.forcing_g(t)), f.impl.ptr, f.expl.ptr)
+        return f
+
+    def u_exact(self, t):
+        return self._from_host(self._profile() * np.cos(t))
+
+
+class advectionNd(GenericNDimFinDiff):
+    def __init__(self, nvars=512, c=1.0, freq=2, stencil_type='center', order=2, lintol=1e-12, liniter=10000,
+                 solver_type='direct', bc='periodic', sigma=6e-2):
+        super().__init__(nvars, -c, 1, freq, stencil_type, order, lintol, liniter, solver_type, bc)
+        self._makeAttributeAndRegister('c', localVars=locals(), readOnly=True)
+        self._makeAttributeAndRegister('sigma', localVars=locals())
+
+    def u_exact(self, t, **kwargs):
+        ndim, freq, c, sigma = self.ndim, self.freq, self.c, self.sigma
+        if ndim == 1:
+            x = self.grids
+            if freq[0] >= 0:
+                sol = np.sin(np.pi * freq[0] * (x - c * t))
+            else:
+                sol = np.exp(-0.5 * (((x - (c * t)) % 1.0 - 0.5) / sigma) ** 2)
+        elif ndim == 2:
+            x, y = self.grids
+            sol = np.sin(np.pi * freq[0] * (x - c * t)) * np.sin(np.pi * freq[1] * (y - c * t))
+        else:
+            x, y, z = self.grids
+            sol = (np.sin(np.pi * freq[0] * (x - c * t)) * np.sin(np.pi * freq[1] * (y - c * t))
+                   * np.sin(np.pi * freq[2] * (z - c * t)))
+        return self._from_host(np.broadcast_to(sol, self.nvars))
+
+
+class advectiondiffusionNd_imex(GenericNDimFinDiff):
+    """u_t = nu * Laplace(u) - c * sum_d du/dx_d, periodic: diffusion implicit (solved in Fourier space),
+    advection explicit; both halves use the reference's stencil generator.  BASELINE config 3."""
+
+    dtype_f = hip_imex_mesh
+    ncomp = 2
+    expl_kind = L.EXPL_STENCIL
+
+    def __init__(self, nvars=512, nu=0.02, c=1.0, freq=2, stencil_type='center', order=2, lintol=1e-12,
+                 liniter=10000, solver_type='direct', bc='periodic'):
+        super().__init__(nvars, nu, 2, freq, 'center', order, lintol, liniter, solver_type, bc)
+        self._stencil_expl = fd.periodic_operator_stencil(1, order, stencil_type, self.dx, -c)
+        self._makeAttributeAndRegister('nu', 'c', localVars=locals(), readOnly=True)
+
+    def configure_engine(self, engine):
+        super().configure_engine(engine)
+        engine.set_stencil(1, *self._stencil_expl)
+
+    @classmethod
+    def get_default_sweeper_class(cls):
+        from pysdc_amd.sweepers import imex_1st_order
+
+        return imex_1st_order
+
+    def eval_f(self, u, t):
+        f = self.f_init
+        self.engine.eval_f(u.ptr, 0.0, f.impl.ptr, f.expl.ptr)
+        return f
+
+    def u_exact(self, t):
+        """sin modes advected with speed c and damped by the *discrete* symbols of both operators."""
+        g = self.grids if self.ndim > 1 else (self.grids,)
+        sol = 1.0
+        for i in range(self.ndim):
+            sol = sol * np.sin(np.pi * self.freq[i] * (g[i] - self.c * t))
+        rho = sum((2.0 - 2.0 * np.cos(np.pi * f * self.dx)) / self.dx**2 for f in self.freq)
+        return self._from_host(np.broadcast_to(sol * np.exp(-t * self.nu * rho), self.nvars))

@@ -1,0 +1,398 @@
+"""Sweepers with the reference's surface (SURVEY.md 8b "Sweeper surface"):
+``predict, update_nodes, compute_residual, compute_end_point, integrate, updateVariableCoeffs,
+get_Qdelta_implicit / _explicit, coll, params, QI, QE, parallelizable, genQI, genQE, level, rank``.
+
+Mirrors  pySDC/core/sweeper.py:33-276, pySDC/implementations/sweeper_classes/generic_implicit.py:4-131 and
+imex_1st_order.py:6-137.  When the problem is one the engine can sweep in one call (``prob.fused``: periodic
+finite-difference operators) each method is ONE C-ABI call on the level's device slabs; otherwise the same
+algorithm runs node by node on ``hip_mesh`` operations with ``prob.eval_f`` / ``prob.solve_system``."""
+import logging
+
+import numpy as np
+
+from pysdc_amd import lib as Lb
+from pysdc_amd.coeffs import CollBase, QDELTA_GENERATORS
+from pysdc_amd.errors import ParameterError
+
+
+class _Pars:
+    """pySDC/core/sweeper.py:20-30."""
+
+    def __init__(self, pars):
+        self.do_coll_update = False
+        self.initial_guess = 'spread'
+        self.skip_residual_computation = ()
+        for k, v in pars.items():
+            if k != 'collocation_class':
+                setattr(self, k, v)
+
+    def get(self, key, default=None):
+        return self.__dict__.get(key, default)
+
+
+def _aliases(cls):
+    return {k for k, v in QDELTA_GENERATORS.items() if v is cls}
+
+
+class Sweeper:
+    def __init__(self, params, level):
+        self.logger = logging.getLogger('sweeper')
+        if 'num_nodes' not in params:
+            msg = 'need num_nodes to instantiate step, only got %s' % str(params.keys())
+            self.logger.error(msg)
+            raise ParameterError(msg)
+        if 'collocation_class' not in params:
+            params['collocation_class'] = CollBase
+        if params.get('initial_guess', 'spread') == 'random':
+            params['random_seed'] = params.get('random_seed', 1984)
+            self.rng = np.random.RandomState(params['random_seed'])
+        self.params = _Pars(params)
+        self.coll = params['collocation_class'](**params)
+        if not self.coll.right_is_node and not self.params.do_coll_update:
+            self.logger.warning(
+                'we need to do a collocation update here, since the right end point is not a node. Changing this!'
+            )
+            self.params.do_coll_update = True
+        self.__level = level
+        self.parallelizable = False
+        for name in ['genQI', 'genQE']:
+            if hasattr(self, name):
+                delattr(self, name)
+
+    # ---- Q-Delta matrices (pySDC/core/sweeper.py:97-123) --------------------------------------------------
+    def buildGenerator(self, qdType):
+        if qdType not in QDELTA_GENERATORS:
+            raise ParameterError(f'unknown Q-Delta type {qdType!r}')
+        return QDELTA_GENERATORS[qdType](qGen=self.coll.generator, tLeft=self.coll.tleft)
+
+    def get_Qdelta_implicit(self, qd_type, k=None):
+        QDmat = np.zeros_like(self.coll.Qmat)
+        if not hasattr(self, 'genQI') or qd_type not in _aliases(type(self.genQI)) | {type(self.genQI).__name__}:
+            self.genQI = self.buildGenerator(qd_type)
+        QDmat[1:, 1:] = self.genQI.genCoeffs(k=k)
+        err_msg = 'Lower triangular matrix expected!'
+        np.testing.assert_array_equal(np.triu(QDmat, k=1), np.zeros(QDmat.shape), err_msg=err_msg)
+        if np.allclose(np.diag(np.diag(QDmat)), QDmat):
+            self.parallelizable = True
+        return QDmat
+
+    def get_Qdelta_explicit(self, qd_type, k=None):
+        QDmat = np.zeros(self.coll.Qmat.shape, dtype=float)
+        if not hasattr(self, 'genQE') or qd_type not in _aliases(type(self.genQE)) | {type(self.genQE).__name__}:
+            self.genQE = self.buildGenerator(qd_type)
+        QDmat[1:, 1:], QDmat[1:, 0] = self.genQE.genCoeffs(k=k, dTau=True)
+        err_msg = 'Strictly lower triangular matrix expected!'
+        np.testing.assert_array_equal(np.triu(QDmat, k=0), np.zeros(QDmat.shape), err_msg=err_msg)
+        if np.allclose(np.diag(np.diag(QDmat)), QDmat):
+            self.parallelizable = True
+        return QDmat
+
+    def updateVariableCoeffs(self, k):
+        """pySDC/core/sweeper.py:262-276."""
+        changed = False
+        if hasattr(self, 'genQI') and self.genQI.isKDependent():
+            self.QI = self.get_Qdelta_implicit(type(self.genQI).__name__, k=k)
+            changed = True
+        if hasattr(self, 'genQE') and self.genQE.isKDependent():
+            self.QE = self.get_Qdelta_explicit(type(self.genQE).__name__, k=k)
+            changed = True
+        if changed and self._fused():
+            self.push_coeffs(self.level.engine)
+
+    # ---- engine plumbing ----------------------------------------------------------------------------------
+    imex = False
+
+    def push_coeffs(self, engine):
+        qe = getattr(self, 'QE', None)
+        if engine.ncomp == 2 and qe is None:
+            qe = np.zeros_like(self.coll.Qmat)
+        engine.set_coeffs(self.coll.Qmat, self.QI, qe if engine.ncomp == 2 else None, self.coll.nodes,
+                          self.coll.weights)
+
+    def _fused(self):
+        L = self.level
+        if L is None:
+            return False
+        P = L.prob
+        if not getattr(P, 'fused', False):
+            return False
+        return (getattr(P, 'ncomp', 1) == 2) == self.imex
+
+    def _node_times(self):
+        L = self.level
+        return [L.time] + [L.time + L.dt * tau for tau in self.coll.nodes]
+
+    def _push_forcing(self):
+        P = self.level.prob
+        if hasattr(P, 'forcing_g'):
+            self.level.engine.set_forcing_values([float(P.forcing_g(t)) for t in self._node_times()])
+
+    # ---- predict (pySDC/core/sweeper.py:125-162) ------------------------------------------------------------
+    def predict(self):
+        L = self.level
+        P = L.prob
+        M = self.coll.num_nodes
+        guess = self.params.initial_guess
+        if guess not in ('spread', 'copy', 'zero', 'random'):
+            raise ParameterError(f'initial_guess option {guess} not implemented')
+        if self._fused():
+            e = L.engine
+            self._push_forcing()
+            fu = ff = 0.0
+            if guess == 'random':
+                # the reference draws one scalar per node and field (sweeper.py:155-156); the engine fills all
+                # nodes with one pair, so draw node by node on the generic path instead
+                return self._predict_generic()
+            e.predict(L.time, L.dt, guess, fu, ff)
+            L.u.mark(range(M + 1))
+            L.f.mark(range(M + 1))
+            L._touched()
+        else:
+            return self._predict_generic()
+        L.status.unlocked = True
+        L.status.updated = True
+
+    def _predict_generic(self):
+        L = self.level
+        P = L.prob
+        L.f[0] = P.eval_f(L.u[0], L.time)
+        for m in range(1, self.coll.num_nodes + 1):
+            g = self.params.initial_guess
+            if g == 'spread':
+                L.u[m] = P.dtype_u(L.u[0])
+                L.f[m] = P.eval_f(L.u[m], L.time + L.dt * self.coll.nodes[m - 1])
+            elif g == 'copy':
+                L.u[m] = P.dtype_u(L.u[0])
+                L.f[m] = P.dtype_f(L.f[0])
+            elif g == 'zero':
+                L.u[m] = P.dtype_u(init=P.init, val=0.0)
+                L.f[m] = P.dtype_f(init=P.init, val=0.0)
+            elif g == 'random':
+                L.u[m] = P.dtype_u(init=P.init, val=self.rng.rand(1)[0])
+                L.f[m] = P.dtype_f(init=P.init, val=self.rng.rand(1)[0])
+        L.status.unlocked = True
+        L.status.updated = True
+
+    # ---- residual (pySDC/core/sweeper.py:164-215) -----------------------------------------------------------
+    def compute_residual(self, stage=''):
+        L = self.level
+        if stage in self.params.skip_residual_computation:
+            L.status.residual = 0.0 if L.status.residual is None else L.status.residual
+            return None
+        rt = L.params.residual_type
+        if rt not in Lb.RES_TYPES:
+            raise ParameterError(
+                f'residual_type = {rt} not implemented, choose full_abs, last_abs, full_rel or last_rel instead'
+            )
+        if self._fused():
+            # the device state is unchanged since the last evaluation -> same value, no second pass
+            # (the controller calls this twice per iteration)
+            if L._res_cache is not None and L._res_cache[0] == (rt, L.dt):
+                L.status.residual = L._res_cache[1]
+            else:
+                res, norms = L.engine.residual(L.dt, rt)
+                L.status.residual = res
+                L._res_cache = ((rt, L.dt), res)
+                L.residual = list(norms)  # node-wise max norms; the M residual vectors are not materialised
+        else:
+            res_norm = []
+            L.residual = self.integrate()
+            for m in range(self.coll.num_nodes):
+                L.residual[m] += L.u[0] - L.u[m + 1]
+                if L.tau[m] is not None:
+                    L.residual[m] += L.tau[m]
+                res_norm.append(abs(L.residual[m]))
+            if rt == 'full_abs':
+                L.status.residual = max(res_norm)
+            elif rt == 'last_abs':
+                L.status.residual = res_norm[-1]
+            elif rt == 'full_rel':
+                L.status.residual = max(res_norm) / abs(L.u[0])
+            else:
+                L.status.residual = res_norm[-1] / abs(L.u[0])
+        L.status.updated = False
+        return None
+
+    def compute_end_point(self):
+        raise NotImplementedError('ERROR: sweeper has to implement compute_end_point(self)')
+
+    def integrate(self):
+        raise NotImplementedError('ERROR: sweeper has to implement integrate(self)')
+
+    def update_nodes(self):
+        raise NotImplementedError('ERROR: sweeper has to implement update_nodes(self)')
+
+    def _integrate_fused(self):
+        L = self.level
+        P = L.prob
+        me = [P.dtype_u(P.init, val=0.0) for _ in range(self.coll.num_nodes)]
+        L.engine.integrate(L.dt, [x.ptr for x in me])
+        return me
+
+    def _update_nodes_fused(self):
+        L = self.level
+        assert L.status.unlocked
+        M = self.coll.num_nodes
+        if not all(L.u[m] is not None for m in range(M + 1)):
+            raise ParameterError('update_nodes needs values at all nodes (predict first)')
+        self._push_forcing()
+        L.engine.sweep(L.time, L.dt)
+        L._touched()
+        L.status.updated = True
+
+    def _end_point_fused(self):
+        L = self.level
+        dcu = not (self.coll.right_is_node and not self.params.do_coll_update)
+        L.engine.end_point(L.dt, dcu)
+        L._uend_valid = True
+
+    @property
+    def level(self):
+        return self.__level
+
+    @level.setter
+    def level(self, L):
+        from pysdc_amd.level import Level
+
+        assert isinstance(L, Level)
+        self.__level = L
+
+    @property
+    def rank(self):
+        return 0
+
+
+class generic_implicit(Sweeper):
+    """generic_implicit.py:4-131."""
+
+    def __init__(self, params, level):
+        if 'QI' not in params:
+            params['QI'] = 'IE'
+        super().__init__(params, level)
+        self.QI = self.get_Qdelta_implicit(qd_type=self.params.QI)
+
+    def integrate(self):
+        if self._fused():
+            return self._integrate_fused()
+        L = self.level
+        P = L.prob
+        me = []
+        for m in range(1, self.coll.num_nodes + 1):
+            me.append(P.dtype_u(P.init, val=0.0))
+            for j in range(1, self.coll.num_nodes + 1):
+                me[-1] += L.dt * self.coll.Qmat[m, j] * L.f[j]
+        return me
+
+    def update_nodes(self):
+        if self._fused():
+            return self._update_nodes_fused()
+        L = self.level
+        P = L.prob
+        assert L.status.unlocked
+        M = self.coll.num_nodes
+        integral = self.integrate()
+        for m in range(M):
+            for j in range(1, M + 1):
+                integral[m] -= L.dt * self.QI[m + 1, j] * L.f[j]
+            integral[m] += L.u[0]
+            if L.tau[m] is not None:
+                integral[m] += L.tau[m]
+        for m in range(0, M):
+            rhs = P.dtype_u(integral[m])
+            for j in range(1, m + 1):
+                rhs += L.dt * self.QI[m + 1, j] * L.f[j]
+            alpha = L.dt * self.QI[m + 1, m + 1]
+            if alpha == 0:
+                L.u[m + 1] = rhs
+            else:
+                L.u[m + 1] = P.solve_system(rhs, alpha, L.u[m + 1], L.time + L.dt * self.coll.nodes[m])
+            L.f[m + 1] = P.eval_f(L.u[m + 1], L.time + L.dt * self.coll.nodes[m])
+        L.status.updated = True
+        return None
+
+    def compute_end_point(self):
+        if self._fused():
+            return self._end_point_fused()
+        L = self.level
+        P = L.prob
+        if self.coll.right_is_node and not self.params.do_coll_update:
+            L.uend = P.dtype_u(L.u[-1])
+        else:
+            uend = P.dtype_u(L.u[0])
+            for m in range(self.coll.num_nodes):
+                uend += L.dt * self.coll.weights[m] * L.f[m + 1]
+            if L.tau[-1] is not None:
+                uend += L.tau[-1]
+            L.uend = uend
+        return None
+
+
+class imex_1st_order(Sweeper):
+    """imex_1st_order.py:6-137."""
+
+    imex = True
+
+    def __init__(self, params, level):
+        if 'QI' not in params:
+            params['QI'] = 'IE'
+        if 'QE' not in params:
+            params['QE'] = 'EE'
+        super().__init__(params, level)
+        self.QI = self.get_Qdelta_implicit(qd_type=self.params.QI)
+        self.QE = self.get_Qdelta_explicit(qd_type=self.params.QE)
+
+    def integrate(self):
+        if self._fused():
+            return self._integrate_fused()
+        L = self.level
+        P = L.prob
+        me = []
+        for m in range(1, self.coll.num_nodes + 1):
+            me.append(P.dtype_u(P.init, val=0.0))
+            for j in range(1, self.coll.num_nodes + 1):
+                me[m - 1] += L.dt * self.coll.Qmat[m, j] * (L.f[j].impl + L.f[j].expl)
+        return me
+
+    def update_nodes(self):
+        if self._fused():
+            return self._update_nodes_fused()
+        L = self.level
+        P = L.prob
+        assert L.status.unlocked
+        M = self.coll.num_nodes
+        integral = self.integrate()
+        for m in range(M):
+            for j in range(1, M + 1):
+                integral[m] -= L.dt * (self.QI[m + 1, j] * L.f[j].impl + self.QE[m + 1, j] * L.f[j].expl)
+            integral[m] += L.u[0]
+            if L.tau[m] is not None:
+                integral[m] += L.tau[m]
+        for m in range(0, M):
+            rhs = P.dtype_u(integral[m])
+            for j in range(1, m + 1):
+                rhs += L.dt * (self.QI[m + 1, j] * L.f[j].impl + self.QE[m + 1, j] * L.f[j].expl)
+            L.u[m + 1] = P.solve_system(
+                rhs, L.dt * self.QI[m + 1, m + 1], L.u[m + 1], L.time + L.dt * self.coll.nodes[m]
+            )
+            L.f[m + 1] = P.eval_f(L.u[m + 1], L.time + L.dt * self.coll.nodes[m])
+        L.status.updated = True
+        return None
+
+    def compute_end_point(self):
+        if self._fused():
+            return self._end_point_fused()
+        L = self.level
+        P = L.prob
+        if self.coll.right_is_node and not self.params.do_coll_update:
+            L.uend = P.dtype_u(L.u[-1])
+        else:
+            uend = P.dtype_u(L.u[0])
+            for m in range(self.coll.num_nodes):
+                uend += L.dt * self.coll.weights[m] * (L.f[m + 1].impl + L.f[m + 1].expl)
+            if L.tau[-1] is not None:
+                uend += L.tau[-1]
+            L.uend = uend
+        return None
+
+    def get_sweeper_mats(self):
+        return self.QE[1:, 1:], self.QI[1:, 1:], self.coll.Qmat[1:, 1:]

@@ -1,0 +1,134 @@
+"""GPU parity through the drop-in plug-in surface: description dict -> controller -> sweeper_class /
+problem_class -> C-ABI.  Compared with golden runs of the reference (tests/golden/runs.npz): iteration counts
+bit-exact, end values <= 1e-10 relative (BASELINE.json north_star), residual history to 1e-6 relative."""
+import numpy as np
+import pytest
+
+from tests._cases import load_cases, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def _classes():
+    from pysdc_amd import problems as P, sweepers as S
+
+    return ({'heat_unforced': P.heatNd_unforced, 'heat_forced': P.heatNd_forced, 'advection': P.advectionNd,
+             'advdiff': P.advectiondiffusionNd_imex},
+            {'generic_implicit': S.generic_implicit, 'imex_1st_order': S.imex_1st_order})
+
+
+def description_from(meta, problem_class=None):
+    probs, sweeps = _classes()
+    pp = dict(meta['prob_params'])
+    if isinstance(pp.get('nvars'), list):
+        pp['nvars'] = tuple(pp['nvars'])
+    return dict(problem_class=problem_class or probs[meta['prob']], problem_params=pp,
+                sweeper_class=sweeps[meta['sweeper']], sweeper_params=dict(meta['sweeper_params']),
+                level_params=dict(meta['level_params']), step_params=dict(maxiter=meta['maxiter']))
+
+
+@pytest.mark.parametrize('name', list(load_cases('runs.npz')))
+@pytest.mark.parametrize('fused', [True, False])
+def test_run_vs_golden(name, fused):
+    from pysdc_amd.controller import controller_nonMPI
+    from pysdc_amd.stats import get_sorted
+
+    case = load_cases('runs.npz')[name]
+    meta = case['meta']
+    probs, _ = _classes()
+    pc = probs[meta['prob']]
+    if not fused:
+        if meta['num_procs'] > 2 or name == 'config1':
+            pytest.skip('node-by-node path covered on the smaller cases')
+        pc = type(pc.__name__ + '_nodewise', (pc,), {'fused': False})
+    desc = description_from(meta, pc)
+    C = controller_nonMPI(meta['num_procs'], dict(logger_level=40, **meta['controller_params']), desc)
+    P = C.MS[0].levels[0].prob
+    u0 = P.u_init
+    u0[:] = case['u0']
+    uend, stats = C.run(u0, meta['t0'], meta['Tend'])
+    niter = get_sorted(stats, type='niter', sortby='time')
+    assert [v for _, v in niter] == list(case['niter'])
+    np.testing.assert_allclose([t for t, _ in niter], case['niter_t'], rtol=0, atol=1e-14)
+    assert rel_err(uend.get(), case['uend']) < TOL
+    res = [v for _, v in get_sorted(stats, type='residual_post_iteration', sortby='time')]
+    np.testing.assert_allclose(res, case['res'], rtol=1e-6, atol=1e-13)
+
+
+def test_datatype_semantics():
+    """mesh behaviour the controllers / transfer classes rely on (tests/tests_core.py:18-60)."""
+    from pysdc_amd.hip_mesh import hip_mesh
+
+    init = ((4, 8), None, np.dtype('float64'))
+    a = hip_mesh(init, val=1.5)
+    b = hip_mesh(a)
+    b += a
+    c = 2.0 * a - b * 0.5 + a
+    assert isinstance(c, hip_mesh) and c.shape == (4, 8)
+    assert np.all(c.get() == 2.0 * 1.5 - 3.0 * 0.5 + 1.5)
+    assert abs(c) == 3.0 and isinstance(abs(c), float)
+    assert np.all(a.get() == 1.5)          # copy constructor is deep (mesh.py:36-38)
+    a[:] = np.arange(32.0).reshape(4, 8)
+    assert a.flatten().shape == (32,) and np.array_equal(np.asarray(a), np.arange(32.0).reshape(4, 8))
+    with pytest.raises(TypeError):
+        import pickle
+
+        pickle.dumps(a)
+
+
+def test_level_views_and_errors():
+    from pysdc_amd.level import Step
+    from pysdc_amd.problems import heatNd_unforced
+    from pysdc_amd.sweepers import generic_implicit
+    from pysdc_amd.errors import ProblemError, ParameterError
+
+    desc = dict(problem_class=heatNd_unforced, problem_params=dict(nvars=(16, 16), nu=0.1, freq=2),
+                sweeper_class=generic_implicit, sweeper_params=dict(num_nodes=3, quad_type='RADAU-RIGHT'),
+                level_params=dict(dt=0.01), step_params=dict(maxiter=5))
+    S = Step(desc)
+    L = S.levels[0]
+    assert L.u[0] is None and L.uend is None and L.tau[0] is None
+    with pytest.raises(AssertionError):
+        L.status.unlocked = False
+        L.u[0] = L.prob.u_exact(0.0)
+        for m in range(1, 4):
+            L.u[m] = L.u[0]
+            L.f[m] = L.prob.eval_f(L.u[0], 0.0)
+        L.sweep.update_nodes()             # assert L.status.unlocked (generic_implicit.py:63)
+    L.status.time = 0.0
+    L.sweep.predict()
+    r0 = None
+    L.sweep.compute_residual()
+    r0 = L.status.residual
+    L.u[2] += L.u[1]                        # in-place write through a view invalidates the cached residual
+    L.sweep.compute_residual()
+    assert L.status.residual != r0
+    L.params.residual_type = 'nonsense'
+    with pytest.raises(ParameterError):
+        L.sweep.compute_residual()
+    with pytest.raises(ProblemError):
+        heatNd_unforced(nvars=(16, 8))
+    with pytest.raises(ProblemError):
+        heatNd_unforced(nvars=(15, 15))
+    with pytest.raises(ProblemError):
+        heatNd_unforced(nvars=16, freq=3)
+    with pytest.raises(ProblemError):
+        heatNd_unforced(nvars=(4, 4, 4, 4))
+    with pytest.raises(ParameterError):
+        generic_implicit(dict(quad_type='RADAU-RIGHT'), None)
+
+
+def test_device_init_field_matches_host():
+    import ctypes as C
+    from pysdc_amd.engine import SweepEngine
+    from pysdc_amd import lib as Lb
+    from pysdc_amd.synth import init_field
+
+    for nv in ((64,), (16, 16), (8, 8, 8)):
+        e = SweepEngine(nv, 2)
+        freq = (C.c_int * 3)(2, 4, 2)
+        Lb.check(e.lib.sdc_init_field(e.ctx, e.ptr(Lb.SLOT_U, 0), freq, 1e-3, 7), e.ctx)
+        host = init_field(nv, (2, 4, 2)[: len(nv)], 1e-3, 7)
+        assert np.max(np.abs(e.download(Lb.SLOT_U, 0) - host)) < 1e-14
+        e.close()
