@@ -155,10 +155,27 @@ DEVI void fft_butterflies(cd (&r)[fft_elems(N)], int j, const cd* __restrict__ t
 #pragma unroll
         for (int t = 0; t < R; ++t) x[t] = r[q + t * NB];
         if constexpr (NS > 1) {
+            // w^t, t = 1..R-1, from ONE table load: powers by squaring / products of depth <= 4, so the
+            // rounding error stays at a few ulp while R-2 dependent L1/L2 look-ups disappear
             const int k = (j + q * P) & (NS - 1);
             constexpr int step = N / (NS * R);
+            const cd w1 = tw_dir<DIR>(tw[k * step]);
+            x[1] = cmul(x[1], w1);
+            if constexpr (R > 2) {
+                const cd w2 = cmul(w1, w1);
+                cd run[4] = {cmul(w2, w2), w1, w2, cmul(w2, w1)};  // w^4, w^1, w^2, w^3
+                x[2] = cmul(x[2], run[2]);
+                x[3] = cmul(x[3], run[3]);
+                if constexpr (R > 4) {
+                    const cd w4 = run[0];
+                    x[4] = cmul(x[4], w4);
 #pragma unroll
-            for (int t = 1; t < R; ++t) x[t] = cmul(x[t], tw_dir<DIR>(tw[t * k * step]));
+                    for (int t = 5; t < R; ++t) {  // w^t = w^(t-4) * w^4: four short chains, five live powers
+                        run[t & 3] = cmul(run[t & 3], w4);
+                        x[t] = cmul(x[t], run[t & 3]);
+                    }
+                }
+            }
         }
         dft<R, DIR>(x);
 #pragma unroll
@@ -166,8 +183,21 @@ DEVI void fft_butterflies(cd (&r)[fft_elems(N)], int j, const cd* __restrict__ t
     }
 }
 
+// block-wide barrier, or - when every column lives inside one wavefront - only a compiler-level fence: the
+// lanes of a wave run in lock step and the LDS serves one wave's requests in order
+template <bool WAVE>
+DEVI void fft_sync() {
+    if constexpr (WAVE) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
+
 // scatter the stage output through LDS and read back the strided set of the next stage
-template <int N, int R, int NS, class LAY>
+template <int N, int R, int NS, class LAY, bool WAVE = false>
 DEVI void fft_exchange(cd (&r)[fft_elems(N)], int j, int col, double* lds) {
     constexpr int E = fft_elems(N), P = N / E, NB = E / R;
 #pragma unroll
@@ -181,31 +211,32 @@ DEVI void fft_exchange(cd (&r)[fft_elems(N)], int j, int col, double* lds) {
             for (int t = 0; t < R; ++t)
                 lds[LAY::idx(col, base + t * NS)] = part == 0 ? r[q + t * NB].x : r[q + t * NB].y;
         }
-        __syncthreads();
+        fft_sync<WAVE>();
 #pragma unroll
         for (int i = 0; i < E; ++i) {
             const double v = lds[LAY::idx(col, j + i * P)];
             if (part == 0) r[i].x = v;
             else r[i].y = v;
         }
-        __syncthreads();
+        fft_sync<WAVE>();
     }
 }
 
-template <int N, int NS, int DIR, class LAY>
+template <int N, int NS, int DIR, class LAY, bool WAVE>
 DEVI void fft_stages(cd (&r)[fft_elems(N)], int j, int col, double* lds, const cd* __restrict__ tw) {
     constexpr int REM = N / NS;
     constexpr int R = REM >= 16 ? 16 : REM;
     fft_butterflies<N, R, NS, DIR>(r, j, tw);
     if constexpr (NS * R < N) {
-        fft_exchange<N, R, NS, LAY>(r, j, col, lds);
-        fft_stages<N, NS * R, DIR, LAY>(r, j, col, lds, tw);
+        fft_exchange<N, R, NS, LAY, WAVE>(r, j, col, lds);
+        fft_stages<N, NS * R, DIR, LAY, WAVE>(r, j, col, lds, tw);
     }
 }
 
 // Full length-N transform of the line held as r[i] <-> index j + i*P; result in the same arrangement.
-// All threads of the block must call this (it contains barriers when N > 16).
-template <int N, int DIR, class LAY>
+// All threads of the block must call this (it contains barriers when N > 16).  WAVE = true: the P threads
+// of a column sit in ONE wavefront (P <= 64, columns wave-aligned), so no block barrier is needed.
+template <int N, int DIR, class LAY, bool WAVE = false>
 DEVI void fft_line(cd (&r)[fft_elems(N)], int j, int col, double* lds, const cd* __restrict__ tw) {
-    fft_stages<N, 1, DIR, LAY>(r, j, col, lds, tw);
+    fft_stages<N, 1, DIR, LAY, WAVE>(r, j, col, lds, tw);
 }

@@ -342,6 +342,142 @@ __global__ __launch_bounds__(256) void k_stencil(StencilArgs a) {
     }
 }
 
+// 3-D fast path for 3-point stencils (offsets -1, 0, 1 per axis): 2.5-D blocking.  A workgroup owns a
+// (TY x TZ) tile of the y-z plane and marches along x; the x neighbours stay in registers, the y/z neighbours
+// of the current plane come from a double-buffered LDS tile with halo, so every input word is read from
+// global memory once per tile (+ halo) instead of seven times.
+struct Stencil3Args {
+    const double* in[MAXM];
+    double* outI[MAXM];
+    double* outE[MAXM];
+    double wI[3], wE[3];  // weights for offsets -1, 0, +1
+    int n, xchunk;
+};
+
+template <int RPT>
+__global__ __launch_bounds__(256) void k_stencil3d(Stencil3Args a) {
+    constexpr int TZ = 64, TYB = 8, TY = TYB * RPT, LW = TZ + 4;  // LDS row: [halo | 64 | halo | pad]
+    __shared__ double tile[2][TY + 2][LW];
+    const int n = a.n;
+    const int tz = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int ntz = n / TZ;
+    const int z0 = (blockIdx.x % ntz) * TZ, y0 = (blockIdx.x / ntz) * TY;
+    const int x0 = blockIdx.y * a.xchunk;
+    const int f = blockIdx.z;
+    const double* __restrict__ u = a.in[f];
+    double* __restrict__ oI = a.outI[f];
+    double* __restrict__ oE = a.outE[f];
+    const size_t sx = (size_t)n * n;
+    // halo duty of this thread: 0..63 -> y halo rows (below / above), 64..64+2*TY-1 -> z halo columns
+    const int t = threadIdx.x;
+    const bool hy = t < 64, hz = t >= 64 && t < 64 + 2 * TY;
+    size_t hoff = 0;   // offset of the halo element(s) within a plane
+    int hrow = 0, hcol = 0;
+    if (hy) {
+        const int side = t >> 5, pz = t & 31;
+        const int yy = side == 0 ? (y0 == 0 ? n - 1 : y0 - 1) : (y0 + TY == n ? 0 : y0 + TY);
+        hoff = (size_t)yy * n + z0 + 2 * pz;
+        hrow = side == 0 ? 0 : TY + 1;
+        hcol = 1 + 2 * pz;
+    } else if (hz) {
+        const int q = t - 64, side = q / TY, r = q % TY;
+        const int zz = side == 0 ? (z0 == 0 ? n - 1 : z0 - 1) : (z0 + TZ == n ? 0 : z0 + TZ);
+        hoff = (size_t)(y0 + r) * n + zz;
+        hrow = r + 1;
+        hcol = side == 0 ? 0 : TZ + 1;
+    }
+    size_t off[RPT];
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) off[r] = (size_t)(y0 + ty + r * TYB) * n + z0 + 2 * tz;
+
+    auto plane = [&](int x) { return u + (size_t)(x < 0 ? x + n : (x >= n ? x - n : x)) * sx; };
+    double2 prev[RPT], cur[RPT], nxt[RPT];
+    double2 hcur = double2{0.0, 0.0}, hnxt = double2{0.0, 0.0};
+    {
+        const double* pm = plane(x0 - 1);
+        const double* p0 = plane(x0);
+        const double* p1 = plane(x0 + 1);
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            prev[r] = *reinterpret_cast<const double2*>(pm + off[r]);
+            cur[r] = *reinterpret_cast<const double2*>(p0 + off[r]);
+            nxt[r] = *reinterpret_cast<const double2*>(p1 + off[r]);
+        }
+        if (hy) {
+            hcur = *reinterpret_cast<const double2*>(p0 + hoff);
+            hnxt = *reinterpret_cast<const double2*>(p1 + hoff);
+        } else if (hz) {
+            hcur.x = p0[hoff];
+            hnxt.x = p1[hoff];
+        }
+    }
+    auto put = [&](int b, const double2 (&v)[RPT], double2 h) {
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            tile[b][ty + r * TYB + 1][1 + 2 * tz] = v[r].x;
+            tile[b][ty + r * TYB + 1][2 + 2 * tz] = v[r].y;
+        }
+        if (hy) {
+            tile[b][hrow][hcol] = h.x;
+            tile[b][hrow][hcol + 1] = h.y;
+        } else if (hz) {
+            tile[b][hrow][hcol] = h.x;
+        }
+    };
+    put(0, cur, hcur);
+    const double cI = 3.0 * a.wI[1], cE = 3.0 * a.wE[1];
+    for (int p = 0; p < a.xchunk; ++p) {
+        const int b = p & 1;
+        const int x = x0 + p;
+        __syncthreads();
+        // prefetch plane x+2 (interior + halo) while computing plane x
+        double2 nn[RPT];
+        double2 hnn = double2{0.0, 0.0};
+        const bool more = p + 1 < a.xchunk;
+        if (more) {
+            const double* p2 = plane(x + 2);
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) nn[r] = *reinterpret_cast<const double2*>(p2 + off[r]);
+            if (hy) hnn = *reinterpret_cast<const double2*>(p2 + hoff);
+            else if (hz) hnn.x = p2[hoff];
+        }
+        const size_t po = (size_t)x * sx;
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            const int row = ty + r * TYB + 1, col = 1 + 2 * tz;
+            const double ym0 = tile[b][row - 1][col], ym1 = tile[b][row - 1][col + 1];
+            const double yp0 = tile[b][row + 1][col], yp1 = tile[b][row + 1][col + 1];
+            const double zm = tile[b][row][col - 1], zp = tile[b][row][col + 2];
+            const double c0 = cur[r].x, c1 = cur[r].y;
+            // same association as the row sums of the Kronecker-sum matrix: per axis (w-,w0,w+), axes added
+            double2 res;
+            res.x = (a.wI[0] * prev[r].x + a.wI[2] * nxt[r].x) + (a.wI[0] * ym0 + a.wI[2] * yp0) +
+                    (a.wI[0] * zm + a.wI[2] * c1) + cI * c0;
+            res.y = (a.wI[0] * prev[r].y + a.wI[2] * nxt[r].y) + (a.wI[0] * ym1 + a.wI[2] * yp1) +
+                    (a.wI[0] * c0 + a.wI[2] * zp) + cI * c1;
+            if (oI) *reinterpret_cast<double2*>(oI + po + off[r]) = res;
+            if (oE) {
+                double2 re;
+                re.x = (a.wE[0] * prev[r].x + a.wE[2] * nxt[r].x) + (a.wE[0] * ym0 + a.wE[2] * yp0) +
+                       (a.wE[0] * zm + a.wE[2] * c1) + cE * c0;
+                re.y = (a.wE[0] * prev[r].y + a.wE[2] * nxt[r].y) + (a.wE[0] * ym1 + a.wE[2] * yp1) +
+                       (a.wE[0] * c0 + a.wE[2] * zp) + cE * c1;
+                *reinterpret_cast<double2*>(oE + po + off[r]) = re;
+            }
+        }
+        if (more) {
+            put(b ^ 1, nxt, hnxt);
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                prev[r] = cur[r];
+                cur[r] = nxt[r];
+                nxt[r] = nn[r];
+            }
+            hnxt = hnn;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // FFT kernels
 // ------------------------------------------------------------------------------------------------------
@@ -534,7 +670,8 @@ __global__ __launch_bounds__(z_lines_per_block<N>() * (N / fft_elems(N)) * MAXM,
     cd r[E];
 #pragma unroll
     for (int i = 0; i < E; ++i) r[i] = ok ? Wl[j + i * P] : cd{0.0, 0.0};
-    fft_line<N, -1, LAY>(r, j, c, lds, a.tw);
+    fft_line<N, -1, LAY, true>(r, j, c, lds, a.tw);
+    __syncthreads();  // the solve buffer aliases other waves' exchange planes
 
     cd* buf = reinterpret_cast<cd*>(lds);  // [column][CH]
     const int nthreads = a.nf * LPB * P;
@@ -585,7 +722,7 @@ __global__ __launch_bounds__(z_lines_per_block<N>() * (N / fft_elems(N)) * MAXM,
     // through the whole kernel for reuse in the inverse
     int j2 = j;
     asm volatile("" : "+v"(j2));
-    fft_line<N, +1, LAY>(r, j2, c, lds, a.tw);
+    fft_line<N, +1, LAY, true>(r, j2, c, lds, a.tw);
     if (ok) {
 #pragma unroll
         for (int i = 0; i < E; ++i) Wl[j2 + i * P] = r[i];
@@ -781,6 +918,30 @@ static int run_stencil(sdc_ctx* c, int nf, const double* const* in, double* cons
         a.g[f] = g ? g[f] : 0.0;
     }
     LaunchTimer lt(c, "stencil");
+    // 3-D fast path: both operators (when present) are 3-point stencils with offsets -1, 0, +1
+    auto three = [](const Stencil& s) { return s.npts == 3 && s.off[0] == -1 && s.off[1] == 0 && s.off[2] == 1; };
+    const bool needE = c->expl_kind == SDC_EXPL_STENCIL && outE != nullptr;
+    constexpr int RPT = 4;
+    if (c->ndim == 3 && c->n % 64 == 0 && c->n % (8 * RPT) == 0 && outI && three(c->st[0]) &&
+        (!needE || three(c->st[1])) && c->expl_kind != SDC_EXPL_FORCING) {
+        Stencil3Args s3;
+        memset(&s3, 0, sizeof s3);
+        for (int f = 0; f < nf; ++f) {
+            s3.in[f] = in[f];
+            s3.outI[f] = outI[f];
+            s3.outE[f] = needE ? outE[f] : nullptr;
+        }
+        for (int k = 0; k < 3; ++k) {
+            s3.wI[k] = c->st[0].w[k];
+            s3.wE[k] = needE ? c->st[1].w[k] : 0.0;
+        }
+        s3.n = c->n;
+        s3.xchunk = c->n >= 32 ? 32 : c->n;
+        const int tiles = (c->n / 64) * (c->n / (8 * RPT));
+        hipLaunchKernelGGL((k_stencil3d<RPT>), dim3(tiles, c->n / s3.xchunk, nf), dim3(256), 0, c->stream, s3);
+        HIPCHK(c, hipGetLastError());
+        return SDC_OK;
+    }
     hipLaunchKernelGGL(k_stencil, dim3(grid_for(c->N / 2, 256), nf), dim3(256), 0, c->stream, a);
     HIPCHK(c, hipGetLastError());
     return SDC_OK;

@@ -53,7 +53,8 @@ def test_run_vs_golden(name, fused):
     np.testing.assert_allclose([t for t, _ in niter], case['niter_t'], rtol=0, atol=1e-14)
     assert rel_err(uend.get(), case['uend']) < TOL
     res = [v for _, v in get_sorted(stats, type='residual_post_iteration', sortby='time')]
-    np.testing.assert_allclose(res, case['res'], rtol=1e-6, atol=1e-13)
+    # residuals are differences of O(|u|) quantities: below ~1e-11 |u| they are rounding noise in both codes
+    np.testing.assert_allclose(res, case['res'], rtol=1e-6, atol=1e-11 * max(1.0, float(np.max(np.abs(case['u0'])))))
 
 
 def test_datatype_semantics():
