@@ -22,23 +22,28 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICRO
 
 def kernel_bytes(name, n, M, ncomp=1):
     """ALGORITHMIC bytes of one launch of each kernel of the sweep (DESIGN.md 'kernels'): fields read + written
-    once, f64; spectra have (n/2+1)/n * 2 words per real word."""
+    once, f64; one half spectrum = (n/2+1) n^2 complex.  Names carry the number of fields, e.g. fft_x_fwd[5]."""
     N = n**3
     field = 8.0 * N
     spec = 16.0 * (n // 2 + 1) * n * n
+    base, nf = name, M
+    if '[' in name:
+        base, nf = name[:name.index('[')], int(name[name.index('[') + 1:-1])
     table = {
         'gather': (1 + M * ncomp + M) * field,          # u0 + F[1..M] -> R[1..M]
-        'fft_x_fwd': M * (field + spec),                # real tiles in, half spectra out
-        'fft_y_fwd': 2 * M * spec,
-        'fft_z_solve': 2 * M * spec,
-        'fft_y_inv': 2 * M * spec,
-        'fft_x_inv': M * (field + spec),
-        'stencil': 2 * M * field * ncomp if ncomp == 1 else M * field * 3,
+        'fft_x_fwd': nf * (field + spec),               # real tiles in, half spectra out
+        'fft_y_fwd': 2 * nf * spec,
+        'fft_z_fwd': 2 * nf * spec,
+        'fft_z_solve': 2 * nf * spec,
+        'spec_z_sweep': (1 + nf) * spec + 2 * nf * spec,  # S0 + S[1..M] in; S[1..M] and W[1..M] out
+        'fft_y_inv': 2 * nf * spec,
+        'fft_x_inv': nf * (field + spec),
+        'stencil': 2 * nf * field * ncomp if ncomp == 1 else nf * field * 3,
         'residual': (1 + M * ncomp + M) * field,        # u0, F[1..M], U[1..M] -> M norms
         'spread': (2 + 2 * M) * field,
         'copy': 2 * field,
     }
-    return table.get(name)
+    return table.get(base)
 
 
 def cpu_baseline(M, dt_ref_n, sample_n=64, target_n=1024, nsweeps=4):
@@ -86,6 +91,8 @@ def main():
     ap.add_argument('--sweeps', type=int, default=4)
     ap.add_argument('--qi', default='IE')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-spectral-reuse', action='store_true',
+                    help='transform the gathered fields in every sweep instead of gathering on cached transforms')
     args = ap.parse_args()
 
     import numpy as np
@@ -124,6 +131,7 @@ def main():
         step = ctrl.S
     L = step.levels[0]
     eng = L.engine  # allocates the device slabs
+    eng.set_spectral_reuse(not args.no_spectral_reuse)
     # synthetic input on the device: sin mode (freq 2) + 1e-3 * seeded noise
     u0 = L.prob.u_init
     freq = (C.c_int * 3)(2, 2, 2)
@@ -168,15 +176,15 @@ def main():
             traffic = None
             tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
             if os.path.exists(tfile):
-                tr = json.load(open(tfile)).get(f'{dom[0]}@{n}')
+                tr = json.load(open(tfile)).get(f'{dom[0].split("[")[0]}@{n}')
                 traffic = tr
             roof = {'kernel': dom[0], 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                     'frac': ach / HBM_PEAK_GBS, 'traffic': traffic,
                     'algorithmic_bytes_per_launch': kernel_bytes(dom[0], n, M),
                     'ms_per_launch': dom[1][0] / dom[1][1]}
-        sweep_ms = sum(v[0] for k, v in prof.items()
-                       if k in ('gather', 'fft_x_fwd', 'fft_y_fwd', 'fft_z_solve', 'fft_y_inv', 'fft_x_inv', 'stencil')
-                       ) / max(1, sweeps_total // world)
+        in_sweep = ('gather', 'fft_x_fwd', 'fft_y_fwd', 'fft_z_fwd', 'fft_z_solve', 'spec_z_sweep', 'fft_y_inv',
+                    'fft_x_inv', 'stencil')
+        sweep_ms = sum(v[0] for k, v in prof.items() if k.split('[')[0] in in_sweep) / max(1, sweeps_total // world)
         out = {
             'metric': 'time-steps/s (HeatND 3-D FD, M=5, implicit SDC sweeps)', 'value': steps_total / el,
             'unit': 'time-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -184,7 +192,7 @@ def main():
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': f'heatNd_unforced {n}^3 periodic order-2 FD, nu=0.1, M={M} LEGENDRE RADAU-RIGHT, '
                                    f'QI={args.qi}, generic_implicit, {K} sweeps/step (restol=-1, maxiter={K}), '
-                                   f'dt={dt:g}, solver=direct (Fourier)',
+                                   f'dt={dt:g}, solver=direct (Fourier), spectral_reuse={not args.no_spectral_reuse}',
                        'time_parallel': f'{world} time-slice(s), one per GPU, multi-step SDC (Jacobi)'},
             'sdc_iters_per_s': sweeps_total / el,
             'sweep_kernels_ms': sweep_ms,

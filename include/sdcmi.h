@@ -74,6 +74,13 @@ void* sdc_slot_ptr(sdc_ctx* ctx, int slot, int m, int comp);
 int sdc_upload(sdc_ctx* ctx, int slot, int m, int comp, const double* host);
 int sdc_download(sdc_ctx* ctx, int slot, int m, int comp, double* host);
 int sdc_set_tau_active(sdc_ctx* ctx, int active); /* L.tau[m] is None  <->  0 */
+/* Spectral reuse: for linear right-hand sides the engine keeps the Fourier transforms of U[0] and
+ * of U[1..M] between sweeps and gathers on them instead of re-transforming M fields every sweep.  Anything
+ * that writes a U field behind the engine's back (datatype operations on slab views, RCCL receives) must say
+ * so: which = 1: U[0] changed, 2: some U[m >= 1] changed, 4: some F[m >= 1] was overwritten (the next sweep then
+ * gathers on the F slab like the reference does); bits combine.  sdc_upload / sdc_predict do it themselves. */
+int sdc_invalidate_spectra(sdc_ctx* ctx, int which);
+int sdc_set_spectral_reuse(sdc_ctx* ctx, int on); /* default on; 0 = transform the gathered fields every sweep */
 /* Synthetic input generated on the device (no multi-GB host arrays): dst[i] = prod_d sin(pi*freq[d]*x_d) on
  * the grid of generic_ND_FD.py:171-180 (the u_exact(0) of HeatEquation_ND_FD.py:103-132) + amp * g(i), g a
  * standard normal from splitmix64(seed, i) + Box-Muller; host equivalent: pysdc_amd.synth.init_field. */

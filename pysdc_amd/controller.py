@@ -374,7 +374,7 @@ class controller_dist(_ControllerBase):
                 self.req_send.wait()
                 self.req_send = None
         if do_recv:
-            L._touched()
+            L._touched(0, 0)  # u[0] was overwritten by the receive
             L.f[0] = L.prob.eval_f(L.u[0], L.time)
         self._hook('post_comm', S, level)
 

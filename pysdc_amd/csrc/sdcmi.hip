@@ -46,6 +46,8 @@ struct sdc_ctx {
     hipStream_t stream = nullptr;
     double *U = nullptr, *F = nullptr, *TAU = nullptr, *UEND = nullptr, *profile = nullptr;
     cd* W = nullptr;
+    cd *S = nullptr, *S0 = nullptr;  // spectral cache: transforms of U[1..M] and of U[0] (lazy)
+    bool spec_valid = false, spec0_valid = false, spec_spread = false, reuse = true, force_gather = false;
     cd *tw = nullptr, *lamI = nullptr, *lamE = nullptr;
     unsigned long long* red = nullptr;  // reduction slots (device)
     unsigned long long* red_host = nullptr;
@@ -126,6 +128,29 @@ struct LaunchTimer {
 };
 
 static inline int is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
+
+// profile names that carry the number of fields of the launch, e.g. "fft_x_fwd[5]" (interned, static lifetime)
+static const char* pname(const char* base, int nf) {
+    static std::map<std::string, std::string> table;
+    std::string key = std::string(base) + "[" + std::to_string(nf) + "]";
+    auto it = table.find(key);
+    if (it == table.end()) it = table.emplace(key, key).first;
+    return it->second.c_str();
+}
+
+// 1/(1 - alpha*lambda): |denominator|^2 is finite and away from zero for the dissipative / skew operators
+// handled here, so the reciprocal is v_rcp_f64 refined by two Newton steps (~1 ulp) instead of the IEEE
+// division sequence (v_div_scale / v_div_fmas / v_div_fixup).
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ cd cinv_fast(cd d) {
+    const double m = fast_rcp(d.x * d.x + d.y * d.y);
+    return cd{d.x * m, -d.y * m};
+}
 
 // ------------------------------------------------------------------------------------------------------
 // elementwise kernels
@@ -351,8 +376,14 @@ struct Stencil3Args {
     double* outI[MAXM];
     double* outE[MAXM];
     double wI[3], wE[3];  // weights for offsets -1, 0, +1
-    int n, xchunk;
+    int n, xchunk, ntiles, nchunks;
 };
+
+// Workgroup b runs on XCD b % 8 (observed dispatch order; used for speed only): give every XCD a contiguous
+// range of the logical grid so that tiles sharing halo lines meet in the same L2.
+__device__ __forceinline__ unsigned xcd_swizzle(unsigned b, unsigned total) {
+    return (total & 7u) ? b : (b & 7u) * (total >> 3) + (b >> 3);
+}
 
 template <int RPT>
 __global__ __launch_bounds__(256) void k_stencil3d(Stencil3Args a) {
@@ -361,9 +392,17 @@ __global__ __launch_bounds__(256) void k_stencil3d(Stencil3Args a) {
     const int n = a.n;
     const int tz = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int ntz = n / TZ;
-    const int z0 = (blockIdx.x % ntz) * TZ, y0 = (blockIdx.x / ntz) * TY;
-    const int x0 = blockIdx.y * a.xchunk;
-    const int f = blockIdx.z;
+    // logical order: z-tile fastest, then y-tile (halo partners stay close), then x-chunk, then field
+    unsigned lb = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int zt = lb % ntz;
+    lb /= ntz;
+    const int nty = n / TY;
+    const int yt = lb % nty;
+    lb /= nty;
+    const int chunk = lb % a.nchunks;
+    const int f = lb / a.nchunks;
+    const int z0 = zt * TZ, y0 = yt * TY;
+    const int x0 = chunk * a.xchunk;
     const double* __restrict__ u = a.in[f];
     double* __restrict__ oI = a.outI[f];
     double* __restrict__ oE = a.outE[f];
@@ -687,12 +726,13 @@ __global__ __launch_bounds__(z_lines_per_block<N>() * (N / fft_elems(N)) * MAXM,
             cd lam = a.lamI[kz], mu = cd{0.0, 0.0};
             if (a.lamE) mu = a.lamE[kz];
             if (a.ndim == 3) {
-                const int kx = (int)(ln / N), ky = (int)(ln % N);
+                const int kx = (int)(ln / N) % (N / 2 + 1), ky = (int)(ln % N);
                 lam = cadd(lam, cadd(a.lamI[kx], a.lamI[ky]));
                 if (a.lamE) mu = cadd(mu, cadd(a.lamE[kx], a.lamE[ky]));
             } else if (a.ndim == 2) {
-                lam = cadd(lam, a.lamI[ln]);
-                if (a.lamE) mu = cadd(mu, a.lamE[ln]);
+                const int kx = (int)(ln % (N / 2 + 1));
+                lam = cadd(lam, a.lamI[kx]);
+                if (a.lamE) mu = cadd(mu, a.lamE[kx]);
             }
             cd u[MAXM];
 #pragma unroll
@@ -708,7 +748,7 @@ __global__ __launch_bounds__(z_lines_per_block<N>() * (N / fft_elems(N)) * MAXM,
                         }
                     }
                     const double al = a.alpha[m];
-                    u[m] = cmul(acc, cinv(cd{1.0 - al * lam.x, -al * lam.y}));
+                    u[m] = cmul(acc, cinv_fast(cd{1.0 - al * lam.x, -al * lam.y}));
                     buf[(m * LPB + ll) * CH + kk] = cscale(u[m], a.invN);
                 }
             }
@@ -726,6 +766,123 @@ __global__ __launch_bounds__(z_lines_per_block<N>() * (N / fft_elems(N)) * MAXM,
     if (ok) {
 #pragma unroll
         for (int i = 0; i < E; ++i) Wl[j2 + i * P] = r[i];
+    }
+}
+
+// plain forward transform along the contiguous axis, in place (used to bring u0 / node values into the
+// fully transformed domain of the spectral cache)
+template <int N>
+__global__ __launch_bounds__(z_lines_per_block<N>() * (N / fft_elems(N)) * MAXM, 3) void k_fftz_fwd(cd* __restrict__ W, size_t fstride,
+                                                                                                    const cd* __restrict__ tw,
+                                                                                                    unsigned nlines) {
+    constexpr int E = fft_elems(N), P = N / E, LPB = z_lines_per_block<N>();
+    using LAY = LayContig<N>;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int c = threadIdx.x / P, j = threadIdx.x % P;
+    const int f = c / LPB, l = c % LPB;
+    const size_t line = (size_t)blockIdx.x * LPB + l;
+    const bool ok = line < nlines;
+    cd* __restrict__ Wl = W + f * fstride + line * N;
+    cd r[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i) r[i] = ok ? Wl[j + i * P] : cd{0.0, 0.0};
+    fft_line<N, -1, LAY, true>(r, j, c, lds, tw);
+    if (ok) {
+#pragma unroll
+        for (int i = 0; i < E; ++i) Wl[j + i * P] = r[i];
+    }
+}
+
+// Sweep in the transformed domain (DESIGN.md "spectral reuse").  For linear f(u) = A u (+ B u) the gathered
+// right-hand side of node m is  u0 + dt sum_j (Q-QI)[m][j] A u_j^k (+ explicit part): its transform follows
+// from the transforms of u0 and of the previous iterate, which the previous sweep left in S.  One launch
+// reads S0 and S[0..nf), applies gather + node-coupled solve per mode, writes the new spectra back to S and
+// their inverse transform along the contiguous axis to W (input of the inverse y / x passes).
+struct SpecArgs {
+    cd* S;
+    size_t fstride;
+    const cd* S0;
+    cd* W;
+    const cd *tw, *lamI, *lamE;
+    double gI[MAXM][MAXM], gE[MAXM][MAXM];  // dt (Q - QI), dt (Q - QE), inner MxM blocks
+    double cI[MAXM][MAXM], cE[MAXM][MAXM], alpha[MAXM];
+    double invN;
+    int nf, ndim, coupled, spread;
+};
+
+template <int N>
+__global__ __launch_bounds__(z_lines_per_block<N>() * (N / fft_elems(N)) * MAXM, 3) void k_specz_sweep(SpecArgs a, unsigned nlines) {
+    constexpr int E = fft_elems(N), P = N / E, LPB = z_lines_per_block<N>();
+    constexpr int NCH = E == 16 ? 2 : 1;
+    constexpr int CH = N / NCH, ECH = E / NCH;
+    using LAY = LayContig<N>;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int c = threadIdx.x / P, j = threadIdx.x % P;
+    const int f = c / LPB, l = c % LPB;
+    const size_t line = (size_t)blockIdx.x * LPB + l;
+    const bool ok = line < nlines;
+    cd* buf = reinterpret_cast<cd*>(lds);
+    const int nthreads = a.nf * LPB * P;
+    cd r[E];
+#pragma unroll
+    for (int ph = 0; ph < NCH; ++ph) {
+        for (int item = threadIdx.x; item < LPB * CH; item += nthreads) {
+            const int ll = item / CH, kk = item % CH;
+            const size_t ln = (size_t)blockIdx.x * LPB + ll;
+            const int kz = ph * CH + kk;
+            const bool lok = ln < nlines;
+            const size_t g = ln * N + kz;
+            cd lam = a.lamI[kz], mu = cd{0.0, 0.0};
+            if (a.lamE) mu = a.lamE[kz];
+            if (a.ndim == 3) {
+                const int kx = (int)(ln / N) % (N / 2 + 1), ky = (int)(ln % N);
+                lam = cadd(lam, cadd(a.lamI[kx], a.lamI[ky]));
+                if (a.lamE) mu = cadd(mu, cadd(a.lamE[kx], a.lamE[ky]));
+            } else if (a.ndim == 2) {
+                const int kx = (int)(ln % (N / 2 + 1));
+                lam = cadd(lam, a.lamI[kx]);
+                if (a.lamE) mu = cadd(mu, a.lamE[kx]);
+            }
+            const cd u0h = lok ? a.S0[g] : cd{0.0, 0.0};
+            cd old[MAXM], u[MAXM];
+#pragma unroll
+            for (int q = 0; q < MAXM; ++q)
+                if (q < a.nf) old[q] = (a.spread || !lok) ? u0h : a.S[q * a.fstride + g];
+#pragma unroll
+            for (int m = 0; m < MAXM; ++m) {
+                if (m < a.nf) {
+                    cd acc = u0h;
+#pragma unroll
+                    for (int q = 0; q < MAXM; ++q) {
+                        if (q < a.nf) {
+                            const double gi = a.gI[m][q], ge = a.gE[m][q];
+                            acc = cfma(cd{gi * lam.x + ge * mu.x, gi * lam.y + ge * mu.y}, old[q], acc);
+                        }
+                    }
+                    if (a.coupled) {
+#pragma unroll
+                        for (int q = 0; q < m; ++q) {
+                            const double ci = a.cI[m][q], ce = a.cE[m][q];
+                            acc = cfma(cd{ci * lam.x + ce * mu.x, ci * lam.y + ce * mu.y}, u[q], acc);
+                        }
+                    }
+                    const double al = a.alpha[m];
+                    u[m] = cmul(acc, cinv_fast(cd{1.0 - al * lam.x, -al * lam.y}));
+                    if (lok) a.S[m * a.fstride + g] = u[m];
+                    buf[(m * LPB + ll) * CH + kk] = cscale(u[m], a.invN);
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < ECH; ++i) r[ph * ECH + i] = buf[c * CH + j + i * P];
+        __syncthreads();
+    }
+    fft_line<N, +1, LAY, true>(r, j, c, lds, a.tw);
+    if (ok) {
+        cd* __restrict__ Wl = a.W + f * a.fstride + line * N;
+#pragma unroll
+        for (int i = 0; i < E; ++i) Wl[j + i * P] = r[i];
     }
 }
 
@@ -917,7 +1074,7 @@ static int run_stencil(sdc_ctx* c, int nf, const double* const* in, double* cons
         a.outE[f] = (outE && c->expl_kind != SDC_EXPL_NONE) ? outE[f] : nullptr;
         a.g[f] = g ? g[f] : 0.0;
     }
-    LaunchTimer lt(c, "stencil");
+    LaunchTimer lt(c, pname("stencil", nf));
     // 3-D fast path: both operators (when present) are 3-point stencils with offsets -1, 0, +1
     auto three = [](const Stencil& s) { return s.npts == 3 && s.off[0] == -1 && s.off[1] == 0 && s.off[2] == 1; };
     const bool needE = c->expl_kind == SDC_EXPL_STENCIL && outE != nullptr;
@@ -936,9 +1093,10 @@ static int run_stencil(sdc_ctx* c, int nf, const double* const* in, double* cons
             s3.wE[k] = needE ? c->st[1].w[k] : 0.0;
         }
         s3.n = c->n;
-        s3.xchunk = c->n >= 32 ? 32 : c->n;
-        const int tiles = (c->n / 64) * (c->n / (8 * RPT));
-        hipLaunchKernelGGL((k_stencil3d<RPT>), dim3(tiles, c->n / s3.xchunk, nf), dim3(256), 0, c->stream, s3);
+        s3.xchunk = c->n >= 64 ? 64 : c->n;
+        s3.nchunks = c->n / s3.xchunk;
+        s3.ntiles = (c->n / 64) * (c->n / (8 * RPT));
+        hipLaunchKernelGGL((k_stencil3d<RPT>), dim3(s3.ntiles * s3.nchunks * nf), dim3(256), 0, c->stream, s3);
         HIPCHK(c, hipGetLastError());
         return SDC_OK;
     }
@@ -962,26 +1120,26 @@ static int fft_pipeline_n(sdc_ctx* c, int nf, const FieldPtrs& p, ZArgs& z) {
     z.invN = 1.0 / (double)c->N;
     size_t lines;
     if (c->ndim == 1) {
-        LaunchTimer lt(c, "promote");
+        LaunchTimer lt(c, pname("promote", nf));
         hipLaunchKernelGGL(k_promote, dim3(grid_for(c->N, 256), nf), dim3(256), 0, c->stream, p, c->W, c->N);
         lines = 1;
     } else {
         const int rest = (int)(c->N / n);
         const int tiles = (rest / 2 + T - 1) / T;
         {
-            LaunchTimer lt(c, "fft_x_fwd");
+            LaunchTimer lt(c, pname("fft_x_fwd", nf));
             hipLaunchKernelGGL((k_fftx_fwd<N, T>), dim3(tiles, nf), dim3(P * T), lds_str, c->stream, p, c->W, c->Nc,
                                rest, c->tw);
         }
         if (c->ndim == 3) {
-            LaunchTimer lt(c, "fft_y_fwd");
+            LaunchTimer lt(c, pname("fft_y_fwd", nf));
             hipLaunchKernelGGL((k_ffty<N, T, -1>), dim3((n + T - 1) / T, n / 2 + 1, nf), dim3(P * T), lds_str,
                                c->stream, c->W, c->Nc, c->tw);
         }
         lines = (size_t)(n / 2 + 1) * (c->ndim == 3 ? n : 1);
     }
     {
-        LaunchTimer lt(c, "fft_z_solve");
+        LaunchTimer lt(c, pname("fft_z_solve", nf));
         constexpr int LPB = z_lines_per_block<N>();
         constexpr int NCH = fft_elems(N) == 16 ? 2 : 1;
         size_t ldsz = (size_t)LayContig<N>::doubles(nf * LPB) * sizeof(double);  // FFT exchange planes
@@ -991,22 +1149,117 @@ static int fft_pipeline_n(sdc_ctx* c, int nf, const FieldPtrs& p, ZArgs& z) {
                            c->stream, z, (unsigned)lines);
     }
     if (c->ndim == 1) {
-        LaunchTimer lt(c, "realpart");
+        LaunchTimer lt(c, pname("realpart", nf));
         hipLaunchKernelGGL(k_realpart, dim3(grid_for(c->N, 256), nf), dim3(256), 0, c->stream, p, c->W, c->N);
     } else {
         const int rest = (int)(c->N / n);
         const int tiles = (rest / 2 + T - 1) / T;
         if (c->ndim == 3) {
-            LaunchTimer lt(c, "fft_y_inv");
+            LaunchTimer lt(c, pname("fft_y_inv", nf));
             hipLaunchKernelGGL((k_ffty<N, T, +1>), dim3((n + T - 1) / T, n / 2 + 1, nf), dim3(P * T), lds_str,
                                c->stream, c->W, c->Nc, c->tw);
         }
-        LaunchTimer lt(c, "fft_x_inv");
+        LaunchTimer lt(c, pname("fft_x_inv", nf));
         hipLaunchKernelGGL((k_fftx_inv<N, T>), dim3(tiles, nf), dim3(P * T), lds_str, c->stream, p, c->W, c->Nc, rest,
                            c->tw);
     }
     HIPCHK(c, hipGetLastError());
     return SDC_OK;
+}
+
+// forward transform of nf real fields into fully transformed spectra dst[f] (dst + f*fstride)
+template <int N>
+static int fwd_transform_n(sdc_ctx* c, int nf, const FieldPtrs& p, cd* dst, size_t fstride) {
+    constexpr int E = fft_elems(N), P = N / E, T = 8, LPB = z_lines_per_block<N>();
+    const size_t lds_str = (size_t)LayStrided<N, T>::doubles(T) * sizeof(double);
+    const int n = c->n;
+    size_t lines;
+    if (c->ndim == 1) {
+        LaunchTimer lt(c, pname("promote", nf));
+        hipLaunchKernelGGL(k_promote, dim3(grid_for(c->N, 256), nf), dim3(256), 0, c->stream, p, dst, c->N);
+        lines = 1;
+    } else {
+        const int rest = (int)(c->N / n);
+        const int tiles = (rest / 2 + T - 1) / T;
+        {
+            LaunchTimer lt(c, pname("fft_x_fwd", nf));
+            hipLaunchKernelGGL((k_fftx_fwd<N, T>), dim3(tiles, nf), dim3(P * T), lds_str, c->stream, p, dst, fstride, rest,
+                               c->tw);
+        }
+        if (c->ndim == 3) {
+            LaunchTimer lt(c, pname("fft_y_fwd", nf));
+            hipLaunchKernelGGL((k_ffty<N, T, -1>), dim3((n + T - 1) / T, n / 2 + 1, nf), dim3(P * T), lds_str, c->stream,
+                               dst, fstride, c->tw);
+        }
+        lines = (size_t)(n / 2 + 1) * (c->ndim == 3 ? n : 1);
+    }
+    LaunchTimer lt(c, pname("fft_z_fwd", nf));
+    const size_t ldsz = (size_t)LayContig<N>::doubles(nf * LPB) * sizeof(double);
+    hipLaunchKernelGGL((k_fftz_fwd<N>), dim3((unsigned)((lines + LPB - 1) / LPB)), dim3(P * LPB * nf), ldsz, c->stream, dst,
+                       fstride, c->tw, (unsigned)lines);
+    HIPCHK(c, hipGetLastError());
+    return SDC_OK;
+}
+
+// spectral sweep + inverse passes into out[f]
+template <int N>
+static int spec_sweep_n(sdc_ctx* c, int nf, SpecArgs& a, const FieldPtrs& p) {
+    constexpr int E = fft_elems(N), P = N / E, T = 8, LPB = z_lines_per_block<N>();
+    constexpr int NCH = E == 16 ? 2 : 1;
+    const size_t lds_str = (size_t)LayStrided<N, T>::doubles(T) * sizeof(double);
+    const int n = c->n;
+    const size_t lines = c->ndim == 1 ? 1 : (size_t)(n / 2 + 1) * (c->ndim == 3 ? n : 1);
+    {
+        LaunchTimer lt(c, pname("spec_z_sweep", nf));
+        size_t ldsz = (size_t)LayContig<N>::doubles(nf * LPB) * sizeof(double);
+        const size_t solve_sz = (size_t)nf * LPB * (N / NCH) * sizeof(cd);
+        if (solve_sz > ldsz) ldsz = solve_sz;
+        hipLaunchKernelGGL((k_specz_sweep<N>), dim3((unsigned)((lines + LPB - 1) / LPB)), dim3(P * LPB * nf), ldsz,
+                           c->stream, a, (unsigned)lines);
+    }
+    if (c->ndim == 1) {
+        LaunchTimer lt(c, pname("realpart", nf));
+        hipLaunchKernelGGL(k_realpart, dim3(grid_for(c->N, 256), nf), dim3(256), 0, c->stream, p, c->W, c->N);
+    } else {
+        const int rest = (int)(c->N / n);
+        const int tiles = (rest / 2 + T - 1) / T;
+        if (c->ndim == 3) {
+            LaunchTimer lt(c, pname("fft_y_inv", nf));
+            hipLaunchKernelGGL((k_ffty<N, T, +1>), dim3((n + T - 1) / T, n / 2 + 1, nf), dim3(P * T), lds_str, c->stream,
+                               c->W, c->Nc, c->tw);
+        }
+        LaunchTimer lt(c, pname("fft_x_inv", nf));
+        hipLaunchKernelGGL((k_fftx_inv<N, T>), dim3(tiles, nf), dim3(P * T), lds_str, c->stream, p, c->W, c->Nc, rest,
+                           c->tw);
+    }
+    HIPCHK(c, hipGetLastError());
+    return SDC_OK;
+}
+
+#define N_DISPATCH(c, CALL)                                                                                 \
+    switch ((c)->n) {                                                                                       \
+        case 2: return CALL(2);                                                                             \
+        case 4: return CALL(4);                                                                             \
+        case 8: return CALL(8);                                                                             \
+        case 16: return CALL(16);                                                                           \
+        case 32: return CALL(32);                                                                           \
+        case 64: return CALL(64);                                                                           \
+        case 128: return CALL(128);                                                                         \
+        case 256: return CALL(256);                                                                         \
+        case 512: return CALL(512);                                                                         \
+        case 1024: return CALL(1024);                                                                       \
+        default: return fail(c, SDC_ERR_UNSUPPORTED, "spectral solve needs n = 2^p <= 1024, got %d", (c)->n); \
+    }
+
+static int fwd_transform(sdc_ctx* c, int nf, const FieldPtrs& p, cd* dst, size_t fstride) {
+#define CALL(NN) fwd_transform_n<NN>(c, nf, p, dst, fstride)
+    N_DISPATCH(c, CALL)
+#undef CALL
+}
+static int spec_sweep(sdc_ctx* c, int nf, SpecArgs& a, const FieldPtrs& p) {
+#define CALL(NN) spec_sweep_n<NN>(c, nf, a, p)
+    N_DISPATCH(c, CALL)
+#undef CALL
 }
 
 // (I - alpha_f A) out_f = in_f + sum_{j<f} (cI[f][j] A + cE[f][j] B) out_j for f = 0..nf-1
@@ -1193,6 +1446,8 @@ int sdc_ctx_destroy(sdc_ctx* c) {
     (void)hipFree(c->TAU);
     (void)hipFree(c->UEND);
     (void)hipFree(c->W);
+    (void)hipFree(c->S);
+    (void)hipFree(c->S0);
     (void)hipFree(c->tw);
     (void)hipFree(c->lamI);
     (void)hipFree(c->lamE);
@@ -1271,6 +1526,8 @@ int sdc_set_forcing_values(sdc_ctx* c, const double* g) {
     return SDC_OK;
 }
 
+extern "C" int sdc_invalidate_spectra(sdc_ctx* c, int which);
+
 static int ensure_tau(sdc_ctx* c) {
     if (!c->TAU) {
         HIPCHK(c, hipMalloc((void**)&c->TAU, c->N * sizeof(double) * c->M));
@@ -1285,6 +1542,27 @@ void* sdc_slot_ptr(sdc_ctx* c, int slot, int m, int comp) {
     if (slot == SDC_SLOT_TAU && ensure_tau(c) != SDC_OK) return nullptr;
     if (slot == SDC_SLOT_WORK) return c->W;
     return slot_ptr(c, slot, m, comp);
+}
+
+int sdc_invalidate_spectra(sdc_ctx* c, int which) {
+    if (!c) return SDC_ERR_PARAM;
+    if (which & 1) {
+        c->spec0_valid = false;
+        c->spec_spread = false;  // "all nodes equal U[0]" no longer holds for the new U[0]
+    }
+    if (which & 2) {
+        c->spec_valid = false;
+        c->spec_spread = false;
+    }
+    if (which & 4) c->force_gather = true;  // some F[m >= 1] no longer equals f(U[m]): gather on F itself
+    return SDC_OK;
+}
+
+int sdc_set_spectral_reuse(sdc_ctx* c, int on) {
+    if (!c) return SDC_ERR_PARAM;
+    c->reuse = on != 0;
+    c->spec_valid = c->spec0_valid = c->spec_spread = false;
+    return SDC_OK;
 }
 
 int sdc_set_tau_active(sdc_ctx* c, int active) {
@@ -1303,6 +1581,7 @@ int sdc_upload(sdc_ctx* c, int slot, int m, int comp, const double* host) {
     if (!d) return fail(c, SDC_ERR_PARAM, "bad slot (%d, %d, %d)", slot, m, comp);
     HIPCHK(c, hipMemcpyAsync(d, host, c->N * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (slot == SDC_SLOT_U) sdc_invalidate_spectra(c, m == 0 ? 1 : 2);
     return SDC_OK;
 }
 
@@ -1355,6 +1634,8 @@ int sdc_predict(sdc_ctx* c, double t, double dt, int guess, double fill_u, doubl
     }
     HIPCHK(c, hipGetLastError());
     c->unlocked = true;
+    c->spec_valid = false;
+    c->spec_spread = (guess == SDC_GUESS_SPREAD || guess == SDC_GUESS_COPY);  // all nodes equal U[0]
     return SDC_OK;
 }
 
@@ -1364,6 +1645,77 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
     if (!c->have_coeffs) return fail(c, SDC_ERR_STATE, "coefficients not set (sdc_set_coeffs)");
     if (!c->unlocked) return fail(c, SDC_ERR_STATE, "level is locked: predict first (assert L.status.unlocked)");
     const int M = c->M;
+    if (c->expl_kind == SDC_EXPL_STENCIL && !c->have_stencil[1])
+        return fail(c, SDC_ERR_STATE, "explicit operator not set (sdc_set_stencil which=1)");
+    const bool gather_once = c->force_gather;
+    c->force_gather = false;
+    if (c->reuse && !gather_once && !c->tau_active && c->expl_kind != SDC_EXPL_FORCING && c->have_stencil[0] &&
+        is_pow2(c->n) && c->n <= 1024) {
+        // ---- spectral reuse: f is linear in u, so the gather happens on the cached transforms ----
+        if (!c->S) {
+            HIPCHK(c, hipMalloc((void**)&c->S, sizeof(cd) * c->Nc * M));
+            HIPCHK(c, hipMalloc((void**)&c->S0, sizeof(cd) * c->Nc));
+            c->bytes += sizeof(cd) * c->Nc * (M + 1);
+            c->spec_valid = c->spec0_valid = false;
+        }
+        FieldPtrs p;
+        memset(&p, 0, sizeof p);
+        if (!c->spec0_valid) {
+            p.in[0] = c->U;
+            int rc0 = fwd_transform(c, 1, p, c->S0, 0);
+            if (rc0 != SDC_OK) return rc0;
+            c->spec0_valid = true;
+        }
+        if (!c->spec_valid && !c->spec_spread) {
+            for (int m = 0; m < M; ++m) p.in[m] = c->U + (size_t)(m + 1) * c->N;
+            int rc0 = fwd_transform(c, M, p, c->S, c->Nc);
+            if (rc0 != SDC_OK) return rc0;
+            c->spec_valid = true;
+        }
+        SpecArgs a;
+        memset(&a, 0, sizeof a);
+        a.S = c->S;
+        a.fstride = c->Nc;
+        a.S0 = c->S0;
+        a.W = c->W;
+        a.tw = c->tw;
+        a.lamI = c->lamI;
+        a.lamE = c->expl_kind == SDC_EXPL_STENCIL ? c->lamE : nullptr;
+        a.invN = 1.0 / (double)c->N;
+        a.nf = M;
+        a.ndim = c->ndim;
+        a.spread = (!c->spec_valid && c->spec_spread) ? 1 : 0;
+        bool coupled = false;
+        for (int m = 0; m < M; ++m) {
+            p.out[m] = c->U + (size_t)(m + 1) * c->N;
+            a.alpha[m] = dt * c->QI[m + 1][m + 1];
+            for (int j = 0; j < M; ++j) {
+                a.gI[m][j] = dt * (c->Q[m + 1][j + 1] - c->QI[m + 1][j + 1]);
+                a.gE[m][j] = a.lamE ? dt * (c->Q[m + 1][j + 1] - c->QE[m + 1][j + 1]) : 0.0;
+                if (j < m) {
+                    a.cI[m][j] = dt * c->QI[m + 1][j + 1];
+                    a.cE[m][j] = a.lamE ? dt * c->QE[m + 1][j + 1] : 0.0;
+                    if (a.cI[m][j] != 0.0 || a.cE[m][j] != 0.0) coupled = true;
+                }
+            }
+        }
+        a.coupled = coupled;
+        int rc0 = spec_sweep(c, M, a, p);
+        if (rc0 != SDC_OK) return rc0;
+        c->spec_valid = true;
+        c->spec_spread = false;
+        const double* in[MAXM];
+        double* oi[MAXM];
+        double* oe[MAXM];
+        for (int m = 0; m < M; ++m) {
+            in[m] = c->U + (size_t)(m + 1) * c->N;
+            oi[m] = c->F + ((size_t)(m + 1) * c->ncomp) * c->N;
+            oe[m] = c->ncomp == 2 ? oi[m] + c->N : nullptr;
+        }
+        return run_stencil(c, M, in, oi, c->expl_kind == SDC_EXPL_STENCIL ? oe : nullptr, nullptr);
+    }
+    c->spec_valid = false;
+    c->spec_spread = false;
     // 1. gather u0 + dt (Q - QI) F_impl + dt (Q - QE) F_expl (+ tau) for all nodes into U[1..M]
     QuadArgs q;
     quad_base(c, q);
@@ -1399,8 +1751,6 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
     }
     z.coupled = coupled;
     z.lamE = c->expl_kind == SDC_EXPL_STENCIL ? c->lamE : nullptr;
-    if (c->expl_kind == SDC_EXPL_STENCIL && !c->have_stencil[1])
-        return fail(c, SDC_ERR_STATE, "explicit operator not set (sdc_set_stencil which=1)");
     rc = fft_pipeline(c, M, p, z);
     if (rc != SDC_OK) return rc;
     // 3. F[m] = f(U[m]) for the new values

@@ -70,6 +70,12 @@ class SweepEngine:
         assert g.size == self.M + 1
         self._chk(self.lib.sdc_set_forcing_values(self.ctx, _dptr(g)))
 
+    def invalidate_spectra(self, which=3):
+        self._chk(self.lib.sdc_invalidate_spectra(self.ctx, int(which)))
+
+    def set_spectral_reuse(self, on):
+        self._chk(self.lib.sdc_set_spectral_reuse(self.ctx, int(bool(on))))
+
     def set_tau_active(self, active):
         self._chk(self.lib.sdc_set_tau_active(self.ctx, int(bool(active))))
         self.tau_active = bool(active)

@@ -64,11 +64,12 @@ class SlabList:
         if self._views[m] is None:
             e = self._L.engine
             shape = e.nvars
+            cb = lambda slot=self._slot, m=m: self._L._touched(slot, m)  # noqa: E731
             if self._imex:
                 self._views[m] = hip_imex_mesh.view(e.ptr(self._slot, m, 0), e.ptr(self._slot, m, 1), shape, keep=e,
-                                                    on_write=self._L._touched)
+                                                    on_write=cb)
             else:
-                self._views[m] = hip_mesh.view(e.ptr(self._slot, m, 0), shape, keep=e, on_write=self._L._touched)
+                self._views[m] = hip_mesh.view(e.ptr(self._slot, m, 0), shape, keep=e, on_write=cb)
         return self._views[m]
 
     def __getitem__(self, m):
@@ -90,7 +91,7 @@ class SlabList:
             self._valid[m] = True
         if self._slot == Lb.SLOT_TAU and not any(self._valid):
             self._L.engine.set_tau_active(False)
-        self._L._touched()
+        self._L._touched(self._slot, m)
 
     def __iter__(self):
         return (self[m] for m in range(self._len))
@@ -185,8 +186,20 @@ class Level:
         e.set_tau_active(True)
         e.vec_fill(e.N * e.M, 0.0, e.ptr(Lb.SLOT_TAU, 0))
 
-    def _touched(self):
+    def _touched(self, slot=None, m=None):
+        """device state was written outside the engine's own sweep calls: drop the cached residual and tell
+        the engine which cached transforms are stale (include/sdcmi.h: sdc_invalidate_spectra)."""
         self._res_cache = None
+        e = self.__engine
+        if e is None:
+            return
+        if slot == Lb.SLOT_U:
+            e.invalidate_spectra(1 if m == 0 else 2)
+        elif slot == Lb.SLOT_F:
+            if m != 0:
+                e.invalidate_spectra(4)
+        elif slot is None:
+            e.invalidate_spectra(7)
 
     def reset_level(self, reset_status=True):
         """pySDC/core/level.py:110-131."""

@@ -34,6 +34,8 @@ PROTOTYPES = {
     'sdc_upload': (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _dp]),
     'sdc_download': (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _dp]),
     'sdc_set_tau_active': (C.c_int, [_vp, C.c_int]),
+    'sdc_invalidate_spectra': (C.c_int, [_vp, C.c_int]),
+    'sdc_set_spectral_reuse': (C.c_int, [_vp, C.c_int]),
     'sdc_init_field': (C.c_int, [_vp, _vp, C.POINTER(C.c_int), C.c_double, C.c_ulonglong]),
     'sdc_predict': (C.c_int, [_vp, C.c_double, C.c_double, C.c_int, C.c_double, C.c_double]),
     'sdc_sweep': (C.c_int, [_vp, C.c_double, C.c_double]),

@@ -146,7 +146,7 @@ class Sweeper:
             e.predict(L.time, L.dt, guess, fu, ff)
             L.u.mark(range(M + 1))
             L.f.mark(range(M + 1))
-            L._touched()
+            L._res_cache = None
         else:
             return self._predict_generic()
         L.status.unlocked = True
@@ -237,7 +237,7 @@ class Sweeper:
             raise ParameterError('update_nodes needs values at all nodes (predict first)')
         self._push_forcing()
         L.engine.sweep(L.time, L.dt)
-        L._touched()
+        L._res_cache = None
         L.status.updated = True
 
     def _end_point_fused(self):

@@ -27,13 +27,17 @@ SWEEP_FILES = ['sweeps_heat.npz', 'sweeps_imex.npz', 'sweeps_adv.npz']
 SWEEP_CASES = [(f, n) for f in SWEEP_FILES for n, c in load_cases(f).items() if supported(c)]
 
 
+@pytest.mark.parametrize('reuse', [True, False])
 @pytest.mark.parametrize('fname,name', SWEEP_CASES)
-def test_sweep_vs_golden(fname, name):
+def test_sweep_vs_golden(fname, name, reuse):
+    """reuse=True: sweeps gather on the cached Fourier transforms (spectral reuse); False: every sweep gathers
+    on the F slab and transforms M fields (the reference's data flow).  Both must match the reference."""
     case = load_cases(fname)[name]
     meta = case['meta']
     M = len(case['coll_nodes'])
     dt, t0 = meta['dt'], meta['t0']
     e = G.engine_for(meta['prob'], meta['prob_params'], M)
+    e.set_spectral_reuse(reuse)
     G.set_case_coeffs(e, case)
     G.set_forcing_times(e, meta, t0, dt, case['coll_nodes'])
     e.upload(L.SLOT_U, 0, case['u0'])
