@@ -769,12 +769,12 @@ __global__ __launch_bounds__(z_lines_per_block<N>() * (N / fft_elems(N)) * MAXM,
     }
 }
 
-// plain forward transform along the contiguous axis, in place (used to bring u0 / node values into the
-// fully transformed domain of the spectral cache)
-template <int N>
-__global__ __launch_bounds__(z_lines_per_block<N>() * (N / fft_elems(N)) * MAXM, 3) void k_fftz_fwd(cd* __restrict__ W, size_t fstride,
-                                                                                                    const cd* __restrict__ tw,
-                                                                                                    unsigned nlines) {
+// plain transform along the contiguous axis, src -> dst (may alias), optionally scaled: forward to bring u0 /
+// node values into the fully transformed domain of the spectral cache, inverse after the spectral sweep
+template <int N, int DIR>
+__global__ __launch_bounds__(z_lines_per_block<N>() * (N / fft_elems(N)) * MAXM, 4) void k_fftz_plain(
+    const cd* __restrict__ src, cd* __restrict__ dst, size_t fstride, const cd* __restrict__ tw, unsigned nlines,
+    double scale) {
     constexpr int E = fft_elems(N), P = N / E, LPB = z_lines_per_block<N>();
     using LAY = LayContig<N>;
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -782,14 +782,18 @@ __global__ __launch_bounds__(z_lines_per_block<N>() * (N / fft_elems(N)) * MAXM,
     const int f = c / LPB, l = c % LPB;
     const size_t line = (size_t)blockIdx.x * LPB + l;
     const bool ok = line < nlines;
-    cd* __restrict__ Wl = W + f * fstride + line * N;
+    const size_t base = f * fstride + line * N;
     cd r[E];
 #pragma unroll
-    for (int i = 0; i < E; ++i) r[i] = ok ? Wl[j + i * P] : cd{0.0, 0.0};
-    fft_line<N, -1, LAY, true>(r, j, c, lds, tw);
+    for (int i = 0; i < E; ++i) r[i] = ok ? src[base + j + i * P] : cd{0.0, 0.0};
+    if (scale != 1.0) {
+#pragma unroll
+        for (int i = 0; i < E; ++i) r[i] = cscale(r[i], scale);
+    }
+    fft_line<N, DIR, LAY, true>(r, j, c, lds, tw);
     if (ok) {
 #pragma unroll
-        for (int i = 0; i < E; ++i) Wl[j + i * P] = r[i];
+        for (int i = 0; i < E; ++i) dst[base + j + i * P] = r[i];
     }
 }
 
@@ -810,79 +814,49 @@ struct SpecArgs {
     int nf, ndim, coupled, spread;
 };
 
-template <int N>
-__global__ __launch_bounds__(z_lines_per_block<N>() * (N / fft_elems(N)) * MAXM, 3) void k_specz_sweep(SpecArgs a, unsigned nlines) {
-    constexpr int E = fft_elems(N), P = N / E, LPB = z_lines_per_block<N>();
-    constexpr int NCH = E == 16 ? 2 : 1;
-    constexpr int CH = N / NCH, ECH = E / NCH;
-    using LAY = LayContig<N>;
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int c = threadIdx.x / P, j = threadIdx.x % P;
-    const int f = c / LPB, l = c % LPB;
-    const size_t line = (size_t)blockIdx.x * LPB + l;
-    const bool ok = line < nlines;
-    cd* buf = reinterpret_cast<cd*>(lds);
-    const int nthreads = a.nf * LPB * P;
-    cd r[E];
+// one thread per Fourier mode: gather on the cached transforms + node-coupled solve, S updated in place
+__global__ __launch_bounds__(256) void k_spec_point(SpecArgs a, int n, size_t nmodes) {
+    for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < nmodes; g += (size_t)gridDim.x * blockDim.x) {
+        const int kz = (int)(g % n);
+        const size_t ln = g / n;
+        cd lam = a.lamI[kz], mu = cd{0.0, 0.0};
+        if (a.lamE) mu = a.lamE[kz];
+        if (a.ndim == 3) {
+            const int kx = (int)(ln / n), ky = (int)(ln % n);
+            lam = cadd(lam, cadd(a.lamI[kx], a.lamI[ky]));
+            if (a.lamE) mu = cadd(mu, cadd(a.lamE[kx], a.lamE[ky]));
+        } else if (a.ndim == 2) {
+            lam = cadd(lam, a.lamI[ln]);
+            if (a.lamE) mu = cadd(mu, a.lamE[ln]);
+        }
+        const cd u0h = a.S0[g];
+        cd old[MAXM], u[MAXM];
 #pragma unroll
-    for (int ph = 0; ph < NCH; ++ph) {
-        for (int item = threadIdx.x; item < LPB * CH; item += nthreads) {
-            const int ll = item / CH, kk = item % CH;
-            const size_t ln = (size_t)blockIdx.x * LPB + ll;
-            const int kz = ph * CH + kk;
-            const bool lok = ln < nlines;
-            const size_t g = ln * N + kz;
-            cd lam = a.lamI[kz], mu = cd{0.0, 0.0};
-            if (a.lamE) mu = a.lamE[kz];
-            if (a.ndim == 3) {
-                const int kx = (int)(ln / N) % (N / 2 + 1), ky = (int)(ln % N);
-                lam = cadd(lam, cadd(a.lamI[kx], a.lamI[ky]));
-                if (a.lamE) mu = cadd(mu, cadd(a.lamE[kx], a.lamE[ky]));
-            } else if (a.ndim == 2) {
-                const int kx = (int)(ln % (N / 2 + 1));
-                lam = cadd(lam, a.lamI[kx]);
-                if (a.lamE) mu = cadd(mu, a.lamE[kx]);
-            }
-            const cd u0h = lok ? a.S0[g] : cd{0.0, 0.0};
-            cd old[MAXM], u[MAXM];
+        for (int q = 0; q < MAXM; ++q)
+            if (q < a.nf) old[q] = a.spread ? u0h : a.S[q * a.fstride + g];
 #pragma unroll
-            for (int q = 0; q < MAXM; ++q)
-                if (q < a.nf) old[q] = (a.spread || !lok) ? u0h : a.S[q * a.fstride + g];
+        for (int m = 0; m < MAXM; ++m) {
+            if (m < a.nf) {
+                cd acc = u0h;
 #pragma unroll
-            for (int m = 0; m < MAXM; ++m) {
-                if (m < a.nf) {
-                    cd acc = u0h;
-#pragma unroll
-                    for (int q = 0; q < MAXM; ++q) {
-                        if (q < a.nf) {
-                            const double gi = a.gI[m][q], ge = a.gE[m][q];
-                            acc = cfma(cd{gi * lam.x + ge * mu.x, gi * lam.y + ge * mu.y}, old[q], acc);
-                        }
+                for (int q = 0; q < MAXM; ++q) {
+                    if (q < a.nf) {
+                        const double gi = a.gI[m][q], ge = a.gE[m][q];
+                        acc = cfma(cd{gi * lam.x + ge * mu.x, gi * lam.y + ge * mu.y}, old[q], acc);
                     }
-                    if (a.coupled) {
-#pragma unroll
-                        for (int q = 0; q < m; ++q) {
-                            const double ci = a.cI[m][q], ce = a.cE[m][q];
-                            acc = cfma(cd{ci * lam.x + ce * mu.x, ci * lam.y + ce * mu.y}, u[q], acc);
-                        }
-                    }
-                    const double al = a.alpha[m];
-                    u[m] = cmul(acc, cinv_fast(cd{1.0 - al * lam.x, -al * lam.y}));
-                    if (lok) a.S[m * a.fstride + g] = u[m];
-                    buf[(m * LPB + ll) * CH + kk] = cscale(u[m], a.invN);
                 }
+                if (a.coupled) {
+#pragma unroll
+                    for (int q = 0; q < m; ++q) {
+                        const double ci = a.cI[m][q], ce = a.cE[m][q];
+                        acc = cfma(cd{ci * lam.x + ce * mu.x, ci * lam.y + ce * mu.y}, u[q], acc);
+                    }
+                }
+                const double al = a.alpha[m];
+                u[m] = cmul(acc, cinv_fast(cd{1.0 - al * lam.x, -al * lam.y}));
+                a.S[m * a.fstride + g] = u[m];
             }
         }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < ECH; ++i) r[ph * ECH + i] = buf[c * CH + j + i * P];
-        __syncthreads();
-    }
-    fft_line<N, +1, LAY, true>(r, j, c, lds, a.tw);
-    if (ok) {
-        cd* __restrict__ Wl = a.W + f * a.fstride + line * N;
-#pragma unroll
-        for (int i = 0; i < E; ++i) Wl[j + i * P] = r[i];
     }
 }
 
@@ -1195,8 +1169,8 @@ static int fwd_transform_n(sdc_ctx* c, int nf, const FieldPtrs& p, cd* dst, size
     }
     LaunchTimer lt(c, pname("fft_z_fwd", nf));
     const size_t ldsz = (size_t)LayContig<N>::doubles(nf * LPB) * sizeof(double);
-    hipLaunchKernelGGL((k_fftz_fwd<N>), dim3((unsigned)((lines + LPB - 1) / LPB)), dim3(P * LPB * nf), ldsz, c->stream, dst,
-                       fstride, c->tw, (unsigned)lines);
+    hipLaunchKernelGGL((k_fftz_plain<N, -1>), dim3((unsigned)((lines + LPB - 1) / LPB)), dim3(P * LPB * nf), ldsz,
+                       c->stream, dst, dst, fstride, c->tw, (unsigned)lines, 1.0);
     HIPCHK(c, hipGetLastError());
     return SDC_OK;
 }
@@ -1210,13 +1184,17 @@ static int spec_sweep_n(sdc_ctx* c, int nf, SpecArgs& a, const FieldPtrs& p) {
     const int n = c->n;
     const size_t lines = c->ndim == 1 ? 1 : (size_t)(n / 2 + 1) * (c->ndim == 3 ? n : 1);
     {
-        LaunchTimer lt(c, pname("spec_z_sweep", nf));
-        size_t ldsz = (size_t)LayContig<N>::doubles(nf * LPB) * sizeof(double);
-        const size_t solve_sz = (size_t)nf * LPB * (N / NCH) * sizeof(cd);
-        if (solve_sz > ldsz) ldsz = solve_sz;
-        hipLaunchKernelGGL((k_specz_sweep<N>), dim3((unsigned)((lines + LPB - 1) / LPB)), dim3(P * LPB * nf), ldsz,
-                           c->stream, a, (unsigned)lines);
+        LaunchTimer lt(c, pname("spec_point", nf));
+        const size_t nmodes = lines * N;
+        hipLaunchKernelGGL(k_spec_point, dim3(grid_for(nmodes, 256)), dim3(256), 0, c->stream, a, n, nmodes);
     }
+    {
+        LaunchTimer lt(c, pname("fft_z_inv", nf));
+        const size_t ldsz = (size_t)LayContig<N>::doubles(nf * LPB) * sizeof(double);
+        hipLaunchKernelGGL((k_fftz_plain<N, +1>), dim3((unsigned)((lines + LPB - 1) / LPB)), dim3(P * LPB * nf), ldsz,
+                           c->stream, c->S, c->W, c->Nc, c->tw, (unsigned)lines, a.invN);
+    }
+    (void)NCH;
     if (c->ndim == 1) {
         LaunchTimer lt(c, pname("realpart", nf));
         hipLaunchKernelGGL(k_realpart, dim3(grid_for(c->N, 256), nf), dim3(256), 0, c->stream, p, c->W, c->N);
