@@ -363,12 +363,10 @@ class controller_dist(_ControllerBase):
             ops.append(self.dist.P2POp(self.dist.irecv, L.u[0].as_torch(), self.rank - 1, self.comm, tag))
         if ops:
             reqs = self.dist.batch_isend_irecv(ops)
-            if send and not S.status.last:
-                # with a batched launch all requests complete together
-                self.req_send = reqs[0]
-                if blocking_send or len(reqs) == 1 and not do_recv:
-                    pass
-            for r in reqs[(1 if (send and not S.status.last) else 0):]:
+            sending = send and not S.status.last
+            if sending:
+                self.req_send = reqs[0]  # waited for before UEND is overwritten again ("send and forget")
+            for r in reqs[(1 if sending else 0):]:
                 r.wait()
             if blocking_send and self.req_send is not None:
                 self.req_send.wait()
