@@ -107,8 +107,9 @@ int sdc_integrate(sdc_ctx* ctx, double dt, double* const* dst);
 /* eval_f (generic_ND_FD.py:188-206; HeatEquation_ND_FD.py:162-204 for the IMEX variant).  g_t is the value
  * of the forcing's time factor g(t) (only read for SDC_EXPL_FORCING); f_expl may be NULL. */
 int sdc_eval_f(sdc_ctx* ctx, const double* u, double g_t, double* f_impl, double* f_expl);
-/* solve_system (generic_ND_FD.py:208-264, 'direct'): (I - factor*A) out = rhs. */
-int sdc_solve(sdc_ctx* ctx, const double* rhs, double factor, double* out);
+/* solve_system(rhs, factor, u0, t) (generic_ND_FD.py:208-264, 'direct'): (I - factor*A) out = rhs; `guess` is
+ * the reference's u0 argument (unused by the direct solver, may be NULL; the Newton solver requires it). */
+int sdc_solve(sdc_ctx* ctx, const double* rhs, double factor, const double* guess, double* out);
 
 /* ---- datatype operations (mesh arithmetic, datatype_classes/mesh.py:12-125) ----------------------------
  * ctx may be NULL: the operation then runs on the null stream of the current device. */
@@ -117,13 +118,17 @@ int sdc_vec_fill(sdc_ctx* ctx, size_t n, double a, double* y);
 int sdc_vec_axpby(sdc_ctx* ctx, size_t n, double a, const double* x, double b, const double* y, double* z);
 int sdc_vec_amax(sdc_ctx* ctx, size_t n, const double* x, double* out); /* abs(): max-norm, synchronises */
 
-/* ---- van der Pol ensemble (BASELINE config 4; Van_der_Pol_implicit.py:106-201) ------------------------- */
-/* ntraj independent trajectories, SoA state x1[ntraj], x2[ntraj] on the device; `nsweeps` sweeps of
- * generic_implicit with Newton per node, all nodes kept in registers.  counters[0] = Newton iterations,
- * counters[1] = rhs evaluations (summed over trajectories); *max_residual = max over trajectories of the
- * full_abs collocation residual after the last sweep.  Uses the ctx coefficient matrices (M <= 8). */
-int sdc_vdp_step(sdc_ctx* ctx, size_t ntraj, double* x1, double* x2, double mu, double dt, int nsweeps,
-                 double newton_tol, int newton_maxiter, unsigned long long* counters, double* max_residual);
+/* ---- van der Pol ensemble (BASELINE config 4; Van_der_Pol_implicit.py:106-201) -------------------------
+ * ntraj independent trajectories are ONE level with N = 2 * ntraj unknowns, SoA fields [x1[ntraj], x2[ntraj]]
+ * (create the context with ndim = 1, n = 2 * ntraj, ncomp = 1).  After this call sdc_eval_f is the van der Pol
+ * right-hand side, sdc_solve the Newton solve with the closed-form 2x2 inverse (guess = previous iterate) and
+ * sdc_sweep one generic_implicit sweep for every trajectory in one launch; predict / residual / end point /
+ * integrate are the generic kernels.  A failed Newton solve makes the call return SDC_ERR_NEWTON
+ * (ProblemError in the reference, Van_der_Pol_implicit.py:179-186). */
+int sdc_set_problem_vdp(sdc_ctx* ctx, double mu, double newton_tol, int newton_maxiter);
+/* out[0] = Newton iterations, out[1] = right-hand side evaluations, out[2] = failed solves (pending), summed
+ * over trajectories since context creation (work_counters of Van_der_Pol_implicit.py:71-73). */
+int sdc_work_counters(sdc_ctx* ctx, unsigned long long* out);
 
 /* ---- stream / timing ------------------------------------------------------------------------------------ */
 int sdc_sync(sdc_ctx* ctx);

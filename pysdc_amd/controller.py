@@ -78,8 +78,7 @@ class controller_nonMPI(_ControllerBase):
     def __init__(self, num_procs, controller_params, description):
         super().__init__(controller_params, description)
         self.MS = [Step(description) for _ in range(num_procs)]
-        if self.params.dump_setup and False:
-            pass
+        self._uend_buf = None
         self.nsweeps = [L.params.nsweeps for L in self.MS[0].levels]
         self.nlevels = len(self.MS[0].levels)
 
@@ -111,9 +110,13 @@ class controller_nonMPI(_ControllerBase):
                 time[active_slots[i]] = time[active_slots[i] - 1] + self.MS[active_slots[i] - 1].dt
             active = [time[p] < Tend - 10 * np.finfo(float).eps for p in slots]
             active_slots = list(itertools.compress(slots, active))
-            if active_slots:
-                # the views into the last step's UEND slab are about to be reset: keep an owning copy
-                uend = type(uend)(uend)
+            # the view into the last step's UEND slab is about to be reset: keep the value in an owning
+            # buffer that lives as long as the controller (allocating 8.6 GB per block costs ~0.25 s)
+            if self._uend_buf is None:
+                self._uend_buf = type(uend)(uend)
+            else:
+                self._uend_buf[:] = uend
+            uend = self._uend_buf
             self.restart_block(active_slots, time, uend)
         for S in self.MS:
             self._hook('post_run', S)

@@ -53,6 +53,10 @@ struct sdc_ctx {
     unsigned long long* red_host = nullptr;
     bool tau_active = false, have_coeffs = false, have_stencil[2] = {false, false}, unlocked = false;
     int expl_kind = SDC_EXPL_NONE;
+    int kind = 0;  // 0: periodic finite differences, 1: van der Pol ensemble (N = 2 * ntraj, SoA)
+    double vdp_mu = 0, vdp_tol = 1e-9;
+    int vdp_maxiter = 100;
+    unsigned long long* counters = nullptr;  // device: [0] newton, [1] rhs, [2] failed solves
     double Q[MAXM + 1][MAXM + 1], QI[MAXM + 1][MAXM + 1], QE[MAXM + 1][MAXM + 1], nodes[MAXM], weights[MAXM];
     double gvals[MAXM + 1];
     Stencil st[2];
@@ -861,100 +865,59 @@ __global__ __launch_bounds__(256) void k_spec_point(SpecArgs a, int n, size_t nm
 }
 
 // ------------------------------------------------------------------------------------------------------
-// van der Pol ensemble: one trajectory per lane, all node values in registers
+// van der Pol ensemble: one trajectory per lane (SoA state [2][T])
 // ------------------------------------------------------------------------------------------------------
-struct VdpArgs {
-    double* x1;
-    double* x2;
-    size_t ntraj;
+struct VdpSweepArgs {
+    double* U;   // slab [(M+1)][2][T]
+    double* F;
+    const double* tau;  // or null
+    size_t T;
     double mu, dt, tol;
-    int nsweeps, maxiter;
-    double Q[MAXM][MAXM], QI[MAXM][MAXM];  // inner MxM blocks
-    unsigned long long* counters;          // [0] newton, [1] rhs, [2] failures
-    unsigned long long* resmax;
+    int maxiter;
+    double Q[MAXM][MAXM], QI[MAXM][MAXM];
+    unsigned long long* counters;
 };
 
+// Newton for u - h f(u) = r with the closed-form 2x2 inverse (Van_der_Pol_implicit.py:131-201)
+__device__ __forceinline__ bool vdp_newton(double& x1, double& x2, double r0, double r1, double h, double mu, double tol,
+                                           int maxiter, unsigned long long& newton) {
+#pragma clang fp contract(off)
+    int it = 0;
+    double res = 99.0;
+    while (it < maxiter) {
+        const double e0 = x1 - h * x2 - r0;
+        const double e1 = x2 - h * (mu * (1 - x1 * x1) * x2 - x1) - r1;
+        res = fmax(fabs(e0), fabs(e1));
+        if (e0 != e0 || e1 != e1) res = e0 + e1;  // NaN
+        if (res < tol || res != res) break;
+        const double c = 1.0 / (-2 * h * h * mu * x1 * x2 - h * h - 1 + h * mu * (1 - x1 * x1));
+        const double d00 = c * (h * mu * (1 - x1 * x1) - 1), d01 = c * (-h);
+        const double d10 = c * (2 * h * mu * x1 * x2 + h), d11 = c * (-1.0);
+        const double nx1 = x1 - (d00 * e0 + d01 * e1);
+        const double nx2 = x2 - (d10 * e0 + d11 * e1);
+        x1 = nx1;
+        x2 = nx2;
+        ++it;
+        ++newton;
+    }
+    return !(res != res || it == maxiter);
+}
+
+// one generic_implicit sweep (generic_implicit.py:51-103) for every trajectory, node values on the slabs
 template <int M>
-__global__ __launch_bounds__(256) void k_vdp(VdpArgs a) {
-#pragma clang fp contract(off)  // keep the reference's separate multiply / add roundings (Newton counts)
+__global__ __launch_bounds__(256) void k_vdp_sweep(VdpSweepArgs a) {
+#pragma clang fp contract(off)
     unsigned long long newton = 0, rhs = 0, failed = 0;
-    double resmax = 0.0;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < a.ntraj; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t T = a.T, N = 2 * a.T;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < T; i += (size_t)gridDim.x * blockDim.x) {
         const double mu = a.mu, dt = a.dt;
-        const double u00 = a.x1[i], u01 = a.x2[i];
-        double u0[M], u1[M], f0[M], f1[M];
-        // predict: spread (core/sweeper.py:140-143); f[0] evaluation counted like the reference does
-        rhs += 1;
+        const double u00 = a.U[i], u01 = a.U[T + i];
+        double f0[M], f1[M], g0[M], g1[M];
 #pragma unroll
         for (int m = 0; m < M; ++m) {
-            u0[m] = u00;
-            u1[m] = u01;
-            f0[m] = u01;
-            f1[m] = mu * (1 - u00 * u00) * u01 - u00;
-            rhs += 1;
+            f0[m] = a.F[(size_t)(m + 1) * N + i];
+            f1[m] = a.F[(size_t)(m + 1) * N + T + i];
         }
-        for (int k = 0; k < a.nsweeps; ++k) {
-            double g0[M], g1[M];
-#pragma unroll
-            for (int m = 0; m < M; ++m) {  // integral[m] = dt*(Q - QI) f + u0 (generic_implicit.py:72-82)
-                double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-                for (int j = 0; j < M; ++j) {
-                    s0 += dt * a.Q[m][j] * f0[j];
-                    s1 += dt * a.Q[m][j] * f1[j];
-                }
-#pragma unroll
-                for (int j = 0; j < M; ++j) {
-                    s0 -= dt * a.QI[m][j] * f0[j];
-                    s1 -= dt * a.QI[m][j] * f1[j];
-                }
-                g0[m] = s0 + u00;
-                g1[m] = s1 + u01;
-            }
-#pragma unroll
-            for (int m = 0; m < M; ++m) {
-                double r0 = g0[m], r1 = g1[m];
-#pragma unroll
-                for (int j = 0; j < M; ++j) {
-                    if (j < m) {
-                        r0 += dt * a.QI[m][j] * f0[j];
-                        r1 += dt * a.QI[m][j] * f1[j];
-                    }
-                }
-                const double h = dt * a.QI[m][m];
-                double x1 = u0[m], x2 = u1[m];
-                if (h == 0.0) {
-                    x1 = r0;
-                    x2 = r1;
-                } else {
-                    // Newton with the closed-form 2x2 inverse (Van_der_Pol_implicit.py:159-201)
-                    int it = 0;
-                    double res = 99.0;
-                    while (it < a.maxiter) {
-                        const double e0 = x1 - h * x2 - r0;
-                        const double e1 = x2 - h * (mu * (1 - x1 * x1) * x2 - x1) - r1;
-                        res = fmax(fabs(e0), fabs(e1));
-                        if (res < a.tol || res != res) break;
-                        const double c = 1.0 / (-2 * h * h * mu * x1 * x2 - h * h - 1 + h * mu * (1 - x1 * x1));
-                        const double d00 = c * (h * mu * (1 - x1 * x1) - 1), d01 = c * (-h);
-                        const double d10 = c * (2 * h * mu * x1 * x2 + h), d11 = c * (-1.0);
-                        const double nx1 = x1 - (d00 * e0 + d01 * e1);
-                        const double nx2 = x2 - (d10 * e0 + d11 * e1);
-                        x1 = nx1;
-                        x2 = nx2;
-                        ++it;
-                        ++newton;
-                    }
-                    if (res != res || it == a.maxiter) failed += 1;
-                }
-                u0[m] = x1;
-                u1[m] = x2;
-                f0[m] = x2;
-                f1[m] = mu * (1 - x1 * x1) * x2 - x1;
-                rhs += 1;
-            }
-        }
-        // full_abs collocation residual (core/sweeper.py:186-199)
 #pragma unroll
         for (int m = 0; m < M; ++m) {
             double s0 = 0.0, s1 = 0.0;
@@ -963,30 +926,94 @@ __global__ __launch_bounds__(256) void k_vdp(VdpArgs a) {
                 s0 += dt * a.Q[m][j] * f0[j];
                 s1 += dt * a.Q[m][j] * f1[j];
             }
-            const double r = fmax(fabs(s0 + (u00 - u0[m])), fabs(s1 + (u01 - u1[m])));
-            resmax = (resmax > r || resmax != resmax) ? resmax : r;
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                s0 -= dt * a.QI[m][j] * f0[j];
+                s1 -= dt * a.QI[m][j] * f1[j];
+            }
+            g0[m] = s0 + u00;
+            g1[m] = s1 + u01;
+            if (a.tau) {
+                g0[m] += a.tau[(size_t)m * N + i];
+                g1[m] += a.tau[(size_t)m * N + T + i];
+            }
         }
-        a.x1[i] = u0[M - 1];
-        a.x2[i] = u1[M - 1];
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            double r0 = g0[m], r1 = g1[m];
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                if (j < m) {
+                    r0 += dt * a.QI[m][j] * f0[j];
+                    r1 += dt * a.QI[m][j] * f1[j];
+                }
+            }
+            const double h = dt * a.QI[m][m];
+            double x1 = a.U[(size_t)(m + 1) * N + i], x2 = a.U[(size_t)(m + 1) * N + T + i];
+            if (h == 0.0) {
+                x1 = r0;
+                x2 = r1;
+            } else if (!vdp_newton(x1, x2, r0, r1, h, mu, a.tol, a.maxiter, newton)) {
+                failed += 1;
+            }
+            a.U[(size_t)(m + 1) * N + i] = x1;
+            a.U[(size_t)(m + 1) * N + T + i] = x2;
+            f0[m] = x2;
+            f1[m] = mu * (1 - x1 * x1) * x2 - x1;
+            a.F[(size_t)(m + 1) * N + i] = f0[m];
+            a.F[(size_t)(m + 1) * N + T + i] = f1[m];
+            rhs += 1;
+        }
     }
-    // wave-level reductions, one atomic per wave
     for (int o = 32; o > 0; o >>= 1) {
         newton += __shfl_xor(newton, o, 64);
         rhs += __shfl_xor(rhs, o, 64);
         failed += __shfl_xor(failed, o, 64);
     }
-    resmax = wave_max(resmax);
     if ((threadIdx.x & 63) == 0) {
         atomicAdd(a.counters + 0, newton);
         atomicAdd(a.counters + 1, rhs);
         atomicAdd(a.counters + 2, failed);
-        atomic_max_abs(a.resmax, resmax);
+    }
+}
+
+__global__ void k_vdp_eval(const double* __restrict__ u, double* __restrict__ f, size_t T, double mu,
+                           unsigned long long* counters) {
+#pragma clang fp contract(off)
+    unsigned long long rhs = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < T; i += (size_t)gridDim.x * blockDim.x) {
+        const double x1 = u[i], x2 = u[T + i];
+        f[i] = x2;
+        f[T + i] = mu * (1 - x1 * x1) * x2 - x1;
+        rhs += 1;
+    }
+    for (int o = 32; o > 0; o >>= 1) rhs += __shfl_xor(rhs, o, 64);
+    if ((threadIdx.x & 63) == 0 && rhs) atomicAdd(counters + 1, rhs);
+}
+
+__global__ void k_vdp_solve(const double* __restrict__ rhsv, const double* __restrict__ guess, double* __restrict__ out,
+                            size_t T, double h, double mu, double tol, int maxiter, unsigned long long* counters) {
+    unsigned long long newton = 0, failed = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < T; i += (size_t)gridDim.x * blockDim.x) {
+        double x1 = guess[i], x2 = guess[T + i];
+        if (!vdp_newton(x1, x2, rhsv[i], rhsv[T + i], h, mu, tol, maxiter, newton)) failed += 1;
+        out[i] = x1;
+        out[T + i] = x2;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        newton += __shfl_xor(newton, o, 64);
+        failed += __shfl_xor(failed, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(counters + 0, newton);
+        atomicAdd(counters + 2, failed);
     }
 }
 
 // ------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------
+static int ensure_work(sdc_ctx* c);
 static inline int grid_for(size_t work, int block) {
     size_t g = (work + block - 1) / block;
     if (g > 4096) g = 4096;
@@ -1235,6 +1262,11 @@ static int fwd_transform(sdc_ctx* c, int nf, const FieldPtrs& p, cd* dst, size_t
 #undef CALL
 }
 static int spec_sweep(sdc_ctx* c, int nf, SpecArgs& a, const FieldPtrs& p) {
+    {
+        int rw = ensure_work(c);
+        if (rw != SDC_OK) return rw;
+        a.W = c->W;
+    }
 #define CALL(NN) spec_sweep_n<NN>(c, nf, a, p)
     N_DISPATCH(c, CALL)
 #undef CALL
@@ -1245,6 +1277,10 @@ static int fft_pipeline(sdc_ctx* c, int nf, const FieldPtrs& p, ZArgs& z) {
     if (!c->have_stencil[0]) return fail(c, SDC_ERR_STATE, "implicit operator not set (sdc_set_stencil)");
     if (!is_pow2(c->n) || c->n > 1024)
         return fail(c, SDC_ERR_UNSUPPORTED, "spectral solve needs n = 2^p <= 1024 per dimension, got %d", c->n);
+    {
+        int rw = ensure_work(c);
+        if (rw != SDC_OK) return rw;
+    }
     switch (c->n) {
         case 2: return fft_pipeline_n<2>(c, nf, p, z);
         case 4: return fft_pipeline_n<4>(c, nf, p, z);
@@ -1385,10 +1421,11 @@ int sdc_ctx_create(sdc_ctx** out, int device, int ndim, int n, int num_nodes, in
         HIPCHK(nullptr, hipMalloc((void**)&c->U, fb * (c->M + 1)));
         HIPCHK(nullptr, hipMalloc((void**)&c->F, fb * (c->M + 1) * ncomp));
         HIPCHK(nullptr, hipMalloc((void**)&c->UEND, fb));
-        HIPCHK(nullptr, hipMalloc((void**)&c->W, sizeof(cd) * c->Nc * c->M));
         HIPCHK(nullptr, hipMalloc((void**)&c->red, sizeof(unsigned long long) * 16));
         HIPCHK(nullptr, hipHostMalloc((void**)&c->red_host, sizeof(unsigned long long) * 16));
-        c->bytes = fb * (c->M + 1) * (1 + ncomp) + fb + sizeof(cd) * c->Nc * c->M;
+        c->bytes = fb * (c->M + 1) * (1 + ncomp) + fb;
+        HIPCHK(nullptr, hipMalloc((void**)&c->counters, sizeof(unsigned long long) * 4));
+        HIPCHK(nullptr, hipMemsetAsync(c->counters, 0, sizeof(unsigned long long) * 4, c->stream));
         HIPCHK(nullptr, hipMemsetAsync(c->U, 0, fb * (c->M + 1), c->stream));
         HIPCHK(nullptr, hipMemsetAsync(c->F, 0, fb * (c->M + 1) * ncomp, c->stream));
         HIPCHK(nullptr, hipMemsetAsync(c->UEND, 0, fb, c->stream));
@@ -1431,6 +1468,7 @@ int sdc_ctx_destroy(sdc_ctx* c) {
     (void)hipFree(c->lamE);
     (void)hipFree(c->profile);
     (void)hipFree(c->red);
+    (void)hipFree(c->counters);
     if (c->red_host) (void)hipHostFree(c->red_host);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -1478,6 +1516,37 @@ int sdc_set_stencil(sdc_ctx* c, int which, int npts, const int* offsets, const d
     return build_symbol(c, which);
 }
 
+int sdc_set_problem_vdp(sdc_ctx* c, double mu, double newton_tol, int newton_maxiter) {
+    if (!c) return SDC_ERR_PARAM;
+    if (c->ndim != 1 || c->ncomp != 1)
+        return fail(c, SDC_ERR_PARAM, "van der Pol ensemble needs a 1-D context with n = 2 * ntraj and ncomp = 1");
+    c->kind = 1;
+    c->vdp_mu = mu;
+    c->vdp_tol = newton_tol;
+    c->vdp_maxiter = newton_maxiter;
+    return SDC_OK;
+}
+
+int sdc_work_counters(sdc_ctx* c, unsigned long long* out) {
+    if (!c || !out) return SDC_ERR_PARAM;
+    HIPCHK(c, hipMemcpyAsync(c->red_host + 12, c->counters, sizeof(unsigned long long) * 3, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int k = 0; k < 3; ++k) out[k] = c->red_host[12 + k];
+    return SDC_OK;
+}
+
+static int vdp_check_failures(sdc_ctx* c) {
+    unsigned long long v[3];
+    int rc = sdc_work_counters(c, v);
+    if (rc != SDC_OK) return rc;
+    if (v[2] != 0) {
+        HIPCHK(c, hipMemsetAsync(c->counters + 2, 0, sizeof(unsigned long long), c->stream));
+        return fail(c, SDC_ERR_NEWTON, "Newton did not converge after %d iterations (or got nan) for %llu solves",
+                    c->vdp_maxiter, v[2]);
+    }
+    return SDC_OK;
+}
+
 int sdc_set_expl_kind(sdc_ctx* c, int kind) {
     if (!c || kind < 0 || kind > 2) return fail(c, SDC_ERR_PARAM, "bad explicit kind");
     if (kind != SDC_EXPL_NONE && c->ncomp != 2) return fail(c, SDC_ERR_PARAM, "explicit part needs ncomp == 2");
@@ -1505,6 +1574,14 @@ int sdc_set_forcing_values(sdc_ctx* c, const double* g) {
 }
 
 extern "C" int sdc_invalidate_spectra(sdc_ctx* c, int which);
+
+static int ensure_work(sdc_ctx* c) {
+    if (!c->W) {
+        HIPCHK(c, hipMalloc((void**)&c->W, sizeof(cd) * c->Nc * c->M));
+        c->bytes += sizeof(cd) * c->Nc * c->M;
+    }
+    return SDC_OK;
+}
 
 static int ensure_tau(sdc_ctx* c) {
     if (!c->TAU) {
@@ -1574,6 +1651,13 @@ int sdc_download(sdc_ctx* c, int slot, int m, int comp, double* host) {
 
 int sdc_eval_f(sdc_ctx* c, const double* u, double g_t, double* f_impl, double* f_expl) {
     if (!c || !u || !f_impl) return fail(c, SDC_ERR_PARAM, "null pointer");
+    if (c->kind == 1) {
+        LaunchTimer lt(c, "vdp_eval");
+        hipLaunchKernelGGL(k_vdp_eval, dim3(grid_for(c->N / 2, 256)), dim3(256), 0, c->stream, u, f_impl, c->N / 2,
+                           c->vdp_mu, c->counters);
+        HIPCHK(c, hipGetLastError());
+        return SDC_OK;
+    }
     if (!c->have_stencil[0]) return fail(c, SDC_ERR_STATE, "implicit operator not set (sdc_set_stencil)");
     if (c->expl_kind == SDC_EXPL_FORCING && !c->profile) return fail(c, SDC_ERR_STATE, "forcing profile not set");
     const double* in[1] = {u};
@@ -1623,6 +1707,36 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
     if (!c->have_coeffs) return fail(c, SDC_ERR_STATE, "coefficients not set (sdc_set_coeffs)");
     if (!c->unlocked) return fail(c, SDC_ERR_STATE, "level is locked: predict first (assert L.status.unlocked)");
     const int M = c->M;
+    if (c->kind == 1) {
+        VdpSweepArgs a;
+        memset(&a, 0, sizeof a);
+        a.U = c->U;
+        a.F = c->F;
+        a.tau = c->tau_active ? c->TAU : nullptr;
+        a.T = c->N / 2;
+        a.mu = c->vdp_mu;
+        a.dt = dt;
+        a.tol = c->vdp_tol;
+        a.maxiter = c->vdp_maxiter;
+        a.counters = c->counters;
+        for (int m = 0; m < M; ++m)
+            for (int j = 0; j < M; ++j) {
+                a.Q[m][j] = c->Q[m + 1][j + 1];
+                a.QI[m][j] = c->QI[m + 1][j + 1];
+            }
+        const int grid = grid_for(a.T, 256);
+        {
+            LaunchTimer lt(c, "vdp_sweep");
+#define VCASE(MM) \
+    case MM: hipLaunchKernelGGL((k_vdp_sweep<MM>), dim3(grid), dim3(256), 0, c->stream, a); break;
+            switch (M) {
+                VCASE(1) VCASE(2) VCASE(3) VCASE(4) VCASE(5) VCASE(6) VCASE(7) VCASE(8)
+            }
+#undef VCASE
+        }
+        HIPCHK(c, hipGetLastError());
+        return vdp_check_failures(c);
+    }
     if (c->expl_kind == SDC_EXPL_STENCIL && !c->have_stencil[1])
         return fail(c, SDC_ERR_STATE, "explicit operator not set (sdc_set_stencil which=1)");
     const bool gather_once = c->force_gather;
@@ -1745,8 +1859,18 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
     return run_stencil(c, M, in, oi, c->expl_kind == SDC_EXPL_STENCIL ? oe : nullptr, g);
 }
 
-int sdc_solve(sdc_ctx* c, const double* rhs, double factor, double* out) {
+int sdc_solve(sdc_ctx* c, const double* rhs, double factor, const double* guess, double* out) {
     if (!c || !rhs || !out) return fail(c, SDC_ERR_PARAM, "null pointer");
+    if (c->kind == 1) {
+        if (!guess) return fail(c, SDC_ERR_PARAM, "the Newton solver needs an initial guess");
+        {
+            LaunchTimer lt(c, "vdp_solve");
+            hipLaunchKernelGGL(k_vdp_solve, dim3(grid_for(c->N / 2, 256)), dim3(256), 0, c->stream, rhs, guess, out,
+                               c->N / 2, factor, c->vdp_mu, c->vdp_tol, c->vdp_maxiter, c->counters);
+        }
+        HIPCHK(c, hipGetLastError());
+        return vdp_check_failures(c);
+    }
     FieldPtrs p;
     memset(&p, 0, sizeof p);
     ZArgs z;
@@ -1865,52 +1989,6 @@ int sdc_vec_amax(sdc_ctx* c, size_t n, const double* x, double* out) {
     HIPCHK(c, hipMemcpyAsync(c->red_host + 9, c->red + 9, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     memcpy(out, &c->red_host[9], sizeof(double));
-    return SDC_OK;
-}
-
-int sdc_vdp_step(sdc_ctx* c, size_t ntraj, double* x1, double* x2, double mu, double dt, int nsweeps,
-                 double newton_tol, int newton_maxiter, unsigned long long* counters, double* max_residual) {
-    if (!c || !x1 || !x2) return fail(c, SDC_ERR_PARAM, "null pointer");
-    if (!c->have_coeffs) return fail(c, SDC_ERR_STATE, "coefficients not set (sdc_set_coeffs)");
-    VdpArgs a;
-    memset(&a, 0, sizeof a);
-    a.x1 = x1;
-    a.x2 = x2;
-    a.ntraj = ntraj;
-    a.mu = mu;
-    a.dt = dt;
-    a.tol = newton_tol;
-    a.nsweeps = nsweeps;
-    a.maxiter = newton_maxiter;
-    for (int m = 0; m < c->M; ++m)
-        for (int j = 0; j < c->M; ++j) {
-            a.Q[m][j] = c->Q[m + 1][j + 1];
-            a.QI[m][j] = c->QI[m + 1][j + 1];
-        }
-    HIPCHK(c, hipMemsetAsync(c->red, 0, sizeof(unsigned long long) * 16, c->stream));
-    a.counters = c->red;
-    a.resmax = c->red + 4;
-    const int grid = grid_for(ntraj, 256);
-    {
-        LaunchTimer lt(c, "vdp_step");
-#define VCASE(MM) \
-    case MM: hipLaunchKernelGGL((k_vdp<MM>), dim3(grid), dim3(256), 0, c->stream, a); break;
-        switch (c->M) {
-            VCASE(1) VCASE(2) VCASE(3) VCASE(4) VCASE(5) VCASE(6) VCASE(7) VCASE(8)
-            default: return fail(c, SDC_ERR_PARAM, "num_nodes %d > %d", c->M, MAXM);
-        }
-#undef VCASE
-    }
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(c->red_host, c->red, sizeof(unsigned long long) * 16, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (counters) {
-        counters[0] = c->red_host[0];
-        counters[1] = c->red_host[1];
-    }
-    if (max_residual) memcpy(max_residual, &c->red_host[4], sizeof(double));
-    if (c->red_host[2] != 0)
-        return fail(c, SDC_ERR_NEWTON, "Newton did not converge (or got nan) for %llu trajectories", c->red_host[2]);
     return SDC_OK;
 }
 

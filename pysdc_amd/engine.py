@@ -135,8 +135,16 @@ class SweepEngine:
     def eval_f(self, u_ptr, g_t, fi_ptr, fe_ptr=None):
         self._chk(self.lib.sdc_eval_f(self.ctx, u_ptr, g_t, fi_ptr, fe_ptr))
 
-    def solve(self, rhs_ptr, factor, out_ptr):
-        self._chk(self.lib.sdc_solve(self.ctx, rhs_ptr, factor, out_ptr))
+    def solve(self, rhs_ptr, factor, out_ptr, guess_ptr=None):
+        self._chk(self.lib.sdc_solve(self.ctx, rhs_ptr, factor, guess_ptr, out_ptr))
+
+    def set_problem_vdp(self, mu, newton_tol, newton_maxiter):
+        self._chk(self.lib.sdc_set_problem_vdp(self.ctx, float(mu), float(newton_tol), int(newton_maxiter)))
+
+    def work_counters(self):
+        out = (C.c_ulonglong * 3)()
+        self._chk(self.lib.sdc_work_counters(self.ctx, out))
+        return dict(newton=int(out[0]), rhs=int(out[1]), failed=int(out[2]))
 
     # ---- vectors ----
     def vec_copy(self, n, x, y):
@@ -180,10 +188,3 @@ class SweepEngine:
     @property
     def device_bytes(self):
         return int(self.lib.sdc_ctx_bytes(self.ctx))
-
-    def vdp_step(self, ntraj, x1_ptr, x2_ptr, mu, dt, nsweeps, newton_tol=1e-9, newton_maxiter=100):
-        counters = (C.c_ulonglong * 2)()
-        res = C.c_double()
-        self._chk(self.lib.sdc_vdp_step(self.ctx, ntraj, x1_ptr, x2_ptr, mu, dt, nsweeps, newton_tol,
-                                        newton_maxiter, counters, C.byref(res)))
-        return dict(newton=int(counters[0]), rhs=int(counters[1]), residual=res.value)

@@ -63,7 +63,7 @@ class SlabList:
     def _view(self, m):
         if self._views[m] is None:
             e = self._L.engine
-            shape = e.nvars
+            shape = self._L._field_shape()
             cb = lambda slot=self._slot, m=m: self._L._touched(slot, m)  # noqa: E731
             if self._imex:
                 self._views[m] = hip_imex_mesh.view(e.ptr(self._slot, m, 0), e.ptr(self._slot, m, 1), shape, keep=e,
@@ -168,7 +168,7 @@ class Level:
             return None
         if self._uend_view is None:
             e = self.engine
-            self._uend_view = hip_mesh.view(e.ptr(Lb.SLOT_UEND), e.nvars, keep=e)
+            self._uend_view = hip_mesh.view(e.ptr(Lb.SLOT_UEND), self._field_shape(), keep=e)
         return self._uend_view
 
     @uend.setter
@@ -180,6 +180,10 @@ class Level:
         v = self.uend
         if value is not v:
             v[:] = value
+
+    def _field_shape(self):
+        shape = self.__prob.init[0]
+        return (int(shape),) if np.isscalar(shape) else tuple(shape)
 
     def _activate_tau(self):
         e = self.engine

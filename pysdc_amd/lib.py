@@ -43,13 +43,13 @@ PROTOTYPES = {
     'sdc_end_point': (C.c_int, [_vp, C.c_double, C.c_int]),
     'sdc_integrate': (C.c_int, [_vp, C.c_double, C.POINTER(_vp)]),
     'sdc_eval_f': (C.c_int, [_vp, _vp, C.c_double, _vp, _vp]),
-    'sdc_solve': (C.c_int, [_vp, _vp, C.c_double, _vp]),
+    'sdc_solve': (C.c_int, [_vp, _vp, C.c_double, _vp, _vp]),
     'sdc_vec_copy': (C.c_int, [_vp, C.c_size_t, _vp, _vp]),
     'sdc_vec_fill': (C.c_int, [_vp, C.c_size_t, C.c_double, _vp]),
     'sdc_vec_axpby': (C.c_int, [_vp, C.c_size_t, C.c_double, _vp, C.c_double, _vp, _vp]),
     'sdc_vec_amax': (C.c_int, [_vp, C.c_size_t, _vp, _dp]),
-    'sdc_vdp_step': (C.c_int, [_vp, C.c_size_t, _vp, _vp, C.c_double, C.c_double, C.c_int, C.c_double, C.c_int,
-                               C.POINTER(C.c_ulonglong), _dp]),
+    'sdc_set_problem_vdp': (C.c_int, [_vp, C.c_double, C.c_double, C.c_int]),
+    'sdc_work_counters': (C.c_int, [_vp, C.POINTER(C.c_ulonglong)]),
     'sdc_sync': (C.c_int, [_vp]),
     'sdc_timer_begin': (C.c_int, [_vp]),
     'sdc_timer_end': (C.c_int, [_vp, _dp]),

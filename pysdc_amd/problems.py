@@ -325,3 +325,84 @@ class advectiondiffusionNd_imex(GenericNDimFinDiff):
             sol = sol * np.sin(np.pi * self.freq[i] * (g[i] - self.c * t))
         rho = sum((2.0 - 2.0 * np.cos(np.pi * f * self.dx)) / self.dx**2 for f in self.freq)
         return self._from_host(np.broadcast_to(sol * np.exp(-t * self.nu * rho), self.nvars))
+
+
+class _DeviceCounter:
+    """work counter whose value lives on the device (summed over trajectories); reading synchronises."""
+
+    def __init__(self, prob, key):
+        self._p, self._k = prob, key
+
+    @property
+    def niter(self):
+        return self._p.engine.work_counters()[self._k]
+
+    def __call__(self, *args, **kwargs):  # counting happens in the kernels
+        pass
+
+    def __str__(self):
+        return f'{self.niter}'
+
+
+class vanderpol_ensemble(Problem):
+    """``ntraj`` independent van der Pol oscillators  x1' = x2,  x2' = mu (1 - x1^2) x2 - x1  as one level with
+    state ``[x1[ntraj], x2[ntraj]]`` (shape (2, ntraj)).  Per trajectory it is the reference's ``vanderpol``
+    (Van_der_Pol_implicit.py:10-201): same right-hand side, same Newton iteration with the closed-form 2x2
+    inverse, same stopping rule ``max|g| < newton_tol`` / NaN / ``newton_maxiter`` and the same failure
+    behaviour (``ProblemError``).  BASELINE config 4."""
+
+    fused = True
+
+    def __init__(self, ntraj=1, u0=None, mu=5.0, newton_maxiter=100, newton_tol=1e-9, stop_at_nan=True,
+                 crash_at_maxiter=True, relative_tolerance=False):
+        if relative_tolerance:
+            raise ProblemError('relative_tolerance is not available in the ensemble kernels')
+        if not (stop_at_nan and crash_at_maxiter):
+            raise ProblemError('the ensemble kernels always report Newton failures (stop_at_nan / crash_at_maxiter)')
+        ntraj = int(ntraj)
+        if u0 is None:
+            u0 = (2.0, 0.0)
+        u0 = np.asarray(u0, dtype=float)
+        if u0.shape == (2,):
+            u0 = np.repeat(u0[:, None], ntraj, axis=1)
+        if u0.shape != (2, ntraj):
+            raise ProblemError(f'u0 must have shape (2,) or (2, {ntraj}), got {u0.shape}')
+        super().__init__(init=((2, ntraj), None, np.dtype('float64')))
+        nvars = (2 * ntraj,)
+        self._makeAttributeAndRegister('nvars', 'ntraj', localVars=locals(), readOnly=True)
+        self._makeAttributeAndRegister('mu', 'newton_maxiter', 'newton_tol', 'stop_at_nan', 'crash_at_maxiter',
+                                       'relative_tolerance', localVars=locals())
+        self._u0 = u0
+        self.work_counters['newton'] = _DeviceCounter(self, 'newton')
+        self.work_counters['rhs'] = _DeviceCounter(self, 'rhs')
+
+    @property
+    def u0(self):
+        return self._u0
+
+    @classmethod
+    def get_default_sweeper_class(cls):
+        from pysdc_amd.sweepers import generic_implicit
+
+        return generic_implicit
+
+    def configure_engine(self, engine):
+        engine.set_problem_vdp(self.mu, self.newton_tol, self.newton_maxiter)
+
+    def u_exact(self, t, u_init=None, t_init=None):
+        if t > 0.0:
+            raise NotImplementedError('the ensemble has no reference solution for t > 0 (the reference integrates '
+                                      'with SciPy, Van_der_Pol_implicit.py:96-103)')
+        me = self.u_init
+        me[:] = self._u0
+        return me
+
+    def eval_f(self, u, t):
+        f = self.f_init
+        self.engine.eval_f(u.ptr, 0.0, f.ptr)
+        return f
+
+    def solve_system(self, rhs, dt, u0, t):
+        sol = self.u_init
+        self.engine.solve(rhs.ptr, float(dt), sol.ptr, guess_ptr=u0.ptr)
+        return sol

@@ -133,3 +133,58 @@ def test_device_init_field_matches_host():
         host = init_field(nv, (2, 4, 2)[: len(nv)], 1e-3, 7)
         assert np.max(np.abs(e.download(Lb.SLOT_U, 0) - host)) < 1e-14
         e.close()
+
+
+def test_vdp_ensemble_vs_golden():
+    """BASELINE config 4 semantics: every trajectory of the ensemble follows the reference's vanderpol
+    (golden single-trajectory sweeps): node values <= 1e-10 relative, Newton iteration total bit-exact."""
+    from pysdc_amd.level import Step
+    from pysdc_amd.problems import vanderpol_ensemble
+    from pysdc_amd.sweepers import generic_implicit
+
+    cases = load_cases('sweeps_vdp.npz')
+    names = sorted(cases)
+    meta = cases[names[0]]['meta']
+    u0 = np.stack([cases[n]['u0'] for n in names], axis=1)          # (2, ntraj)
+    desc = dict(problem_class=vanderpol_ensemble,
+                problem_params=dict(ntraj=len(names), u0=u0, mu=5.0, newton_tol=1e-9),
+                sweeper_class=generic_implicit, sweeper_params=dict(meta['sweeper_params']),
+                level_params=dict(dt=meta['dt']), step_params=dict(maxiter=4))
+    for fused in (True, False):
+        pc = vanderpol_ensemble if fused else type('vdp_nodewise', (vanderpol_ensemble,), {'fused': False})
+        desc['problem_class'] = pc
+        S = Step(desc)
+        L = S.levels[0]
+        L.status.time = meta['t0']
+        L.u[0] = L.prob.u_exact(0.0)
+        L.sweep.predict()
+        for k in range(1, meta['nsweeps'] + 1):
+            L.sweep.update_nodes()
+            L.sweep.compute_residual()
+            U = np.stack([np.asarray(L.u[m]) for m in range(6)])     # (M+1, 2, ntraj)
+            F = np.stack([np.asarray(L.f[m]) for m in range(6)])
+            for i, n in enumerate(names):
+                assert rel_err(U[:, :, i], cases[n][f'k{k}_u']) < TOL, (n, k)
+                assert rel_err(F[:, :, i], cases[n][f'k{k}_f']) < 1e-9, (n, k)
+            ref_res = max(float(cases[n][f'k{k}_res_full_abs']) for n in names)
+            assert abs(L.status.residual - ref_res) <= 1e-9 * max(ref_res, 1e-6)
+        assert L.prob.work_counters['newton'].niter == sum(int(cases[n]['work_newton'][-1]) for n in names)
+        assert L.prob.work_counters['rhs'].niter == sum(int(cases[n]['work_rhs'][-1]) for n in names)
+
+
+def test_vdp_newton_failure_raises():
+    from pysdc_amd.level import Step
+    from pysdc_amd.problems import vanderpol_ensemble
+    from pysdc_amd.sweepers import generic_implicit
+    from pysdc_amd.errors import ProblemError
+
+    desc = dict(problem_class=vanderpol_ensemble,
+                problem_params=dict(ntraj=64, mu=5.0, newton_tol=1e-14, newton_maxiter=2),
+                sweeper_class=generic_implicit, sweeper_params=dict(num_nodes=3, quad_type='RADAU-RIGHT', QI='LU'),
+                level_params=dict(dt=0.5), step_params=dict(maxiter=4))
+    L = Step(desc).levels[0]
+    L.status.time = 0.0
+    L.u[0] = L.prob.u_exact(0.0)
+    L.sweep.predict()
+    with pytest.raises(ProblemError):
+        L.sweep.update_nodes()
