@@ -20,7 +20,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
-def kernel_bytes(name, n, M, ncomp=1):
+def _kernel_bytes(name, n, M, ncomp=1):
     """ALGORITHMIC bytes of one launch of each kernel of the sweep (DESIGN.md 'kernels'): fields read + written
     once, f64; one half spectrum = (n/2+1) n^2 complex.  Names carry the number of fields, e.g. fft_x_fwd[5]."""
     N = n**3
@@ -39,7 +39,7 @@ def kernel_bytes(name, n, M, ncomp=1):
         'fft_z_inv': 2 * nf * spec,
         'fft_y_inv': 2 * nf * spec,
         'fft_x_inv': nf * (field + spec),
-        'stencil': 2 * nf * field * ncomp if ncomp == 1 else nf * field * 3,
+        'stencil': 2 * nf * field if ncomp == 1 else 3 * nf * field,  # IMEX: one read, impl + expl written
         'residual': (1 + M * ncomp + M) * field,        # u0, F[1..M], U[1..M] -> M norms
         'spread': (2 + 2 * M) * field,
         'copy': 2 * field,
@@ -87,7 +87,10 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--n', type=int, default=1024, help='grid points per dimension (1024 = BASELINE metric)')
+    ap.add_argument('--workload', default='heat', choices=['heat', 'advdiff', 'vdp'],
+                    help='heat = BASELINE metric (default); advdiff = config 3 (IMEX); vdp = config 4 (ensemble)')
+    ap.add_argument('--n', type=int, default=None, help='grid points per dimension (heat: 1024 = BASELINE metric; advdiff: 512)')
+    ap.add_argument('--ntraj', type=int, default=10_000_000)
     ap.add_argument('--nodes', type=int, default=5)
     ap.add_argument('--sweeps', type=int, default=4)
     ap.add_argument('--qi', default='IE')
@@ -114,16 +117,47 @@ def main():
 
     from pysdc_amd import lib as Lb
     from pysdc_amd.controller import controller_nonMPI, controller_dist
-    from pysdc_amd.problems import heatNd_unforced
-    from pysdc_amd.sweepers import generic_implicit
+    from pysdc_amd.problems import heatNd_unforced, advectiondiffusionNd_imex, vanderpol_ensemble
+    from pysdc_amd.sweepers import generic_implicit, imex_1st_order
     from pysdc_amd.stats import get_sorted
 
-    n, M, K = args.n, args.nodes, args.sweeps
-    dt = 1e-3 * (512.0 / n) ** 2  # dt*nu*12/dx^2 ~ 315 at every size
-    desc = dict(problem_class=heatNd_unforced, problem_params=dict(nvars=(n, n, n), nu=0.1, freq=2, order=2),
-                sweeper_class=generic_implicit,
-                sweeper_params=dict(num_nodes=M, quad_type='RADAU-RIGHT', QI=args.qi),
-                level_params=dict(dt=dt, restol=-1.0, nsweeps=1), step_params=dict(maxiter=K))
+    M, K = args.nodes, args.sweeps
+    ncomp = 1
+    if args.workload == 'heat':
+        n = args.n or 1024
+        dt = 1e-3 * (512.0 / n) ** 2  # dt*nu*12/dx^2 ~ 315 at every size
+        desc = dict(problem_class=heatNd_unforced, problem_params=dict(nvars=(n, n, n), nu=0.1, freq=2, order=2),
+                    sweeper_class=generic_implicit,
+                    sweeper_params=dict(num_nodes=M, quad_type='RADAU-RIGHT', QI=args.qi),
+                    level_params=dict(dt=dt, restol=-1.0, nsweeps=1), step_params=dict(maxiter=K))
+        wl = (f'heatNd_unforced {n}^3 periodic order-2 FD, nu=0.1, M={M} LEGENDRE RADAU-RIGHT, QI={args.qi}, '
+              f'generic_implicit')
+        unit = 'time-steps/s'
+    elif args.workload == 'advdiff':
+        n = args.n or 512
+        ncomp = 2
+        dt = 1e-3 * (512.0 / n) ** 2
+        desc = dict(problem_class=advectiondiffusionNd_imex,
+                    problem_params=dict(nvars=(n, n, n), nu=0.02, c=1.0, freq=2, order=2),
+                    sweeper_class=imex_1st_order,
+                    sweeper_params=dict(num_nodes=M, quad_type='RADAU-RIGHT', QI=args.qi, QE='EE'),
+                    level_params=dict(dt=dt, restol=-1.0, nsweeps=1), step_params=dict(maxiter=K))
+        wl = (f'advectiondiffusionNd_imex {n}^3 periodic order-2 FD, nu=0.02 (implicit), c=1 (explicit), M={M} '
+              f'RADAU-RIGHT, QI={args.qi}, QE=EE, imex_1st_order')
+        unit = 'time-steps/s'
+    else:
+        n = 0
+        dt = 0.05
+        rng = np.random.default_rng(0)
+        u0h = rng.uniform(-2.0, 2.0, (2, args.ntraj))
+        desc = dict(problem_class=vanderpol_ensemble,
+                    problem_params=dict(ntraj=args.ntraj, u0=u0h, mu=5.0, newton_tol=1e-9, newton_maxiter=100),
+                    sweeper_class=generic_implicit, sweeper_params=dict(num_nodes=M, quad_type='RADAU-RIGHT', QI='LU'),
+                    level_params=dict(dt=dt, restol=-1.0, nsweeps=1), step_params=dict(maxiter=K))
+        wl = f'vanderpol ensemble, {args.ntraj} trajectories, mu=5, M={M} RADAU-RIGHT, QI=LU, Newton tol 1e-9'
+        unit = 'trajectory-steps/s'
+        if world > 1:
+            raise SystemExit('the ensemble shards trivially over GPUs (independent trajectories); run --gpus 1')
     if world == 1:
         ctrl = controller_nonMPI(1, dict(logger_level=40), desc)
         step = ctrl.MS[0]
@@ -133,10 +167,13 @@ def main():
     L = step.levels[0]
     eng = L.engine  # allocates the device slabs
     eng.set_spectral_reuse(not args.no_spectral_reuse)
-    # synthetic input on the device: sin mode (freq 2) + 1e-3 * seeded noise
-    u0 = L.prob.u_init
-    freq = (C.c_int * 3)(2, 2, 2)
-    Lb.check(eng.lib.sdc_init_field(eng.ctx, u0.ptr, freq, 1e-3, 0), eng.ctx)
+    if args.workload == 'vdp':
+        u0 = L.prob.u_exact(0.0)
+    else:
+        # synthetic input on the device: sin mode (freq 2) + 1e-3 * seeded noise
+        u0 = L.prob.u_init
+        freq = (C.c_int * 3)(2, 2, 2)
+        Lb.check(eng.lib.sdc_init_field(eng.ctx, u0.ptr, freq, 1e-3, 0), eng.ctx)
 
     def sync():
         torch.cuda.synchronize()
@@ -163,9 +200,18 @@ def main():
     assert niter == [K] * len(niter), niter
     finite = bool(np.isfinite(abs(uend)))
 
+    def kernel_bytes(name, n_, M_):  # noqa: F811  (workload-aware wrapper)
+        if args.workload == 'vdp':
+            T = args.ntraj
+            return {'vdp_sweep': 8.0 * T * (2 + 2 * M_ + 2 * M_ + 4 * M_), 'vdp_eval': 8.0 * T * 4,
+                    'residual': 8.0 * 2 * T * (1 + 2 * M_), 'spread': 8.0 * 2 * T * (2 + 2 * M_),
+                    'copy': 8.0 * 2 * T * 2}.get(name.split('[')[0])
+        return _kernel_bytes(name, n_, M_, ncomp)
+
     if rank == 0:
         steps_total = args.steps * world
         sweeps_total = steps_total * K
+        units = args.ntraj if args.workload == 'vdp' else 1
         # dominant kernel of the timed region, from HIP events on the engine's stream
         dom = max(prof.items(), key=lambda kv: kv[1][0]) if prof else (None, (0.0, 0))
         kern = {k: {'ms_per_launch': v[0] / v[1], 'launches': v[1],
@@ -184,24 +230,26 @@ def main():
                     'algorithmic_bytes_per_launch': kernel_bytes(dom[0], n, M),
                     'ms_per_launch': dom[1][0] / dom[1][1]}
         in_sweep = ('gather', 'fft_x_fwd', 'fft_y_fwd', 'fft_z_fwd', 'fft_z_solve', 'spec_point', 'fft_z_inv', 'fft_y_inv',
-                    'fft_x_inv', 'stencil')
+                    'fft_x_inv', 'stencil', 'vdp_sweep')
         sweep_ms = sum(v[0] for k, v in prof.items() if k.split('[')[0] in in_sweep) / max(1, sweeps_total // world)
         out = {
-            'metric': 'time-steps/s (HeatND 3-D FD, M=5, implicit SDC sweeps)', 'value': steps_total / el,
-            'unit': 'time-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'metric': {'heat': 'time-steps/s (HeatND 3-D FD, M=5, implicit SDC sweeps)',
+                       'advdiff': 'time-steps/s (advection-diffusion 3-D FD IMEX, M=5)',
+                       'vdp': 'trajectory-steps/s (van der Pol ensemble, M=5)'}[args.workload],
+            'value': units * steps_total / el, 'unit': unit, 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * el / args.steps, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': f'heatNd_unforced {n}^3 periodic order-2 FD, nu=0.1, M={M} LEGENDRE RADAU-RIGHT, '
-                                   f'QI={args.qi}, generic_implicit, {K} sweeps/step (restol=-1, maxiter={K}), '
-                                   f'dt={dt:g}, solver=direct (Fourier), spectral_reuse={not args.no_spectral_reuse}',
+            'config': {'workload': f'{wl}, {K} sweeps/step (restol=-1, maxiter={K}), dt={dt:g}, '
+                                   f'solver=direct (Fourier), spectral_reuse={not args.no_spectral_reuse}',
                        'time_parallel': f'{world} time-slice(s), one per GPU, multi-step SDC (Jacobi)'},
-            'sdc_iters_per_s': sweeps_total / el,
+            'sdc_iters_per_s': units * sweeps_total / el,
             'sweep_kernels_ms': sweep_ms,
-            'sweep_floor_gbs': 8.0 * n**3 * (3 * M + 1) / sweep_ms / 1e6 if sweep_ms else None,
+            'sweep_floor_gbs': (8.0 * n**3 * ((3 if ncomp == 1 else 5) * M + 1) / sweep_ms / 1e6
+                                if sweep_ms and n else None),
             'roofline': roof, 'kernels': kern, 'finite': finite,
             'device_bytes_per_gpu': eng.device_bytes,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == 'heat':
             try:
                 out['cpu_baseline'] = cpu_baseline(M, dt, target_n=n)
             except Exception as e:  # pragma: no cover

@@ -57,6 +57,7 @@ struct sdc_ctx {
     double vdp_mu = 0, vdp_tol = 1e-9;
     int vdp_maxiter = 100;
     unsigned long long* counters = nullptr;  // device: [0] newton, [1] rhs, [2] failed solves
+    unsigned long long rhs_host = 0;         // evaluations the reference would have made where the engine copies
     double Q[MAXM + 1][MAXM + 1], QI[MAXM + 1][MAXM + 1], QE[MAXM + 1][MAXM + 1], nodes[MAXM], weights[MAXM];
     double gvals[MAXM + 1];
     Stencil st[2];
@@ -1532,6 +1533,7 @@ int sdc_work_counters(sdc_ctx* c, unsigned long long* out) {
     HIPCHK(c, hipMemcpyAsync(c->red_host + 12, c->counters, sizeof(unsigned long long) * 3, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (int k = 0; k < 3; ++k) out[k] = c->red_host[12 + k];
+    out[1] += c->rhs_host;
     return SDC_OK;
 }
 
@@ -1695,6 +1697,8 @@ int sdc_predict(sdc_ctx* c, double t, double dt, int guess, double fill_u, doubl
         hipLaunchKernelGGL(k_spread, dim3(grid_for(c->N / 2, 256)), dim3(256), 0, c->stream, a);
     }
     HIPCHK(c, hipGetLastError());
+    // 'spread' evaluates f at every node in the reference (core/sweeper.py:142-143); the engine copies F[0]
+    if (c->kind == 1 && guess == SDC_GUESS_SPREAD) c->rhs_host += (unsigned long long)c->M * (c->N / 2);
     c->unlocked = true;
     c->spec_valid = false;
     c->spec_spread = (guess == SDC_GUESS_SPREAD || guess == SDC_GUESS_COPY);  // all nodes equal U[0]
