@@ -1,0 +1,138 @@
+"""GPU parity at BASELINE sizes (512^3, 1024^3), where the oracle cannot run, through size-independent
+properties:
+  * eigenmode sweep: for u0 = an eigenvector of the periodic Laplacian every node value is a scalar multiple
+    of u0, the scalars being those of the reference's sweep on the scalar test equation (the property
+    tests/test_sweepers/test_imexsweeper.py:110-128 checks in matrix form);
+  * solve round trip: (I - factor*A) applied to the result of solve_system returns the right-hand side;
+  * the two sweep data flows (spectral reuse / gather on F) agree on a noisy field.
+All comparisons run on the device (axpby + max norm), no multi-GB host copies."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from pysdc_amd import lib as L
+from tests import _gpu as G
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_gb():
+    import torch
+
+    return torch.cuda.mem_get_info()[0] / 1e9
+
+
+def _coeffs(M, QI='IE'):
+    from pysdc_amd.coeffs import CollBase, QDELTA_GENERATORS
+
+    c = CollBase(M, 0, 1, 'LEGENDRE', 'RADAU-RIGHT')
+    qi = np.zeros_like(c.Qmat)
+    qi[1:, 1:] = QDELTA_GENERATORS[QI](qGen=c.generator, tLeft=0).genCoeffs()
+    return c, qi
+
+
+def _scalar_sweeps(lam, dt, c, qi, nsweeps):
+    """the reference's generic_implicit sweep on u' = lam*u, u0 = 1, spread predictor."""
+    M = c.num_nodes
+    u = np.ones(M + 1)
+    f = lam * u
+    out = []
+    for _ in range(nsweeps):
+        integral = np.array([sum(dt * c.Qmat[m + 1, j] * f[j] for j in range(1, M + 1)) for m in range(M)])
+        for m in range(M):
+            for j in range(1, M + 1):
+                integral[m] -= dt * qi[m + 1, j] * f[j]
+            integral[m] += u[0]
+        for m in range(M):
+            rhs = integral[m]
+            for j in range(1, m + 1):
+                rhs += dt * qi[m + 1, j] * f[j]
+            u[m + 1] = rhs / (1.0 - dt * qi[m + 1, m + 1] * lam)
+            f[m + 1] = lam * u[m + 1]
+        out.append(u.copy())
+    return out
+
+
+@pytest.mark.parametrize('n,QI,reuse', [(512, 'IE', True), (512, 'LU', False), (1024, 'IE', True)])
+def test_eigenmode_sweep_fullsize(n, QI, reuse):
+    need = 8e-9 * n**3 * (24 if reuse else 19)
+    if _free_gb() < need + 4:
+        pytest.skip(f'needs {need:.0f} GB of HBM')
+    M, nu = 5, 0.1
+    dt = 1e-3 * (512.0 / n) ** 2
+    e = G.engine_for('heat_unforced', dict(nvars=(n, n, n), nu=nu), M)
+    c, qi = _coeffs(M, QI)
+    e.set_coeffs(c.Qmat, qi, None, c.nodes, c.weights)
+    e.set_spectral_reuse(reuse)
+    freq = (C.c_int * 3)(2, 2, 2)
+    L.check(e.lib.sdc_init_field(e.ctx, e.ptr(L.SLOT_U, 0), freq, 0.0, 0), e.ctx)
+    e.invalidate_spectra(1)
+    dx = 1.0 / n
+    lam = 3.0 * nu * (2.0 * np.cos(2.0 * np.pi / n) - 2.0) / dx**2      # discrete eigenvalue of sin(2 pi x) per axis
+    e.predict(0.0, dt)
+    expected = _scalar_sweeps(lam, dt, c, qi, 3)
+    u0n = e.vec_amax(e.N, e.ptr(L.SLOT_U, 0))
+    assert abs(u0n - 1.0) < 1e-12
+    tmp = e.ptr(L.SLOT_UEND)
+    for k in range(3):
+        e.sweep(0.0, dt)
+        for m in range(1, M + 1):
+            # U[m] - c_m * U[0]  and  F[m] - lam * c_m * U[0]
+            e.vec_axpby(e.N, 1.0, e.ptr(L.SLOT_U, m), -expected[k][m], e.ptr(L.SLOT_U, 0), tmp)
+            assert e.vec_amax(e.N, tmp) < 1e-12, (k, m)
+            e.vec_axpby(e.N, 1.0, e.ptr(L.SLOT_F, m), -lam * expected[k][m], e.ptr(L.SLOT_U, 0), tmp)
+            assert e.vec_amax(e.N, tmp) < 1e-10 * abs(lam), (k, m)
+    # collocation residual of the scalar problem
+    res, _ = e.residual(dt)
+    u = expected[-1]
+    ref = max(abs(1.0 + dt * sum(c.Qmat[m, j] * lam * u[j] for j in range(1, M + 1)) - u[m]) for m in range(1, M + 1))
+    assert abs(res - ref) < 1e-11
+    e.close()
+
+
+@pytest.mark.parametrize('n', [512, 1024])
+def test_solve_roundtrip_fullsize(n):
+    if _free_gb() < 8e-9 * n**3 * 10 + 4:
+        pytest.skip('not enough HBM')
+    nu = 0.1
+    e = G.engine_for('heat_unforced', dict(nvars=(n, n, n), nu=nu), 2)
+    freq = (C.c_int * 3)(2, 4, 6)
+    rhs, sol, back = e.ptr(L.SLOT_U, 0), e.ptr(L.SLOT_U, 1), e.ptr(L.SLOT_U, 2)
+    L.check(e.lib.sdc_init_field(e.ctx, rhs, freq, 0.5, 3), e.ctx)          # O(1) noise: all modes excited
+    factor = 63.0 / (12.0 * nu * n * n)
+    e.solve(rhs, factor, sol)
+    e.eval_f(sol, 0.0, e.ptr(L.SLOT_F, 0))                                  # A sol
+    e.vec_axpby(e.N, 1.0, sol, -factor, e.ptr(L.SLOT_F, 0), back)           # (I - factor A) sol
+    e.vec_axpby(e.N, 1.0, back, -1.0, rhs, back)
+    assert e.vec_amax(e.N, back) < 1e-12 * e.vec_amax(e.N, rhs)
+    e.close()
+
+
+def test_reuse_and_gather_paths_agree_fullsize():
+    n, M = 512, 5
+    if _free_gb() < 8e-9 * n**3 * 45 + 4:
+        pytest.skip('not enough HBM')
+    dt = 1e-3
+    c, qi = _coeffs(M, 'IE')
+    engines = []
+    for reuse in (True, False):
+        e = G.engine_for('heat_unforced', dict(nvars=(n, n, n), nu=0.1), M)
+        e.set_coeffs(c.Qmat, qi, None, c.nodes, c.weights)
+        e.set_spectral_reuse(reuse)
+        freq = (C.c_int * 3)(2, 2, 2)
+        L.check(e.lib.sdc_init_field(e.ctx, e.ptr(L.SLOT_U, 0), freq, 1e-3, 0), e.ctx)
+        e.invalidate_spectra(1)
+        e.predict(0.0, dt)
+        for _ in range(3):
+            e.sweep(0.0, dt)
+        engines.append(e)
+    a, b = engines
+    tmp = a.ptr(L.SLOT_UEND)
+    for m in range(1, M + 1):
+        a.vec_axpby(a.N, 1.0, a.ptr(L.SLOT_U, m), -1.0, b.ptr(L.SLOT_U, m), tmp)
+        assert a.vec_amax(a.N, tmp) < 1e-13
+    ra, rb = a.residual(dt)[0], b.residual(dt)[0]
+    assert abs(ra - rb) < 1e-11
+    for e in engines:
+        e.close()
