@@ -80,7 +80,10 @@ int sdc_set_tau_active(sdc_ctx* ctx, int active); /* L.tau[m] is None  <->  0 */
  * so: which = 1: U[0] changed, 2: some U[m >= 1] changed, 4: some F[m >= 1] was overwritten (the next sweep then
  * gathers on the F slab like the reference does); bits combine.  sdc_upload / sdc_predict do it themselves. */
 int sdc_invalidate_spectra(sdc_ctx* ctx, int which);
-int sdc_set_spectral_reuse(sdc_ctx* ctx, int on); /* default on; 0 = transform the gathered fields every sweep */
+int sdc_set_spectral_reuse(sdc_ctx* ctx, int on);
+/* L.status.unlocked: set by sdc_predict; a coarse level is unlocked by the restriction instead
+ * (pySDC/core/base_transfer.py:166) - the host mirrors that here. */
+int sdc_set_unlocked(sdc_ctx* ctx, int unlocked); /* default on; 0 = transform the gathered fields every sweep */
 /* Synthetic input generated on the device (no multi-GB host arrays): dst[i] = prod_d sin(pi*freq[d]*x_d) on
  * the grid of generic_ND_FD.py:171-180 (the u_exact(0) of HeatEquation_ND_FD.py:103-132) + amp * g(i), g a
  * standard normal from splitmix64(seed, i) + Box-Muller; host equivalent: pysdc_amd.synth.init_field. */
@@ -129,6 +132,15 @@ int sdc_set_problem_vdp(sdc_ctx* ctx, double mu, double newton_tol, int newton_m
 /* out[0] = Newton iterations, out[1] = right-hand side evaluations, out[2] = failed solves (pending), summed
  * over trajectories since context creation (work_counters of Van_der_Pol_implicit.py:71-73). */
 int sdc_work_counters(sdc_ctx* ctx, unsigned long long* out);
+
+/* ---- space transfer between nested periodic grids (coarsening factor 2) -------------------------------- *
+ * mesh_to_mesh (transfer_classes/TransferMesh.py:9-218) for periodic, equidistant, nested grids: the
+ * interpolation matrix of helpers/transfer_helper.py:153-186 applied matrix-free as a tensor product:
+ *   fine[2i] = coarse[i],  fine[2i+1] = sum_j w[j] coarse[i - k/2 + 1 + j]            (k = iorder, even)
+ * and the restriction 0.5^ndim * P_rorder^T (k = rorder; k = 0: injection).  nc = coarse points per axis.
+ * Context-free (two levels are involved); errors are reported through sdc_last_error(NULL). */
+int sdc_transfer_prolong(void* stream, int ndim, int nc, int k, const double* w, const double* coarse, double* fine);
+int sdc_transfer_restrict(void* stream, int ndim, int nc, int k, const double* w, const double* fine, double* coarse);
 
 /* ---- stream / timing ------------------------------------------------------------------------------------ */
 int sdc_sync(sdc_ctx* ctx);

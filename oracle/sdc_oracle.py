@@ -775,3 +775,84 @@ def fmt_float(x):
 def isclose_rel(a, b, tol):
     """max |a-b| / max |b|."""
     return float(np.max(np.abs(np.asarray(a) - np.asarray(b)))) / max(float(np.max(np.abs(b))), math.ulp(0.0))
+
+
+# ----------------------------------------------------------------------------------------------
+# space transfer between nested periodic grids (helpers/transfer_helper.py, transfer_classes/TransferMesh.py)
+# ----------------------------------------------------------------------------------------------
+def interpolation_matrix_1d_periodic(fine_grid, coarse_grid, k):
+    """helpers/transfer_helper.py:153-186 (periodic, equidist_nested branch): even fine points copy their
+    coarse twin, odd ones interpolate the k nearest coarse points with barycentric Lagrange polynomials."""
+    from scipy.interpolate import BarycentricInterpolator
+
+    M = np.zeros((fine_grid.size, coarse_grid.size))
+    for i, p in enumerate(fine_grid):
+        if i % 2 == 0:
+            M[i, int(i / 2)] = 1.0
+            continue
+        if k == 0:
+            continue
+        nn = []
+        cpos, offset = int(i / 2), int(k / 2)
+        for j in range(k):
+            nn.append(cpos - offset + 1 + j)
+            if nn[-1] < 0:
+                nn[-1] += coarse_grid.size
+            elif nn[-1] > coarse_grid.size - 1:
+                nn[-1] -= coarse_grid.size
+        nn = sorted(nn)
+        # periodic continuation of the coarse nodes (transfer_helper.py:72-92)
+        d = np.diff(nn)
+        if np.all(d == 1):
+            cont = coarse_grid[nn].astype(float)
+        else:
+            cont, shift = [coarse_grid[nn[0]]], 0.0
+            for n_, d_ in zip(nn[1:], d):
+                if d_ != 1:
+                    shift = -1
+                cont.append(coarse_grid[n_] + shift)
+            cont = np.asarray(cont, dtype=float)
+        if p > np.mean(fine_grid) and not (cont[0] <= p <= cont[-1]):
+            cont = cont + 1
+        one = np.asarray([1.0] + [0.0] * (k - 1))
+        with np.errstate(divide='ignore'):
+            M[i, nn] = np.asarray([BarycentricInterpolator(cont, np.roll(one, l))(p) for l in range(k)])
+    return sp.csc_matrix(M)
+
+
+class MeshToMesh:
+    """transfer_classes/TransferMesh.py:25-146 (periodic): P = kron of 1-D interpolation matrices of order
+    iorder, R = kron of restr_factor * (interpolation matrix of order rorder)^T; :148-218 restrict / prolong
+    (component-wise for imex arrays of shape (2, *nvars))."""
+
+    def __init__(self, nvars_fine, nvars_coarse, iorder=2, rorder=2):
+        nf = (nvars_fine,) if isinstance(nvars_fine, int) else tuple(nvars_fine)
+        nc = (nvars_coarse,) if isinstance(nvars_coarse, int) else tuple(nvars_coarse)
+        self.nf, self.nc = nf, nc
+        P, R = [], []
+        for a in range(len(nf)):
+            if nf == nc:
+                P.append(sp.eye(nf[a]))
+                R.append(sp.eye(nc[a]))
+                continue
+            fg = np.array([j * (1.0 / nf[a]) for j in range(nf[a])])
+            cg = np.array([j * (1.0 / nc[a]) for j in range(nc[a])])
+            P.append(interpolation_matrix_1d_periodic(fg, cg, iorder))
+            factor = 0.5 if rorder > 0 else 1.0
+            R.append(factor * (P[-1] if iorder == rorder else interpolation_matrix_1d_periodic(fg, cg, rorder)).T)
+        self.P, self.R = P[0], R[0]
+        for a in range(1, len(nf)):
+            self.P = sp.kron(self.P, P[a], format='csc')
+            self.R = sp.kron(self.R, R[a], format='csc')
+
+    def _apply(self, Mx, x, shape_in, shape_out):
+        x = np.asarray(x)
+        if x.shape == shape_in:
+            return Mx.dot(x.flatten()).reshape(shape_out)
+        return np.stack([Mx.dot(x[c].flatten()).reshape(shape_out) for c in range(x.shape[0])])
+
+    def restrict(self, F):
+        return self._apply(self.R, F, self.nf, self.nc)
+
+    def prolong(self, G):
+        return self._apply(self.P, G, self.nc, self.nf)

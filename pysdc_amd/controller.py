@@ -77,7 +77,8 @@ class _ControllerBase:
 class controller_nonMPI(_ControllerBase):
     def __init__(self, num_procs, controller_params, description):
         super().__init__(controller_params, description)
-        self.MS = [Step(description) for _ in range(num_procs)]
+        step_class = description.get('step_class', Step)
+        self.MS = [step_class(description) for _ in range(num_procs)]
         self._uend_buf = None
         self.nsweeps = [L.params.nsweeps for L in self.MS[0].levels]
         self.nlevels = len(self.MS[0].levels)
@@ -173,8 +174,8 @@ class controller_nonMPI(_ControllerBase):
         else:
             raise ControllerError('not all stages are equal')
         MS_running = [S for S in local_MS_active if S.status.stage != 'DONE']
-        switcher = {'SPREAD': self.spread, 'IT_CHECK': self.it_check, 'IT_FINE': self.it_fine,
-                    'IT_COARSE': self.it_coarse}
+        switcher = {'SPREAD': self.spread, 'PREDICT': self.predict, 'IT_CHECK': self.it_check,
+                    'IT_FINE': self.it_fine, 'IT_DOWN': self.it_down, 'IT_COARSE': self.it_coarse, 'IT_UP': self.it_up}
         if stage not in switcher:
             raise ControllerError('Unknown stage, got %s' % stage)
         switcher[stage](MS_running)
@@ -184,6 +185,44 @@ class controller_nonMPI(_ControllerBase):
         for S in local_MS_running:
             self._hook('pre_step', S)
             S.levels[0].sweep.predict()
+            S.status.stage = 'PREDICT' if len(S.levels) > 1 else 'IT_CHECK'
+
+    # controller_nonMPI.py:358-477
+    def predict(self, local_MS_running):
+        for S in local_MS_running:
+            self._hook('pre_predict', S)
+        pt = self.params.predict_type
+        if pt is None:
+            pass
+        elif pt == 'fine_only':
+            for S in local_MS_running:
+                S.levels[0].sweep.update_nodes()
+        elif pt == 'pfasst_burnin':
+            for S in local_MS_running:
+                for l in range(1, len(S.levels)):
+                    S.transfer(source=S.levels[l - 1], target=S.levels[l])
+            for q in range(len(local_MS_running)):
+                for p in range(q, len(local_MS_running)):
+                    S = local_MS_running[p]
+                    S.levels[-1].sweep.update_nodes()
+                    self.send_full(S, level=len(S.levels) - 1)
+                for p in range(q + 1, len(local_MS_running)):
+                    S = local_MS_running[p]
+                    self.recv_full(S, level=len(S.levels) - 1, add_to_stats=(p == len(local_MS_running) - 1))
+            for S in local_MS_running:
+                for l in range(len(S.levels) - 1, 0, -1):
+                    S.transfer(source=S.levels[l], target=S.levels[l - 1])
+                self.send_full(S, level=0)
+                self.recv_full(S, level=0)
+            for S in local_MS_running:
+                S.levels[0].sweep.update_nodes()
+        elif pt == 'fmg':
+            raise NotImplementedError('FMG predictor is not yet implemented')
+        else:
+            raise ControllerError('Wrong predictor type, got %s' % pt)
+        for S in local_MS_running:
+            self._hook('post_predict', S)
+        for S in local_MS_running:
             S.status.stage = 'IT_CHECK'
 
     # controller_nonMPI.py:479-543
@@ -206,7 +245,9 @@ class controller_nonMPI(_ControllerBase):
             if not S.status.done:
                 S.status.iter += 1
                 self._hook('pre_iteration', S)
-                if len(local_MS_running) == 1 or self.params.mssdc_jac:
+                if len(S.levels) > 1:
+                    S.status.stage = 'IT_DOWN'
+                elif len(local_MS_running) == 1 or self.params.mssdc_jac:
                     S.status.stage = 'IT_FINE'
                 else:
                     S.status.stage = 'IT_COARSE'
@@ -234,16 +275,54 @@ class controller_nonMPI(_ControllerBase):
         for S in local_MS_running:
             S.status.stage = 'IT_CHECK'
 
-    # controller_nonMPI.py:636-666 (single level: serial multi-step SDC)
+    # controller_nonMPI.py:584-634
+    def it_down(self, local_MS_running):
+        for S in local_MS_running:
+            S.transfer(source=S.levels[0], target=S.levels[1])
+        for l in range(1, self.nlevels - 1):
+            for _ in range(self.nsweeps[l]):
+                for S in local_MS_running:
+                    self.send_full(S, level=l)
+                    self.recv_full(S, level=l)
+                for S in local_MS_running:
+                    self._hook('pre_sweep', S, l)
+                    S.levels[l].sweep.update_nodes()
+                    S.levels[l].sweep.compute_residual(stage='IT_DOWN')
+                    self._hook('post_sweep', S, l)
+            for S in local_MS_running:
+                S.transfer(source=S.levels[l], target=S.levels[l + 1])
+        for S in local_MS_running:
+            S.status.stage = 'IT_COARSE'
+
+    # controller_nonMPI.py:636-666
     def it_coarse(self, local_MS_running):
         for S in local_MS_running:
-            self.recv_full(S, level=0)
-            self._hook('pre_sweep', S)
-            S.levels[0].sweep.update_nodes()
-            S.levels[0].sweep.compute_residual(stage='IT_COARSE')
-            self._hook('post_sweep', S)
-            self.send_full(S, level=0, add_to_stats=True)
-            S.status.stage = 'IT_CHECK'
+            lc = len(S.levels) - 1
+            self.recv_full(S, level=lc)
+            self._hook('pre_sweep', S, lc)
+            S.levels[-1].sweep.update_nodes()
+            S.levels[-1].sweep.compute_residual(stage='IT_COARSE')
+            self._hook('post_sweep', S, lc)
+            self.send_full(S, level=lc, add_to_stats=True)
+            S.status.stage = 'IT_UP' if len(S.levels) > 1 else 'IT_CHECK'
+
+    # controller_nonMPI.py:668-689
+    def it_up(self, local_MS_running):
+        for l in range(self.nlevels - 1, 0, -1):
+            for S in local_MS_running:
+                S.transfer(source=S.levels[l], target=S.levels[l - 1])
+            if l - 1 > 0:
+                for k in range(self.nsweeps[l - 1]):
+                    for S in local_MS_running:
+                        self.send_full(S, level=l - 1)
+                        self.recv_full(S, level=l - 1, add_to_stats=(k == self.nsweeps[l - 1] - 1))
+                    for S in local_MS_running:
+                        self._hook('pre_sweep', S, l - 1)
+                        S.levels[l - 1].sweep.update_nodes()
+                        S.levels[l - 1].sweep.compute_residual(stage='IT_UP')
+                        self._hook('post_sweep', S, l - 1)
+        for S in local_MS_running:
+            S.status.stage = 'IT_FINE'
 
 
 class controller_dist(_ControllerBase):
@@ -267,7 +346,7 @@ class controller_dist(_ControllerBase):
         self.S = description.get('step_class', Step)(description)
         self.S.status.slot = self.rank
         self.nsweeps = [L.params.nsweeps for L in self.S.levels]
-        self.req_send = None
+        self.req_send = [None] * len(self.S.levels)
 
     # ---- host-side scalars (check_convergence.py:105-160; controller_MPI.py:90,120,142) ---------------------
     def _send_flag(self, value, dst):
@@ -343,7 +422,7 @@ class controller_dist(_ControllerBase):
             lvl.tag = None
             lvl.status.sweep = 1
             lvl.status.time = time
-        self.req_send = None
+        self.req_send = [None] * len(S.levels)
 
     # controller_MPI.py:235-305.  send_full followed by recv_full is issued as ONE batched P2P group
     # (ncclGroupStart/End under RCCL) so that the send to rank+1 and the receive from rank-1 progress
@@ -355,9 +434,9 @@ class controller_dist(_ControllerBase):
         ops = []
         tag = level * 100 + S.status.iter
         if send:
-            if self.req_send is not None:
-                self.req_send.wait()  # the previous message still reads UEND
-                self.req_send = None
+            if self.req_send[level] is not None:
+                self.req_send[level].wait()  # the previous message still reads UEND
+                self.req_send[level] = None
             L.sweep.compute_end_point()
             if not S.status.last:
                 ops.append(self.dist.P2POp(self.dist.isend, L.uend.as_torch(), self.rank + 1, self.comm, tag))
@@ -368,12 +447,12 @@ class controller_dist(_ControllerBase):
             reqs = self.dist.batch_isend_irecv(ops)
             sending = send and not S.status.last
             if sending:
-                self.req_send = reqs[0]  # waited for before UEND is overwritten again ("send and forget")
+                self.req_send[level] = reqs[0]  # waited for before UEND is overwritten again ("send and forget")
             for r in reqs[(1 if sending else 0):]:
                 r.wait()
-            if blocking_send and self.req_send is not None:
-                self.req_send.wait()
-                self.req_send = None
+            if blocking_send and self.req_send[level] is not None:
+                self.req_send[level].wait()
+                self.req_send[level] = None
         if do_recv:
             L._touched(0, 0)  # u[0] was overwritten by the receive
             L.f[0] = L.prob.eval_f(L.u[0], L.time)
@@ -385,13 +464,19 @@ class controller_dist(_ControllerBase):
         if stage == 'SPREAD':
             self._hook('pre_step', S)
             S.levels[0].sweep.predict()
-            S.status.stage = 'IT_CHECK'
+            S.status.stage = 'PREDICT' if len(S.levels) > 1 else 'IT_CHECK'
+        elif stage == 'PREDICT':
+            self.predict()
         elif stage == 'IT_CHECK':
             self.it_check(size)
         elif stage == 'IT_FINE':
             self.it_fine()
+        elif stage == 'IT_DOWN':
+            self.it_down()
         elif stage == 'IT_COARSE':
             self.it_coarse()
+        elif stage == 'IT_UP':
+            self.it_up()
         else:
             raise ControllerError('Unknown stage, got %s' % stage)
 
@@ -416,14 +501,17 @@ class controller_dist(_ControllerBase):
         if not S.status.done:
             S.status.iter += 1
             self._hook('pre_iteration', S)
-            if size == 1 or self.params.mssdc_jac:
+            if len(S.levels) > 1:
+                S.status.stage = 'IT_DOWN'
+            elif size == 1 or self.params.mssdc_jac:
                 S.status.stage = 'IT_FINE'
             else:
                 S.status.stage = 'IT_COARSE'
         else:
-            if self.req_send is not None:
-                self.req_send.wait()
-                self.req_send = None
+            for l, req in enumerate(self.req_send):
+                if req is not None:
+                    req.wait()
+                    self.req_send[l] = None
             self._hook('post_step', S)
             S.status.stage = 'DONE'
 
@@ -442,14 +530,71 @@ class controller_dist(_ControllerBase):
             self._hook('post_sweep', S)
         S.status.stage = 'IT_CHECK'
 
-    # controller_MPI.py:736-768 (single level: Gauss-Seidel-like multi-step SDC)
+    # controller_MPI.py:482-536: predictor with burn-in on the coarsest level
+    def predict(self):
+        S = self.S
+        self._hook('pre_predict', S)
+        pt = self.params.predict_type
+        lc = len(S.levels) - 1
+        if pt is None:
+            pass
+        elif pt == 'fine_only':
+            S.levels[0].sweep.update_nodes()
+        elif pt == 'pfasst_burnin':
+            for l in range(1, len(S.levels)):
+                S.transfer(source=S.levels[l - 1], target=S.levels[l])
+            for p in range(S.status.slot + 1):
+                if p != 0:
+                    self.exchange(lc, send=False, recv=True)
+                S.levels[-1].sweep.update_nodes()
+                self.exchange(lc, send=True, recv=False, blocking_send=True)
+            for l in range(lc, 0, -1):
+                S.transfer(source=S.levels[l], target=S.levels[l - 1])
+            self.exchange(0)
+            S.levels[0].sweep.update_nodes()
+        else:
+            raise ControllerError('Wrong predictor type, got %s' % pt)
+        self._hook('post_predict', S)
+        S.status.stage = 'IT_CHECK'
+
+    # controller_MPI.py:702-734
+    def it_down(self):
+        S = self.S
+        S.transfer(source=S.levels[0], target=S.levels[1])
+        for l in range(1, len(S.levels) - 1):
+            for _ in range(S.levels[l].params.nsweeps):
+                self.exchange(l)
+                self._hook('pre_sweep', S, l)
+                S.levels[l].sweep.update_nodes()
+                S.levels[l].sweep.compute_residual(stage='IT_DOWN')
+                self._hook('post_sweep', S, l)
+            S.transfer(source=S.levels[l], target=S.levels[l + 1])
+        S.status.stage = 'IT_COARSE'
+
+    # controller_MPI.py:736-768: receive, sweep, blocking send on the coarsest level (the serial part)
     def it_coarse(self):
         S = self.S
-        L = S.levels[0]
-        self.exchange(0, send=False, recv=True)
-        self._hook('pre_sweep', S)
+        lc = len(S.levels) - 1
+        L = S.levels[lc]
+        self.exchange(lc, send=False, recv=True)
+        self._hook('pre_sweep', S, lc)
+        assert L.params.nsweeps == 1, 'ERROR: this controller can only work with one sweep on the coarse level'
         L.sweep.update_nodes()
         L.sweep.compute_residual(stage='IT_COARSE')
-        self._hook('post_sweep', S)
-        self.exchange(0, send=True, recv=False, blocking_send=True)
-        S.status.stage = 'IT_CHECK'
+        self._hook('post_sweep', S, lc)
+        self.exchange(lc, send=True, recv=False, blocking_send=True)
+        S.status.stage = 'IT_UP' if len(S.levels) > 1 else 'IT_CHECK'
+
+    # controller_MPI.py:770-801
+    def it_up(self):
+        S = self.S
+        for l in range(len(S.levels) - 1, 0, -1):
+            S.transfer(source=S.levels[l], target=S.levels[l - 1])
+            if l - 1 > 0:
+                for k in range(S.levels[l - 1].params.nsweeps):
+                    self.exchange(l - 1)
+                    self._hook('pre_sweep', S, l - 1)
+                    S.levels[l - 1].sweep.update_nodes()
+                    S.levels[l - 1].sweep.compute_residual(stage='IT_UP')
+                    self._hook('post_sweep', S, l - 1)
+        S.status.stage = 'IT_FINE'

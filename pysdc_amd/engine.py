@@ -73,6 +73,9 @@ class SweepEngine:
     def invalidate_spectra(self, which=3):
         self._chk(self.lib.sdc_invalidate_spectra(self.ctx, int(which)))
 
+    def set_unlocked(self, unlocked=True):
+        self._chk(self.lib.sdc_set_unlocked(self.ctx, int(bool(unlocked))))
+
     def set_spectral_reuse(self, on):
         self._chk(self.lib.sdc_set_spectral_reuse(self.ctx, int(bool(on))))
 

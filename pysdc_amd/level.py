@@ -278,32 +278,69 @@ class StepStatus(_Frozen):
 
 
 class Step:
-    """pySDC/core/step.py:47-331: one time step with its level hierarchy (single level in this round)."""
+    """pySDC/core/step.py:47-331: one time step with its level hierarchy (list-valued parameters = one entry per
+    level, step.py:175-199) and the transfer operators between neighbouring levels (step.py:201-253)."""
 
     def __init__(self, description):
+        from pysdc_amd.transfer import BaseTransfer
+
         self.logger = logging.getLogger('step')
         self.params = StepParams(description.get('step_params', {}))
         self.status = StepStatus()
         self.levels = []
         self.__prev = None
         self.__next = None
-        essential = ['problem_class', 'sweeper_class', 'sweeper_params', 'level_params']
-        for key in essential:
-            if key not in description:
-                raise ParameterError('need %s to instantiate step, only got %s' % (key, str(description.keys())))
-        pp = dict(description.get('problem_params', {}))
-        sp = dict(description['sweeper_params'])
-        lp = dict(description['level_params'])
-        for name, d in (('problem_params', pp), ('sweeper_params', sp), ('level_params', lp)):
-            for k, v in d.items():
-                if isinstance(v, list) and len(v) > 1:
-                    raise ParameterError(
-                        f'{name}[{k!r}] is a list: lists mean one entry per level (pySDC/core/step.py:175-199) and '
-                        'multi-level hierarchies are not part of this engine yet; pass tuples / arrays for values'
-                    )
-                if isinstance(v, list) and len(v) == 1:
-                    d[k] = v[0]
-        self.levels.append(Level(description['problem_class'], pp, description['sweeper_class'], sp, lp, 0))
+        self.__transfer_dict = {}
+        self.base_transfer = None
+        descr = dict(description)
+        for key in ['problem_class', 'sweeper_class', 'sweeper_params', 'level_params']:
+            if key not in descr:
+                raise ParameterError('need %s to instantiate step, only got %s' % (key, str(descr.keys())))
+        descr['problem_params'] = descr.get('problem_params', {})
+        descr['base_transfer_class'] = descr.get('base_transfer_class', BaseTransfer)
+        descr['base_transfer_params'] = descr.get('base_transfer_params', {})
+        descr['space_transfer_class'] = descr.get('space_transfer_class', {})
+        descr['space_transfer_params'] = descr.get('space_transfer_params', {})
+        descr.pop('step_params', None)
+        descr.pop('step_class', None)
+        descr_new = dict(descr)
+        for key in ('problem_params', 'level_params', 'sweeper_params'):
+            descr_new[key] = self._dict_to_list(descr[key])
+        descr_list = self._dict_to_list(descr_new)
+        if len(descr_list) > 1 and not descr_new['space_transfer_class']:
+            raise ParameterError('need space_transfer_class to instantiate step, only got %s' % str(descr_new.keys()))
+        for l, d in enumerate(descr_list):
+            L = Level(d['problem_class'], dict(d['problem_params']), d['sweeper_class'], dict(d['sweeper_params']),
+                      dict(d['level_params']), l)
+            self.levels.append(L)
+            if l > 0:
+                self.connect_levels(descr_new['base_transfer_class'], d['base_transfer_params'],
+                                    d['space_transfer_class'], d['space_transfer_params'], self.levels[l - 1], L)
+
+    @staticmethod
+    def _dict_to_list(in_dict):
+        max_val = 1
+        for v in in_dict.values():
+            if type(v) is list:
+                max_val = max(max_val, len(v))
+        ld = [{} for _ in range(max_val)]
+        for d in range(len(ld)):
+            for k, v in in_dict.items():
+                ld[d][k] = v if type(v) is not list else v[min(d, len(v) - 1)]
+        return ld
+
+    def connect_levels(self, base_transfer_class, base_transfer_params, space_transfer_class, space_transfer_params,
+                       fine_level, coarse_level):
+        self.base_transfer = base_transfer_class(fine_level, coarse_level, base_transfer_params,
+                                                 space_transfer_class, space_transfer_params)
+        self.__transfer_dict[(fine_level, coarse_level)] = self.base_transfer.restrict
+        if self.base_transfer.params.finter:
+            self.__transfer_dict[(coarse_level, fine_level)] = self.base_transfer.prolong_f
+        else:
+            self.__transfer_dict[(coarse_level, fine_level)] = self.base_transfer.prolong
+
+    def transfer(self, source, target):
+        self.__transfer_dict[(source, target)]()
 
     @property
     def time(self):

@@ -36,6 +36,7 @@ PROTOTYPES = {
     'sdc_set_tau_active': (C.c_int, [_vp, C.c_int]),
     'sdc_invalidate_spectra': (C.c_int, [_vp, C.c_int]),
     'sdc_set_spectral_reuse': (C.c_int, [_vp, C.c_int]),
+    'sdc_set_unlocked': (C.c_int, [_vp, C.c_int]),
     'sdc_init_field': (C.c_int, [_vp, _vp, C.POINTER(C.c_int), C.c_double, C.c_ulonglong]),
     'sdc_predict': (C.c_int, [_vp, C.c_double, C.c_double, C.c_int, C.c_double, C.c_double]),
     'sdc_sweep': (C.c_int, [_vp, C.c_double, C.c_double]),
@@ -50,6 +51,8 @@ PROTOTYPES = {
     'sdc_vec_amax': (C.c_int, [_vp, C.c_size_t, _vp, _dp]),
     'sdc_set_problem_vdp': (C.c_int, [_vp, C.c_double, C.c_double, C.c_int]),
     'sdc_work_counters': (C.c_int, [_vp, C.POINTER(C.c_ulonglong)]),
+    'sdc_transfer_prolong': (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _dp, _vp, _vp]),
+    'sdc_transfer_restrict': (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _dp, _vp, _vp]),
     'sdc_sync': (C.c_int, [_vp]),
     'sdc_timer_begin': (C.c_int, [_vp]),
     'sdc_timer_end': (C.c_int, [_vp, _dp]),

@@ -236,6 +236,7 @@ class Sweeper:
         if not all(L.u[m] is not None for m in range(M + 1)):
             raise ParameterError('update_nodes needs values at all nodes (predict first)')
         self._push_forcing()
+        L.engine.set_unlocked(True)
         L.engine.sweep(L.time, L.dt)
         L._res_cache = None
         L.status.updated = True

@@ -31,8 +31,10 @@ class _Prob:
         self.init = (oprob.nvars, None, np.dtype('float64'))
         self.dtype_u = np_mesh
 
+        self.dtype_f = np_mesh
+
     def eval_f(self, u, t):
-        return self.o.eval_f(np.asarray(u), t)
+        return np_mesh(self.o.eval_f(np.asarray(u), t))
 
 
 class _Sweep:
@@ -41,9 +43,14 @@ class _Sweep:
 
     def predict(self):
         O.predict(self.l.o)
+        self.l.status.unlocked = True
+        self.l.status.updated = True
 
     def update_nodes(self):
+        assert self.l.status.unlocked
+        self.l.o.unlocked = True
         O.sweep(self.l.o)
+        self.l.status.updated = True
 
     def compute_residual(self, stage=''):
         O.compute_residual(self.l.o)
@@ -51,6 +58,13 @@ class _Sweep:
 
     def compute_end_point(self):
         O.compute_end_point(self.l.o)
+
+    def integrate(self):
+        return [np_mesh(x) for x in O.integrate(self.l.o)]
+
+    @property
+    def coll(self):
+        return self.l.o.coll
 
     def updateVariableCoeffs(self, k):
         pass
@@ -72,11 +86,40 @@ class _UList:
 
 
 class _FList(_UList):
+    def __len__(self):
+        return len(self.l.o.f)
+
     def __getitem__(self, m):
-        return self.l.o.f[m]
+        v = self.l.o.f[m]
+        return None if v is None else v.view(np_mesh)
 
     def __setitem__(self, m, value):
-        self.l.o.f[m] = value
+        self.l.o.f[m] = None if value is None else np.array(value, dtype=float)
+
+
+class _TauList(_UList):
+    def __len__(self):
+        return len(self.l.o.tau)
+
+    def __getitem__(self, m):
+        v = self.l.o.tau[m]
+        return None if v is None else v.view(np_mesh)
+
+    def __setitem__(self, m, value):
+        self.l.o.tau[m] = None if value is None else np.array(value, dtype=float)
+
+
+class OracleMeshToMesh:
+    """space_transfer_class for oracle-backed levels (same constructor signature as the product classes)."""
+
+    def __init__(self, fine_prob, coarse_prob, params):
+        self.T = O.MeshToMesh(fine_prob.o.nvars, coarse_prob.o.nvars, params.get('iorder', 2), params.get('rorder', 2))
+
+    def restrict(self, F):
+        return np_mesh(self.T.restrict(np.asarray(F)))
+
+    def prolong(self, G):
+        return np_mesh(self.T.prolong(np.asarray(G)))
 
 
 class OracleLevel:
@@ -88,6 +131,9 @@ class OracleLevel:
         self.sweep = _Sweep(self)
         self.u = _UList(self)
         self.f = _FList(self)
+        self.tau = _TauList(self)
+        self.uold = [None] * len(olevel.u)
+        self.fold = [None] * len(olevel.u)
         self.tag = None
         self.level_index = 0
         self.sweep.rank = 0
@@ -116,6 +162,8 @@ class OracleLevel:
 
     def reset_level(self):
         self.o.reset()
+        self.uold = [None] * len(self.o.u)
+        self.fold = [None] * len(self.o.u)
         self._status = _TimeStatus(self.o)
 
 
@@ -131,19 +179,42 @@ class _TimeStatus(LevelStatus):
             self._o.time = v
         if k == 'sweep':
             self._o.sweep = v
+        if k == 'unlocked':
+            self._o.unlocked = bool(v)
         object.__setattr__(self, k, v)
 
 
 class OracleStep:
-    """description['oracle_level_factory']() -> oracle Level."""
+    """description['oracle_level_factory'] -> callable (single level) or list of callables (finest first),
+    each returning an oracle Level; level_params may be a dict or dict of per-level lists."""
 
     def __init__(self, description):
+        from pysdc_amd.transfer import BaseTransfer
+
         self.params = StepParams(description.get('step_params', {}))
         self.status = StepStatus()
-        ol = description['oracle_level_factory']()
-        self.levels = [OracleLevel(ol, description['level_params'])]
-        self.levels[0]._status = _TimeStatus(ol)
+        fac = description['oracle_level_factory']
+        facs = fac if isinstance(fac, list) else [fac]
+        lp = description['level_params']
+        self.levels = []
+        self._tr = {}
         self.prev = None
+        for l, f in enumerate(facs):
+            ol = f()
+            lpl = {k: (v[min(l, len(v) - 1)] if isinstance(v, list) else v) for k, v in lp.items()}
+            L = OracleLevel(ol, lpl)
+            L.level_index = l
+            L._status = _TimeStatus(ol)
+            self.levels.append(L)
+            if l > 0:
+                bt = BaseTransfer(self.levels[l - 1], L, description.get('base_transfer_params', {}),
+                                  description['space_transfer_class'], description.get('space_transfer_params', {}))
+                self.base_transfer = bt
+                self._tr[(self.levels[l - 1], L)] = bt.restrict
+                self._tr[(L, self.levels[l - 1])] = bt.prolong_f if bt.params.finter else bt.prolong
+
+    def transfer(self, source, target):
+        self._tr[(source, target)]()
 
     @property
     def dt(self):
@@ -154,7 +225,8 @@ class OracleStep:
         return self.levels[0].time
 
     def reset_step(self):
-        self.levels[0].reset_level()
+        for L in self.levels:
+            L.reset_level()
 
     def init_step(self, u0):
         self.levels[0].u[0] = u0

@@ -281,3 +281,147 @@ def main():
 
 if __name__ == '__main__':
     main()
+
+
+# ------------------------------------------------------------------------------------------------------
+# multi-level goldens (space transfer, FAS restriction / prolongation, MLSDC and PFASST runs)
+# ------------------------------------------------------------------------------------------------------
+def transfer_cases():
+    from pySDC.implementations.transfer_classes.TransferMesh import mesh_to_mesh
+
+    out = {}
+    for tag, nf, nc, io, ro in (('1d', 32, 16, 2, 2), ('2d', (16, 16), (8, 8), 6, 2), ('3d', (8, 8, 8), (4, 4, 4), 4, 2),
+                                ('2d_inj', (16, 16), (8, 8), 2, 0), ('1d_66', 64, 32, 6, 6)):
+        pf = heatNd_unforced(nvars=nf, nu=0.1, freq=2, bc='periodic')
+        pc = heatNd_unforced(nvars=nc, nu=0.1, freq=2, bc='periodic')
+        T = mesh_to_mesh(pf, pc, dict(iorder=io, rorder=ro, periodic=True))
+        rng = np.random.default_rng(4)
+        F = pf.dtype_u(pf.init)
+        F[:] = rng.standard_normal(pf.init[0])
+        G = pc.dtype_u(pc.init)
+        G[:] = rng.standard_normal(pc.init[0])
+        out[f'transfer_{tag}/fine'] = np.asarray(F).copy()
+        out[f'transfer_{tag}/coarse'] = np.asarray(G).copy()
+        out[f'transfer_{tag}/restricted'] = np.asarray(T.restrict(F)).copy()
+        out[f'transfer_{tag}/prolonged'] = np.asarray(T.prolong(G)).copy()
+        out[f'transfer_{tag}/meta'] = np.array(json.dumps(dict(name=f'transfer_{tag}', nf=nf, nc=nc, iorder=io, rorder=ro)))
+    np.savez_compressed(os.path.join(OUT, 'transfer.npz'), **out)
+    print('transfer.npz', os.path.getsize(os.path.join(OUT, 'transfer.npz')) // 1024, 'KiB')
+
+
+def ml_description(prob, pp_lists, sweeper, sw, lp, maxiter, io=6, ro=2):
+    from pySDC.implementations.transfer_classes.TransferMesh import mesh_to_mesh
+
+    return dict(problem_class=PROBS[prob], problem_params=pp_lists, sweeper_class=SWEEPERS[sweeper],
+                sweeper_params=sw, level_params=lp, step_params=dict(maxiter=maxiter),
+                space_transfer_class=mesh_to_mesh, space_transfer_params=dict(rorder=ro, iorder=io, periodic=True))
+
+
+def fas_case(name, prob, pp, sweeper, sw, dt, seed=0):
+    """predict on the fine level, restrict, one coarse sweep, prolong: all node values / tau captured."""
+    desc = ml_description(prob, pp, sweeper, sw, dict(dt=dt), 10)
+    S = Step(desc)
+    F, G = S.levels
+    rng = np.random.default_rng(seed)
+    for L in S.levels:
+        L.status.time = 0.1
+    u0 = np.asarray(F.prob.u_exact(0.0)) + 1e-2 * rng.standard_normal(F.prob.init[0])
+    F.u[0] = F.prob.dtype_u(F.prob.init)
+    F.u[0][:] = u0
+    F.sweep.predict()
+    F.sweep.update_nodes()
+    out = {'u0': u0}
+
+    def snap(tag):
+        out[f'{tag}_fu'] = np.stack([np.asarray(x) for x in F.u])
+        out[f'{tag}_ff'] = np.stack([fstack(x) for x in F.f])
+        if G.u[0] is not None:
+            out[f'{tag}_gu'] = np.stack([np.asarray(x) for x in G.u])
+            out[f'{tag}_gf'] = np.stack([fstack(x) for x in G.f])
+            out[f'{tag}_gtau'] = np.stack([np.asarray(x) for x in G.tau])
+
+    snap('a')
+    S.transfer(source=F, target=G)
+    snap('b')
+    G.sweep.update_nodes()
+    G.sweep.compute_residual()
+    out['c_gres'] = np.array(G.status.residual)
+    snap('c')
+    S.transfer(source=G, target=F)
+    snap('d')
+    out['coll_f_QI'] = F.sweep.QI
+    out['coll_g_QI'] = G.sweep.QI
+    if hasattr(F.sweep, 'QE'):
+        out['coll_f_QE'] = F.sweep.QE
+        out['coll_g_QE'] = G.sweep.QE
+    out['meta'] = np.array(json.dumps(dict(name=name, prob=prob, prob_params=pp, sweeper=sweeper, sweeper_params=sw,
+                                           dt=dt, t0=0.1)))
+    return out
+
+
+def ml_run_case(name, prob, pp, sweeper, sw, lp, maxiter, t0, Tend, num_procs, controller_params=None, seed=5,
+                io=6, ro=2):
+    desc = ml_description(prob, pp, sweeper, sw, lp, maxiter, io, ro)
+    cp = dict(logger_level=40)
+    cp.update(controller_params or {})
+    C = controller_nonMPI(num_procs, cp, desc)
+    P = C.MS[0].levels[0].prob
+    u0 = P.u_exact(t0) + 1e-3 * np.random.default_rng(seed).standard_normal(P.init[0])
+    u0 = P.dtype_u(P.init) + u0
+    uend, stats = C.run(u0, t0, Tend)
+    out = {'u0': np.asarray(u0).copy(), 'uend': np.asarray(uend).copy()}
+    niter = get_sorted(stats, type='niter', sortby='time')
+    out['niter_t'] = np.array([t for t, _ in niter])
+    out['niter'] = np.array([v for _, v in niter])
+    res = get_sorted(stats, type='residual_post_iteration', sortby='time')
+    out['res'] = np.array([v for _, v in res])
+    out['meta'] = np.array(json.dumps(dict(name=name, prob=prob, prob_params=pp, sweeper=sweeper, sweeper_params=sw,
+                                           level_params=lp, maxiter=maxiter, t0=t0, Tend=Tend, num_procs=num_procs,
+                                           controller_params=controller_params or {}, iorder=io, rorder=ro)))
+    return out
+
+
+def multilevel_main():
+    transfer_cases()
+    RR = dict(quad_type='RADAU-RIGHT')
+    cases = []
+    heat2 = dict(nvars=[(16, 16), (8, 8)], nu=0.1, freq=2, bc='periodic')
+    cases.append(fas_case('fas_heat2d_M3', 'heat_unforced', heat2, 'generic_implicit', dict(num_nodes=3, QI='LU', **RR), 0.02))
+    cases.append(fas_case('fas_heat2d_M53', 'heat_unforced', heat2, 'generic_implicit',
+                          dict(num_nodes=[5, 3], QI='IE', **RR), 0.02))
+    cases.append(fas_case('fas_heat1d', 'heat_unforced', dict(nvars=[64, 32], nu=0.1, freq=2, bc='periodic'),
+                          'generic_implicit', dict(num_nodes=3, QI='LU', **RR), 0.01))
+    cases.append(fas_case('fas_forced2d', 'heat_forced', heat2, 'imex_1st_order',
+                          dict(num_nodes=3, QI='LU', QE='EE', **RR), 0.02))
+    save('fas.npz', cases)
+
+    cases = []
+    base = dict(prob='heat_unforced', pp=heat2, sweeper='generic_implicit', sw=dict(num_nodes=3, QI='LU', **RR),
+                lp=dict(dt=0.02, restol=1e-9), maxiter=50, t0=0.0, Tend=0.16)
+    cases.append(ml_run_case('mlsdc_heat2d', num_procs=1, **base))
+    for P_ in (2, 4):
+        cases.append(ml_run_case(f'pfasst_heat2d_P{P_}', num_procs=P_,
+                                 controller_params=dict(predict_type='pfasst_burnin'), **base))
+    cases.append(ml_run_case('pfasst_heat2d_P2_nopred', num_procs=2, **base))
+    cases.append(ml_run_case('pfasst_heat2d_P4_all_to_done', num_procs=4,
+                             controller_params=dict(predict_type='pfasst_burnin', all_to_done=True), **base))
+    b53 = dict(base)
+    b53['sw'] = dict(num_nodes=[5, 3], QI='IE', **RR)
+    cases.append(ml_run_case('mlsdc_heat2d_M53', num_procs=1, **b53))
+    cases.append(ml_run_case('pfasst_heat2d_M53_P2', num_procs=2, controller_params=dict(predict_type='pfasst_burnin'),
+                             **b53))
+    forced = dict(prob='heat_forced', pp=heat2, sweeper='imex_1st_order', sw=dict(num_nodes=3, QI='LU', QE='EE', **RR),
+                  lp=dict(dt=0.05, restol=1e-9), maxiter=50, t0=0.0, Tend=0.2)
+    cases.append(ml_run_case('mlsdc_forced2d', num_procs=1, **forced))
+    cases.append(ml_run_case('pfasst_forced2d_P2', num_procs=2, controller_params=dict(predict_type='pfasst_burnin'),
+                             **forced))
+    h3 = dict(prob='heat_unforced', pp=dict(nvars=[(8, 8, 8), (4, 4, 4)], nu=0.1, freq=2, bc='periodic'),
+              sweeper='generic_implicit', sw=dict(num_nodes=3, QI='LU', **RR), lp=dict(dt=0.01, restol=1e-9),
+              maxiter=50, t0=0.0, Tend=0.04)
+    cases.append(ml_run_case('pfasst_heat3d_P2', num_procs=2, controller_params=dict(predict_type='pfasst_burnin'),
+                             io=4, **h3))
+    save('runs_ml.npz', cases)
+
+
+if __name__ == '__main__' and os.environ.get('GOLDEN_ML', '1') == '1':
+    multilevel_main()

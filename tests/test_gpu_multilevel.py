@@ -1,0 +1,111 @@
+"""GPU: space transfer kernels, FAS restriction / prolongation and MLSDC / PFASST runs on device levels
+against golden vectors of the reference (tests/golden/{transfer,fas,runs_ml}.npz)."""
+import numpy as np
+import pytest
+
+from tests._cases import load_cases, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def _tup(v):
+    return tuple(v) if isinstance(v, list) else v
+
+
+def _classes():
+    from pysdc_amd import problems as P, sweepers as S
+
+    return ({'heat_unforced': P.heatNd_unforced, 'heat_forced': P.heatNd_forced},
+            {'generic_implicit': S.generic_implicit, 'imex_1st_order': S.imex_1st_order})
+
+
+def _description(meta, lp, io=6, ro=2):
+    from pysdc_amd.transfer import mesh_to_mesh
+
+    probs, sweeps = _classes()
+    pp = {k: ([_tup(x) if isinstance(x, list) else x for x in v] if isinstance(v, list) and k == 'nvars' else v)
+          for k, v in meta['prob_params'].items()}
+    if isinstance(pp['nvars'], list) and not isinstance(pp['nvars'][0], (tuple, int)):
+        pp['nvars'] = [tuple(x) for x in pp['nvars']]
+    return dict(problem_class=probs[meta['prob']], problem_params=pp, sweeper_class=sweeps[meta['sweeper']],
+                sweeper_params=dict(meta['sweeper_params']), level_params=dict(lp),
+                step_params=dict(maxiter=meta.get('maxiter', 10)), space_transfer_class=mesh_to_mesh,
+                space_transfer_params=dict(iorder=io, rorder=ro, periodic=True))
+
+
+@pytest.mark.parametrize('name', list(load_cases('transfer.npz')))
+def test_space_transfer_kernels(name):
+    from pysdc_amd.problems import heatNd_unforced
+    from pysdc_amd.transfer import mesh_to_mesh
+
+    c = load_cases('transfer.npz')[name]
+    m = c['meta']
+    nf, nc = _tup(m['nf']), _tup(m['nc'])
+    pf = heatNd_unforced(nvars=nf, nu=0.1, freq=2)
+    pc = heatNd_unforced(nvars=nc, nu=0.1, freq=2)
+    T = mesh_to_mesh(pf, pc, dict(iorder=m['iorder'], rorder=m['rorder'], periodic=True))
+    F, G = pf.u_init, pc.u_init
+    F[:] = c['fine']
+    G[:] = c['coarse']
+    assert rel_err(T.restrict(F).get(), c['restricted']) < 1e-14
+    assert rel_err(T.prolong(G).get(), c['prolonged']) < 1e-14
+
+
+@pytest.mark.parametrize('name', list(load_cases('fas.npz')))
+def test_fas_on_device(name):
+    from pysdc_amd.level import Step
+
+    case = load_cases('fas.npz')[name]
+    meta = case['meta']
+    S = Step(_description(meta, dict(dt=meta['dt'])))
+    F, G = S.levels
+    for L in S.levels:
+        L.status.time = meta['t0']
+    u0 = F.prob.u_init
+    u0[:] = case['u0']
+    F.u[0] = u0
+    F.sweep.predict()
+    F.sweep.update_nodes()
+
+    def stack(lst):
+        return np.stack([np.asarray(x) for x in lst])
+
+    def check(tag, coarse=True):
+        assert rel_err(stack(F.u), case[f'{tag}_fu']) < TOL, tag
+        assert rel_err(stack(F.f), case[f'{tag}_ff']) < TOL, tag
+        if coarse:
+            assert rel_err(stack(G.u), case[f'{tag}_gu']) < TOL, tag
+            assert rel_err(stack(G.f), case[f'{tag}_gf']) < TOL, tag
+            tau_scale = max(float(np.max(np.abs(case[f'{tag}_gu']))), 1.0)
+            assert np.max(np.abs(stack(G.tau) - case[f'{tag}_gtau'])) < 1e-9 * tau_scale, tag
+
+    check('a', coarse=False)
+    S.transfer(F, G)
+    check('b')
+    G.sweep.update_nodes()
+    G.sweep.compute_residual()
+    assert abs(G.status.residual - float(case['c_gres'])) < 1e-9
+    check('c')
+    S.transfer(G, F)
+    check('d')
+
+
+@pytest.mark.parametrize('name', list(load_cases('runs_ml.npz')))
+def test_mlsdc_pfasst_on_device(name):
+    from pysdc_amd.controller import controller_nonMPI
+    from pysdc_amd.stats import get_sorted
+
+    case = load_cases('runs_ml.npz')[name]
+    meta = case['meta']
+    desc = _description(meta, meta['level_params'], meta['iorder'], meta['rorder'])
+    C = controller_nonMPI(meta['num_procs'], dict(logger_level=40, **meta['controller_params']), desc)
+    P = C.MS[0].levels[0].prob
+    u0 = P.u_init
+    u0[:] = case['u0']
+    uend, stats = C.run(u0, meta['t0'], meta['Tend'])
+    niter = get_sorted(stats, type='niter', sortby='time')
+    assert [v for _, v in niter] == list(case['niter'])          # bit-exact iteration counts
+    assert rel_err(uend.get(), case['uend']) < TOL
+    res = [v for _, v in get_sorted(stats, type='residual_post_iteration', sortby='time')]
+    np.testing.assert_allclose(res, case['res'], rtol=1e-5, atol=1e-11)

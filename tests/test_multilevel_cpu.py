@@ -1,0 +1,171 @@
+"""CPU: the host-side multi-level logic of the product (pysdc_amd.transfer.BaseTransfer, the MLSDC / PFASST
+stages of pysdc_amd.controller) driven with oracle-backed levels, against golden runs of the reference
+(tests/golden/{transfer,fas,runs_ml}.npz)."""
+import os
+import socket
+import tempfile
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from oracle import sdc_oracle as O
+from tests._cases import load_cases, make_oracle_problem, rel_err
+
+
+def _tup(v):
+    return tuple(v) if isinstance(v, list) else v
+
+
+def test_space_transfer_oracle_vs_golden():
+    for name, c in load_cases('transfer.npz').items():
+        m = c['meta']
+        T = O.MeshToMesh(_tup(m['nf']), _tup(m['nc']), m['iorder'], m['rorder'])
+        assert rel_err(T.restrict(c['fine']), c['restricted']) < 1e-15, name
+        assert rel_err(T.prolong(c['coarse']), c['prolonged']) < 1e-15, name
+
+
+def level_factories(meta, case, lp):
+    """one oracle-level factory per level from a golden multi-level description."""
+    from pysdc_amd.coeffs import CollBase, QDELTA_GENERATORS
+
+    pp, sw = meta['prob_params'], meta['sweeper_params']
+    nlev = max([len(v) for v in list(pp.values()) + list(sw.values()) if isinstance(v, list)] + [1])
+
+    def pick(d, l):
+        return {k: (v[min(l, len(v) - 1)] if isinstance(v, list) and k != 'nvars_single' else v) for k, v in d.items()}
+
+    facs = []
+    for l in range(nlev):
+        ppl, swl = pick(pp, l), pick(sw, l)
+        if isinstance(ppl.get('nvars'), list):
+            ppl['nvars'] = tuple(ppl['nvars'])
+        c = CollBase(swl['num_nodes'], 0, 1, 'LEGENDRE', swl['quad_type'])
+        QI = np.zeros_like(c.Qmat)
+        QI[1:, 1:] = QDELTA_GENERATORS[swl.get('QI', 'IE')](qGen=c.generator, tLeft=0).genCoeffs()
+        QE = None
+        if meta['sweeper'] == 'imex_1st_order':
+            QE = np.zeros_like(c.Qmat)
+            QE[1:, 1:], QE[1:, 0] = QDELTA_GENERATORS[swl.get('QE', 'EE')](qGen=c.generator, tLeft=0).genCoeffs(dTau=True)
+        coll = O.Coll(c.nodes, c.weights, c.Qmat, QI, QE)
+
+        def fac(ppl=ppl, coll=coll):
+            return O.Level(make_oracle_problem(meta['prob'], ppl), coll, lp['dt'], restol=lp.get('restol', -1.0),
+                           nsweeps=lp.get('nsweeps', 1))
+
+        facs.append(fac)
+    return facs
+
+
+@pytest.mark.parametrize('name', list(load_cases('fas.npz')))
+def test_fas_restrict_prolong(name):
+    from tests._oracle_step import OracleStep, OracleMeshToMesh, np_mesh
+
+    case = load_cases('fas.npz')[name]
+    meta = case['meta']
+    lp = dict(dt=meta['dt'])
+    S = OracleStep(dict(oracle_level_factory=level_factories(meta, case, lp), level_params=lp,
+                        step_params=dict(maxiter=10), space_transfer_class=OracleMeshToMesh,
+                        space_transfer_params=dict(iorder=6, rorder=2)))
+    F, G = S.levels
+    for L in S.levels:
+        L.status.time = meta['t0']
+    F.u[0] = np_mesh(np.array(case['u0']).reshape(F.o.prob.nvars))
+    F.sweep.predict()
+    F.status.unlocked = True
+    F.sweep.update_nodes()
+
+    def check(tag, coarse=True):
+        assert rel_err(np.stack(F.o.u), case[f'{tag}_fu']) < 1e-13, tag
+        assert rel_err(np.stack(F.o.f), case[f'{tag}_ff']) < 1e-12, tag
+        if coarse:
+            assert rel_err(np.stack(G.o.u), case[f'{tag}_gu']) < 1e-13, tag
+            assert rel_err(np.stack(G.o.f), case[f'{tag}_gf']) < 1e-12, tag
+            assert rel_err(np.stack(G.o.tau), case[f'{tag}_gtau']) < 1e-11, tag
+
+    check('a', coarse=False)
+    S.transfer(F, G)
+    check('b')
+    G.sweep.update_nodes()
+    G.sweep.compute_residual()
+    assert abs(G.status.residual - float(case['c_gres'])) < 1e-12
+    check('c')
+    S.transfer(G, F)
+    check('d')
+
+
+ML_RUNS = list(load_cases('runs_ml.npz'))
+
+
+def _ml_description(meta, case):
+    from tests._oracle_step import OracleStep, OracleMeshToMesh
+
+    lp = meta['level_params']
+    return dict(step_class=OracleStep, oracle_level_factory=level_factories(meta, case, lp), level_params=lp,
+                step_params=dict(maxiter=meta['maxiter']), space_transfer_class=OracleMeshToMesh,
+                space_transfer_params=dict(iorder=meta['iorder'], rorder=meta['rorder']))
+
+
+@pytest.mark.parametrize('name', ML_RUNS)
+def test_mlsdc_pfasst_serial_controller(name):
+    from pysdc_amd.controller import controller_nonMPI
+    from pysdc_amd.stats import get_sorted
+    from tests._oracle_step import np_mesh
+
+    case = load_cases('runs_ml.npz')[name]
+    meta = case['meta']
+    C = controller_nonMPI(meta['num_procs'], dict(logger_level=40, **meta['controller_params']),
+                          _ml_description(meta, case))
+    shape = C.MS[0].levels[0].o.prob.nvars
+    uend, stats = C.run(np_mesh(np.array(case['u0']).reshape(shape)), meta['t0'], meta['Tend'])
+    niter = get_sorted(stats, type='niter', sortby='time')
+    assert [v for _, v in niter] == list(case['niter'])
+    assert rel_err(np.asarray(uend), case['uend']) < 1e-12
+    res = [v for _, v in get_sorted(stats, type='residual_post_iteration', sortby='time')]
+    np.testing.assert_allclose(res, case['res'], rtol=1e-6, atol=1e-13)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, name, outdir):
+    import torch.distributed as dist
+
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from pysdc_amd.controller import controller_dist
+        from pysdc_amd.stats import get_sorted
+        from tests._oracle_step import np_mesh
+
+        case = load_cases('runs_ml.npz')[name]
+        meta = case['meta']
+        C = controller_dist(dict(logger_level=40, **meta['controller_params']), _ml_description(meta, case))
+        shape = C.S.levels[0].o.prob.nvars
+        uend, stats = C.run(np_mesh(np.array(case['u0']).reshape(shape)), meta['t0'], meta['Tend'])
+        niter = get_sorted(stats, type='niter', sortby='time')
+        np.savez(os.path.join(outdir, f'r{rank}.npz'), uend=np.asarray(uend), t=[t for t, _ in niter],
+                 n=[v for _, v in niter])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('name', ['pfasst_heat2d_P2', 'pfasst_heat2d_P2_nopred', 'pfasst_forced2d_P2',
+                                  'pfasst_heat2d_M53_P2'])
+def test_pfasst_two_ranks_gloo(name):
+    case = load_cases('runs_ml.npz')[name]
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(2, _free_port(), name, d), nprocs=2, join=True)
+        r = [np.load(os.path.join(d, f'r{k}.npz')) for k in range(2)]
+    times = np.concatenate([r[0]['t'], r[1]['t']])
+    niter = np.concatenate([r[0]['n'], r[1]['n']])
+    order = np.argsort(times)
+    assert list(niter[order]) == list(case['niter'])
+    for k in range(2):
+        assert rel_err(r[k]['uend'], case['uend']) < 1e-12
