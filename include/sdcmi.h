@@ -133,14 +133,14 @@ int sdc_set_problem_vdp(sdc_ctx* ctx, double mu, double newton_tol, int newton_m
  * over trajectories since context creation (work_counters of Van_der_Pol_implicit.py:71-73). */
 int sdc_work_counters(sdc_ctx* ctx, unsigned long long* out);
 
-/* ---- space transfer between nested periodic grids (coarsening factor 2) -------------------------------- *
- * mesh_to_mesh (transfer_classes/TransferMesh.py:9-218) for periodic, equidistant, nested grids: the
- * interpolation matrix of helpers/transfer_helper.py:153-186 applied matrix-free as a tensor product:
- *   fine[2i] = coarse[i],  fine[2i+1] = sum_j w[j] coarse[i - k/2 + 1 + j]            (k = iorder, even)
- * and the restriction 0.5^ndim * P_rorder^T (k = rorder; k = 0: injection).  nc = coarse points per axis.
- * Context-free (two levels are involved); errors are reported through sdc_last_error(NULL). */
-int sdc_transfer_prolong(void* stream, int ndim, int nc, int k, const double* w, const double* coarse, double* fine);
-int sdc_transfer_restrict(void* stream, int ndim, int nc, int k, const double* w, const double* fine, double* coarse);
+/* ---- space transfer between two grids --------------------------------------------------------------------
+ * mesh_to_mesh (transfer_classes/TransferMesh.py:9-218): Pspace / Rspace are Kronecker products of ONE 1-D
+ * sparse matrix (helpers/transfer_helper.py:140-242).  The host builds that 1-D matrix exactly as the reference
+ * does and hands its rows over as fixed-width tables on the device: out[i] = sum_j w[i][j] * in[idx[i][j]] per
+ * axis, zero-padded to `width`.  Applied as a tensor product over ndim axes in one launch.  Context-free (two
+ * levels are involved); errors are reported through sdc_last_error(NULL). */
+int sdc_transfer_apply(void* stream, int ndim, int n_out, int n_in, int width, const int* idx, const double* w,
+                       const double* in, double* out);
 
 /* ---- stream / timing ------------------------------------------------------------------------------------ */
 int sdc_sync(sdc_ctx* ctx);

@@ -1019,86 +1019,43 @@ __global__ void k_vdp_solve(const double* __restrict__ rhsv, const double* __res
 struct XferArgs {
     const double* in;
     double* out;
-    int ndim, nc, k;   // nc: coarse points per axis, k: stencil order (0 = injection)
-    double w[8];
-    double scale;      // restriction factor (0.5 if rorder > 0 else 1)
+    const int* idx;     // [n_out][W] source indices along one axis (device)
+    const double* w;    // [n_out][W] weights (zero-padded)
+    int ndim, n_out, n_in, W;
 };
 
-__device__ __forceinline__ int pmod(int i, int n) {
-    i %= n;
-    return i < 0 ? i + n : i;
-}
-
-__global__ void k_prolong(XferArgs a) {
-    const int nf = 2 * a.nc, nc = a.nc, k = a.k;
-    const size_t NF = a.ndim == 1 ? (size_t)nf : (a.ndim == 2 ? (size_t)nf * nf : (size_t)nf * nf * nf);
-    for (size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x; p < NF; p += (size_t)gridDim.x * blockDim.x) {
-        int idx[3] = {0, 0, 0};
+// out = (T x T x T) in for the 1-D sparse operator T given as fixed-width rows (same T on every axis)
+__global__ void k_xfer(XferArgs a) {
+    const int no = a.n_out, ni = a.n_in, W = a.W;
+    const size_t NO = a.ndim == 1 ? (size_t)no : (a.ndim == 2 ? (size_t)no * no : (size_t)no * no * no);
+    for (size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x; p < NO; p += (size_t)gridDim.x * blockDim.x) {
+        int i[3] = {0, 0, 0};
         size_t r = p;
         for (int d = a.ndim - 1; d >= 0; --d) {
-            idx[d] = (int)(r % nf);
-            r /= nf;
+            i[d] = (int)(r % no);
+            r /= no;
         }
-        // per axis: number of sources and their (index, weight)
-        int cnt[3] = {1, 1, 1};
-        for (int d = 0; d < a.ndim; ++d) cnt[d] = (idx[d] & 1) ? k : 1;
         double acc = 0.0;
-        for (int j0 = 0; j0 < cnt[0]; ++j0) {
-            const int c0 = (idx[0] & 1) ? pmod(idx[0] / 2 - k / 2 + 1 + j0, nc) : idx[0] / 2;
-            const double w0 = (idx[0] & 1) ? a.w[j0] : 1.0;
+        for (int j0 = 0; j0 < W; ++j0) {
+            const double w0 = a.w[i[0] * W + j0];
+            if (w0 == 0.0) continue;
+            const size_t s0 = a.idx[i[0] * W + j0];
             if (a.ndim == 1) {
-                acc += w0 * a.in[c0];
+                acc += w0 * a.in[s0];
                 continue;
             }
-            for (int j1 = 0; j1 < cnt[1]; ++j1) {
-                const int c1 = (idx[1] & 1) ? pmod(idx[1] / 2 - k / 2 + 1 + j1, nc) : idx[1] / 2;
-                const double w1 = w0 * ((idx[1] & 1) ? a.w[j1] : 1.0);
+            for (int j1 = 0; j1 < W; ++j1) {
+                const double w1 = a.w[i[1] * W + j1];
+                if (w1 == 0.0) continue;
+                const size_t s1 = s0 * ni + a.idx[i[1] * W + j1];
                 if (a.ndim == 2) {
-                    acc += w1 * a.in[(size_t)c0 * nc + c1];
+                    acc += w0 * w1 * a.in[s1];
                     continue;
                 }
-                for (int j2 = 0; j2 < cnt[2]; ++j2) {
-                    const int c2 = (idx[2] & 1) ? pmod(idx[2] / 2 - k / 2 + 1 + j2, nc) : idx[2] / 2;
-                    const double w2 = w1 * ((idx[2] & 1) ? a.w[j2] : 1.0);
-                    acc += w2 * a.in[((size_t)c0 * nc + c1) * nc + c2];
-                }
-            }
-        }
-        a.out[p] = acc;
-    }
-}
-
-__global__ void k_restrict(XferArgs a) {
-    const int nf = 2 * a.nc, nc = a.nc, k = a.k;
-    const size_t NC = a.ndim == 1 ? (size_t)nc : (a.ndim == 2 ? (size_t)nc * nc : (size_t)nc * nc * nc);
-    for (size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x; p < NC; p += (size_t)gridDim.x * blockDim.x) {
-        int idx[3] = {0, 0, 0};
-        size_t r = p;
-        for (int d = a.ndim - 1; d >= 0; --d) {
-            idx[d] = (int)(r % nc);
-            r /= nc;
-        }
-        // per axis k+1 sources: j = -1 -> fine[2i] (weight 1), j >= 0 -> fine[2 (i + k/2 - 1 - j) + 1] (weight w[j])
-        auto src = [&](int i, int j) { return j < 0 ? 2 * i : pmod(2 * (i + k / 2 - 1 - j) + 1, nf); };
-        auto wt = [&](int j) { return j < 0 ? 1.0 : a.w[j]; };
-        double acc = 0.0;
-        for (int j0 = -1; j0 < k; ++j0) {
-            const int f0 = src(idx[0], j0);
-            const double w0 = a.scale * wt(j0);
-            if (a.ndim == 1) {
-                acc += w0 * a.in[f0];
-                continue;
-            }
-            for (int j1 = -1; j1 < k; ++j1) {
-                const int f1 = src(idx[1], j1);
-                const double w1 = w0 * a.scale * wt(j1);
-                if (a.ndim == 2) {
-                    acc += w1 * a.in[(size_t)f0 * nf + f1];
-                    continue;
-                }
-                for (int j2 = -1; j2 < k; ++j2) {
-                    const int f2 = src(idx[2], j2);
-                    acc += w1 * a.scale * wt(j2) * a.in[((size_t)f0 * nf + f1) * nf + f2];
+                for (int j2 = 0; j2 < W; ++j2) {
+                    const double w2 = a.w[i[2] * W + j2];
+                    if (w2 == 0.0) continue;
+                    acc += w0 * w1 * w2 * a.in[s1 * ni + a.idx[i[2] * W + j2]];
                 }
             }
         }
@@ -2097,38 +2054,22 @@ int sdc_vec_amax(sdc_ctx* c, size_t n, const double* x, double* out) {
     return SDC_OK;
 }
 
-static int xfer_args(XferArgs& a, int ndim, int nc, int k, const double* w, const double* in, double* out) {
-    if (ndim < 1 || ndim > 3 || nc < 1 || k < 0 || k > 8 || (k & 1) || !in || !out || (k > 0 && !w)) return SDC_ERR_PARAM;
-    if (k > 2 * nc) return SDC_ERR_PARAM;
-    memset(&a, 0, sizeof a);
+int sdc_transfer_apply(void* stream, int ndim, int n_out, int n_in, int width, const int* idx, const double* w,
+                       const double* in, double* out) {
+    if (ndim < 1 || ndim > 3 || n_out < 1 || n_in < 1 || width < 1 || !idx || !w || !in || !out)
+        return fail(nullptr, SDC_ERR_PARAM, "bad transfer arguments");
+    XferArgs a;
     a.in = in;
     a.out = out;
+    a.idx = idx;
+    a.w = w;
     a.ndim = ndim;
-    a.nc = nc;
-    a.k = k;
-    for (int j = 0; j < k; ++j) a.w[j] = w[j];
-    return SDC_OK;
-}
-
-int sdc_transfer_prolong(void* stream, int ndim, int nc, int k, const double* w, const double* coarse, double* fine) {
-    XferArgs a;
-    if (xfer_args(a, ndim, nc, k, w, coarse, fine) != SDC_OK)
-        return fail(nullptr, SDC_ERR_PARAM, "bad transfer arguments (even order 0..8, 1-3 dimensions)");
-    size_t NF = 1;
-    for (int d = 0; d < ndim; ++d) NF *= (size_t)(2 * nc);
-    hipLaunchKernelGGL(k_prolong, dim3(grid_for(NF, 256)), dim3(256), 0, (hipStream_t)stream, a);
-    HIPCHK(nullptr, hipGetLastError());
-    return SDC_OK;
-}
-
-int sdc_transfer_restrict(void* stream, int ndim, int nc, int k, const double* w, const double* fine, double* coarse) {
-    XferArgs a;
-    if (xfer_args(a, ndim, nc, k, w, fine, coarse) != SDC_OK)
-        return fail(nullptr, SDC_ERR_PARAM, "bad transfer arguments (even order 0..8, 1-3 dimensions)");
-    a.scale = k > 0 ? 0.5 : 1.0;
-    size_t NC = 1;
-    for (int d = 0; d < ndim; ++d) NC *= (size_t)nc;
-    hipLaunchKernelGGL(k_restrict, dim3(grid_for(NC, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    a.n_out = n_out;
+    a.n_in = n_in;
+    a.W = width;
+    size_t NO = 1;
+    for (int d = 0; d < ndim; ++d) NO *= (size_t)n_out;
+    hipLaunchKernelGGL(k_xfer, dim3(grid_for(NO, 256)), dim3(256), 0, (hipStream_t)stream, a);
     HIPCHK(nullptr, hipGetLastError());
     return SDC_OK;
 }

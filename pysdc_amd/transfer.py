@@ -136,18 +136,62 @@ class _SpacePars:
             setattr(self, k, v)
 
 
-def midpoint_weights(k):
-    """Lagrange weights of the k nearest coarse points for the fine point half way between the two middle ones
-    (the rows of interpolation_matrix_1d for odd fine indices, transfer_helper.py:160-186)."""
-    if k == 0:
-        return np.zeros(0)
-    t = np.arange(k, dtype=float) - k / 2 + 1  # coarse offsets relative to i; the fine point sits at 0.5
-    w = np.ones(k)
-    for j in range(k):
-        for l in range(k):
-            if l != j:
-                w[j] *= (0.5 - t[l]) / (t[j] - t[l])
-    return w
+def _continue_periodic_array(arr, nn):
+    """helpers/transfer_helper.py:72-92."""
+    nn = np.asarray(nn)
+    d_nn = nn[1:] - nn[:-1]
+    if np.all(d_nn == np.ones(nn.shape[0] - 1)):
+        return arr[nn]
+    cont_arr = [arr[nn[0]]]
+    shift = 0.0
+    for n, d in zip(nn[1:], d_nn):
+        if d != 1:
+            shift = -1
+        cont_arr.append(arr[n] + shift)
+    return np.asarray(cont_arr)
+
+
+def interpolation_matrix_1d(fine_grid, coarse_grid, k=2):
+    """Dense (n_fine x n_coarse) interpolation matrix for periodic, equidistant, nested grids: the same
+    construction, row by row, as helpers/transfer_helper.py:153-186 (including its behaviour when the k nearest
+    neighbours wrap around a very small coarse grid), so the device operator equals the reference's matrix."""
+    from scipy.interpolate import BarycentricInterpolator
+
+    M = np.zeros((fine_grid.size, coarse_grid.size))
+    for i, p in enumerate(fine_grid):
+        if i % 2 == 0:
+            M[i, int(i / 2)] = 1.0
+            continue
+        if k == 0:
+            continue
+        nn = []
+        cpos, offset = int(i / 2), int(k / 2)
+        for j in range(k):
+            nn.append(cpos - offset + 1 + j)
+            if nn[-1] < 0:
+                nn[-1] += coarse_grid.size
+            elif nn[-1] > coarse_grid.size - 1:
+                nn[-1] -= coarse_grid.size
+        nn = sorted(nn)
+        cont_arr = np.array(_continue_periodic_array(coarse_grid, nn), dtype=float)
+        if p > np.mean(fine_grid) and not (cont_arr[0] <= p <= cont_arr[-1]):
+            cont_arr += 1
+        one = np.asarray([1.0] + [0.0] * (k - 1))
+        with np.errstate(divide='ignore'):
+            M[i, nn] = np.asarray([BarycentricInterpolator(cont_arr, np.roll(one, l))(p) for l in range(k)])
+    return M
+
+
+def _row_tables(M):
+    """fixed-width (idx, w) rows of a dense 1-D operator, zero-padded."""
+    width = max(1, int(np.max(np.count_nonzero(M, axis=1))))
+    idx = np.zeros((M.shape[0], width), dtype=np.int32)
+    w = np.zeros((M.shape[0], width))
+    for i in range(M.shape[0]):
+        cols = np.nonzero(M[i])[0]
+        idx[i, : len(cols)] = cols
+        w[i, : len(cols)] = M[i, cols]
+    return idx, w, width
 
 
 class mesh_to_mesh:
@@ -173,25 +217,38 @@ class mesh_to_mesh:
                 raise TransferError('the MI355X transfer kernels implement periodic, equidistant, nested grids')
             if any(f != 2 * c for f, c in zip(nf, nc)):
                 raise TransferError(f'need coarsening by a factor of 2 per axis, got {nf} -> {nc}')
-        self.ndim, self.nc = len(nc), nc[0]
-        self.wi = np.ascontiguousarray(midpoint_weights(self.params.iorder))
-        self.wr = np.ascontiguousarray(midpoint_weights(self.params.rorder))
+        self.ndim, self.nc, self.nf = len(nc), nc[0], nf[0]
+        if not self.identity:
+            import torch
 
-    def _apply(self, fn, k, w, src, dst):
-        wp = w.ctypes.data_as(C.POINTER(C.c_double)) if k > 0 else None
-        Lb.check(fn(None, self.ndim, self.nc, k, wp, src.ptr, dst.ptr), None)
+            fine_grid = np.array([j * fine_prob.dx for j in range(nf[0])])
+            coarse_grid = np.array([j * coarse_prob.dx for j in range(nc[0])])
+            P = interpolation_matrix_1d(fine_grid, coarse_grid, k=self.params.iorder)
+            restr_factor = 0.5 if self.params.rorder > 0 else 1.0
+            Pr = P if self.params.iorder == self.params.rorder else interpolation_matrix_1d(
+                fine_grid, coarse_grid, k=self.params.rorder)
+            R = restr_factor * Pr.T
+            self._tab = {}
+            for key, Mx in (('P', P), ('R', R)):
+                idx, w, width = _row_tables(Mx)
+                self._tab[key] = (torch.from_numpy(idx).cuda(), torch.from_numpy(w).cuda(), width, Mx.shape)
+
+    def _apply(self, key, src, dst):
+        idx, w, width, (n_out, n_in) = self._tab[key]
+        Lb.check(Lb.load().sdc_transfer_apply(None, self.ndim, n_out, n_in, width, idx.data_ptr(), w.data_ptr(),
+                                              src.ptr, dst.ptr), None)
 
     def _restrict(self, fine, coarse):
         if self.identity:
             coarse[:] = fine
         else:
-            self._apply(Lb.load().sdc_transfer_restrict, self.params.rorder, self.wr, fine, coarse)
+            self._apply('R', fine, coarse)
 
     def _prolong(self, coarse, fine):
         if self.identity:
             fine[:] = coarse
         else:
-            self._apply(Lb.load().sdc_transfer_prolong, self.params.iorder, self.wi, coarse, fine)
+            self._apply('P', coarse, fine)
 
     def restrict(self, F):
         """TransferMesh.py:148-183."""
