@@ -39,7 +39,8 @@ enum sdc_guess { SDC_GUESS_SPREAD = 0, SDC_GUESS_COPY = 1, SDC_GUESS_ZERO = 2, S
 enum sdc_expl_kind {
     SDC_EXPL_NONE = 0,    /* fully implicit problem (generic_implicit) */
     SDC_EXPL_STENCIL = 1, /* f.expl = B u with a periodic FD stencil (advection part of config 3) */
-    SDC_EXPL_FORCING = 2  /* f.expl = P(x) g(t), independent of u (heatNd_forced, HeatEquation_ND_FD.py:162-204) */
+    SDC_EXPL_FORCING = 2, /* f.expl = P(x) g(t), independent of u (heatNd_forced, HeatEquation_ND_FD.py:162-204) */
+    SDC_EXPL_REACTION = 3 /* f.expl = pointwise nonlinear function of u (Allen-Cahn); swept node by node */
 };
 
 /* ---- context ----------------------------------------------------------------------------------------- */
@@ -61,6 +62,14 @@ int sdc_set_coeffs(sdc_ctx* ctx, const double* Qmat, const double* QI, const dou
  * (weights already carry coeff / dx^derivative): the matrix generic_ND_FD.py:140-149 assembles through
  * helpers/problem_helper.py:83-242.  which = 0: implicit part (solved), 1: explicit part (SDC_EXPL_STENCIL). */
 int sdc_set_stencil(sdc_ctx* ctx, int which, int npts, const int* offsets, const double* weights);
+/* Implicit (which = 0) / explicit (1) operator given directly by its 1-D Fourier symbol, n complex values
+ * (re, im interleaved); the N-D symbol is the sum over the axes.  Used for the pseudo-spectral Laplacian
+ * -(2 pi k / L)^2 of AllenCahn_2D_FFT.py:84-93 / generic_MPIFFT_Laplacian.py:113-124; eval_f then applies the
+ * operator through the FFT pipeline instead of a stencil. */
+int sdc_set_symbol(sdc_ctx* ctx, int which, const double* table);
+/* Pointwise explicit term (SDC_EXPL_REACTION): kind 1: p0 * u * (1 - u^nu)  (AllenCahn_2D_FFT.py:140-141, p0 =
+ * 1/eps^2); kind 2: p0 * u (1-u)(1-2u) - p1 * u (1-u)  (AllenCahn_MPIFFT.py:83-85, p0 = -2/eps^2, p1 = 6 dw). */
+int sdc_set_reaction(sdc_ctx* ctx, int kind, double p0, double p1, int nu);
 /* Explicit part = profile[N] * g(t) with the profile given on the host (SDC_EXPL_FORCING). */
 int sdc_set_expl_kind(sdc_ctx* ctx, int kind);
 int sdc_set_forcing_profile(sdc_ctx* ctx, const double* host_profile);

@@ -856,3 +856,92 @@ class MeshToMesh:
 
     def prolong(self, G):
         return self._apply(self.P, G, self.nc, self.nf)
+
+
+# ----------------------------------------------------------------------------------------------
+# pseudo-spectral Allen-Cahn (problem_classes/AllenCahn_2D_FFT.py, AllenCahn_MPIFFT.py)
+# ----------------------------------------------------------------------------------------------
+class AllenCahn2D:
+    """AllenCahn_2D_FFT.py:61-200: lap = -kx^2 - ky^2 on the rfft2 layout (:84-93), eval_f (:95-116),
+    solve_system (:118-146), circle initial condition (:171-174)."""
+
+    imex = True
+
+    def __init__(self, nvars=(128, 128), nu=2, eps=0.04, radius=0.25, L=1.0, init_type='circle'):
+        self.nvars, self.nu, self.eps, self.radius, self.L, self.init_type = tuple(nvars), nu, eps, radius, L, init_type
+        self.ndim = 2
+        n = self.nvars[0]
+        self.dx = L / n
+        self.xvalues = np.array([i * self.dx - L / 2.0 for i in range(n)])
+        kx = np.zeros(n)
+        ky = np.zeros(n // 2 + 1)
+        kx[: int(n / 2) + 1] = 2 * np.pi / L * np.arange(0, int(n / 2) + 1)
+        kx[int(n / 2) + 1:] = 2 * np.pi / L * np.arange(int(n / 2) + 1 - n, 0)
+        ky[:] = 2 * np.pi / L * np.arange(0, n // 2 + 1)
+        xv, yv = np.meshgrid(kx, ky, indexing='ij')
+        self.lap = -(xv**2) - yv**2
+        self.work_counters = {}
+
+    def u_init(self):
+        return np.zeros(self.nvars)
+
+    def f_init(self):
+        return np.zeros((2,) + self.nvars)
+
+    def eval_f(self, u, t):
+        f = self.f_init()
+        f[0][:] = np.fft.irfft2(self.lap * np.fft.rfft2(u))
+        if self.eps > 0:
+            f[1][:] = 1.0 / self.eps**2 * u * (1.0 - u**self.nu)
+        return f
+
+    def solve_system(self, rhs, factor, u0, t):
+        return np.fft.irfft2(np.fft.rfft2(rhs) / (1.0 - factor * self.lap))
+
+    def u_exact(self, t):
+        assert t == 0
+        xv, yv = np.meshgrid(self.xvalues, self.xvalues, indexing='ij')
+        return np.tanh((self.radius - np.sqrt(xv**2 + yv**2)) / (np.sqrt(2) * self.eps))
+
+
+class AllenCahnND:
+    """AllenCahn_MPIFFT.py:63-139 on generic_MPIFFT_Laplacian.py:113-124 (K2), :164-171 (Laplacian), :202-211
+    (inversion), real-space variant; numpy's rfftn replaces the distributed FFT (not importable here, so this
+    class is pinned per operation against AllenCahn2D's golden-pinned pieces and by closed-form checks only)."""
+
+    imex = True
+
+    def __init__(self, nvars=(64, 64, 64), eps=0.04, radius=0.25, dw=0.0, init_type='circle', L=1.0):
+        self.nvars, self.eps, self.radius, self.dw, self.init_type, self.L = tuple(nvars), eps, radius, dw, init_type, L
+        self.ndim = len(self.nvars)
+        n = self.nvars[0]
+        k = [np.fft.fftfreq(n, 1.0 / n)] * (self.ndim - 1) + [np.fft.rfftfreq(n, 1.0 / n)]
+        Ks = np.meshgrid(*k, indexing='ij', sparse=True)
+        self.K2 = sum((Ki * 2 * np.pi / L) ** 2 for Ki in Ks)
+        self.work_counters = {'rhs': _Counter()}
+
+    def u_init(self):
+        return np.zeros(self.nvars)
+
+    def f_init(self):
+        return np.zeros((2,) + self.nvars)
+
+    def eval_f(self, u, t):
+        f = self.f_init()
+        f[0][:] = np.fft.irfftn(-self.K2 * np.fft.rfftn(u), s=self.nvars)
+        if self.eps > 0:
+            f[1][:] = -2.0 / self.eps**2 * u * (1.0 - u) * (1.0 - 2.0 * u) - 6.0 * self.dw * u * (1.0 - u)
+        self.work_counters['rhs']()
+        return f
+
+    def solve_system(self, rhs, factor, u0, t):
+        return np.fft.irfftn(np.fft.rfftn(rhs) / (1.0 + factor * self.K2), s=self.nvars)
+
+    def u_exact(self, t):
+        assert t == 0
+        n = self.nvars[0]
+        x = np.arange(n) * self.L / n
+        X = np.meshgrid(*([x] * self.ndim), indexing='ij', sparse=True)
+        r2 = (X[0] - 0.5) ** 2 + (X[1] - 0.5) ** 2 if self.init_type == 'circle' else sum((Xi - 0.5) ** 2 for Xi in X)
+        return np.broadcast_to(0.5 * (1.0 + np.tanh((self.radius - np.sqrt(r2)) / (np.sqrt(2) * self.eps))),
+                               self.nvars).copy()

@@ -53,6 +53,9 @@ struct sdc_ctx {
     unsigned long long* red_host = nullptr;
     bool tau_active = false, have_coeffs = false, have_stencil[2] = {false, false}, unlocked = false;
     int expl_kind = SDC_EXPL_NONE;
+    bool spectral_op = false;  // implicit operator given by its Fourier symbol only (no stencil): eval_f by FFT
+    int react_kind = 0, react_nu = 2;
+    double react_p0 = 0, react_p1 = 0;
     int kind = 0;  // 0: periodic finite differences, 1: van der Pol ensemble (N = 2 * ntraj, SoA)
     double vdp_mu = 0, vdp_tol = 1e-9;
     int vdp_maxiter = 100;
@@ -522,6 +525,26 @@ __global__ __launch_bounds__(256) void k_stencil3d(Stencil3Args a) {
     }
 }
 
+// pointwise explicit (reaction) terms of the Allen-Cahn problems
+//   kind 1: c * u * (1 - u^nu),  c = 1/eps^2          (AllenCahn_2D_FFT.py:140-141)
+//   kind 2: -2/eps^2 u (1-u)(1-2u) - 6 dw u (1-u)     (AllenCahn_MPIFFT.py:83-85)
+__global__ void k_reaction(const double* __restrict__ u, double* __restrict__ out, size_t n, int kind, double p0,
+                           double p1, int nu) {
+#pragma clang fp contract(off)
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const double v = u[i];
+        double r;
+        if (kind == 1) {
+            double pw = 1.0;
+            for (int q = 0; q < nu; ++q) pw *= v;
+            r = p0 * v * (1.0 - pw);
+        } else {
+            r = p0 * v * (1.0 - v) * (1.0 - 2.0 * v) - p1 * v * (1.0 - v);
+        }
+        out[i] = r;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // FFT kernels
 // ------------------------------------------------------------------------------------------------------
@@ -686,6 +709,7 @@ struct ZArgs {
     double alpha[MAXM];          // dt*QI[m+1][m+1]
     double invN;
     int nf, ndim, coupled;
+    int apply;  // 1: multiply by the symbol (operator application) instead of dividing by 1 - alpha*symbol
 };
 
 // forward FFT along the contiguous axis, node-coupled implicit solve in Fourier space, inverse FFT.
@@ -753,7 +777,7 @@ __global__ __launch_bounds__(z_lines_per_block<N>() * (N / fft_elems(N)) * MAXM,
                         }
                     }
                     const double al = a.alpha[m];
-                    u[m] = cmul(acc, cinv_fast(cd{1.0 - al * lam.x, -al * lam.y}));
+                    u[m] = a.apply ? cmul(acc, lam) : cmul(acc, cinv_fast(cd{1.0 - al * lam.x, -al * lam.y}));
                     buf[(m * LPB + ll) * CH + kk] = cscale(u[m], a.invN);
                 }
             }
@@ -1601,8 +1625,34 @@ static int vdp_check_failures(sdc_ctx* c) {
     return SDC_OK;
 }
 
+int sdc_set_symbol(sdc_ctx* c, int which, const double* table) {
+    if (!c || which < 0 || which > 1 || !table) return fail(c, SDC_ERR_PARAM, "bad symbol table");
+    cd** dst = which == 0 ? &c->lamI : &c->lamE;
+    if (!*dst) {
+        HIPCHK(c, hipMalloc((void**)dst, sizeof(cd) * c->n));
+        c->bytes += sizeof(cd) * c->n;
+    }
+    HIPCHK(c, hipMemcpyAsync(*dst, table, sizeof(cd) * c->n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->have_stencil[which] = true;
+    if (which == 0) c->spectral_op = true;
+    c->spec_valid = c->spec0_valid = false;
+    return SDC_OK;
+}
+
+int sdc_set_reaction(sdc_ctx* c, int kind, double p0, double p1, int nu) {
+    if (!c || kind < 1 || kind > 2 || nu < 1 || nu > 16) return fail(c, SDC_ERR_PARAM, "bad reaction term");
+    if (c->ncomp != 2) return fail(c, SDC_ERR_PARAM, "explicit part needs ncomp == 2");
+    c->react_kind = kind;
+    c->react_p0 = p0;
+    c->react_p1 = p1;
+    c->react_nu = nu;
+    c->expl_kind = SDC_EXPL_REACTION;
+    return SDC_OK;
+}
+
 int sdc_set_expl_kind(sdc_ctx* c, int kind) {
-    if (!c || kind < 0 || kind > 2) return fail(c, SDC_ERR_PARAM, "bad explicit kind");
+    if (!c || kind < 0 || kind > 3) return fail(c, SDC_ERR_PARAM, "bad explicit kind");
     if (kind != SDC_EXPL_NONE && c->ncomp != 2) return fail(c, SDC_ERR_PARAM, "explicit part needs ncomp == 2");
     c->expl_kind = kind;
     return SDC_OK;
@@ -1720,6 +1770,33 @@ int sdc_eval_f(sdc_ctx* c, const double* u, double g_t, double* f_impl, double* 
     }
     if (!c->have_stencil[0]) return fail(c, SDC_ERR_STATE, "implicit operator not set (sdc_set_stencil)");
     if (c->expl_kind == SDC_EXPL_FORCING && !c->profile) return fail(c, SDC_ERR_STATE, "forcing profile not set");
+    if (c->spectral_op || c->expl_kind == SDC_EXPL_REACTION) {
+        if (c->spectral_op) {
+            FieldPtrs p;
+            memset(&p, 0, sizeof p);
+            ZArgs z;
+            memset(&z, 0, sizeof z);
+            p.in[0] = u;
+            p.out[0] = f_impl;
+            z.apply = 1;
+            int rc0 = fft_pipeline(c, 1, p, z);
+            if (rc0 != SDC_OK) return rc0;
+        } else {
+            const double* in1[1] = {u};
+            double* oi1[1] = {f_impl};
+            int rc0 = run_stencil(c, 1, in1, oi1, nullptr, nullptr);
+            if (rc0 != SDC_OK) return rc0;
+        }
+        if (f_expl && c->expl_kind == SDC_EXPL_REACTION) {
+            LaunchTimer lt(c, "reaction");
+            hipLaunchKernelGGL(k_reaction, dim3(grid_for(c->N, 256)), dim3(256), 0, c->stream, u, f_expl, c->N,
+                               c->react_kind, c->react_p0, c->react_p1, c->react_nu);
+            HIPCHK(c, hipGetLastError());
+        } else if (f_expl && c->expl_kind == SDC_EXPL_STENCIL) {
+            return fail(c, SDC_ERR_UNSUPPORTED, "explicit stencil together with a spectral implicit operator");
+        }
+        return SDC_OK;
+    }
     const double* in[1] = {u};
     double* oi[1] = {f_impl};
     double* oe[1] = {f_expl};
@@ -1801,6 +1878,10 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
     }
     if (c->expl_kind == SDC_EXPL_STENCIL && !c->have_stencil[1])
         return fail(c, SDC_ERR_STATE, "explicit operator not set (sdc_set_stencil which=1)");
+    if (c->expl_kind == SDC_EXPL_REACTION)
+        return fail(c, SDC_ERR_UNSUPPORTED, "a nonlinear explicit part is swept node by node (eval_f / solve), not fused");
+    if (c->spectral_op)
+        return fail(c, SDC_ERR_UNSUPPORTED, "operators given by their symbol only are swept node by node (eval_f / solve)");
     const bool gather_once = c->force_gather;
     c->force_gather = false;
     if (c->reuse && !gather_once && !c->tau_active && c->expl_kind != SDC_EXPL_FORCING && c->have_stencil[0] &&

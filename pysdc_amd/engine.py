@@ -60,6 +60,14 @@ class SweepEngine:
         w = np.ascontiguousarray(weights, dtype=np.float64)
         self._chk(self.lib.sdc_set_stencil(self.ctx, which, len(offsets), off, _dptr(w)))
 
+    def set_symbol(self, which, table):
+        t = np.ascontiguousarray(np.asarray(table, dtype=np.complex128)).view(np.float64)
+        assert t.size == 2 * self.n
+        self._chk(self.lib.sdc_set_symbol(self.ctx, which, _dptr(t)))
+
+    def set_reaction(self, kind, p0, p1=0.0, nu=2):
+        self._chk(self.lib.sdc_set_reaction(self.ctx, int(kind), float(p0), float(p1), int(nu)))
+
     def set_forcing_profile(self, profile):
         p = np.ascontiguousarray(profile, dtype=np.float64).reshape(-1)
         assert p.size == self.N

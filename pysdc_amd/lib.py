@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, 'libsdcmi.so')
 SLOT_U, SLOT_F, SLOT_TAU, SLOT_UEND, SLOT_WORK = 0, 1, 2, 3, 4
 RES_TYPES = {'full_abs': 0, 'last_abs': 1, 'full_rel': 2, 'last_rel': 3}
 GUESS = {'spread': 0, 'copy': 1, 'zero': 2, 'random': 3}
-EXPL_NONE, EXPL_STENCIL, EXPL_FORCING = 0, 1, 2
+EXPL_NONE, EXPL_STENCIL, EXPL_FORCING, EXPL_REACTION = 0, 1, 2, 3
 
 ERR_PARAM, ERR_HIP, ERR_STATE, ERR_UNSUPPORTED, ERR_NOMEM, ERR_NEWTON = -1, -2, -3, -4, -5, -6
 
@@ -27,6 +27,8 @@ PROTOTYPES = {
     'sdc_ctx_bytes': (C.c_size_t, [_vp]),
     'sdc_set_coeffs': (C.c_int, [_vp, _dp, _dp, _dp, _dp, _dp]),
     'sdc_set_stencil': (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_int), _dp]),
+    'sdc_set_symbol': (C.c_int, [_vp, C.c_int, _dp]),
+    'sdc_set_reaction': (C.c_int, [_vp, C.c_int, C.c_double, C.c_double, C.c_int]),
     'sdc_set_expl_kind': (C.c_int, [_vp, C.c_int]),
     'sdc_set_forcing_profile': (C.c_int, [_vp, _dp]),
     'sdc_set_forcing_values': (C.c_int, [_vp, _dp]),

@@ -34,6 +34,10 @@ def make_oracle_problem(prob, pp):
         return O.AdvectionDiffusionIMEX(**pp)
     if prob == 'vanderpol':
         return O.VanDerPol(**pp)
+    if prob == 'allencahn2d':
+        return O.AllenCahn2D(**pp)
+    if prob == 'allencahnNd':
+        return O.AllenCahnND(**pp)
     raise ValueError(prob)
 
 

@@ -366,7 +366,9 @@ def ml_run_case(name, prob, pp, sweeper, sw, lp, maxiter, t0, Tend, num_procs, c
     cp.update(controller_params or {})
     C = controller_nonMPI(num_procs, cp, desc)
     P = C.MS[0].levels[0].prob
-    u0 = P.u_exact(t0) + 1e-3 * np.random.default_rng(seed).standard_normal(P.init[0])
+    u0 = P.u_exact(t0)
+    if seed is not None:
+        u0 = u0 + 1e-3 * np.random.default_rng(seed).standard_normal(P.init[0])
     u0 = P.dtype_u(P.init) + u0
     uend, stats = C.run(u0, t0, Tend)
     out = {'u0': np.asarray(u0).copy(), 'uend': np.asarray(uend).copy()}
@@ -425,3 +427,31 @@ def multilevel_main():
 
 if __name__ == '__main__' and os.environ.get('GOLDEN_ML', '1') == '1':
     multilevel_main()
+
+
+def allencahn_main():
+    """G6: allencahn2d_imex sweeps and two-level runs (mesh_to_mesh periodic transfer)."""
+    from pySDC.implementations.problem_classes.AllenCahn_2D_FFT import allencahn2d_imex
+
+    PROBS['allencahn2d'] = allencahn2d_imex
+    RR = dict(quad_type='RADAU-RIGHT')
+    cases = []
+    cases.append(sweep_case('ac2d_M3', 'allencahn2d', dict(nvars=(32, 32), nu=2, eps=0.04, radius=0.25),
+                            'imex_1st_order', dict(num_nodes=3, QI='LU', QE='EE', **RR), 1e-3, t0=0.0, u0_kind='exact'))
+    cases.append(sweep_case('ac2d_M5_IE', 'allencahn2d', dict(nvars=(64, 64), nu=2, eps=0.08, radius=0.25),
+                            'imex_1st_order', dict(num_nodes=5, QI='IE', QE='EE', **RR), 5e-4, t0=0.0, u0_kind='exact'))
+    save('sweeps_ac.npz', cases)
+    cases = []
+    pp = dict(nvars=[(32, 32), (16, 16)], nu=2, eps=0.04, radius=0.25)
+    base = dict(prob='allencahn2d', pp=pp, sweeper='imex_1st_order', sw=dict(num_nodes=3, QI='LU', QE='EE', **RR),
+                lp=dict(dt=1e-3, restol=1e-8), maxiter=50, t0=0.0, Tend=4e-3, seed=None)
+    cases.append(ml_run_case('ac2d_mlsdc', num_procs=1, **base))
+    cases.append(ml_run_case('ac2d_pfasst_P2', num_procs=2, controller_params=dict(predict_type='pfasst_burnin'), **base))
+    cases.append(ml_run_case('ac2d_pfasst_P4', num_procs=4, controller_params=dict(predict_type='pfasst_burnin'), **base))
+    sl = dict(base)
+    sl['pp'] = dict(nvars=(32, 32), nu=2, eps=0.04, radius=0.25)
+    save('runs_ac.npz', cases)
+
+
+if __name__ == '__main__' and os.environ.get('GOLDEN_ML', '1') == '1':
+    allencahn_main()

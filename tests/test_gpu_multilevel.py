@@ -16,7 +16,7 @@ def _tup(v):
 def _classes():
     from pysdc_amd import problems as P, sweepers as S
 
-    return ({'heat_unforced': P.heatNd_unforced, 'heat_forced': P.heatNd_forced},
+    return ({'heat_unforced': P.heatNd_unforced, 'heat_forced': P.heatNd_forced, 'allencahn2d': P.allencahn2d_imex},
             {'generic_implicit': S.generic_implicit, 'imex_1st_order': S.imex_1st_order})
 
 
@@ -91,12 +91,15 @@ def test_fas_on_device(name):
     check('d')
 
 
-@pytest.mark.parametrize('name', list(load_cases('runs_ml.npz')))
-def test_mlsdc_pfasst_on_device(name):
+ML_RUNS = [('runs_ml.npz', n) for n in load_cases('runs_ml.npz')] + [('runs_ac.npz', n) for n in load_cases('runs_ac.npz')]
+
+
+@pytest.mark.parametrize('fname,name', ML_RUNS)
+def test_mlsdc_pfasst_on_device(fname, name):
     from pysdc_amd.controller import controller_nonMPI
     from pysdc_amd.stats import get_sorted
 
-    case = load_cases('runs_ml.npz')[name]
+    case = load_cases(fname)[name]
     meta = case['meta']
     desc = _description(meta, meta['level_params'], meta['iorder'], meta['rorder'])
     C = controller_nonMPI(meta['num_procs'], dict(logger_level=40, **meta['controller_params']), desc)
@@ -109,3 +112,56 @@ def test_mlsdc_pfasst_on_device(name):
     assert rel_err(uend.get(), case['uend']) < TOL
     res = [v for _, v in get_sorted(stats, type='residual_post_iteration', sortby='time')]
     np.testing.assert_allclose(res, case['res'], rtol=1e-5, atol=1e-11)
+
+
+@pytest.mark.parametrize('name', list(load_cases('sweeps_ac.npz')))
+def test_allencahn_sweeps_on_device(name):
+    """pseudo-spectral Allen-Cahn (nonlinear explicit part): node-by-node IMEX sweeps on the device against
+    golden sweeps of the reference's allencahn2d_imex."""
+    from pysdc_amd.level import Step
+    from pysdc_amd.problems import allencahn2d_imex
+    from pysdc_amd.sweepers import imex_1st_order
+
+    case = load_cases('sweeps_ac.npz')[name]
+    meta = case['meta']
+    pp = dict(meta['prob_params'])
+    pp['nvars'] = tuple(pp['nvars'])
+    S = Step(dict(problem_class=allencahn2d_imex, problem_params=pp, sweeper_class=imex_1st_order,
+                  sweeper_params=dict(meta['sweeper_params']), level_params=dict(dt=meta['dt']),
+                  step_params=dict(maxiter=10)))
+    L = S.levels[0]
+    L.status.time = meta['t0']
+    L.u[0] = L.prob.u_exact(0.0)
+    assert rel_err(L.u[0].get(), case['u0']) < 1e-14
+    L.sweep.predict()
+
+    def check(tag):
+        assert rel_err(np.stack([np.asarray(x) for x in L.u]), case[f'{tag}_u']) < TOL, tag
+        assert rel_err(np.stack([np.asarray(x) for x in L.f]), case[f'{tag}_f']) < TOL, tag
+        L.sweep.compute_residual()
+        ref = float(case[f'{tag}_res_full_abs'])
+        assert abs(L.status.residual - ref) <= 1e-8 * abs(ref) + 1e-11, tag
+        L.sweep.compute_end_point()
+        assert rel_err(L.uend.get(), case[f'{tag}_uend_0']) < TOL, tag
+
+    check('k0')
+    for k in range(1, meta['nsweeps'] + 1):
+        L.sweep.update_nodes()
+        check(f'k{k}')
+
+
+def test_allencahn_3d_vs_oracle():
+    """3-D variant (formulas of AllenCahn_MPIFFT.py; not importable as reference): device vs the NumPy oracle."""
+    from oracle import sdc_oracle as O
+    from pysdc_amd.problems import allencahn_imex
+
+    for nv, it in (((16, 16, 16), 'sphere'), ((32, 32), 'circle')):
+        P = allencahn_imex(nvars=nv, eps=0.08, radius=0.25, init_type=it)
+        Po = O.AllenCahnND(nvars=nv, eps=0.08, radius=0.25, init_type=it)
+        u = P.u_exact(0.0)
+        assert rel_err(u.get(), Po.u_exact(0.0)) < 1e-14
+        f, fo = P.eval_f(u, 0.0), Po.eval_f(Po.u_exact(0.0), 0.0)
+        assert rel_err(f.impl.get(), fo[0]) < 1e-11
+        assert rel_err(f.expl.get(), fo[1]) < 1e-13
+        sol = P.solve_system(u, 1e-3, u, 0.0)
+        assert rel_err(sol.get(), Po.solve_system(Po.u_exact(0.0), 1e-3, None, 0.0)) < 1e-13

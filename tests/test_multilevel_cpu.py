@@ -94,7 +94,7 @@ def test_fas_restrict_prolong(name):
     check('d')
 
 
-ML_RUNS = list(load_cases('runs_ml.npz'))
+ML_RUNS = [('runs_ml.npz', n) for n in load_cases('runs_ml.npz')] + [('runs_ac.npz', n) for n in load_cases('runs_ac.npz')]
 
 
 def _ml_description(meta, case):
@@ -106,13 +106,13 @@ def _ml_description(meta, case):
                 space_transfer_params=dict(iorder=meta['iorder'], rorder=meta['rorder']))
 
 
-@pytest.mark.parametrize('name', ML_RUNS)
-def test_mlsdc_pfasst_serial_controller(name):
+@pytest.mark.parametrize('fname,name', ML_RUNS)
+def test_mlsdc_pfasst_serial_controller(fname, name):
     from pysdc_amd.controller import controller_nonMPI
     from pysdc_amd.stats import get_sorted
     from tests._oracle_step import np_mesh
 
-    case = load_cases('runs_ml.npz')[name]
+    case = load_cases(fname)[name]
     meta = case['meta']
     C = controller_nonMPI(meta['num_procs'], dict(logger_level=40, **meta['controller_params']),
                           _ml_description(meta, case))
