@@ -928,14 +928,14 @@ class AllenCahnND:
 
     def eval_f(self, u, t):
         f = self.f_init()
-        f[0][:] = np.fft.irfftn(-self.K2 * np.fft.rfftn(u), s=self.nvars)
+        f[0][:] = np.fft.irfftn(-self.K2 * np.fft.rfftn(u), s=self.nvars, axes=tuple(range(self.ndim)))
         if self.eps > 0:
             f[1][:] = -2.0 / self.eps**2 * u * (1.0 - u) * (1.0 - 2.0 * u) - 6.0 * self.dw * u * (1.0 - u)
         self.work_counters['rhs']()
         return f
 
     def solve_system(self, rhs, factor, u0, t):
-        return np.fft.irfftn(np.fft.rfftn(rhs) / (1.0 + factor * self.K2), s=self.nvars)
+        return np.fft.irfftn(np.fft.rfftn(rhs) / (1.0 + factor * self.K2), s=self.nvars, axes=tuple(range(self.ndim)))
 
     def u_exact(self, t):
         assert t == 0
