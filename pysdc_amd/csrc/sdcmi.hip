@@ -394,7 +394,7 @@ __device__ __forceinline__ unsigned xcd_swizzle(unsigned b, unsigned total) {
 }
 
 template <int RPT>
-__global__ __launch_bounds__(256) void k_stencil3d(Stencil3Args a) {
+__global__ __launch_bounds__(256, 4) void k_stencil3d(Stencil3Args a) {
     constexpr int TZ = 64, TYB = 8, TY = TYB * RPT, LW = TZ + 4;  // LDS row: [halo | 64 | halo | pad]
     __shared__ double tile[2][TY + 2][LW];
     const int n = a.n;
@@ -438,24 +438,28 @@ __global__ __launch_bounds__(256) void k_stencil3d(Stencil3Args a) {
     for (int r = 0; r < RPT; ++r) off[r] = (size_t)(y0 + ty + r * TYB) * n + z0 + 2 * tz;
 
     auto plane = [&](int x) { return u + (size_t)(x < 0 ? x + n : (x >= n ? x - n : x)) * sx; };
-    double2 prev[RPT], cur[RPT], nxt[RPT];
-    double2 hcur = double2{0.0, 0.0}, hnxt = double2{0.0, 0.0};
+    double2 prev[RPT], cur[RPT], nxt[RPT], nx2[RPT];
+    double2 hcur = double2{0.0, 0.0}, hnxt = double2{0.0, 0.0}, hnx2 = double2{0.0, 0.0};
     {
         const double* pm = plane(x0 - 1);
         const double* p0 = plane(x0);
         const double* p1 = plane(x0 + 1);
+        const double* p2 = plane(x0 + 2);
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
             prev[r] = *reinterpret_cast<const double2*>(pm + off[r]);
             cur[r] = *reinterpret_cast<const double2*>(p0 + off[r]);
             nxt[r] = *reinterpret_cast<const double2*>(p1 + off[r]);
+            nx2[r] = *reinterpret_cast<const double2*>(p2 + off[r]);
         }
         if (hy) {
             hcur = *reinterpret_cast<const double2*>(p0 + hoff);
             hnxt = *reinterpret_cast<const double2*>(p1 + hoff);
+            hnx2 = *reinterpret_cast<const double2*>(p2 + hoff);
         } else if (hz) {
             hcur.x = p0[hoff];
             hnxt.x = p1[hoff];
+            hnx2.x = p2[hoff];
         }
     }
     auto put = [&](int b, const double2 (&v)[RPT], double2 h) {
@@ -477,16 +481,16 @@ __global__ __launch_bounds__(256) void k_stencil3d(Stencil3Args a) {
         const int b = p & 1;
         const int x = x0 + p;
         __syncthreads();
-        // prefetch plane x+2 (interior + halo) while computing plane x
+        // prefetch plane x+3 (interior + halo): two planes are always in flight behind the one in use
         double2 nn[RPT];
         double2 hnn = double2{0.0, 0.0};
         const bool more = p + 1 < a.xchunk;
-        if (more) {
-            const double* p2 = plane(x + 2);
+        if (p + 2 < a.xchunk) {
+            const double* p3 = plane(x + 3);
 #pragma unroll
-            for (int r = 0; r < RPT; ++r) nn[r] = *reinterpret_cast<const double2*>(p2 + off[r]);
-            if (hy) hnn = *reinterpret_cast<const double2*>(p2 + hoff);
-            else if (hz) hnn.x = p2[hoff];
+            for (int r = 0; r < RPT; ++r) nn[r] = *reinterpret_cast<const double2*>(p3 + off[r]);
+            if (hy) hnn = *reinterpret_cast<const double2*>(p3 + hoff);
+            else if (hz) hnn.x = p3[hoff];
         }
         const size_t po = (size_t)x * sx;
 #pragma unroll
@@ -518,9 +522,11 @@ __global__ __launch_bounds__(256) void k_stencil3d(Stencil3Args a) {
             for (int r = 0; r < RPT; ++r) {
                 prev[r] = cur[r];
                 cur[r] = nxt[r];
-                nxt[r] = nn[r];
+                nxt[r] = nx2[r];
+                nx2[r] = nn[r];
             }
-            hnxt = hnn;
+            hnxt = hnx2;
+            hnx2 = hnn;
         }
     }
 }
@@ -844,6 +850,7 @@ struct SpecArgs {
 };
 
 // one thread per Fourier mode: gather on the cached transforms + node-coupled solve, S updated in place
+template <int NF>
 __global__ __launch_bounds__(256) void k_spec_point(SpecArgs a, int n, size_t nmodes) {
     for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < nmodes; g += (size_t)gridDim.x * blockDim.x) {
         const int kz = (int)(g % n);
@@ -859,32 +866,27 @@ __global__ __launch_bounds__(256) void k_spec_point(SpecArgs a, int n, size_t nm
             if (a.lamE) mu = cadd(mu, a.lamE[ln]);
         }
         const cd u0h = a.S0[g];
-        cd old[MAXM], u[MAXM];
+        cd old[NF], u[NF];
 #pragma unroll
-        for (int q = 0; q < MAXM; ++q)
-            if (q < a.nf) old[q] = a.spread ? u0h : a.S[q * a.fstride + g];
+        for (int q = 0; q < NF; ++q) old[q] = a.spread ? u0h : a.S[q * a.fstride + g];
 #pragma unroll
-        for (int m = 0; m < MAXM; ++m) {
-            if (m < a.nf) {
-                cd acc = u0h;
+        for (int m = 0; m < NF; ++m) {
+            cd acc = u0h;
 #pragma unroll
-                for (int q = 0; q < MAXM; ++q) {
-                    if (q < a.nf) {
-                        const double gi = a.gI[m][q], ge = a.gE[m][q];
-                        acc = cfma(cd{gi * lam.x + ge * mu.x, gi * lam.y + ge * mu.y}, old[q], acc);
-                    }
-                }
-                if (a.coupled) {
-#pragma unroll
-                    for (int q = 0; q < m; ++q) {
-                        const double ci = a.cI[m][q], ce = a.cE[m][q];
-                        acc = cfma(cd{ci * lam.x + ce * mu.x, ci * lam.y + ce * mu.y}, u[q], acc);
-                    }
-                }
-                const double al = a.alpha[m];
-                u[m] = cmul(acc, cinv_fast(cd{1.0 - al * lam.x, -al * lam.y}));
-                a.S[m * a.fstride + g] = u[m];
+            for (int q = 0; q < NF; ++q) {
+                const double gi = a.gI[m][q], ge = a.gE[m][q];
+                acc = cfma(cd{gi * lam.x + ge * mu.x, gi * lam.y + ge * mu.y}, old[q], acc);
             }
+            if (a.coupled) {
+#pragma unroll
+                for (int q = 0; q < m; ++q) {
+                    const double ci = a.cI[m][q], ce = a.cE[m][q];
+                    acc = cfma(cd{ci * lam.x + ce * mu.x, ci * lam.y + ce * mu.y}, u[q], acc);
+                }
+            }
+            const double al = a.alpha[m];
+            u[m] = cmul(acc, cinv_fast(cd{1.0 - al * lam.x, -al * lam.y}));
+            a.S[m * a.fstride + g] = u[m];
         }
     }
 }
@@ -1290,7 +1292,11 @@ static int spec_sweep_n(sdc_ctx* c, int nf, SpecArgs& a, const FieldPtrs& p) {
     {
         LaunchTimer lt(c, pname("spec_point", nf));
         const size_t nmodes = lines * N;
-        hipLaunchKernelGGL(k_spec_point, dim3(grid_for(nmodes, 256)), dim3(256), 0, c->stream, a, n, nmodes);
+        const dim3 grid(grid_for(nmodes, 256));
+#define SCASE(MM) \
+    case MM: hipLaunchKernelGGL((k_spec_point<MM>), grid, dim3(256), 0, c->stream, a, n, nmodes); break;
+        switch (nf) { SCASE(1) SCASE(2) SCASE(3) SCASE(4) SCASE(5) SCASE(6) SCASE(7) SCASE(8) }
+#undef SCASE
     }
     {
         LaunchTimer lt(c, pname("fft_z_inv", nf));
