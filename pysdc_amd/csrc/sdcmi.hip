@@ -248,6 +248,29 @@ __global__ __launch_bounds__(256) void k_quad(QuadArgs a) {
     }
 }
 
+struct LinArgs {
+    double* out;
+    const double* base;  // may alias out
+    const double* x[2 * MAXM];
+    double c[2 * MAXM];
+    int nterms;
+    size_t n;
+};
+
+// out = base + sum_k c[k] * x[k]   (right-hand side of one node: generic_implicit.py:87-89 / imex_1st_order.py:92-94)
+__global__ __launch_bounds__(256) void k_lincomb(LinArgs a) {
+    const size_t n2 = a.n >> 1;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x * blockDim.x) {
+        double2 acc = reinterpret_cast<const double2*>(a.base)[i];
+        for (int k = 0; k < a.nterms; ++k) {
+            const double2 v = reinterpret_cast<const double2*>(a.x[k])[i];
+            acc.x += a.c[k] * v.x;
+            acc.y += a.c[k] * v.y;
+        }
+        reinterpret_cast<double2*>(a.out)[i] = acc;
+    }
+}
+
 __global__ void k_amax(const double* __restrict__ x, size_t n, unsigned long long* slot) {
     double m = 0.0;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -1684,6 +1707,8 @@ int sdc_set_forcing_values(sdc_ctx* c, const double* g) {
 }
 
 extern "C" int sdc_invalidate_spectra(sdc_ctx* c, int which);
+extern "C" int sdc_solve(sdc_ctx* c, const double* rhs, double factor, const double* guess, double* out);
+extern "C" int sdc_eval_f(sdc_ctx* c, const double* u, double g_t, double* f_impl, double* f_expl);
 
 static int ensure_work(sdc_ctx* c) {
     if (!c->W) {
@@ -1846,6 +1871,64 @@ int sdc_predict(sdc_ctx* c, double t, double dt, int guess, double fill_u, doubl
     return SDC_OK;
 }
 
+// Node-by-node sweep on the device for right-hand sides that are not linear in u (pointwise reaction terms) or
+// whose implicit operator is given by its symbol only: the reference's loop (imex_1st_order.py:57-108 /
+// generic_implicit.py:51-103) with every step a kernel on the stream - gather for all nodes, then per node
+// right-hand side, solve (FFT pipeline), f evaluation (operator by FFT or stencil + explicit part).
+static int sweep_nodewise(sdc_ctx* c, double dt) {
+    const int M = c->M;
+    const bool imex = c->ncomp == 2;
+    QuadArgs q;
+    quad_base(c, q);
+    q.u0 = c->U;
+    q.tau = c->tau_active ? c->TAU : nullptr;
+    for (int m = 0; m < M; ++m) {
+        q.out[m] = c->U + (size_t)(m + 1) * c->N;  // the old iterate is only a solver guess: reuse its storage
+        for (int j = 0; j < M; ++j) {
+            q.cI[m][j] = dt * (c->Q[m + 1][j + 1] - c->QI[m + 1][j + 1]);
+            q.cE[m][j] = dt * (c->Q[m + 1][j + 1] - c->QE[m + 1][j + 1]);
+        }
+    }
+    int rc = launch_quad<0>(c, q, "gather");
+    if (rc != SDC_OK) return rc;
+    c->spec_valid = c->spec_spread = false;
+    for (int m = 0; m < M; ++m) {
+        double* um = c->U + (size_t)(m + 1) * c->N;
+        if (m > 0) {
+            LinArgs la;
+            memset(&la, 0, sizeof la);
+            la.out = um;
+            la.base = um;
+            la.n = c->N;
+            for (int j = 0; j < m; ++j) {
+                const double ci = dt * c->QI[m + 1][j + 1], ce = dt * c->QE[m + 1][j + 1];
+                if (ci != 0.0) {
+                    la.x[la.nterms] = c->F + ((size_t)(j + 1) * c->ncomp) * c->N;
+                    la.c[la.nterms++] = ci;
+                }
+                if (imex && ce != 0.0) {
+                    la.x[la.nterms] = c->F + ((size_t)(j + 1) * c->ncomp + 1) * c->N;
+                    la.c[la.nterms++] = ce;
+                }
+            }
+            if (la.nterms > 0) {
+                LaunchTimer lt(c, "node_rhs");
+                hipLaunchKernelGGL(k_lincomb, dim3(grid_for(c->N / 2, 256)), dim3(256), 0, c->stream, la);
+                HIPCHK(c, hipGetLastError());
+            }
+        }
+        const double alpha = dt * c->QI[m + 1][m + 1];
+        if (alpha != 0.0) {
+            rc = sdc_solve(c, um, alpha, um, um);
+            if (rc != SDC_OK) return rc;
+        }
+        rc = sdc_eval_f(c, um, c->gvals[m + 1], c->F + ((size_t)(m + 1) * c->ncomp) * c->N,
+                        imex ? c->F + ((size_t)(m + 1) * c->ncomp + 1) * c->N : nullptr);
+        if (rc != SDC_OK) return rc;
+    }
+    return SDC_OK;
+}
+
 int sdc_sweep(sdc_ctx* c, double t, double dt) {
     (void)t;
     if (!c) return SDC_ERR_PARAM;
@@ -1884,10 +1967,7 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
     }
     if (c->expl_kind == SDC_EXPL_STENCIL && !c->have_stencil[1])
         return fail(c, SDC_ERR_STATE, "explicit operator not set (sdc_set_stencil which=1)");
-    if (c->expl_kind == SDC_EXPL_REACTION)
-        return fail(c, SDC_ERR_UNSUPPORTED, "a nonlinear explicit part is swept node by node (eval_f / solve), not fused");
-    if (c->spectral_op)
-        return fail(c, SDC_ERR_UNSUPPORTED, "operators given by their symbol only are swept node by node (eval_f / solve)");
+    if (c->expl_kind == SDC_EXPL_REACTION || c->spectral_op) return sweep_nodewise(c, dt);
     const bool gather_once = c->force_gather;
     c->force_gather = false;
     if (c->reuse && !gather_once && !c->tau_active && c->expl_kind != SDC_EXPL_FORCING && c->have_stencil[0] &&

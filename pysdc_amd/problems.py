@@ -414,7 +414,7 @@ class _SpectralLaplacianIMEX(Problem):
 
     dtype_f = hip_imex_mesh
     ncomp = 2
-    fused = False  # nonlinear explicit part: the sweeper goes node by node through eval_f / solve_system
+    fused = True  # the engine sweeps node by node on the device (nonlinear explicit part: sdc_sweep -> sweep_nodewise)
 
     def _symbol(self):
         n = self.nvars[0]

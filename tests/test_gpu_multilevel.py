@@ -114,8 +114,9 @@ def test_mlsdc_pfasst_on_device(fname, name):
     np.testing.assert_allclose(res, case['res'], rtol=1e-5, atol=1e-11)
 
 
+@pytest.mark.parametrize('fused', [True, False])
 @pytest.mark.parametrize('name', list(load_cases('sweeps_ac.npz')))
-def test_allencahn_sweeps_on_device(name):
+def test_allencahn_sweeps_on_device(name, fused):
     """pseudo-spectral Allen-Cahn (nonlinear explicit part): node-by-node IMEX sweeps on the device against
     golden sweeps of the reference's allencahn2d_imex."""
     from pysdc_amd.level import Step
@@ -126,7 +127,8 @@ def test_allencahn_sweeps_on_device(name):
     meta = case['meta']
     pp = dict(meta['prob_params'])
     pp['nvars'] = tuple(pp['nvars'])
-    S = Step(dict(problem_class=allencahn2d_imex, problem_params=pp, sweeper_class=imex_1st_order,
+    pc = allencahn2d_imex if fused else type('ac2d_python_nodes', (allencahn2d_imex,), {'fused': False})
+    S = Step(dict(problem_class=pc, problem_params=pp, sweeper_class=imex_1st_order,
                   sweeper_params=dict(meta['sweeper_params']), level_params=dict(dt=meta['dt']),
                   step_params=dict(maxiter=10)))
     L = S.levels[0]
