@@ -96,6 +96,8 @@ def main():
     ap.add_argument('--sweeps', type=int, default=4)
     ap.add_argument('--qi', default='IE')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--force-dist', action='store_true',
+                    help='use the one-step-per-rank controller and torch.distributed even with one GPU (self test)')
     ap.add_argument('--no-spectral-reuse', action='store_true',
                     help='transform the gathered fields in every sweep instead of gathering on cached transforms')
     args = ap.parse_args()
@@ -110,9 +112,12 @@ def main():
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29531')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
 
     import ctypes as C
 
@@ -179,7 +184,7 @@ def main():
     cparams = dict(logger_level=40)
     if args.workload == 'allencahn' and world > 1:
         cparams['predict_type'] = 'pfasst_burnin'
-    if world == 1:
+    if not use_dist:
         ctrl = controller_nonMPI(1, cparams, desc)
         step = ctrl.MS[0]
     else:
@@ -198,7 +203,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -214,7 +219,7 @@ def main():
     eng.profile_enable(False)
 
     elt = torch.tensor([el], dtype=torch.float64, device='cuda')
-    if world > 1:
+    if use_dist:
         dist.all_reduce(elt, op=dist.ReduceOp.MAX)
     el = float(elt.item())
     niter = [v for _, v in get_sorted(stats, type='niter')]
@@ -277,7 +282,7 @@ def main():
             except Exception as e:  # pragma: no cover
                 out['cpu_baseline'] = {'error': repr(e)}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

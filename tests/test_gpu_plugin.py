@@ -188,3 +188,45 @@ def test_vdp_newton_failure_raises():
     L.sweep.predict()
     with pytest.raises(ProblemError):
         L.sweep.update_nodes()
+
+
+def test_slab_view_as_torch_aliases_device_memory():
+    """the tensors handed to torch.distributed (RCCL send / recv / broadcast) alias the engine's slabs."""
+    import torch
+    from pysdc_amd.level import Step
+    from pysdc_amd.problems import heatNd_unforced
+    from pysdc_amd.sweepers import generic_implicit
+
+    S = Step(dict(problem_class=heatNd_unforced, problem_params=dict(nvars=(16, 16), nu=0.1, freq=2),
+                  sweeper_class=generic_implicit, sweeper_params=dict(num_nodes=3, quad_type='RADAU-RIGHT'),
+                  level_params=dict(dt=0.01), step_params=dict(maxiter=5)))
+    L = S.levels[0]
+    L.u[0] = L.prob.u_exact(0.0)
+    t = L.u[0].as_torch()
+    assert t.is_cuda and t.dtype == torch.float64 and t.numel() == 256 and t.data_ptr() == L.u[0].ptr
+    t.mul_(2.0)
+    torch.cuda.synchronize()
+    assert np.allclose(L.u[0].get(), 2.0 * L.prob.u_exact(0.0).get())
+    own = L.prob.u_init
+    assert own.as_torch().data_ptr() == own.ptr
+
+
+def test_bench_single_rank_distributed_path():
+    """bench.py through controller_dist + torch.distributed (nccl world of one rank, gloo side group):
+    the multi-GPU code path minus the neighbour exchange."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT='29547')
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--n', '64', '--steps', '2', '--warmup', '1',
+                          '--no-cpu-baseline', '--force-dist'], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith('{')][-1]
+    d = json.loads(line)
+    assert d['n_gpus'] == 1 and d['finite'] and d['value'] > 0
+    ref = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--n', '64', '--steps', '2', '--warmup', '1',
+                          '--no-cpu-baseline'], capture_output=True, text=True, timeout=600)
+    assert ref.returncode == 0, ref.stderr[-2000:]
