@@ -325,6 +325,15 @@ class controller_nonMPI(_ControllerBase):
             S.status.stage = 'IT_FINE'
 
 
+class _WorkList:
+    def __init__(self, works):
+        self.works = works
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+
+
 class controller_dist(_ControllerBase):
     """One time step per rank (= per GPU).  ``comm``: torch.distributed group carrying the state vectors
     (RCCL on GPUs); 1-byte convergence flags and step counts use a gloo side group so they never touch the
@@ -444,15 +453,16 @@ class controller_dist(_ControllerBase):
         if do_recv:
             ops.append(self.dist.P2POp(self.dist.irecv, L.u[0].as_torch(), self.rank - 1, self.comm, tag))
         if ops:
+            # one batched launch (ncclGroupStart/End under RCCL): depending on the torch version this returns one
+            # work object per operation or a single one for the whole group, so a group that contains the
+            # receive is completed as a whole; a lone send stays in flight behind the next sweep
             reqs = self.dist.batch_isend_irecv(ops)
             sending = send and not S.status.last
-            if sending:
-                self.req_send[level] = reqs[0]  # waited for before UEND is overwritten again ("send and forget")
-            for r in reqs[(1 if sending else 0):]:
-                r.wait()
-            if blocking_send and self.req_send[level] is not None:
-                self.req_send[level].wait()
-                self.req_send[level] = None
+            if do_recv or blocking_send or not sending:
+                for r in reqs:
+                    r.wait()
+            else:
+                self.req_send[level] = reqs[0] if len(reqs) == 1 else _WorkList(reqs)
         if do_recv:
             L._touched(0, 0)  # u[0] was overwritten by the receive
             L.f[0] = L.prob.eval_f(L.u[0], L.time)
