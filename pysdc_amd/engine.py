@@ -16,8 +16,15 @@ class SweepEngine:
 
     nvars: tuple of equal even ints (ndim <= 3); ncomp: 1 (implicit) or 2 (IMEX)."""
 
-    def __init__(self, nvars, num_nodes, ncomp=1, device=0, stream=0):
+    def __init__(self, nvars, num_nodes, ncomp=1, device=None, stream=0):
         self.lib = L.load()
+        if device is None:  # one process per GPU: follow torch's current device (LOCAL_RANK)
+            try:
+                import torch
+
+                device = torch.cuda.current_device() if torch.cuda.is_available() else 0
+            except Exception:  # pragma: no cover
+                device = 0
         nvars = (nvars,) if isinstance(nvars, int) else tuple(int(v) for v in nvars)
         if len(set(nvars)) != 1:
             raise ParameterError('need a square domain, got %s' % (nvars,))
