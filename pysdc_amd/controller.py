@@ -356,6 +356,7 @@ class controller_dist(_ControllerBase):
         self.S.status.slot = self.rank
         self.nsweeps = [L.params.nsweeps for L in self.S.levels]
         self.req_send = [None] * len(self.S.levels)
+        self._exchanged_unchanged = False
 
     # ---- host-side scalars (check_convergence.py:105-160; controller_MPI.py:90,120,142) ---------------------
     def _send_flag(self, value, dst):
@@ -432,6 +433,7 @@ class controller_dist(_ControllerBase):
             lvl.status.sweep = 1
             lvl.status.time = time
         self.req_send = [None] * len(S.levels)
+        self._exchanged_unchanged = False
 
     # controller_MPI.py:235-305.  send_full followed by recv_full is issued as ONE batched P2P group
     # (ncclGroupStart/End under RCCL) so that the send to rank+1 and the receive from rank-1 progress
@@ -495,6 +497,7 @@ class controller_dist(_ControllerBase):
         S = self.S
         L = S.levels[0]
         self.exchange(0)
+        self._exchanged_unchanged = True  # nothing on level 0 changes until the next sweep / prolongation
         L.sweep.compute_residual(stage='IT_CHECK')
         if S.status.iter > 0:
             self._hook('post_iteration', S)
@@ -532,7 +535,13 @@ class controller_dist(_ControllerBase):
         L.status.sweep = 0
         for k in range(self.nsweeps[0]):
             L.status.sweep += 1
-            self.exchange(0)
+            # Straight after it_check (single level) the reference sends the same end value again and the
+            # receiver overwrites u[0] with the same bits (controller_MPI.py:574-583 then :680-688).  Every rank
+            # knows that from the stage sequence alone, so the second message is skipped: identical results,
+            # half the neighbour traffic.
+            if not (k == 0 and len(S.levels) == 1 and self._exchanged_unchanged):
+                self.exchange(0)
+            self._exchanged_unchanged = False
             self._hook('pre_sweep', S)
             L.sweep.updateVariableCoeffs(k + 1)
             L.sweep.update_nodes()
