@@ -40,6 +40,7 @@ def _kernel_bytes(name, n, M, ncomp=1):
         'fft_y_inv': 2 * nf * spec,
         'fft_x_inv': nf * (field + spec),
         'stencil': 2 * nf * field if ncomp == 1 else 3 * nf * field,  # IMEX: one read, impl + expl written
+        'stencil_res': (1 + 2 * nf) * field,            # u0 + U[1..M] in, F[1..M] out, node norms of the residual
         'residual': (1 + M * ncomp + M) * field,        # u0, F[1..M], U[1..M] -> M norms
         'spread': (2 + 2 * M) * field,
         'copy': 2 * field,
@@ -256,7 +257,7 @@ def main():
                     'algorithmic_bytes_per_launch': kernel_bytes(dom[0], n, M),
                     'ms_per_launch': dom[1][0] / dom[1][1]}
         in_sweep = ('gather', 'fft_x_fwd', 'fft_y_fwd', 'fft_z_fwd', 'fft_z_solve', 'spec_point', 'fft_z_inv', 'fft_y_inv',
-                    'fft_x_inv', 'stencil', 'vdp_sweep')
+                    'fft_x_inv', 'stencil', 'stencil_res', 'vdp_sweep')
         sweep_ms = sum(v[0] for k, v in prof.items() if k.split('[')[0] in in_sweep) / max(1, sweeps_total // world)
         out = {
             'metric': {'heat': 'time-steps/s (HeatND 3-D FD, M=5, implicit SDC sweeps)',

@@ -90,6 +90,9 @@ int sdc_set_tau_active(sdc_ctx* ctx, int active); /* L.tau[m] is None  <->  0 */
  * gathers on the F slab like the reference does); bits combine.  sdc_upload / sdc_predict do it themselves. */
 int sdc_invalidate_spectra(sdc_ctx* ctx, int which);
 int sdc_set_spectral_reuse(sdc_ctx* ctx, int on);
+/* The 3-D sweep evaluates f at all nodes and the node norms of the collocation residual in ONE kernel; a
+ * following sdc_residual with the same dt then returns those norms without another pass (default on). */
+int sdc_set_fused_residual(sdc_ctx* ctx, int on);
 /* L.status.unlocked: set by sdc_predict; a coarse level is unlocked by the restriction instead
  * (pySDC/core/base_transfer.py:166) - the host mirrors that here. */
 int sdc_set_unlocked(sdc_ctx* ctx, int unlocked); /* default on; 0 = transform the gathered fields every sweep */

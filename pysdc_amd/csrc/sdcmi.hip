@@ -53,6 +53,10 @@ struct sdc_ctx {
     unsigned long long* red_host = nullptr;
     bool tau_active = false, have_coeffs = false, have_stencil[2] = {false, false}, unlocked = false;
     int expl_kind = SDC_EXPL_NONE;
+    bool fuse_residual = true;
+    bool res_valid = false;   // node norms of the residual were produced by the fused stencil kernel
+    double res_dt = 0.0;
+    unsigned long long* res_dev = nullptr;  // device slots of those norms
     bool spectral_op = false;  // implicit operator given by its Fourier symbol only (no stencil): eval_f by FFT
     int react_kind = 0, react_nu = 2;
     double react_p0 = 0, react_p1 = 0;
@@ -551,6 +555,155 @@ __global__ __launch_bounds__(256, 4) void k_stencil3d(Stencil3Args a) {
             hnxt = hnx2;
             hnx2 = hnn;
         }
+    }
+}
+
+// eval_f for ALL nodes fused with the collocation residual: a workgroup marches the (y,z) tile through x for
+// the M fields U[1..M] at once, so at every point all f_j = A u_j are in registers when the residual
+// u0 + dt sum_j Q[m][j] f_j - u_m (core/sweeper.py:186-199) is formed.  Replaces stencil (10 field passes) +
+// residual (11) by one kernel with 6 reads + 5 writes.
+struct StencilResArgs {
+    const double* U;  // slab: U[0] = u0, U[1..M]
+    double* F;        // slab (ncomp == 1)
+    double wI[3];
+    double cQ[MAXM][MAXM];  // dt * Q[m+1][j+1]
+    unsigned long long* norms;
+    int n, xchunk, nchunks;
+    size_t N;
+};
+
+template <int M>
+__global__ __launch_bounds__(256, 2) void k_stencil3d_res(StencilResArgs a) {
+    constexpr int TZ = 64, TY = 8, LW = TZ + 4;
+    __shared__ double tile[2][M][TY + 2][LW];
+    const int n = a.n;
+    const int tz = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int ntz = n / TZ, nty = n / TY;
+    unsigned lb = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int zt = lb % ntz;
+    lb /= ntz;
+    const int yt = lb % nty;
+    const int chunk = lb / nty;
+    const int z0 = zt * TZ, y0 = yt * TY, x0 = chunk * a.xchunk;
+    const size_t sx = (size_t)n * n;
+    const int t = threadIdx.x;
+    const bool hy = t < 64, hz = t >= 64 && t < 64 + 2 * TY;
+    size_t hoff = 0;
+    int hrow = 0, hcol = 0;
+    if (hy) {
+        const int side = t >> 5, pz = t & 31;
+        const int yy = side == 0 ? (y0 == 0 ? n - 1 : y0 - 1) : (y0 + TY == n ? 0 : y0 + TY);
+        hoff = (size_t)yy * n + z0 + 2 * pz;
+        hrow = side == 0 ? 0 : TY + 1;
+        hcol = 1 + 2 * pz;
+    } else if (hz) {
+        const int q = t - 64, side = q / TY, r = q % TY;
+        const int zz = side == 0 ? (z0 == 0 ? n - 1 : z0 - 1) : (z0 + TZ == n ? 0 : z0 + TZ);
+        hoff = (size_t)(y0 + r) * n + zz;
+        hrow = r + 1;
+        hcol = side == 0 ? 0 : TZ + 1;
+    }
+    const size_t off = (size_t)(y0 + ty) * n + z0 + 2 * tz;
+    auto wrapx = [&](int x) { return (size_t)(x < 0 ? x + n : (x >= n ? x - n : x)) * sx; };
+    double2 prev[M], cur[M], nxt[M], hnxt[M];
+    double2 u0c, u0n = double2{0.0, 0.0};
+    double nmax[M];
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+        const double* uj = a.U + (size_t)(j + 1) * a.N;
+        prev[j] = *reinterpret_cast<const double2*>(uj + wrapx(x0 - 1) + off);
+        cur[j] = *reinterpret_cast<const double2*>(uj + wrapx(x0) + off);
+        nxt[j] = *reinterpret_cast<const double2*>(uj + wrapx(x0 + 1) + off);
+        double2 hc = double2{0.0, 0.0};
+        hnxt[j] = double2{0.0, 0.0};
+        if (hy) {
+            hc = *reinterpret_cast<const double2*>(uj + wrapx(x0) + hoff);
+            hnxt[j] = *reinterpret_cast<const double2*>(uj + wrapx(x0 + 1) + hoff);
+        } else if (hz) {
+            hc.x = uj[wrapx(x0) + hoff];
+            hnxt[j].x = uj[wrapx(x0 + 1) + hoff];
+        }
+        tile[0][j][ty + 1][1 + 2 * tz] = cur[j].x;
+        tile[0][j][ty + 1][2 + 2 * tz] = cur[j].y;
+        if (hy) {
+            tile[0][j][hrow][hcol] = hc.x;
+            tile[0][j][hrow][hcol + 1] = hc.y;
+        } else if (hz) {
+            tile[0][j][hrow][hcol] = hc.x;
+        }
+        nmax[j] = 0.0;
+    }
+    u0c = *reinterpret_cast<const double2*>(a.U + wrapx(x0) + off);
+    const double cI = 3.0 * a.wI[1];
+    for (int p = 0; p < a.xchunk; ++p) {
+        const int b = p & 1;
+        const int x = x0 + p;
+        __syncthreads();
+        const bool more = p + 1 < a.xchunk;
+        double2 nn[M], hnn[M];
+        if (more) {
+            const size_t px2 = wrapx(x + 2);
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                const double* uj = a.U + (size_t)(j + 1) * a.N;
+                nn[j] = *reinterpret_cast<const double2*>(uj + px2 + off);
+                hnn[j] = double2{0.0, 0.0};
+                if (hy) hnn[j] = *reinterpret_cast<const double2*>(uj + px2 + hoff);
+                else if (hz) hnn[j].x = uj[px2 + hoff];
+            }
+            u0n = *reinterpret_cast<const double2*>(a.U + wrapx(x + 1) + off);
+        }
+        const size_t po = (size_t)x * sx + off;
+        double2 fv[M];
+        const int row = ty + 1, col = 1 + 2 * tz;
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            const double ym0 = tile[b][j][row - 1][col], ym1 = tile[b][j][row - 1][col + 1];
+            const double yp0 = tile[b][j][row + 1][col], yp1 = tile[b][j][row + 1][col + 1];
+            const double zm = tile[b][j][row][col - 1], zp = tile[b][j][row][col + 2];
+            const double c0 = cur[j].x, c1 = cur[j].y;
+            fv[j].x = (a.wI[0] * prev[j].x + a.wI[2] * nxt[j].x) + (a.wI[0] * ym0 + a.wI[2] * yp0) +
+                      (a.wI[0] * zm + a.wI[2] * c1) + cI * c0;
+            fv[j].y = (a.wI[0] * prev[j].y + a.wI[2] * nxt[j].y) + (a.wI[0] * ym1 + a.wI[2] * yp1) +
+                      (a.wI[0] * c0 + a.wI[2] * zp) + cI * c1;
+            *reinterpret_cast<double2*>(a.F + (size_t)(j + 1) * a.N + po) = fv[j];
+        }
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            double r0 = 0.0, r1 = 0.0;
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                r0 += a.cQ[m][j] * fv[j].x;
+                r1 += a.cQ[m][j] * fv[j].y;
+            }
+            r0 = fabs((r0 + u0c.x) - cur[m].x);
+            r1 = fabs((r1 + u0c.y) - cur[m].y);
+            const double r = (r0 > r1 || r0 != r0) ? r0 : r1;
+            nmax[m] = (nmax[m] > r || nmax[m] != nmax[m]) ? nmax[m] : r;
+        }
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                tile[b ^ 1][j][ty + 1][1 + 2 * tz] = nxt[j].x;
+                tile[b ^ 1][j][ty + 1][2 + 2 * tz] = nxt[j].y;
+                if (hy) {
+                    tile[b ^ 1][j][hrow][hcol] = hnxt[j].x;
+                    tile[b ^ 1][j][hrow][hcol + 1] = hnxt[j].y;
+                } else if (hz) {
+                    tile[b ^ 1][j][hrow][hcol] = hnxt[j].x;
+                }
+                prev[j] = cur[j];
+                cur[j] = nxt[j];
+                nxt[j] = nn[j];
+                hnxt[j] = hnn[j];
+            }
+            u0c = u0n;
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        const double v = wave_max(nmax[m]);
+        if ((threadIdx.x & 63) == 0) atomic_max_abs(a.norms + m, v);
     }
 }
 
@@ -1208,6 +1361,50 @@ static int run_stencil(sdc_ctx* c, int nf, const double* const* in, double* cons
     return SDC_OK;
 }
 
+// F[1..M] = A U[1..M] for the new iterate; fused with the residual when the fast 3-D kernel applies
+static int eval_nodes(sdc_ctx* c, double dt) {
+    const int M = c->M;
+    auto three = [](const Stencil& s) { return s.npts == 3 && s.off[0] == -1 && s.off[1] == 0 && s.off[2] == 1; };
+    if (c->fuse_residual && c->ndim == 3 && c->ncomp == 1 && !c->tau_active && c->n % 64 == 0 && three(c->st[0])) {
+        StencilResArgs a;
+        memset(&a, 0, sizeof a);
+        a.U = c->U;
+        a.F = c->F;
+        for (int k = 0; k < 3; ++k) a.wI[k] = c->st[0].w[k];
+        for (int m = 0; m < M; ++m)
+            for (int j = 0; j < M; ++j) a.cQ[m][j] = dt * c->Q[m + 1][j + 1];
+        a.norms = c->res_dev;
+        a.n = c->n;
+        a.N = c->N;
+        a.xchunk = c->n >= 64 ? 64 : c->n;
+        a.nchunks = c->n / a.xchunk;
+        HIPCHK(c, hipMemsetAsync(c->res_dev, 0, sizeof(unsigned long long) * 8, c->stream));
+        const unsigned grid = (unsigned)((c->n / 64) * (c->n / 8) * a.nchunks);
+        {
+            LaunchTimer lt(c, pname("stencil_res", M));
+#define RCASE(MM) \
+    case MM: hipLaunchKernelGGL((k_stencil3d_res<MM>), dim3(grid), dim3(256), 0, c->stream, a); break;
+            switch (M) { RCASE(1) RCASE(2) RCASE(3) RCASE(4) RCASE(5) RCASE(6) RCASE(7) RCASE(8) }
+#undef RCASE
+        }
+        HIPCHK(c, hipGetLastError());
+        c->res_valid = true;
+        c->res_dt = dt;
+        return SDC_OK;
+    }
+    const double* in[MAXM];
+    double* oi[MAXM];
+    double* oe[MAXM];
+    double g[MAXM];
+    for (int m = 0; m < M; ++m) {
+        in[m] = c->U + (size_t)(m + 1) * c->N;
+        oi[m] = c->F + ((size_t)(m + 1) * c->ncomp) * c->N;
+        oe[m] = (c->ncomp == 2 && c->expl_kind == SDC_EXPL_STENCIL) ? oi[m] + c->N : nullptr;
+        g[m] = c->gvals[m + 1];
+    }
+    return run_stencil(c, M, in, oi, c->expl_kind == SDC_EXPL_STENCIL ? oe : nullptr, g);
+}
+
 template <int N>
 static int fft_pipeline_n(sdc_ctx* c, int nf, const FieldPtrs& p, ZArgs& z) {
     constexpr int E = fft_elems(N), P = N / E;
@@ -1531,6 +1728,7 @@ int sdc_ctx_create(sdc_ctx** out, int device, int ndim, int n, int num_nodes, in
         HIPCHK(nullptr, hipHostMalloc((void**)&c->red_host, sizeof(unsigned long long) * 16));
         c->bytes = fb * (c->M + 1) * (1 + ncomp) + fb;
         HIPCHK(nullptr, hipMalloc((void**)&c->counters, sizeof(unsigned long long) * 4));
+        HIPCHK(nullptr, hipMalloc((void**)&c->res_dev, sizeof(unsigned long long) * 8));
         HIPCHK(nullptr, hipMemsetAsync(c->counters, 0, sizeof(unsigned long long) * 4, c->stream));
         HIPCHK(nullptr, hipMemsetAsync(c->U, 0, fb * (c->M + 1), c->stream));
         HIPCHK(nullptr, hipMemsetAsync(c->F, 0, fb * (c->M + 1) * ncomp, c->stream));
@@ -1575,6 +1773,7 @@ int sdc_ctx_destroy(sdc_ctx* c) {
     (void)hipFree(c->profile);
     (void)hipFree(c->red);
     (void)hipFree(c->counters);
+    (void)hipFree(c->res_dev);
     if (c->red_host) (void)hipHostFree(c->red_host);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -1604,6 +1803,7 @@ int sdc_set_coeffs(sdc_ctx* c, const double* Qmat, const double* QI, const doubl
         c->weights[m] = weights[m];
     }
     c->have_coeffs = true;
+    c->res_valid = false;
     return SDC_OK;
 }
 
@@ -1736,6 +1936,7 @@ void* sdc_slot_ptr(sdc_ctx* c, int slot, int m, int comp) {
 
 int sdc_invalidate_spectra(sdc_ctx* c, int which) {
     if (!c) return SDC_ERR_PARAM;
+    c->res_valid = false;
     if (which & 1) {
         c->spec0_valid = false;
         c->spec_spread = false;  // "all nodes equal U[0]" no longer holds for the new U[0]
@@ -1745,6 +1946,13 @@ int sdc_invalidate_spectra(sdc_ctx* c, int which) {
         c->spec_spread = false;
     }
     if (which & 4) c->force_gather = true;  // some F[m >= 1] no longer equals f(U[m]): gather on F itself
+    return SDC_OK;
+}
+
+int sdc_set_fused_residual(sdc_ctx* c, int on) {
+    if (!c) return SDC_ERR_PARAM;
+    c->fuse_residual = on != 0;
+    c->res_valid = false;
     return SDC_OK;
 }
 
@@ -1768,6 +1976,7 @@ int sdc_set_tau_active(sdc_ctx* c, int active) {
         if (rc != SDC_OK) return rc;
     }
     c->tau_active = active != 0;
+    c->res_valid = false;
     return SDC_OK;
 }
 
@@ -1777,6 +1986,7 @@ int sdc_upload(sdc_ctx* c, int slot, int m, int comp, const double* host) {
     if (!d) return fail(c, SDC_ERR_PARAM, "bad slot (%d, %d, %d)", slot, m, comp);
     HIPCHK(c, hipMemcpyAsync(d, host, c->N * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->res_valid = false;
     if (slot == SDC_SLOT_U) sdc_invalidate_spectra(c, m == 0 ? 1 : 2);
     return SDC_OK;
 }
@@ -1866,6 +2076,7 @@ int sdc_predict(sdc_ctx* c, double t, double dt, int guess, double fill_u, doubl
     // 'spread' evaluates f at every node in the reference (core/sweeper.py:142-143); the engine copies F[0]
     if (c->kind == 1 && guess == SDC_GUESS_SPREAD) c->rhs_host += (unsigned long long)c->M * (c->N / 2);
     c->unlocked = true;
+    c->res_valid = false;
     c->spec_valid = false;
     c->spec_spread = (guess == SDC_GUESS_SPREAD || guess == SDC_GUESS_COPY);  // all nodes equal U[0]
     return SDC_OK;
@@ -1935,6 +2146,7 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
     if (!c->have_coeffs) return fail(c, SDC_ERR_STATE, "coefficients not set (sdc_set_coeffs)");
     if (!c->unlocked) return fail(c, SDC_ERR_STATE, "level is locked: predict first (assert L.status.unlocked)");
     const int M = c->M;
+    c->res_valid = false;
     if (c->kind == 1) {
         VdpSweepArgs a;
         memset(&a, 0, sizeof a);
@@ -2025,15 +2237,7 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
         if (rc0 != SDC_OK) return rc0;
         c->spec_valid = true;
         c->spec_spread = false;
-        const double* in[MAXM];
-        double* oi[MAXM];
-        double* oe[MAXM];
-        for (int m = 0; m < M; ++m) {
-            in[m] = c->U + (size_t)(m + 1) * c->N;
-            oi[m] = c->F + ((size_t)(m + 1) * c->ncomp) * c->N;
-            oe[m] = c->ncomp == 2 ? oi[m] + c->N : nullptr;
-        }
-        return run_stencil(c, M, in, oi, c->expl_kind == SDC_EXPL_STENCIL ? oe : nullptr, nullptr);
+        return eval_nodes(c, dt);
     }
     c->spec_valid = false;
     c->spec_spread = false;
@@ -2074,18 +2278,8 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
     z.lamE = c->expl_kind == SDC_EXPL_STENCIL ? c->lamE : nullptr;
     rc = fft_pipeline(c, M, p, z);
     if (rc != SDC_OK) return rc;
-    // 3. F[m] = f(U[m]) for the new values
-    const double* in[MAXM];
-    double* oi[MAXM];
-    double* oe[MAXM];
-    double g[MAXM];
-    for (int m = 0; m < M; ++m) {
-        in[m] = c->U + (size_t)(m + 1) * c->N;
-        oi[m] = c->F + ((size_t)(m + 1) * c->ncomp) * c->N;
-        oe[m] = (c->ncomp == 2 && c->expl_kind == SDC_EXPL_STENCIL) ? oi[m] + c->N : nullptr;
-        g[m] = c->gvals[m + 1];
-    }
-    return run_stencil(c, M, in, oi, c->expl_kind == SDC_EXPL_STENCIL ? oe : nullptr, g);
+    // 3. F[m] = f(U[m]) for the new values (+ the residual when it fuses)
+    return eval_nodes(c, dt);
 }
 
 int sdc_solve(sdc_ctx* c, const double* rhs, double factor, const double* guess, double* out) {
@@ -2120,16 +2314,21 @@ int sdc_residual(sdc_ctx* c, double dt, int type, double* node_norms, double* re
                     "residual_type = %d not implemented, choose full_abs, last_abs, full_rel or last_rel instead", type);
     const int M = c->M;
     HIPCHK(c, hipMemsetAsync(c->red, 0, sizeof(unsigned long long) * 16, c->stream));
-    QuadArgs q;
-    quad_base(c, q);
-    q.u0 = c->U;
-    q.tau = c->tau_active ? c->TAU : nullptr;
-    q.Usub = c->U;
-    q.norms = c->red;
-    for (int m = 0; m < M; ++m)
-        for (int j = 0; j < M; ++j) q.cI[m][j] = q.cE[m][j] = dt * c->Q[m + 1][j + 1];
-    int rc = launch_quad<1>(c, q, "residual");
-    if (rc != SDC_OK) return rc;
+    if (c->res_valid && c->res_dt == dt) {
+        // the sweep's fused eval_f kernel already reduced the node norms of this very state
+        HIPCHK(c, hipMemcpyAsync(c->red, c->res_dev, sizeof(unsigned long long) * 8, hipMemcpyDeviceToDevice, c->stream));
+    } else {
+        QuadArgs q;
+        quad_base(c, q);
+        q.u0 = c->U;
+        q.tau = c->tau_active ? c->TAU : nullptr;
+        q.Usub = c->U;
+        q.norms = c->red;
+        for (int m = 0; m < M; ++m)
+            for (int j = 0; j < M; ++j) q.cI[m][j] = q.cE[m][j] = dt * c->Q[m + 1][j + 1];
+        int rc = launch_quad<1>(c, q, "residual");
+        if (rc != SDC_OK) return rc;
+    }
     if (type >= SDC_RES_FULL_REL) {
         LaunchTimer lt(c, "amax");
         hipLaunchKernelGGL(k_amax, dim3(grid_for(c->N, 256)), dim3(256), 0, c->stream, c->U, c->N, c->red + 8);

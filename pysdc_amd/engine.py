@@ -88,6 +88,9 @@ class SweepEngine:
     def invalidate_spectra(self, which=3):
         self._chk(self.lib.sdc_invalidate_spectra(self.ctx, int(which)))
 
+    def set_fused_residual(self, on):
+        self._chk(self.lib.sdc_set_fused_residual(self.ctx, int(bool(on))))
+
     def set_unlocked(self, unlocked=True):
         self._chk(self.lib.sdc_set_unlocked(self.ctx, int(bool(unlocked))))
 

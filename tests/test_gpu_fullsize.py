@@ -136,3 +136,35 @@ def test_reuse_and_gather_paths_agree_fullsize():
     assert abs(ra - rb) < 1e-11
     for e in engines:
         e.close()
+
+
+@pytest.mark.parametrize('n', [64, 256])
+def test_fused_residual_matches_separate_kernels(n):
+    """the sweep's fused eval_f + residual kernel against the separate stencil and residual kernels on the
+    same noisy state (same U by construction; F and the node norms must agree)."""
+    M, dt = 5, 1e-3 * (512.0 / n) ** 2
+    c, qi = _coeffs(M, 'LU')
+    out = []
+    for fused in (True, False):
+        e = G.engine_for('heat_unforced', dict(nvars=(n, n, n), nu=0.1), M)
+        e.set_coeffs(c.Qmat, qi, None, c.nodes, c.weights)
+        e.set_fused_residual(fused)
+        freq = (C.c_int * 3)(2, 4, 2)
+        L.check(e.lib.sdc_init_field(e.ctx, e.ptr(L.SLOT_U, 0), freq, 0.3, 11), e.ctx)
+        e.invalidate_spectra(1)
+        e.predict(0.0, dt)
+        for _ in range(2):
+            e.sweep(0.0, dt)
+        res, norms = e.residual(dt)
+        out.append((e, res, norms))
+    (a, ra, na), (b, rb, nb) = out
+    assert np.allclose(na, nb, rtol=1e-9, atol=1e-13) and abs(ra - rb) <= 1e-9 * abs(rb)
+    tmp = a.ptr(L.SLOT_UEND)
+    for m in range(1, M + 1):
+        a.vec_axpby(a.N, 1.0, a.ptr(L.SLOT_F, m), -1.0, b.ptr(L.SLOT_F, m), tmp)
+        assert a.vec_amax(a.N, tmp) <= 1e-12 * b.vec_amax(b.N, b.ptr(L.SLOT_F, m))
+    # a write through the API invalidates the cached norms
+    a.upload(L.SLOT_U, 2, np.zeros((n, n, n)))
+    assert abs(a.residual(dt)[0] - ra) > 0
+    for e, _, _ in out:
+        e.close()
