@@ -17,7 +17,7 @@ import logging
 import numpy as np
 
 from pysdc_amd.errors import CommunicationError, ControllerError, ParameterError
-from pysdc_amd.hooks import DefaultHooks, Hooks, Timings
+from pysdc_amd.hooks import CPUTimings, DefaultHooks, Hooks
 from pysdc_amd.level import Step
 
 
@@ -50,7 +50,7 @@ class _ControllerBase:
     def __init__(self, controller_params, description):
         self.params = _Pars(dict(controller_params))
         self.logger = logging.getLogger('controller')
-        self.hooks = [DefaultHooks(), Timings()]
+        self.hooks = [DefaultHooks(), CPUTimings()]
         hook_class = controller_params.get('hook_class', [])
         if not isinstance(hook_class, list):
             hook_class = [hook_class]

@@ -75,33 +75,102 @@ class DefaultHooks(Hooks):
 
 
 class Timings(Hooks):
-    """log_timings.py: timing_run / timing_step / timing_iteration / timing_sweep / timing_comm."""
+    """log_timings.py:10-342: timing_run / timing_step / timing_iteration / timing_sweep / timing_comm, keyed
+    like the reference (value in seconds).  ``_get_event`` / ``_compute_time_elapsed`` select the clock."""
+
+    prefix = ''
 
     def __init__(self):
         super().__init__()
         self._t = {}
 
-    @staticmethod
-    def _now(step=None):
+    def _get_event(self):
         return time.perf_counter()
 
+    def _compute_time_elapsed(self, event_after, event_before):
+        return event_after - event_before
+
+    def _start(self, key, step):
+        self._t[(key, id(step))] = self._get_event()
+
+    def _stop(self, key, step, level_number, add=True):
+        t0 = self._t.pop((key, id(step)), None)
+        if t0 is None or not add:
+            return
+        L = step.levels[level_number]
+        self.add_to_stats(self._compute_time_elapsed(self._get_event(), t0),
+                          **_meta(step, L, type=f'{self.prefix}timing_{key}'))
+
     def pre_run(self, step, level_number):
-        self._t[('run', id(step))] = self._now()
+        self._start('run', step)
 
     def post_run(self, step, level_number):
-        L = step.levels[level_number]
-        self.add_to_stats(self._now() - self._t.pop(('run', id(step))), **_meta(step, L, type='timing_run'))
+        self._stop('run', step, level_number)
 
     def pre_step(self, step, level_number):
-        self._t[('step', id(step))] = self._now()
+        self._start('step', step)
+
+    def post_step(self, step, level_number):
+        self._stop('step', step, level_number)
+
+    def pre_iteration(self, step, level_number):
+        self._start('iteration', step)
+
+    def post_iteration(self, step, level_number):
+        self._stop('iteration', step, level_number)
+
+    def pre_sweep(self, step, level_number):
+        self._start('sweep', step)
+
+    def post_sweep(self, step, level_number):
+        self._stop('sweep', step, level_number)
+
+    def pre_comm(self, step, level_number):
+        self._start('comm', step)
+
+    def post_comm(self, step, level_number, add_to_stats=False):
+        self._stop('comm', step, level_number, add=add_to_stats)
+
+
+class CPUTimings(Timings):
+    """always installed by the controllers (pySDC/core/controller.py:51)."""
+
+
+class GPUTimings(Timings):
+    """log_timings.py:328-342 with HIP events (through torch's stream events, recorded on the stream the
+    engine launches on): device time between the hook calls, keys prefixed ``GPU_``."""
+
+    prefix = 'GPU_'
+
+    def _get_event(self):
+        import torch
+
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
+    def _compute_time_elapsed(self, event_after, event_before):
+        event_after.synchronize()
+        return event_before.elapsed_time(event_after) / 1e3
+
+
+class LogWork(Hooks):
+    """hooks/log_work.py:4-56: increments of all work counters of the problem between pre_step and post_step as
+    ``work_<key>`` statistics (e.g. ``work_newton``, ``work_rhs``)."""
+
+    def __init__(self):
+        super().__init__()
+        self._last = {}
+
+    def pre_step(self, step, level_number):
+        if level_number == 0:
+            self._last[step.status.slot] = [
+                {k: L.prob.work_counters[k].niter for k in L.prob.work_counters.keys()} for L in step.levels
+            ]
 
     def post_step(self, step, level_number):
         L = step.levels[level_number]
-        self.add_to_stats(self._now() - self._t.pop(('step', id(step))), **_meta(step, L, type='timing_step'))
-
-    def pre_sweep(self, step, level_number):
-        self._t[('sweep', id(step))] = self._now()
-
-    def post_sweep(self, step, level_number):
-        L = step.levels[level_number]
-        self.add_to_stats(self._now() - self._t.pop(('sweep', id(step))), **_meta(step, L, type='timing_sweep'))
+        for key, before in self._last[step.status.slot][level_number].items():
+            self.add_to_stats(L.prob.work_counters[key].niter - before, process=step.status.slot,
+                              process_sweeper=L.sweep.rank, time=L.time + L.dt, level=L.level_index,
+                              iter=step.status.iter, sweep=L.status.sweep, type=f'work_{key}')

@@ -32,6 +32,7 @@ class _Prob:
         self.dtype_u = np_mesh
 
         self.dtype_f = np_mesh
+        self.work_counters = getattr(oprob, 'work_counters', {})
 
     def eval_f(self, u, t):
         return np_mesh(self.o.eval_f(np.asarray(u), t))

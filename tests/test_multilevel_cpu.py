@@ -169,3 +169,24 @@ def test_pfasst_two_ranks_gloo(name):
     assert list(niter[order]) == list(case['niter'])
     for k in range(2):
         assert rel_err(r[k]['uend'], case['uend']) < 1e-12
+
+
+def test_hooks_stats_keys():
+    """always-on hooks (DefaultHooks, CPUTimings: pySDC/core/controller.py:51) and LogWork produce the
+    reference's statistic types."""
+    from pysdc_amd.controller import controller_nonMPI
+    from pysdc_amd.hooks import LogWork
+    from pysdc_amd.stats import get_list_of_types, get_sorted
+    from tests._oracle_step import np_mesh
+
+    case = load_cases('runs_ml.npz')['mlsdc_heat2d']
+    meta = case['meta']
+    cp = dict(logger_level=40, hook_class=[LogWork])
+    C = controller_nonMPI(1, cp, _ml_description(meta, case))
+    shape = C.MS[0].levels[0].o.prob.nvars
+    C.run(np_mesh(np.array(case['u0']).reshape(shape)), meta['t0'], meta['t0'] + 2 * meta['level_params']['dt'])
+    types = get_list_of_types(C.return_stats())
+    for t in ('niter', 'residual_post_sweep', 'residual_post_iteration', 'residual_post_step', 'timing_run',
+              'timing_step', 'timing_iteration', 'timing_sweep'):
+        assert t in types, (t, types)
+    assert len(get_sorted(C.return_stats(), type='timing_step')) == 2
