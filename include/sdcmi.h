@@ -154,6 +154,13 @@ int sdc_work_counters(sdc_ctx* ctx, unsigned long long* out);
 int sdc_transfer_apply(void* stream, int ndim, int n_out, int n_in, int width, const int* idx, const double* w,
                        const double* in, double* out);
 
+/* Dirichlet-zero boundaries in 1-D (generic_ND_FD.py:99-133 'dirichlet-zero', order 2): the n interior values
+ * live inside their odd extension [0, u_0..u_{n-1}, 0, -u_{n-1}..-u_0] of length 2(n+1) = 2^p, on which the
+ * Dirichlet 3-point operator IS the periodic one, so every kernel of the periodic engine applies unchanged
+ * (the Fourier solve becomes the sine-transform solve).  This rebuilds the end points and the mirrored half of
+ * one field after its interior was written.  ctx may be NULL. */
+int sdc_odd_mirror(sdc_ctx* ctx, double* field, int n_interior);
+
 /* ---- stream / timing ------------------------------------------------------------------------------------ */
 int sdc_sync(sdc_ctx* ctx);
 /* hipEvent timing on the context's stream (GPUTimings analogue, hooks/log_timings.py:328-342):

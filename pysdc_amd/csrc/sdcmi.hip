@@ -275,6 +275,17 @@ __global__ __launch_bounds__(256) void k_lincomb(LinArgs a) {
     }
 }
 
+// odd (Dirichlet-zero) extension of a 1-D field stored as [0, u_0..u_{n-1}, 0, -u_{n-1}..-u_0] (length 2(n+1)):
+// rebuild the zero end points and the mirrored half from the interior
+__global__ void k_odd_mirror(double* __restrict__ f, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) f[2 * n + 1 - i] = -f[1 + i];
+    if (i == 0) {
+        f[0] = 0.0;
+        f[n + 1] = 0.0;
+    }
+}
+
 __global__ void k_amax(const double* __restrict__ x, size_t n, unsigned long long* slot) {
     double m = 0.0;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -920,7 +931,7 @@ __global__ __launch_bounds__(z_lines_per_block<N>() * (N / fft_elems(N)) * MAXM,
     cd r[E];
 #pragma unroll
     for (int i = 0; i < E; ++i) r[i] = ok ? Wl[j + i * P] : cd{0.0, 0.0};
-    fft_line<N, -1, LAY, true>(r, j, c, lds, a.tw);
+    fft_line<N, -1, LAY, (N / fft_elems(N)) <= 64>(r, j, c, lds, a.tw);
     __syncthreads();  // the solve buffer aliases other waves' exchange planes
 
     cd* buf = reinterpret_cast<cd*>(lds);  // [column][CH]
@@ -973,7 +984,7 @@ __global__ __launch_bounds__(z_lines_per_block<N>() * (N / fft_elems(N)) * MAXM,
     // through the whole kernel for reuse in the inverse
     int j2 = j;
     asm volatile("" : "+v"(j2));
-    fft_line<N, +1, LAY, true>(r, j2, c, lds, a.tw);
+    fft_line<N, +1, LAY, (N / fft_elems(N)) <= 64>(r, j2, c, lds, a.tw);
     if (ok) {
 #pragma unroll
         for (int i = 0; i < E; ++i) Wl[j2 + i * P] = r[i];
@@ -1001,7 +1012,7 @@ __global__ __launch_bounds__(z_lines_per_block<N>() * (N / fft_elems(N)) * MAXM,
 #pragma unroll
         for (int i = 0; i < E; ++i) r[i] = cscale(r[i], scale);
     }
-    fft_line<N, DIR, LAY, true>(r, j, c, lds, tw);
+    fft_line<N, DIR, LAY, (N / fft_elems(N)) <= 64>(r, j, c, lds, tw);
     if (ok) {
 #pragma unroll
         for (int i = 0; i < E; ++i) dst[base + j + i * P] = r[i];
@@ -1365,7 +1376,8 @@ static int run_stencil(sdc_ctx* c, int nf, const double* const* in, double* cons
 static int eval_nodes(sdc_ctx* c, double dt) {
     const int M = c->M;
     auto three = [](const Stencil& s) { return s.npts == 3 && s.off[0] == -1 && s.off[1] == 0 && s.off[2] == 1; };
-    if (c->fuse_residual && c->ndim == 3 && c->ncomp == 1 && !c->tau_active && c->n % 64 == 0 && three(c->st[0])) {
+    if (c->fuse_residual && c->ndim == 3 && c->ncomp == 1 && !c->tau_active && c->n % 64 == 0 && M <= 6 &&
+        three(c->st[0])) {
         StencilResArgs a;
         memset(&a, 0, sizeof a);
         a.U = c->U;
@@ -1384,7 +1396,7 @@ static int eval_nodes(sdc_ctx* c, double dt) {
             LaunchTimer lt(c, pname("stencil_res", M));
 #define RCASE(MM) \
     case MM: hipLaunchKernelGGL((k_stencil3d_res<MM>), dim3(grid), dim3(256), 0, c->stream, a); break;
-            switch (M) { RCASE(1) RCASE(2) RCASE(3) RCASE(4) RCASE(5) RCASE(6) RCASE(7) RCASE(8) }
+            switch (M) { RCASE(1) RCASE(2) RCASE(3) RCASE(4) RCASE(5) RCASE(6) }
 #undef RCASE
         }
         HIPCHK(c, hipGetLastError());
@@ -1408,7 +1420,7 @@ static int eval_nodes(sdc_ctx* c, double dt) {
 template <int N>
 static int fft_pipeline_n(sdc_ctx* c, int nf, const FieldPtrs& p, ZArgs& z) {
     constexpr int E = fft_elems(N), P = N / E;
-    constexpr int T = 8;  // complex columns per strided tile = 128 bytes per row
+    constexpr int T = N >= 2048 ? 4 : 8;  // complex columns per strided tile (128-byte row segments up to N = 1024)
     const size_t lds_str = (size_t)LayStrided<N, T>::doubles(T) * sizeof(double);
     const int n = c->n;
     z.W = c->W;
@@ -1470,7 +1482,7 @@ static int fft_pipeline_n(sdc_ctx* c, int nf, const FieldPtrs& p, ZArgs& z) {
 // forward transform of nf real fields into fully transformed spectra dst[f] (dst + f*fstride)
 template <int N>
 static int fwd_transform_n(sdc_ctx* c, int nf, const FieldPtrs& p, cd* dst, size_t fstride) {
-    constexpr int E = fft_elems(N), P = N / E, T = 8, LPB = z_lines_per_block<N>();
+    constexpr int E = fft_elems(N), P = N / E, T = N >= 2048 ? 4 : 8, LPB = z_lines_per_block<N>();
     const size_t lds_str = (size_t)LayStrided<N, T>::doubles(T) * sizeof(double);
     const int n = c->n;
     size_t lines;
@@ -1504,7 +1516,7 @@ static int fwd_transform_n(sdc_ctx* c, int nf, const FieldPtrs& p, cd* dst, size
 // spectral sweep + inverse passes into out[f]
 template <int N>
 static int spec_sweep_n(sdc_ctx* c, int nf, SpecArgs& a, const FieldPtrs& p) {
-    constexpr int E = fft_elems(N), P = N / E, T = 8, LPB = z_lines_per_block<N>();
+    constexpr int E = fft_elems(N), P = N / E, T = N >= 2048 ? 4 : 8, LPB = z_lines_per_block<N>();
     constexpr int NCH = E == 16 ? 2 : 1;
     const size_t lds_str = (size_t)LayStrided<N, T>::doubles(T) * sizeof(double);
     const int n = c->n;
@@ -1556,7 +1568,8 @@ static int spec_sweep_n(sdc_ctx* c, int nf, SpecArgs& a, const FieldPtrs& p) {
         case 256: return CALL(256);                                                                         \
         case 512: return CALL(512);                                                                         \
         case 1024: return CALL(1024);                                                                       \
-        default: return fail(c, SDC_ERR_UNSUPPORTED, "spectral solve needs n = 2^p <= 1024, got %d", (c)->n); \
+        case 2048: return CALL(2048);                                                                       \
+        default: return fail(c, SDC_ERR_UNSUPPORTED, "spectral solve needs n = 2^p <= 2048, got %d", (c)->n); \
     }
 
 static int fwd_transform(sdc_ctx* c, int nf, const FieldPtrs& p, cd* dst, size_t fstride) {
@@ -1578,8 +1591,9 @@ static int spec_sweep(sdc_ctx* c, int nf, SpecArgs& a, const FieldPtrs& p) {
 // (I - alpha_f A) out_f = in_f + sum_{j<f} (cI[f][j] A + cE[f][j] B) out_j for f = 0..nf-1
 static int fft_pipeline(sdc_ctx* c, int nf, const FieldPtrs& p, ZArgs& z) {
     if (!c->have_stencil[0]) return fail(c, SDC_ERR_STATE, "implicit operator not set (sdc_set_stencil)");
-    if (!is_pow2(c->n) || c->n > 1024)
-        return fail(c, SDC_ERR_UNSUPPORTED, "spectral solve needs n = 2^p <= 1024 per dimension, got %d", c->n);
+    if (!is_pow2(c->n) || c->n > 2048 || (c->n > 1024 && c->ndim > 1))
+        return fail(c, SDC_ERR_UNSUPPORTED,
+                    "spectral solve needs n = 2^p <= 1024 per dimension (<= 2048 in 1-D), got %d", c->n);
     {
         int rw = ensure_work(c);
         if (rw != SDC_OK) return rw;
@@ -1595,6 +1609,7 @@ static int fft_pipeline(sdc_ctx* c, int nf, const FieldPtrs& p, ZArgs& z) {
         case 256: return fft_pipeline_n<256>(c, nf, p, z);
         case 512: return fft_pipeline_n<512>(c, nf, p, z);
         case 1024: return fft_pipeline_n<1024>(c, nf, p, z);
+        case 2048: return fft_pipeline_n<2048>(c, nf, p, z);
     }
     return fail(c, SDC_ERR_UNSUPPORTED, "n = %d", c->n);
 }
@@ -2183,7 +2198,7 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
     const bool gather_once = c->force_gather;
     c->force_gather = false;
     if (c->reuse && !gather_once && !c->tau_active && c->expl_kind != SDC_EXPL_FORCING && c->have_stencil[0] &&
-        is_pow2(c->n) && c->n <= 1024) {
+        is_pow2(c->n) && (c->n <= 1024 || (c->n == 2048 && c->ndim == 1))) {
         // ---- spectral reuse: f is linear in u, so the gather happens on the cached transforms ----
         if (!c->S) {
             HIPCHK(c, hipMalloc((void**)&c->S, sizeof(cd) * c->Nc * M));
@@ -2437,6 +2452,15 @@ int sdc_transfer_apply(void* stream, int ndim, int n_out, int n_in, int width, c
     for (int d = 0; d < ndim; ++d) NO *= (size_t)n_out;
     hipLaunchKernelGGL(k_xfer, dim3(grid_for(NO, 256)), dim3(256), 0, (hipStream_t)stream, a);
     HIPCHK(nullptr, hipGetLastError());
+    return SDC_OK;
+}
+
+int sdc_odd_mirror(sdc_ctx* c, double* field, int n_interior) {
+    CTX_OR_DEFAULT(c);
+    if (!field || n_interior < 1) return fail(c, SDC_ERR_PARAM, "bad odd-extension arguments");
+    hipLaunchKernelGGL(k_odd_mirror, dim3((n_interior + 255) / 256), dim3(256), 0, c->stream, field, n_interior);
+    HIPCHK(c, hipGetLastError());
+    c->res_valid = false;
     return SDC_OK;
 }
 

@@ -65,11 +65,12 @@ class SlabList:
             e = self._L.engine
             shape = self._L._field_shape()
             cb = lambda slot=self._slot, m=m: self._L._touched(slot, m)  # noqa: E731
+            off = 8 * self._L._view_offset()
             if self._imex:
-                self._views[m] = hip_imex_mesh.view(e.ptr(self._slot, m, 0), e.ptr(self._slot, m, 1), shape, keep=e,
-                                                    on_write=cb)
+                self._views[m] = hip_imex_mesh.view(e.ptr(self._slot, m, 0) + off, e.ptr(self._slot, m, 1) + off, shape,
+                                                    keep=e, on_write=cb)
             else:
-                self._views[m] = hip_mesh.view(e.ptr(self._slot, m, 0), shape, keep=e, on_write=cb)
+                self._views[m] = hip_mesh.view(e.ptr(self._slot, m, 0) + off, shape, keep=e, on_write=cb)
         return self._views[m]
 
     def __getitem__(self, m):
@@ -134,7 +135,7 @@ class Level:
             nvars = getattr(P, 'nvars', None)
             if nvars is None:
                 raise ParameterError('problem does not define nvars: cannot create device slabs')
-            self.__engine = SweepEngine(nvars, M, getattr(P, 'ncomp', 1))
+            self.__engine = SweepEngine(getattr(P, 'engine_nvars', nvars), M, getattr(P, 'ncomp', 1))
             P.bind_engine(self.__engine)
             self.__sweep.push_coeffs(self.__engine)
         return self.__engine
@@ -168,7 +169,8 @@ class Level:
             return None
         if self._uend_view is None:
             e = self.engine
-            self._uend_view = hip_mesh.view(e.ptr(Lb.SLOT_UEND), self._field_shape(), keep=e)
+            self._uend_view = hip_mesh.view(e.ptr(Lb.SLOT_UEND) + 8 * self._view_offset(), self._field_shape(), keep=e,
+                                            on_write=lambda: self._touched(Lb.SLOT_UEND, 0))
         return self._uend_view
 
     @uend.setter
@@ -185,6 +187,9 @@ class Level:
         shape = self.__prob.init[0]
         return (int(shape),) if np.isscalar(shape) else tuple(shape)
 
+    def _view_offset(self):
+        return int(getattr(self.__prob, 'view_offset', 0))
+
     def _activate_tau(self):
         e = self.engine
         e.set_tau_active(True)
@@ -197,6 +202,12 @@ class Level:
         e = self.__engine
         if e is None:
             return
+        if self._view_offset() and slot is not None:
+            # dirichlet-zero: the interior was written through a view - rebuild the odd extension of that field
+            n = self._field_shape()[0]
+            comps = range(e.ncomp) if slot == Lb.SLOT_F else (0,)
+            for comp in comps:
+                Lb.check(e.lib.sdc_odd_mirror(e.ctx, e.ptr(slot, m if slot != Lb.SLOT_UEND else 0, comp), n), e.ctx)
         if slot == Lb.SLOT_U:
             e.invalidate_spectra(1 if m == 0 else 2)
         elif slot == Lb.SLOT_F:

@@ -134,8 +134,13 @@ class GenericNDimFinDiff(Problem):
                 raise ProblemError('setup requires nvars = 2^p - 1')
         if ndim > 1 and nvars[1:] != nvars[:-1]:
             raise ProblemError('need a square domain, got %s' % (nvars,))
-        if bc != 'periodic':
-            raise ProblemError(f'the MI355X engine implements periodic boundary conditions only, got bc={bc!r}')
+        if bc not in ('periodic', 'dirichlet-zero'):
+            raise ProblemError(f'the MI355X engine implements periodic and dirichlet-zero boundaries, got bc={bc!r}')
+        if bc == 'dirichlet-zero' and (ndim != 1 or order != 2 or derivative != 2 or stencil_type != 'center'):
+            raise ProblemError(
+                'dirichlet-zero is available for the 1-D second-order centred second derivative (odd extension); '
+                f'got ndim={ndim}, order={order}, derivative={derivative}'
+            )
         if solver_type != 'direct':
             raise ProblemError(
                 f"solver_type {solver_type!r} is not available on the MI355X engine: the periodic operator is "
@@ -145,6 +150,10 @@ class GenericNDimFinDiff(Problem):
         dx, xvalues = fd.get_1d_grid(size=nvars[0], bc=bc, left_boundary=0.0, right_boundary=1.0)
         self._stencil = fd.periodic_operator_stencil(derivative, order, stencil_type, dx, coeff)
         self.xvalues = xvalues
+        # dirichlet-zero: the engine works on the odd extension of length 2(n+1) (include/sdcmi.h: sdc_odd_mirror)
+        self.view_offset = 1 if bc == 'dirichlet-zero' else 0
+        self.engine_nvars = (2 * (nvars[0] + 1),) if bc == 'dirichlet-zero' else nvars
+        self._scratch = None
         self._makeAttributeAndRegister('nvars', 'stencil_type', 'order', 'bc', localVars=locals(), readOnly=True)
         self._makeAttributeAndRegister('freq', 'lintol', 'liniter', 'solver_type', localVars=locals())
 
@@ -174,14 +183,40 @@ class GenericNDimFinDiff(Problem):
     def configure_engine(self, engine):
         engine.set_stencil(0, *self._stencil)
 
+    # ---- odd-extension staging for fields that are not slab views (dirichlet-zero) ----------------------------
+    def _ext(self, k):
+        if self._scratch is None:
+            n2 = self.engine_nvars[0]
+            self._scratch = [hip_mesh(((n2,), None, np.dtype('float64'))) for _ in range(3)]
+        return self._scratch[k]
+
+    def _stage_in(self, u, k):
+        """pointer the engine can read: the field itself (periodic) or its odd extension in scratch k"""
+        if not self.view_offset:
+            return u.ptr
+        e = self._ext(k)
+        n = self.nvars[0]
+        self.engine.vec_copy(n, u.ptr, e.ptr + 8)
+        L.check(self.engine.lib.sdc_odd_mirror(self.engine.ctx, e.ptr, n), self.engine.ctx)
+        return e.ptr
+
+    def _stage_out(self, k, dst):
+        if self.view_offset:
+            self.engine.vec_copy(self.nvars[0], self._ext(k).ptr + 8, dst.ptr)
+
+    def _out_ptr(self, k, dst):
+        return self._ext(k).ptr if self.view_offset else dst.ptr
+
     def eval_f(self, u, t):
         f = self.f_init
-        self.engine.eval_f(u.ptr, 0.0, f.ptr)
+        self.engine.eval_f(self._stage_in(u, 0), 0.0, self._out_ptr(1, f))
+        self._stage_out(1, f)
         return f
 
     def solve_system(self, rhs, factor, u0, t):
         sol = self.u_init
-        self.engine.solve(rhs.ptr, float(factor), sol.ptr)
+        self.engine.solve(self._stage_in(rhs, 0), float(factor), self._out_ptr(1, sol))
+        self._stage_out(1, sol)
         return sol
 
     def _from_host(self, values):
@@ -246,7 +281,11 @@ class heatNd_forced(heatNd_unforced):
 
     def configure_engine(self, engine):
         super().configure_engine(engine)
-        engine.set_forcing_profile(self._profile())
+        if self.view_offset:  # the sine profile continued over the odd extension is the same sine
+            x = np.arange(self.engine_nvars[0]) * self.dx
+            engine.set_forcing_profile(np.sin(np.pi * self.freq[0] * x))
+        else:
+            engine.set_forcing_profile(self._profile())
 
     @classmethod
     def get_default_sweeper_class(cls):
@@ -256,7 +295,13 @@ class heatNd_forced(heatNd_unforced):
 
     def eval_f(self, u, t):
         f = self.f_init
-        self.engine.eval_f(u.ptr, float(self.forcing_g(t)), f.impl.ptr, f.expl.ptr)
+        if self.view_offset:
+            self.engine.eval_f(self._stage_in(u, 0), float(self.forcing_g(t)), self._ext(1).ptr, self._ext(2).ptr)
+            n = self.nvars[0]
+            self.engine.vec_copy(n, self._ext(1).ptr + 8, f.impl.ptr)
+            self.engine.vec_copy(n, self._ext(2).ptr + 8, f.expl.ptr)
+        else:
+            self.engine.eval_f(u.ptr, float(self.forcing_g(t)), f.impl.ptr, f.expl.ptr)
         return f
 
     def u_exact(self, t):

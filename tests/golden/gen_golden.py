@@ -455,3 +455,22 @@ def allencahn_main():
 
 if __name__ == '__main__' and os.environ.get('GOLDEN_ML', '1') == '1':
     allencahn_main()
+
+
+def dirichlet_main():
+    """tutorial-style 1-D Dirichlet runs (step_2/C, step_3: heat 1-D, dirichlet-zero)."""
+    RR = dict(quad_type='RADAU-RIGHT')
+    cases = []
+    cases.append(run_case('dirichlet_heat1d_1023', 'heat_unforced', dict(nvars=1023, nu=0.1, freq=4, bc='dirichlet-zero'),
+                          'generic_implicit', dict(num_nodes=3, QI='LU', **RR), dict(dt=0.1, restol=1e-10), 50, 0.1, 0.5))
+    cases.append(run_case('dirichlet_forced1d_127', 'heat_forced', dict(nvars=127, nu=0.1, freq=2, bc='dirichlet-zero'),
+                          'imex_1st_order', dict(num_nodes=3, QI='LU', QE='EE', **RR), dict(dt=0.05, restol=1e-10),
+                          50, 0.0, 0.2))
+    cases.append(run_case('dirichlet_heat1d_P2', 'heat_unforced', dict(nvars=255, nu=0.1, freq=2, bc='dirichlet-zero'),
+                          'generic_implicit', dict(num_nodes=5, QI='IE', **RR), dict(dt=0.02, restol=1e-9), 50, 0.0,
+                          0.08, num_procs=2, seed=3))
+    save('runs_dirichlet.npz', cases)
+
+
+if __name__ == '__main__' and os.environ.get('GOLDEN_ML', '1') == '1':
+    dirichlet_main()

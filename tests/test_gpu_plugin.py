@@ -28,13 +28,16 @@ def description_from(meta, problem_class=None):
                 level_params=dict(meta['level_params']), step_params=dict(maxiter=meta['maxiter']))
 
 
-@pytest.mark.parametrize('name', list(load_cases('runs.npz')))
+RUNS = [('runs.npz', n) for n in load_cases('runs.npz')] + [('runs_dirichlet.npz', n) for n in load_cases('runs_dirichlet.npz')]
+
+
+@pytest.mark.parametrize('fname,name', RUNS)
 @pytest.mark.parametrize('fused', [True, False])
-def test_run_vs_golden(name, fused):
+def test_run_vs_golden(fname, name, fused):
     from pysdc_amd.controller import controller_nonMPI
     from pysdc_amd.stats import get_sorted
 
-    case = load_cases('runs.npz')[name]
+    case = load_cases(fname)[name]
     meta = case['meta']
     probs, _ = _classes()
     pc = probs[meta['prob']]
@@ -230,3 +233,43 @@ def test_bench_single_rank_distributed_path():
     ref = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--n', '64', '--steps', '2', '--warmup', '1',
                           '--no-cpu-baseline'], capture_output=True, text=True, timeout=600)
     assert ref.returncode == 0, ref.stderr[-2000:]
+
+
+@pytest.mark.parametrize('fname,name', [('sweeps_heat.npz', 'heat1d_dirichlet'), ('sweeps_imex.npz', 'forced1d_dirichlet')])
+@pytest.mark.parametrize('fused', [True, False])
+def test_dirichlet_1d_sweeps_vs_golden(fname, name, fused):
+    """dirichlet-zero in 1-D (odd extension inside the engine) against golden sweeps of the reference."""
+    from pysdc_amd.level import Step
+
+    case = load_cases(fname)[name]
+    meta = case['meta']
+    probs, sweeps = _classes()
+    pc = probs[meta['prob']]
+    if not fused:
+        pc = type(pc.__name__ + '_nodewise', (pc,), {'fused': False})
+    S = Step(dict(problem_class=pc, problem_params=dict(meta['prob_params']), sweeper_class=sweeps[meta['sweeper']],
+                  sweeper_params=dict(meta['sweeper_params']), level_params=dict(dt=meta['dt']),
+                  step_params=dict(maxiter=10)))
+    L = S.levels[0]
+    L.status.time = meta['t0']
+    u0 = L.prob.u_init
+    u0[:] = case['u0']
+    L.u[0] = u0
+    L.sweep.predict()
+
+    def check(tag):
+        assert rel_err(np.stack([np.asarray(x) for x in L.u]), case[f'{tag}_u']) < TOL, tag
+        assert rel_err(np.stack([np.asarray(x) for x in L.f]), case[f'{tag}_f']) < TOL, tag
+        for rt in ('full_abs', 'last_rel'):
+            L.params.residual_type = rt
+            L.sweep.compute_residual()
+            ref = float(case[f'{tag}_res_{rt}'])
+            assert abs(L.status.residual - ref) <= 1e-8 * abs(ref) + 1e-11, (tag, rt)
+        L.params.residual_type = 'full_abs'
+        L.sweep.compute_end_point()
+        assert rel_err(L.uend.get(), case[f'{tag}_uend_0']) < TOL, tag
+
+    check('k0')
+    for k in range(1, meta['nsweeps'] + 1):
+        L.sweep.update_nodes()
+        check(f'k{k}')

@@ -53,12 +53,12 @@ def test_sweep_case(fname, name):
         assert counter.niter == int(case[f'work_{key}'][-1]), key
 
 
-RUN_CASES = list(load_cases('runs.npz'))
+RUN_CASES = [('runs.npz', n) for n in load_cases('runs.npz')] + [('runs_dirichlet.npz', n) for n in load_cases('runs_dirichlet.npz')]
 
 
-@pytest.mark.parametrize('name', RUN_CASES)
-def test_run_case(name):
-    case = load_cases('runs.npz')[name]
+@pytest.mark.parametrize('fname,name', RUN_CASES)
+def test_run_case(fname, name):
+    case = load_cases(fname)[name]
     meta = case['meta']
     lp = meta['level_params']
     coll = make_oracle_coll(case)
