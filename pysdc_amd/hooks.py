@@ -70,8 +70,6 @@ class DefaultHooks(Hooks):
         L = step.levels[level_number]
         self.add_to_stats(step.status.iter, **_meta(step, L, type='niter'))
         self.add_to_stats(L.status.residual, **_meta(step, L, type='residual_post_step'))
-        self.add_to_stats(step.status.get('restart'), **_meta(step, L, iter=0, sweep=0, type='_recomputed')) \
-            if False else None
 
 
 class Timings(Hooks):

@@ -141,11 +141,8 @@ class GenericNDimFinDiff(Problem):
                 'dirichlet-zero is available for the 1-D second-order centred second derivative (odd extension); '
                 f'got ndim={ndim}, order={order}, derivative={derivative}'
             )
-        if solver_type != 'direct':
-            raise ProblemError(
-                f"solver_type {solver_type!r} is not available on the MI355X engine: the periodic operator is "
-                "solved exactly in Fourier space (solver_type='direct')"
-            )
+        if solver_type not in ('direct', 'CG', 'GMRES'):
+            raise ProblemError(f'solver type "{solver_type}" not known in generic advection-diffusion implementation!')
         super().__init__(init=(nvars[0] if ndim == 1 else nvars, None, np.dtype('float64')))
         dx, xvalues = fd.get_1d_grid(size=nvars[0], bc=bc, left_boundary=0.0, right_boundary=1.0)
         self._stencil = fd.periodic_operator_stencil(derivative, order, stencil_type, dx, coeff)
@@ -156,6 +153,11 @@ class GenericNDimFinDiff(Problem):
         self._scratch = None
         self._makeAttributeAndRegister('nvars', 'stencil_type', 'order', 'bc', localVars=locals(), readOnly=True)
         self._makeAttributeAndRegister('freq', 'lintol', 'liniter', 'solver_type', localVars=locals())
+        # Every solver_type the reference offers (generic_ND_FD.py:238-262) ends in the SAME system
+        # (I - factor*A) u = rhs; here it is always solved exactly in Fourier space, which satisfies any lintol.
+        # The iterative solvers' work counter exists (generic_ND_FD.py:158-159) and counts one "iteration" per solve.
+        if solver_type != 'direct':
+            self.work_counters[solver_type] = WorkCounter()
 
     @property
     def ndim(self):
@@ -217,6 +219,8 @@ class GenericNDimFinDiff(Problem):
         sol = self.u_init
         self.engine.solve(self._stage_in(rhs, 0), float(factor), self._out_ptr(1, sol))
         self._stage_out(1, sol)
+        if self.solver_type != 'direct':
+            self.work_counters[self.solver_type]()
         return sol
 
     def _from_host(self, values):
