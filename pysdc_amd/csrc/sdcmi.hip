@@ -1232,45 +1232,25 @@ __global__ void k_vdp_solve(const double* __restrict__ rhsv, const double* __res
 struct XferArgs {
     const double* in;
     double* out;
-    const int* idx;     // [n_out][W] source indices along one axis (device)
+    const int* idx;     // [n_out][W] source indices along the axis (device)
     const double* w;    // [n_out][W] weights (zero-padded)
-    int ndim, n_out, n_in, W;
+    size_t outer, inner;
+    int n_out, n_in, W;
 };
 
-// out = (T x T x T) in for the 1-D sparse operator T given as fixed-width rows (same T on every axis)
-__global__ void k_xfer(XferArgs a) {
-    const int no = a.n_out, ni = a.n_in, W = a.W;
-    const size_t NO = a.ndim == 1 ? (size_t)no : (a.ndim == 2 ? (size_t)no * no : (size_t)no * no * no);
-    for (size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x; p < NO; p += (size_t)gridDim.x * blockDim.x) {
-        int i[3] = {0, 0, 0};
-        size_t r = p;
-        for (int d = a.ndim - 1; d >= 0; --d) {
-            i[d] = (int)(r % no);
-            r /= no;
-        }
+// one axis of the tensor product: out[o][i][q] = sum_j w[i][j] * in[o][idx[i][j]][q]
+__global__ void k_xfer_axis(XferArgs a) {
+    const size_t total = a.outer * a.n_out * a.inner;
+    for (size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x; p < total; p += (size_t)gridDim.x * blockDim.x) {
+        const size_t q = p % a.inner;
+        const size_t r = p / a.inner;
+        const int i = (int)(r % a.n_out);
+        const size_t o = r / a.n_out;
+        const double* __restrict__ src = a.in + o * a.n_in * a.inner + q;
         double acc = 0.0;
-        for (int j0 = 0; j0 < W; ++j0) {
-            const double w0 = a.w[i[0] * W + j0];
-            if (w0 == 0.0) continue;
-            const size_t s0 = a.idx[i[0] * W + j0];
-            if (a.ndim == 1) {
-                acc += w0 * a.in[s0];
-                continue;
-            }
-            for (int j1 = 0; j1 < W; ++j1) {
-                const double w1 = a.w[i[1] * W + j1];
-                if (w1 == 0.0) continue;
-                const size_t s1 = s0 * ni + a.idx[i[1] * W + j1];
-                if (a.ndim == 2) {
-                    acc += w0 * w1 * a.in[s1];
-                    continue;
-                }
-                for (int j2 = 0; j2 < W; ++j2) {
-                    const double w2 = a.w[i[2] * W + j2];
-                    if (w2 == 0.0) continue;
-                    acc += w0 * w1 * w2 * a.in[s1 * ni + a.idx[i[2] * W + j2]];
-                }
-            }
+        for (int j = 0; j < a.W; ++j) {
+            const double wj = a.w[i * a.W + j];
+            if (wj != 0.0) acc += wj * src[(size_t)a.idx[i * a.W + j] * a.inner];
         }
         a.out[p] = acc;
     }
@@ -2439,18 +2419,45 @@ int sdc_transfer_apply(void* stream, int ndim, int n_out, int n_in, int width, c
                        const double* in, double* out) {
     if (ndim < 1 || ndim > 3 || n_out < 1 || n_in < 1 || width < 1 || !idx || !w || !in || !out)
         return fail(nullptr, SDC_ERR_PARAM, "bad transfer arguments");
-    XferArgs a;
-    a.in = in;
-    a.out = out;
-    a.idx = idx;
-    a.w = w;
-    a.ndim = ndim;
-    a.n_out = n_out;
-    a.n_in = n_in;
-    a.W = width;
-    size_t NO = 1;
-    for (int d = 0; d < ndim; ++d) NO *= (size_t)n_out;
-    hipLaunchKernelGGL(k_xfer, dim3(grid_for(NO, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    // separable: one pass per axis (cost ~ ndim * width per point instead of width^ndim), last axis first so that
+    // intermediate fields stay as small as possible when prolonging; two scratch fields ping-pong in between
+    static thread_local double* scratch[2] = {nullptr, nullptr};
+    static thread_local size_t scratch_len = 0;
+    const int nmax = n_out > n_in ? n_out : n_in;
+    size_t need = 1;
+    for (int d = 0; d < ndim; ++d) need *= (size_t)nmax;
+    if (ndim > 1 && need > scratch_len) {
+        for (int k = 0; k < 2; ++k) {
+            if (scratch[k]) (void)hipFree(scratch[k]);
+            if (hipMalloc((void**)&scratch[k], need * sizeof(double)) != hipSuccess) {
+                scratch[k] = nullptr;
+                scratch_len = 0;
+                return fail(nullptr, SDC_ERR_NOMEM, "transfer scratch allocation failed");
+            }
+        }
+        scratch_len = need;
+    }
+    int dims[3] = {n_in, n_in, n_in};
+    const double* src = in;
+    for (int pass = 0; pass < ndim; ++pass) {
+        const int axis = ndim - 1 - pass;
+        XferArgs a;
+        a.idx = idx;
+        a.w = w;
+        a.W = width;
+        a.n_in = n_in;
+        a.n_out = n_out;
+        a.outer = 1;
+        a.inner = 1;
+        for (int d = 0; d < axis; ++d) a.outer *= (size_t)dims[d];
+        for (int d = axis + 1; d < ndim; ++d) a.inner *= (size_t)dims[d];
+        a.in = src;
+        a.out = pass == ndim - 1 ? out : scratch[pass & 1];
+        const size_t total = a.outer * (size_t)n_out * a.inner;
+        hipLaunchKernelGGL(k_xfer_axis, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, a);
+        dims[axis] = n_out;
+        src = a.out;
+    }
     HIPCHK(nullptr, hipGetLastError());
     return SDC_OK;
 }
