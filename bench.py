@@ -251,7 +251,7 @@ def main():
             tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
             if os.path.exists(tfile):
                 tr = json.load(open(tfile)).get(f'{dom[0].split("[")[0]}@{n}')
-                traffic = tr
+                traffic = tr['hbm_bytes_per_launch'] if tr else None  # PMC passes of the same build (profiles/)
             roof = {'kernel': dom[0], 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                     'frac': ach / HBM_PEAK_GBS, 'traffic': traffic,
                     'algorithmic_bytes_per_launch': kernel_bytes(dom[0], n, M),
