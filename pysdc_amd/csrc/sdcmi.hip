@@ -53,6 +53,7 @@ struct sdc_ctx {
     unsigned long long* red_host = nullptr;
     bool tau_active = false, have_coeffs = false, have_stencil[2] = {false, false}, unlocked = false;
     int expl_kind = SDC_EXPL_NONE;
+    bool res_spread = false;  // state = spread predictor of an autonomous f: residual_m = dt |sum_j Q[m][j]| max|f(u0)|
     bool fuse_residual = true;
     bool res_valid = false;   // node norms of the residual were produced by the fused stencil kernel
     double res_dt = 0.0;
@@ -320,16 +321,23 @@ struct SpreadArgs {
     size_t N;
     int M, ncomp, guess, forcing;
     double fill_u, fill_f;
+    unsigned long long* f0max;  // max |F[0]| (implicit + explicit) for the residual of the spread state, or null
 };
 
 // predictor fill of the node values; core/sweeper.py:140-158
 __global__ __launch_bounds__(256) void k_spread(SpreadArgs a) {
     const size_t n2 = a.N >> 1;
+    double fmaxv = 0.0;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x * blockDim.x) {
         double2 u = reinterpret_cast<const double2*>(a.u0)[i];
         double2 fi = reinterpret_cast<const double2*>(a.f0)[i];
         double2 fe = double2{0.0, 0.0}, pr = double2{0.0, 0.0};
         if (a.ncomp == 2) fe = reinterpret_cast<const double2*>(a.f0 + a.N)[i];
+        if (a.f0max) {
+            const double s0 = fabs(fi.x + fe.x), s1 = fabs(fi.y + fe.y);
+            const double sm = (s0 > s1 || s0 != s0) ? s0 : s1;
+            fmaxv = (fmaxv > sm || fmaxv != fmaxv) ? fmaxv : sm;
+        }
         if (a.forcing) pr = reinterpret_cast<const double2*>(a.profile)[i];
         for (int m = 1; m <= a.M; ++m) {
             double2 um = u, fim = fi, fem = fe;
@@ -345,6 +353,10 @@ __global__ __launch_bounds__(256) void k_spread(SpreadArgs a) {
             reinterpret_cast<double2*>(a.F + ((size_t)m * a.ncomp) * a.N)[i] = fim;
             if (a.ncomp == 2) reinterpret_cast<double2*>(a.F + ((size_t)m * a.ncomp + 1) * a.N)[i] = fem;
         }
+    }
+    if (a.f0max) {
+        fmaxv = wave_max(fmaxv);
+        if ((threadIdx.x & 63) == 0) atomic_max_abs(a.f0max, fmaxv);
     }
 }
 
@@ -1932,6 +1944,7 @@ void* sdc_slot_ptr(sdc_ctx* c, int slot, int m, int comp) {
 int sdc_invalidate_spectra(sdc_ctx* c, int which) {
     if (!c) return SDC_ERR_PARAM;
     c->res_valid = false;
+    c->res_spread = false;
     if (which & 1) {
         c->spec0_valid = false;
         c->spec_spread = false;  // "all nodes equal U[0]" no longer holds for the new U[0]
@@ -1972,6 +1985,7 @@ int sdc_set_tau_active(sdc_ctx* c, int active) {
     }
     c->tau_active = active != 0;
     c->res_valid = false;
+    c->res_spread = false;
     return SDC_OK;
 }
 
@@ -1982,6 +1996,7 @@ int sdc_upload(sdc_ctx* c, int slot, int m, int comp, const double* host) {
     HIPCHK(c, hipMemcpyAsync(d, host, c->N * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->res_valid = false;
+    c->res_spread = false;
     if (slot == SDC_SLOT_U) sdc_invalidate_spectra(c, m == 0 ? 1 : 2);
     return SDC_OK;
 }
@@ -2063,6 +2078,13 @@ int sdc_predict(sdc_ctx* c, double t, double dt, int guess, double fill_u, doubl
     a.fill_u = fill_u;
     a.fill_f = fill_f;
     for (int m = 0; m <= c->M; ++m) a.g[m] = c->gvals[m];
+    // all nodes equal u0 and f does not depend on t: every f_j equals f(u0), so the node residuals are
+    // dt * |sum_j Q[m][j]| * max|f(u0)| and the fill kernel can reduce max|f(u0)| on the way
+    const bool spread_res = guess == SDC_GUESS_SPREAD && c->expl_kind != SDC_EXPL_FORCING && !c->tau_active;
+    if (spread_res) {
+        HIPCHK(c, hipMemsetAsync(c->res_dev, 0, sizeof(unsigned long long) * 8, c->stream));
+        a.f0max = c->res_dev + 7;
+    }
     {
         LaunchTimer lt(c, "spread");
         hipLaunchKernelGGL(k_spread, dim3(grid_for(c->N / 2, 256)), dim3(256), 0, c->stream, a);
@@ -2072,6 +2094,7 @@ int sdc_predict(sdc_ctx* c, double t, double dt, int guess, double fill_u, doubl
     if (c->kind == 1 && guess == SDC_GUESS_SPREAD) c->rhs_host += (unsigned long long)c->M * (c->N / 2);
     c->unlocked = true;
     c->res_valid = false;
+    c->res_spread = spread_res;
     c->spec_valid = false;
     c->spec_spread = (guess == SDC_GUESS_SPREAD || guess == SDC_GUESS_COPY);  // all nodes equal U[0]
     return SDC_OK;
@@ -2142,6 +2165,7 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
     if (!c->unlocked) return fail(c, SDC_ERR_STATE, "level is locked: predict first (assert L.status.unlocked)");
     const int M = c->M;
     c->res_valid = false;
+    c->res_spread = false;
     if (c->kind == 1) {
         VdpSweepArgs a;
         memset(&a, 0, sizeof a);
@@ -2309,9 +2333,13 @@ int sdc_residual(sdc_ctx* c, double dt, int type, double* node_norms, double* re
                     "residual_type = %d not implemented, choose full_abs, last_abs, full_rel or last_rel instead", type);
     const int M = c->M;
     HIPCHK(c, hipMemsetAsync(c->red, 0, sizeof(unsigned long long) * 16, c->stream));
+    bool from_spread = false;
     if (c->res_valid && c->res_dt == dt) {
         // the sweep's fused eval_f kernel already reduced the node norms of this very state
         HIPCHK(c, hipMemcpyAsync(c->red, c->res_dev, sizeof(unsigned long long) * 8, hipMemcpyDeviceToDevice, c->stream));
+    } else if (c->res_spread) {
+        HIPCHK(c, hipMemcpyAsync(c->red + 7, c->res_dev + 7, sizeof(unsigned long long), hipMemcpyDeviceToDevice, c->stream));
+        from_spread = true;
     } else {
         QuadArgs q;
         quad_base(c, q);
@@ -2331,8 +2359,15 @@ int sdc_residual(sdc_ctx* c, double dt, int type, double* node_norms, double* re
     HIPCHK(c, hipMemcpyAsync(c->red_host, c->red, sizeof(unsigned long long) * 16, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     double norms[MAXM], mx = 0.0;
+    double f0max = 0.0;
+    memcpy(&f0max, &c->red_host[7], sizeof(double));
     for (int m = 0; m < M; ++m) {
         memcpy(&norms[m], &c->red_host[m], sizeof(double));
+        if (from_spread) {
+            double sq = 0.0;
+            for (int j = 1; j <= M; ++j) sq += dt * c->Q[m + 1][j];
+            norms[m] = fabs(sq) * f0max;
+        }
         if (node_norms) node_norms[m] = norms[m];
         mx = (norms[m] > mx || norms[m] != norms[m]) ? norms[m] : mx;
     }
