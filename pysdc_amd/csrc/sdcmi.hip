@@ -596,8 +596,9 @@ struct StencilResArgs {
 };
 
 template <int M>
-__global__ __launch_bounds__(256, 2) void k_stencil3d_res(StencilResArgs a) {
-    constexpr int TZ = 64, TY = 8, LW = TZ + 4;
+__global__ __launch_bounds__(256, 3) void k_stencil3d_res(StencilResArgs a) {
+    // LDS: 2 buffers x M fields x (8+2) rows x 66 doubles = 52.8 KB at M = 5 -> three workgroups per CU
+    constexpr int TZ = 64, TY = 8, LW = TZ + 2;
     __shared__ double tile[2][M][TY + 2][LW];
     const int n = a.n;
     const int tz = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -628,7 +629,23 @@ __global__ __launch_bounds__(256, 2) void k_stencil3d_res(StencilResArgs a) {
     }
     const size_t off = (size_t)(y0 + ty) * n + z0 + 2 * tz;
     auto wrapx = [&](int x) { return (size_t)(x < 0 ? x + n : (x >= n ? x - n : x)) * sx; };
-    double2 prev[M], cur[M], nxt[M], hnxt[M];
+    auto halo_load = [&](const double* plane) {
+        double2 h = double2{0.0, 0.0};
+        if (hy) h = *reinterpret_cast<const double2*>(plane + hoff);
+        else if (hz) h.x = plane[hoff];
+        return h;
+    };
+    auto put = [&](int b, int j, double2 v, double2 h) {
+        tile[b][j][ty + 1][1 + 2 * tz] = v.x;
+        tile[b][j][ty + 1][2 + 2 * tz] = v.y;
+        if (hy) {
+            tile[b][j][hrow][hcol] = h.x;
+            tile[b][j][hrow][hcol + 1] = h.y;
+        } else if (hz) {
+            tile[b][j][hrow][hcol] = h.x;
+        }
+    };
+    double2 prev[M], cur[M], nxt[M];
     double2 u0c, u0n = double2{0.0, 0.0};
     double nmax[M];
 #pragma unroll
@@ -637,23 +654,7 @@ __global__ __launch_bounds__(256, 2) void k_stencil3d_res(StencilResArgs a) {
         prev[j] = *reinterpret_cast<const double2*>(uj + wrapx(x0 - 1) + off);
         cur[j] = *reinterpret_cast<const double2*>(uj + wrapx(x0) + off);
         nxt[j] = *reinterpret_cast<const double2*>(uj + wrapx(x0 + 1) + off);
-        double2 hc = double2{0.0, 0.0};
-        hnxt[j] = double2{0.0, 0.0};
-        if (hy) {
-            hc = *reinterpret_cast<const double2*>(uj + wrapx(x0) + hoff);
-            hnxt[j] = *reinterpret_cast<const double2*>(uj + wrapx(x0 + 1) + hoff);
-        } else if (hz) {
-            hc.x = uj[wrapx(x0) + hoff];
-            hnxt[j].x = uj[wrapx(x0 + 1) + hoff];
-        }
-        tile[0][j][ty + 1][1 + 2 * tz] = cur[j].x;
-        tile[0][j][ty + 1][2 + 2 * tz] = cur[j].y;
-        if (hy) {
-            tile[0][j][hrow][hcol] = hc.x;
-            tile[0][j][hrow][hcol + 1] = hc.y;
-        } else if (hz) {
-            tile[0][j][hrow][hcol] = hc.x;
-        }
+        put(0, j, cur[j], halo_load(uj + wrapx(x0)));
         nmax[j] = 0.0;
     }
     u0c = *reinterpret_cast<const double2*>(a.U + wrapx(x0) + off);
@@ -663,18 +664,17 @@ __global__ __launch_bounds__(256, 2) void k_stencil3d_res(StencilResArgs a) {
         const int x = x0 + p;
         __syncthreads();
         const bool more = p + 1 < a.xchunk;
-        double2 nn[M], hnn[M];
+        // in flight while this plane is computed: the interior of plane x+2 and the halo of plane x+1
+        double2 nn[M], hn[M];
         if (more) {
-            const size_t px2 = wrapx(x + 2);
+            const size_t px1 = wrapx(x + 1), px2 = wrapx(x + 2);
 #pragma unroll
             for (int j = 0; j < M; ++j) {
                 const double* uj = a.U + (size_t)(j + 1) * a.N;
                 nn[j] = *reinterpret_cast<const double2*>(uj + px2 + off);
-                hnn[j] = double2{0.0, 0.0};
-                if (hy) hnn[j] = *reinterpret_cast<const double2*>(uj + px2 + hoff);
-                else if (hz) hnn[j].x = uj[px2 + hoff];
+                hn[j] = halo_load(uj + px1);
             }
-            u0n = *reinterpret_cast<const double2*>(a.U + wrapx(x + 1) + off);
+            u0n = *reinterpret_cast<const double2*>(a.U + px1 + off);
         }
         const size_t po = (size_t)x * sx + off;
         double2 fv[M];
@@ -707,18 +707,10 @@ __global__ __launch_bounds__(256, 2) void k_stencil3d_res(StencilResArgs a) {
         if (more) {
 #pragma unroll
             for (int j = 0; j < M; ++j) {
-                tile[b ^ 1][j][ty + 1][1 + 2 * tz] = nxt[j].x;
-                tile[b ^ 1][j][ty + 1][2 + 2 * tz] = nxt[j].y;
-                if (hy) {
-                    tile[b ^ 1][j][hrow][hcol] = hnxt[j].x;
-                    tile[b ^ 1][j][hrow][hcol + 1] = hnxt[j].y;
-                } else if (hz) {
-                    tile[b ^ 1][j][hrow][hcol] = hnxt[j].x;
-                }
+                put(b ^ 1, j, nxt[j], hn[j]);
                 prev[j] = cur[j];
                 cur[j] = nxt[j];
                 nxt[j] = nn[j];
-                hnxt[j] = hnn[j];
             }
             u0c = u0n;
         }
