@@ -276,6 +276,43 @@ class hip_imex_mesh:
             return self.expl
         return self
 
+    # component-wise arithmetic (MultiComponentMesh keeps ndarray arithmetic, datatype_classes/mesh.py:128-173)
+    def _zip(self, other, op):
+        if isinstance(other, hip_imex_mesh):
+            return hip_imex_mesh(_parts=(op(self.impl, other.impl), op(self.expl, other.expl)))
+        return hip_imex_mesh(_parts=(op(self.impl, other), op(self.expl, other)))
+
+    def __add__(self, o):
+        return self._zip(o, lambda a, b: a + b)
+
+    __radd__ = __add__
+
+    def __sub__(self, o):
+        return self._zip(o, lambda a, b: a - b)
+
+    def __mul__(self, a):
+        return self._zip(a, lambda x, y: x * y)
+
+    __rmul__ = __mul__
+
+    def __iadd__(self, o):
+        if isinstance(o, hip_imex_mesh):
+            self.impl += o.impl
+            self.expl += o.expl
+        else:
+            self.impl += o
+            self.expl += o
+        return self
+
+    def __isub__(self, o):
+        if isinstance(o, hip_imex_mesh):
+            self.impl -= o.impl
+            self.expl -= o.expl
+        else:
+            self.impl -= o
+            self.expl -= o
+        return self
+
 
 # ---- raw HIP runtime access for host copies (same runtime instance the engine uses) ---------------------
 _hiprt = None

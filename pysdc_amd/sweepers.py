@@ -263,6 +263,77 @@ class Sweeper:
         return 0
 
 
+# ---- node-by-node algorithm on datatype operations (problems the engine cannot sweep in one call) ----------
+def _rhs_sum(L, j, imex):
+    """f_j as one field: impl + expl for IMEX right-hand sides"""
+    return L.f[j].impl + L.f[j].expl if imex else L.f[j]
+
+
+def _quadrature(sw, weights_of_row):
+    """[dt * sum_j row[j] * f_j for each row]: rows of Qmat give integrate(), the weights give the end point"""
+    L = sw.level
+    P = L.prob
+    out = []
+    for row in weights_of_row:
+        acc = P.dtype_u(P.init, val=0.0)
+        for j in range(1, sw.coll.num_nodes + 1):
+            acc += L.dt * row[j] * _rhs_sum(L, j, sw.imex)
+        out.append(acc)
+    return out
+
+
+def _weighted_f(sw, m, j):
+    """dt * (QI[m][j] f_impl_j (+ QE[m][j] f_expl_j))"""
+    L = sw.level
+    if sw.imex:
+        return L.dt * (sw.QI[m, j] * L.f[j].impl + sw.QE[m, j] * L.f[j].expl)
+    return L.dt * sw.QI[m, j] * L.f[j]
+
+
+def _sweep_nodes(sw):
+    """one sweep, node after node (generic_implicit.py:51-103, imex_1st_order.py:57-108): known terms first
+    (u0 + dt (Q - QDelta) F^k + tau), then for each node the lower-triangular part with the NEW f values, the
+    implicit solve and the evaluation of f.  Only generic_implicit skips the solve when its factor is zero."""
+    L = sw.level
+    P = L.prob
+    assert L.status.unlocked
+    M = sw.coll.num_nodes
+    known = _quadrature(sw, [sw.coll.Qmat[m] for m in range(1, M + 1)])
+    for m in range(M):
+        for j in range(1, M + 1):
+            known[m] -= _weighted_f(sw, m + 1, j)
+        known[m] += L.u[0]
+        if L.tau[m] is not None:
+            known[m] += L.tau[m]
+    for m in range(M):
+        rhs = P.dtype_u(known[m])
+        for j in range(1, m + 1):
+            rhs += _weighted_f(sw, m + 1, j)
+        factor = L.dt * sw.QI[m + 1, m + 1]
+        t_node = L.time + L.dt * sw.coll.nodes[m]
+        if factor == 0 and not sw.imex:
+            L.u[m + 1] = rhs
+        else:
+            L.u[m + 1] = P.solve_system(rhs, factor, L.u[m + 1], t_node)
+        L.f[m + 1] = P.eval_f(L.u[m + 1], t_node)
+    L.status.updated = True
+
+
+def _end_point(sw):
+    """generic_implicit.py:105-131 / imex_1st_order.py:110-137"""
+    L = sw.level
+    P = L.prob
+    if sw.coll.right_is_node and not sw.params.do_coll_update:
+        L.uend = P.dtype_u(L.u[-1])
+        return
+    weights = np.concatenate([[0.0], sw.coll.weights])
+    uend = P.dtype_u(L.u[0])
+    uend += _quadrature(sw, [weights])[0]
+    if L.tau[-1] is not None:
+        uend += L.tau[-1]
+    L.uend = uend
+
+
 class generic_implicit(Sweeper):
     """generic_implicit.py:4-131."""
 
@@ -275,57 +346,13 @@ class generic_implicit(Sweeper):
     def integrate(self):
         if self._fused():
             return self._integrate_fused()
-        L = self.level
-        P = L.prob
-        me = []
-        for m in range(1, self.coll.num_nodes + 1):
-            me.append(P.dtype_u(P.init, val=0.0))
-            for j in range(1, self.coll.num_nodes + 1):
-                me[-1] += L.dt * self.coll.Qmat[m, j] * L.f[j]
-        return me
+        return _quadrature(self, [self.coll.Qmat[m] for m in range(1, self.coll.num_nodes + 1)])
 
     def update_nodes(self):
-        if self._fused():
-            return self._update_nodes_fused()
-        L = self.level
-        P = L.prob
-        assert L.status.unlocked
-        M = self.coll.num_nodes
-        integral = self.integrate()
-        for m in range(M):
-            for j in range(1, M + 1):
-                integral[m] -= L.dt * self.QI[m + 1, j] * L.f[j]
-            integral[m] += L.u[0]
-            if L.tau[m] is not None:
-                integral[m] += L.tau[m]
-        for m in range(0, M):
-            rhs = P.dtype_u(integral[m])
-            for j in range(1, m + 1):
-                rhs += L.dt * self.QI[m + 1, j] * L.f[j]
-            alpha = L.dt * self.QI[m + 1, m + 1]
-            if alpha == 0:
-                L.u[m + 1] = rhs
-            else:
-                L.u[m + 1] = P.solve_system(rhs, alpha, L.u[m + 1], L.time + L.dt * self.coll.nodes[m])
-            L.f[m + 1] = P.eval_f(L.u[m + 1], L.time + L.dt * self.coll.nodes[m])
-        L.status.updated = True
-        return None
+        return self._update_nodes_fused() if self._fused() else _sweep_nodes(self)
 
     def compute_end_point(self):
-        if self._fused():
-            return self._end_point_fused()
-        L = self.level
-        P = L.prob
-        if self.coll.right_is_node and not self.params.do_coll_update:
-            L.uend = P.dtype_u(L.u[-1])
-        else:
-            uend = P.dtype_u(L.u[0])
-            for m in range(self.coll.num_nodes):
-                uend += L.dt * self.coll.weights[m] * L.f[m + 1]
-            if L.tau[-1] is not None:
-                uend += L.tau[-1]
-            L.uend = uend
-        return None
+        return self._end_point_fused() if self._fused() else _end_point(self)
 
 
 class imex_1st_order(Sweeper):
@@ -345,55 +372,13 @@ class imex_1st_order(Sweeper):
     def integrate(self):
         if self._fused():
             return self._integrate_fused()
-        L = self.level
-        P = L.prob
-        me = []
-        for m in range(1, self.coll.num_nodes + 1):
-            me.append(P.dtype_u(P.init, val=0.0))
-            for j in range(1, self.coll.num_nodes + 1):
-                me[m - 1] += L.dt * self.coll.Qmat[m, j] * (L.f[j].impl + L.f[j].expl)
-        return me
+        return _quadrature(self, [self.coll.Qmat[m] for m in range(1, self.coll.num_nodes + 1)])
 
     def update_nodes(self):
-        if self._fused():
-            return self._update_nodes_fused()
-        L = self.level
-        P = L.prob
-        assert L.status.unlocked
-        M = self.coll.num_nodes
-        integral = self.integrate()
-        for m in range(M):
-            for j in range(1, M + 1):
-                integral[m] -= L.dt * (self.QI[m + 1, j] * L.f[j].impl + self.QE[m + 1, j] * L.f[j].expl)
-            integral[m] += L.u[0]
-            if L.tau[m] is not None:
-                integral[m] += L.tau[m]
-        for m in range(0, M):
-            rhs = P.dtype_u(integral[m])
-            for j in range(1, m + 1):
-                rhs += L.dt * (self.QI[m + 1, j] * L.f[j].impl + self.QE[m + 1, j] * L.f[j].expl)
-            L.u[m + 1] = P.solve_system(
-                rhs, L.dt * self.QI[m + 1, m + 1], L.u[m + 1], L.time + L.dt * self.coll.nodes[m]
-            )
-            L.f[m + 1] = P.eval_f(L.u[m + 1], L.time + L.dt * self.coll.nodes[m])
-        L.status.updated = True
-        return None
+        return self._update_nodes_fused() if self._fused() else _sweep_nodes(self)
 
     def compute_end_point(self):
-        if self._fused():
-            return self._end_point_fused()
-        L = self.level
-        P = L.prob
-        if self.coll.right_is_node and not self.params.do_coll_update:
-            L.uend = P.dtype_u(L.u[-1])
-        else:
-            uend = P.dtype_u(L.u[0])
-            for m in range(self.coll.num_nodes):
-                uend += L.dt * self.coll.weights[m] * (L.f[m + 1].impl + L.f[m + 1].expl)
-            if L.tau[-1] is not None:
-                uend += L.tau[-1]
-            L.uend = uend
-        return None
+        return self._end_point_fused() if self._fused() else _end_point(self)
 
     def get_sweeper_mats(self):
         return self.QE[1:, 1:], self.QI[1:, 1:], self.coll.Qmat[1:, 1:]

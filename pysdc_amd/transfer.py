@@ -47,81 +47,81 @@ class BaseTransfer:
     def get_transfer_matrix_Q(f_nodes, c_nodes):
         return LagrangeApproximation(c_nodes).getInterpolationMatrix(f_nodes)
 
+    # ---- helpers: node-space combinations with a small dense matrix ------------------------------------------
+    @staticmethod
+    def _mix(matrix_row, fields):
+        """sum_m matrix_row[m] * fields[m], accumulated left to right like the reference's loops."""
+        acc = matrix_row[0] * fields[0]
+        for coeff, field in zip(matrix_row[1:], fields[1:]):
+            acc += coeff * field
+        return acc
+
+    def _to_coarse_nodes(self, fine_fields):
+        """space restriction of every fine-node field followed by the node restriction Rcoll."""
+        in_space = [self.space_transfer.restrict(x) for x in fine_fields]
+        return [self._mix(self.Rcoll[n], in_space) for n in range(self.coarse.sweep.coll.num_nodes)]
+
     def restrict(self):
-        """base_transfer.py:93-168."""
-        F, G = self.fine, self.coarse
-        PG = G.prob
-        SF, SG = F.sweep, G.sweep
-        if not F.status.unlocked:
+        """FAS restriction (base_transfer.py:93-168): coarse node values R u_F, coarse right-hand sides
+        re-evaluated there, tau = R(Q_F f_F) - Q_G f_G (+ R tau_F), and the snapshot uold / fold that the
+        coarse-grid correction is measured against."""
+        fine, coarse = self.fine, self.coarse
+        if not fine.status.unlocked:
             raise UnlockError('fine level is still locked, cannot use data from there')
-        tmp_u = []
-        for m in range(1, SF.coll.num_nodes + 1):
-            tmp_u.append(self.space_transfer.restrict(F.u[m]))
-        G.u[0] = self.space_transfer.restrict(F.u[0])
-        for n in range(1, SG.coll.num_nodes + 1):
-            G.u[n] = self.Rcoll[n - 1, 0] * tmp_u[0]
-            for m in range(1, SF.coll.num_nodes):
-                G.u[n] += self.Rcoll[n - 1, m] * tmp_u[m]
-        G.f[0] = PG.eval_f(G.u[0], G.time)
-        for m in range(1, SG.coll.num_nodes + 1):
-            G.f[m] = PG.eval_f(G.u[m], G.time + G.dt * SG.coll.nodes[m - 1])
-        tauG = G.sweep.integrate()
-        tauF = F.sweep.integrate()
-        tmp_tau = []
-        for m in range(SF.coll.num_nodes):
-            tmp_tau.append(self.space_transfer.restrict(tauF[m]))
-        tauFG = []
-        for n in range(1, SG.coll.num_nodes + 1):
-            tauFG.append(self.Rcoll[n - 1, 0] * tmp_tau[0])
-            for m in range(1, SF.coll.num_nodes):
-                tauFG[-1] += self.Rcoll[n - 1, m] * tmp_tau[m]
-        for m in range(SG.coll.num_nodes):
-            G.tau[m] = tauFG[m] - tauG[m]
-        if F.tau[0] is not None:
-            tmp_tau = []
-            for m in range(SF.coll.num_nodes):
-                tmp_tau.append(self.space_transfer.restrict(F.tau[m]))
-            for n in range(SG.coll.num_nodes):
-                for m in range(SF.coll.num_nodes):
-                    G.tau[n] += self.Rcoll[n, m] * tmp_tau[m]
-        for m in range(1, SG.coll.num_nodes + 1):
-            G.uold[m] = PG.dtype_u(G.u[m])
-            G.fold[m] = PG.dtype_f(G.f[m])
-        G.status.unlocked = True
-        return None
+        Mf, Mc = fine.sweep.coll.num_nodes, coarse.sweep.coll.num_nodes
+        cprob = coarse.prob
+
+        coarse.u[0] = self.space_transfer.restrict(fine.u[0])
+        for n, value in enumerate(self._to_coarse_nodes([fine.u[m] for m in range(1, Mf + 1)]), start=1):
+            coarse.u[n] = value
+        coarse.f[0] = cprob.eval_f(coarse.u[0], coarse.time)
+        for n in range(1, Mc + 1):
+            coarse.f[n] = cprob.eval_f(coarse.u[n], coarse.time + coarse.dt * coarse.sweep.coll.nodes[n - 1])
+
+        quad_coarse = coarse.sweep.integrate()
+        quad_fine_on_coarse = self._to_coarse_nodes(fine.sweep.integrate())
+        for n in range(Mc):
+            coarse.tau[n] = quad_fine_on_coarse[n] - quad_coarse[n]
+        if fine.tau[0] is not None:  # a correction the fine level itself received from above travels down too
+            carried = [self.space_transfer.restrict(fine.tau[m]) for m in range(Mf)]
+            for n in range(Mc):
+                for m in range(Mf):
+                    coarse.tau[n] += self.Rcoll[n, m] * carried[m]
+
+        for n in range(1, Mc + 1):
+            coarse.uold[n] = cprob.dtype_u(coarse.u[n])
+            coarse.fold[n] = cprob.dtype_f(coarse.f[n])
+        coarse.status.unlocked = True
+
+    def _coarse_correction(self, new_fields, old_fields):
+        Mc = self.coarse.sweep.coll.num_nodes
+        return [self.space_transfer.prolong(new_fields[n] - old_fields[n]) for n in range(1, Mc + 1)]
 
     def prolong(self):
-        """base_transfer.py:170-207."""
-        F, G = self.fine, self.coarse
-        PF = F.prob
-        SF, SG = F.sweep, G.sweep
-        if not G.status.unlocked:
+        """coarse-grid correction (base_transfer.py:170-207): u_F += P (u_G - uold_G), then f re-evaluated."""
+        fine, coarse = self.fine, self.coarse
+        if not coarse.status.unlocked:
             raise UnlockError('coarse level is still locked, cannot use data from there')
-        tmp_u = []
-        for m in range(1, SG.coll.num_nodes + 1):
-            tmp_u.append(self.space_transfer.prolong(G.u[m] - G.uold[m]))
-        for n in range(1, SF.coll.num_nodes + 1):
-            for m in range(SG.coll.num_nodes):
-                F.u[n] += self.Pcoll[n - 1, m] * tmp_u[m]
-        for m in range(1, SF.coll.num_nodes + 1):
-            F.f[m] = PF.eval_f(F.u[m], F.time + F.dt * SF.coll.nodes[m - 1])
-        return None
+        Mf, Mc = fine.sweep.coll.num_nodes, coarse.sweep.coll.num_nodes
+        delta = self._coarse_correction(coarse.u, coarse.uold)
+        for n in range(1, Mf + 1):
+            for m in range(Mc):
+                fine.u[n] += self.Pcoll[n - 1, m] * delta[m]
+        for n in range(1, Mf + 1):
+            fine.f[n] = fine.prob.eval_f(fine.u[n], fine.time + fine.dt * fine.sweep.coll.nodes[n - 1])
 
     def prolong_f(self):
-        """base_transfer.py:209-251."""
-        F, G = self.fine, self.coarse
-        SF, SG = F.sweep, G.sweep
-        if not G.status.unlocked:
+        """variant that also interpolates the change of f instead of re-evaluating it (base_transfer.py:209-251)."""
+        fine, coarse = self.fine, self.coarse
+        if not coarse.status.unlocked:
             raise UnlockError('coarse level is still locked, cannot use data from there')
-        tmp_u, tmp_f = [], []
-        for m in range(1, SG.coll.num_nodes + 1):
-            tmp_u.append(self.space_transfer.prolong(G.u[m] - G.uold[m]))
-            tmp_f.append(self.space_transfer.prolong(G.f[m] - G.fold[m]))
-        for n in range(1, SF.coll.num_nodes + 1):
-            for m in range(SG.coll.num_nodes):
-                F.u[n] += self.Pcoll[n - 1, m] * tmp_u[m]
-                F.f[n] += self.Pcoll[n - 1, m] * tmp_f[m]
-        return None
+        Mf, Mc = fine.sweep.coll.num_nodes, coarse.sweep.coll.num_nodes
+        du = self._coarse_correction(coarse.u, coarse.uold)
+        df = self._coarse_correction(coarse.f, coarse.fold)
+        for n in range(1, Mf + 1):
+            for m in range(Mc):
+                fine.u[n] += self.Pcoll[n - 1, m] * du[m]
+                fine.f[n] += self.Pcoll[n - 1, m] * df[m]
 
 
 class _SpacePars:
