@@ -131,8 +131,18 @@ def main():
 
     M, K = args.nodes, args.sweeps
     ncomp = 1
+    fallback_note = ''
     if args.workload == 'heat':
         n = args.n or 1024
+        if args.n is None:
+            # 1024^3 with M = 5 needs ~26 fields of 8.6 GB (slabs, work + cached spectra, in/out buffers);
+            # fall back to the largest configuration that fits if this GPU cannot hold it
+            need = 26.5 * 8.0 * n**3
+            free = torch.cuda.mem_get_info()[0]
+            if free < need:
+                n = 512
+                fallback_note = f' [1024^3 needs {need / 1e9:.0f} GB, {free / 1e9:.0f} GB free: fell back to 512^3]'
+
         dt = 1e-3 * (512.0 / n) ** 2  # dt*nu*12/dx^2 ~ 315 at every size
         desc = dict(problem_class=heatNd_unforced, problem_params=dict(nvars=(n, n, n), nu=0.1, freq=2, order=2),
                     sweeper_class=generic_implicit,
@@ -267,7 +277,7 @@ def main():
             'value': units * steps_total / el, 'unit': unit, 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * el / args.steps, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': f'{wl}, {K} sweeps/step (restol=-1, maxiter={K}), dt={dt:g}, '
+            'config': {'workload': f'{wl}{fallback_note}, {K} sweeps/step (restol=-1, maxiter={K}), dt={dt:g}, '
                                    f'solver=direct (Fourier), spectral_reuse={not args.no_spectral_reuse}',
                        'time_parallel': f'{world} time-slice(s), one per GPU, multi-step SDC (Jacobi)'},
             'sdc_iters_per_s': units * sweeps_total / el,
