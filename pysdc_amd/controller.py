@@ -348,10 +348,16 @@ class controller_dist(_ControllerBase):
         self.comm = comm
         self.rank = dist.get_rank(comm)
         self.size = dist.get_world_size(comm)
+        self._flag_device = 'cpu'
         if dist.get_backend(comm) == 'gloo':
             self.host_comm = comm
         else:
-            self.host_comm = dist.new_group(backend='gloo')
+            try:
+                self.host_comm = dist.new_group(backend='gloo')
+            except Exception as e:  # e.g. no usable network interface for gloo: keep the flags on the main group
+                self.logger.warning(f'no gloo side group ({e}); convergence flags travel through the device group')
+                self.host_comm = comm
+                self._flag_device = 'cuda'
         self.S = description.get('step_class', Step)(description)
         self.S.status.slot = self.rank
         self.nsweeps = [L.params.nsweeps for L in self.S.levels]
@@ -363,19 +369,20 @@ class controller_dist(_ControllerBase):
     def _send_flag(self, value, dst):
         import torch
 
-        self.dist.send(torch.tensor([1 if value else 0], dtype=torch.int32), dst=dst, group=self.host_comm)
+        self.dist.send(torch.tensor([1 if value else 0], dtype=torch.int32, device=self._flag_device), dst=dst,
+                       group=self.host_comm)
 
     def _recv_flag(self, src):
         import torch
 
-        t = torch.zeros(1, dtype=torch.int32)
+        t = torch.zeros(1, dtype=torch.int32, device=self._flag_device)
         self.dist.recv(t, src=src, group=self.host_comm)
         return bool(t.item())
 
     def _all_sum(self, value):
         import torch
 
-        t = torch.tensor([int(value)], dtype=torch.int64)
+        t = torch.tensor([int(value)], dtype=torch.int64, device=self._flag_device)
         self.dist.all_reduce(t, group=self.host_comm)
         return int(t.item())
 
