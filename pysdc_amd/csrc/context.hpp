@@ -1,0 +1,155 @@
+// libsdcmi: context of one level (device slabs, coefficients, operator tables) and launch timing.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+#include "../../include/sdcmi.h"
+#include "fft.hpp"
+#define MAXM 8
+#define MAXSTEN 12
+
+// ------------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------------
+struct Stencil {
+    int npts = 0;
+    int off[MAXSTEN];
+    double w[MAXSTEN];
+};
+
+struct ProfEntry {
+    double ms = 0;
+    int calls = 0;
+};
+
+struct sdc_ctx {
+    int device = 0, ndim = 0, n = 0, M = 0, ncomp = 1;
+    size_t N = 0;       // n^ndim
+    size_t Nc = 0;      // complex entries of one spectrum field
+    hipStream_t stream = nullptr;
+    double *U = nullptr, *F = nullptr, *TAU = nullptr, *UEND = nullptr, *profile = nullptr;
+    cd* W = nullptr;
+    cd *S = nullptr, *S0 = nullptr;  // spectral cache: transforms of U[1..M] and of U[0] (lazy)
+    bool spec_valid = false, spec0_valid = false, spec_spread = false, reuse = true, force_gather = false;
+    cd *tw = nullptr, *lamI = nullptr, *lamE = nullptr;
+    unsigned long long* red = nullptr;  // reduction slots (device)
+    unsigned long long* red_host = nullptr;
+    bool tau_active = false, have_coeffs = false, have_stencil[2] = {false, false}, unlocked = false;
+    int expl_kind = SDC_EXPL_NONE;
+    bool res_spread = false;  // state = spread predictor of an autonomous f: residual_m = dt |sum_j Q[m][j]| max|f(u0)|
+    bool fuse_residual = true;
+    bool res_valid = false;   // node norms of the residual were produced by the fused stencil kernel
+    double res_dt = 0.0;
+    unsigned long long* res_dev = nullptr;  // device slots of those norms
+    bool spectral_op = false;  // implicit operator given by its Fourier symbol only (no stencil): eval_f by FFT
+    int react_kind = 0, react_nu = 2;
+    double react_p0 = 0, react_p1 = 0;
+    int kind = 0;  // 0: periodic finite differences, 1: van der Pol ensemble (N = 2 * ntraj, SoA)
+    double vdp_mu = 0, vdp_tol = 1e-9;
+    int vdp_maxiter = 100;
+    unsigned long long* counters = nullptr;  // device: [0] newton, [1] rhs, [2] failed solves
+    unsigned long long rhs_host = 0;         // evaluations the reference would have made where the engine copies
+    double Q[MAXM + 1][MAXM + 1], QI[MAXM + 1][MAXM + 1], QE[MAXM + 1][MAXM + 1], nodes[MAXM], weights[MAXM];
+    double gvals[MAXM + 1];
+    Stencil st[2];
+    size_t bytes = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, pev0 = nullptr, pev1 = nullptr;
+    bool profiling = false;
+    std::vector<hipEvent_t> pool;            // event pairs recorded around launches while profiling
+    std::vector<const char*> pool_names;
+    size_t pool_used = 0;                    // pairs in flight
+    std::map<std::string, ProfEntry> prof;
+    std::vector<std::string> prof_names;
+    std::string err;
+};
+
+static thread_local std::string g_create_err;
+
+static int fail(sdc_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    else g_create_err = buf;
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                              \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess)                                                                        \
+            return fail(c, e_ == hipErrorOutOfMemory ? SDC_ERR_NOMEM : SDC_ERR_HIP, "%s: %s", #call, \
+                        hipGetErrorString(e_));                                                      \
+    } while (0)
+
+// Per-kernel device time: a pair of events from a pool is recorded around every launch on the context's
+// stream; nothing synchronises until the pool is full or the profile is read, so the timed region of bench.py
+// is not perturbed.
+static void prof_flush(sdc_ctx* c) {
+    if (c->pool_used == 0) return;
+    (void)hipEventSynchronize(c->pool[2 * c->pool_used - 1]);
+    for (size_t i = 0; i < c->pool_used; ++i) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, c->pool[2 * i], c->pool[2 * i + 1]) == hipSuccess) {
+            ProfEntry& e = c->prof[c->pool_names[i]];
+            e.ms += ms;
+            e.calls += 1;
+        }
+    }
+    c->pool_used = 0;
+}
+
+struct LaunchTimer {
+    sdc_ctx* c;
+    size_t slot = 0;
+    bool on;
+    LaunchTimer(sdc_ctx* c_, const char* n) : c(c_), on(c_->profiling) {
+        if (!on) return;
+        constexpr size_t kPairs = 2048;
+        if (c->pool.empty()) {
+            c->pool.resize(2 * kPairs);
+            c->pool_names.resize(kPairs);
+            for (auto& e : c->pool) (void)hipEventCreate(&e);
+        }
+        if (c->pool_used == kPairs) prof_flush(c);
+        slot = c->pool_used++;
+        c->pool_names[slot] = n;
+        (void)hipEventRecord(c->pool[2 * slot], c->stream);
+    }
+    ~LaunchTimer() {
+        if (on) (void)hipEventRecord(c->pool[2 * slot + 1], c->stream);
+    }
+};
+
+static inline int is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
+
+// profile names that carry the number of fields of the launch, e.g. "fft_x_fwd[5]" (interned, static lifetime)
+static const char* pname(const char* base, int nf) {
+    static std::map<std::string, std::string> table;
+    std::string key = std::string(base) + "[" + std::to_string(nf) + "]";
+    auto it = table.find(key);
+    if (it == table.end()) it = table.emplace(key, key).first;
+    return it->second.c_str();
+}
+
+// 1/(1 - alpha*lambda): |denominator|^2 is finite and away from zero for the dissipative / skew operators
+// handled here, so the reciprocal is v_rcp_f64 refined by two Newton steps (~1 ulp) instead of the IEEE
+// division sequence (v_div_scale / v_div_fmas / v_div_fixup).
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ cd cinv_fast(cd d) {
+    const double m = fast_rcp(d.x * d.x + d.y * d.y);
+    return cd{d.x * m, -d.y * m};
+}
+

@@ -1,0 +1,344 @@
+// libsdcmi kernels: axis passes of the 3-D real FFT, node-coupled Fourier solve, spectral-cache sweep.
+#pragma once
+#include "context.hpp"
+
+// ------------------------------------------------------------------------------------------------------
+// FFT kernels
+// ------------------------------------------------------------------------------------------------------
+struct FieldPtrs {
+    const double* in[MAXM];
+    double* out[MAXM];
+};
+
+// 1-D problems: promote the real line to complex / take the real part back
+__global__ void k_promote(FieldPtrs p, cd* W, size_t N) {
+    const int f = blockIdx.y;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < N; i += (size_t)gridDim.x * blockDim.x)
+        W[(size_t)f * N + i] = cd{p.in[f][i], 0.0};
+}
+__global__ void k_realpart(FieldPtrs p, const cd* W, size_t N) {
+    const int f = blockIdx.y;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < N; i += (size_t)gridDim.x * blockDim.x)
+        p.out[f][i] = W[(size_t)f * N + i].x;
+}
+
+// r2c along axis 0: real field [N][rest] seen as complex pairs [N][rest/2]; two real columns per complex
+// column ("two for one"), unpacked to the half spectra W[k][rest], k = 0..N/2.
+template <int N, int T>
+__global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_fwd(FieldPtrs p, cd* __restrict__ W, size_t fstride,
+                                                                      int rest, const cd* __restrict__ tw) {
+    constexpr int E = fft_elems(N), P = N / E;
+    using LAY = LayStrided<N, T>;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int col = threadIdx.x % T, j = threadIdx.x / T;
+    const int ncol = rest >> 1;  // complex columns
+    const int c = blockIdx.x * T + col;
+    const bool ok = c < ncol;
+    const double* __restrict__ in = p.in[blockIdx.y];
+    cd r[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i)
+        r[i] = ok ? *reinterpret_cast<const cd*>(in + (size_t)(j + i * P) * rest + 2 * (size_t)c) : cd{0.0, 0.0};
+    fft_line<N, -1, LAY>(r, j, col, lds, tw);
+    // unpack: A[k] = (C[k] + conj C[N-k]) / 2, B[k] = (C[k] - conj C[N-k]) / (2i)
+    cd A[E], B[E];
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+#pragma unroll
+        for (int i = 0; i < E; ++i) lds[LAY::idx(col, j + i * P)] = part == 0 ? r[i].x : r[i].y;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            const int k = j + i * P;
+            const double v = lds[LAY::idx(col, (N - k) & (N - 1))];
+            if (part == 0) {
+                A[i].x = 0.5 * (r[i].x + v);
+                B[i].y = -0.5 * (r[i].x - v);
+            } else {
+                A[i].y = 0.5 * (r[i].y - v);
+                B[i].x = 0.5 * (r[i].y + v);
+            }
+        }
+        __syncthreads();
+    }
+    cd* __restrict__ Wf = W + blockIdx.y * fstride;
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+        const int k = j + i * P;
+        if (ok && k <= N / 2) {
+            cd* dst = Wf + (size_t)k * rest + 2 * (size_t)c;
+            dst[0] = A[i];
+            dst[1] = B[i];
+        }
+    }
+}
+
+// c2r along axis 0 (inverse of the above, unnormalised)
+template <int N, int T>
+__global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_inv(FieldPtrs p, const cd* __restrict__ W,
+                                                                      size_t fstride, int rest,
+                                                                      const cd* __restrict__ tw) {
+    constexpr int E = fft_elems(N), P = N / E;
+    using LAY = LayStrided<N, T>;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int col = threadIdx.x % T, j = threadIdx.x / T;
+    const int ncol = rest >> 1;
+    const int c = blockIdx.x * T + col;
+    const bool ok = c < ncol;
+    const cd* __restrict__ Wf = W + blockIdx.y * fstride;
+    cd A[E], B[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+        const int k = j + i * P;
+        if (ok && k <= N / 2) {
+            const cd* src = Wf + (size_t)k * rest + 2 * (size_t)c;
+            A[i] = src[0];
+            B[i] = src[1];
+        } else {
+            A[i] = B[i] = cd{0.0, 0.0};
+        }
+    }
+    cd r[E];
+    // C[k] = A[k] + i B[k] (k <= N/2), C[N-k] = conj A[k] + i conj B[k]
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            const int k = j + i * P;
+            if (k <= N / 2) {
+                const bool edge = (k == 0) || (k == N / 2);
+                double own, mir;
+                if (part == 0) {
+                    own = edge ? A[i].x : A[i].x - B[i].y;
+                    mir = A[i].x + B[i].y;
+                } else {
+                    own = edge ? B[i].x : A[i].y + B[i].x;
+                    mir = -A[i].y + B[i].x;
+                }
+                lds[LAY::idx(col, k)] = own;
+                if (!edge) lds[LAY::idx(col, N - k)] = mir;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            const double v = lds[LAY::idx(col, j + i * P)];
+            if (part == 0) r[i].x = v;
+            else r[i].y = v;
+        }
+        __syncthreads();
+    }
+    fft_line<N, +1, LAY>(r, j, col, lds, tw);
+    double* __restrict__ out = p.out[blockIdx.y];
+    if (ok) {
+#pragma unroll
+        for (int i = 0; i < E; ++i) *reinterpret_cast<cd*>(out + (size_t)(j + i * P) * rest + 2 * (size_t)c) = r[i];
+    }
+}
+
+// c2c in place along the middle axis of W[f][kx][y][z] (3-D only): tile = all y x T z-columns
+template <int N, int T, int DIR>
+__global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_ffty(cd* __restrict__ W, size_t fstride,
+                                                                  const cd* __restrict__ tw) {
+    constexpr int E = fft_elems(N), P = N / E;
+    using LAY = LayStrided<N, T>;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int col = threadIdx.x % T, j = threadIdx.x / T;
+    const int c = blockIdx.x * T + col;
+    const bool ok = c < N;
+    cd* __restrict__ base = W + blockIdx.z * fstride + (size_t)blockIdx.y * N * N + c;
+    cd r[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i) r[i] = ok ? base[(size_t)(j + i * P) * N] : cd{0.0, 0.0};
+    fft_line<N, DIR, LAY>(r, j, col, lds, tw);
+    if (ok) {
+#pragma unroll
+        for (int i = 0; i < E; ++i) base[(size_t)(j + i * P) * N] = r[i];
+    }
+}
+
+struct ZArgs {
+    cd* W;
+    size_t fstride;
+    const cd *tw, *lamI, *lamE;  // lamE may be null
+    double cI[MAXM][MAXM];       // strictly lower: dt*QI[m+1][j+1], j < m
+    double cE[MAXM][MAXM];       // strictly lower: dt*QE[m+1][j+1]
+    double alpha[MAXM];          // dt*QI[m+1][m+1]
+    double invN;
+    int nf, ndim, coupled;
+    int apply;  // 1: multiply by the symbol (operator application) instead of dividing by 1 - alpha*symbol
+};
+
+// forward FFT along the contiguous axis, node-coupled implicit solve in Fourier space, inverse FFT.
+// One workgroup = LPB lines x all nf fields; column c = f*LPB + l occupies threads [c*P, (c+1)*P).
+// After the forward transform the spectra go through LDS once more so that one thread holds ALL nf node
+// values of a mode: the lower-triangular node coupling is then a register recurrence with wave-uniform
+// coefficient indices (scalar kernarg loads, no per-lane table look-ups).
+template <int N>
+constexpr int z_lines_per_block() {
+    constexpr int P = N / fft_elems(N);
+    return P >= 64 ? 1 : 64 / P;
+}
+
+template <int N>
+__global__ __launch_bounds__(z_lines_per_block<N>() * (N / fft_elems(N)) * MAXM, 3) void k_fftz_solve(ZArgs a, unsigned nlines) {
+    constexpr int E = fft_elems(N), P = N / E, LPB = z_lines_per_block<N>();
+    constexpr int NCH = E == 16 ? 2 : 1;  // the solve buffer holds N/NCH modes per column at a time
+    constexpr int CH = N / NCH, ECH = E / NCH;
+    using LAY = LayContig<N>;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int c = threadIdx.x / P, j = threadIdx.x % P;
+    const int f = c / LPB, l = c % LPB;
+    const size_t line = (size_t)blockIdx.x * LPB + l;
+    const bool ok = line < nlines;
+    cd* __restrict__ Wl = a.W + f * a.fstride + line * N;
+    cd r[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i) r[i] = ok ? Wl[j + i * P] : cd{0.0, 0.0};
+    fft_line<N, -1, LAY, (N / fft_elems(N)) <= 64>(r, j, c, lds, a.tw);
+    __syncthreads();  // the solve buffer aliases other waves' exchange planes
+
+    cd* buf = reinterpret_cast<cd*>(lds);  // [column][CH]
+    const int nthreads = a.nf * LPB * P;
+#pragma unroll
+    for (int ph = 0; ph < NCH; ++ph) {
+#pragma unroll
+        for (int i = 0; i < ECH; ++i) buf[c * CH + j + i * P] = r[ph * ECH + i];
+        __syncthreads();
+        for (int item = threadIdx.x; item < LPB * CH; item += nthreads) {
+            const int ll = item / CH, kk = item % CH;
+            const size_t ln = (size_t)blockIdx.x * LPB + ll;
+            const int kz = ph * CH + kk;
+            cd lam = a.lamI[kz], mu = cd{0.0, 0.0};
+            if (a.lamE) mu = a.lamE[kz];
+            if (a.ndim == 3) {
+                const int kx = (int)(ln / N) % (N / 2 + 1), ky = (int)(ln % N);
+                lam = cadd(lam, cadd(a.lamI[kx], a.lamI[ky]));
+                if (a.lamE) mu = cadd(mu, cadd(a.lamE[kx], a.lamE[ky]));
+            } else if (a.ndim == 2) {
+                const int kx = (int)(ln % (N / 2 + 1));
+                lam = cadd(lam, a.lamI[kx]);
+                if (a.lamE) mu = cadd(mu, a.lamE[kx]);
+            }
+            cd u[MAXM];
+#pragma unroll
+            for (int m = 0; m < MAXM; ++m) {
+                if (m < a.nf) {
+                    cd acc = buf[(m * LPB + ll) * CH + kk];
+                    if (a.coupled) {
+#pragma unroll
+                        for (int q = 0; q < m; ++q) {
+                            const double ci = a.cI[m][q], ce = a.cE[m][q];
+                            const cd coef = cd{ci * lam.x + ce * mu.x, ci * lam.y + ce * mu.y};
+                            acc = cfma(coef, u[q], acc);
+                        }
+                    }
+                    const double al = a.alpha[m];
+                    u[m] = a.apply ? cmul(acc, lam) : cmul(acc, cinv_fast(cd{1.0 - al * lam.x, -al * lam.y}));
+                    buf[(m * LPB + ll) * CH + kk] = cscale(u[m], a.invN);
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < ECH; ++i) r[ph * ECH + i] = buf[c * CH + j + i * P];
+        __syncthreads();
+    }
+    // opaque copy of the lane index: without it the forward transform's twiddles stay live (~100 VGPRs)
+    // through the whole kernel for reuse in the inverse
+    int j2 = j;
+    asm volatile("" : "+v"(j2));
+    fft_line<N, +1, LAY, (N / fft_elems(N)) <= 64>(r, j2, c, lds, a.tw);
+    if (ok) {
+#pragma unroll
+        for (int i = 0; i < E; ++i) Wl[j2 + i * P] = r[i];
+    }
+}
+
+// plain transform along the contiguous axis, src -> dst (may alias), optionally scaled: forward to bring u0 /
+// node values into the fully transformed domain of the spectral cache, inverse after the spectral sweep
+template <int N, int DIR>
+__global__ __launch_bounds__(z_lines_per_block<N>() * (N / fft_elems(N)) * MAXM, 4) void k_fftz_plain(
+    const cd* __restrict__ src, cd* __restrict__ dst, size_t fstride, const cd* __restrict__ tw, unsigned nlines,
+    double scale) {
+    constexpr int E = fft_elems(N), P = N / E, LPB = z_lines_per_block<N>();
+    using LAY = LayContig<N>;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int c = threadIdx.x / P, j = threadIdx.x % P;
+    const int f = c / LPB, l = c % LPB;
+    const size_t line = (size_t)blockIdx.x * LPB + l;
+    const bool ok = line < nlines;
+    const size_t base = f * fstride + line * N;
+    cd r[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i) r[i] = ok ? src[base + j + i * P] : cd{0.0, 0.0};
+    if (scale != 1.0) {
+#pragma unroll
+        for (int i = 0; i < E; ++i) r[i] = cscale(r[i], scale);
+    }
+    fft_line<N, DIR, LAY, (N / fft_elems(N)) <= 64>(r, j, c, lds, tw);
+    if (ok) {
+#pragma unroll
+        for (int i = 0; i < E; ++i) dst[base + j + i * P] = r[i];
+    }
+}
+
+// Sweep in the transformed domain (DESIGN.md "spectral reuse").  For linear f(u) = A u (+ B u) the gathered
+// right-hand side of node m is  u0 + dt sum_j (Q-QI)[m][j] A u_j^k (+ explicit part): its transform follows
+// from the transforms of u0 and of the previous iterate, which the previous sweep left in S.  One launch
+// reads S0 and S[0..nf), applies gather + node-coupled solve per mode, writes the new spectra back to S and
+// their inverse transform along the contiguous axis to W (input of the inverse y / x passes).
+struct SpecArgs {
+    cd* S;
+    size_t fstride;
+    const cd* S0;
+    cd* W;
+    const cd *tw, *lamI, *lamE;
+    double gI[MAXM][MAXM], gE[MAXM][MAXM];  // dt (Q - QI), dt (Q - QE), inner MxM blocks
+    double cI[MAXM][MAXM], cE[MAXM][MAXM], alpha[MAXM];
+    double invN;
+    int nf, ndim, coupled, spread;
+};
+
+// one thread per Fourier mode: gather on the cached transforms + node-coupled solve, S updated in place
+template <int NF>
+__global__ __launch_bounds__(256) void k_spec_point(SpecArgs a, int n, size_t nmodes) {
+    for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < nmodes; g += (size_t)gridDim.x * blockDim.x) {
+        const int kz = (int)(g % n);
+        const size_t ln = g / n;
+        cd lam = a.lamI[kz], mu = cd{0.0, 0.0};
+        if (a.lamE) mu = a.lamE[kz];
+        if (a.ndim == 3) {
+            const int kx = (int)(ln / n), ky = (int)(ln % n);
+            lam = cadd(lam, cadd(a.lamI[kx], a.lamI[ky]));
+            if (a.lamE) mu = cadd(mu, cadd(a.lamE[kx], a.lamE[ky]));
+        } else if (a.ndim == 2) {
+            lam = cadd(lam, a.lamI[ln]);
+            if (a.lamE) mu = cadd(mu, a.lamE[ln]);
+        }
+        const cd u0h = a.S0[g];
+        cd old[NF], u[NF];
+#pragma unroll
+        for (int q = 0; q < NF; ++q) old[q] = a.spread ? u0h : a.S[q * a.fstride + g];
+#pragma unroll
+        for (int m = 0; m < NF; ++m) {
+            cd acc = u0h;
+#pragma unroll
+            for (int q = 0; q < NF; ++q) {
+                const double gi = a.gI[m][q], ge = a.gE[m][q];
+                acc = cfma(cd{gi * lam.x + ge * mu.x, gi * lam.y + ge * mu.y}, old[q], acc);
+            }
+            if (a.coupled) {
+#pragma unroll
+                for (int q = 0; q < m; ++q) {
+                    const double ci = a.cI[m][q], ce = a.cE[m][q];
+                    acc = cfma(cd{ci * lam.x + ce * mu.x, ci * lam.y + ce * mu.y}, u[q], acc);
+                }
+            }
+            const double al = a.alpha[m];
+            u[m] = cmul(acc, cinv_fast(cd{1.0 - al * lam.x, -al * lam.y}));
+            a.S[m * a.fstride + g] = u[m];
+        }
+    }
+}
+

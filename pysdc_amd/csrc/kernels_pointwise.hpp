@@ -1,0 +1,199 @@
+// libsdcmi kernels: quadrature gathers / residual norms / predictor fill / vector operations.
+#pragma once
+#include "context.hpp"
+
+// ------------------------------------------------------------------------------------------------------
+// elementwise kernels
+// ------------------------------------------------------------------------------------------------------
+struct QuadArgs {
+    const double* u0;    // may be null
+    const double* F;     // F slab base; field (j, comp) at F + (j*ncomp + comp)*N
+    const double* tau;   // TAU base or null
+    const double* Usub;  // U slab base for the residual (subtract U[mo+1]) or null
+    double* out[MAXM];   // MODE 0 outputs
+    double cI[MAXM][MAXM];  // [mo][j-1]
+    double cE[MAXM][MAXM];
+    unsigned long long* norms;  // MODE 1: per-node max |.| as ordered bit patterns
+    size_t N;
+    int nout;  // number of output rows (M, or 1 for the end point)
+    int tau_row0;  // tau row used for output 0 (end point uses the last row)
+};
+
+__device__ inline void atomic_max_abs(unsigned long long* slot, double v) {
+    // |v| >= 0: IEEE order == unsigned order of the bit pattern; NaN (0x7ff8...) wins, like np.max
+    atomicMax(slot, (unsigned long long)__double_as_longlong(fabs(v)));
+}
+
+__device__ inline double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        double w = __shfl_xor(v, o, 64);
+        v = (v > w || v != v) ? v : w;  // propagate NaN
+    }
+    return v;
+}
+
+// out[mo] = u0 + sum_j cI[mo][j] F_impl[j] (+ cE[mo][j] F_expl[j]) (+ tau[mo]) (- U[mo+1], max-norm)
+template <int M, int NCOMP, int MODE>
+__global__ __launch_bounds__(256) void k_quad(QuadArgs a) {
+    const size_t n2 = a.N >> 1;
+    double nmax[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) nmax[m] = 0.0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x * blockDim.x) {
+        double2 fi[M], fe[M];
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            fi[j] = reinterpret_cast<const double2*>(a.F + ((size_t)(j + 1) * NCOMP) * a.N)[i];
+            if (NCOMP == 2) fe[j] = reinterpret_cast<const double2*>(a.F + ((size_t)(j + 1) * NCOMP + 1) * a.N)[i];
+        }
+        double2 u0 = a.u0 ? reinterpret_cast<const double2*>(a.u0)[i] : double2{0.0, 0.0};
+#pragma unroll
+        for (int mo = 0; mo < M; ++mo) {
+            if (mo < a.nout) {
+                double2 acc = double2{0.0, 0.0};
+#pragma unroll
+                for (int j = 0; j < M; ++j) {
+                    if (NCOMP == 2) {
+                        // same grouping as imex_1st_order.py:52: Q * (impl + expl) when both weights agree
+                        acc.x += a.cI[mo][j] * fi[j].x + a.cE[mo][j] * fe[j].x;
+                        acc.y += a.cI[mo][j] * fi[j].y + a.cE[mo][j] * fe[j].y;
+                    } else {
+                        acc.x += a.cI[mo][j] * fi[j].x;
+                        acc.y += a.cI[mo][j] * fi[j].y;
+                    }
+                }
+                acc.x += u0.x;
+                acc.y += u0.y;
+                if (a.tau) {
+                    double2 t = reinterpret_cast<const double2*>(a.tau + (size_t)(a.tau_row0 + mo) * a.N)[i];
+                    acc.x += t.x;
+                    acc.y += t.y;
+                }
+                if (MODE == 0) {
+                    reinterpret_cast<double2*>(a.out[mo])[i] = acc;
+                } else {
+                    double2 us = reinterpret_cast<const double2*>(a.Usub + (size_t)(mo + 1) * a.N)[i];
+                    double r0 = fabs(acc.x - us.x), r1 = fabs(acc.y - us.y);
+                    double r = (r0 > r1 || r0 != r0) ? r0 : r1;
+                    nmax[mo] = (nmax[mo] > r || nmax[mo] != nmax[mo]) ? nmax[mo] : r;
+                }
+            }
+        }
+    }
+    if (MODE == 1) {
+#pragma unroll
+        for (int mo = 0; mo < M; ++mo) {
+            double v = wave_max(nmax[mo]);
+            if ((threadIdx.x & 63) == 0 && mo < a.nout) atomic_max_abs(a.norms + mo, v);
+        }
+    }
+}
+
+struct LinArgs {
+    double* out;
+    const double* base;  // may alias out
+    const double* x[2 * MAXM];
+    double c[2 * MAXM];
+    int nterms;
+    size_t n;
+};
+
+// out = base + sum_k c[k] * x[k]   (right-hand side of one node: generic_implicit.py:87-89 / imex_1st_order.py:92-94)
+__global__ __launch_bounds__(256) void k_lincomb(LinArgs a) {
+    const size_t n2 = a.n >> 1;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x * blockDim.x) {
+        double2 acc = reinterpret_cast<const double2*>(a.base)[i];
+        for (int k = 0; k < a.nterms; ++k) {
+            const double2 v = reinterpret_cast<const double2*>(a.x[k])[i];
+            acc.x += a.c[k] * v.x;
+            acc.y += a.c[k] * v.y;
+        }
+        reinterpret_cast<double2*>(a.out)[i] = acc;
+    }
+}
+
+// odd (Dirichlet-zero) extension of a 1-D field stored as [0, u_0..u_{n-1}, 0, -u_{n-1}..-u_0] (length 2(n+1)):
+// rebuild the zero end points and the mirrored half from the interior
+__global__ void k_odd_mirror(double* __restrict__ f, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) f[2 * n + 1 - i] = -f[1 + i];
+    if (i == 0) {
+        f[0] = 0.0;
+        f[n + 1] = 0.0;
+    }
+}
+
+__global__ void k_amax(const double* __restrict__ x, size_t n, unsigned long long* slot) {
+    double m = 0.0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        double v = fabs(x[i]);
+        m = (m > v || m != m) ? m : v;
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomic_max_abs(slot, m);
+}
+
+__global__ void k_axpby(size_t n, double a, const double* __restrict__ x, double b, const double* __restrict__ y,
+                        double* __restrict__ z) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        double v = 0.0;
+        if (x) v = a * x[i];
+        if (y) v += b * y[i];
+        z[i] = v;
+    }
+}
+
+__global__ void k_fill(size_t n, double a, double* __restrict__ y) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = a;
+}
+
+struct SpreadArgs {
+    const double* u0;       // U[0]
+    const double* f0;       // F[0] base (ncomp fields)
+    const double* profile;  // forcing profile or null
+    double* U;              // slab
+    double* F;              // slab
+    double g[MAXM + 1];     // forcing scalars at t and the node times
+    size_t N;
+    int M, ncomp, guess, forcing;
+    double fill_u, fill_f;
+    unsigned long long* f0max;  // max |F[0]| (implicit + explicit) for the residual of the spread state, or null
+};
+
+// predictor fill of the node values; core/sweeper.py:140-158
+__global__ __launch_bounds__(256) void k_spread(SpreadArgs a) {
+    const size_t n2 = a.N >> 1;
+    double fmaxv = 0.0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x * blockDim.x) {
+        double2 u = reinterpret_cast<const double2*>(a.u0)[i];
+        double2 fi = reinterpret_cast<const double2*>(a.f0)[i];
+        double2 fe = double2{0.0, 0.0}, pr = double2{0.0, 0.0};
+        if (a.ncomp == 2) fe = reinterpret_cast<const double2*>(a.f0 + a.N)[i];
+        if (a.f0max) {
+            const double s0 = fabs(fi.x + fe.x), s1 = fabs(fi.y + fe.y);
+            const double sm = (s0 > s1 || s0 != s0) ? s0 : s1;
+            fmaxv = (fmaxv > sm || fmaxv != fmaxv) ? fmaxv : sm;
+        }
+        if (a.forcing) pr = reinterpret_cast<const double2*>(a.profile)[i];
+        for (int m = 1; m <= a.M; ++m) {
+            double2 um = u, fim = fi, fem = fe;
+            if (a.guess == SDC_GUESS_SPREAD) {
+                if (a.forcing) fem = double2{pr.x * a.g[m], pr.y * a.g[m]};
+            } else if (a.guess == SDC_GUESS_ZERO) {
+                um = fim = fem = double2{0.0, 0.0};
+            } else if (a.guess == SDC_GUESS_CONST) {
+                um = double2{a.fill_u, a.fill_u};
+                fim = fem = double2{a.fill_f, a.fill_f};
+            }
+            reinterpret_cast<double2*>(a.U + (size_t)m * a.N)[i] = um;
+            reinterpret_cast<double2*>(a.F + ((size_t)m * a.ncomp) * a.N)[i] = fim;
+            if (a.ncomp == 2) reinterpret_cast<double2*>(a.F + ((size_t)m * a.ncomp + 1) * a.N)[i] = fem;
+        }
+    }
+    if (a.f0max) {
+        fmaxv = wave_max(fmaxv);
+        if ((threadIdx.x & 63) == 0) atomic_max_abs(a.f0max, fmaxv);
+    }
+}
+

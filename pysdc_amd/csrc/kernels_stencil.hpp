@@ -1,0 +1,386 @@
+// libsdcmi kernels: finite-difference operators: generic stencil, 2.5-D 3-point kernel, fused eval_f + residual, reaction terms.
+#pragma once
+#include "context.hpp"
+
+// ------------------------------------------------------------------------------------------------------
+// periodic finite-difference operator (eval_f), any stencil width, 1-3 dimensions
+// ------------------------------------------------------------------------------------------------------
+struct StencilArgs {
+    const double* in[MAXM];
+    double* outI[MAXM];  // implicit-operator result or null
+    double* outE[MAXM];  // explicit-stencil result or null
+    const double* profile;  // forcing profile (outE = profile * g[f]) or null
+    double g[MAXM];
+    Stencil sI, sE;
+    int nf, ndim, n;
+    int useE;  // 0 none, 1 stencil, 2 forcing
+};
+
+__device__ inline int wrapi(int i, int n) { return i < 0 ? i + n : (i >= n ? i - n : i); }
+
+__global__ __launch_bounds__(256) void k_stencil(StencilArgs a) {
+    const int n = a.n;
+    const size_t N = a.ndim == 1 ? (size_t)n : (a.ndim == 2 ? (size_t)n * n : (size_t)n * n * n);
+    const size_t n2 = N >> 1;
+    const int f = blockIdx.y;
+    const double* __restrict__ u = a.in[f];
+    for (size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x; p < n2; p += (size_t)gridDim.x * blockDim.x) {
+        const size_t i0 = p * 2;
+        const int z = (int)(i0 % n);
+        const size_t rest = i0 / n;
+        const int y = a.ndim >= 2 ? (int)(rest % n) : 0;
+        const int x = a.ndim == 3 ? (int)(rest / n) : 0;
+        const size_t line = i0 - z;  // start of the contiguous line
+        for (int which = 0; which < 2; ++which) {
+            double* out = which == 0 ? a.outI[f] : a.outE[f];
+            if (!out) continue;
+            if (which == 1 && a.useE == 2) {
+                double2 pr = reinterpret_cast<const double2*>(a.profile)[p];
+                reinterpret_cast<double2*>(out)[p] = double2{pr.x * a.g[f], pr.y * a.g[f]};
+                continue;
+            }
+            const Stencil& s = which == 0 ? a.sI : a.sE;
+            double r0 = 0.0, r1 = 0.0;
+            // axis order follows the Kronecker sum of problem_helper.py:226-235: slowest axis first
+            if (a.ndim == 3) {
+                for (int k = 0; k < s.npts; ++k) {
+                    const size_t q = ((size_t)wrapi(x + s.off[k], n) * n + y) * n + z;
+                    double2 v = *reinterpret_cast<const double2*>(u + q);
+                    r0 += s.w[k] * v.x;
+                    r1 += s.w[k] * v.y;
+                }
+            }
+            if (a.ndim >= 2) {
+                for (int k = 0; k < s.npts; ++k) {
+                    const size_t q = ((size_t)x * n + wrapi(y + s.off[k], n)) * n + z;
+                    double2 v = *reinterpret_cast<const double2*>(u + q);
+                    r0 += s.w[k] * v.x;
+                    r1 += s.w[k] * v.y;
+                }
+            }
+            for (int k = 0; k < s.npts; ++k) {
+                r0 += s.w[k] * u[line + wrapi(z + s.off[k], n)];
+                r1 += s.w[k] * u[line + wrapi(z + 1 + s.off[k], n)];
+            }
+            reinterpret_cast<double2*>(out)[p] = double2{r0, r1};
+        }
+    }
+}
+
+// 3-D fast path for 3-point stencils (offsets -1, 0, 1 per axis): 2.5-D blocking.  A workgroup owns a
+// (TY x TZ) tile of the y-z plane and marches along x; the x neighbours stay in registers, the y/z neighbours
+// of the current plane come from a double-buffered LDS tile with halo, so every input word is read from
+// global memory once per tile (+ halo) instead of seven times.
+struct Stencil3Args {
+    const double* in[MAXM];
+    double* outI[MAXM];
+    double* outE[MAXM];
+    double wI[3], wE[3];  // weights for offsets -1, 0, +1
+    int n, xchunk, ntiles, nchunks;
+};
+
+// Workgroup b runs on XCD b % 8 (observed dispatch order; used for speed only): give every XCD a contiguous
+// range of the logical grid so that tiles sharing halo lines meet in the same L2.
+__device__ __forceinline__ unsigned xcd_swizzle(unsigned b, unsigned total) {
+    return (total & 7u) ? b : (b & 7u) * (total >> 3) + (b >> 3);
+}
+
+template <int RPT>
+__global__ __launch_bounds__(256, 4) void k_stencil3d(Stencil3Args a) {
+    constexpr int TZ = 64, TYB = 8, TY = TYB * RPT, LW = TZ + 4;  // LDS row: [halo | 64 | halo | pad]
+    __shared__ double tile[2][TY + 2][LW];
+    const int n = a.n;
+    const int tz = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int ntz = n / TZ;
+    // logical order: z-tile fastest, then y-tile (halo partners stay close), then x-chunk, then field
+    unsigned lb = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int zt = lb % ntz;
+    lb /= ntz;
+    const int nty = n / TY;
+    const int yt = lb % nty;
+    lb /= nty;
+    const int chunk = lb % a.nchunks;
+    const int f = lb / a.nchunks;
+    const int z0 = zt * TZ, y0 = yt * TY;
+    const int x0 = chunk * a.xchunk;
+    const double* __restrict__ u = a.in[f];
+    double* __restrict__ oI = a.outI[f];
+    double* __restrict__ oE = a.outE[f];
+    const size_t sx = (size_t)n * n;
+    // halo duty of this thread: 0..63 -> y halo rows (below / above), 64..64+2*TY-1 -> z halo columns
+    const int t = threadIdx.x;
+    const bool hy = t < 64, hz = t >= 64 && t < 64 + 2 * TY;
+    size_t hoff = 0;   // offset of the halo element(s) within a plane
+    int hrow = 0, hcol = 0;
+    if (hy) {
+        const int side = t >> 5, pz = t & 31;
+        const int yy = side == 0 ? (y0 == 0 ? n - 1 : y0 - 1) : (y0 + TY == n ? 0 : y0 + TY);
+        hoff = (size_t)yy * n + z0 + 2 * pz;
+        hrow = side == 0 ? 0 : TY + 1;
+        hcol = 1 + 2 * pz;
+    } else if (hz) {
+        const int q = t - 64, side = q / TY, r = q % TY;
+        const int zz = side == 0 ? (z0 == 0 ? n - 1 : z0 - 1) : (z0 + TZ == n ? 0 : z0 + TZ);
+        hoff = (size_t)(y0 + r) * n + zz;
+        hrow = r + 1;
+        hcol = side == 0 ? 0 : TZ + 1;
+    }
+    size_t off[RPT];
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) off[r] = (size_t)(y0 + ty + r * TYB) * n + z0 + 2 * tz;
+
+    auto plane = [&](int x) { return u + (size_t)(x < 0 ? x + n : (x >= n ? x - n : x)) * sx; };
+    double2 prev[RPT], cur[RPT], nxt[RPT], nx2[RPT];
+    double2 hcur = double2{0.0, 0.0}, hnxt = double2{0.0, 0.0}, hnx2 = double2{0.0, 0.0};
+    {
+        const double* pm = plane(x0 - 1);
+        const double* p0 = plane(x0);
+        const double* p1 = plane(x0 + 1);
+        const double* p2 = plane(x0 + 2);
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            prev[r] = *reinterpret_cast<const double2*>(pm + off[r]);
+            cur[r] = *reinterpret_cast<const double2*>(p0 + off[r]);
+            nxt[r] = *reinterpret_cast<const double2*>(p1 + off[r]);
+            nx2[r] = *reinterpret_cast<const double2*>(p2 + off[r]);
+        }
+        if (hy) {
+            hcur = *reinterpret_cast<const double2*>(p0 + hoff);
+            hnxt = *reinterpret_cast<const double2*>(p1 + hoff);
+            hnx2 = *reinterpret_cast<const double2*>(p2 + hoff);
+        } else if (hz) {
+            hcur.x = p0[hoff];
+            hnxt.x = p1[hoff];
+            hnx2.x = p2[hoff];
+        }
+    }
+    auto put = [&](int b, const double2 (&v)[RPT], double2 h) {
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            tile[b][ty + r * TYB + 1][1 + 2 * tz] = v[r].x;
+            tile[b][ty + r * TYB + 1][2 + 2 * tz] = v[r].y;
+        }
+        if (hy) {
+            tile[b][hrow][hcol] = h.x;
+            tile[b][hrow][hcol + 1] = h.y;
+        } else if (hz) {
+            tile[b][hrow][hcol] = h.x;
+        }
+    };
+    put(0, cur, hcur);
+    const double cI = 3.0 * a.wI[1], cE = 3.0 * a.wE[1];
+    for (int p = 0; p < a.xchunk; ++p) {
+        const int b = p & 1;
+        const int x = x0 + p;
+        __syncthreads();
+        // prefetch plane x+3 (interior + halo): two planes are always in flight behind the one in use
+        double2 nn[RPT];
+        double2 hnn = double2{0.0, 0.0};
+        const bool more = p + 1 < a.xchunk;
+        if (p + 2 < a.xchunk) {
+            const double* p3 = plane(x + 3);
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) nn[r] = *reinterpret_cast<const double2*>(p3 + off[r]);
+            if (hy) hnn = *reinterpret_cast<const double2*>(p3 + hoff);
+            else if (hz) hnn.x = p3[hoff];
+        }
+        const size_t po = (size_t)x * sx;
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            const int row = ty + r * TYB + 1, col = 1 + 2 * tz;
+            const double ym0 = tile[b][row - 1][col], ym1 = tile[b][row - 1][col + 1];
+            const double yp0 = tile[b][row + 1][col], yp1 = tile[b][row + 1][col + 1];
+            const double zm = tile[b][row][col - 1], zp = tile[b][row][col + 2];
+            const double c0 = cur[r].x, c1 = cur[r].y;
+            // same association as the row sums of the Kronecker-sum matrix: per axis (w-,w0,w+), axes added
+            double2 res;
+            res.x = (a.wI[0] * prev[r].x + a.wI[2] * nxt[r].x) + (a.wI[0] * ym0 + a.wI[2] * yp0) +
+                    (a.wI[0] * zm + a.wI[2] * c1) + cI * c0;
+            res.y = (a.wI[0] * prev[r].y + a.wI[2] * nxt[r].y) + (a.wI[0] * ym1 + a.wI[2] * yp1) +
+                    (a.wI[0] * c0 + a.wI[2] * zp) + cI * c1;
+            if (oI) *reinterpret_cast<double2*>(oI + po + off[r]) = res;
+            if (oE) {
+                double2 re;
+                re.x = (a.wE[0] * prev[r].x + a.wE[2] * nxt[r].x) + (a.wE[0] * ym0 + a.wE[2] * yp0) +
+                       (a.wE[0] * zm + a.wE[2] * c1) + cE * c0;
+                re.y = (a.wE[0] * prev[r].y + a.wE[2] * nxt[r].y) + (a.wE[0] * ym1 + a.wE[2] * yp1) +
+                       (a.wE[0] * c0 + a.wE[2] * zp) + cE * c1;
+                *reinterpret_cast<double2*>(oE + po + off[r]) = re;
+            }
+        }
+        if (more) {
+            put(b ^ 1, nxt, hnxt);
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                prev[r] = cur[r];
+                cur[r] = nxt[r];
+                nxt[r] = nx2[r];
+                nx2[r] = nn[r];
+            }
+            hnxt = hnx2;
+            hnx2 = hnn;
+        }
+    }
+}
+
+// eval_f for ALL nodes fused with the collocation residual: a workgroup marches the (y,z) tile through x for
+// the M fields U[1..M] at once, so at every point all f_j = A u_j are in registers when the residual
+// u0 + dt sum_j Q[m][j] f_j - u_m (core/sweeper.py:186-199) is formed.  Replaces stencil (10 field passes) +
+// residual (11) by one kernel with 6 reads + 5 writes.
+struct StencilResArgs {
+    const double* U;  // slab: U[0] = u0, U[1..M]
+    double* F;        // slab (ncomp == 1)
+    double wI[3];
+    double cQ[MAXM][MAXM];  // dt * Q[m+1][j+1]
+    unsigned long long* norms;
+    int n, xchunk, nchunks;
+    size_t N;
+};
+
+template <int M>
+__global__ __launch_bounds__(256, 3) void k_stencil3d_res(StencilResArgs a) {
+    // LDS: 2 buffers x M fields x (8+2) rows x 66 doubles = 52.8 KB at M = 5 -> three workgroups per CU
+    constexpr int TZ = 64, TY = 8, LW = TZ + 2;
+    __shared__ double tile[2][M][TY + 2][LW];
+    const int n = a.n;
+    const int tz = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int ntz = n / TZ, nty = n / TY;
+    unsigned lb = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int zt = lb % ntz;
+    lb /= ntz;
+    const int yt = lb % nty;
+    const int chunk = lb / nty;
+    const int z0 = zt * TZ, y0 = yt * TY, x0 = chunk * a.xchunk;
+    const size_t sx = (size_t)n * n;
+    const int t = threadIdx.x;
+    const bool hy = t < 64, hz = t >= 64 && t < 64 + 2 * TY;
+    size_t hoff = 0;
+    int hrow = 0, hcol = 0;
+    if (hy) {
+        const int side = t >> 5, pz = t & 31;
+        const int yy = side == 0 ? (y0 == 0 ? n - 1 : y0 - 1) : (y0 + TY == n ? 0 : y0 + TY);
+        hoff = (size_t)yy * n + z0 + 2 * pz;
+        hrow = side == 0 ? 0 : TY + 1;
+        hcol = 1 + 2 * pz;
+    } else if (hz) {
+        const int q = t - 64, side = q / TY, r = q % TY;
+        const int zz = side == 0 ? (z0 == 0 ? n - 1 : z0 - 1) : (z0 + TZ == n ? 0 : z0 + TZ);
+        hoff = (size_t)(y0 + r) * n + zz;
+        hrow = r + 1;
+        hcol = side == 0 ? 0 : TZ + 1;
+    }
+    const size_t off = (size_t)(y0 + ty) * n + z0 + 2 * tz;
+    auto wrapx = [&](int x) { return (size_t)(x < 0 ? x + n : (x >= n ? x - n : x)) * sx; };
+    auto halo_load = [&](const double* plane) {
+        double2 h = double2{0.0, 0.0};
+        if (hy) h = *reinterpret_cast<const double2*>(plane + hoff);
+        else if (hz) h.x = plane[hoff];
+        return h;
+    };
+    auto put = [&](int b, int j, double2 v, double2 h) {
+        tile[b][j][ty + 1][1 + 2 * tz] = v.x;
+        tile[b][j][ty + 1][2 + 2 * tz] = v.y;
+        if (hy) {
+            tile[b][j][hrow][hcol] = h.x;
+            tile[b][j][hrow][hcol + 1] = h.y;
+        } else if (hz) {
+            tile[b][j][hrow][hcol] = h.x;
+        }
+    };
+    double2 prev[M], cur[M], nxt[M];
+    double2 u0c, u0n = double2{0.0, 0.0};
+    double nmax[M];
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+        const double* uj = a.U + (size_t)(j + 1) * a.N;
+        prev[j] = *reinterpret_cast<const double2*>(uj + wrapx(x0 - 1) + off);
+        cur[j] = *reinterpret_cast<const double2*>(uj + wrapx(x0) + off);
+        nxt[j] = *reinterpret_cast<const double2*>(uj + wrapx(x0 + 1) + off);
+        put(0, j, cur[j], halo_load(uj + wrapx(x0)));
+        nmax[j] = 0.0;
+    }
+    u0c = *reinterpret_cast<const double2*>(a.U + wrapx(x0) + off);
+    const double cI = 3.0 * a.wI[1];
+    for (int p = 0; p < a.xchunk; ++p) {
+        const int b = p & 1;
+        const int x = x0 + p;
+        __syncthreads();
+        const bool more = p + 1 < a.xchunk;
+        // in flight while this plane is computed: the interior of plane x+2 and the halo of plane x+1
+        double2 nn[M], hn[M];
+        if (more) {
+            const size_t px1 = wrapx(x + 1), px2 = wrapx(x + 2);
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                const double* uj = a.U + (size_t)(j + 1) * a.N;
+                nn[j] = *reinterpret_cast<const double2*>(uj + px2 + off);
+                hn[j] = halo_load(uj + px1);
+            }
+            u0n = *reinterpret_cast<const double2*>(a.U + px1 + off);
+        }
+        const size_t po = (size_t)x * sx + off;
+        double2 fv[M];
+        const int row = ty + 1, col = 1 + 2 * tz;
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            const double ym0 = tile[b][j][row - 1][col], ym1 = tile[b][j][row - 1][col + 1];
+            const double yp0 = tile[b][j][row + 1][col], yp1 = tile[b][j][row + 1][col + 1];
+            const double zm = tile[b][j][row][col - 1], zp = tile[b][j][row][col + 2];
+            const double c0 = cur[j].x, c1 = cur[j].y;
+            fv[j].x = (a.wI[0] * prev[j].x + a.wI[2] * nxt[j].x) + (a.wI[0] * ym0 + a.wI[2] * yp0) +
+                      (a.wI[0] * zm + a.wI[2] * c1) + cI * c0;
+            fv[j].y = (a.wI[0] * prev[j].y + a.wI[2] * nxt[j].y) + (a.wI[0] * ym1 + a.wI[2] * yp1) +
+                      (a.wI[0] * c0 + a.wI[2] * zp) + cI * c1;
+            *reinterpret_cast<double2*>(a.F + (size_t)(j + 1) * a.N + po) = fv[j];
+        }
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            double r0 = 0.0, r1 = 0.0;
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                r0 += a.cQ[m][j] * fv[j].x;
+                r1 += a.cQ[m][j] * fv[j].y;
+            }
+            r0 = fabs((r0 + u0c.x) - cur[m].x);
+            r1 = fabs((r1 + u0c.y) - cur[m].y);
+            const double r = (r0 > r1 || r0 != r0) ? r0 : r1;
+            nmax[m] = (nmax[m] > r || nmax[m] != nmax[m]) ? nmax[m] : r;
+        }
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                put(b ^ 1, j, nxt[j], hn[j]);
+                prev[j] = cur[j];
+                cur[j] = nxt[j];
+                nxt[j] = nn[j];
+            }
+            u0c = u0n;
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        const double v = wave_max(nmax[m]);
+        if ((threadIdx.x & 63) == 0) atomic_max_abs(a.norms + m, v);
+    }
+}
+
+// pointwise explicit (reaction) terms of the Allen-Cahn problems
+//   kind 1: c * u * (1 - u^nu),  c = 1/eps^2          (AllenCahn_2D_FFT.py:140-141)
+//   kind 2: -2/eps^2 u (1-u)(1-2u) - 6 dw u (1-u)     (AllenCahn_MPIFFT.py:83-85)
+__global__ void k_reaction(const double* __restrict__ u, double* __restrict__ out, size_t n, int kind, double p0,
+                           double p1, int nu) {
+#pragma clang fp contract(off)
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const double v = u[i];
+        double r;
+        if (kind == 1) {
+            double pw = 1.0;
+            for (int q = 0; q < nu; ++q) pw *= v;
+            r = p0 * v * (1.0 - pw);
+        } else {
+            r = p0 * v * (1.0 - v) * (1.0 - 2.0 * v) - p1 * v * (1.0 - v);
+        }
+        out[i] = r;
+    }
+}
+

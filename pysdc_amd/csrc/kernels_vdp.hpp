@@ -1,0 +1,150 @@
+// libsdcmi kernels: van der Pol ensemble.
+#pragma once
+#include "context.hpp"
+
+// ------------------------------------------------------------------------------------------------------
+// van der Pol ensemble: one trajectory per lane (SoA state [2][T])
+// ------------------------------------------------------------------------------------------------------
+struct VdpSweepArgs {
+    double* U;   // slab [(M+1)][2][T]
+    double* F;
+    const double* tau;  // or null
+    size_t T;
+    double mu, dt, tol;
+    int maxiter;
+    double Q[MAXM][MAXM], QI[MAXM][MAXM];
+    unsigned long long* counters;
+};
+
+// Newton for u - h f(u) = r with the closed-form 2x2 inverse (Van_der_Pol_implicit.py:131-201)
+__device__ __forceinline__ bool vdp_newton(double& x1, double& x2, double r0, double r1, double h, double mu, double tol,
+                                           int maxiter, unsigned long long& newton) {
+#pragma clang fp contract(off)
+    int it = 0;
+    double res = 99.0;
+    while (it < maxiter) {
+        const double e0 = x1 - h * x2 - r0;
+        const double e1 = x2 - h * (mu * (1 - x1 * x1) * x2 - x1) - r1;
+        res = fmax(fabs(e0), fabs(e1));
+        if (e0 != e0 || e1 != e1) res = e0 + e1;  // NaN
+        if (res < tol || res != res) break;
+        const double c = 1.0 / (-2 * h * h * mu * x1 * x2 - h * h - 1 + h * mu * (1 - x1 * x1));
+        const double d00 = c * (h * mu * (1 - x1 * x1) - 1), d01 = c * (-h);
+        const double d10 = c * (2 * h * mu * x1 * x2 + h), d11 = c * (-1.0);
+        const double nx1 = x1 - (d00 * e0 + d01 * e1);
+        const double nx2 = x2 - (d10 * e0 + d11 * e1);
+        x1 = nx1;
+        x2 = nx2;
+        ++it;
+        ++newton;
+    }
+    return !(res != res || it == maxiter);
+}
+
+// one generic_implicit sweep (generic_implicit.py:51-103) for every trajectory, node values on the slabs
+template <int M>
+__global__ __launch_bounds__(256) void k_vdp_sweep(VdpSweepArgs a) {
+#pragma clang fp contract(off)
+    unsigned long long newton = 0, rhs = 0, failed = 0;
+    const size_t T = a.T, N = 2 * a.T;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < T; i += (size_t)gridDim.x * blockDim.x) {
+        const double mu = a.mu, dt = a.dt;
+        const double u00 = a.U[i], u01 = a.U[T + i];
+        double f0[M], f1[M], g0[M], g1[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            f0[m] = a.F[(size_t)(m + 1) * N + i];
+            f1[m] = a.F[(size_t)(m + 1) * N + T + i];
+        }
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                s0 += dt * a.Q[m][j] * f0[j];
+                s1 += dt * a.Q[m][j] * f1[j];
+            }
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                s0 -= dt * a.QI[m][j] * f0[j];
+                s1 -= dt * a.QI[m][j] * f1[j];
+            }
+            g0[m] = s0 + u00;
+            g1[m] = s1 + u01;
+            if (a.tau) {
+                g0[m] += a.tau[(size_t)m * N + i];
+                g1[m] += a.tau[(size_t)m * N + T + i];
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            double r0 = g0[m], r1 = g1[m];
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                if (j < m) {
+                    r0 += dt * a.QI[m][j] * f0[j];
+                    r1 += dt * a.QI[m][j] * f1[j];
+                }
+            }
+            const double h = dt * a.QI[m][m];
+            double x1 = a.U[(size_t)(m + 1) * N + i], x2 = a.U[(size_t)(m + 1) * N + T + i];
+            if (h == 0.0) {
+                x1 = r0;
+                x2 = r1;
+            } else if (!vdp_newton(x1, x2, r0, r1, h, mu, a.tol, a.maxiter, newton)) {
+                failed += 1;
+            }
+            a.U[(size_t)(m + 1) * N + i] = x1;
+            a.U[(size_t)(m + 1) * N + T + i] = x2;
+            f0[m] = x2;
+            f1[m] = mu * (1 - x1 * x1) * x2 - x1;
+            a.F[(size_t)(m + 1) * N + i] = f0[m];
+            a.F[(size_t)(m + 1) * N + T + i] = f1[m];
+            rhs += 1;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        newton += __shfl_xor(newton, o, 64);
+        rhs += __shfl_xor(rhs, o, 64);
+        failed += __shfl_xor(failed, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(a.counters + 0, newton);
+        atomicAdd(a.counters + 1, rhs);
+        atomicAdd(a.counters + 2, failed);
+    }
+}
+
+__global__ void k_vdp_eval(const double* __restrict__ u, double* __restrict__ f, size_t T, double mu,
+                           unsigned long long* counters) {
+#pragma clang fp contract(off)
+    unsigned long long rhs = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < T; i += (size_t)gridDim.x * blockDim.x) {
+        const double x1 = u[i], x2 = u[T + i];
+        f[i] = x2;
+        f[T + i] = mu * (1 - x1 * x1) * x2 - x1;
+        rhs += 1;
+    }
+    for (int o = 32; o > 0; o >>= 1) rhs += __shfl_xor(rhs, o, 64);
+    if ((threadIdx.x & 63) == 0 && rhs) atomicAdd(counters + 1, rhs);
+}
+
+__global__ void k_vdp_solve(const double* __restrict__ rhsv, const double* __restrict__ guess, double* __restrict__ out,
+                            size_t T, double h, double mu, double tol, int maxiter, unsigned long long* counters) {
+    unsigned long long newton = 0, failed = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < T; i += (size_t)gridDim.x * blockDim.x) {
+        double x1 = guess[i], x2 = guess[T + i];
+        if (!vdp_newton(x1, x2, rhsv[i], rhsv[T + i], h, mu, tol, maxiter, newton)) failed += 1;
+        out[i] = x1;
+        out[T + i] = x2;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        newton += __shfl_xor(newton, o, 64);
+        failed += __shfl_xor(failed, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(counters + 0, newton);
+        atomicAdd(counters + 2, failed);
+    }
+}
+

@@ -9,1256 +9,12 @@
 //   c2c FFT along the contiguous axis + node-coupled solve + inverse, all M nodes of one line per workgroup
 //   inverse axis 1, inverse axis 0 (c2r)                     -> U[1..M]
 //   stencil A*U[m] (+ explicit stencil)                      -> F[1..M]
-#include <hip/hip_runtime.h>
-
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstring>
-#include <map>
-#include <string>
-#include <vector>
-
-#include "../../include/sdcmi.h"
-#include "fft.hpp"
-
-#define MAXM 8
-#define MAXSTEN 12
-
-// ------------------------------------------------------------------------------------------------------
-// context
-// ------------------------------------------------------------------------------------------------------
-struct Stencil {
-    int npts = 0;
-    int off[MAXSTEN];
-    double w[MAXSTEN];
-};
-
-struct ProfEntry {
-    double ms = 0;
-    int calls = 0;
-};
-
-struct sdc_ctx {
-    int device = 0, ndim = 0, n = 0, M = 0, ncomp = 1;
-    size_t N = 0;       // n^ndim
-    size_t Nc = 0;      // complex entries of one spectrum field
-    hipStream_t stream = nullptr;
-    double *U = nullptr, *F = nullptr, *TAU = nullptr, *UEND = nullptr, *profile = nullptr;
-    cd* W = nullptr;
-    cd *S = nullptr, *S0 = nullptr;  // spectral cache: transforms of U[1..M] and of U[0] (lazy)
-    bool spec_valid = false, spec0_valid = false, spec_spread = false, reuse = true, force_gather = false;
-    cd *tw = nullptr, *lamI = nullptr, *lamE = nullptr;
-    unsigned long long* red = nullptr;  // reduction slots (device)
-    unsigned long long* red_host = nullptr;
-    bool tau_active = false, have_coeffs = false, have_stencil[2] = {false, false}, unlocked = false;
-    int expl_kind = SDC_EXPL_NONE;
-    bool res_spread = false;  // state = spread predictor of an autonomous f: residual_m = dt |sum_j Q[m][j]| max|f(u0)|
-    bool fuse_residual = true;
-    bool res_valid = false;   // node norms of the residual were produced by the fused stencil kernel
-    double res_dt = 0.0;
-    unsigned long long* res_dev = nullptr;  // device slots of those norms
-    bool spectral_op = false;  // implicit operator given by its Fourier symbol only (no stencil): eval_f by FFT
-    int react_kind = 0, react_nu = 2;
-    double react_p0 = 0, react_p1 = 0;
-    int kind = 0;  // 0: periodic finite differences, 1: van der Pol ensemble (N = 2 * ntraj, SoA)
-    double vdp_mu = 0, vdp_tol = 1e-9;
-    int vdp_maxiter = 100;
-    unsigned long long* counters = nullptr;  // device: [0] newton, [1] rhs, [2] failed solves
-    unsigned long long rhs_host = 0;         // evaluations the reference would have made where the engine copies
-    double Q[MAXM + 1][MAXM + 1], QI[MAXM + 1][MAXM + 1], QE[MAXM + 1][MAXM + 1], nodes[MAXM], weights[MAXM];
-    double gvals[MAXM + 1];
-    Stencil st[2];
-    size_t bytes = 0;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, pev0 = nullptr, pev1 = nullptr;
-    bool profiling = false;
-    std::vector<hipEvent_t> pool;            // event pairs recorded around launches while profiling
-    std::vector<const char*> pool_names;
-    size_t pool_used = 0;                    // pairs in flight
-    std::map<std::string, ProfEntry> prof;
-    std::vector<std::string> prof_names;
-    std::string err;
-};
-
-static thread_local std::string g_create_err;
-
-static int fail(sdc_ctx* c, int code, const char* fmt, ...) {
-    char buf[512];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof buf, fmt, ap);
-    va_end(ap);
-    if (c) c->err = buf;
-    else g_create_err = buf;
-    return code;
-}
-
-#define HIPCHK(c, call)                                                                              \
-    do {                                                                                             \
-        hipError_t e_ = (call);                                                                      \
-        if (e_ != hipSuccess)                                                                        \
-            return fail(c, e_ == hipErrorOutOfMemory ? SDC_ERR_NOMEM : SDC_ERR_HIP, "%s: %s", #call, \
-                        hipGetErrorString(e_));                                                      \
-    } while (0)
-
-// Per-kernel device time: a pair of events from a pool is recorded around every launch on the context's
-// stream; nothing synchronises until the pool is full or the profile is read, so the timed region of bench.py
-// is not perturbed.
-static void prof_flush(sdc_ctx* c) {
-    if (c->pool_used == 0) return;
-    (void)hipEventSynchronize(c->pool[2 * c->pool_used - 1]);
-    for (size_t i = 0; i < c->pool_used; ++i) {
-        float ms = 0;
-        if (hipEventElapsedTime(&ms, c->pool[2 * i], c->pool[2 * i + 1]) == hipSuccess) {
-            ProfEntry& e = c->prof[c->pool_names[i]];
-            e.ms += ms;
-            e.calls += 1;
-        }
-    }
-    c->pool_used = 0;
-}
-
-struct LaunchTimer {
-    sdc_ctx* c;
-    size_t slot = 0;
-    bool on;
-    LaunchTimer(sdc_ctx* c_, const char* n) : c(c_), on(c_->profiling) {
-        if (!on) return;
-        constexpr size_t kPairs = 2048;
-        if (c->pool.empty()) {
-            c->pool.resize(2 * kPairs);
-            c->pool_names.resize(kPairs);
-            for (auto& e : c->pool) (void)hipEventCreate(&e);
-        }
-        if (c->pool_used == kPairs) prof_flush(c);
-        slot = c->pool_used++;
-        c->pool_names[slot] = n;
-        (void)hipEventRecord(c->pool[2 * slot], c->stream);
-    }
-    ~LaunchTimer() {
-        if (on) (void)hipEventRecord(c->pool[2 * slot + 1], c->stream);
-    }
-};
-
-static inline int is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
-
-// profile names that carry the number of fields of the launch, e.g. "fft_x_fwd[5]" (interned, static lifetime)
-static const char* pname(const char* base, int nf) {
-    static std::map<std::string, std::string> table;
-    std::string key = std::string(base) + "[" + std::to_string(nf) + "]";
-    auto it = table.find(key);
-    if (it == table.end()) it = table.emplace(key, key).first;
-    return it->second.c_str();
-}
-
-// 1/(1 - alpha*lambda): |denominator|^2 is finite and away from zero for the dissipative / skew operators
-// handled here, so the reciprocal is v_rcp_f64 refined by two Newton steps (~1 ulp) instead of the IEEE
-// division sequence (v_div_scale / v_div_fmas / v_div_fixup).
-__device__ __forceinline__ double fast_rcp(double x) {
-    double r = __builtin_amdgcn_rcp(x);
-    r = fma(fma(-x, r, 1.0), r, r);
-    r = fma(fma(-x, r, 1.0), r, r);
-    return r;
-}
-__device__ __forceinline__ cd cinv_fast(cd d) {
-    const double m = fast_rcp(d.x * d.x + d.y * d.y);
-    return cd{d.x * m, -d.y * m};
-}
-
-// ------------------------------------------------------------------------------------------------------
-// elementwise kernels
-// ------------------------------------------------------------------------------------------------------
-struct QuadArgs {
-    const double* u0;    // may be null
-    const double* F;     // F slab base; field (j, comp) at F + (j*ncomp + comp)*N
-    const double* tau;   // TAU base or null
-    const double* Usub;  // U slab base for the residual (subtract U[mo+1]) or null
-    double* out[MAXM];   // MODE 0 outputs
-    double cI[MAXM][MAXM];  // [mo][j-1]
-    double cE[MAXM][MAXM];
-    unsigned long long* norms;  // MODE 1: per-node max |.| as ordered bit patterns
-    size_t N;
-    int nout;  // number of output rows (M, or 1 for the end point)
-    int tau_row0;  // tau row used for output 0 (end point uses the last row)
-};
-
-__device__ inline void atomic_max_abs(unsigned long long* slot, double v) {
-    // |v| >= 0: IEEE order == unsigned order of the bit pattern; NaN (0x7ff8...) wins, like np.max
-    atomicMax(slot, (unsigned long long)__double_as_longlong(fabs(v)));
-}
-
-__device__ inline double wave_max(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        double w = __shfl_xor(v, o, 64);
-        v = (v > w || v != v) ? v : w;  // propagate NaN
-    }
-    return v;
-}
-
-// out[mo] = u0 + sum_j cI[mo][j] F_impl[j] (+ cE[mo][j] F_expl[j]) (+ tau[mo]) (- U[mo+1], max-norm)
-template <int M, int NCOMP, int MODE>
-__global__ __launch_bounds__(256) void k_quad(QuadArgs a) {
-    const size_t n2 = a.N >> 1;
-    double nmax[M];
-#pragma unroll
-    for (int m = 0; m < M; ++m) nmax[m] = 0.0;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x * blockDim.x) {
-        double2 fi[M], fe[M];
-#pragma unroll
-        for (int j = 0; j < M; ++j) {
-            fi[j] = reinterpret_cast<const double2*>(a.F + ((size_t)(j + 1) * NCOMP) * a.N)[i];
-            if (NCOMP == 2) fe[j] = reinterpret_cast<const double2*>(a.F + ((size_t)(j + 1) * NCOMP + 1) * a.N)[i];
-        }
-        double2 u0 = a.u0 ? reinterpret_cast<const double2*>(a.u0)[i] : double2{0.0, 0.0};
-#pragma unroll
-        for (int mo = 0; mo < M; ++mo) {
-            if (mo < a.nout) {
-                double2 acc = double2{0.0, 0.0};
-#pragma unroll
-                for (int j = 0; j < M; ++j) {
-                    if (NCOMP == 2) {
-                        // same grouping as imex_1st_order.py:52: Q * (impl + expl) when both weights agree
-                        acc.x += a.cI[mo][j] * fi[j].x + a.cE[mo][j] * fe[j].x;
-                        acc.y += a.cI[mo][j] * fi[j].y + a.cE[mo][j] * fe[j].y;
-                    } else {
-                        acc.x += a.cI[mo][j] * fi[j].x;
-                        acc.y += a.cI[mo][j] * fi[j].y;
-                    }
-                }
-                acc.x += u0.x;
-                acc.y += u0.y;
-                if (a.tau) {
-                    double2 t = reinterpret_cast<const double2*>(a.tau + (size_t)(a.tau_row0 + mo) * a.N)[i];
-                    acc.x += t.x;
-                    acc.y += t.y;
-                }
-                if (MODE == 0) {
-                    reinterpret_cast<double2*>(a.out[mo])[i] = acc;
-                } else {
-                    double2 us = reinterpret_cast<const double2*>(a.Usub + (size_t)(mo + 1) * a.N)[i];
-                    double r0 = fabs(acc.x - us.x), r1 = fabs(acc.y - us.y);
-                    double r = (r0 > r1 || r0 != r0) ? r0 : r1;
-                    nmax[mo] = (nmax[mo] > r || nmax[mo] != nmax[mo]) ? nmax[mo] : r;
-                }
-            }
-        }
-    }
-    if (MODE == 1) {
-#pragma unroll
-        for (int mo = 0; mo < M; ++mo) {
-            double v = wave_max(nmax[mo]);
-            if ((threadIdx.x & 63) == 0 && mo < a.nout) atomic_max_abs(a.norms + mo, v);
-        }
-    }
-}
-
-struct LinArgs {
-    double* out;
-    const double* base;  // may alias out
-    const double* x[2 * MAXM];
-    double c[2 * MAXM];
-    int nterms;
-    size_t n;
-};
-
-// out = base + sum_k c[k] * x[k]   (right-hand side of one node: generic_implicit.py:87-89 / imex_1st_order.py:92-94)
-__global__ __launch_bounds__(256) void k_lincomb(LinArgs a) {
-    const size_t n2 = a.n >> 1;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x * blockDim.x) {
-        double2 acc = reinterpret_cast<const double2*>(a.base)[i];
-        for (int k = 0; k < a.nterms; ++k) {
-            const double2 v = reinterpret_cast<const double2*>(a.x[k])[i];
-            acc.x += a.c[k] * v.x;
-            acc.y += a.c[k] * v.y;
-        }
-        reinterpret_cast<double2*>(a.out)[i] = acc;
-    }
-}
-
-// odd (Dirichlet-zero) extension of a 1-D field stored as [0, u_0..u_{n-1}, 0, -u_{n-1}..-u_0] (length 2(n+1)):
-// rebuild the zero end points and the mirrored half from the interior
-__global__ void k_odd_mirror(double* __restrict__ f, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) f[2 * n + 1 - i] = -f[1 + i];
-    if (i == 0) {
-        f[0] = 0.0;
-        f[n + 1] = 0.0;
-    }
-}
-
-__global__ void k_amax(const double* __restrict__ x, size_t n, unsigned long long* slot) {
-    double m = 0.0;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        double v = fabs(x[i]);
-        m = (m > v || m != m) ? m : v;
-    }
-    m = wave_max(m);
-    if ((threadIdx.x & 63) == 0) atomic_max_abs(slot, m);
-}
-
-__global__ void k_axpby(size_t n, double a, const double* __restrict__ x, double b, const double* __restrict__ y,
-                        double* __restrict__ z) {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        double v = 0.0;
-        if (x) v = a * x[i];
-        if (y) v += b * y[i];
-        z[i] = v;
-    }
-}
-
-__global__ void k_fill(size_t n, double a, double* __restrict__ y) {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = a;
-}
-
-struct SpreadArgs {
-    const double* u0;       // U[0]
-    const double* f0;       // F[0] base (ncomp fields)
-    const double* profile;  // forcing profile or null
-    double* U;              // slab
-    double* F;              // slab
-    double g[MAXM + 1];     // forcing scalars at t and the node times
-    size_t N;
-    int M, ncomp, guess, forcing;
-    double fill_u, fill_f;
-    unsigned long long* f0max;  // max |F[0]| (implicit + explicit) for the residual of the spread state, or null
-};
-
-// predictor fill of the node values; core/sweeper.py:140-158
-__global__ __launch_bounds__(256) void k_spread(SpreadArgs a) {
-    const size_t n2 = a.N >> 1;
-    double fmaxv = 0.0;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x * blockDim.x) {
-        double2 u = reinterpret_cast<const double2*>(a.u0)[i];
-        double2 fi = reinterpret_cast<const double2*>(a.f0)[i];
-        double2 fe = double2{0.0, 0.0}, pr = double2{0.0, 0.0};
-        if (a.ncomp == 2) fe = reinterpret_cast<const double2*>(a.f0 + a.N)[i];
-        if (a.f0max) {
-            const double s0 = fabs(fi.x + fe.x), s1 = fabs(fi.y + fe.y);
-            const double sm = (s0 > s1 || s0 != s0) ? s0 : s1;
-            fmaxv = (fmaxv > sm || fmaxv != fmaxv) ? fmaxv : sm;
-        }
-        if (a.forcing) pr = reinterpret_cast<const double2*>(a.profile)[i];
-        for (int m = 1; m <= a.M; ++m) {
-            double2 um = u, fim = fi, fem = fe;
-            if (a.guess == SDC_GUESS_SPREAD) {
-                if (a.forcing) fem = double2{pr.x * a.g[m], pr.y * a.g[m]};
-            } else if (a.guess == SDC_GUESS_ZERO) {
-                um = fim = fem = double2{0.0, 0.0};
-            } else if (a.guess == SDC_GUESS_CONST) {
-                um = double2{a.fill_u, a.fill_u};
-                fim = fem = double2{a.fill_f, a.fill_f};
-            }
-            reinterpret_cast<double2*>(a.U + (size_t)m * a.N)[i] = um;
-            reinterpret_cast<double2*>(a.F + ((size_t)m * a.ncomp) * a.N)[i] = fim;
-            if (a.ncomp == 2) reinterpret_cast<double2*>(a.F + ((size_t)m * a.ncomp + 1) * a.N)[i] = fem;
-        }
-    }
-    if (a.f0max) {
-        fmaxv = wave_max(fmaxv);
-        if ((threadIdx.x & 63) == 0) atomic_max_abs(a.f0max, fmaxv);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------
-// periodic finite-difference operator (eval_f), any stencil width, 1-3 dimensions
-// ------------------------------------------------------------------------------------------------------
-struct StencilArgs {
-    const double* in[MAXM];
-    double* outI[MAXM];  // implicit-operator result or null
-    double* outE[MAXM];  // explicit-stencil result or null
-    const double* profile;  // forcing profile (outE = profile * g[f]) or null
-    double g[MAXM];
-    Stencil sI, sE;
-    int nf, ndim, n;
-    int useE;  // 0 none, 1 stencil, 2 forcing
-};
-
-__device__ inline int wrapi(int i, int n) { return i < 0 ? i + n : (i >= n ? i - n : i); }
-
-__global__ __launch_bounds__(256) void k_stencil(StencilArgs a) {
-    const int n = a.n;
-    const size_t N = a.ndim == 1 ? (size_t)n : (a.ndim == 2 ? (size_t)n * n : (size_t)n * n * n);
-    const size_t n2 = N >> 1;
-    const int f = blockIdx.y;
-    const double* __restrict__ u = a.in[f];
-    for (size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x; p < n2; p += (size_t)gridDim.x * blockDim.x) {
-        const size_t i0 = p * 2;
-        const int z = (int)(i0 % n);
-        const size_t rest = i0 / n;
-        const int y = a.ndim >= 2 ? (int)(rest % n) : 0;
-        const int x = a.ndim == 3 ? (int)(rest / n) : 0;
-        const size_t line = i0 - z;  // start of the contiguous line
-        for (int which = 0; which < 2; ++which) {
-            double* out = which == 0 ? a.outI[f] : a.outE[f];
-            if (!out) continue;
-            if (which == 1 && a.useE == 2) {
-                double2 pr = reinterpret_cast<const double2*>(a.profile)[p];
-                reinterpret_cast<double2*>(out)[p] = double2{pr.x * a.g[f], pr.y * a.g[f]};
-                continue;
-            }
-            const Stencil& s = which == 0 ? a.sI : a.sE;
-            double r0 = 0.0, r1 = 0.0;
-            // axis order follows the Kronecker sum of problem_helper.py:226-235: slowest axis first
-            if (a.ndim == 3) {
-                for (int k = 0; k < s.npts; ++k) {
-                    const size_t q = ((size_t)wrapi(x + s.off[k], n) * n + y) * n + z;
-                    double2 v = *reinterpret_cast<const double2*>(u + q);
-                    r0 += s.w[k] * v.x;
-                    r1 += s.w[k] * v.y;
-                }
-            }
-            if (a.ndim >= 2) {
-                for (int k = 0; k < s.npts; ++k) {
-                    const size_t q = ((size_t)x * n + wrapi(y + s.off[k], n)) * n + z;
-                    double2 v = *reinterpret_cast<const double2*>(u + q);
-                    r0 += s.w[k] * v.x;
-                    r1 += s.w[k] * v.y;
-                }
-            }
-            for (int k = 0; k < s.npts; ++k) {
-                r0 += s.w[k] * u[line + wrapi(z + s.off[k], n)];
-                r1 += s.w[k] * u[line + wrapi(z + 1 + s.off[k], n)];
-            }
-            reinterpret_cast<double2*>(out)[p] = double2{r0, r1};
-        }
-    }
-}
-
-// 3-D fast path for 3-point stencils (offsets -1, 0, 1 per axis): 2.5-D blocking.  A workgroup owns a
-// (TY x TZ) tile of the y-z plane and marches along x; the x neighbours stay in registers, the y/z neighbours
-// of the current plane come from a double-buffered LDS tile with halo, so every input word is read from
-// global memory once per tile (+ halo) instead of seven times.
-struct Stencil3Args {
-    const double* in[MAXM];
-    double* outI[MAXM];
-    double* outE[MAXM];
-    double wI[3], wE[3];  // weights for offsets -1, 0, +1
-    int n, xchunk, ntiles, nchunks;
-};
-
-// Workgroup b runs on XCD b % 8 (observed dispatch order; used for speed only): give every XCD a contiguous
-// range of the logical grid so that tiles sharing halo lines meet in the same L2.
-__device__ __forceinline__ unsigned xcd_swizzle(unsigned b, unsigned total) {
-    return (total & 7u) ? b : (b & 7u) * (total >> 3) + (b >> 3);
-}
-
-template <int RPT>
-__global__ __launch_bounds__(256, 4) void k_stencil3d(Stencil3Args a) {
-    constexpr int TZ = 64, TYB = 8, TY = TYB * RPT, LW = TZ + 4;  // LDS row: [halo | 64 | halo | pad]
-    __shared__ double tile[2][TY + 2][LW];
-    const int n = a.n;
-    const int tz = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int ntz = n / TZ;
-    // logical order: z-tile fastest, then y-tile (halo partners stay close), then x-chunk, then field
-    unsigned lb = xcd_swizzle(blockIdx.x, gridDim.x);
-    const int zt = lb % ntz;
-    lb /= ntz;
-    const int nty = n / TY;
-    const int yt = lb % nty;
-    lb /= nty;
-    const int chunk = lb % a.nchunks;
-    const int f = lb / a.nchunks;
-    const int z0 = zt * TZ, y0 = yt * TY;
-    const int x0 = chunk * a.xchunk;
-    const double* __restrict__ u = a.in[f];
-    double* __restrict__ oI = a.outI[f];
-    double* __restrict__ oE = a.outE[f];
-    const size_t sx = (size_t)n * n;
-    // halo duty of this thread: 0..63 -> y halo rows (below / above), 64..64+2*TY-1 -> z halo columns
-    const int t = threadIdx.x;
-    const bool hy = t < 64, hz = t >= 64 && t < 64 + 2 * TY;
-    size_t hoff = 0;   // offset of the halo element(s) within a plane
-    int hrow = 0, hcol = 0;
-    if (hy) {
-        const int side = t >> 5, pz = t & 31;
-        const int yy = side == 0 ? (y0 == 0 ? n - 1 : y0 - 1) : (y0 + TY == n ? 0 : y0 + TY);
-        hoff = (size_t)yy * n + z0 + 2 * pz;
-        hrow = side == 0 ? 0 : TY + 1;
-        hcol = 1 + 2 * pz;
-    } else if (hz) {
-        const int q = t - 64, side = q / TY, r = q % TY;
-        const int zz = side == 0 ? (z0 == 0 ? n - 1 : z0 - 1) : (z0 + TZ == n ? 0 : z0 + TZ);
-        hoff = (size_t)(y0 + r) * n + zz;
-        hrow = r + 1;
-        hcol = side == 0 ? 0 : TZ + 1;
-    }
-    size_t off[RPT];
-#pragma unroll
-    for (int r = 0; r < RPT; ++r) off[r] = (size_t)(y0 + ty + r * TYB) * n + z0 + 2 * tz;
-
-    auto plane = [&](int x) { return u + (size_t)(x < 0 ? x + n : (x >= n ? x - n : x)) * sx; };
-    double2 prev[RPT], cur[RPT], nxt[RPT], nx2[RPT];
-    double2 hcur = double2{0.0, 0.0}, hnxt = double2{0.0, 0.0}, hnx2 = double2{0.0, 0.0};
-    {
-        const double* pm = plane(x0 - 1);
-        const double* p0 = plane(x0);
-        const double* p1 = plane(x0 + 1);
-        const double* p2 = plane(x0 + 2);
-#pragma unroll
-        for (int r = 0; r < RPT; ++r) {
-            prev[r] = *reinterpret_cast<const double2*>(pm + off[r]);
-            cur[r] = *reinterpret_cast<const double2*>(p0 + off[r]);
-            nxt[r] = *reinterpret_cast<const double2*>(p1 + off[r]);
-            nx2[r] = *reinterpret_cast<const double2*>(p2 + off[r]);
-        }
-        if (hy) {
-            hcur = *reinterpret_cast<const double2*>(p0 + hoff);
-            hnxt = *reinterpret_cast<const double2*>(p1 + hoff);
-            hnx2 = *reinterpret_cast<const double2*>(p2 + hoff);
-        } else if (hz) {
-            hcur.x = p0[hoff];
-            hnxt.x = p1[hoff];
-            hnx2.x = p2[hoff];
-        }
-    }
-    auto put = [&](int b, const double2 (&v)[RPT], double2 h) {
-#pragma unroll
-        for (int r = 0; r < RPT; ++r) {
-            tile[b][ty + r * TYB + 1][1 + 2 * tz] = v[r].x;
-            tile[b][ty + r * TYB + 1][2 + 2 * tz] = v[r].y;
-        }
-        if (hy) {
-            tile[b][hrow][hcol] = h.x;
-            tile[b][hrow][hcol + 1] = h.y;
-        } else if (hz) {
-            tile[b][hrow][hcol] = h.x;
-        }
-    };
-    put(0, cur, hcur);
-    const double cI = 3.0 * a.wI[1], cE = 3.0 * a.wE[1];
-    for (int p = 0; p < a.xchunk; ++p) {
-        const int b = p & 1;
-        const int x = x0 + p;
-        __syncthreads();
-        // prefetch plane x+3 (interior + halo): two planes are always in flight behind the one in use
-        double2 nn[RPT];
-        double2 hnn = double2{0.0, 0.0};
-        const bool more = p + 1 < a.xchunk;
-        if (p + 2 < a.xchunk) {
-            const double* p3 = plane(x + 3);
-#pragma unroll
-            for (int r = 0; r < RPT; ++r) nn[r] = *reinterpret_cast<const double2*>(p3 + off[r]);
-            if (hy) hnn = *reinterpret_cast<const double2*>(p3 + hoff);
-            else if (hz) hnn.x = p3[hoff];
-        }
-        const size_t po = (size_t)x * sx;
-#pragma unroll
-        for (int r = 0; r < RPT; ++r) {
-            const int row = ty + r * TYB + 1, col = 1 + 2 * tz;
-            const double ym0 = tile[b][row - 1][col], ym1 = tile[b][row - 1][col + 1];
-            const double yp0 = tile[b][row + 1][col], yp1 = tile[b][row + 1][col + 1];
-            const double zm = tile[b][row][col - 1], zp = tile[b][row][col + 2];
-            const double c0 = cur[r].x, c1 = cur[r].y;
-            // same association as the row sums of the Kronecker-sum matrix: per axis (w-,w0,w+), axes added
-            double2 res;
-            res.x = (a.wI[0] * prev[r].x + a.wI[2] * nxt[r].x) + (a.wI[0] * ym0 + a.wI[2] * yp0) +
-                    (a.wI[0] * zm + a.wI[2] * c1) + cI * c0;
-            res.y = (a.wI[0] * prev[r].y + a.wI[2] * nxt[r].y) + (a.wI[0] * ym1 + a.wI[2] * yp1) +
-                    (a.wI[0] * c0 + a.wI[2] * zp) + cI * c1;
-            if (oI) *reinterpret_cast<double2*>(oI + po + off[r]) = res;
-            if (oE) {
-                double2 re;
-                re.x = (a.wE[0] * prev[r].x + a.wE[2] * nxt[r].x) + (a.wE[0] * ym0 + a.wE[2] * yp0) +
-                       (a.wE[0] * zm + a.wE[2] * c1) + cE * c0;
-                re.y = (a.wE[0] * prev[r].y + a.wE[2] * nxt[r].y) + (a.wE[0] * ym1 + a.wE[2] * yp1) +
-                       (a.wE[0] * c0 + a.wE[2] * zp) + cE * c1;
-                *reinterpret_cast<double2*>(oE + po + off[r]) = re;
-            }
-        }
-        if (more) {
-            put(b ^ 1, nxt, hnxt);
-#pragma unroll
-            for (int r = 0; r < RPT; ++r) {
-                prev[r] = cur[r];
-                cur[r] = nxt[r];
-                nxt[r] = nx2[r];
-                nx2[r] = nn[r];
-            }
-            hnxt = hnx2;
-            hnx2 = hnn;
-        }
-    }
-}
-
-// eval_f for ALL nodes fused with the collocation residual: a workgroup marches the (y,z) tile through x for
-// the M fields U[1..M] at once, so at every point all f_j = A u_j are in registers when the residual
-// u0 + dt sum_j Q[m][j] f_j - u_m (core/sweeper.py:186-199) is formed.  Replaces stencil (10 field passes) +
-// residual (11) by one kernel with 6 reads + 5 writes.
-struct StencilResArgs {
-    const double* U;  // slab: U[0] = u0, U[1..M]
-    double* F;        // slab (ncomp == 1)
-    double wI[3];
-    double cQ[MAXM][MAXM];  // dt * Q[m+1][j+1]
-    unsigned long long* norms;
-    int n, xchunk, nchunks;
-    size_t N;
-};
-
-template <int M>
-__global__ __launch_bounds__(256, 3) void k_stencil3d_res(StencilResArgs a) {
-    // LDS: 2 buffers x M fields x (8+2) rows x 66 doubles = 52.8 KB at M = 5 -> three workgroups per CU
-    constexpr int TZ = 64, TY = 8, LW = TZ + 2;
-    __shared__ double tile[2][M][TY + 2][LW];
-    const int n = a.n;
-    const int tz = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int ntz = n / TZ, nty = n / TY;
-    unsigned lb = xcd_swizzle(blockIdx.x, gridDim.x);
-    const int zt = lb % ntz;
-    lb /= ntz;
-    const int yt = lb % nty;
-    const int chunk = lb / nty;
-    const int z0 = zt * TZ, y0 = yt * TY, x0 = chunk * a.xchunk;
-    const size_t sx = (size_t)n * n;
-    const int t = threadIdx.x;
-    const bool hy = t < 64, hz = t >= 64 && t < 64 + 2 * TY;
-    size_t hoff = 0;
-    int hrow = 0, hcol = 0;
-    if (hy) {
-        const int side = t >> 5, pz = t & 31;
-        const int yy = side == 0 ? (y0 == 0 ? n - 1 : y0 - 1) : (y0 + TY == n ? 0 : y0 + TY);
-        hoff = (size_t)yy * n + z0 + 2 * pz;
-        hrow = side == 0 ? 0 : TY + 1;
-        hcol = 1 + 2 * pz;
-    } else if (hz) {
-        const int q = t - 64, side = q / TY, r = q % TY;
-        const int zz = side == 0 ? (z0 == 0 ? n - 1 : z0 - 1) : (z0 + TZ == n ? 0 : z0 + TZ);
-        hoff = (size_t)(y0 + r) * n + zz;
-        hrow = r + 1;
-        hcol = side == 0 ? 0 : TZ + 1;
-    }
-    const size_t off = (size_t)(y0 + ty) * n + z0 + 2 * tz;
-    auto wrapx = [&](int x) { return (size_t)(x < 0 ? x + n : (x >= n ? x - n : x)) * sx; };
-    auto halo_load = [&](const double* plane) {
-        double2 h = double2{0.0, 0.0};
-        if (hy) h = *reinterpret_cast<const double2*>(plane + hoff);
-        else if (hz) h.x = plane[hoff];
-        return h;
-    };
-    auto put = [&](int b, int j, double2 v, double2 h) {
-        tile[b][j][ty + 1][1 + 2 * tz] = v.x;
-        tile[b][j][ty + 1][2 + 2 * tz] = v.y;
-        if (hy) {
-            tile[b][j][hrow][hcol] = h.x;
-            tile[b][j][hrow][hcol + 1] = h.y;
-        } else if (hz) {
-            tile[b][j][hrow][hcol] = h.x;
-        }
-    };
-    double2 prev[M], cur[M], nxt[M];
-    double2 u0c, u0n = double2{0.0, 0.0};
-    double nmax[M];
-#pragma unroll
-    for (int j = 0; j < M; ++j) {
-        const double* uj = a.U + (size_t)(j + 1) * a.N;
-        prev[j] = *reinterpret_cast<const double2*>(uj + wrapx(x0 - 1) + off);
-        cur[j] = *reinterpret_cast<const double2*>(uj + wrapx(x0) + off);
-        nxt[j] = *reinterpret_cast<const double2*>(uj + wrapx(x0 + 1) + off);
-        put(0, j, cur[j], halo_load(uj + wrapx(x0)));
-        nmax[j] = 0.0;
-    }
-    u0c = *reinterpret_cast<const double2*>(a.U + wrapx(x0) + off);
-    const double cI = 3.0 * a.wI[1];
-    for (int p = 0; p < a.xchunk; ++p) {
-        const int b = p & 1;
-        const int x = x0 + p;
-        __syncthreads();
-        const bool more = p + 1 < a.xchunk;
-        // in flight while this plane is computed: the interior of plane x+2 and the halo of plane x+1
-        double2 nn[M], hn[M];
-        if (more) {
-            const size_t px1 = wrapx(x + 1), px2 = wrapx(x + 2);
-#pragma unroll
-            for (int j = 0; j < M; ++j) {
-                const double* uj = a.U + (size_t)(j + 1) * a.N;
-                nn[j] = *reinterpret_cast<const double2*>(uj + px2 + off);
-                hn[j] = halo_load(uj + px1);
-            }
-            u0n = *reinterpret_cast<const double2*>(a.U + px1 + off);
-        }
-        const size_t po = (size_t)x * sx + off;
-        double2 fv[M];
-        const int row = ty + 1, col = 1 + 2 * tz;
-#pragma unroll
-        for (int j = 0; j < M; ++j) {
-            const double ym0 = tile[b][j][row - 1][col], ym1 = tile[b][j][row - 1][col + 1];
-            const double yp0 = tile[b][j][row + 1][col], yp1 = tile[b][j][row + 1][col + 1];
-            const double zm = tile[b][j][row][col - 1], zp = tile[b][j][row][col + 2];
-            const double c0 = cur[j].x, c1 = cur[j].y;
-            fv[j].x = (a.wI[0] * prev[j].x + a.wI[2] * nxt[j].x) + (a.wI[0] * ym0 + a.wI[2] * yp0) +
-                      (a.wI[0] * zm + a.wI[2] * c1) + cI * c0;
-            fv[j].y = (a.wI[0] * prev[j].y + a.wI[2] * nxt[j].y) + (a.wI[0] * ym1 + a.wI[2] * yp1) +
-                      (a.wI[0] * c0 + a.wI[2] * zp) + cI * c1;
-            *reinterpret_cast<double2*>(a.F + (size_t)(j + 1) * a.N + po) = fv[j];
-        }
-#pragma unroll
-        for (int m = 0; m < M; ++m) {
-            double r0 = 0.0, r1 = 0.0;
-#pragma unroll
-            for (int j = 0; j < M; ++j) {
-                r0 += a.cQ[m][j] * fv[j].x;
-                r1 += a.cQ[m][j] * fv[j].y;
-            }
-            r0 = fabs((r0 + u0c.x) - cur[m].x);
-            r1 = fabs((r1 + u0c.y) - cur[m].y);
-            const double r = (r0 > r1 || r0 != r0) ? r0 : r1;
-            nmax[m] = (nmax[m] > r || nmax[m] != nmax[m]) ? nmax[m] : r;
-        }
-        if (more) {
-#pragma unroll
-            for (int j = 0; j < M; ++j) {
-                put(b ^ 1, j, nxt[j], hn[j]);
-                prev[j] = cur[j];
-                cur[j] = nxt[j];
-                nxt[j] = nn[j];
-            }
-            u0c = u0n;
-        }
-    }
-#pragma unroll
-    for (int m = 0; m < M; ++m) {
-        const double v = wave_max(nmax[m]);
-        if ((threadIdx.x & 63) == 0) atomic_max_abs(a.norms + m, v);
-    }
-}
-
-// pointwise explicit (reaction) terms of the Allen-Cahn problems
-//   kind 1: c * u * (1 - u^nu),  c = 1/eps^2          (AllenCahn_2D_FFT.py:140-141)
-//   kind 2: -2/eps^2 u (1-u)(1-2u) - 6 dw u (1-u)     (AllenCahn_MPIFFT.py:83-85)
-__global__ void k_reaction(const double* __restrict__ u, double* __restrict__ out, size_t n, int kind, double p0,
-                           double p1, int nu) {
-#pragma clang fp contract(off)
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const double v = u[i];
-        double r;
-        if (kind == 1) {
-            double pw = 1.0;
-            for (int q = 0; q < nu; ++q) pw *= v;
-            r = p0 * v * (1.0 - pw);
-        } else {
-            r = p0 * v * (1.0 - v) * (1.0 - 2.0 * v) - p1 * v * (1.0 - v);
-        }
-        out[i] = r;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------
-// FFT kernels
-// ------------------------------------------------------------------------------------------------------
-struct FieldPtrs {
-    const double* in[MAXM];
-    double* out[MAXM];
-};
-
-// 1-D problems: promote the real line to complex / take the real part back
-__global__ void k_promote(FieldPtrs p, cd* W, size_t N) {
-    const int f = blockIdx.y;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < N; i += (size_t)gridDim.x * blockDim.x)
-        W[(size_t)f * N + i] = cd{p.in[f][i], 0.0};
-}
-__global__ void k_realpart(FieldPtrs p, const cd* W, size_t N) {
-    const int f = blockIdx.y;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < N; i += (size_t)gridDim.x * blockDim.x)
-        p.out[f][i] = W[(size_t)f * N + i].x;
-}
-
-// r2c along axis 0: real field [N][rest] seen as complex pairs [N][rest/2]; two real columns per complex
-// column ("two for one"), unpacked to the half spectra W[k][rest], k = 0..N/2.
-template <int N, int T>
-__global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_fwd(FieldPtrs p, cd* __restrict__ W, size_t fstride,
-                                                                      int rest, const cd* __restrict__ tw) {
-    constexpr int E = fft_elems(N), P = N / E;
-    using LAY = LayStrided<N, T>;
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int col = threadIdx.x % T, j = threadIdx.x / T;
-    const int ncol = rest >> 1;  // complex columns
-    const int c = blockIdx.x * T + col;
-    const bool ok = c < ncol;
-    const double* __restrict__ in = p.in[blockIdx.y];
-    cd r[E];
-#pragma unroll
-    for (int i = 0; i < E; ++i)
-        r[i] = ok ? *reinterpret_cast<const cd*>(in + (size_t)(j + i * P) * rest + 2 * (size_t)c) : cd{0.0, 0.0};
-    fft_line<N, -1, LAY>(r, j, col, lds, tw);
-    // unpack: A[k] = (C[k] + conj C[N-k]) / 2, B[k] = (C[k] - conj C[N-k]) / (2i)
-    cd A[E], B[E];
-#pragma unroll
-    for (int part = 0; part < 2; ++part) {
-#pragma unroll
-        for (int i = 0; i < E; ++i) lds[LAY::idx(col, j + i * P)] = part == 0 ? r[i].x : r[i].y;
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < E; ++i) {
-            const int k = j + i * P;
-            const double v = lds[LAY::idx(col, (N - k) & (N - 1))];
-            if (part == 0) {
-                A[i].x = 0.5 * (r[i].x + v);
-                B[i].y = -0.5 * (r[i].x - v);
-            } else {
-                A[i].y = 0.5 * (r[i].y - v);
-                B[i].x = 0.5 * (r[i].y + v);
-            }
-        }
-        __syncthreads();
-    }
-    cd* __restrict__ Wf = W + blockIdx.y * fstride;
-#pragma unroll
-    for (int i = 0; i < E; ++i) {
-        const int k = j + i * P;
-        if (ok && k <= N / 2) {
-            cd* dst = Wf + (size_t)k * rest + 2 * (size_t)c;
-            dst[0] = A[i];
-            dst[1] = B[i];
-        }
-    }
-}
-
-// c2r along axis 0 (inverse of the above, unnormalised)
-template <int N, int T>
-__global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_inv(FieldPtrs p, const cd* __restrict__ W,
-                                                                      size_t fstride, int rest,
-                                                                      const cd* __restrict__ tw) {
-    constexpr int E = fft_elems(N), P = N / E;
-    using LAY = LayStrided<N, T>;
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int col = threadIdx.x % T, j = threadIdx.x / T;
-    const int ncol = rest >> 1;
-    const int c = blockIdx.x * T + col;
-    const bool ok = c < ncol;
-    const cd* __restrict__ Wf = W + blockIdx.y * fstride;
-    cd A[E], B[E];
-#pragma unroll
-    for (int i = 0; i < E; ++i) {
-        const int k = j + i * P;
-        if (ok && k <= N / 2) {
-            const cd* src = Wf + (size_t)k * rest + 2 * (size_t)c;
-            A[i] = src[0];
-            B[i] = src[1];
-        } else {
-            A[i] = B[i] = cd{0.0, 0.0};
-        }
-    }
-    cd r[E];
-    // C[k] = A[k] + i B[k] (k <= N/2), C[N-k] = conj A[k] + i conj B[k]
-#pragma unroll
-    for (int part = 0; part < 2; ++part) {
-#pragma unroll
-        for (int i = 0; i < E; ++i) {
-            const int k = j + i * P;
-            if (k <= N / 2) {
-                const bool edge = (k == 0) || (k == N / 2);
-                double own, mir;
-                if (part == 0) {
-                    own = edge ? A[i].x : A[i].x - B[i].y;
-                    mir = A[i].x + B[i].y;
-                } else {
-                    own = edge ? B[i].x : A[i].y + B[i].x;
-                    mir = -A[i].y + B[i].x;
-                }
-                lds[LAY::idx(col, k)] = own;
-                if (!edge) lds[LAY::idx(col, N - k)] = mir;
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < E; ++i) {
-            const double v = lds[LAY::idx(col, j + i * P)];
-            if (part == 0) r[i].x = v;
-            else r[i].y = v;
-        }
-        __syncthreads();
-    }
-    fft_line<N, +1, LAY>(r, j, col, lds, tw);
-    double* __restrict__ out = p.out[blockIdx.y];
-    if (ok) {
-#pragma unroll
-        for (int i = 0; i < E; ++i) *reinterpret_cast<cd*>(out + (size_t)(j + i * P) * rest + 2 * (size_t)c) = r[i];
-    }
-}
-
-// c2c in place along the middle axis of W[f][kx][y][z] (3-D only): tile = all y x T z-columns
-template <int N, int T, int DIR>
-__global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_ffty(cd* __restrict__ W, size_t fstride,
-                                                                  const cd* __restrict__ tw) {
-    constexpr int E = fft_elems(N), P = N / E;
-    using LAY = LayStrided<N, T>;
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int col = threadIdx.x % T, j = threadIdx.x / T;
-    const int c = blockIdx.x * T + col;
-    const bool ok = c < N;
-    cd* __restrict__ base = W + blockIdx.z * fstride + (size_t)blockIdx.y * N * N + c;
-    cd r[E];
-#pragma unroll
-    for (int i = 0; i < E; ++i) r[i] = ok ? base[(size_t)(j + i * P) * N] : cd{0.0, 0.0};
-    fft_line<N, DIR, LAY>(r, j, col, lds, tw);
-    if (ok) {
-#pragma unroll
-        for (int i = 0; i < E; ++i) base[(size_t)(j + i * P) * N] = r[i];
-    }
-}
-
-struct ZArgs {
-    cd* W;
-    size_t fstride;
-    const cd *tw, *lamI, *lamE;  // lamE may be null
-    double cI[MAXM][MAXM];       // strictly lower: dt*QI[m+1][j+1], j < m
-    double cE[MAXM][MAXM];       // strictly lower: dt*QE[m+1][j+1]
-    double alpha[MAXM];          // dt*QI[m+1][m+1]
-    double invN;
-    int nf, ndim, coupled;
-    int apply;  // 1: multiply by the symbol (operator application) instead of dividing by 1 - alpha*symbol
-};
-
-// forward FFT along the contiguous axis, node-coupled implicit solve in Fourier space, inverse FFT.
-// One workgroup = LPB lines x all nf fields; column c = f*LPB + l occupies threads [c*P, (c+1)*P).
-// After the forward transform the spectra go through LDS once more so that one thread holds ALL nf node
-// values of a mode: the lower-triangular node coupling is then a register recurrence with wave-uniform
-// coefficient indices (scalar kernarg loads, no per-lane table look-ups).
-template <int N>
-constexpr int z_lines_per_block() {
-    constexpr int P = N / fft_elems(N);
-    return P >= 64 ? 1 : 64 / P;
-}
-
-template <int N>
-__global__ __launch_bounds__(z_lines_per_block<N>() * (N / fft_elems(N)) * MAXM, 3) void k_fftz_solve(ZArgs a, unsigned nlines) {
-    constexpr int E = fft_elems(N), P = N / E, LPB = z_lines_per_block<N>();
-    constexpr int NCH = E == 16 ? 2 : 1;  // the solve buffer holds N/NCH modes per column at a time
-    constexpr int CH = N / NCH, ECH = E / NCH;
-    using LAY = LayContig<N>;
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int c = threadIdx.x / P, j = threadIdx.x % P;
-    const int f = c / LPB, l = c % LPB;
-    const size_t line = (size_t)blockIdx.x * LPB + l;
-    const bool ok = line < nlines;
-    cd* __restrict__ Wl = a.W + f * a.fstride + line * N;
-    cd r[E];
-#pragma unroll
-    for (int i = 0; i < E; ++i) r[i] = ok ? Wl[j + i * P] : cd{0.0, 0.0};
-    fft_line<N, -1, LAY, (N / fft_elems(N)) <= 64>(r, j, c, lds, a.tw);
-    __syncthreads();  // the solve buffer aliases other waves' exchange planes
-
-    cd* buf = reinterpret_cast<cd*>(lds);  // [column][CH]
-    const int nthreads = a.nf * LPB * P;
-#pragma unroll
-    for (int ph = 0; ph < NCH; ++ph) {
-#pragma unroll
-        for (int i = 0; i < ECH; ++i) buf[c * CH + j + i * P] = r[ph * ECH + i];
-        __syncthreads();
-        for (int item = threadIdx.x; item < LPB * CH; item += nthreads) {
-            const int ll = item / CH, kk = item % CH;
-            const size_t ln = (size_t)blockIdx.x * LPB + ll;
-            const int kz = ph * CH + kk;
-            cd lam = a.lamI[kz], mu = cd{0.0, 0.0};
-            if (a.lamE) mu = a.lamE[kz];
-            if (a.ndim == 3) {
-                const int kx = (int)(ln / N) % (N / 2 + 1), ky = (int)(ln % N);
-                lam = cadd(lam, cadd(a.lamI[kx], a.lamI[ky]));
-                if (a.lamE) mu = cadd(mu, cadd(a.lamE[kx], a.lamE[ky]));
-            } else if (a.ndim == 2) {
-                const int kx = (int)(ln % (N / 2 + 1));
-                lam = cadd(lam, a.lamI[kx]);
-                if (a.lamE) mu = cadd(mu, a.lamE[kx]);
-            }
-            cd u[MAXM];
-#pragma unroll
-            for (int m = 0; m < MAXM; ++m) {
-                if (m < a.nf) {
-                    cd acc = buf[(m * LPB + ll) * CH + kk];
-                    if (a.coupled) {
-#pragma unroll
-                        for (int q = 0; q < m; ++q) {
-                            const double ci = a.cI[m][q], ce = a.cE[m][q];
-                            const cd coef = cd{ci * lam.x + ce * mu.x, ci * lam.y + ce * mu.y};
-                            acc = cfma(coef, u[q], acc);
-                        }
-                    }
-                    const double al = a.alpha[m];
-                    u[m] = a.apply ? cmul(acc, lam) : cmul(acc, cinv_fast(cd{1.0 - al * lam.x, -al * lam.y}));
-                    buf[(m * LPB + ll) * CH + kk] = cscale(u[m], a.invN);
-                }
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < ECH; ++i) r[ph * ECH + i] = buf[c * CH + j + i * P];
-        __syncthreads();
-    }
-    // opaque copy of the lane index: without it the forward transform's twiddles stay live (~100 VGPRs)
-    // through the whole kernel for reuse in the inverse
-    int j2 = j;
-    asm volatile("" : "+v"(j2));
-    fft_line<N, +1, LAY, (N / fft_elems(N)) <= 64>(r, j2, c, lds, a.tw);
-    if (ok) {
-#pragma unroll
-        for (int i = 0; i < E; ++i) Wl[j2 + i * P] = r[i];
-    }
-}
-
-// plain transform along the contiguous axis, src -> dst (may alias), optionally scaled: forward to bring u0 /
-// node values into the fully transformed domain of the spectral cache, inverse after the spectral sweep
-template <int N, int DIR>
-__global__ __launch_bounds__(z_lines_per_block<N>() * (N / fft_elems(N)) * MAXM, 4) void k_fftz_plain(
-    const cd* __restrict__ src, cd* __restrict__ dst, size_t fstride, const cd* __restrict__ tw, unsigned nlines,
-    double scale) {
-    constexpr int E = fft_elems(N), P = N / E, LPB = z_lines_per_block<N>();
-    using LAY = LayContig<N>;
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int c = threadIdx.x / P, j = threadIdx.x % P;
-    const int f = c / LPB, l = c % LPB;
-    const size_t line = (size_t)blockIdx.x * LPB + l;
-    const bool ok = line < nlines;
-    const size_t base = f * fstride + line * N;
-    cd r[E];
-#pragma unroll
-    for (int i = 0; i < E; ++i) r[i] = ok ? src[base + j + i * P] : cd{0.0, 0.0};
-    if (scale != 1.0) {
-#pragma unroll
-        for (int i = 0; i < E; ++i) r[i] = cscale(r[i], scale);
-    }
-    fft_line<N, DIR, LAY, (N / fft_elems(N)) <= 64>(r, j, c, lds, tw);
-    if (ok) {
-#pragma unroll
-        for (int i = 0; i < E; ++i) dst[base + j + i * P] = r[i];
-    }
-}
-
-// Sweep in the transformed domain (DESIGN.md "spectral reuse").  For linear f(u) = A u (+ B u) the gathered
-// right-hand side of node m is  u0 + dt sum_j (Q-QI)[m][j] A u_j^k (+ explicit part): its transform follows
-// from the transforms of u0 and of the previous iterate, which the previous sweep left in S.  One launch
-// reads S0 and S[0..nf), applies gather + node-coupled solve per mode, writes the new spectra back to S and
-// their inverse transform along the contiguous axis to W (input of the inverse y / x passes).
-struct SpecArgs {
-    cd* S;
-    size_t fstride;
-    const cd* S0;
-    cd* W;
-    const cd *tw, *lamI, *lamE;
-    double gI[MAXM][MAXM], gE[MAXM][MAXM];  // dt (Q - QI), dt (Q - QE), inner MxM blocks
-    double cI[MAXM][MAXM], cE[MAXM][MAXM], alpha[MAXM];
-    double invN;
-    int nf, ndim, coupled, spread;
-};
-
-// one thread per Fourier mode: gather on the cached transforms + node-coupled solve, S updated in place
-template <int NF>
-__global__ __launch_bounds__(256) void k_spec_point(SpecArgs a, int n, size_t nmodes) {
-    for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < nmodes; g += (size_t)gridDim.x * blockDim.x) {
-        const int kz = (int)(g % n);
-        const size_t ln = g / n;
-        cd lam = a.lamI[kz], mu = cd{0.0, 0.0};
-        if (a.lamE) mu = a.lamE[kz];
-        if (a.ndim == 3) {
-            const int kx = (int)(ln / n), ky = (int)(ln % n);
-            lam = cadd(lam, cadd(a.lamI[kx], a.lamI[ky]));
-            if (a.lamE) mu = cadd(mu, cadd(a.lamE[kx], a.lamE[ky]));
-        } else if (a.ndim == 2) {
-            lam = cadd(lam, a.lamI[ln]);
-            if (a.lamE) mu = cadd(mu, a.lamE[ln]);
-        }
-        const cd u0h = a.S0[g];
-        cd old[NF], u[NF];
-#pragma unroll
-        for (int q = 0; q < NF; ++q) old[q] = a.spread ? u0h : a.S[q * a.fstride + g];
-#pragma unroll
-        for (int m = 0; m < NF; ++m) {
-            cd acc = u0h;
-#pragma unroll
-            for (int q = 0; q < NF; ++q) {
-                const double gi = a.gI[m][q], ge = a.gE[m][q];
-                acc = cfma(cd{gi * lam.x + ge * mu.x, gi * lam.y + ge * mu.y}, old[q], acc);
-            }
-            if (a.coupled) {
-#pragma unroll
-                for (int q = 0; q < m; ++q) {
-                    const double ci = a.cI[m][q], ce = a.cE[m][q];
-                    acc = cfma(cd{ci * lam.x + ce * mu.x, ci * lam.y + ce * mu.y}, u[q], acc);
-                }
-            }
-            const double al = a.alpha[m];
-            u[m] = cmul(acc, cinv_fast(cd{1.0 - al * lam.x, -al * lam.y}));
-            a.S[m * a.fstride + g] = u[m];
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------
-// van der Pol ensemble: one trajectory per lane (SoA state [2][T])
-// ------------------------------------------------------------------------------------------------------
-struct VdpSweepArgs {
-    double* U;   // slab [(M+1)][2][T]
-    double* F;
-    const double* tau;  // or null
-    size_t T;
-    double mu, dt, tol;
-    int maxiter;
-    double Q[MAXM][MAXM], QI[MAXM][MAXM];
-    unsigned long long* counters;
-};
-
-// Newton for u - h f(u) = r with the closed-form 2x2 inverse (Van_der_Pol_implicit.py:131-201)
-__device__ __forceinline__ bool vdp_newton(double& x1, double& x2, double r0, double r1, double h, double mu, double tol,
-                                           int maxiter, unsigned long long& newton) {
-#pragma clang fp contract(off)
-    int it = 0;
-    double res = 99.0;
-    while (it < maxiter) {
-        const double e0 = x1 - h * x2 - r0;
-        const double e1 = x2 - h * (mu * (1 - x1 * x1) * x2 - x1) - r1;
-        res = fmax(fabs(e0), fabs(e1));
-        if (e0 != e0 || e1 != e1) res = e0 + e1;  // NaN
-        if (res < tol || res != res) break;
-        const double c = 1.0 / (-2 * h * h * mu * x1 * x2 - h * h - 1 + h * mu * (1 - x1 * x1));
-        const double d00 = c * (h * mu * (1 - x1 * x1) - 1), d01 = c * (-h);
-        const double d10 = c * (2 * h * mu * x1 * x2 + h), d11 = c * (-1.0);
-        const double nx1 = x1 - (d00 * e0 + d01 * e1);
-        const double nx2 = x2 - (d10 * e0 + d11 * e1);
-        x1 = nx1;
-        x2 = nx2;
-        ++it;
-        ++newton;
-    }
-    return !(res != res || it == maxiter);
-}
-
-// one generic_implicit sweep (generic_implicit.py:51-103) for every trajectory, node values on the slabs
-template <int M>
-__global__ __launch_bounds__(256) void k_vdp_sweep(VdpSweepArgs a) {
-#pragma clang fp contract(off)
-    unsigned long long newton = 0, rhs = 0, failed = 0;
-    const size_t T = a.T, N = 2 * a.T;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < T; i += (size_t)gridDim.x * blockDim.x) {
-        const double mu = a.mu, dt = a.dt;
-        const double u00 = a.U[i], u01 = a.U[T + i];
-        double f0[M], f1[M], g0[M], g1[M];
-#pragma unroll
-        for (int m = 0; m < M; ++m) {
-            f0[m] = a.F[(size_t)(m + 1) * N + i];
-            f1[m] = a.F[(size_t)(m + 1) * N + T + i];
-        }
-#pragma unroll
-        for (int m = 0; m < M; ++m) {
-            double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-            for (int j = 0; j < M; ++j) {
-                s0 += dt * a.Q[m][j] * f0[j];
-                s1 += dt * a.Q[m][j] * f1[j];
-            }
-#pragma unroll
-            for (int j = 0; j < M; ++j) {
-                s0 -= dt * a.QI[m][j] * f0[j];
-                s1 -= dt * a.QI[m][j] * f1[j];
-            }
-            g0[m] = s0 + u00;
-            g1[m] = s1 + u01;
-            if (a.tau) {
-                g0[m] += a.tau[(size_t)m * N + i];
-                g1[m] += a.tau[(size_t)m * N + T + i];
-            }
-        }
-#pragma unroll
-        for (int m = 0; m < M; ++m) {
-            double r0 = g0[m], r1 = g1[m];
-#pragma unroll
-            for (int j = 0; j < M; ++j) {
-                if (j < m) {
-                    r0 += dt * a.QI[m][j] * f0[j];
-                    r1 += dt * a.QI[m][j] * f1[j];
-                }
-            }
-            const double h = dt * a.QI[m][m];
-            double x1 = a.U[(size_t)(m + 1) * N + i], x2 = a.U[(size_t)(m + 1) * N + T + i];
-            if (h == 0.0) {
-                x1 = r0;
-                x2 = r1;
-            } else if (!vdp_newton(x1, x2, r0, r1, h, mu, a.tol, a.maxiter, newton)) {
-                failed += 1;
-            }
-            a.U[(size_t)(m + 1) * N + i] = x1;
-            a.U[(size_t)(m + 1) * N + T + i] = x2;
-            f0[m] = x2;
-            f1[m] = mu * (1 - x1 * x1) * x2 - x1;
-            a.F[(size_t)(m + 1) * N + i] = f0[m];
-            a.F[(size_t)(m + 1) * N + T + i] = f1[m];
-            rhs += 1;
-        }
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-        newton += __shfl_xor(newton, o, 64);
-        rhs += __shfl_xor(rhs, o, 64);
-        failed += __shfl_xor(failed, o, 64);
-    }
-    if ((threadIdx.x & 63) == 0) {
-        atomicAdd(a.counters + 0, newton);
-        atomicAdd(a.counters + 1, rhs);
-        atomicAdd(a.counters + 2, failed);
-    }
-}
-
-__global__ void k_vdp_eval(const double* __restrict__ u, double* __restrict__ f, size_t T, double mu,
-                           unsigned long long* counters) {
-#pragma clang fp contract(off)
-    unsigned long long rhs = 0;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < T; i += (size_t)gridDim.x * blockDim.x) {
-        const double x1 = u[i], x2 = u[T + i];
-        f[i] = x2;
-        f[T + i] = mu * (1 - x1 * x1) * x2 - x1;
-        rhs += 1;
-    }
-    for (int o = 32; o > 0; o >>= 1) rhs += __shfl_xor(rhs, o, 64);
-    if ((threadIdx.x & 63) == 0 && rhs) atomicAdd(counters + 1, rhs);
-}
-
-__global__ void k_vdp_solve(const double* __restrict__ rhsv, const double* __restrict__ guess, double* __restrict__ out,
-                            size_t T, double h, double mu, double tol, int maxiter, unsigned long long* counters) {
-    unsigned long long newton = 0, failed = 0;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < T; i += (size_t)gridDim.x * blockDim.x) {
-        double x1 = guess[i], x2 = guess[T + i];
-        if (!vdp_newton(x1, x2, rhsv[i], rhsv[T + i], h, mu, tol, maxiter, newton)) failed += 1;
-        out[i] = x1;
-        out[T + i] = x2;
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-        newton += __shfl_xor(newton, o, 64);
-        failed += __shfl_xor(failed, o, 64);
-    }
-    if ((threadIdx.x & 63) == 0) {
-        atomicAdd(counters + 0, newton);
-        atomicAdd(counters + 2, failed);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------
-// space transfer between nested periodic grids (coarsening by 2 per axis): tensor products of the 1-D
-// interpolation  fine[2i] = coarse[i], fine[2i+1] = sum_j w[j] coarse[i - k/2 + 1 + j]  and of its scaled
-// transpose (TransferMesh.py:49-146 with helpers/transfer_helper.py:153-186, periodic / equidist_nested)
-// ------------------------------------------------------------------------------------------------------
-struct XferArgs {
-    const double* in;
-    double* out;
-    const int* idx;     // [n_out][W] source indices along the axis (device)
-    const double* w;    // [n_out][W] weights (zero-padded)
-    size_t outer, inner;
-    int n_out, n_in, W;
-};
-
-// one axis of the tensor product: out[o][i][q] = sum_j w[i][j] * in[o][idx[i][j]][q]
-__global__ void k_xfer_axis(XferArgs a) {
-    const size_t total = a.outer * a.n_out * a.inner;
-    for (size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x; p < total; p += (size_t)gridDim.x * blockDim.x) {
-        const size_t q = p % a.inner;
-        const size_t r = p / a.inner;
-        const int i = (int)(r % a.n_out);
-        const size_t o = r / a.n_out;
-        const double* __restrict__ src = a.in + o * a.n_in * a.inner + q;
-        double acc = 0.0;
-        for (int j = 0; j < a.W; ++j) {
-            const double wj = a.w[i * a.W + j];
-            if (wj != 0.0) acc += wj * src[(size_t)a.idx[i * a.W + j] * a.inner];
-        }
-        a.out[p] = acc;
-    }
-}
+#include "context.hpp"
+#include "kernels_pointwise.hpp"
+#include "kernels_stencil.hpp"
+#include "kernels_fft.hpp"
+#include "kernels_vdp.hpp"
+#include "kernels_transfer.hpp"
 
 // ------------------------------------------------------------------------------------------------------
 // host side
