@@ -40,7 +40,7 @@ def _kernel_bytes(name, n, M, ncomp=1):
         'fft_y_inv': 2 * nf * spec,
         'fft_x_inv': nf * (field + spec),
         'stencil': 2 * nf * field if ncomp == 1 else 3 * nf * field,  # IMEX: one read, impl + expl written
-        'stencil_res': (1 + 2 * nf) * field,            # u0 + U[1..M] in, F[1..M] out, node norms of the residual
+        'stencil_res': (1 + (1 + ncomp) * nf) * field,  # u0 + U[1..M] in, F[1..M] (impl, expl) out, residual norms
         'residual': (1 + M * ncomp + M) * field,        # u0, F[1..M], U[1..M] -> M norms
         'spread': (2 + 2 * M) * field,
         'copy': 2 * field,

@@ -230,15 +230,15 @@ __global__ __launch_bounds__(256, 4) void k_stencil3d(Stencil3Args a) {
 struct StencilResArgs {
     const double* U;  // slab: U[0] = u0, U[1..M]
     double* F;        // slab (ncomp == 1)
-    double wI[3];
+    double wI[3], wE[3];    // implicit operator; explicit stencil operator when ncomp == 2
     double cQ[MAXM][MAXM];  // dt * Q[m+1][j+1]
     unsigned long long* norms;
-    int n, xchunk, nchunks;
+    int n, xchunk, nchunks, ncomp;
     size_t N;
 };
 
-template <int M>
-__global__ __launch_bounds__(256, 3) void k_stencil3d_res(StencilResArgs a) {
+template <int M, bool EXPL>
+__global__ __launch_bounds__(256, EXPL ? 2 : 3) void k_stencil3d_res(StencilResArgs a) {
     // LDS: 2 buffers x M fields x (8+2) rows x 66 doubles = 52.8 KB at M = 5 -> three workgroups per CU
     constexpr int TZ = 64, TY = 8, LW = TZ + 2;
     __shared__ double tile[2][M][TY + 2][LW];
@@ -300,7 +300,8 @@ __global__ __launch_bounds__(256, 3) void k_stencil3d_res(StencilResArgs a) {
         nmax[j] = 0.0;
     }
     u0c = *reinterpret_cast<const double2*>(a.U + wrapx(x0) + off);
-    const double cI = 3.0 * a.wI[1];
+    const double cI = 3.0 * a.wI[1], cE = EXPL ? 3.0 * a.wE[1] : 0.0;
+    const size_t fstep = (size_t)(EXPL ? 2 : 1) * a.N;  // distance between F[j] and F[j+1]
     for (int p = 0; p < a.xchunk; ++p) {
         const int b = p & 1;
         const int x = x0 + p;
@@ -331,7 +332,17 @@ __global__ __launch_bounds__(256, 3) void k_stencil3d_res(StencilResArgs a) {
                       (a.wI[0] * zm + a.wI[2] * c1) + cI * c0;
             fv[j].y = (a.wI[0] * prev[j].y + a.wI[2] * nxt[j].y) + (a.wI[0] * ym1 + a.wI[2] * yp1) +
                       (a.wI[0] * c0 + a.wI[2] * zp) + cI * c1;
-            *reinterpret_cast<double2*>(a.F + (size_t)(j + 1) * a.N + po) = fv[j];
+            *reinterpret_cast<double2*>(a.F + (size_t)(j + 1) * fstep + po) = fv[j];
+            if (EXPL) {
+                double2 fe;
+                fe.x = (a.wE[0] * prev[j].x + a.wE[2] * nxt[j].x) + (a.wE[0] * ym0 + a.wE[2] * yp0) +
+                       (a.wE[0] * zm + a.wE[2] * c1) + cE * c0;
+                fe.y = (a.wE[0] * prev[j].y + a.wE[2] * nxt[j].y) + (a.wE[0] * ym1 + a.wE[2] * yp1) +
+                       (a.wE[0] * c0 + a.wE[2] * zp) + cE * c1;
+                *reinterpret_cast<double2*>(a.F + (size_t)(j + 1) * fstep + a.N + po) = fe;
+                fv[j].x += fe.x;  // the residual integrates impl + expl (imex_1st_order.py:52)
+                fv[j].y += fe.y;
+            }
         }
 #pragma unroll
         for (int m = 0; m < M; ++m) {

@@ -116,13 +116,18 @@ static int run_stencil(sdc_ctx* c, int nf, const double* const* in, double* cons
 static int eval_nodes(sdc_ctx* c, double dt) {
     const int M = c->M;
     auto three = [](const Stencil& s) { return s.npts == 3 && s.off[0] == -1 && s.off[1] == 0 && s.off[2] == 1; };
-    if (c->fuse_residual && c->ndim == 3 && c->ncomp == 1 && !c->tau_active && c->n % 64 == 0 && M <= 6 &&
-        three(c->st[0])) {
+    const bool expl = c->ncomp == 2 && c->expl_kind == SDC_EXPL_STENCIL;
+    if (c->fuse_residual && c->ndim == 3 && (c->ncomp == 1 || expl) && !c->tau_active && c->n % 64 == 0 &&
+        M <= (expl ? 5 : 6) && three(c->st[0]) && (!expl || three(c->st[1]))) {
         StencilResArgs a;
         memset(&a, 0, sizeof a);
         a.U = c->U;
         a.F = c->F;
-        for (int k = 0; k < 3; ++k) a.wI[k] = c->st[0].w[k];
+        for (int k = 0; k < 3; ++k) {
+            a.wI[k] = c->st[0].w[k];
+            a.wE[k] = expl ? c->st[1].w[k] : 0.0;
+        }
+        a.ncomp = c->ncomp;
         for (int m = 0; m < M; ++m)
             for (int j = 0; j < M; ++j) a.cQ[m][j] = dt * c->Q[m + 1][j + 1];
         a.norms = c->res_dev;
@@ -134,8 +139,11 @@ static int eval_nodes(sdc_ctx* c, double dt) {
         const unsigned grid = (unsigned)((c->n / 64) * (c->n / 8) * a.nchunks);
         {
             LaunchTimer lt(c, pname("stencil_res", M));
-#define RCASE(MM) \
-    case MM: hipLaunchKernelGGL((k_stencil3d_res<MM>), dim3(grid), dim3(256), 0, c->stream, a); break;
+#define RCASE(MM)                                                                                          \
+    case MM:                                                                                               \
+        if (expl) hipLaunchKernelGGL((k_stencil3d_res<MM, true>), dim3(grid), dim3(256), 0, c->stream, a); \
+        else hipLaunchKernelGGL((k_stencil3d_res<MM, false>), dim3(grid), dim3(256), 0, c->stream, a);     \
+        break;
             switch (M) { RCASE(1) RCASE(2) RCASE(3) RCASE(4) RCASE(5) RCASE(6) }
 #undef RCASE
         }

@@ -138,16 +138,22 @@ def test_reuse_and_gather_paths_agree_fullsize():
         e.close()
 
 
-@pytest.mark.parametrize('n', [64, 256])
-def test_fused_residual_matches_separate_kernels(n):
+@pytest.mark.parametrize('n,prob', [(64, 'heat_unforced'), (256, 'heat_unforced'), (64, 'advdiff'), (128, 'advdiff')])
+def test_fused_residual_matches_separate_kernels(n, prob):
     """the sweep's fused eval_f + residual kernel against the separate stencil and residual kernels on the
-    same noisy state (same U by construction; F and the node norms must agree)."""
+    same noisy state (same U by construction; F and the node norms must agree); implicit and IMEX operators."""
     M, dt = 5, 1e-3 * (512.0 / n) ** 2
     c, qi = _coeffs(M, 'LU')
+    qe = None
+    if prob == 'advdiff':
+        from pysdc_amd.coeffs import QDELTA_GENERATORS
+
+        qe = np.zeros_like(c.Qmat)
+        qe[1:, 1:], qe[1:, 0] = QDELTA_GENERATORS['EE'](qGen=c.generator, tLeft=0).genCoeffs(dTau=True)
     out = []
     for fused in (True, False):
-        e = G.engine_for('heat_unforced', dict(nvars=(n, n, n), nu=0.1), M)
-        e.set_coeffs(c.Qmat, qi, None, c.nodes, c.weights)
+        e = G.engine_for(prob, dict(nvars=(n, n, n), nu=0.1), M)
+        e.set_coeffs(c.Qmat, qi, qe, c.nodes, c.weights)
         e.set_fused_residual(fused)
         freq = (C.c_int * 3)(2, 4, 2)
         L.check(e.lib.sdc_init_field(e.ctx, e.ptr(L.SLOT_U, 0), freq, 0.3, 11), e.ctx)
@@ -161,8 +167,9 @@ def test_fused_residual_matches_separate_kernels(n):
     assert np.allclose(na, nb, rtol=1e-9, atol=1e-13) and abs(ra - rb) <= 1e-9 * abs(rb)
     tmp = a.ptr(L.SLOT_UEND)
     for m in range(1, M + 1):
-        a.vec_axpby(a.N, 1.0, a.ptr(L.SLOT_F, m), -1.0, b.ptr(L.SLOT_F, m), tmp)
-        assert a.vec_amax(a.N, tmp) <= 1e-12 * b.vec_amax(b.N, b.ptr(L.SLOT_F, m))
+        for comp in range(a.ncomp):
+            a.vec_axpby(a.N, 1.0, a.ptr(L.SLOT_F, m, comp), -1.0, b.ptr(L.SLOT_F, m, comp), tmp)
+            assert a.vec_amax(a.N, tmp) <= 1e-12 * b.vec_amax(b.N, b.ptr(L.SLOT_F, m, comp))
     # a write through the API invalidates the cached norms
     a.upload(L.SLOT_U, 2, np.zeros((n, n, n)))
     assert abs(a.residual(dt)[1][1] - na[1]) > 1e-6      # node 2's norm is recomputed from the new state
