@@ -14,6 +14,7 @@ struct VdpSweepArgs {
     int maxiter;
     double Q[MAXM][MAXM], QI[MAXM][MAXM];
     unsigned long long* counters;
+    unsigned long long* norms;  // node-wise max of the collocation residual after the sweep, or null
 };
 
 // Newton for u - h f(u) = r with the closed-form 2x2 inverse (Van_der_Pol_implicit.py:131-201)
@@ -47,10 +48,13 @@ __global__ __launch_bounds__(256) void k_vdp_sweep(VdpSweepArgs a) {
 #pragma clang fp contract(off)
     unsigned long long newton = 0, rhs = 0, failed = 0;
     const size_t T = a.T, N = 2 * a.T;
+    double nmax[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) nmax[m] = 0.0;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < T; i += (size_t)gridDim.x * blockDim.x) {
         const double mu = a.mu, dt = a.dt;
         const double u00 = a.U[i], u01 = a.U[T + i];
-        double f0[M], f1[M], g0[M], g1[M];
+        double f0[M], f1[M], g0[M], g1[M], un0[M], un1[M];
 #pragma unroll
         for (int m = 0; m < M; ++m) {
             f0[m] = a.F[(size_t)(m + 1) * N + i];
@@ -96,11 +100,34 @@ __global__ __launch_bounds__(256) void k_vdp_sweep(VdpSweepArgs a) {
             }
             a.U[(size_t)(m + 1) * N + i] = x1;
             a.U[(size_t)(m + 1) * N + T + i] = x2;
+            un0[m] = x1;
+            un1[m] = x2;
             f0[m] = x2;
             f1[m] = mu * (1 - x1 * x1) * x2 - x1;
             a.F[(size_t)(m + 1) * N + i] = f0[m];
             a.F[(size_t)(m + 1) * N + T + i] = f1[m];
             rhs += 1;
+        }
+        if (a.norms) {
+            // collocation residual of the new iterate (core/sweeper.py:186-199), all values still in registers
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                for (int j = 0; j < M; ++j) {
+                    s0 += dt * a.Q[m][j] * f0[j];
+                    s1 += dt * a.Q[m][j] * f1[j];
+                }
+                s0 += u00 - un0[m];
+                s1 += u01 - un1[m];
+                if (a.tau) {
+                    s0 += a.tau[(size_t)m * N + i];
+                    s1 += a.tau[(size_t)m * N + T + i];
+                }
+                const double r0 = fabs(s0), r1 = fabs(s1);
+                const double r = (r0 > r1 || r0 != r0) ? r0 : r1;
+                nmax[m] = (nmax[m] > r || nmax[m] != nmax[m]) ? nmax[m] : r;
+            }
         }
     }
     for (int o = 32; o > 0; o >>= 1) {
@@ -112,6 +139,13 @@ __global__ __launch_bounds__(256) void k_vdp_sweep(VdpSweepArgs a) {
         atomicAdd(a.counters + 0, newton);
         atomicAdd(a.counters + 1, rhs);
         atomicAdd(a.counters + 2, failed);
+    }
+    if (a.norms) {
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const double v = wave_max(nmax[m]);
+            if ((threadIdx.x & 63) == 0) atomic_max_abs(a.norms + m, v);
+        }
     }
 }
 

@@ -934,6 +934,8 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
         a.tol = c->vdp_tol;
         a.maxiter = c->vdp_maxiter;
         a.counters = c->counters;
+        a.norms = c->fuse_residual ? c->res_dev : nullptr;
+        if (a.norms) HIPCHK(c, hipMemsetAsync(c->res_dev, 0, sizeof(unsigned long long) * 8, c->stream));
         for (int m = 0; m < M; ++m)
             for (int j = 0; j < M; ++j) {
                 a.Q[m][j] = c->Q[m + 1][j + 1];
@@ -950,6 +952,10 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
 #undef VCASE
         }
         HIPCHK(c, hipGetLastError());
+        if (a.norms) {
+            c->res_valid = true;
+            c->res_dt = dt;
+        }
         return vdp_check_failures(c);
     }
     if (c->expl_kind == SDC_EXPL_STENCIL && !c->have_stencil[1])
