@@ -41,6 +41,8 @@ def _kernel_bytes(name, n, M, ncomp=1):
         'fft_x_inv': nf * (field + spec),
         'stencil': 2 * nf * field if ncomp == 1 else 3 * nf * field,  # IMEX: one read, impl + expl written
         'stencil_res': (1 + (1 + ncomp) * nf) * field,  # u0 + U[1..M] in, F[1..M] (impl, expl) out, residual norms
+        'res_stencil': (1 + nf) * field,                # same launch with F deferred: u0 + U[1..M] in, norms out
+        'amax': ncomp * field,
         'residual': (1 + M * ncomp + M) * field,        # u0, F[1..M], U[1..M] -> M norms
         'spread': (2 + 2 * M) * field,
         'copy': 2 * field,
@@ -101,6 +103,8 @@ def main():
                     help='use the one-step-per-rank controller and torch.distributed even with one GPU (self test)')
     ap.add_argument('--no-spectral-reuse', action='store_true',
                     help='transform the gathered fields in every sweep instead of gathering on cached transforms')
+    ap.add_argument('--eager-fields', action='store_true',
+                    help='store F[1..M] and the predictor copies in every sweep / predict even when nothing reads them')
     args = ap.parse_args()
 
     import numpy as np
@@ -204,6 +208,7 @@ def main():
     L = step.levels[0]
     eng = L.engine  # allocates the device slabs
     eng.set_spectral_reuse(not args.no_spectral_reuse)
+    eng.set_deferred(not args.eager_fields)
     if args.workload in ('vdp', 'allencahn'):
         u0 = L.prob.u_exact(0.0)
     else:
@@ -267,7 +272,7 @@ def main():
                     'algorithmic_bytes_per_launch': kernel_bytes(dom[0], n, M),
                     'ms_per_launch': dom[1][0] / dom[1][1]}
         in_sweep = ('gather', 'fft_x_fwd', 'fft_y_fwd', 'fft_z_fwd', 'fft_z_solve', 'spec_point', 'fft_z_inv', 'fft_y_inv',
-                    'fft_x_inv', 'stencil', 'stencil_res', 'vdp_sweep')
+                    'fft_x_inv', 'stencil', 'stencil_res', 'res_stencil', 'vdp_sweep')
         sweep_ms = sum(v[0] for k, v in prof.items() if k.split('[')[0] in in_sweep) / max(1, sweeps_total // world)
         out = {
             'metric': {'heat': 'time-steps/s (HeatND 3-D FD, M=5, implicit SDC sweeps)',
@@ -278,7 +283,8 @@ def main():
             'ms_per_step': 1e3 * el / args.steps, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': f'{wl}{fallback_note}, {K} sweeps/step (restol=-1, maxiter={K}), dt={dt:g}, '
-                                   f'solver=direct (Fourier), spectral_reuse={not args.no_spectral_reuse}',
+                                   f'solver=direct (Fourier), spectral_reuse={not args.no_spectral_reuse}, '
+                                   f'deferred_node_fields={not args.eager_fields}',
                        'time_parallel': f'{world} time-slice(s), one per GPU, multi-step SDC (Jacobi)'},
             'sdc_iters_per_s': units * sweeps_total / el,
             'sweep_kernels_ms': sweep_ms,

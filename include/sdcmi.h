@@ -93,6 +93,14 @@ int sdc_set_spectral_reuse(sdc_ctx* ctx, int on);
 /* The 3-D sweep evaluates f at all nodes and the node norms of the collocation residual in ONE kernel; a
  * following sdc_residual with the same dt then returns those norms without another pass (default on). */
 int sdc_set_fused_residual(sdc_ctx* ctx, int on);
+/* Deferred node fields (default on).  The spectral-reuse sweep reads neither F[1..M] nor the M copies a 'spread'
+ * predictor makes (core/sweeper.py:140-146): the engine therefore leaves them unwritten until somebody needs
+ * them.  sdc_slot_ptr / sdc_upload / sdc_download / sdc_integrate / sdc_end_point / sdc_residual and the
+ * non-reuse sweeps bring them up to date themselves; a caller that KEEPS a pointer from sdc_slot_ptr across a
+ * sweep or predict calls sdc_materialize(ctx, slot) (SDC_SLOT_U, SDC_SLOT_F, or -1 for both) before it
+ * dereferences it again.  Values are the ones the reference stores in L.u[m] / L.f[m]. */
+int sdc_set_deferred(sdc_ctx* ctx, int on);
+int sdc_materialize(sdc_ctx* ctx, int slot);
 /* L.status.unlocked: set by sdc_predict; a coarse level is unlocked by the restriction instead
  * (pySDC/core/base_transfer.py:166) - the host mirrors that here. */
 int sdc_set_unlocked(sdc_ctx* ctx, int unlocked); /* default on; 0 = transform the gathered fields every sweep */

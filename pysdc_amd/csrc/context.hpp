@@ -43,6 +43,11 @@ struct sdc_ctx {
     int expl_kind = SDC_EXPL_NONE;
     bool res_spread = false;  // state = spread predictor of an autonomous f: residual_m = dt |sum_j Q[m][j]| max|f(u0)|
     bool fuse_residual = true;
+    // deferred real-space state (sdc_set_deferred): the spectral-reuse sweep reads neither F[1..M] nor the node
+    // copies of a spread predictor, so they are only written when somebody asks for them (sdc_materialize)
+    bool deferred = true;
+    bool spread_pending = false;  // U[1..M] = U[0], F[1..M] = F[0] not stored yet
+    bool f_pending = false;       // F[1..M] = f(U[1..M]) not stored yet
     bool res_valid = false;   // node norms of the residual were produced by the fused stencil kernel
     double res_dt = 0.0;
     unsigned long long* res_dev = nullptr;  // device slots of those norms

@@ -134,6 +134,18 @@ __global__ void k_amax(const double* __restrict__ x, size_t n, unsigned long lon
     if ((threadIdx.x & 63) == 0) atomic_max_abs(slot, m);
 }
 
+// max |x + y| (y may be null): max |f_impl(u0) + f_expl(u0)| for the residual of a deferred spread predictor
+__global__ void k_amax_sum(const double* __restrict__ x, const double* __restrict__ y, size_t n,
+                           unsigned long long* slot) {
+    double m = 0.0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        double v = fabs(y ? x[i] + y[i] : x[i]);
+        m = (m > v || m != m) ? m : v;
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomic_max_abs(slot, m);
+}
+
 __global__ void k_axpby(size_t n, double a, const double* __restrict__ x, double b, const double* __restrict__ y,
                         double* __restrict__ z) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {

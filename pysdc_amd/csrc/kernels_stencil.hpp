@@ -237,7 +237,8 @@ struct StencilResArgs {
     size_t N;
 };
 
-template <int M, bool EXPL>
+// WF = false: F is not stored (deferred, sdc_materialize) - the launch then only reads u0 and U[1..M].
+template <int M, bool EXPL, bool WF>
 __global__ __launch_bounds__(256, EXPL ? 2 : 3) void k_stencil3d_res(StencilResArgs a) {
     // LDS: 2 buffers x M fields x (8+2) rows x 66 doubles = 52.8 KB at M = 5 -> three workgroups per CU
     constexpr int TZ = 64, TY = 8, LW = TZ + 2;
@@ -332,14 +333,14 @@ __global__ __launch_bounds__(256, EXPL ? 2 : 3) void k_stencil3d_res(StencilResA
                       (a.wI[0] * zm + a.wI[2] * c1) + cI * c0;
             fv[j].y = (a.wI[0] * prev[j].y + a.wI[2] * nxt[j].y) + (a.wI[0] * ym1 + a.wI[2] * yp1) +
                       (a.wI[0] * c0 + a.wI[2] * zp) + cI * c1;
-            *reinterpret_cast<double2*>(a.F + (size_t)(j + 1) * fstep + po) = fv[j];
+            if (WF) *reinterpret_cast<double2*>(a.F + (size_t)(j + 1) * fstep + po) = fv[j];
             if (EXPL) {
                 double2 fe;
                 fe.x = (a.wE[0] * prev[j].x + a.wE[2] * nxt[j].x) + (a.wE[0] * ym0 + a.wE[2] * yp0) +
                        (a.wE[0] * zm + a.wE[2] * c1) + cE * c0;
                 fe.y = (a.wE[0] * prev[j].y + a.wE[2] * nxt[j].y) + (a.wE[0] * ym1 + a.wE[2] * yp1) +
                        (a.wE[0] * c0 + a.wE[2] * zp) + cE * c1;
-                *reinterpret_cast<double2*>(a.F + (size_t)(j + 1) * fstep + a.N + po) = fe;
+                if (WF) *reinterpret_cast<double2*>(a.F + (size_t)(j + 1) * fstep + a.N + po) = fe;
                 fv[j].x += fe.x;  // the residual integrates impl + expl (imex_1st_order.py:52)
                 fv[j].y += fe.y;
             }

@@ -112,6 +112,8 @@ static int run_stencil(sdc_ctx* c, int nf, const double* const* in, double* cons
     return SDC_OK;
 }
 
+static int eval_nodes_plain(sdc_ctx* c);
+
 // F[1..M] = A U[1..M] for the new iterate; fused with the residual when the fast 3-D kernel applies
 static int eval_nodes(sdc_ctx* c, double dt) {
     const int M = c->M;
@@ -137,21 +139,35 @@ static int eval_nodes(sdc_ctx* c, double dt) {
         a.nchunks = c->n / a.xchunk;
         HIPCHK(c, hipMemsetAsync(c->res_dev, 0, sizeof(unsigned long long) * 8, c->stream));
         const unsigned grid = (unsigned)((c->n / 64) * (c->n / 8) * a.nchunks);
+        const bool wf = !c->deferred;
         {
-            LaunchTimer lt(c, pname("stencil_res", M));
-#define RCASE(MM)                                                                                          \
-    case MM:                                                                                               \
-        if (expl) hipLaunchKernelGGL((k_stencil3d_res<MM, true>), dim3(grid), dim3(256), 0, c->stream, a); \
-        else hipLaunchKernelGGL((k_stencil3d_res<MM, false>), dim3(grid), dim3(256), 0, c->stream, a);     \
+            LaunchTimer lt(c, pname(wf ? "stencil_res" : "res_stencil", M));
+#define RLAUNCH(MM, EX, WF) \
+    hipLaunchKernelGGL((k_stencil3d_res<MM, EX, WF>), dim3(grid), dim3(256), 0, c->stream, a)
+#define RCASE(MM)                                \
+    case MM:                                     \
+        if (expl && wf) RLAUNCH(MM, true, true); \
+        else if (expl) RLAUNCH(MM, true, false); \
+        else if (wf) RLAUNCH(MM, false, true);   \
+        else RLAUNCH(MM, false, false);          \
         break;
             switch (M) { RCASE(1) RCASE(2) RCASE(3) RCASE(4) RCASE(5) RCASE(6) }
 #undef RCASE
+#undef RLAUNCH
         }
         HIPCHK(c, hipGetLastError());
         c->res_valid = true;
         c->res_dt = dt;
+        c->f_pending = !wf;
         return SDC_OK;
     }
+    return eval_nodes_plain(c);
+}
+
+// F[1..M] = f(U[1..M]) by the plain stencil launch
+static int eval_nodes_plain(sdc_ctx* c) {
+    const int M = c->M;
+    c->f_pending = false;
     const double* in[MAXM];
     double* oi[MAXM];
     double* oe[MAXM];
@@ -690,8 +706,58 @@ static int ensure_tau(sdc_ctx* c) {
     return SDC_OK;
 }
 
+static int launch_spread(sdc_ctx* c, int guess, double fill_u, double fill_f, bool reduce_f0) {
+    SpreadArgs a;
+    memset(&a, 0, sizeof a);
+    a.u0 = c->U;
+    a.f0 = c->F;
+    a.profile = c->profile;
+    a.U = c->U;
+    a.F = c->F;
+    a.N = c->N;
+    a.M = c->M;
+    a.ncomp = c->ncomp;
+    a.guess = guess;
+    a.forcing = c->expl_kind == SDC_EXPL_FORCING;
+    a.fill_u = fill_u;
+    a.fill_f = fill_f;
+    for (int m = 0; m <= c->M; ++m) a.g[m] = c->gvals[m];
+    if (reduce_f0) a.f0max = c->res_dev + 7;
+    {
+        LaunchTimer lt(c, "spread");
+        hipLaunchKernelGGL(k_spread, dim3(grid_for(c->N / 2, 256)), dim3(256), 0, c->stream, a);
+    }
+    HIPCHK(c, hipGetLastError());
+    return SDC_OK;
+}
+
+// bring deferred real-space state up to date before it is read (or partially overwritten)
+static int materialize(sdc_ctx* c, bool need_u, bool need_f) {
+    if (c->spread_pending && (need_u || need_f)) {
+        c->spread_pending = false;
+        c->f_pending = false;
+        return launch_spread(c, SDC_GUESS_SPREAD, 0.0, 0.0, false);
+    }
+    if (c->f_pending && need_f) return eval_nodes_plain(c);
+    return SDC_OK;
+}
+
+int sdc_materialize(sdc_ctx* c, int slot) {
+    if (!c) return SDC_ERR_PARAM;
+    return materialize(c, slot == SDC_SLOT_U || slot < 0, slot == SDC_SLOT_F || slot < 0);
+}
+
+int sdc_set_deferred(sdc_ctx* c, int on) {
+    if (!c) return SDC_ERR_PARAM;
+    c->deferred = on != 0;
+    return on ? SDC_OK : materialize(c, true, true);
+}
+
 void* sdc_slot_ptr(sdc_ctx* c, int slot, int m, int comp) {
     if (!c) return nullptr;
+    // whoever asks for the address of a node field is about to read or write it
+    if (slot == SDC_SLOT_U && materialize(c, true, false) != SDC_OK) return nullptr;
+    if (slot == SDC_SLOT_F && m >= 1 && materialize(c, false, true) != SDC_OK) return nullptr;
     if (slot == SDC_SLOT_TAU && ensure_tau(c) != SDC_OK) return nullptr;
     if (slot == SDC_SLOT_WORK) return c->W;
     return slot_ptr(c, slot, m, comp);
@@ -819,33 +885,24 @@ int sdc_predict(sdc_ctx* c, double t, double dt, int guess, double fill_u, doubl
     if (guess < 0 || guess > 3) return fail(c, SDC_ERR_PARAM, "initial_guess option %d not implemented", guess);
     int rc = sdc_eval_f(c, c->U, c->gvals[0], c->F, c->ncomp == 2 ? c->F + c->N : nullptr);
     if (rc != SDC_OK) return rc;
-    SpreadArgs a;
-    memset(&a, 0, sizeof a);
-    a.u0 = c->U;
-    a.f0 = c->F;
-    a.profile = c->profile;
-    a.U = c->U;
-    a.F = c->F;
-    a.N = c->N;
-    a.M = c->M;
-    a.ncomp = c->ncomp;
-    a.guess = guess;
-    a.forcing = c->expl_kind == SDC_EXPL_FORCING;
-    a.fill_u = fill_u;
-    a.fill_f = fill_f;
-    for (int m = 0; m <= c->M; ++m) a.g[m] = c->gvals[m];
     // all nodes equal u0 and f does not depend on t: every f_j equals f(u0), so the node residuals are
     // dt * |sum_j Q[m][j]| * max|f(u0)| and the fill kernel can reduce max|f(u0)| on the way
     const bool spread_res = guess == SDC_GUESS_SPREAD && c->expl_kind != SDC_EXPL_FORCING && !c->tau_active;
-    if (spread_res) {
-        HIPCHK(c, hipMemsetAsync(c->res_dev, 0, sizeof(unsigned long long) * 8, c->stream));
-        a.f0max = c->res_dev + 7;
+    if (spread_res) HIPCHK(c, hipMemsetAsync(c->res_dev, 0, sizeof(unsigned long long) * 8, c->stream));
+    c->spread_pending = c->f_pending = false;
+    if (c->deferred && c->kind == 0 && guess == SDC_GUESS_SPREAD && c->expl_kind != SDC_EXPL_FORCING) {
+        // the node copies are not stored until somebody reads them (materialize); only max|f(u0)| is needed now
+        if (spread_res) {
+            LaunchTimer lt(c, "amax");
+            hipLaunchKernelGGL(k_amax_sum, dim3(grid_for(c->N, 256)), dim3(256), 0, c->stream, c->F,
+                               c->ncomp == 2 ? c->F + c->N : nullptr, c->N, c->res_dev + 7);
+            HIPCHK(c, hipGetLastError());
+        }
+        c->spread_pending = true;
+    } else {
+        rc = launch_spread(c, guess, fill_u, fill_f, spread_res);
+        if (rc != SDC_OK) return rc;
     }
-    {
-        LaunchTimer lt(c, "spread");
-        hipLaunchKernelGGL(k_spread, dim3(grid_for(c->N / 2, 256)), dim3(256), 0, c->stream, a);
-    }
-    HIPCHK(c, hipGetLastError());
     // 'spread' evaluates f at every node in the reference (core/sweeper.py:142-143); the engine copies F[0]
     if (c->kind == 1 && guess == SDC_GUESS_SPREAD) c->rhs_host += (unsigned long long)c->M * (c->N / 2);
     c->unlocked = true;
@@ -863,6 +920,8 @@ int sdc_predict(sdc_ctx* c, double t, double dt, int guess, double fill_u, doubl
 static int sweep_nodewise(sdc_ctx* c, double dt) {
     const int M = c->M;
     const bool imex = c->ncomp == 2;
+    int rcm = materialize(c, true, true);
+    if (rcm != SDC_OK) return rcm;
     QuadArgs q;
     quad_base(c, q);
     q.u0 = c->U;
@@ -981,6 +1040,8 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
             c->spec0_valid = true;
         }
         if (!c->spec_valid && !c->spec_spread) {
+            int rcm = materialize(c, true, false);
+            if (rcm != SDC_OK) return rcm;
             for (int m = 0; m < M; ++m) p.in[m] = c->U + (size_t)(m + 1) * c->N;
             int rc0 = fwd_transform(c, M, p, c->S, c->Nc);
             if (rc0 != SDC_OK) return rc0;
@@ -1018,10 +1079,15 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
         if (rc0 != SDC_OK) return rc0;
         c->spec_valid = true;
         c->spec_spread = false;
+        c->spread_pending = false;  // U[1..M] hold the new iterate; F follows in eval_nodes
         return eval_nodes(c, dt);
     }
     c->spec_valid = false;
     c->spec_spread = false;
+    {
+        int rcm = materialize(c, false, true);
+        if (rcm != SDC_OK) return rcm;
+    }
     // 1. gather u0 + dt (Q - QI) F_impl + dt (Q - QE) F_expl (+ tau) for all nodes into U[1..M]
     QuadArgs q;
     quad_base(c, q);
@@ -1103,6 +1169,8 @@ int sdc_residual(sdc_ctx* c, double dt, int type, double* node_norms, double* re
         HIPCHK(c, hipMemcpyAsync(c->red + 7, c->res_dev + 7, sizeof(unsigned long long), hipMemcpyDeviceToDevice, c->stream));
         from_spread = true;
     } else {
+        int rcm = materialize(c, true, true);
+        if (rcm != SDC_OK) return rcm;
         QuadArgs q;
         quad_base(c, q);
         q.u0 = c->U;
@@ -1147,7 +1215,10 @@ int sdc_residual(sdc_ctx* c, double dt, int type, double* node_norms, double* re
 int sdc_end_point(sdc_ctx* c, double dt, int do_coll_update) {
     if (!c) return SDC_ERR_PARAM;
     if (!c->have_coeffs) return fail(c, SDC_ERR_STATE, "coefficients not set (sdc_set_coeffs)");
-    if (!do_coll_update) return sdc_vec_copy(c, c->N, c->U + (size_t)c->M * c->N, c->UEND);
+    if (!do_coll_update)  // a pending spread means U[M] equals U[0]
+        return sdc_vec_copy(c, c->N, c->U + (c->spread_pending ? 0 : (size_t)c->M * c->N), c->UEND);
+    int rcm = materialize(c, false, true);
+    if (rcm != SDC_OK) return rcm;
     QuadArgs q;
     quad_base(c, q);
     q.u0 = c->U;
@@ -1162,6 +1233,8 @@ int sdc_end_point(sdc_ctx* c, double dt, int do_coll_update) {
 int sdc_integrate(sdc_ctx* c, double dt, double* const* dst) {
     if (!c || !dst) return fail(c, SDC_ERR_PARAM, "null pointer");
     if (!c->have_coeffs) return fail(c, SDC_ERR_STATE, "coefficients not set (sdc_set_coeffs)");
+    int rcm = materialize(c, false, true);
+    if (rcm != SDC_OK) return rcm;
     QuadArgs q;
     quad_base(c, q);
     for (int m = 0; m < c->M; ++m) {

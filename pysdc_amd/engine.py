@@ -91,6 +91,13 @@ class SweepEngine:
     def set_fused_residual(self, on):
         self._chk(self.lib.sdc_set_fused_residual(self.ctx, int(bool(on))))
 
+    def set_deferred(self, on):
+        """leave F[1..M] / the spread copies unwritten until they are read (include/sdcmi.h: sdc_set_deferred)"""
+        self._chk(self.lib.sdc_set_deferred(self.ctx, int(bool(on))))
+
+    def materialize(self, slot=-1):
+        self._chk(self.lib.sdc_materialize(self.ctx, int(slot)))
+
     def set_unlocked(self, unlocked=True):
         self._chk(self.lib.sdc_set_unlocked(self.ctx, int(bool(unlocked))))
 

@@ -35,10 +35,11 @@ class hip_mesh:
     xp = None
     __array_priority__ = 1000  # ndarray * hip_mesh -> hip_mesh.__rmul__
 
-    def __init__(self, init=None, val=0.0, *, _ptr=None, _shape=None, _keep=None, _on_write=None):
+    def __init__(self, init=None, val=0.0, *, _ptr=None, _shape=None, _keep=None, _on_write=None, _on_access=None):
         self._buf = None
         self._keep = _keep
         self._on_write = _on_write  # slab views tell their level that device state changed
+        self._on_access = _on_access  # ... and ask it to store deferred node fields before the memory is used
         if _ptr is not None:  # non-owning view
             self.shape = tuple(_shape)
             self.size = int(np.prod(self.shape))
@@ -67,9 +68,19 @@ class hip_mesh:
         self.ptr = self._buf.data_ptr()
 
     # ---- views / host access -------------------------------------------------------------------------
+    @property
+    def ptr(self):
+        if self._on_access is not None:
+            self._on_access()
+        return self._p
+
+    @ptr.setter
+    def ptr(self, value):
+        self._p = int(value)
+
     @classmethod
-    def view(cls, ptr, shape, keep=None, on_write=None):
-        return cls(_ptr=ptr, _shape=shape, _keep=keep, _on_write=on_write)
+    def view(cls, ptr, shape, keep=None, on_write=None, on_access=None):
+        return cls(_ptr=ptr, _shape=shape, _keep=keep, _on_write=on_write, _on_access=on_access)
 
     def _wrote(self):
         if self._on_write is not None:
@@ -103,7 +114,7 @@ class hip_mesh:
         return a if dtype is None else a.astype(dtype)
 
     def flatten(self):
-        return hip_mesh.view(self.ptr, (self.size,), keep=self)
+        return hip_mesh.view(self.ptr, (self.size,), keep=self, on_write=self._on_write, on_access=self._on_access)
 
     def as_torch(self):
         """torch tensor aliasing this buffer (for torch.distributed send/recv over RCCL)."""
@@ -136,7 +147,7 @@ class hip_mesh:
     def _new_like(self):
         out = hip_mesh.__new__(type(self))
         out._keep = None
-        out._on_write = None
+        out._on_write = out._on_access = None
         out.shape, out.size = self.shape, self.size
         hip_mesh._alloc(out)
         return out
@@ -247,9 +258,9 @@ class hip_imex_mesh:
         self.shape = (2,) + self.impl.shape
 
     @classmethod
-    def view(cls, ptr_impl, ptr_expl, shape, keep=None, on_write=None):
-        return cls(_parts=(hip_mesh.view(ptr_impl, shape, keep, on_write),
-                           hip_mesh.view(ptr_expl, shape, keep, on_write)))
+    def view(cls, ptr_impl, ptr_expl, shape, keep=None, on_write=None, on_access=None):
+        return cls(_parts=(hip_mesh.view(ptr_impl, shape, keep, on_write, on_access),
+                           hip_mesh.view(ptr_expl, shape, keep, on_write, on_access)))
 
     def get(self):
         return np.stack([self.impl.get(), self.expl.get()])

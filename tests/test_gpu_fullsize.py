@@ -175,3 +175,71 @@ def test_fused_residual_matches_separate_kernels(n, prob):
     assert abs(a.residual(dt)[1][1] - na[1]) > 1e-6      # node 2's norm is recomputed from the new state
     for e, _, _ in out:
         e.close()
+
+
+@pytest.mark.parametrize('n,prob', [(64, 'heat_unforced'), (128, 'heat_unforced'), (64, 'advdiff')])
+def test_deferred_node_fields_match_eager(n, prob):
+    """sdc_set_deferred: the sweep that does not store F[1..M] / the predictor that does not store the node
+    copies must hand out the same bits as the eager engine once the fields are asked for, at every stage."""
+    M, dt = 5, 1e-3 * (512.0 / n) ** 2
+    c, qi = _coeffs(M, 'IE')
+    qe = None
+    if prob == 'advdiff':
+        from pysdc_amd.coeffs import QDELTA_GENERATORS
+
+        qe = np.zeros_like(c.Qmat)
+        qe[1:, 1:], qe[1:, 0] = QDELTA_GENERATORS['EE'](qGen=c.generator, tLeft=0).genCoeffs(dTau=True)
+    engines = []
+    for deferred in (True, False):
+        e = G.engine_for(prob, dict(nvars=(n, n, n), nu=0.1), M)
+        e.set_coeffs(c.Qmat, qi, qe, c.nodes, c.weights)
+        e.set_deferred(deferred)
+        freq = (C.c_int * 3)(2, 4, 2)
+        L.check(e.lib.sdc_init_field(e.ctx, e.ptr(L.SLOT_U, 0), freq, 0.3, 5), e.ctx)
+        e.invalidate_spectra(1)
+        engines.append(e)
+    a, b = engines
+
+    def same(stage, slots=('u', 'f')):
+        if 'u' in slots:
+            assert np.array_equal(a.download_u(), b.download_u()), stage
+        if 'f' in slots:
+            assert np.array_equal(a.download_f(), b.download_f()), stage
+
+    for e in engines:
+        e.predict(0.0, dt)
+    ra, rb = a.residual(dt), b.residual(dt)
+    assert ra[0] == rb[0] and np.array_equal(ra[1], rb[1])
+    for e in engines:
+        e.end_point(dt, False)                      # pending spread: uend = u0
+    assert np.array_equal(a.download(L.SLOT_UEND), b.download(L.SLOT_UEND))
+    for e in engines:
+        e.sweep(0.0, dt)                            # first sweep straight from the pending spread
+    ra, rb = a.residual(dt), b.residual(dt)
+    assert ra[0] == rb[0] and np.array_equal(ra[1], rb[1])
+    same('sweep 1', ('f',))                          # F asked for first ...
+    same('sweep 1')                                  # ... and again together with U
+    for e in engines:
+        e.sweep(0.0, dt)
+        e.end_point(dt, True)                       # the collocation update integrates F
+    assert np.array_equal(a.download(L.SLOT_UEND), b.download(L.SLOT_UEND))
+    for e in engines:
+        e.sweep(0.0, dt)
+    for e in engines:
+        e.integrate(dt, [e.ptr(L.SLOT_TAU, m) for m in range(M)])
+    for m in range(M):
+        assert np.array_equal(a.download(L.SLOT_TAU, m), b.download(L.SLOT_TAU, m))
+    same('sweep 3')
+    # a predictor whose copies are still pending when U[0] is replaced keeps the OLD u0 at the nodes
+    for e in engines:
+        e.predict(0.0, dt)
+        e.upload(L.SLOT_U, 0, np.full((n, n, n), 0.25))
+    same('u0 replaced after predict')
+    # switching the mode off stores whatever is pending
+    for e in engines:
+        e.predict(0.0, dt)
+        e.sweep(0.0, dt)
+    a.set_deferred(False)
+    same('mode switched off')
+    for e in engines:
+        e.close()

@@ -273,3 +273,36 @@ def test_dirichlet_1d_sweeps_vs_golden(fname, name, fused):
     for k in range(1, meta['nsweeps'] + 1):
         L.sweep.update_nodes()
         check(f'k{k}')
+
+
+def test_views_kept_across_sweeps_see_current_values():
+    """the engine defers storing F[1..M] and the predictor's node copies (sdc_set_deferred); a view taken once
+    and read later must still show what the reference's L.f[m] / L.u[m] would hold at that moment."""
+    from pysdc_amd.level import Step
+    from pysdc_amd.problems import heatNd_unforced
+    from pysdc_amd.sweepers import generic_implicit
+
+    n = 64
+    desc = dict(problem_class=heatNd_unforced, problem_params=dict(nvars=(n, n, n), nu=0.1, freq=(2, 2, 2)),
+                sweeper_class=generic_implicit,
+                sweeper_params=dict(num_nodes=3, quad_type='RADAU-RIGHT', QI='LU'),
+                level_params=dict(dt=1e-2), step_params=dict(maxiter=4))
+    out = []
+    for deferred in (True, False):
+        S = Step(desc)
+        L = S.levels[0]
+        L.status.time = 0.0
+        L.u[0] = L.prob.u_exact(0.0)
+        L.engine.set_deferred(deferred)
+        L.sweep.predict()
+        u2, f2 = L.u[2], L.f[2]                  # views taken while the spread is still pending
+        seen = [u2.get(), f2.get()]
+        L.sweep.update_nodes()
+        L.sweep.compute_residual()
+        seen += [abs(f2), u2.get(), L.status.residual]
+        L.sweep.update_nodes()
+        g = f2 + f2                               # arithmetic on a kept view
+        seen += [g.get(), (2.0 * L.f[3]).get()]
+        out.append(seen)
+    for x, y in zip(*out):
+        assert np.array_equal(np.asarray(x), np.asarray(y))
