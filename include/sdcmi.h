@@ -97,10 +97,13 @@ int sdc_set_fused_residual(sdc_ctx* ctx, int on);
  * predictor makes (core/sweeper.py:140-146): the engine therefore leaves them unwritten until somebody needs
  * them.  sdc_slot_ptr / sdc_upload / sdc_download / sdc_integrate / sdc_end_point / sdc_residual and the
  * non-reuse sweeps bring them up to date themselves; a caller that KEEPS a pointer from sdc_slot_ptr across a
- * sweep or predict calls sdc_materialize(ctx, slot) (SDC_SLOT_U, SDC_SLOT_F, or -1 for both) before it
- * dereferences it again.  Values are the ones the reference stores in L.u[m] / L.f[m]. */
+ * sweep or predict calls sdc_materialize(ctx, slot, m) (slot = SDC_SLOT_U, SDC_SLOT_F, or -1 for both; m = the
+ * node it is about to touch, -1 for all) before it dereferences it again.  Values are the ones the reference
+ * stores in L.u[m] / L.f[m].  With the mode on, sweeps that gather on the cached transforms do not leave Fourier
+ * space at all: they return the node norms of the collocation residual (reduced from the inverse transform of
+ * its spectrum) and keep U[1..M] in the cache; sdc_end_point transforms only the last node. */
 int sdc_set_deferred(sdc_ctx* ctx, int on);
-int sdc_materialize(sdc_ctx* ctx, int slot);
+int sdc_materialize(sdc_ctx* ctx, int slot, int m);
 /* L.status.unlocked: set by sdc_predict; a coarse level is unlocked by the restriction instead
  * (pySDC/core/base_transfer.py:166) - the host mirrors that here. */
 int sdc_set_unlocked(sdc_ctx* ctx, int unlocked); /* default on; 0 = transform the gathered fields every sweep */

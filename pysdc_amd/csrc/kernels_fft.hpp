@@ -73,11 +73,13 @@ __global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_fwd(FieldPtr
     }
 }
 
-// c2r along axis 0 (inverse of the above, unnormalised)
-template <int N, int T>
+// c2r along axis 0 (inverse of the above, unnormalised).  NORM: the real field is not stored, only max |.| per
+// field goes to norms[field] (the fields are the collocation residuals of the spectral sweep).
+template <int N, int T, bool NORM>
 __global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_inv(FieldPtrs p, const cd* __restrict__ W,
                                                                       size_t fstride, int rest,
-                                                                      const cd* __restrict__ tw) {
+                                                                      const cd* __restrict__ tw,
+                                                                      unsigned long long* __restrict__ norms) {
     constexpr int E = fft_elems(N), P = N / E;
     using LAY = LayStrided<N, T>;
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -129,10 +131,23 @@ __global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_inv(FieldPtr
         __syncthreads();
     }
     fft_line<N, +1, LAY>(r, j, col, lds, tw);
-    double* __restrict__ out = p.out[blockIdx.y];
-    if (ok) {
+    if constexpr (NORM) {
+        double m = 0.0;  // columns beyond the edge were transformed from zeros
 #pragma unroll
-        for (int i = 0; i < E; ++i) *reinterpret_cast<cd*>(out + (size_t)(j + i * P) * rest + 2 * (size_t)c) = r[i];
+        for (int i = 0; i < E; ++i) {
+            const double v0 = fabs(r[i].x), v1 = fabs(r[i].y);
+            const double v = (v0 > v1 || v0 != v0) ? v0 : v1;
+            m = (m > v || m != m) ? m : v;
+        }
+        m = wave_max(m);
+        if ((threadIdx.x & 63) == 0) atomic_max_abs(norms + blockIdx.y, m);
+    } else {
+        double* __restrict__ out = p.out[blockIdx.y];
+        if (ok) {
+#pragma unroll
+            for (int i = 0; i < E; ++i)
+                *reinterpret_cast<cd*>(out + (size_t)(j + i * P) * rest + 2 * (size_t)c) = r[i];
+        }
     }
 }
 
@@ -296,12 +311,16 @@ struct SpecArgs {
     const cd *tw, *lamI, *lamE;
     double gI[MAXM][MAXM], gE[MAXM][MAXM];  // dt (Q - QI), dt (Q - QE), inner MxM blocks
     double cI[MAXM][MAXM], cE[MAXM][MAXM], alpha[MAXM];
+    double rQ[MAXM][MAXM];  // dt Q, inner MxM block (RES)
     double invN;
     int nf, ndim, coupled, spread;
 };
 
-// one thread per Fourier mode: gather on the cached transforms + node-coupled solve, S updated in place
-template <int NF>
+// one thread per Fourier mode: gather on the cached transforms + node-coupled solve, S updated in place.
+// RES: the transform of the collocation residual of the NEW iterate, u0 - u_m + dt sum_j Q[m][j] f(u_j)
+// (core/sweeper.py:186-199 with f(u) = (A + B) u), goes to W[m]; its inverse transform only has to be reduced
+// to a max norm, so neither U[1..M] nor F[1..M] are needed in real space to continue sweeping.
+template <int NF, bool RES>
 __global__ __launch_bounds__(256) void k_spec_point(SpecArgs a, int n, size_t nmodes) {
     for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < nmodes; g += (size_t)gridDim.x * blockDim.x) {
         const int kz = (int)(g % n);
@@ -338,6 +357,19 @@ __global__ __launch_bounds__(256) void k_spec_point(SpecArgs a, int n, size_t nm
             const double al = a.alpha[m];
             u[m] = cmul(acc, cinv_fast(cd{1.0 - al * lam.x, -al * lam.y}));
             a.S[m * a.fstride + g] = u[m];
+        }
+        if constexpr (RES) {
+            const cd sym = cadd(lam, mu);
+#pragma unroll
+            for (int m = 0; m < NF; ++m) {
+                cd acc = csub(u0h, u[m]);
+#pragma unroll
+                for (int q = 0; q < NF; ++q) {
+                    const double rq = a.rQ[m][q];
+                    acc = cfma(cd{rq * sym.x, rq * sym.y}, u[q], acc);
+                }
+                a.W[m * a.fstride + g] = acc;
+            }
         }
     }
 }

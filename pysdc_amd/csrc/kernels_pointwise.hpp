@@ -21,7 +21,10 @@ struct QuadArgs {
 
 __device__ inline void atomic_max_abs(unsigned long long* slot, double v) {
     // |v| >= 0: IEEE order == unsigned order of the bit pattern; NaN (0x7ff8...) wins, like np.max
-    atomicMax(slot, (unsigned long long)__double_as_longlong(fabs(v)));
+    // The slot only grows: a relaxed read first keeps the millions of waves that cannot raise it away from
+    // the read-modify-write queue of that one address.
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(fabs(v));
+    if (bits > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, bits);
 }
 
 __device__ inline double wave_max(double v) {

@@ -236,8 +236,8 @@ static int fft_pipeline_n(sdc_ctx* c, int nf, const FieldPtrs& p, ZArgs& z) {
                                c->stream, c->W, c->Nc, c->tw);
         }
         LaunchTimer lt(c, pname("fft_x_inv", nf));
-        hipLaunchKernelGGL((k_fftx_inv<N, T>), dim3(tiles, nf), dim3(P * T), lds_str, c->stream, p, c->W, c->Nc, rest,
-                           c->tw);
+        hipLaunchKernelGGL((k_fftx_inv<N, T, false>), dim3(tiles, nf), dim3(P * T), lds_str, c->stream, p, c->W, c->Nc,
+                           rest, c->tw, nullptr);
     }
     HIPCHK(c, hipGetLastError());
     return SDC_OK;
@@ -277,47 +277,67 @@ static int fwd_transform_n(sdc_ctx* c, int nf, const FieldPtrs& p, cd* dst, size
     return SDC_OK;
 }
 
-// spectral sweep + inverse passes into out[f]
+// inverse transform of nf fully transformed spectra src[f] (src + f*Nc) through the work buffer work[f]
+// (work may equal src: in place) into the real fields out[f] - or, with norms != null, into max |.| per field
 template <int N>
-static int spec_sweep_n(sdc_ctx* c, int nf, SpecArgs& a, const FieldPtrs& p) {
+static int inverse_passes_n(sdc_ctx* c, int nf, const cd* src, cd* work, const FieldPtrs& p, unsigned long long* norms,
+                            double scale) {
     constexpr int E = fft_elems(N), P = N / E, T = N >= 2048 ? 4 : 8, LPB = z_lines_per_block<N>();
-    constexpr int NCH = E == 16 ? 2 : 1;
     const size_t lds_str = (size_t)LayStrided<N, T>::doubles(T) * sizeof(double);
     const int n = c->n;
     const size_t lines = c->ndim == 1 ? 1 : (size_t)(n / 2 + 1) * (c->ndim == 3 ? n : 1);
     {
-        LaunchTimer lt(c, pname("spec_point", nf));
-        const size_t nmodes = lines * N;
-        const dim3 grid(grid_for(nmodes, 256));
-#define SCASE(MM) \
-    case MM: hipLaunchKernelGGL((k_spec_point<MM>), grid, dim3(256), 0, c->stream, a, n, nmodes); break;
-        switch (nf) { SCASE(1) SCASE(2) SCASE(3) SCASE(4) SCASE(5) SCASE(6) SCASE(7) SCASE(8) }
-#undef SCASE
-    }
-    {
         LaunchTimer lt(c, pname("fft_z_inv", nf));
         const size_t ldsz = (size_t)LayContig<N>::doubles(nf * LPB) * sizeof(double);
         hipLaunchKernelGGL((k_fftz_plain<N, +1>), dim3((unsigned)((lines + LPB - 1) / LPB)), dim3(P * LPB * nf), ldsz,
-                           c->stream, c->S, c->W, c->Nc, c->tw, (unsigned)lines, a.invN);
+                           c->stream, src, work, c->Nc, c->tw, (unsigned)lines, scale);
     }
-    (void)NCH;
     if (c->ndim == 1) {
+        if (norms) return fail(c, SDC_ERR_UNSUPPORTED, "norm-only inverse transform in 1-D");
         LaunchTimer lt(c, pname("realpart", nf));
-        hipLaunchKernelGGL(k_realpart, dim3(grid_for(c->N, 256), nf), dim3(256), 0, c->stream, p, c->W, c->N);
+        hipLaunchKernelGGL(k_realpart, dim3(grid_for(c->N, 256), nf), dim3(256), 0, c->stream, p, work, c->N);
     } else {
         const int rest = (int)(c->N / n);
         const int tiles = (rest / 2 + T - 1) / T;
         if (c->ndim == 3) {
             LaunchTimer lt(c, pname("fft_y_inv", nf));
             hipLaunchKernelGGL((k_ffty<N, T, +1>), dim3((n + T - 1) / T, n / 2 + 1, nf), dim3(P * T), lds_str, c->stream,
-                               c->W, c->Nc, c->tw);
+                               work, c->Nc, c->tw);
         }
-        LaunchTimer lt(c, pname("fft_x_inv", nf));
-        hipLaunchKernelGGL((k_fftx_inv<N, T>), dim3(tiles, nf), dim3(P * T), lds_str, c->stream, p, c->W, c->Nc, rest,
-                           c->tw);
+        if (norms) {
+            LaunchTimer lt(c, pname("fft_x_norm", nf));
+            hipLaunchKernelGGL((k_fftx_inv<N, T, true>), dim3(tiles, nf), dim3(P * T), lds_str, c->stream, p, work, c->Nc,
+                               rest, c->tw, norms);
+        } else {
+            LaunchTimer lt(c, pname("fft_x_inv", nf));
+            hipLaunchKernelGGL((k_fftx_inv<N, T, false>), dim3(tiles, nf), dim3(P * T), lds_str, c->stream, p, work,
+                               c->Nc, rest, c->tw, nullptr);
+        }
     }
     HIPCHK(c, hipGetLastError());
     return SDC_OK;
+}
+
+// spectral sweep; then either the inverse passes into out[f], or (norms != null) only the node norms of the
+// collocation residual of the new iterate
+template <int N>
+static int spec_sweep_n(sdc_ctx* c, int nf, SpecArgs& a, const FieldPtrs& p, unsigned long long* norms) {
+    const int n = c->n;
+    const size_t lines = c->ndim == 1 ? 1 : (size_t)(n / 2 + 1) * (c->ndim == 3 ? n : 1);
+    {
+        LaunchTimer lt(c, pname(norms ? "spec_point_res" : "spec_point", nf));
+        const size_t nmodes = lines * N;
+        const dim3 grid(grid_for(nmodes, 256));
+#define SCASE(MM)                                                                                             \
+    case MM:                                                                                                  \
+        if (norms) hipLaunchKernelGGL((k_spec_point<MM, true>), grid, dim3(256), 0, c->stream, a, n, nmodes); \
+        else hipLaunchKernelGGL((k_spec_point<MM, false>), grid, dim3(256), 0, c->stream, a, n, nmodes);      \
+        break;
+        switch (nf) { SCASE(1) SCASE(2) SCASE(3) SCASE(4) SCASE(5) SCASE(6) SCASE(7) SCASE(8) }
+#undef SCASE
+    }
+    HIPCHK(c, hipGetLastError());
+    return inverse_passes_n<N>(c, nf, norms ? c->W : c->S, c->W, p, norms, a.invN);
 }
 
 #define N_DISPATCH(c, CALL)                                                                                 \
@@ -341,13 +361,22 @@ static int fwd_transform(sdc_ctx* c, int nf, const FieldPtrs& p, cd* dst, size_t
     N_DISPATCH(c, CALL)
 #undef CALL
 }
-static int spec_sweep(sdc_ctx* c, int nf, SpecArgs& a, const FieldPtrs& p) {
+static int spec_sweep(sdc_ctx* c, int nf, SpecArgs& a, const FieldPtrs& p, unsigned long long* norms) {
     {
         int rw = ensure_work(c);
         if (rw != SDC_OK) return rw;
         a.W = c->W;
     }
-#define CALL(NN) spec_sweep_n<NN>(c, nf, a, p)
+#define CALL(NN) spec_sweep_n<NN>(c, nf, a, p, norms)
+    N_DISPATCH(c, CALL)
+#undef CALL
+}
+// real fields out[f] from the cached spectra S[first .. first + nf)
+static int inverse_from_cache(sdc_ctx* c, int first, int nf, const FieldPtrs& p) {
+    int rw = ensure_work(c);
+    if (rw != SDC_OK) return rw;
+    const double invN = 1.0 / (double)c->N;
+#define CALL(NN) inverse_passes_n<NN>(c, nf, c->S + (size_t)first * c->Nc, c->W, p, nullptr, invN)
     N_DISPATCH(c, CALL)
 #undef CALL
 }
@@ -738,12 +767,25 @@ static int materialize(sdc_ctx* c, bool need_u, bool need_f) {
         c->f_pending = false;
         return launch_spread(c, SDC_GUESS_SPREAD, 0.0, 0.0, false);
     }
+    if (c->u_pending && (need_u || (need_f && c->f_pending))) {
+        FieldPtrs p;
+        memset(&p, 0, sizeof p);
+        for (int m = 0; m < c->M; ++m) p.out[m] = c->U + (size_t)(m + 1) * c->N;
+        c->u_pending = false;
+        int rc = inverse_from_cache(c, 0, c->M, p);
+        if (rc != SDC_OK) return rc;
+    }
     if (c->f_pending && need_f) return eval_nodes_plain(c);
     return SDC_OK;
 }
 
-int sdc_materialize(sdc_ctx* c, int slot) {
+int sdc_materialize(sdc_ctx* c, int slot, int m) {
     if (!c) return SDC_ERR_PARAM;
+    if (slot == SDC_SLOT_U && m == 0) {  // U[0] itself is never deferred, but a pending spread still reads it
+        if (!c->spread_pending) return SDC_OK;
+        return materialize(c, true, false);
+    }
+    if (slot == SDC_SLOT_F && m == 0) return SDC_OK;
     return materialize(c, slot == SDC_SLOT_U || slot < 0, slot == SDC_SLOT_F || slot < 0);
 }
 
@@ -756,8 +798,7 @@ int sdc_set_deferred(sdc_ctx* c, int on) {
 void* sdc_slot_ptr(sdc_ctx* c, int slot, int m, int comp) {
     if (!c) return nullptr;
     // whoever asks for the address of a node field is about to read or write it
-    if (slot == SDC_SLOT_U && materialize(c, true, false) != SDC_OK) return nullptr;
-    if (slot == SDC_SLOT_F && m >= 1 && materialize(c, false, true) != SDC_OK) return nullptr;
+    if ((slot == SDC_SLOT_U || slot == SDC_SLOT_F) && sdc_materialize(c, slot, m) != SDC_OK) return nullptr;
     if (slot == SDC_SLOT_TAU && ensure_tau(c) != SDC_OK) return nullptr;
     if (slot == SDC_SLOT_WORK) return c->W;
     return slot_ptr(c, slot, m, comp);
@@ -765,6 +806,8 @@ void* sdc_slot_ptr(sdc_ctx* c, int slot, int m, int comp) {
 
 int sdc_invalidate_spectra(sdc_ctx* c, int which) {
     if (!c) return SDC_ERR_PARAM;
+    if ((which & 2) && c->u_pending)
+        return fail(c, SDC_ERR_STATE, "U[1..M] were deferred: sdc_materialize before writing through a kept pointer");
     c->res_valid = false;
     c->res_spread = false;
     if (which & 1) {
@@ -794,6 +837,8 @@ int sdc_set_unlocked(sdc_ctx* c, int unlocked) {
 
 int sdc_set_spectral_reuse(sdc_ctx* c, int on) {
     if (!c) return SDC_ERR_PARAM;
+    int rcm = materialize(c, true, false);  // the cache may be the only holder of U[1..M]
+    if (rcm != SDC_OK) return rcm;
     c->reuse = on != 0;
     c->spec_valid = c->spec0_valid = c->spec_spread = false;
     return SDC_OK;
@@ -889,7 +934,7 @@ int sdc_predict(sdc_ctx* c, double t, double dt, int guess, double fill_u, doubl
     // dt * |sum_j Q[m][j]| * max|f(u0)| and the fill kernel can reduce max|f(u0)| on the way
     const bool spread_res = guess == SDC_GUESS_SPREAD && c->expl_kind != SDC_EXPL_FORCING && !c->tau_active;
     if (spread_res) HIPCHK(c, hipMemsetAsync(c->res_dev, 0, sizeof(unsigned long long) * 8, c->stream));
-    c->spread_pending = c->f_pending = false;
+    c->spread_pending = c->f_pending = c->u_pending = false;
     if (c->deferred && c->kind == 0 && guess == SDC_GUESS_SPREAD && c->expl_kind != SDC_EXPL_FORCING) {
         // the node copies are not stored until somebody reads them (materialize); only max|f(u0)| is needed now
         if (spread_res) {
@@ -1075,19 +1120,35 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
             }
         }
         a.coupled = coupled;
-        int rc0 = spec_sweep(c, M, a, p);
+        // nothing downstream needs the node values in real space to keep sweeping: only the node norms of the
+        // residual are produced (from its transform), U and F stay deferred
+        const bool norms_only = c->deferred && c->fuse_residual && c->ndim >= 2;
+        if (norms_only) {
+            for (int m = 0; m < M; ++m)
+                for (int j = 0; j < M; ++j) a.rQ[m][j] = dt * c->Q[m + 1][j + 1];
+            HIPCHK(c, hipMemsetAsync(c->res_dev, 0, sizeof(unsigned long long) * 8, c->stream));
+        }
+        int rc0 = spec_sweep(c, M, a, p, norms_only ? c->res_dev : nullptr);
         if (rc0 != SDC_OK) return rc0;
         c->spec_valid = true;
         c->spec_spread = false;
-        c->spread_pending = false;  // U[1..M] hold the new iterate; F follows in eval_nodes
+        c->spread_pending = false;
+        if (norms_only) {
+            c->u_pending = c->f_pending = true;
+            c->res_valid = true;
+            c->res_dt = dt;
+            return SDC_OK;
+        }
+        c->u_pending = false;  // U[1..M] hold the new iterate; F follows in eval_nodes
         return eval_nodes(c, dt);
+    }
+    {
+        int rcm = materialize(c, false, true);  // the gather reads F[1..M]
+        if (rcm != SDC_OK) return rcm;
     }
     c->spec_valid = false;
     c->spec_spread = false;
-    {
-        int rcm = materialize(c, false, true);
-        if (rcm != SDC_OK) return rcm;
-    }
+    c->u_pending = false;  // U[1..M] are overwritten below
     // 1. gather u0 + dt (Q - QI) F_impl + dt (Q - QE) F_expl (+ tau) for all nodes into U[1..M]
     QuadArgs q;
     quad_base(c, q);
@@ -1215,8 +1276,16 @@ int sdc_residual(sdc_ctx* c, double dt, int type, double* node_norms, double* re
 int sdc_end_point(sdc_ctx* c, double dt, int do_coll_update) {
     if (!c) return SDC_ERR_PARAM;
     if (!c->have_coeffs) return fail(c, SDC_ERR_STATE, "coefficients not set (sdc_set_coeffs)");
-    if (!do_coll_update)  // a pending spread means U[M] equals U[0]
+    if (!do_coll_update) {
+        if (c->u_pending && !c->spread_pending) {  // only the last node is needed: transform it straight into UEND
+            FieldPtrs p;
+            memset(&p, 0, sizeof p);
+            p.out[0] = c->UEND;
+            return inverse_from_cache(c, c->M - 1, 1, p);
+        }
+        // a pending spread means U[M] equals U[0]
         return sdc_vec_copy(c, c->N, c->U + (c->spread_pending ? 0 : (size_t)c->M * c->N), c->UEND);
+    }
     int rcm = materialize(c, false, true);
     if (rcm != SDC_OK) return rcm;
     QuadArgs q;

@@ -95,8 +95,8 @@ class SweepEngine:
         """leave F[1..M] / the spread copies unwritten until they are read (include/sdcmi.h: sdc_set_deferred)"""
         self._chk(self.lib.sdc_set_deferred(self.ctx, int(bool(on))))
 
-    def materialize(self, slot=-1):
-        self._chk(self.lib.sdc_materialize(self.ctx, int(slot)))
+    def materialize(self, slot=-1, m=-1):
+        self._chk(self.lib.sdc_materialize(self.ctx, int(slot), int(m)))
 
     def set_unlocked(self, unlocked=True):
         self._chk(self.lib.sdc_set_unlocked(self.ctx, int(bool(unlocked))))

@@ -67,7 +67,7 @@ class SlabList:
             cb = lambda slot=self._slot, m=m: self._L._touched(slot, m)  # noqa: E731
             acc = None
             if self._slot in (Lb.SLOT_U, Lb.SLOT_F):  # node fields may be deferred (sdc_materialize)
-                acc = lambda slot=self._slot: e.materialize(slot)  # noqa: E731
+                acc = lambda slot=self._slot, m=m: e.materialize(slot, m)  # noqa: E731
             off = 8 * self._L._view_offset()
             if self._imex:
                 self._views[m] = hip_imex_mesh.view(e.ptr(self._slot, m, 0) + off, e.ptr(self._slot, m, 1) + off, shape,

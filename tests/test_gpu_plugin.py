@@ -304,5 +304,8 @@ def test_views_kept_across_sweeps_see_current_values():
         g = f2 + f2                               # arithmetic on a kept view
         seen += [g.get(), (2.0 * L.f[3]).get()]
         out.append(seen)
-    for x, y in zip(*out):
-        assert np.array_equal(np.asarray(x), np.asarray(y))
+    for i, (x, y) in enumerate(zip(*out)):
+        if i == 4:   # the residual: deferred mode reduces it from its Fourier transform (round-off level change)
+            assert abs(x - y) <= 1e-9 * abs(y)
+        else:
+            assert np.array_equal(np.asarray(x), np.asarray(y)), i
