@@ -9,6 +9,12 @@
 //   c2c FFT along the contiguous axis + node-coupled solve + inverse, all M nodes of one line per workgroup
 //   inverse axis 1, inverse axis 0 (c2r)                     -> U[1..M]
 //   stencil A*U[m] (+ explicit stencil)                      -> F[1..M]
+#ifndef SDC_T1024
+#define SDC_T1024 8
+#endif
+#ifndef SDC_SPEC_GRID
+#define SDC_SPEC_GRID 4096
+#endif
 #include "context.hpp"
 #include "kernels_pointwise.hpp"
 #include "kernels_stencil.hpp"
@@ -184,7 +190,7 @@ static int eval_nodes_plain(sdc_ctx* c) {
 template <int N>
 static int fft_pipeline_n(sdc_ctx* c, int nf, const FieldPtrs& p, ZArgs& z) {
     constexpr int E = fft_elems(N), P = N / E;
-    constexpr int T = N >= 2048 ? 4 : 8;  // complex columns per strided tile (128-byte row segments up to N = 1024)
+    constexpr int T = N >= 2048 ? 4 : (N == 1024 ? SDC_T1024 : 8);  // complex columns per strided tile (128-byte row segments up to N = 1024)
     const size_t lds_str = (size_t)LayStrided<N, T>::doubles(T) * sizeof(double);
     const int n = c->n;
     z.W = c->W;
@@ -246,7 +252,7 @@ static int fft_pipeline_n(sdc_ctx* c, int nf, const FieldPtrs& p, ZArgs& z) {
 // forward transform of nf real fields into fully transformed spectra dst[f] (dst + f*fstride)
 template <int N>
 static int fwd_transform_n(sdc_ctx* c, int nf, const FieldPtrs& p, cd* dst, size_t fstride) {
-    constexpr int E = fft_elems(N), P = N / E, T = N >= 2048 ? 4 : 8, LPB = z_lines_per_block<N>();
+    constexpr int E = fft_elems(N), P = N / E, T = N >= 2048 ? 4 : (N == 1024 ? SDC_T1024 : 8), LPB = z_lines_per_block<N>();
     const size_t lds_str = (size_t)LayStrided<N, T>::doubles(T) * sizeof(double);
     const int n = c->n;
     size_t lines;
@@ -282,7 +288,7 @@ static int fwd_transform_n(sdc_ctx* c, int nf, const FieldPtrs& p, cd* dst, size
 template <int N>
 static int inverse_passes_n(sdc_ctx* c, int nf, const cd* src, cd* work, const FieldPtrs& p, unsigned long long* norms,
                             double scale) {
-    constexpr int E = fft_elems(N), P = N / E, T = N >= 2048 ? 4 : 8, LPB = z_lines_per_block<N>();
+    constexpr int E = fft_elems(N), P = N / E, T = N >= 2048 ? 4 : (N == 1024 ? SDC_T1024 : 8), LPB = z_lines_per_block<N>();
     const size_t lds_str = (size_t)LayStrided<N, T>::doubles(T) * sizeof(double);
     const int n = c->n;
     const size_t lines = c->ndim == 1 ? 1 : (size_t)(n / 2 + 1) * (c->ndim == 3 ? n : 1);
@@ -327,7 +333,9 @@ static int spec_sweep_n(sdc_ctx* c, int nf, SpecArgs& a, const FieldPtrs& p, uns
     {
         LaunchTimer lt(c, pname(norms ? "spec_point_res" : "spec_point", nf));
         const size_t nmodes = lines * N;
-        const dim3 grid(grid_for(nmodes, 256));
+        size_t gblocks = (nmodes + 255) / 256;
+        if (gblocks > SDC_SPEC_GRID) gblocks = SDC_SPEC_GRID;
+        const dim3 grid((unsigned)gblocks);
 #define SCASE(MM)                                                                                             \
     case MM:                                                                                                  \
         if (norms) hipLaunchKernelGGL((k_spec_point<MM, true>), grid, dim3(256), 0, c->stream, a, n, nmodes); \
