@@ -374,3 +374,37 @@ __global__ __launch_bounds__(256) void k_spec_point(SpecArgs a, int n, size_t nm
     }
 }
 
+// transform of the collocation residual of the CACHED iterate against the current S0 (u[0] was replaced after
+// the sweep, e.g. by a receive): W[m] = S0 - S[m] + dt sum_j Q[m][j] (lam + mu) S[j]
+template <int NF>
+__global__ __launch_bounds__(256) void k_spec_residual(SpecArgs a, int n, size_t nmodes) {
+    for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < nmodes; g += (size_t)gridDim.x * blockDim.x) {
+        const int kz = (int)(g % n);
+        const size_t ln = g / n;
+        cd sym = a.lamI[kz];
+        if (a.lamE) sym = cadd(sym, a.lamE[kz]);
+        if (a.ndim == 3) {
+            const int kx = (int)(ln / n), ky = (int)(ln % n);
+            sym = cadd(sym, cadd(a.lamI[kx], a.lamI[ky]));
+            if (a.lamE) sym = cadd(sym, cadd(a.lamE[kx], a.lamE[ky]));
+        } else if (a.ndim == 2) {
+            sym = cadd(sym, a.lamI[ln]);
+            if (a.lamE) sym = cadd(sym, a.lamE[ln]);
+        }
+        const cd u0h = a.S0[g];
+        cd u[NF];
+#pragma unroll
+        for (int q = 0; q < NF; ++q) u[q] = a.S[q * a.fstride + g];
+#pragma unroll
+        for (int m = 0; m < NF; ++m) {
+            cd acc = csub(u0h, u[m]);
+#pragma unroll
+            for (int q = 0; q < NF; ++q) {
+                const double rq = a.rQ[m][q];
+                acc = cfma(cd{rq * sym.x, rq * sym.y}, u[q], acc);
+            }
+            a.W[m * a.fstride + g] = acc;
+        }
+    }
+}
+

@@ -379,6 +379,56 @@ static int spec_sweep(sdc_ctx* c, int nf, SpecArgs& a, const FieldPtrs& p, unsig
     N_DISPATCH(c, CALL)
 #undef CALL
 }
+// node norms of the collocation residual of the cached iterate against the current U[0], reduced into norms[0..M)
+template <int N>
+static int spec_residual_n(sdc_ctx* c, SpecArgs& a, unsigned long long* norms) {
+    const int n = c->n, nf = c->M;
+    const size_t lines = c->ndim == 1 ? 1 : (size_t)(n / 2 + 1) * (c->ndim == 3 ? n : 1);
+    {
+        LaunchTimer lt(c, pname("spec_residual", nf));
+        const size_t nmodes = lines * N;
+        size_t gblocks = (nmodes + 255) / 256;
+        if (gblocks > SDC_SPEC_GRID) gblocks = SDC_SPEC_GRID;
+        const dim3 grid((unsigned)gblocks);
+#define SCASE(MM) \
+    case MM: hipLaunchKernelGGL((k_spec_residual<MM>), grid, dim3(256), 0, c->stream, a, n, nmodes); break;
+        switch (nf) { SCASE(1) SCASE(2) SCASE(3) SCASE(4) SCASE(5) SCASE(6) SCASE(7) SCASE(8) }
+#undef SCASE
+    }
+    HIPCHK(c, hipGetLastError());
+    FieldPtrs p;
+    memset(&p, 0, sizeof p);
+    return inverse_passes_n<N>(c, nf, c->W, c->W, p, norms, a.invN);
+}
+static int fwd_transform(sdc_ctx* c, int nf, const FieldPtrs& p, cd* dst, size_t fstride);
+static int spec_residual(sdc_ctx* c, double dt, unsigned long long* norms) {
+    int rw = ensure_work(c);
+    if (rw != SDC_OK) return rw;
+    if (!c->spec0_valid) {
+        FieldPtrs p0;
+        memset(&p0, 0, sizeof p0);
+        p0.in[0] = c->U;
+        int rc0 = fwd_transform(c, 1, p0, c->S0, 0);
+        if (rc0 != SDC_OK) return rc0;
+        c->spec0_valid = true;
+    }
+    SpecArgs a;
+    memset(&a, 0, sizeof a);
+    a.S = c->S;
+    a.fstride = c->Nc;
+    a.S0 = c->S0;
+    a.W = c->W;
+    a.lamI = c->lamI;
+    a.lamE = c->expl_kind == SDC_EXPL_STENCIL ? c->lamE : nullptr;
+    a.invN = 1.0 / (double)c->N;
+    a.nf = c->M;
+    a.ndim = c->ndim;
+    for (int m = 0; m < c->M; ++m)
+        for (int j = 0; j < c->M; ++j) a.rQ[m][j] = dt * c->Q[m + 1][j + 1];
+#define CALL(NN) spec_residual_n<NN>(c, a, norms)
+    N_DISPATCH(c, CALL)
+#undef CALL
+}
 // real fields out[f] from the cached spectra S[first .. first + nf)
 static int inverse_from_cache(sdc_ctx* c, int first, int nf, const FieldPtrs& p) {
     int rw = ensure_work(c);
@@ -1237,6 +1287,11 @@ int sdc_residual(sdc_ctx* c, double dt, int type, double* node_norms, double* re
     } else if (c->res_spread) {
         HIPCHK(c, hipMemcpyAsync(c->red + 7, c->res_dev + 7, sizeof(unsigned long long), hipMemcpyDeviceToDevice, c->stream));
         from_spread = true;
+    } else if (c->u_pending && !c->spread_pending && c->spec_valid && !c->tau_active && c->ndim >= 2) {
+        // the iterate lives in the spectral cache (u[0] was replaced after the sweep, or dt differs): reduce the
+        // residual from its transform instead of bringing U and F back to real space
+        int rcs = spec_residual(c, dt, c->red);
+        if (rcs != SDC_OK) return rcs;
     } else {
         int rcm = materialize(c, true, true);
         if (rcm != SDC_OK) return rcm;

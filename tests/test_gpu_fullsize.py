@@ -230,6 +230,18 @@ def test_deferred_node_fields_match_eager(n, prob):
     for m in range(M):
         assert np.array_equal(a.download(L.SLOT_TAU, m), b.download(L.SLOT_TAU, m))
     same('sweep 3')
+    # u[0] replaced after a sweep (what a receive from the previous time slice does): the residual of the
+    # cached iterate against the NEW u[0] is reduced from its transform; the node fields stay what they were
+    new_u0 = a.download(L.SLOT_U, 0) * 1.001 + 1e-4
+    for e in engines:
+        e.sweep(0.0, dt)
+        e.upload(L.SLOT_U, 0, new_u0)
+    ra, rb = a.residual(dt), b.residual(dt)
+    assert np.allclose(ra[1], rb[1], rtol=1e-9, atol=1e-14) and abs(ra[0] - rb[0]) <= 1e-9 * rb[0]
+    same('u0 replaced after a sweep')
+    for e in engines:
+        e.sweep(0.0, dt)                            # ... and the next sweep starts from the new u[0]
+    same('sweep after the replaced u0')
     # a predictor whose copies are still pending when U[0] is replaced keeps the OLD u0 at the nodes
     for e in engines:
         e.predict(0.0, dt)
