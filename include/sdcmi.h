@@ -165,6 +165,14 @@ int sdc_work_counters(sdc_ctx* ctx, unsigned long long* out);
 int sdc_transfer_apply(void* stream, int ndim, int n_out, int n_in, int width, const int* idx, const double* w,
                        const double* in, double* out);
 
+/* Fourier prolongation between two periodic grids held by two contexts (the levels' engines):
+ * mesh_to_mesh_fft (1-D, transfer_classes/TransferMesh_FFT.py:36-57: rfft, low modes + Nyquist copied, irfft,
+ * factor = ratio) and mesh_to_mesh_fft2d (2-D, TransferMesh_FFT2D.py:58-77: fft2, four corner blocks, real part of
+ * ifft2, factor = 2 * ratio - the reference's constant).  dst = factor * IFFT_fine(pad(FFT_coarse(src))) with the
+ * reference's index conventions.  src / dst are plain device fields of the two grids; the restriction of both
+ * classes is the injection F[::ratio] (sdc_transfer_apply with width 1). */
+int sdc_fft_prolong(sdc_ctx* coarse, sdc_ctx* fine, const double* src, double* dst, double factor);
+
 /* Dirichlet-zero boundaries in 1-D (generic_ND_FD.py:99-133 'dirichlet-zero', order 2): the n interior values
  * live inside their odd extension [0, u_0..u_{n-1}, 0, -u_{n-1}..-u_0] of length 2(n+1) = 2^p, on which the
  * Dirichlet 3-point operator IS the periodic one, so every kernel of the periodic engine applies unchanged

@@ -858,6 +858,64 @@ class MeshToMesh:
         return self._apply(self.P, G, self.nc, self.nf)
 
 
+class MeshToMeshFFT:
+    """transfer_classes/TransferMesh_FFT.py (1-D): restrict = injection F[::ratio] (:21-34); prolong = rfft of
+    the coarse vector, modes [0, nc/2) and the LAST coarse entry (its Nyquist mode, stored at the fine Nyquist
+    index) copied into a zero fine spectrum, irfft, times ratio (:36-57)."""
+
+    def __init__(self, nvars_fine, nvars_coarse):
+        self.nf, self.nc = int(np.prod(nvars_fine)), int(np.prod(nvars_coarse))
+        self.ratio = self.nf // self.nc
+
+    def _each(self, fn, x, n):
+        x = np.asarray(x)
+        return fn(x) if x.shape == (n,) else np.stack([fn(x[c]) for c in range(x.shape[0])])
+
+    def restrict(self, F):
+        return self._each(lambda v: v[:: self.ratio].copy(), F, self.nf)
+
+    def prolong(self, G):
+        def one(g):
+            ch = np.fft.rfft(g)
+            fh = np.zeros(self.nf // 2 + 1, dtype=np.complex128)
+            h = self.nc // 2
+            fh[0:h] = ch[0:h]
+            fh[-1] = ch[-1]
+            return np.fft.irfft(fh) * self.ratio
+
+        return self._each(one, G, self.nc)
+
+
+class MeshToMeshFFT2D:
+    """transfer_classes/TransferMesh_FFT2D.py (square 2-D grids): restrict = injection F[::r, ::r] (:40-56);
+    prolong = fft2, the four corner blocks of half-width nc/2 placed in the corners of a zero nf x nf spectrum,
+    real part of ifft2, times 2 * ratio (:58-77; the constant is the reference's)."""
+
+    def __init__(self, nvars_fine, nvars_coarse):
+        self.nf, self.nc = int(nvars_fine[0]), int(nvars_coarse[0])
+        self.ratio = self.nf // self.nc
+
+    def _each(self, fn, x, n):
+        x = np.asarray(x)
+        return fn(x) if x.shape == (n, n) else np.stack([fn(x[c]) for c in range(x.shape[0])])
+
+    def restrict(self, F):
+        return self._each(lambda v: v[:: self.ratio, :: self.ratio].copy(), F, self.nf)
+
+    def prolong(self, G):
+        def one(g):
+            tg = np.fft.fft2(g)
+            tf = np.zeros((self.nf, self.nf), dtype=np.complex128)
+            h, nf = self.nc // 2, self.nf
+            tf[0:h, 0:h] = tg[0:h, 0:h]
+            tf[nf - h:, 0:h] = tg[h:, 0:h]
+            tf[0:h, nf - h:] = tg[0:h, h:]
+            tf[nf - h:, nf - h:] = tg[h:, h:]
+            return np.real(np.fft.ifft2(tf)) * self.ratio * 2
+
+        return self._each(one, G, self.nc)
+
+
 # ----------------------------------------------------------------------------------------------
 # pseudo-spectral Allen-Cahn (problem_classes/AllenCahn_2D_FFT.py, AllenCahn_MPIFFT.py)
 # ----------------------------------------------------------------------------------------------

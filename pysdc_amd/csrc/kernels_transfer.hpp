@@ -34,3 +34,47 @@ __global__ void k_xfer_axis(XferArgs a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// Fourier prolongation (mesh_to_mesh_fft, TransferMesh_FFT.py:36-57; mesh_to_mesh_fft2d,
+// TransferMesh_FFT2D.py:58-77): the coarse spectrum is copied into the low modes of a fine spectrum.  The
+// reference's index conventions are kept as they are, including where the coarse Nyquist mode ends up.
+// ------------------------------------------------------------------------------------------------------
+
+// 1-D: fine_hat[0:h] = coarse_hat[0:h], fine_hat[nf/2] = coarse_hat[nc/2] (h = nc/2), irfft.  Both engines
+// hold FULL complex spectra of the promoted line; irfft ignores the imaginary parts of DC and Nyquist.
+__global__ void k_pad_spectrum_1d(const cd* __restrict__ G, cd* __restrict__ T, int nc, int nf) {
+    const int h = nc / 2;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nf; k += gridDim.x * blockDim.x) {
+        const int kk = k <= nf / 2 ? k : nf - k;
+        cd v = cd{0.0, 0.0};
+        if (kk < h) v = G[kk];
+        else if (kk == nf / 2) v = G[h];
+        if (kk == 0 || kk == nf / 2) v.y = 0.0;
+        if (k > nf / 2) v.y = -v.y;
+        T[k] = v;
+    }
+}
+
+// 2-D: the four corner blocks of fft2(G) go to the four corners of a zero fine spectrum, real(ifft2).  The
+// fine engine transforms back from the half spectrum kx <= nf/2 of a real field, i.e. of the Hermitian part
+// H(a,b) = (T(a,b) + conj T(-a,-b)) / 2 of the padded spectrum T - which is what taking the real part does.
+// G: coarse half spectrum [nc/2+1][nc] (fft2 of a real field: G(-a,-b) = conj G(a,b)).
+__device__ __forceinline__ cd pad2d_T(const cd* __restrict__ G, int nc, int nf, int a, int b) {
+    const int h = nc / 2;
+    const bool ina = a < h || a >= nf - h, inb = b < h || b >= nf - h;
+    if (!ina || !inb) return cd{0.0, 0.0};
+    const int ca = a < h ? a : a - (nf - nc), cb = b < h ? b : b - (nf - nc);
+    if (ca <= nc / 2) return G[(size_t)ca * nc + cb];
+    const cd g = G[(size_t)(nc - ca) * nc + ((nc - cb) % nc)];
+    return cd{g.x, -g.y};
+}
+__global__ void k_pad_spectrum_2d(const cd* __restrict__ G, cd* __restrict__ T, int nc, int nf) {
+    const int rows = nf / 2 + 1;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < rows * nf; p += gridDim.x * blockDim.x) {
+        const int a = p / nf, b = p % nf;
+        const cd t0 = pad2d_T(G, nc, nf, a, b);
+        const cd t1 = pad2d_T(G, nc, nf, (nf - a) % nf, (nf - b) % nf);
+        T[p] = cd{0.5 * (t0.x + t1.x), 0.5 * (t0.y - t1.y)};
+    }
+}

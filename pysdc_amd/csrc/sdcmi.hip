@@ -1464,6 +1464,49 @@ int sdc_transfer_apply(void* stream, int ndim, int n_out, int n_in, int width, c
     return SDC_OK;
 }
 
+int sdc_fft_prolong(sdc_ctx* coarse, sdc_ctx* fine, const double* src, double* dst, double factor) {
+    if (!coarse || !fine || !src || !dst) return fail(fine, SDC_ERR_PARAM, "null pointer");
+    if (coarse->ndim != fine->ndim || fine->ndim > 2)
+        return fail(fine, SDC_ERR_UNSUPPORTED, "Fourier prolongation is built for 1-D and 2-D grids (got %d-D -> %d-D)",
+                    coarse->ndim, fine->ndim);
+    if (coarse->kind != 0 || fine->kind != 0 || !is_pow2(coarse->n) || !is_pow2(fine->n) || fine->n < coarse->n ||
+        coarse->n < 2 || fine->n > 1024)
+        return fail(fine, SDC_ERR_UNSUPPORTED, "Fourier prolongation needs n = 2^p <= 1024 on both grids (%d -> %d)",
+                    coarse->n, fine->n);
+    int rc = ensure_work(coarse);
+    if (rc == SDC_OK) rc = ensure_work(fine);
+    if (rc != SDC_OK) return rc;
+    FieldPtrs p;
+    memset(&p, 0, sizeof p);
+    p.in[0] = src;
+    rc = fwd_transform(coarse, 1, p, coarse->W, 0);
+    if (rc != SDC_OK) {
+        fine->err = coarse->err;
+        return rc;
+    }
+    if (coarse->stream != fine->stream) {
+        HIPCHK(fine, hipEventRecord(coarse->ev0, coarse->stream));
+        HIPCHK(fine, hipStreamWaitEvent(fine->stream, coarse->ev0, 0));
+    }
+    const int nc = coarse->n, nf = fine->n;
+    {
+        LaunchTimer lt(fine, "pad_spectrum");
+        if (fine->ndim == 1)
+            hipLaunchKernelGGL(k_pad_spectrum_1d, dim3(grid_for(nf, 256)), dim3(256), 0, fine->stream, coarse->W, fine->W,
+                               nc, nf);
+        else
+            hipLaunchKernelGGL(k_pad_spectrum_2d, dim3(grid_for((size_t)(nf / 2 + 1) * nf, 256)), dim3(256), 0,
+                               fine->stream, coarse->W, fine->W, nc, nf);
+    }
+    HIPCHK(fine, hipGetLastError());
+    memset(&p, 0, sizeof p);
+    p.out[0] = dst;
+    const double scale = factor / (double)fine->N;
+#define CALL(NN) inverse_passes_n<NN>(fine, 1, fine->W, fine->W, p, nullptr, scale)
+    N_DISPATCH(fine, CALL)
+#undef CALL
+}
+
 int sdc_odd_mirror(sdc_ctx* c, double* field, int n_interior) {
     CTX_OR_DEFAULT(c);
     if (!field || n_interior < 1) return fail(c, SDC_ERR_PARAM, "bad odd-extension arguments");

@@ -275,3 +275,94 @@ class mesh_to_mesh:
         else:
             raise TransferError('Wrong data type for prolongation, got %s' % type(G))
         return F
+
+
+class _fourier_transfer:
+    """Common part of the two FFT-based space transfers for periodic grids: restriction by injection
+    (``F[::ratio]`` per axis), prolongation by copying the coarse spectrum into the low modes of a fine spectrum
+    (``sdc_fft_prolong``; the transforms run in the two levels' engines)."""
+
+    ndim = None
+
+    def __init__(self, fine_prob, coarse_prob, params):
+        self.params = _SpacePars(params)
+        self.logger = logging.getLogger('space-transfer')
+        self.fine_prob, self.coarse_prob = fine_prob, coarse_prob
+        nf, nc = self._shape(fine_prob.nvars), self._shape(coarse_prob.nvars)
+        if len(nf) != self.ndim or len(nc) != self.ndim:
+            raise TransferError(f'{type(self).__name__} transfers between {self.ndim}-D grids, got {nf} -> {nc}')
+        if len(set(nf)) != 1 or len(set(nc)) != 1:
+            raise TransferError(f'need square grids, got {nf} -> {nc}')
+        if getattr(fine_prob, 'view_offset', 0) or getattr(coarse_prob, 'view_offset', 0):
+            raise TransferError('Fourier transfer needs periodic problems on both levels')
+        self.nf, self.nc = nf[0], nc[0]
+        self.ratio = int(self.nf / self.nc)
+        if self.ratio * self.nc != self.nf:
+            raise TransferError(f'fine grid is not a multiple of the coarse grid: {nf} -> {nc}')
+        self._tab = None
+
+    @staticmethod
+    def _shape(nvars):
+        return (int(nvars),) if np.isscalar(nvars) else tuple(int(v) for v in nvars)
+
+    def _factor(self):
+        raise NotImplementedError
+
+    def _inject(self, fine, coarse):
+        if self._tab is None:
+            import torch
+
+            idx = (np.arange(self.nc, dtype=np.int32) * self.ratio).reshape(self.nc, 1)
+            self._tab = (torch.from_numpy(np.ascontiguousarray(idx)).cuda(),
+                         torch.ones((self.nc, 1), dtype=torch.float64, device='cuda'))
+        idx, w = self._tab
+        Lb.check(Lb.load().sdc_transfer_apply(None, self.ndim, self.nc, self.nf, 1, idx.data_ptr(), w.data_ptr(),
+                                              fine.ptr, coarse.ptr), None)
+
+    def _pad(self, coarse, fine):
+        ec, ef = self.coarse_prob.engine, self.fine_prob.engine
+        Lb.check(ef.lib.sdc_fft_prolong(ec.ctx, ef.ctx, coarse.ptr, fine.ptr, float(self._factor())), ef.ctx)
+
+    def restrict(self, F):
+        if isinstance(F, hip_imex_mesh):
+            G = hip_imex_mesh(self.coarse_prob.init)
+            self._inject(F.impl, G.impl)
+            self._inject(F.expl, G.expl)
+        elif isinstance(F, hip_mesh):
+            G = hip_mesh(self.coarse_prob.init)
+            self._inject(F, G)
+        else:
+            raise TransferError('Unknown data type, got %s' % type(F))
+        return G
+
+    def prolong(self, G):
+        if isinstance(G, hip_imex_mesh):
+            F = hip_imex_mesh(self.fine_prob.init)
+            self._pad(G.impl, F.impl)
+            self._pad(G.expl, F.expl)
+        elif isinstance(G, hip_mesh):
+            F = hip_mesh(self.fine_prob.init)
+            self._pad(G, F)
+        else:
+            raise TransferError('Unknown data type, got %s' % type(G))
+        return F
+
+
+class mesh_to_mesh_fft(_fourier_transfer):
+    """pySDC/implementations/transfer_classes/TransferMesh_FFT.py:5-57 (1-D, rfft / irfft, factor = ratio)."""
+
+    ndim = 1
+
+    def _factor(self):
+        return self.ratio
+
+
+class mesh_to_mesh_fft2d(_fourier_transfer):
+    """pySDC/implementations/transfer_classes/TransferMesh_FFT2D.py:8-77 (2-D, fft2 / real part of ifft2, the
+    reference's factor 2 * ratio).  imex data is transferred component by component (the reference's imex branch
+    of prolong cannot run: it multiplies the shape tuple by the communicator, :96)."""
+
+    ndim = 2
+
+    def _factor(self):
+        return self.ratio * 2

@@ -123,6 +123,19 @@ class OracleMeshToMesh:
         return np_mesh(self.T.prolong(np.asarray(G)))
 
 
+class OracleMeshToMeshFFT2D:
+    """oracle-backed stand-in of mesh_to_mesh_fft2d"""
+
+    def __init__(self, fine_prob, coarse_prob, params):
+        self.T = O.MeshToMeshFFT2D(fine_prob.o.nvars, coarse_prob.o.nvars)
+
+    def restrict(self, F):
+        return np_mesh(self.T.restrict(np.asarray(F)))
+
+    def prolong(self, G):
+        return np_mesh(self.T.prolong(np.asarray(G)))
+
+
 class OracleLevel:
     def __init__(self, olevel, level_params):
         self.o = olevel

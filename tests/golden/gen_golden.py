@@ -474,3 +474,73 @@ def dirichlet_main():
 
 if __name__ == '__main__' and os.environ.get('GOLDEN_ML', '1') == '1':
     dirichlet_main()
+
+
+def fft_transfer_main():
+    """mesh_to_mesh_fft (1-D) / mesh_to_mesh_fft2d per-operator vectors and the G6 two-level Allen-Cahn run with
+    the FFT transfer."""
+    from types import SimpleNamespace
+    from pySDC.implementations.datatype_classes.mesh import mesh
+    from pySDC.implementations.problem_classes.AllenCahn_2D_FFT import allencahn2d_imex
+    from pySDC.implementations.transfer_classes.TransferMesh_FFT import mesh_to_mesh_fft
+    from pySDC.implementations.transfer_classes.TransferMesh_FFT2D import mesh_to_mesh_fft2d
+
+    out = {}
+    rng = np.random.default_rng(9)
+    for tag, nf, nc in (('fft1d_32_16', 32, 16), ('fft1d_64_16', 64, 16), ('fft1d_256_128', 256, 128)):
+        pf = SimpleNamespace(nvars=nf, init=(nf, None, np.dtype('float64')))
+        pc = SimpleNamespace(nvars=nc, init=(nc, None, np.dtype('float64')))
+        T = mesh_to_mesh_fft(pf, pc, {})
+        F = mesh(pf.init)
+        F[:] = rng.standard_normal(nf)
+        G = mesh(pc.init)
+        G[:] = rng.standard_normal(nc)
+        out[f'{tag}/fine'], out[f'{tag}/coarse'] = np.asarray(F).copy(), np.asarray(G).copy()
+        out[f'{tag}/restricted'] = np.asarray(T.restrict(F)).copy()
+        out[f'{tag}/prolonged'] = np.asarray(T.prolong(G)).copy()
+        out[f'{tag}/meta'] = np.array(json.dumps(dict(name=tag, kind='fft1d', nf=nf, nc=nc)))
+    for tag, nf, nc in (('fft2d_32_16', 32, 16), ('fft2d_64_16', 64, 16), ('fft2d_128_64', 128, 64)):
+        pf = SimpleNamespace(nvars=(nf, nf), init=((nf, nf), None, np.dtype('float64')))
+        pc = SimpleNamespace(nvars=(nc, nc), init=((nc, nc), None, np.dtype('float64')))
+        T = mesh_to_mesh_fft2d(pf, pc, {})
+        F = mesh(pf.init)
+        F[:] = rng.standard_normal((nf, nf))
+        G = mesh(pc.init)
+        G[:] = rng.standard_normal((nc, nc))
+        out[f'{tag}/fine'], out[f'{tag}/coarse'] = np.asarray(F).copy(), np.asarray(G).copy()
+        out[f'{tag}/restricted'] = np.asarray(T.restrict(F)).copy()
+        out[f'{tag}/prolonged'] = np.asarray(T.prolong(G)).copy()
+        out[f'{tag}/meta'] = np.array(json.dumps(dict(name=tag, kind='fft2d', nf=nf, nc=nc)))
+    np.savez_compressed(os.path.join(OUT, 'transfer_fft.npz'), **out)
+    print('transfer_fft.npz', os.path.getsize(os.path.join(OUT, 'transfer_fft.npz')) // 1024, 'KiB')
+
+    PROBS['allencahn2d'] = allencahn2d_imex
+    RR = dict(quad_type='RADAU-RIGHT')
+    pp = dict(nvars=[(32, 32), (16, 16)], nu=2, eps=0.04, radius=0.25)
+    cases = []
+    for name, P_, cp in (('ac2d_fft2d_mlsdc', 1, None), ('ac2d_fft2d_pfasst_P2', 2, dict(predict_type='pfasst_burnin'))):
+        desc = ml_description('allencahn2d', pp, 'imex_1st_order', dict(num_nodes=3, QI='LU', QE='EE', **RR),
+                              dict(dt=1e-3, restol=1e-8), 50)
+        desc['space_transfer_class'] = mesh_to_mesh_fft2d
+        desc['space_transfer_params'] = {}
+        cpar = dict(logger_level=40)
+        cpar.update(cp or {})
+        C = controller_nonMPI(P_, cpar, desc)
+        P = C.MS[0].levels[0].prob
+        u0 = P.dtype_u(P.init) + P.u_exact(0.0)
+        uend, stats = C.run(u0, 0.0, 4e-3)
+        o = {'u0': np.asarray(u0).copy(), 'uend': np.asarray(uend).copy()}
+        niter = get_sorted(stats, type='niter', sortby='time')
+        o['niter_t'] = np.array([t for t, _ in niter])
+        o['niter'] = np.array([v for _, v in niter])
+        o['res'] = np.array([v for _, v in get_sorted(stats, type='residual_post_iteration', sortby='time')])
+        o['meta'] = np.array(json.dumps(dict(name=name, prob='allencahn2d', prob_params=pp, sweeper='imex_1st_order',
+                                             sweeper_params=dict(num_nodes=3, QI='LU', QE='EE', **RR),
+                                             level_params=dict(dt=1e-3, restol=1e-8), maxiter=50, t0=0.0, Tend=4e-3,
+                                             num_procs=P_, controller_params=cp or {}, transfer='mesh_to_mesh_fft2d')))
+        cases.append(o)
+    save('runs_ac_fft.npz', cases)
+
+
+if __name__ == '__main__' and os.environ.get('GOLDEN_FFT', '0') == '1':
+    fft_transfer_main()

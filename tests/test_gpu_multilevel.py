@@ -52,6 +52,25 @@ def test_space_transfer_kernels(name):
     assert rel_err(T.prolong(G).get(), c['prolonged']) < 1e-14
 
 
+@pytest.mark.parametrize('name', list(load_cases('transfer_fft.npz')))
+def test_fourier_transfer_kernels(name):
+    """mesh_to_mesh_fft (1-D) / mesh_to_mesh_fft2d on the device against vectors of the reference classes."""
+    from pysdc_amd.problems import heatNd_unforced
+    from pysdc_amd.transfer import mesh_to_mesh_fft, mesh_to_mesh_fft2d
+
+    c = load_cases('transfer_fft.npz')[name]
+    m = c['meta']
+    d = 1 if m['kind'] == 'fft1d' else 2
+    pf = heatNd_unforced(nvars=(m['nf'],) * d, nu=0.1, freq=2)
+    pc = heatNd_unforced(nvars=(m['nc'],) * d, nu=0.1, freq=2)
+    T = (mesh_to_mesh_fft if d == 1 else mesh_to_mesh_fft2d)(pf, pc, {})
+    F, G = pf.u_init, pc.u_init
+    F[:] = c['fine']
+    G[:] = c['coarse']
+    assert np.array_equal(T.restrict(F).get(), c['restricted'])
+    assert rel_err(T.prolong(G).get(), c['prolonged']) < 1e-13
+
+
 @pytest.mark.parametrize('name', list(load_cases('fas.npz')))
 def test_fas_on_device(name):
     from pysdc_amd.level import Step
@@ -91,7 +110,8 @@ def test_fas_on_device(name):
     check('d')
 
 
-ML_RUNS = [('runs_ml.npz', n) for n in load_cases('runs_ml.npz')] + [('runs_ac.npz', n) for n in load_cases('runs_ac.npz')]
+ML_RUNS = ([('runs_ml.npz', n) for n in load_cases('runs_ml.npz')] + [('runs_ac.npz', n) for n in load_cases('runs_ac.npz')]
+           + [('runs_ac_fft.npz', n) for n in load_cases('runs_ac_fft.npz')])
 
 
 @pytest.mark.parametrize('fname,name', ML_RUNS)
@@ -101,7 +121,11 @@ def test_mlsdc_pfasst_on_device(fname, name):
 
     case = load_cases(fname)[name]
     meta = case['meta']
-    desc = _description(meta, meta['level_params'], meta['iorder'], meta['rorder'])
+    desc = _description(meta, meta['level_params'], meta.get('iorder', 6), meta.get('rorder', 2))
+    if meta.get('transfer') == 'mesh_to_mesh_fft2d':
+        from pysdc_amd.transfer import mesh_to_mesh_fft2d
+
+        desc['space_transfer_class'], desc['space_transfer_params'] = mesh_to_mesh_fft2d, {}
     C = controller_nonMPI(meta['num_procs'], dict(logger_level=40, **meta['controller_params']), desc)
     P = C.MS[0].levels[0].prob
     u0 = P.u_init

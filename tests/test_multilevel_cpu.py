@@ -25,6 +25,16 @@ def test_space_transfer_oracle_vs_golden():
         assert rel_err(T.prolong(c['coarse']), c['prolonged']) < 1e-15, name
 
 
+def test_fourier_transfer_oracle_vs_golden():
+    """mesh_to_mesh_fft / mesh_to_mesh_fft2d restated in the oracle against vectors of the reference classes."""
+    for name, c in load_cases('transfer_fft.npz').items():
+        m = c['meta']
+        T = O.MeshToMeshFFT((m['nf'],), (m['nc'],)) if m['kind'] == 'fft1d' else O.MeshToMeshFFT2D((m['nf'],) * 2,
+                                                                                                    (m['nc'],) * 2)
+        assert np.array_equal(T.restrict(c['fine']), c['restricted']), name
+        assert rel_err(T.prolong(c['coarse']), c['prolonged']) < 1e-15, name
+
+
 def level_factories(meta, case, lp):
     """one oracle-level factory per level from a golden multi-level description."""
     from pysdc_amd.coeffs import CollBase, QDELTA_GENERATORS
@@ -94,13 +104,18 @@ def test_fas_restrict_prolong(name):
     check('d')
 
 
-ML_RUNS = [('runs_ml.npz', n) for n in load_cases('runs_ml.npz')] + [('runs_ac.npz', n) for n in load_cases('runs_ac.npz')]
+ML_RUNS = ([('runs_ml.npz', n) for n in load_cases('runs_ml.npz')] + [('runs_ac.npz', n) for n in load_cases('runs_ac.npz')]
+           + [('runs_ac_fft.npz', n) for n in load_cases('runs_ac_fft.npz')])
 
 
 def _ml_description(meta, case):
-    from tests._oracle_step import OracleStep, OracleMeshToMesh
+    from tests._oracle_step import OracleStep, OracleMeshToMesh, OracleMeshToMeshFFT2D
 
     lp = meta['level_params']
+    if meta.get('transfer') == 'mesh_to_mesh_fft2d':
+        return dict(step_class=OracleStep, oracle_level_factory=level_factories(meta, case, lp), level_params=lp,
+                    step_params=dict(maxiter=meta['maxiter']), space_transfer_class=OracleMeshToMeshFFT2D,
+                    space_transfer_params={})
     return dict(step_class=OracleStep, oracle_level_factory=level_factories(meta, case, lp), level_params=lp,
                 step_params=dict(maxiter=meta['maxiter']), space_transfer_class=OracleMeshToMesh,
                 space_transfer_params=dict(iorder=meta['iorder'], rorder=meta['rorder']))
