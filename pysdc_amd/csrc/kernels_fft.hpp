@@ -408,3 +408,124 @@ __global__ __launch_bounds__(256) void k_spec_residual(SpecArgs a, int n, size_t
     }
 }
 
+
+// Spectral sweep fused with the first inverse pass.  One workgroup owns the same LPB lines of all NF fields
+// as k_fftz_plain does (column c = f*LPB + l on threads [c*P, (c+1)*P)), i.e. a contiguous span of LPB*N
+// modes per field.  Phase 1 treats that span pointwise (one thread = one mode, all NF node values in
+// registers: gather on the cached transforms, node-coupled solve, S updated in place, residual spectrum) and
+// hands the field to transform - the residual spectrum (RES) or the new iterate - to the FFT threads through
+// LDS in chunks of <= 512 modes; phase 2 is the inverse line transform, whose exchange planes reuse that LDS.
+// Saves writing and re-reading NF spectra between k_spec_point and k_fftz_plain.
+template <int N, int NF, bool RES, bool HASE>
+__global__ __launch_bounds__(z_lines_per_block<N>() * (N / fft_elems(N)) * NF, 4) void k_spec_z(SpecArgs a, unsigned nlines) {
+    constexpr int E = fft_elems(N), P = N / E, LPB = z_lines_per_block<N>();
+    constexpr int SPAN = LPB * N, CH = SPAN > 512 ? 512 : SPAN, NCH = SPAN / CH, NT = LPB * P * NF;
+    constexpr int ITS = (CH + NT - 1) / NT;  // modes per thread and chunk
+    using LAY = LayContig<N>;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    cd* rbuf = reinterpret_cast<cd*>(lds);  // [NF][CH]
+    const int c = threadIdx.x / P, j = threadIdx.x % P;
+    const int f = c / LPB, l = c % LPB;
+    const size_t line = (size_t)blockIdx.x * LPB + l;
+    const bool ok = line < nlines;
+    const size_t span0 = (size_t)blockIdx.x * SPAN, nmodes = (size_t)nlines * N;
+    cd r[E];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        // all loads of this chunk first: (NF + 1) * ITS independent 16-byte loads per thread in flight
+        cd in0[ITS], inq[ITS][NF];
+#pragma unroll
+        for (int it = 0; it < ITS; ++it) {
+            const int k = threadIdx.x + it * NT;
+            const size_t g = span0 + (size_t)ch * CH + k;
+            if (k < CH && g < nmodes) {
+                in0[it] = a.S0[g];
+                if (!a.spread) {
+#pragma unroll
+                    for (int q = 0; q < NF; ++q) inq[it][q] = a.S[q * a.fstride + g];
+                }
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < ITS; ++it) {
+            const int k = threadIdx.x + it * NT;
+            const size_t g = span0 + (size_t)ch * CH + k;
+            if (k < CH && g < nmodes) {
+                const int kz = (int)(g % N);
+                const size_t ln = g / N;
+                cd lam = a.lamI[kz], mu = cd{0.0, 0.0};
+                if (HASE) mu = a.lamE[kz];
+                if (a.ndim == 3) {
+                    const int kx = (int)(ln / N), ky = (int)(ln % N);
+                    lam = cadd(lam, cadd(a.lamI[kx], a.lamI[ky]));
+                    if (HASE) mu = cadd(mu, cadd(a.lamE[kx], a.lamE[ky]));
+                } else if (a.ndim == 2) {
+                    lam = cadd(lam, a.lamI[ln]);
+                    if (HASE) mu = cadd(mu, a.lamE[ln]);
+                }
+                const cd u0h = in0[it];
+                cd old[NF], u[NF];
+#pragma unroll
+                for (int q = 0; q < NF; ++q) old[q] = a.spread ? u0h : inq[it][q];
+#pragma unroll
+                for (int m = 0; m < NF; ++m) {
+                    cd acc = u0h;
+#pragma unroll
+                    for (int q = 0; q < NF; ++q) {
+                        const double gi = a.gI[m][q];
+                        cd coef = cd{gi * lam.x, gi * lam.y};
+                        if (HASE) {
+                            const double ge = a.gE[m][q];
+                            coef = cd{fma(ge, mu.x, coef.x), fma(ge, mu.y, coef.y)};
+                        }
+                        acc = cfma(coef, old[q], acc);
+                    }
+                    if (a.coupled) {
+#pragma unroll
+                        for (int q = 0; q < m; ++q) {
+                            const double ci = a.cI[m][q];
+                            cd coef = cd{ci * lam.x, ci * lam.y};
+                            if (HASE) {
+                                const double ce = a.cE[m][q];
+                                coef = cd{fma(ce, mu.x, coef.x), fma(ce, mu.y, coef.y)};
+                            }
+                            acc = cfma(coef, u[q], acc);
+                        }
+                    }
+                    const double al = a.alpha[m];
+                    u[m] = cmul(acc, cinv_fast(cd{1.0 - al * lam.x, -al * lam.y}));
+                    a.S[m * a.fstride + g] = u[m];
+                }
+                if constexpr (RES) {
+                    const cd sym = HASE ? cadd(lam, mu) : lam;
+#pragma unroll
+                    for (int m = 0; m < NF; ++m) {
+                        cd acc = csub(u0h, u[m]);
+#pragma unroll
+                        for (int q = 0; q < NF; ++q) {
+                            const double rq = a.rQ[m][q];
+                            acc = cfma(cd{rq * sym.x, rq * sym.y}, u[q], acc);
+                        }
+                        rbuf[m * CH + k] = cscale(acc, a.invN);
+                    }
+                } else {
+#pragma unroll
+                    for (int m = 0; m < NF; ++m) rbuf[m * CH + k] = cscale(u[m], a.invN);
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            const int o = l * N + j + i * P;  // offset of element i inside the span
+            if (o / CH == ch) r[i] = ok ? rbuf[f * CH + (o % CH)] : cd{0.0, 0.0};
+        }
+        __syncthreads();  // the next chunk / the exchange planes of the transform overwrite the buffer
+    }
+    fft_line<N, +1, LAY, (N / fft_elems(N)) <= 64>(r, j, c, lds, a.tw);
+    if (ok) {
+        cd* __restrict__ dst = a.W + f * a.fstride + line * N;
+#pragma unroll
+        for (int i = 0; i < E; ++i) dst[j + i * P] = r[i];
+    }
+}

@@ -12,6 +12,9 @@
 #ifndef SDC_T1024
 #define SDC_T1024 8
 #endif
+#ifndef SDC_FUSE_SPECZ
+#define SDC_FUSE_SPECZ 1
+#endif
 #ifndef SDC_SPEC_GRID
 #define SDC_SPEC_GRID 4096
 #endif
@@ -283,21 +286,12 @@ static int fwd_transform_n(sdc_ctx* c, int nf, const FieldPtrs& p, cd* dst, size
     return SDC_OK;
 }
 
-// inverse transform of nf fully transformed spectra src[f] (src + f*Nc) through the work buffer work[f]
-// (work may equal src: in place) into the real fields out[f] - or, with norms != null, into max |.| per field
+// the inverse passes after the contiguous-axis one: work[f] -> real fields out[f] or (norms != null) max |.|
 template <int N>
-static int inverse_passes_n(sdc_ctx* c, int nf, const cd* src, cd* work, const FieldPtrs& p, unsigned long long* norms,
-                            double scale) {
-    constexpr int E = fft_elems(N), P = N / E, T = N >= 2048 ? 4 : (N == 1024 ? SDC_T1024 : 8), LPB = z_lines_per_block<N>();
+static int inverse_tail_n(sdc_ctx* c, int nf, cd* work, const FieldPtrs& p, unsigned long long* norms) {
+    constexpr int E = fft_elems(N), P = N / E, T = N >= 2048 ? 4 : (N == 1024 ? SDC_T1024 : 8);
     const size_t lds_str = (size_t)LayStrided<N, T>::doubles(T) * sizeof(double);
     const int n = c->n;
-    const size_t lines = c->ndim == 1 ? 1 : (size_t)(n / 2 + 1) * (c->ndim == 3 ? n : 1);
-    {
-        LaunchTimer lt(c, pname("fft_z_inv", nf));
-        const size_t ldsz = (size_t)LayContig<N>::doubles(nf * LPB) * sizeof(double);
-        hipLaunchKernelGGL((k_fftz_plain<N, +1>), dim3((unsigned)((lines + LPB - 1) / LPB)), dim3(P * LPB * nf), ldsz,
-                           c->stream, src, work, c->Nc, c->tw, (unsigned)lines, scale);
-    }
     if (c->ndim == 1) {
         if (norms) return fail(c, SDC_ERR_UNSUPPORTED, "norm-only inverse transform in 1-D");
         LaunchTimer lt(c, pname("realpart", nf));
@@ -324,12 +318,56 @@ static int inverse_passes_n(sdc_ctx* c, int nf, const cd* src, cd* work, const F
     return SDC_OK;
 }
 
+// inverse transform of nf fully transformed spectra src[f] (src + f*Nc) through the work buffer work[f]
+// (work may equal src: in place) into the real fields out[f] - or, with norms != null, into max |.| per field
+template <int N>
+static int inverse_passes_n(sdc_ctx* c, int nf, const cd* src, cd* work, const FieldPtrs& p, unsigned long long* norms,
+                            double scale) {
+    constexpr int P = N / fft_elems(N), LPB = z_lines_per_block<N>();
+    const int n = c->n;
+    const size_t lines = c->ndim == 1 ? 1 : (size_t)(n / 2 + 1) * (c->ndim == 3 ? n : 1);
+    {
+        LaunchTimer lt(c, pname("fft_z_inv", nf));
+        const size_t ldsz = (size_t)LayContig<N>::doubles(nf * LPB) * sizeof(double);
+        hipLaunchKernelGGL((k_fftz_plain<N, +1>), dim3((unsigned)((lines + LPB - 1) / LPB)), dim3(P * LPB * nf), ldsz,
+                           c->stream, src, work, c->Nc, c->tw, (unsigned)lines, scale);
+    }
+    return inverse_tail_n<N>(c, nf, work, p, norms);
+}
+
+template <int N, int NF>
+static void launch_spec_z(sdc_ctx* c, SpecArgs& a, size_t lines, bool res) {
+    constexpr int P = N / fft_elems(N), LPB = z_lines_per_block<N>();
+    constexpr int SPAN = LPB * N, CH = SPAN > 512 ? 512 : SPAN;
+    size_t ldsz = (size_t)LayContig<N>::doubles(NF * LPB) * sizeof(double);
+    if ((size_t)NF * CH * sizeof(cd) > ldsz) ldsz = (size_t)NF * CH * sizeof(cd);
+    const dim3 grid((unsigned)((lines + LPB - 1) / LPB)), block(P * LPB * NF);
+    const bool hase = a.lamE != nullptr;
+#define ZL(R_, E_) hipLaunchKernelGGL((k_spec_z<N, NF, R_, E_>), grid, block, ldsz, c->stream, a, (unsigned)lines)
+    if (res && hase) ZL(true, true);
+    else if (res) ZL(true, false);
+    else if (hase) ZL(false, true);
+    else ZL(false, false);
+#undef ZL
+}
+
 // spectral sweep; then either the inverse passes into out[f], or (norms != null) only the node norms of the
 // collocation residual of the new iterate
 template <int N>
 static int spec_sweep_n(sdc_ctx* c, int nf, SpecArgs& a, const FieldPtrs& p, unsigned long long* norms) {
     const int n = c->n;
     const size_t lines = c->ndim == 1 ? 1 : (size_t)(n / 2 + 1) * (c->ndim == 3 ? n : 1);
+    if constexpr (SDC_FUSE_SPECZ && N <= 1024) {
+        {
+            LaunchTimer lt(c, pname(norms ? "spec_z_res" : "spec_z", nf));
+#define ZCASE(MM) \
+    case MM: launch_spec_z<N, MM>(c, a, lines, norms != nullptr); break;
+            switch (nf) { ZCASE(1) ZCASE(2) ZCASE(3) ZCASE(4) ZCASE(5) ZCASE(6) ZCASE(7) ZCASE(8) }
+#undef ZCASE
+        }
+        HIPCHK(c, hipGetLastError());
+        return inverse_tail_n<N>(c, nf, c->W, p, norms);
+    }
     {
         LaunchTimer lt(c, pname(norms ? "spec_point_res" : "spec_point", nf));
         const size_t nmodes = lines * N;
