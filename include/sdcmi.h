@@ -127,6 +127,10 @@ int sdc_residual(sdc_ctx* ctx, double dt, int type, double* node_norms, double* 
 int sdc_end_point(sdc_ctx* ctx, double dt, int do_coll_update);
 /* integrate() (generic_implicit.py:29-49 / imex_1st_order.py:37-55): dst[m] = dt sum_j Q[m+1][j] f[j],
  * dst = M device pointers (called by BaseTransfer.restrict, pySDC/core/base_transfer.py:134,137). */
+/* Next time step on the same level: u[0] <- uend (controller_nonMPI.py:148 hands the end value of a block to
+ * its first step; core/step.py:271).  When UEND is the inverse transform of the cached spectrum of the last node
+ * and nothing changed since, that spectrum becomes the transform of the new u[0] (no forward transform). */
+int sdc_advance(sdc_ctx* ctx);
 int sdc_integrate(sdc_ctx* ctx, double dt, double* const* dst);
 
 /* ---- problem-level operations on raw device fields (the non-fused plug-in path) ------------------------ */

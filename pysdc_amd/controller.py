@@ -105,12 +105,18 @@ class controller_nonMPI(_ControllerBase):
             done = False
             while not done:
                 done = self.pfasst(MS_active)
-            uend = self.MS[active_slots[-1]].levels[0].uend
+            last_step = self.MS[active_slots[-1]]
+            uend = last_step.levels[0].uend
             time[active_slots[0]] = time[active_slots[-1]] + self.MS[active_slots[-1]].dt
             for i in range(1, len(active_slots)):
                 time[active_slots[i]] = time[active_slots[i] - 1] + self.MS[active_slots[i] - 1].dt
             active = [time[p] < Tend - 10 * np.finfo(float).eps for p in slots]
             active_slots = list(itertools.compress(slots, active))
+            if (active_slots and self.MS[active_slots[0]] is last_step and len(active_slots) == 1
+                    and hasattr(last_step.levels[0], 'advance')):
+                # one step per block: the next block starts on the same level from its own end value
+                self.restart_block(active_slots, time, None)
+                continue
             # the view into the last step's UEND slab is about to be reset: keep the value in an owning
             # buffer that lives as long as the controller (allocating 8.6 GB per block costs ~0.25 s)
             if self._uend_buf is None:
@@ -133,7 +139,10 @@ class controller_nonMPI(_ControllerBase):
             S.reset_step()
             S.status.first = active_slots.index(p) == 0
             S.status.last = active_slots.index(p) == len(active_slots) - 1
-            S.init_step(u0)
+            if u0 is None:
+                S.levels[0].advance()
+            else:
+                S.init_step(u0)
             S.status.done = False
             S.status.prev_done = False
             S.status.iter = 0
@@ -412,10 +421,14 @@ class controller_dist(_ControllerBase):
                     self.pfasst(num_active)
             # end value of the block travels from its last active rank to everybody (controller_MPI.py:125-130)
             root = num_active - 1
+            time = time + dt * num_active
+            if self.size == 1 and time < Tend - eps10 and hasattr(S.levels[0], 'advance'):
+                # a single time rank: the next block starts on the same level from its own end value
+                self.restart_block(1, time, None, True)
+                continue
             if self.rank == root:
                 uend[:] = S.levels[0].uend
             uend.bcast(root=root, comm=self.comm)
-            time = time + dt * num_active
             active = time < Tend - eps10
             num_active = self._all_sum(active)
             if num_active > 0:
@@ -433,7 +446,10 @@ class controller_dist(_ControllerBase):
         S.reset_step()
         S.status.first = self.rank == 0
         S.status.last = self.rank == size - 1
-        S.init_step(u0)
+        if u0 is None:
+            S.levels[0].advance()
+        else:
+            S.init_step(u0)
         S.status.done = False
         S.status.prev_done = False
         S.status.iter = 0

@@ -416,8 +416,11 @@ __global__ __launch_bounds__(256) void k_spec_residual(SpecArgs a, int n, size_t
 // hands the field to transform - the residual spectrum (RES) or the new iterate - to the FFT threads through
 // LDS in chunks of <= 512 modes; phase 2 is the inverse line transform, whose exchange planes reuse that LDS.
 // Saves writing and re-reading NF spectra between k_spec_point and k_fftz_plain.
-template <int N, int NF, bool RES, bool HASE>
+// MODE 0: sweep, the new iterate is transformed; 1: sweep, the residual spectrum is transformed (RES);
+// 2: no sweep - residual spectrum of the CACHED iterate against the current S0 (u[0] was replaced).
+template <int N, int NF, int MODE, bool HASE>
 __global__ __launch_bounds__(z_lines_per_block<N>() * (N / fft_elems(N)) * NF, 4) void k_spec_z(SpecArgs a, unsigned nlines) {
+    constexpr bool RES = MODE >= 1, UPD = MODE <= 1;
     constexpr int E = fft_elems(N), P = N / E, LPB = z_lines_per_block<N>();
     constexpr int SPAN = LPB * N, CH = SPAN > 512 ? 512 : SPAN, NCH = SPAN / CH, NT = LPB * P * NF;
     constexpr int ITS = (CH + NT - 1) / NT;  // modes per thread and chunk
@@ -440,7 +443,7 @@ __global__ __launch_bounds__(z_lines_per_block<N>() * (N / fft_elems(N)) * NF, 4
             const size_t g = span0 + (size_t)ch * CH + k;
             if (k < CH && g < nmodes) {
                 in0[it] = a.S0[g];
-                if (!a.spread) {
+                if (!UPD || !a.spread) {
 #pragma unroll
                     for (int q = 0; q < NF; ++q) inq[it][q] = a.S[q * a.fstride + g];
                 }
@@ -466,9 +469,13 @@ __global__ __launch_bounds__(z_lines_per_block<N>() * (N / fft_elems(N)) * NF, 4
                 const cd u0h = in0[it];
                 cd old[NF], u[NF];
 #pragma unroll
-                for (int q = 0; q < NF; ++q) old[q] = a.spread ? u0h : inq[it][q];
+                for (int q = 0; q < NF; ++q) old[q] = (UPD && a.spread) ? u0h : inq[it][q];
 #pragma unroll
                 for (int m = 0; m < NF; ++m) {
+                    if constexpr (!UPD) {
+                        u[m] = old[m];
+                        continue;
+                    }
                     cd acc = u0h;
 #pragma unroll
                     for (int q = 0; q < NF; ++q) {

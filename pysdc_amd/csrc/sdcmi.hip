@@ -336,18 +336,23 @@ static int inverse_passes_n(sdc_ctx* c, int nf, const cd* src, cd* work, const F
 }
 
 template <int N, int NF>
-static void launch_spec_z(sdc_ctx* c, SpecArgs& a, size_t lines, bool res) {
+static void launch_spec_z(sdc_ctx* c, SpecArgs& a, size_t lines, int mode) {
     constexpr int P = N / fft_elems(N), LPB = z_lines_per_block<N>();
     constexpr int SPAN = LPB * N, CH = SPAN > 512 ? 512 : SPAN;
     size_t ldsz = (size_t)LayContig<N>::doubles(NF * LPB) * sizeof(double);
     if ((size_t)NF * CH * sizeof(cd) > ldsz) ldsz = (size_t)NF * CH * sizeof(cd);
     const dim3 grid((unsigned)((lines + LPB - 1) / LPB)), block(P * LPB * NF);
     const bool hase = a.lamE != nullptr;
-#define ZL(R_, E_) hipLaunchKernelGGL((k_spec_z<N, NF, R_, E_>), grid, block, ldsz, c->stream, a, (unsigned)lines)
-    if (res && hase) ZL(true, true);
-    else if (res) ZL(true, false);
-    else if (hase) ZL(false, true);
-    else ZL(false, false);
+#define ZL(M_, E_) hipLaunchKernelGGL((k_spec_z<N, NF, M_, E_>), grid, block, ldsz, c->stream, a, (unsigned)lines)
+    if (hase) {
+        if (mode == 0) ZL(0, true);
+        else if (mode == 1) ZL(1, true);
+        else ZL(2, true);
+    } else {
+        if (mode == 0) ZL(0, false);
+        else if (mode == 1) ZL(1, false);
+        else ZL(2, false);
+    }
 #undef ZL
 }
 
@@ -357,16 +362,18 @@ template <int N>
 static int spec_sweep_n(sdc_ctx* c, int nf, SpecArgs& a, const FieldPtrs& p, unsigned long long* norms) {
     const int n = c->n;
     const size_t lines = c->ndim == 1 ? 1 : (size_t)(n / 2 + 1) * (c->ndim == 3 ? n : 1);
-    if constexpr (SDC_FUSE_SPECZ && N <= 1024) {
-        {
-            LaunchTimer lt(c, pname(norms ? "spec_z_res" : "spec_z", nf));
+    if constexpr (SDC_FUSE_SPECZ && N >= 64 && N <= 1024) {  // fused with the first inverse pass (M <= 5)
+        if (nf <= 5) {
+            {
+                LaunchTimer lt(c, pname(norms ? "spec_z_res" : "spec_z", nf));
 #define ZCASE(MM) \
-    case MM: launch_spec_z<N, MM>(c, a, lines, norms != nullptr); break;
-            switch (nf) { ZCASE(1) ZCASE(2) ZCASE(3) ZCASE(4) ZCASE(5) ZCASE(6) ZCASE(7) ZCASE(8) }
+    case MM: launch_spec_z<N, MM>(c, a, lines, norms ? 1 : 0); break;
+                switch (nf) { ZCASE(1) ZCASE(2) ZCASE(3) ZCASE(4) ZCASE(5) }
 #undef ZCASE
+            }
+            HIPCHK(c, hipGetLastError());
+            return inverse_tail_n<N>(c, nf, c->W, p, norms);
         }
-        HIPCHK(c, hipGetLastError());
-        return inverse_tail_n<N>(c, nf, c->W, p, norms);
     }
     {
         LaunchTimer lt(c, pname(norms ? "spec_point_res" : "spec_point", nf));
@@ -422,6 +429,21 @@ template <int N>
 static int spec_residual_n(sdc_ctx* c, SpecArgs& a, unsigned long long* norms) {
     const int n = c->n, nf = c->M;
     const size_t lines = c->ndim == 1 ? 1 : (size_t)(n / 2 + 1) * (c->ndim == 3 ? n : 1);
+    FieldPtrs p0;
+    memset(&p0, 0, sizeof p0);
+    if constexpr (SDC_FUSE_SPECZ && N >= 64 && N <= 1024) {
+        if (nf <= 5) {
+            {
+                LaunchTimer lt(c, pname("spec_z_resid", nf));
+#define ZCASE(MM) \
+    case MM: launch_spec_z<N, MM>(c, a, lines, 2); break;
+                switch (nf) { ZCASE(1) ZCASE(2) ZCASE(3) ZCASE(4) ZCASE(5) }
+#undef ZCASE
+            }
+            HIPCHK(c, hipGetLastError());
+            return inverse_tail_n<N>(c, nf, c->W, p0, norms);
+        }
+    }
     {
         LaunchTimer lt(c, pname("spec_residual", nf));
         const size_t nmodes = lines * N;
@@ -456,6 +478,7 @@ static int spec_residual(sdc_ctx* c, double dt, unsigned long long* norms) {
     a.fstride = c->Nc;
     a.S0 = c->S0;
     a.W = c->W;
+    a.tw = c->tw;
     a.lamI = c->lamI;
     a.lamE = c->expl_kind == SDC_EXPL_STENCIL ? c->lamE : nullptr;
     a.invN = 1.0 / (double)c->N;
@@ -896,6 +919,7 @@ void* sdc_slot_ptr(sdc_ctx* c, int slot, int m, int comp) {
     // whoever asks for the address of a node field is about to read or write it
     if ((slot == SDC_SLOT_U || slot == SDC_SLOT_F) && sdc_materialize(c, slot, m) != SDC_OK) return nullptr;
     if (slot == SDC_SLOT_TAU && ensure_tau(c) != SDC_OK) return nullptr;
+    if (slot == SDC_SLOT_UEND) c->uend_gen = -1;  // the holder may write it
     if (slot == SDC_SLOT_WORK) return c->W;
     return slot_ptr(c, slot, m, comp);
 }
@@ -915,6 +939,7 @@ int sdc_invalidate_spectra(sdc_ctx* c, int which) {
         c->spec_spread = false;
     }
     if (which & 4) c->force_gather = true;  // some F[m >= 1] no longer equals f(U[m]): gather on F itself
+    if (which & 8) c->uend_gen = -1;        // UEND was overwritten
     return SDC_OK;
 }
 
@@ -1186,6 +1211,7 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
             for (int m = 0; m < M; ++m) p.in[m] = c->U + (size_t)(m + 1) * c->N;
             int rc0 = fwd_transform(c, M, p, c->S, c->Nc);
             if (rc0 != SDC_OK) return rc0;
+            c->spec_gen++;
             c->spec_valid = true;
         }
         SpecArgs a;
@@ -1224,6 +1250,7 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
                 for (int j = 0; j < M; ++j) a.rQ[m][j] = dt * c->Q[m + 1][j + 1];
             HIPCHK(c, hipMemsetAsync(c->res_dev, 0, sizeof(unsigned long long) * 8, c->stream));
         }
+        c->spec_gen++;
         int rc0 = spec_sweep(c, M, a, p, norms_only ? c->res_dev : nullptr);
         if (rc0 != SDC_OK) return rc0;
         c->spec_valid = true;
@@ -1378,15 +1405,19 @@ int sdc_end_point(sdc_ctx* c, double dt, int do_coll_update) {
     if (!c) return SDC_ERR_PARAM;
     if (!c->have_coeffs) return fail(c, SDC_ERR_STATE, "coefficients not set (sdc_set_coeffs)");
     if (!do_coll_update) {
+        c->uend_gen = -1;
         if (c->u_pending && !c->spread_pending) {  // only the last node is needed: transform it straight into UEND
             FieldPtrs p;
             memset(&p, 0, sizeof p);
             p.out[0] = c->UEND;
-            return inverse_from_cache(c, c->M - 1, 1, p);
+            int rci = inverse_from_cache(c, c->M - 1, 1, p);
+            if (rci == SDC_OK) c->uend_gen = c->spec_gen;
+            return rci;
         }
         // a pending spread means U[M] equals U[0]
         return sdc_vec_copy(c, c->N, c->U + (c->spread_pending ? 0 : (size_t)c->M * c->N), c->UEND);
     }
+    c->uend_gen = -1;
     int rcm = materialize(c, false, true);
     if (rcm != SDC_OK) return rcm;
     QuadArgs q;
@@ -1398,6 +1429,25 @@ int sdc_end_point(sdc_ctx* c, double dt, int do_coll_update) {
     q.out[0] = c->UEND;
     for (int j = 0; j < c->M; ++j) q.cI[0][j] = q.cE[0][j] = dt * c->weights[j];
     return launch_quad<0>(c, q, "end_point");
+}
+
+int sdc_advance(sdc_ctx* c) {
+    if (!c) return SDC_ERR_PARAM;
+    int rcm = materialize(c, c->spread_pending, false);  // pending copies of the OLD u[0] are stored first
+    if (rcm != SDC_OK) return rcm;
+    HIPCHK(c, hipMemcpyAsync(c->U, c->UEND, c->N * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    c->res_valid = false;
+    c->res_spread = false;
+    c->spec_spread = false;
+    if (c->S && c->spec_valid && c->uend_gen >= 0 && c->uend_gen == c->spec_gen) {
+        // UEND is the inverse transform of S[M-1]: that spectrum is the transform of the new u[0]
+        HIPCHK(c, hipMemcpyAsync(c->S0, c->S + (size_t)(c->M - 1) * c->Nc, sizeof(cd) * c->Nc, hipMemcpyDeviceToDevice,
+                                 c->stream));
+        c->spec0_valid = true;
+    } else {
+        c->spec0_valid = false;
+    }
+    return SDC_OK;
 }
 
 int sdc_integrate(sdc_ctx* c, double dt, double* const* dst) {

@@ -95,6 +95,10 @@ class SweepEngine:
         """leave F[1..M] / the spread copies unwritten until they are read (include/sdcmi.h: sdc_set_deferred)"""
         self._chk(self.lib.sdc_set_deferred(self.ctx, int(bool(on))))
 
+    def advance(self):
+        """u[0] <- uend for the next time step on this level (include/sdcmi.h: sdc_advance)"""
+        self._chk(self.lib.sdc_advance(self.ctx))
+
     def materialize(self, slot=-1, m=-1):
         self._chk(self.lib.sdc_materialize(self.ctx, int(slot), int(m)))
 

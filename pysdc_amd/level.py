@@ -217,8 +217,17 @@ class Level:
         elif slot == Lb.SLOT_F:
             if m != 0:
                 e.invalidate_spectra(4)
+        elif slot == Lb.SLOT_UEND:
+            e.invalidate_spectra(8)
         elif slot is None:
-            e.invalidate_spectra(7)
+            e.invalidate_spectra(15)
+
+    def advance(self):
+        """next time step on this very level: u[0] <- uend inside the engine (what core/step.py:271 does with the
+        end value of the previous block, controller_nonMPI.py:148); include/sdcmi.h: sdc_advance"""
+        self.engine.advance()
+        self._u.mark([0])
+        self._res_cache = None
 
     def reset_level(self, reset_status=True):
         """pySDC/core/level.py:110-131."""

@@ -255,3 +255,37 @@ def test_deferred_node_fields_match_eager(n, prob):
     same('mode switched off')
     for e in engines:
         e.close()
+
+
+@pytest.mark.parametrize('n,ndim', [(64, 3), (256, 2), (512, 1)])
+def test_advance_hands_the_spectrum_over(n, ndim):
+    """sdc_advance (u[0] <- uend on the same level, spectrum of the last node reused as the transform of the new
+    u[0]) against the plain hand-over through host memory: the next step must agree to round-off."""
+    M, dt = 3, 2e-4
+    c, qi = _coeffs(M, 'LU')
+    engines = []
+    for adv in (True, False):
+        e = G.engine_for('heat_unforced', dict(nvars=(n,) * ndim, nu=0.1), M)
+        e.set_coeffs(c.Qmat, qi, None, c.nodes, c.weights)
+        freq = (C.c_int * 3)(2, 4, 2)
+        L.check(e.lib.sdc_init_field(e.ctx, e.ptr(L.SLOT_U, 0), freq, 0.1, 3), e.ctx)
+        e.invalidate_spectra(1)
+        for step in range(3):
+            e.predict(0.0, dt)
+            for _ in range(3):
+                e.sweep(0.0, dt)
+            e.end_point(dt, False)
+            if adv:
+                e.advance()
+            else:
+                e.upload(L.SLOT_U, 0, e.download(L.SLOT_UEND))
+        e.predict(0.0, dt)
+        e.sweep(0.0, dt)
+        engines.append(e)
+    a, b = engines
+    ua, ub = a.download_u(), b.download_u()
+    assert np.max(np.abs(ua - ub)) <= 1e-13 * np.max(np.abs(ub))
+    ra, rb = a.residual(dt), b.residual(dt)
+    assert np.allclose(ra[1], rb[1], rtol=1e-7, atol=1e-14)
+    for e in engines:
+        e.close()
