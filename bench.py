@@ -39,6 +39,8 @@ def _kernel_bytes(name, n, M, ncomp=1):
         'spec_point_res': (1 + nf) * spec + 2 * nf * spec,  # ... + the residual spectra out
         'spec_z_res': (1 + nf) * spec + 2 * nf * spec,      # spectral sweep + first inverse pass in one launch:
         'spec_z': (1 + nf) * spec + 2 * nf * spec,          # S0 + S in, S and the line-transformed field out
+        'spec_z_res_spread': (1 + 2 * nf) * spec,           # first sweep after a spread predictor: only S0 is read
+        'spec_z_spread': (1 + 2 * nf) * spec,
         'fft_x_norm': nf * spec,                        # half spectra in, max norms out
         'fft_z_inv': 2 * nf * spec,
         'fft_y_inv': 2 * nf * spec,
@@ -275,7 +277,8 @@ def main():
                     'frac': ach / HBM_PEAK_GBS, 'traffic': traffic,
                     'algorithmic_bytes_per_launch': kernel_bytes(dom[0], n, M),
                     'ms_per_launch': dom[1][0] / dom[1][1]}
-        in_sweep = ('gather', 'fft_x_fwd', 'fft_y_fwd', 'fft_z_fwd', 'fft_z_solve', 'spec_point', 'spec_point_res', 'spec_z', 'spec_z_res', 'fft_x_norm',
+        in_sweep = ('gather', 'fft_x_fwd', 'fft_y_fwd', 'fft_z_fwd', 'fft_z_solve', 'spec_point', 'spec_point_res', 'spec_z', 'spec_z_res', 'spec_z_spread', 'spec_z_res_spread',
+                    'fft_x_norm',
                     'fft_z_inv', 'fft_y_inv',
                     'fft_x_inv', 'stencil', 'stencil_res', 'res_stencil', 'vdp_sweep')
         sweep_ms = sum(v[0] for k, v in prof.items() if k.split('[')[0] in in_sweep) / max(1, sweeps_total // world)

@@ -365,7 +365,9 @@ static int spec_sweep_n(sdc_ctx* c, int nf, SpecArgs& a, const FieldPtrs& p, uns
     if constexpr (SDC_FUSE_SPECZ && N >= 64 && N <= 1024) {  // fused with the first inverse pass (M <= 5)
         if (nf <= 5) {
             {
-                LaunchTimer lt(c, pname(norms ? "spec_z_res" : "spec_z", nf));
+                // after a spread predictor all nodes share S0: that launch does not read S (fewer bytes)
+                LaunchTimer lt(c, pname(norms ? (a.spread ? "spec_z_res_spread" : "spec_z_res")
+                                              : (a.spread ? "spec_z_spread" : "spec_z"), nf));
 #define ZCASE(MM) \
     case MM: launch_spec_z<N, MM>(c, a, lines, norms ? 1 : 0); break;
                 switch (nf) { ZCASE(1) ZCASE(2) ZCASE(3) ZCASE(4) ZCASE(5) }
