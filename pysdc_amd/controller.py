@@ -13,6 +13,7 @@ through ``torch.distributed`` (RCCL over xGMI on GPUs, gloo in the CPU tests); t
 broadcast from the last rank (controller_MPI.py:125-130).  Convergence flags travel on the host side."""
 import itertools
 import logging
+import os
 
 import numpy as np
 
@@ -373,6 +374,9 @@ class controller_dist(_ControllerBase):
         self.req_send = [None] * len(self.S.levels)
         self._exchanged_unchanged = False
         self._uend_buf = None
+        self._relay_stage = None
+        self.relay = os.environ.get('PYSDC_AMD_RELAY', '1') != '0'
+        self.two_hop_calls = 0
 
     # ---- host-side scalars (check_convergence.py:105-160; controller_MPI.py:90,120,142) ---------------------
     def _send_flag(self, value, dst):
@@ -498,6 +502,84 @@ class controller_dist(_ControllerBase):
             L.f[0] = L.prob.eval_f(L.u[0], L.time)
         self._hook('post_comm', S, level)
 
+    def _lockstep(self, size):
+        """True when every active rank is known to run the same stage sequence with the same iteration count
+        (single level, Jacobi-type multi-step SDC, and either a fixed number of sweeps - restol < 0 - or
+        all_to_done): only then may a neighbour exchange be carried by ALL ranks together."""
+        S = self.S
+        return (self.relay and size > 2 and len(S.levels) == 1 and self.params.mssdc_jac
+                and (self.params.all_to_done or S.levels[0].params.restol < 0))
+
+    def exchange_two_hop(self, size):
+        """The forward hand-over uend(rank) -> u[0](rank + 1) of ALL active ranks at once, over two hops.
+
+        xGMI is a full mesh of point-to-point links: the direct message uses one of a GPU's seven links while six
+        idle.  Every message is cut into `size` pieces; piece j travels via rank j (phase 1: owner -> relay, phase 2:
+        relay -> destination; the pieces whose relay is the owner or the destination go directly).  Each link then
+        carries 1/size of a message per phase: 2/size of the direct transfer time.  Both phases are one batched
+        group of point-to-point operations (ncclGroupStart/End under RCCL) in which every active rank takes part,
+        which is why the caller must have established lock step (`_lockstep`).  Bit-identical to the direct copy."""
+        import torch
+
+        S, dist = self.S, self.dist
+        L = S.levels[0]
+        r, P = self.rank, size
+        self.two_hop_calls += 1
+        self._hook('pre_comm', S, 0)
+        if self.req_send[0] is not None:
+            self.req_send[0].wait()
+            self.req_send[0] = None
+        L.sweep.compute_end_point()
+        src = L.uend.as_torch().reshape(-1)
+        dst = L.u[0].as_torch().reshape(-1)
+        n = src.numel()
+        csz = -(-n // P)
+
+        def piece(t, j):
+            return t[j * csz:min(n, (j + 1) * csz)]
+
+        mine = min(n, (r + 1) * csz) - r * csz                  # length of the pieces this rank relays
+        if self._relay_stage is None or self._relay_stage.numel() < (P - 1) * max(mine, 1):
+            self._relay_stage = torch.empty((P - 1) * max(mine, 1), dtype=src.dtype, device=src.device)
+
+        def slot(origin):
+            return self._relay_stage[origin * mine:(origin + 1) * mine]
+
+        tag = S.status.iter
+        # phase 1: owners hand piece j to rank j (the destination's own piece lands in place)
+        ops = []
+        if r <= P - 2:
+            for j in range(P):
+                if j != r and piece(src, j).numel() > 0:
+                    ops.append(dist.P2POp(dist.isend, piece(src, j), j, self.comm, tag))
+        if mine > 0:
+            for origin in range(P - 1):
+                if origin != r:
+                    buf = piece(dst, r) if origin == r - 1 else slot(origin)
+                    ops.append(dist.P2POp(dist.irecv, buf, origin, self.comm, tag))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        # phase 2: relays forward to the destinations
+        ops = []
+        if mine > 0:
+            for d in range(1, P):
+                if d != r:
+                    origin = d - 1
+                    ops.append(dist.P2POp(dist.isend, piece(src, r) if origin == r else slot(origin), d, self.comm,
+                                          tag))
+        if r >= 1:
+            for j in range(P):
+                if j != r and piece(dst, j).numel() > 0:
+                    ops.append(dist.P2POp(dist.irecv, piece(dst, j), j, self.comm, tag))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        if r >= 1:
+            L._touched(0, 0)  # u[0] was overwritten by the receive
+            L.f[0] = L.prob.eval_f(L.u[0], L.time)
+        self._hook('post_comm', S, 0)
+
     def pfasst(self, size):
         S = self.S
         stage = S.status.stage
@@ -524,7 +606,10 @@ class controller_dist(_ControllerBase):
     def it_check(self, size):
         S = self.S
         L = S.levels[0]
-        self.exchange(0)
+        if self._lockstep(size):
+            self.exchange_two_hop(size)
+        else:
+            self.exchange(0)
         self._exchanged_unchanged = True  # nothing on level 0 changes until the next sweep / prolongation
         L.sweep.compute_residual(stage='IT_CHECK')
         if S.status.iter > 0:

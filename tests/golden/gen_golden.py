@@ -544,3 +544,25 @@ def fft_transfer_main():
 
 if __name__ == '__main__' and os.environ.get('GOLDEN_FFT', '0') == '1':
     fft_transfer_main()
+
+
+def relay_main():
+    """multi-step SDC runs whose ranks all iterate the same number of times (fixed K / all_to_done): the setting
+    in which controller_dist forwards end values over two hops (tests/test_dist_gloo.py, 3 and 4 ranks)."""
+    RR = dict(quad_type='RADAU-RIGHT')
+    h2 = dict(nvars=(16, 16), nu=0.1, freq=2, bc='periodic')
+    sw = dict(num_nodes=3, QI='LU', **RR)
+    cases = []
+    cases.append(run_case('fixedK_2d_P4', 'heat_unforced', h2, 'generic_implicit', sw, dict(dt=0.02, restol=-1), 4, 0.0,
+                          0.16, num_procs=4, seed=1))
+    cases.append(run_case('fixedK_2d_P3', 'heat_unforced', h2, 'generic_implicit', sw, dict(dt=0.02, restol=-1), 3, 0.0,
+                          0.12, num_procs=3, seed=2))
+    cases.append(run_case('alltodone_2d_P4', 'heat_unforced', h2, 'generic_implicit', sw, dict(dt=0.02, restol=1e-9), 50,
+                          0.0, 0.16, num_procs=4, controller_params=dict(all_to_done=True), seed=3))
+    cases.append(run_case('fixedK_2d_P4_tail', 'heat_unforced', h2, 'generic_implicit', sw, dict(dt=0.02, restol=-1), 4,
+                          0.0, 0.12, num_procs=4, seed=4))     # second block: 2 of 4 ranks active
+    save('runs_relay.npz', cases)
+
+
+if __name__ == '__main__' and os.environ.get('GOLDEN_RELAY', '0') == '1':
+    relay_main()

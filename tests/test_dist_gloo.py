@@ -20,9 +20,10 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, name, outdir):
+def _worker(rank, world, port, name, outdir, fname='runs.npz', relay='1'):
     import torch.distributed as dist
 
+    os.environ['PYSDC_AMD_RELAY'] = relay
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -32,7 +33,7 @@ def _worker(rank, world, port, name, outdir):
         from pysdc_amd.stats import get_sorted
         from tests._oracle_step import OracleStep, np_mesh
 
-        case = load_cases('runs.npz')[name]
+        case = load_cases(fname)[name]
         meta = case['meta']
         lp = meta['level_params']
         coll = make_oracle_coll(case)
@@ -49,7 +50,7 @@ def _worker(rank, world, port, name, outdir):
         uend, stats = C.run(u0, meta['t0'], meta['Tend'])
         niter = get_sorted(stats, type='niter', sortby='time')
         np.savez(os.path.join(outdir, f'r{rank}.npz'), uend=np.asarray(uend), t=[t for t, _ in niter],
-                 n=[v for _, v in niter])
+                 n=[v for _, v in niter], two_hop=getattr(C, 'two_hop_calls', 0))
     finally:
         dist.destroy_process_group()
 
@@ -67,3 +68,25 @@ def test_two_ranks_match_serial_golden(name):
     np.testing.assert_allclose(times[order], case['niter_t'], rtol=0, atol=1e-14)
     for k in range(2):                                                # every rank holds the broadcast end value
         assert rel_err(r[k]['uend'], case['uend']) < 1e-13
+
+
+@pytest.mark.parametrize('relay', ['1', '0'])
+@pytest.mark.parametrize('name,world', [('fixedK_2d_P4', 4), ('fixedK_2d_P3', 3), ('alltodone_2d_P4', 4),
+                                        ('fixedK_2d_P4_tail', 4)])
+def test_lockstep_runs_with_two_hop_exchange(name, world, relay):
+    """3 and 4 ranks whose iteration counts are equal by construction (fixed K, all_to_done): the end values are
+    forwarded over two hops by all ranks together (controller_dist.exchange_two_hop; relay='0': direct
+    messages).  Same golden serial runs, same bits either way."""
+    case = load_cases('runs_relay.npz')[name]
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(world, _free_port(), name, d, 'runs_relay.npz', relay), nprocs=world, join=True)
+        r = [np.load(os.path.join(d, f'r{k}.npz')) for k in range(world)]
+    times = np.concatenate([x['t'] for x in r])
+    niter = np.concatenate([x['n'] for x in r])
+    order = np.argsort(times)
+    assert list(niter[order]) == list(case['niter'])
+    np.testing.assert_allclose(times[order], case['niter_t'], rtol=0, atol=1e-14)
+    for k in range(world):
+        assert rel_err(r[k]['uend'], case['uend']) < 1e-13
+        assert (int(r[k]['two_hop']) > 0) == (relay == '1')
+    assert all(np.array_equal(r[0]['uend'], x['uend']) for x in r[1:])
