@@ -104,6 +104,10 @@ int sdc_set_fused_residual(sdc_ctx* ctx, int on);
  * its spectrum) and keep U[1..M] in the cache; sdc_end_point transforms only the last node. */
 int sdc_set_deferred(sdc_ctx* ctx, int on);
 int sdc_materialize(sdc_ctx* ctx, int slot, int m);
+/* f[0] = f(u[0]) after u[0] was replaced by a receive (controller_MPI.py:233, controller_nonMPI.py:284).  No sweep,
+ * residual or end point reads f[0] (all node loops start at 1); the evaluation happens when F[0] is asked for
+ * (sdc_slot_ptr / sdc_materialize / views), or at once when the deferred mode is off. */
+int sdc_defer_f0(sdc_ctx* ctx);
 /* L.status.unlocked: set by sdc_predict; a coarse level is unlocked by the restriction instead
  * (pySDC/core/base_transfer.py:166) - the host mirrors that here. */
 int sdc_set_unlocked(sdc_ctx* ctx, int unlocked); /* default on; 0 = transform the gathered fields every sweep */

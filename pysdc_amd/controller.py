@@ -173,7 +173,10 @@ class controller_nonMPI(_ControllerBase):
             if source.tag != tag:
                 raise CommunicationError('source and target tag are not the same, got %s and %s' % (source.tag, tag))
             target.u[0] = source.uend
-            target.f[0] = target.prob.eval_f(target.u[0], target.time)
+            if hasattr(target, 'refresh_f0'):
+                target.refresh_f0()
+            else:
+                target.f[0] = target.prob.eval_f(target.u[0], target.time)
         self._hook('post_comm', S, level, add_to_stats=add_to_stats)
 
     # controller_nonMPI.py:297-332
@@ -499,7 +502,10 @@ class controller_dist(_ControllerBase):
                 self.req_send[level] = reqs[0] if len(reqs) == 1 else _WorkList(reqs)
         if do_recv:
             L._touched(0, 0)  # u[0] was overwritten by the receive
-            L.f[0] = L.prob.eval_f(L.u[0], L.time)
+            if hasattr(L, 'refresh_f0'):
+                L.refresh_f0()
+            else:
+                L.f[0] = L.prob.eval_f(L.u[0], L.time)
         self._hook('post_comm', S, level)
 
     def _lockstep(self, size):
@@ -577,7 +583,10 @@ class controller_dist(_ControllerBase):
                 req.wait()
         if r >= 1:
             L._touched(0, 0)  # u[0] was overwritten by the receive
-            L.f[0] = L.prob.eval_f(L.u[0], L.time)
+            if hasattr(L, 'refresh_f0'):
+                L.refresh_f0()
+            else:
+                L.f[0] = L.prob.eval_f(L.u[0], L.time)
         self._hook('post_comm', S, 0)
 
     def pfasst(self, size):

@@ -48,6 +48,7 @@ struct sdc_ctx {
     bool deferred = true;
     bool spread_pending = false;  // U[1..M] = U[0], F[1..M] = F[0] not stored yet
     bool f_pending = false;       // F[1..M] = f(U[1..M]) not stored yet
+    bool f0_pending = false;      // F[0] = f(U[0]) not evaluated yet (no sweep reads it)
     long long spec_gen = 0;       // bumped whenever the contents of S change
     long long uend_gen = -1;      // spec_gen at which UEND was produced as the inverse transform of S[M-1], or -1
     bool u_pending = false;       // U[1..M] live in the spectral cache S only (inverse transform not done yet)

@@ -836,6 +836,7 @@ int sdc_set_forcing_values(sdc_ctx* c, const double* g) {
 }
 
 extern "C" int sdc_invalidate_spectra(sdc_ctx* c, int which);
+extern "C" int sdc_materialize(sdc_ctx* c, int slot, int m);
 extern "C" int sdc_solve(sdc_ctx* c, const double* rhs, double factor, const double* guess, double* out);
 extern "C" int sdc_eval_f(sdc_ctx* c, const double* u, double g_t, double* f_impl, double* f_expl);
 
@@ -906,14 +907,29 @@ int sdc_materialize(sdc_ctx* c, int slot, int m) {
         if (!c->spread_pending) return SDC_OK;
         return materialize(c, true, false);
     }
-    if (slot == SDC_SLOT_F && m == 0) return SDC_OK;
+    if (slot == SDC_SLOT_F && m == 0) {
+        if (!c->f0_pending) return SDC_OK;
+        c->f0_pending = false;
+        return sdc_eval_f(c, c->U, c->gvals[0], c->F, c->ncomp == 2 ? c->F + c->N : nullptr);
+    }
+    if (slot < 0 && c->f0_pending) {
+        c->f0_pending = false;
+        int rc0 = sdc_eval_f(c, c->U, c->gvals[0], c->F, c->ncomp == 2 ? c->F + c->N : nullptr);
+        if (rc0 != SDC_OK) return rc0;
+    }
     return materialize(c, slot == SDC_SLOT_U || slot < 0, slot == SDC_SLOT_F || slot < 0);
 }
 
 int sdc_set_deferred(sdc_ctx* c, int on) {
     if (!c) return SDC_ERR_PARAM;
     c->deferred = on != 0;
-    return on ? SDC_OK : materialize(c, true, true);
+    return on ? SDC_OK : sdc_materialize(c, -1, -1);
+}
+
+int sdc_defer_f0(sdc_ctx* c) {
+    if (!c) return SDC_ERR_PARAM;
+    c->f0_pending = true;
+    return c->deferred ? SDC_OK : sdc_materialize(c, SDC_SLOT_F, 0);
 }
 
 void* sdc_slot_ptr(sdc_ctx* c, int slot, int m, int comp) {
@@ -1057,7 +1073,7 @@ int sdc_predict(sdc_ctx* c, double t, double dt, int guess, double fill_u, doubl
     // dt * |sum_j Q[m][j]| * max|f(u0)| and the fill kernel can reduce max|f(u0)| on the way
     const bool spread_res = guess == SDC_GUESS_SPREAD && c->expl_kind != SDC_EXPL_FORCING && !c->tau_active;
     if (spread_res) HIPCHK(c, hipMemsetAsync(c->res_dev, 0, sizeof(unsigned long long) * 8, c->stream));
-    c->spread_pending = c->f_pending = c->u_pending = false;
+    c->spread_pending = c->f_pending = c->u_pending = c->f0_pending = false;
     if (c->deferred && c->kind == 0 && guess == SDC_GUESS_SPREAD && c->expl_kind != SDC_EXPL_FORCING) {
         // the node copies are not stored until somebody reads them (materialize); only max|f(u0)| is needed now
         if (spread_res) {

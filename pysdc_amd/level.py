@@ -222,6 +222,15 @@ class Level:
         elif slot is None:
             e.invalidate_spectra(15)
 
+    def refresh_f0(self):
+        """f[0] = f(u[0]) after u[0] was replaced (controller_MPI.py:233, controller_nonMPI.py:284).  Nothing on
+        the sweep path reads f[0]; an engine-backed problem evaluates it when it is asked for."""
+        if getattr(self.prob, 'fused', False) and self.__engine is not None:
+            Lb.check(self.__engine.lib.sdc_defer_f0(self.__engine.ctx), self.__engine.ctx)
+            self._f.mark([0])
+        else:
+            self.f[0] = self.prob.eval_f(self.u[0], self.time)
+
     def advance(self):
         """next time step on this very level: u[0] <- uend inside the engine (what core/step.py:271 does with the
         end value of the previous block, controller_nonMPI.py:148); include/sdcmi.h: sdc_advance"""
