@@ -108,6 +108,13 @@ int sdc_materialize(sdc_ctx* ctx, int slot, int m);
  * residual or end point reads f[0] (all node loops start at 1); the evaluation happens when F[0] is asked for
  * (sdc_slot_ptr / sdc_materialize / views), or at once when the deferred mode is off. */
 int sdc_defer_f0(sdc_ctx* ctx);
+/* Time-parallel runs replace u[0] between sweeps (the receive of controller_MPI.py:218-233) and then ask for the
+ * residual against the new value (:592).  With sdc_set_keep_residual_fields(ctx, 1) a sweep that stays in Fourier
+ * space also stores the residual fields r_m it reduces (in the U[1..M] slab, free while the iterate lives in the
+ * cache); sdc_replace_u0(ctx, src) then copies the new value in and updates the node norms in the same pass
+ * (r_m changes by new - old for every m).  Without kept fields it is a plain copy. src: device field of N doubles. */
+int sdc_set_keep_residual_fields(sdc_ctx* ctx, int on);
+int sdc_replace_u0(sdc_ctx* ctx, const double* src);
 /* L.status.unlocked: set by sdc_predict; a coarse level is unlocked by the restriction instead
  * (pySDC/core/base_transfer.py:166) - the host mirrors that here. */
 int sdc_set_unlocked(sdc_ctx* ctx, int unlocked); /* default on; 0 = transform the gathered fields every sweep */

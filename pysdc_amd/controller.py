@@ -378,10 +378,30 @@ class controller_dist(_ControllerBase):
         self._exchanged_unchanged = False
         self._uend_buf = None
         self._relay_stage = None
+        self._inbox = None
         self.relay = os.environ.get('PYSDC_AMD_RELAY', '1') != '0'
         self.two_hop_calls = 0
 
     # ---- host-side scalars (check_convergence.py:105-160; controller_MPI.py:90,120,142) ---------------------
+    def _recv_target(self, L):
+        """where a received u[0] lands: device levels take it through Level.replace_u0 (the engine then updates the
+        residual norms in the same pass), so it goes to an inbox first"""
+        if hasattr(L, 'replace_u0') and L is self.S.levels[0] and not L._view_offset():
+            if self._inbox is None:
+                self._inbox = L.prob.dtype_u(L.prob.init)
+            return self._inbox
+        return None
+
+    def _received(self, L, inbox):
+        if inbox is not None:
+            L.replace_u0(inbox)
+        else:
+            L._touched(0, 0)  # u[0] was overwritten by the receive
+        if hasattr(L, 'refresh_f0'):
+            L.refresh_f0()
+        else:
+            L.f[0] = L.prob.eval_f(L.u[0], L.time)
+
     def _send_flag(self, value, dst):
         import torch
 
@@ -415,6 +435,9 @@ class controller_dist(_ControllerBase):
         if num_active == 0:
             raise ControllerError('Nothing to do, check t0, dt and Tend!')
         P = S.levels[0].prob
+        if self.size > 1 and hasattr(S.levels[0], 'replace_u0') and hasattr(S.levels[0], 'engine'):
+            # u[0] is replaced between sweeps and the residual is asked for again: keep the residual fields
+            S.levels[0].engine.set_keep_residual_fields(True)
         if self._uend_buf is None:   # lives as long as the controller: allocating 8.6 GB per run costs ~0.25 s
             self._uend_buf = P.dtype_u(u0)
         elif self._uend_buf is not u0:
@@ -487,8 +510,10 @@ class controller_dist(_ControllerBase):
             if not S.status.last:
                 ops.append(self.dist.P2POp(self.dist.isend, L.uend.as_torch(), self.rank + 1, self.comm, tag))
         do_recv = recv and not S.status.first and not S.status.prev_done
+        inbox = self._recv_target(L) if do_recv else None
         if do_recv:
-            ops.append(self.dist.P2POp(self.dist.irecv, L.u[0].as_torch(), self.rank - 1, self.comm, tag))
+            ops.append(self.dist.P2POp(self.dist.irecv, (inbox if inbox is not None else L.u[0]).as_torch(),
+                                       self.rank - 1, self.comm, tag))
         if ops:
             # one batched launch (ncclGroupStart/End under RCCL): depending on the torch version this returns one
             # work object per operation or a single one for the whole group, so a group that contains the
@@ -501,11 +526,7 @@ class controller_dist(_ControllerBase):
             else:
                 self.req_send[level] = reqs[0] if len(reqs) == 1 else _WorkList(reqs)
         if do_recv:
-            L._touched(0, 0)  # u[0] was overwritten by the receive
-            if hasattr(L, 'refresh_f0'):
-                L.refresh_f0()
-            else:
-                L.f[0] = L.prob.eval_f(L.u[0], L.time)
+            self._received(L, inbox)
         self._hook('post_comm', S, level)
 
     def _lockstep(self, size):
@@ -537,7 +558,8 @@ class controller_dist(_ControllerBase):
             self.req_send[0] = None
         L.sweep.compute_end_point()
         src = L.uend.as_torch().reshape(-1)
-        dst = L.u[0].as_torch().reshape(-1)
+        inbox = self._recv_target(L) if r >= 1 else None
+        dst = (inbox if inbox is not None else L.u[0]).as_torch().reshape(-1)
         n = src.numel()
         csz = -(-n // P)
 
@@ -582,11 +604,7 @@ class controller_dist(_ControllerBase):
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
         if r >= 1:
-            L._touched(0, 0)  # u[0] was overwritten by the receive
-            if hasattr(L, 'refresh_f0'):
-                L.refresh_f0()
-            else:
-                L.f[0] = L.prob.eval_f(L.u[0], L.time)
+            self._received(L, inbox)
         self._hook('post_comm', S, 0)
 
     def pfasst(self, size):

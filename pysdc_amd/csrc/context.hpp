@@ -48,6 +48,8 @@ struct sdc_ctx {
     bool deferred = true;
     bool spread_pending = false;  // U[1..M] = U[0], F[1..M] = F[0] not stored yet
     bool f_pending = false;       // F[1..M] = f(U[1..M]) not stored yet
+    bool keep_rfields = false;    // sweeps that only reduce the residual also store its fields in the U[1..M] slab
+    bool rfields_valid = false;   // ... and they are there now (U[1..M] themselves live in S: u_pending)
     bool f0_pending = false;      // F[0] = f(U[0]) not evaluated yet (no sweep reads it)
     long long spec_gen = 0;       // bumped whenever the contents of S change
     long long uend_gen = -1;      // spec_gen at which UEND was produced as the inverse transform of S[M-1], or -1

@@ -73,9 +73,9 @@ __global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_fwd(FieldPtr
     }
 }
 
-// c2r along axis 0 (inverse of the above, unnormalised).  NORM: the real field is not stored, only max |.| per
-// field goes to norms[field] (the fields are the collocation residuals of the spectral sweep).
-template <int N, int T, bool NORM>
+// c2r along axis 0 (inverse of the above, unnormalised).  NORM: max |.| per field goes to norms[field] (the fields
+// are the collocation residuals of the spectral sweep); STORE: the real field is written to out[field].
+template <int N, int T, bool NORM, bool STORE>
 __global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_inv(FieldPtrs p, const cd* __restrict__ W,
                                                                       size_t fstride, int rest,
                                                                       const cd* __restrict__ tw,
@@ -141,7 +141,8 @@ __global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_inv(FieldPtr
         }
         m = wave_max(m);
         if ((threadIdx.x & 63) == 0) atomic_max_abs(norms + blockIdx.y, m);
-    } else {
+    }
+    if constexpr (STORE) {
         double* __restrict__ out = p.out[blockIdx.y];
         if (ok) {
 #pragma unroll

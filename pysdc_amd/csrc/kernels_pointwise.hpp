@@ -212,3 +212,33 @@ __global__ __launch_bounds__(256) void k_spread(SpreadArgs a) {
     }
 }
 
+// u[0] is replaced while the residual FIELDS r_m = u0 + dt sum_j Q[m][j] f_j - u_m of the current iterate are
+// at hand (kept by the sweep in the U[1..M] slab): r_m changes by the same difference for every node, so the
+// node norms against the new u[0] follow in one pass:  d = new - old, u0 <- new, norms[m] = max |r_m + d|.
+template <int M>
+__global__ __launch_bounds__(256) void k_replace_u0(const double* __restrict__ src, double* __restrict__ U, size_t N,
+                                                    unsigned long long* __restrict__ norms) {
+    double nm[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) nm[m] = 0.0;
+    const size_t n2 = N >> 1;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x * blockDim.x) {
+        const double2 nw = reinterpret_cast<const double2*>(src)[i];
+        const double2 od = reinterpret_cast<const double2*>(U)[i];
+        const double d0 = nw.x - od.x, d1 = nw.y - od.y;
+        reinterpret_cast<double2*>(U)[i] = nw;
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const double2 r = reinterpret_cast<const double2*>(U + (size_t)(m + 1) * N)[i];
+            const double v0 = fabs(r.x + d0), v1 = fabs(r.y + d1);
+            const double v = (v0 > v1 || v0 != v0) ? v0 : v1;
+            nm[m] = (nm[m] > v || nm[m] != nm[m]) ? nm[m] : v;
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        const double v = wave_max(nm[m]);
+        if ((threadIdx.x & 63) == 0) atomic_max_abs(norms + m, v);
+    }
+}
+

@@ -245,7 +245,7 @@ static int fft_pipeline_n(sdc_ctx* c, int nf, const FieldPtrs& p, ZArgs& z) {
                                c->stream, c->W, c->Nc, c->tw);
         }
         LaunchTimer lt(c, pname("fft_x_inv", nf));
-        hipLaunchKernelGGL((k_fftx_inv<N, T, false>), dim3(tiles, nf), dim3(P * T), lds_str, c->stream, p, c->W, c->Nc,
+        hipLaunchKernelGGL((k_fftx_inv<N, T, false, true>), dim3(tiles, nf), dim3(P * T), lds_str, c->stream, p, c->W, c->Nc,
                            rest, c->tw, nullptr);
     }
     HIPCHK(c, hipGetLastError());
@@ -305,12 +305,18 @@ static int inverse_tail_n(sdc_ctx* c, int nf, cd* work, const FieldPtrs& p, unsi
                                work, c->Nc, c->tw);
         }
         if (norms) {
-            LaunchTimer lt(c, pname("fft_x_norm", nf));
-            hipLaunchKernelGGL((k_fftx_inv<N, T, true>), dim3(tiles, nf), dim3(P * T), lds_str, c->stream, p, work, c->Nc,
-                               rest, c->tw, norms);
+            if (p.out[0]) {  // the residual fields are kept as well
+                LaunchTimer lt(c, pname("fft_x_inv_norm", nf));
+                hipLaunchKernelGGL((k_fftx_inv<N, T, true, true>), dim3(tiles, nf), dim3(P * T), lds_str, c->stream, p,
+                                   work, c->Nc, rest, c->tw, norms);
+            } else {
+                LaunchTimer lt(c, pname("fft_x_norm", nf));
+                hipLaunchKernelGGL((k_fftx_inv<N, T, true, false>), dim3(tiles, nf), dim3(P * T), lds_str, c->stream, p,
+                                   work, c->Nc, rest, c->tw, norms);
+            }
         } else {
             LaunchTimer lt(c, pname("fft_x_inv", nf));
-            hipLaunchKernelGGL((k_fftx_inv<N, T, false>), dim3(tiles, nf), dim3(P * T), lds_str, c->stream, p, work,
+            hipLaunchKernelGGL((k_fftx_inv<N, T, false, true>), dim3(tiles, nf), dim3(P * T), lds_str, c->stream, p, work,
                                c->Nc, rest, c->tw, nullptr);
         }
     }
@@ -894,6 +900,7 @@ static int materialize(sdc_ctx* c, bool need_u, bool need_f) {
         memset(&p, 0, sizeof p);
         for (int m = 0; m < c->M; ++m) p.out[m] = c->U + (size_t)(m + 1) * c->N;
         c->u_pending = false;
+        c->rfields_valid = false;
         int rc = inverse_from_cache(c, 0, c->M, p);
         if (rc != SDC_OK) return rc;
     }
@@ -1073,7 +1080,7 @@ int sdc_predict(sdc_ctx* c, double t, double dt, int guess, double fill_u, doubl
     // dt * |sum_j Q[m][j]| * max|f(u0)| and the fill kernel can reduce max|f(u0)| on the way
     const bool spread_res = guess == SDC_GUESS_SPREAD && c->expl_kind != SDC_EXPL_FORCING && !c->tau_active;
     if (spread_res) HIPCHK(c, hipMemsetAsync(c->res_dev, 0, sizeof(unsigned long long) * 8, c->stream));
-    c->spread_pending = c->f_pending = c->u_pending = c->f0_pending = false;
+    c->spread_pending = c->f_pending = c->u_pending = c->f0_pending = c->rfields_valid = false;
     if (c->deferred && c->kind == 0 && guess == SDC_GUESS_SPREAD && c->expl_kind != SDC_EXPL_FORCING) {
         // the node copies are not stored until somebody reads them (materialize); only max|f(u0)| is needed now
         if (spread_res) {
@@ -1165,6 +1172,7 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
     const int M = c->M;
     c->res_valid = false;
     c->res_spread = false;
+    c->rfields_valid = false;
     if (c->kind == 1) {
         VdpSweepArgs a;
         memset(&a, 0, sizeof a);
@@ -1246,8 +1254,11 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
         a.ndim = c->ndim;
         a.spread = (!c->spec_valid && c->spec_spread) ? 1 : 0;
         bool coupled = false;
+        const bool norms_only = c->deferred && c->fuse_residual && c->ndim >= 2;
         for (int m = 0; m < M; ++m) {
-            p.out[m] = c->U + (size_t)(m + 1) * c->N;
+            // norms only: nothing is stored in real space - unless the residual FIELDS are wanted (keep_rfields),
+            // which then occupy the U[1..M] slab while the iterate itself lives in the cache
+            p.out[m] = (norms_only && !c->keep_rfields) ? nullptr : c->U + (size_t)(m + 1) * c->N;
             a.alpha[m] = dt * c->QI[m + 1][m + 1];
             for (int j = 0; j < M; ++j) {
                 a.gI[m][j] = dt * (c->Q[m + 1][j + 1] - c->QI[m + 1][j + 1]);
@@ -1262,7 +1273,6 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
         a.coupled = coupled;
         // nothing downstream needs the node values in real space to keep sweeping: only the node norms of the
         // residual are produced (from its transform), U and F stay deferred
-        const bool norms_only = c->deferred && c->fuse_residual && c->ndim >= 2;
         if (norms_only) {
             for (int m = 0; m < M; ++m)
                 for (int j = 0; j < M; ++j) a.rQ[m][j] = dt * c->Q[m + 1][j + 1];
@@ -1278,6 +1288,7 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
             c->u_pending = c->f_pending = true;
             c->res_valid = true;
             c->res_dt = dt;
+            c->rfields_valid = c->keep_rfields;
             return SDC_OK;
         }
         c->u_pending = false;  // U[1..M] hold the new iterate; F follows in eval_nodes
@@ -1465,6 +1476,38 @@ int sdc_advance(sdc_ctx* c) {
     } else {
         c->spec0_valid = false;
     }
+    return SDC_OK;
+}
+
+int sdc_set_keep_residual_fields(sdc_ctx* c, int on) {
+    if (!c) return SDC_ERR_PARAM;
+    c->keep_rfields = on != 0;
+    if (!on) c->rfields_valid = false;
+    return SDC_OK;
+}
+
+int sdc_replace_u0(sdc_ctx* c, const double* src) {
+    if (!c || !src) return fail(c, SDC_ERR_PARAM, "null pointer");
+    int rcm = materialize(c, c->spread_pending, false);  // pending copies of the OLD u[0] are stored first
+    if (rcm != SDC_OK) return rcm;
+    const bool fast = c->rfields_valid && c->res_valid && c->u_pending && !c->tau_active;
+    if (fast) {
+        HIPCHK(c, hipMemsetAsync(c->res_dev, 0, sizeof(unsigned long long) * 8, c->stream));
+        LaunchTimer lt(c, pname("replace_u0", c->M));
+        const int grid = grid_for(c->N / 2, 256);
+#define RCASE(MM) \
+    case MM: hipLaunchKernelGGL((k_replace_u0<MM>), dim3(grid), dim3(256), 0, c->stream, src, c->U, c->N, c->res_dev); break;
+        switch (c->M) { RCASE(1) RCASE(2) RCASE(3) RCASE(4) RCASE(5) RCASE(6) RCASE(7) RCASE(8) }
+#undef RCASE
+        HIPCHK(c, hipGetLastError());
+        c->rfields_valid = false;  // the stored fields belong to the old u[0]
+    } else {
+        HIPCHK(c, hipMemcpyAsync(c->U, src, c->N * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        c->res_valid = false;
+    }
+    c->res_spread = false;
+    c->spec0_valid = false;
+    c->spec_spread = false;
     return SDC_OK;
 }
 

@@ -95,6 +95,14 @@ class SweepEngine:
         """leave F[1..M] / the spread copies unwritten until they are read (include/sdcmi.h: sdc_set_deferred)"""
         self._chk(self.lib.sdc_set_deferred(self.ctx, int(bool(on))))
 
+    def set_keep_residual_fields(self, on):
+        self._chk(self.lib.sdc_set_keep_residual_fields(self.ctx, int(bool(on))))
+
+    def replace_u0(self, src_ptr):
+        """u[0] <- src with the node norms of the residual updated in the same pass when the sweep kept the residual
+        fields (include/sdcmi.h: sdc_replace_u0)"""
+        self._chk(self.lib.sdc_replace_u0(self.ctx, src_ptr))
+
     def advance(self):
         """u[0] <- uend for the next time step on this level (include/sdcmi.h: sdc_advance)"""
         self._chk(self.lib.sdc_advance(self.ctx))

@@ -222,6 +222,16 @@ class Level:
         elif slot is None:
             e.invalidate_spectra(15)
 
+    def replace_u0(self, src):
+        """u[0] <- src (a device field of this level's shape), e.g. the value received from the previous time slice;
+        the engine updates the node norms of the residual on the way when it kept the residual fields"""
+        if self._view_offset():
+            self.u[0] = src
+            return
+        self.engine.replace_u0(src.ptr)
+        self._u.mark([0])
+        self._res_cache = None
+
     def refresh_f0(self):
         """f[0] = f(u[0]) after u[0] was replaced (controller_MPI.py:233, controller_nonMPI.py:284).  Nothing on
         the sweep path reads f[0]; an engine-backed problem evaluates it when it is asked for."""

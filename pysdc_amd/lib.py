@@ -43,6 +43,8 @@ PROTOTYPES = {
     'sdc_set_deferred': (C.c_int, [_vp, C.c_int]),
     'sdc_advance': (C.c_int, [_vp]),
     'sdc_defer_f0': (C.c_int, [_vp]),
+    'sdc_set_keep_residual_fields': (C.c_int, [_vp, C.c_int]),
+    'sdc_replace_u0': (C.c_int, [_vp, _vp]),
     'sdc_fft_prolong': (C.c_int, [_vp, _vp, _vp, _vp, C.c_double]),
     'sdc_materialize': (C.c_int, [_vp, C.c_int, C.c_int]),
     'sdc_init_field': (C.c_int, [_vp, _vp, C.POINTER(C.c_int), C.c_double, C.c_ulonglong]),

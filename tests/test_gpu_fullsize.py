@@ -289,3 +289,48 @@ def test_advance_hands_the_spectrum_over(n, ndim):
     assert np.allclose(ra[1], rb[1], rtol=1e-7, atol=1e-14)
     for e in engines:
         e.close()
+
+
+@pytest.mark.parametrize('n,prob', [(64, 'heat_unforced'), (64, 'advdiff')])
+def test_replace_u0_updates_the_residual_from_kept_fields(n, prob):
+    """time-parallel flow on one engine: sweep, u[0] replaced (a receive), residual against the new u[0], next
+    sweep.  With kept residual fields the norms come out of the replacing pass itself; they must agree with the
+    eager engine that recomputes the residual from U and F, and the following sweeps must not notice."""
+    M, dt = 5, 1e-3 * (512.0 / n) ** 2
+    c, qi = _coeffs(M, 'IE')
+    qe = None
+    if prob == 'advdiff':
+        from pysdc_amd.coeffs import QDELTA_GENERATORS
+
+        qe = np.zeros_like(c.Qmat)
+        qe[1:, 1:], qe[1:, 0] = QDELTA_GENERATORS['EE'](qGen=c.generator, tLeft=0).genCoeffs(dTau=True)
+    engines = []
+    for keep in (True, False):
+        e = G.engine_for(prob, dict(nvars=(n, n, n), nu=0.1), M)
+        e.set_coeffs(c.Qmat, qi, qe, c.nodes, c.weights)
+        e.set_deferred(keep)
+        e.set_keep_residual_fields(keep)
+        freq = (C.c_int * 3)(2, 4, 2)
+        L.check(e.lib.sdc_init_field(e.ctx, e.ptr(L.SLOT_U, 0), freq, 0.3, 5), e.ctx)
+        e.invalidate_spectra(1)
+        e.predict(0.0, dt)
+        engines.append(e)
+    a, b = engines
+    import torch
+
+    for it in range(3):
+        for e in engines:
+            e.sweep(0.0, dt)
+        ra, rb = a.residual(dt), b.residual(dt)
+        assert np.allclose(ra[1], rb[1], rtol=1e-9, atol=1e-14)
+        new_u0 = b.download(L.SLOT_U, 0) * (1.0 + 1e-3 * (it + 1)) + 1e-5
+        t = torch.from_numpy(new_u0.reshape(-1)).cuda()
+        for e in engines:
+            e.replace_u0(t.data_ptr())
+        ra, rb = a.residual(dt), b.residual(dt)                 # a: norms from the replacing pass
+        assert np.allclose(ra[1], rb[1], rtol=1e-9, atol=1e-14) and abs(ra[0] - rb[0]) <= 1e-9 * rb[0]
+        assert np.array_equal(a.download(L.SLOT_U, 0), new_u0)
+    ua, ub = a.download_u(), b.download_u()
+    assert np.max(np.abs(ua - ub)) <= 1e-13 * np.max(np.abs(ub))
+    for e in engines:
+        e.close()

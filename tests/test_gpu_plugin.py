@@ -309,3 +309,30 @@ def test_views_kept_across_sweeps_see_current_values():
             assert abs(x - y) <= 1e-9 * abs(y)
         else:
             assert np.array_equal(np.asarray(x), np.asarray(y)), i
+
+
+def test_refresh_f0_is_evaluated_on_demand():
+    """Level.refresh_f0 (f[0] = f(u[0]) after a receive, controller_MPI.py:233) defers the evaluation; reading
+    L.f[0] afterwards gives f of the NEW u[0]."""
+    from pysdc_amd.level import Step
+    from pysdc_amd.problems import heatNd_unforced, advectiondiffusionNd_imex
+    from pysdc_amd.sweepers import generic_implicit, imex_1st_order
+
+    for pc, sc, extra in ((heatNd_unforced, generic_implicit, {}), (advectiondiffusionNd_imex, imex_1st_order, dict(c=1.0))):
+        desc = dict(problem_class=pc, problem_params=dict(nvars=(16, 16, 16), nu=0.1, freq=(2, 2, 2), **extra),
+                    sweeper_class=sc, sweeper_params=dict(num_nodes=3, quad_type='RADAU-RIGHT'),
+                    level_params=dict(dt=1e-2), step_params=dict(maxiter=4))
+        S = Step(desc)
+        L = S.levels[0]
+        L.status.time = 0.0
+        L.u[0] = L.prob.u_exact(0.0)
+        L.sweep.predict()
+        L.sweep.update_nodes()
+        new = L.prob.u_exact(0.3)
+        new *= 1.5
+        L.u[0] = new                                   # what a receive does
+        L.refresh_f0()
+        L.sweep.update_nodes()                         # sweeps do not need f[0]
+        want = L.prob.eval_f(new, 0.0)
+        got = L.f[0]
+        assert np.array_equal(np.asarray(got), np.asarray(want))
