@@ -1,0 +1,59 @@
+"""Device work of ONE time slice of a multi-GPU multi-step SDC run, measured on a single GPU: per iteration
+sweep -> end point -> u[0] replaced by a received value (here: a local buffer) -> residual against it.  The message
+itself (8 N bytes over xGMI) is not part of this number.  Usage: python scripts/emulate_timeslice.py [n] [iters]"""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from pysdc_amd import lib as L
+from pysdc_amd.coeffs import CollBase, QDELTA_GENERATORS
+from pysdc_amd.engine import SweepEngine
+from pysdc_amd import fd
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+M = 5
+dt = 2.5e-4 * (1024.0 / n) ** 2
+c = CollBase(M, 0, 1, 'LEGENDRE', 'RADAU-RIGHT')
+QI = np.zeros_like(c.Qmat)
+QI[1:, 1:] = QDELTA_GENERATORS['IE'](qGen=c.generator, tLeft=0).genCoeffs()
+out = {}
+for keep in (True, False):
+    e = SweepEngine((n, n, n), M)
+    e.set_coeffs(c.Qmat, QI, None, c.nodes, c.weights)
+    e.set_stencil(0, *fd.periodic_operator_stencil(2, 2, 'center', 1.0 / n, 0.1))
+    e.set_keep_residual_fields(keep)
+    freq = (C.c_int * 3)(2, 2, 2)
+    L.check(e.lib.sdc_init_field(e.ctx, e.ptr(L.SLOT_U, 0), freq, 1e-3, 0), e.ctx)
+    e.invalidate_spectra(1)
+    inbox = torch.empty(e.N, dtype=torch.float64, device='cuda')
+    e.vec_copy(e.N, e.ptr(L.SLOT_U, 0), inbox.data_ptr())
+    e.predict(0.0, dt)
+    e.residual(dt)
+    e.sweep(0.0, dt)                        # warm-up: allocates the spectral cache
+    e.residual(dt)
+    e.end_point(dt, False)
+    e.replace_u0(inbox.data_ptr())
+    e.residual(dt)
+    e.profile_enable(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(iters):
+        e.sweep(0.0, dt)
+        e.residual(dt)                      # IT_FINE
+        e.end_point(dt, False)              # what is sent
+        e.replace_u0(inbox.data_ptr())      # what arrives
+        e.residual(dt)                      # IT_CHECK
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / iters
+    prof = e.profile_read()
+    out['kept_residual_fields' if keep else 'recomputed_residual'] = {
+        'ms_per_iteration': 1e3 * el, 'kernels_ms': {k: round(v[0] / v[1], 2) for k, v in prof.items() if v[1]}}
+    e.close()
+print(json.dumps(out))
