@@ -114,6 +114,12 @@ int sdc_defer_f0(sdc_ctx* ctx);
  * cache); sdc_replace_u0(ctx, src) then copies the new value in and updates the node norms in the same pass
  * (r_m changes by new - old for every m).  Without kept fields it is a plain copy. src: device field of N doubles. */
 int sdc_set_keep_residual_fields(sdc_ctx* ctx, int on);
+/* Sending the end value while the residual passes still run: with sdc_set_early_end_point(ctx, 1) a sweep that
+ * stays in Fourier space transforms its last node into UEND right after the spectral update (a following
+ * sdc_end_point without collocation update is then free); sdc_stream_wait_uend(ctx, stream) makes another HIP
+ * stream (the one the message is posted on) wait until UEND is complete - and for nothing queued after it. */
+int sdc_set_early_end_point(sdc_ctx* ctx, int on);
+int sdc_stream_wait_uend(sdc_ctx* ctx, void* other_stream);
 int sdc_replace_u0(sdc_ctx* ctx, const double* src);
 /* L.status.unlocked: set by sdc_predict; a coarse level is unlocked by the restriction instead
  * (pySDC/core/base_transfer.py:166) - the host mirrors that here. */

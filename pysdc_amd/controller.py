@@ -379,6 +379,9 @@ class controller_dist(_ControllerBase):
         self._uend_buf = None
         self._relay_stage = None
         self._inbox = None
+        self._posted = None
+        self._comm_stream = None
+        self._overlap = False
         self.relay = os.environ.get('PYSDC_AMD_RELAY', '1') != '0'
         self.two_hop_calls = 0
 
@@ -435,9 +438,14 @@ class controller_dist(_ControllerBase):
         if num_active == 0:
             raise ControllerError('Nothing to do, check t0, dt and Tend!')
         P = S.levels[0].prob
+        self._overlap = False
         if self.size > 1 and hasattr(S.levels[0], 'replace_u0') and hasattr(S.levels[0], 'engine'):
-            # u[0] is replaced between sweeps and the residual is asked for again: keep the residual fields
+            # u[0] is replaced between sweeps and the residual is asked for again: keep the residual fields;
+            # produce the end value early so that it can be sent while the residual is reduced
             S.levels[0].engine.set_keep_residual_fields(True)
+            if len(S.levels) == 1 and not S.levels[0]._view_offset() and os.environ.get('PYSDC_AMD_OVERLAP', '1') != '0':
+                S.levels[0].engine.set_early_end_point(True)
+                self._overlap = True
         if self._uend_buf is None:   # lives as long as the controller: allocating 8.6 GB per run costs ~0.25 s
             self._uend_buf = P.dtype_u(u0)
         elif self._uend_buf is not u0:
@@ -537,7 +545,7 @@ class controller_dist(_ControllerBase):
         return (self.relay and size > 2 and len(S.levels) == 1 and self.params.mssdc_jac
                 and (self.params.all_to_done or S.levels[0].params.restol < 0))
 
-    def exchange_two_hop(self, size):
+    def _two_hop_ops(self, L, size, inbox):
         """The forward hand-over uend(rank) -> u[0](rank + 1) of ALL active ranks at once, over two hops.
 
         xGMI is a full mesh of point-to-point links: the direct message uses one of a GPU's seven links while six
@@ -545,20 +553,14 @@ class controller_dist(_ControllerBase):
         relay -> destination; the pieces whose relay is the owner or the destination go directly).  Each link then
         carries 1/size of a message per phase: 2/size of the direct transfer time.  Both phases are one batched
         group of point-to-point operations (ncclGroupStart/End under RCCL) in which every active rank takes part,
-        which is why the caller must have established lock step (`_lockstep`).  Bit-identical to the direct copy."""
+        which is why the caller must have established lock step (`_lockstep`).  Bit-identical to the direct copy.
+        Returns the requests of phase 2 (phase 1 is waited for - on the posting stream - before phase 2 is posted)."""
         import torch
 
-        S, dist = self.S, self.dist
-        L = S.levels[0]
+        dist = self.dist
         r, P = self.rank, size
         self.two_hop_calls += 1
-        self._hook('pre_comm', S, 0)
-        if self.req_send[0] is not None:
-            self.req_send[0].wait()
-            self.req_send[0] = None
-        L.sweep.compute_end_point()
         src = L.uend.as_torch().reshape(-1)
-        inbox = self._recv_target(L) if r >= 1 else None
         dst = (inbox if inbox is not None else L.u[0]).as_torch().reshape(-1)
         n = src.numel()
         csz = -(-n // P)
@@ -573,7 +575,7 @@ class controller_dist(_ControllerBase):
         def slot(origin):
             return self._relay_stage[origin * mine:(origin + 1) * mine]
 
-        tag = S.status.iter
+        tag = self.S.status.iter
         # phase 1: owners hand piece j to rank j (the destination's own piece lands in place)
         ops = []
         if r <= P - 2:
@@ -600,12 +602,67 @@ class controller_dist(_ControllerBase):
             for j in range(P):
                 if j != r and piece(dst, j).numel() > 0:
                     ops.append(dist.P2POp(dist.irecv, piece(dst, j), j, self.comm, tag))
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
-        if r >= 1:
+        return list(dist.batch_isend_irecv(ops)) if ops else []
+
+    def _uniform(self, size):
+        """every active rank runs the same stage sequence with the same iteration count (see _lockstep)"""
+        S = self.S
+        return (size > 1 and len(S.levels) == 1 and self.params.mssdc_jac
+                and (self.params.all_to_done or S.levels[0].params.restol < 0))
+
+    def handover_post(self, size, side_stream=False):
+        """Post uend(rank) -> u[0](rank + 1) for all active ranks of a lock-step run (two hops for more than two
+        ranks, a direct message otherwise) and return without waiting for the data.  side_stream: the operations
+        are queued behind the completion of UEND only (sdc_stream_wait_uend), on a stream of their own, so that the
+        message travels while the engine's stream still reduces the residual."""
+        S, dist = self.S, self.dist
+        L = S.levels[0]
+        self._hook('pre_comm', S, 0)
+        if self.req_send[0] is not None:
+            self.req_send[0].wait()
+            self.req_send[0] = None
+        L.sweep.compute_end_point()  # free when the sweep produced UEND early
+        inbox = self._recv_target(L) if self.rank >= 1 else None
+        ctx = None
+        if side_stream:
+            import torch
+
+            if self._comm_stream is None:
+                self._comm_stream = torch.cuda.Stream()
+            L.engine.stream_wait_uend(self._comm_stream.cuda_stream)
+            ctx = torch.cuda.stream(self._comm_stream)
+            ctx.__enter__()
+        try:
+            if self._lockstep(size):
+                reqs = self._two_hop_ops(L, size, inbox)
+            else:
+                ops = []
+                tag = S.status.iter
+                if self.rank < size - 1:
+                    ops.append(dist.P2POp(dist.isend, L.uend.as_torch(), self.rank + 1, self.comm, tag))
+                if self.rank >= 1:
+                    ops.append(dist.P2POp(dist.irecv, (inbox if inbox is not None else L.u[0]).as_torch(), self.rank - 1,
+                                          self.comm, tag))
+                reqs = list(dist.batch_isend_irecv(ops)) if ops else []
+        finally:
+            if ctx is not None:
+                ctx.__exit__(None, None, None)
+        self._posted = (reqs, inbox)
+
+    def handover_complete(self):
+        S = self.S
+        L = S.levels[0]
+        reqs, inbox = self._posted
+        self._posted = None
+        for req in reqs:
+            req.wait()
+        if self.rank >= 1:
             self._received(L, inbox)
         self._hook('post_comm', S, 0)
+
+    def exchange_two_hop(self, size):
+        self.handover_post(size)
+        self.handover_complete()
 
     def pfasst(self, size):
         S = self.S
@@ -633,7 +690,9 @@ class controller_dist(_ControllerBase):
     def it_check(self, size):
         S = self.S
         L = S.levels[0]
-        if self._lockstep(size):
+        if self._posted is not None:
+            self.handover_complete()      # posted right after the sweep (it_fine)
+        elif self._lockstep(size):
             self.exchange_two_hop(size)
         else:
             self.exchange(0)
@@ -685,6 +744,11 @@ class controller_dist(_ControllerBase):
             self._hook('pre_sweep', S)
             L.sweep.updateVariableCoeffs(k + 1)
             L.sweep.update_nodes()
+            if k == self.nsweeps[0] - 1 and self._overlap and self._uniform(S.status.time_size):
+                # lock-step run on device levels: the hand-over of the coming it_check is posted now, behind the
+                # end value only, and travels while the residual below is reduced (same data, same order of
+                # values - only the moment of posting differs from controller_MPI.py:574-583)
+                self.handover_post(S.status.time_size, side_stream=True)
             L.sweep.compute_residual(stage='IT_FINE')
             self._hook('post_sweep', S)
         S.status.stage = 'IT_CHECK'

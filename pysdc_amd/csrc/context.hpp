@@ -48,6 +48,10 @@ struct sdc_ctx {
     bool deferred = true;
     bool spread_pending = false;  // U[1..M] = U[0], F[1..M] = F[0] not stored yet
     bool f_pending = false;       // F[1..M] = f(U[1..M]) not stored yet
+    bool early_uend = false;      // sweeps produce UEND right after the spectral update (before the residual passes)
+    hipEvent_t uend_ev = nullptr;  // recorded when UEND is complete
+    bool uend_ev_recorded = false;
+    cd* W2 = nullptr;             // one-spectrum work buffer of that early transform (W is busy)
     bool keep_rfields = false;    // sweeps that only reduce the residual also store its fields in the U[1..M] slab
     bool rfields_valid = false;   // ... and they are there now (U[1..M] themselves live in S: u_pending)
     bool f0_pending = false;      // F[0] = f(U[0]) not evaluated yet (no sweep reads it)

@@ -341,6 +341,27 @@ static int inverse_passes_n(sdc_ctx* c, int nf, const cd* src, cd* work, const F
     return inverse_tail_n<N>(c, nf, work, p, norms);
 }
 
+// time-parallel runs: the end value is wanted as early as possible (it is sent while the residual passes run).
+// Right after the spectral update S[M-1] is final: transform it into UEND through the spare work buffer.
+template <int N>
+static int early_end_point_n(sdc_ctx* c, bool norms_only) {
+    if (!c->early_uend || !norms_only) return SDC_OK;
+    if (!c->W2) {
+        HIPCHK(c, hipMalloc((void**)&c->W2, sizeof(cd) * c->Nc));
+        c->bytes += sizeof(cd) * c->Nc;
+    }
+    if (!c->uend_ev) HIPCHK(c, hipEventCreateWithFlags(&c->uend_ev, hipEventDisableTiming));
+    FieldPtrs pe;
+    memset(&pe, 0, sizeof pe);
+    pe.out[0] = c->UEND;
+    int rc = inverse_passes_n<N>(c, 1, c->S + (size_t)(c->M - 1) * c->Nc, c->W2, pe, nullptr, 1.0 / (double)c->N);
+    if (rc != SDC_OK) return rc;
+    c->uend_gen = c->spec_gen;
+    HIPCHK(c, hipEventRecord(c->uend_ev, c->stream));
+    c->uend_ev_recorded = true;
+    return SDC_OK;
+}
+
 template <int N, int NF>
 static void launch_spec_z(sdc_ctx* c, SpecArgs& a, size_t lines, int mode) {
     constexpr int P = N / fft_elems(N), LPB = z_lines_per_block<N>();
@@ -380,6 +401,8 @@ static int spec_sweep_n(sdc_ctx* c, int nf, SpecArgs& a, const FieldPtrs& p, uns
 #undef ZCASE
             }
             HIPCHK(c, hipGetLastError());
+            int rce = early_end_point_n<N>(c, norms != nullptr);
+            if (rce != SDC_OK) return rce;
             return inverse_tail_n<N>(c, nf, c->W, p, norms);
         }
     }
@@ -398,7 +421,20 @@ static int spec_sweep_n(sdc_ctx* c, int nf, SpecArgs& a, const FieldPtrs& p, uns
 #undef SCASE
     }
     HIPCHK(c, hipGetLastError());
-    return inverse_passes_n<N>(c, nf, norms ? c->W : c->S, c->W, p, norms, a.invN);
+    if (norms) {  // W holds the residual spectra: the contiguous-axis pass runs first, then the early end value
+        constexpr int P = N / fft_elems(N), LPB = z_lines_per_block<N>();
+        {
+            LaunchTimer lt(c, pname("fft_z_inv", nf));
+            const size_t ldsz = (size_t)LayContig<N>::doubles(nf * LPB) * sizeof(double);
+            hipLaunchKernelGGL((k_fftz_plain<N, +1>), dim3((unsigned)((lines + LPB - 1) / LPB)), dim3(P * LPB * nf), ldsz,
+                               c->stream, c->W, c->W, c->Nc, c->tw, (unsigned)lines, a.invN);
+        }
+        HIPCHK(c, hipGetLastError());
+        int rce = early_end_point_n<N>(c, true);
+        if (rce != SDC_OK) return rce;
+        return inverse_tail_n<N>(c, nf, c->W, p, norms);
+    }
+    return inverse_passes_n<N>(c, nf, c->S, c->W, p, norms, a.invN);
 }
 
 #define N_DISPATCH(c, CALL)                                                                                 \
@@ -700,6 +736,8 @@ int sdc_ctx_destroy(sdc_ctx* c) {
     (void)hipFree(c->TAU);
     (void)hipFree(c->UEND);
     (void)hipFree(c->W);
+    (void)hipFree(c->W2);
+    if (c->uend_ev) (void)hipEventDestroy(c->uend_ev);
     (void)hipFree(c->S);
     (void)hipFree(c->S0);
     (void)hipFree(c->tw);
@@ -1434,6 +1472,8 @@ int sdc_end_point(sdc_ctx* c, double dt, int do_coll_update) {
     if (!c) return SDC_ERR_PARAM;
     if (!c->have_coeffs) return fail(c, SDC_ERR_STATE, "coefficients not set (sdc_set_coeffs)");
     if (!do_coll_update) {
+        if (c->u_pending && !c->spread_pending && c->uend_gen >= 0 && c->uend_gen == c->spec_gen)
+            return SDC_OK;  // the sweep already produced it (sdc_set_early_end_point)
         c->uend_gen = -1;
         if (c->u_pending && !c->spread_pending) {  // only the last node is needed: transform it straight into UEND
             FieldPtrs p;
@@ -1476,6 +1516,24 @@ int sdc_advance(sdc_ctx* c) {
     } else {
         c->spec0_valid = false;
     }
+    return SDC_OK;
+}
+
+int sdc_set_early_end_point(sdc_ctx* c, int on) {
+    if (!c) return SDC_ERR_PARAM;
+    c->early_uend = on != 0;
+    return SDC_OK;
+}
+
+int sdc_stream_wait_uend(sdc_ctx* c, void* other_stream) {
+    if (!c) return SDC_ERR_PARAM;
+    if (!c->uend_ev) HIPCHK(c, hipEventCreateWithFlags(&c->uend_ev, hipEventDisableTiming));
+    if (!(c->uend_ev_recorded && c->uend_gen >= 0 && c->uend_gen == c->spec_gen)) {
+        // UEND was written by the latest work on the engine's stream (sdc_end_point): everything so far
+        HIPCHK(c, hipEventRecord(c->uend_ev, c->stream));
+    }
+    c->uend_ev_recorded = false;
+    HIPCHK(c, hipStreamWaitEvent((hipStream_t)other_stream, c->uend_ev, 0));
     return SDC_OK;
 }
 

@@ -95,6 +95,13 @@ class SweepEngine:
         """leave F[1..M] / the spread copies unwritten until they are read (include/sdcmi.h: sdc_set_deferred)"""
         self._chk(self.lib.sdc_set_deferred(self.ctx, int(bool(on))))
 
+    def set_early_end_point(self, on):
+        self._chk(self.lib.sdc_set_early_end_point(self.ctx, int(bool(on))))
+
+    def stream_wait_uend(self, stream_handle):
+        """make another HIP stream (raw handle, e.g. torch.cuda.Stream().cuda_stream) wait until UEND is complete"""
+        self._chk(self.lib.sdc_stream_wait_uend(self.ctx, C.c_void_p(int(stream_handle))))
+
     def set_keep_residual_fields(self, on):
         self._chk(self.lib.sdc_set_keep_residual_fields(self.ctx, int(bool(on))))
 

@@ -44,6 +44,8 @@ PROTOTYPES = {
     'sdc_advance': (C.c_int, [_vp]),
     'sdc_defer_f0': (C.c_int, [_vp]),
     'sdc_set_keep_residual_fields': (C.c_int, [_vp, C.c_int]),
+    'sdc_set_early_end_point': (C.c_int, [_vp, C.c_int]),
+    'sdc_stream_wait_uend': (C.c_int, [_vp, _vp]),
     'sdc_replace_u0': (C.c_int, [_vp, _vp]),
     'sdc_fft_prolong': (C.c_int, [_vp, _vp, _vp, _vp, C.c_double]),
     'sdc_materialize': (C.c_int, [_vp, C.c_int, C.c_int]),

@@ -14,6 +14,7 @@ import torch
 from pysdc_amd import lib as L
 from pysdc_amd.coeffs import CollBase, QDELTA_GENERATORS
 from pysdc_amd.engine import SweepEngine
+from pysdc_amd.hip_mesh import _CAI
 from pysdc_amd import fd
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
@@ -24,11 +25,14 @@ c = CollBase(M, 0, 1, 'LEGENDRE', 'RADAU-RIGHT')
 QI = np.zeros_like(c.Qmat)
 QI[1:, 1:] = QDELTA_GENERATORS['IE'](qGen=c.generator, tLeft=0).genCoeffs()
 out = {}
-for keep in (True, False):
+copies = int(sys.argv[3]) if len(sys.argv) > 3 else 8       # the "message": that many 8 N byte device copies
+side = torch.cuda.Stream()
+for keep in ('overlap', True, False):
     e = SweepEngine((n, n, n), M)
     e.set_coeffs(c.Qmat, QI, None, c.nodes, c.weights)
     e.set_stencil(0, *fd.periodic_operator_stencil(2, 2, 'center', 1.0 / n, 0.1))
-    e.set_keep_residual_fields(keep)
+    e.set_keep_residual_fields(bool(keep))
+    e.set_early_end_point(keep == 'overlap')
     freq = (C.c_int * 3)(2, 2, 2)
     L.check(e.lib.sdc_init_field(e.ctx, e.ptr(L.SLOT_U, 0), freq, 1e-3, 0), e.ctx)
     e.invalidate_spectra(1)
@@ -44,16 +48,29 @@ for keep in (True, False):
     e.profile_enable(True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    uend = torch.as_tensor(_CAI(e.ptr(L.SLOT_UEND), e.N, e), device='cuda')
     for k in range(iters):
         e.sweep(0.0, dt)
-        e.residual(dt)                      # IT_FINE
-        e.end_point(dt, False)              # what is sent
+        if keep == 'overlap':
+            e.end_point(dt, False)          # free: the sweep produced UEND right after the spectral update
+            e.stream_wait_uend(side.cuda_stream)
+            with torch.cuda.stream(side):   # the message, posted behind UEND only
+                for _ in range(copies):
+                    inbox.copy_(uend)
+            e.residual(dt)                  # IT_FINE, while the message travels
+            torch.cuda.current_stream().wait_stream(side)
+        else:
+            e.residual(dt)                  # IT_FINE
+            e.end_point(dt, False)          # what is sent
+            for _ in range(copies):
+                inbox.copy_(uend)
         e.replace_u0(inbox.data_ptr())      # what arrives
         e.residual(dt)                      # IT_CHECK
     torch.cuda.synchronize()
     el = (time.perf_counter() - t0) / iters
     prof = e.profile_read()
-    out['kept_residual_fields' if keep else 'recomputed_residual'] = {
-        'ms_per_iteration': 1e3 * el, 'kernels_ms': {k: round(v[0] / v[1], 2) for k, v in prof.items() if v[1]}}
+    check = float(torch.max(torch.abs(inbox - uend)))       # the last message is the last end value
+    out[{'overlap': 'overlapped_message', True: 'kept_residual_fields', False: 'recomputed_residual'}[keep]] = {
+        'ms_per_iteration': 1e3 * el, 'message_copies': copies, 'inbox_minus_uend': check, 'kernels_ms': {k: round(v[0] / v[1], 2) for k, v in prof.items() if v[1]}}
     e.close()
 print(json.dumps(out))

@@ -334,3 +334,43 @@ def test_replace_u0_updates_the_residual_from_kept_fields(n, prob):
     assert np.max(np.abs(ua - ub)) <= 1e-13 * np.max(np.abs(ub))
     for e in engines:
         e.close()
+
+
+def test_early_end_point_and_stream_wait():
+    """sdc_set_early_end_point: the sweep leaves the end value in UEND (same bits as sdc_end_point afterwards) and
+    another stream that waits through sdc_stream_wait_uend sees it complete while the engine's stream goes on."""
+    import torch
+    from pysdc_amd.hip_mesh import _CAI
+
+    n, M, dt = 128, 5, 4e-3
+    c, qi = _coeffs(M, 'IE')
+    engines = []
+    for early in (True, False):
+        e = G.engine_for('heat_unforced', dict(nvars=(n, n, n), nu=0.1), M)
+        e.set_coeffs(c.Qmat, qi, None, c.nodes, c.weights)
+        e.set_early_end_point(early)
+        freq = (C.c_int * 3)(2, 4, 2)
+        L.check(e.lib.sdc_init_field(e.ctx, e.ptr(L.SLOT_U, 0), freq, 0.3, 5), e.ctx)
+        e.invalidate_spectra(1)
+        e.predict(0.0, dt)
+        engines.append(e)
+    a, b = engines
+    side = torch.cuda.Stream()
+    got = torch.empty(a.N, dtype=torch.float64, device='cuda')
+    uend_a = torch.as_tensor(_CAI(a.lib.sdc_slot_ptr(a.ctx, L.SLOT_UEND, 0, 0), a.N, a), device='cuda')
+    for it in range(3):
+        for e in engines:
+            e.sweep(0.0, dt)
+        a.end_point(dt, False)                       # free for a
+        a.stream_wait_uend(side.cuda_stream)
+        with torch.cuda.stream(side):
+            got.copy_(uend_a)
+        ra = a.residual(dt)
+        b.end_point(dt, False)
+        rb = b.residual(dt)
+        side.synchronize()
+        want = b.download(L.SLOT_UEND)
+        assert np.array_equal(got.cpu().numpy().reshape(want.shape), want), it
+        assert np.array_equal(ra[1], rb[1])
+    for e in engines:
+        e.close()
