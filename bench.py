@@ -41,7 +41,10 @@ def _kernel_bytes(name, n, M, ncomp=1):
         'spec_z': (1 + nf) * spec + 2 * nf * spec,          # S0 + S in, S and the line-transformed field out
         'spec_z_res_spread': (1 + 2 * nf) * spec,           # first sweep after a spread predictor: only S0 is read
         'spec_z_spread': (1 + 2 * nf) * spec,
-        'fft_x_norm': nf * spec,                        # half spectra in, max norms out
+        'fft_x_norm': nf * spec,
+        'fft_x_inv_norm': nf * (field + spec),          # norms and the residual fields (time-parallel runs)
+        'spec_z_resid': (1 + nf) * spec + nf * spec,        # residual spectrum of the cached iterate, no update
+        'replace_u0': (3 + nf) * field,                 # new + old u0 in, u0 out, M residual fields in                        # half spectra in, max norms out
         'fft_z_inv': 2 * nf * spec,
         'fft_y_inv': 2 * nf * spec,
         'fft_x_inv': nf * (field + spec),
@@ -278,7 +281,7 @@ def main():
                     'algorithmic_bytes_per_launch': kernel_bytes(dom[0], n, M),
                     'ms_per_launch': dom[1][0] / dom[1][1]}
         in_sweep = ('gather', 'fft_x_fwd', 'fft_y_fwd', 'fft_z_fwd', 'fft_z_solve', 'spec_point', 'spec_point_res', 'spec_z', 'spec_z_res', 'spec_z_spread', 'spec_z_res_spread',
-                    'fft_x_norm',
+                    'fft_x_norm', 'fft_x_inv_norm',
                     'fft_z_inv', 'fft_y_inv',
                     'fft_x_inv', 'stencil', 'stencil_res', 'res_stencil', 'vdp_sweep')
         sweep_ms = sum(v[0] for k, v in prof.items() if k.split('[')[0] in in_sweep) / max(1, sweeps_total // world)

@@ -962,7 +962,9 @@ int sdc_materialize(sdc_ctx* c, int slot, int m) {
         int rc0 = sdc_eval_f(c, c->U, c->gvals[0], c->F, c->ncomp == 2 ? c->F + c->N : nullptr);
         if (rc0 != SDC_OK) return rc0;
     }
-    return materialize(c, slot == SDC_SLOT_U || slot < 0, slot == SDC_SLOT_F || slot < 0);
+    // a node value that is handed out may be overwritten by the holder: F[1..M] = f(U[1..M]) of the CURRENT node
+    // values must be stored before that can happen (the reference's L.f[m] does not follow a later L.u[m] = x)
+    return materialize(c, slot == SDC_SLOT_U || slot < 0, slot == SDC_SLOT_F || slot < 0 || c->f_pending);
 }
 
 int sdc_set_deferred(sdc_ctx* c, int on) {

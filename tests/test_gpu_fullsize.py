@@ -374,3 +374,117 @@ def test_early_end_point_and_stream_wait():
         assert np.array_equal(ra[1], rb[1])
     for e in engines:
         e.close()
+
+
+@pytest.mark.parametrize('seed', list(range(12)))
+@pytest.mark.parametrize('prob', ['heat_unforced', 'advdiff'])
+def test_deferred_state_machine_random_walk(prob, seed):
+    """random sequences of C-ABI calls on two engines - every deferral switched on (deferred node fields, kept
+    residual fields, early end value) against everything eager: whatever is read back must agree."""
+    import torch
+
+    n, M = 64, 3
+    dt = 0.05
+    c, qi = _coeffs(M, 'LU')
+    qe = None
+    if prob == 'advdiff':
+        from pysdc_amd.coeffs import QDELTA_GENERATORS
+
+        qe = np.zeros_like(c.Qmat)
+        qe[1:, 1:], qe[1:, 0] = QDELTA_GENERATORS['EE'](qGen=c.generator, tLeft=0).genCoeffs(dTau=True)
+    engines = []
+    for lazy in (True, False):
+        e = G.engine_for(prob, dict(nvars=(n, n, n), nu=0.1), M)
+        e.set_coeffs(c.Qmat, qi, qe, c.nodes, c.weights)
+        e.set_deferred(lazy)
+        e.set_keep_residual_fields(lazy and seed % 2 == 0)
+        e.set_early_end_point(lazy and seed % 2 == 1)
+        freq = (C.c_int * 3)(2, 2, 4)
+        L.check(e.lib.sdc_init_field(e.ctx, e.ptr(L.SLOT_U, 0), freq, 0.2, 17), e.ctx)
+        e.invalidate_spectra(1)
+        e.predict(0.0, dt)
+        engines.append(e)
+    a, b = engines
+    rng = np.random.default_rng(100 + seed)
+
+    def close(x, y, what):
+        x, y = np.asarray(x), np.asarray(y)
+        assert np.max(np.abs(x - y)) <= 1e-12 * max(1.0, np.max(np.abs(y))), ' '.join(what)
+
+    ops = ['sweep'] * 6 + ['residual'] * 3 + ['end_point', 'end_point_coll', 'get_u', 'get_f', 'put_u0', 'put_um',
+                                               'replace_u0', 'advance', 'integrate', 'predict', 'predict_copy', 'get_f0',
+                                               'toggle_reuse', 'toggle_fused', 'tau_on', 'tau_off']
+    state = dict(reuse=True, fused=True)
+    trace = []
+    for step in range(60):
+        op = ops[rng.integers(len(ops))]
+        trace.append(op)
+        m = int(rng.integers(1, M + 1))
+        if op == 'sweep':
+            for e in engines:
+                e.sweep(0.0, dt)
+        elif op == 'residual':
+            rt = ['full_abs', 'last_abs', 'full_rel', 'last_rel'][rng.integers(4)]
+            ra, rb = a.residual(dt, rt), b.residual(dt, rt)
+            assert np.allclose(ra[1], rb[1], rtol=1e-7, atol=1e-13), trace
+            assert abs(ra[0] - rb[0]) <= 1e-7 * abs(rb[0]) + 1e-13, trace
+        elif op in ('end_point', 'end_point_coll'):
+            for e in engines:
+                e.end_point(dt, op == 'end_point_coll')
+            close(a.download(L.SLOT_UEND), b.download(L.SLOT_UEND), trace)
+        elif op == 'get_u':
+            close(a.download(L.SLOT_U, m), b.download(L.SLOT_U, m), trace)
+        elif op == 'get_f':
+            for comp in range(a.ncomp):
+                close(a.download(L.SLOT_F, m, comp), b.download(L.SLOT_F, m, comp), trace)
+        elif op == 'get_f0':
+            close(a.download(L.SLOT_F, 0), b.download(L.SLOT_F, 0), trace)
+        elif op in ('put_u0', 'put_um'):
+            x = rng.standard_normal((n, n, n)) * 0.1
+            for e in engines:
+                e.upload(L.SLOT_U, 0 if op == 'put_u0' else m, x)
+            if op == 'put_u0':                       # the hosts' f[0] = f(u[0]) after a receive
+                for e in engines:
+                    L.check(e.lib.sdc_defer_f0(e.ctx), e.ctx)
+        elif op == 'replace_u0':
+            x = torch.from_numpy(rng.standard_normal(n**3) * 0.1).cuda()
+            for e in engines:
+                e.replace_u0(x.data_ptr())
+                L.check(e.lib.sdc_defer_f0(e.ctx), e.ctx)
+        elif op == 'advance':
+            for e in engines:
+                e.end_point(dt, False)
+                e.advance()
+                e.predict(0.0, dt)
+        elif op == 'integrate':
+            for e in engines:
+                e.integrate(dt, [e.ptr(L.SLOT_TAU, k) for k in range(M)])
+            for k in range(M):
+                close(a.download(L.SLOT_TAU, k), b.download(L.SLOT_TAU, k), trace)
+        elif op == 'predict':
+            for e in engines:
+                e.predict(0.0, dt)
+        elif op == 'predict_copy':
+            for e in engines:
+                e.predict(0.0, dt, 'copy')
+        elif op == 'toggle_reuse':
+            state['reuse'] = not state['reuse']
+            for e in engines:
+                e.set_spectral_reuse(state['reuse'])
+        elif op == 'toggle_fused':
+            state['fused'] = not state['fused']
+            for e in engines:
+                e.set_fused_residual(state['fused'])
+        elif op == 'tau_on':
+            taus = [rng.standard_normal((n, n, n)) * 1e-3 for _ in range(M)]
+            for e in engines:
+                e.set_tau_active(True)
+                for k in range(M):
+                    e.upload(L.SLOT_TAU, k, taus[k])
+        elif op == 'tau_off':
+            for e in engines:
+                e.set_tau_active(False)
+    close(a.download_u(), b.download_u(), trace)
+    close(a.download_f(), b.download_f(), trace)
+    for e in engines:
+        e.close()
