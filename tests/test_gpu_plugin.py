@@ -336,3 +336,80 @@ def test_refresh_f0_is_evaluated_on_demand():
         want = L.prob.eval_f(new, 0.0)
         got = L.f[0]
         assert np.array_equal(np.asarray(got), np.asarray(want))
+
+
+@pytest.mark.parametrize('seed', [0, 1, 2, 3, 4, 5])
+def test_plugin_random_walk_deferred_vs_eager(seed):
+    """the same random sequence of sweeper calls and datatype operations on L.u / L.f views of two levels, one
+    with deferred node fields and one eager: everything a user can read must agree."""
+    from pysdc_amd.level import Step
+    from pysdc_amd.problems import heatNd_unforced
+    from pysdc_amd.sweepers import generic_implicit
+
+    n, M = 64, 3
+    desc = dict(problem_class=heatNd_unforced, problem_params=dict(nvars=(n, n, n), nu=0.1, freq=(2, 2, 2)),
+                sweeper_class=generic_implicit, sweeper_params=dict(num_nodes=M, quad_type='RADAU-RIGHT', QI='LU'),
+                level_params=dict(dt=2e-2), step_params=dict(maxiter=4))
+    levels = []
+    for deferred in (True, False):
+        S = Step(desc)
+        Lv = S.levels[0]
+        Lv.status.time = 0.0
+        Lv.u[0] = Lv.prob.u_exact(0.0)
+        Lv.engine.set_deferred(deferred)
+        Lv.sweep.predict()
+        levels.append((S, Lv))
+    rng = np.random.default_rng(seed)
+    ops = ['sweep'] * 5 + ['residual'] * 2 + ['end_point', 'read_u', 'read_f', 'scale_u', 'iadd_f', 'set_u0', 'integrate',
+                                              'predict', 'abs_u', 'copy_u', 'kept_view']
+    kept = [None, None]
+    trace = []
+
+    def same(x, y):
+        x, y = np.asarray(x), np.asarray(y)
+        assert np.max(np.abs(x - y)) <= 1e-12 * max(1.0, float(np.max(np.abs(y)))), ' '.join(trace)
+
+    for _ in range(40):
+        op = ops[rng.integers(len(ops))]
+        m = int(rng.integers(1, M + 1))
+        trace.append(f'{op}{m}')
+        outs = []
+        for i, (S, Lv) in enumerate(levels):
+            if op == 'sweep':
+                Lv.sweep.update_nodes()
+            elif op == 'residual':
+                Lv.sweep.compute_residual()
+                outs.append(Lv.status.residual)
+            elif op == 'end_point':
+                Lv.sweep.compute_end_point()
+                outs.append(Lv.uend.get())
+            elif op == 'read_u':
+                outs.append(Lv.u[m].get())
+            elif op == 'read_f':
+                outs.append(Lv.f[m].get())
+            elif op == 'scale_u':
+                Lv.u[m] = 0.5 * Lv.u[m]
+            elif op == 'iadd_f':
+                Lv.f[m] += Lv.f[0]
+            elif op == 'set_u0':
+                Lv.u[0] = Lv.u[m] + Lv.u[0]
+                Lv.f[0] = Lv.prob.eval_f(Lv.u[0], 0.0)
+            elif op == 'integrate':
+                outs.append(np.stack([x.get() for x in Lv.sweep.integrate()]))
+            elif op == 'predict':
+                Lv.sweep.predict()
+            elif op == 'abs_u':
+                outs.append(abs(Lv.u[m] - Lv.u[0]))
+            elif op == 'copy_u':
+                outs.append(Lv.prob.dtype_u(Lv.u[m]).get())
+            elif op == 'kept_view':
+                if kept[i] is None:
+                    kept[i] = (Lv.u[m], Lv.f[m])
+                outs.append(np.stack([kept[i][0].get(), kept[i][1].get()]))
+        if outs:
+            if op == 'residual':
+                assert abs(outs[0] - outs[1]) <= 1e-7 * abs(outs[1]) + 1e-13, ' '.join(trace)
+            else:
+                same(outs[0], outs[1])
+    same(np.stack([levels[0][1].u[k].get() for k in range(M + 1)]), np.stack([levels[1][1].u[k].get() for k in range(M + 1)]))
+    same(np.stack([levels[0][1].f[k].get() for k in range(M + 1)]), np.stack([levels[1][1].f[k].get() for k in range(M + 1)]))
