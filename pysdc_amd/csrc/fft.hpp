@@ -9,6 +9,26 @@
 typedef double2 cd;
 #define DEVI __device__ __forceinline__
 
+// streaming accesses of the in-place middle-axis pass (every element is touched once): nontemporal loads / stores
+// measured 3 % faster there at 1024^3; slower for the norm pass and neutral for the fused sweep kernel
+#ifndef SDC_NT
+#define SDC_NT 1
+#endif
+DEVI cd ld_stream(const cd* p) {
+#if SDC_NT
+    return cd{__builtin_nontemporal_load(&p->x), __builtin_nontemporal_load(&p->y)};
+#else
+    return *p;
+#endif
+}
+DEVI void st_stream(cd* p, cd v) {
+#if SDC_NT
+    __builtin_nontemporal_store(v.x, &p->x);
+    __builtin_nontemporal_store(v.y, &p->y);
+#else
+    *p = v;
+#endif
+}
 DEVI cd cadd(cd a, cd b) { return cd{a.x + b.x, a.y + b.y}; }
 DEVI cd csub(cd a, cd b) { return cd{a.x - b.x, a.y - b.y}; }
 DEVI cd cmul(cd a, cd b) { return cd{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }

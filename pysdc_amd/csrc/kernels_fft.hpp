@@ -165,11 +165,11 @@ __global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_ffty(cd* __restri
     cd* __restrict__ base = W + blockIdx.z * fstride + (size_t)blockIdx.y * N * N + c;
     cd r[E];
 #pragma unroll
-    for (int i = 0; i < E; ++i) r[i] = ok ? base[(size_t)(j + i * P) * N] : cd{0.0, 0.0};
+    for (int i = 0; i < E; ++i) r[i] = ok ? ld_stream(base + (size_t)(j + i * P) * N) : cd{0.0, 0.0};
     fft_line<N, DIR, LAY>(r, j, col, lds, tw);
     if (ok) {
 #pragma unroll
-        for (int i = 0; i < E; ++i) base[(size_t)(j + i * P) * N] = r[i];
+        for (int i = 0; i < E; ++i) st_stream(base + (size_t)(j + i * P) * N, r[i]);
     }
 }
 
