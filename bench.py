@@ -52,6 +52,7 @@ def _kernel_bytes(name, n, M, ncomp=1):
         'stencil_res': (1 + (1 + ncomp) * nf) * field,  # u0 + U[1..M] in, F[1..M] (impl, expl) out, residual norms
         'res_stencil': (1 + nf) * field,                # same launch with F deferred: u0 + U[1..M] in, norms out
         'amax': ncomp * field,
+        'stencil_max': field,                           # f(u0) evaluated for its max norm only (predictor)
         'residual': (1 + M * ncomp + M) * field,        # u0, F[1..M], U[1..M] -> M norms
         'spread': (2 + 2 * M) * field,
         'copy': 2 * field,

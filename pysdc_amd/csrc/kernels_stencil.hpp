@@ -77,6 +77,8 @@ struct Stencil3Args {
     double* outE[MAXM];
     double wI[3], wE[3];  // weights for offsets -1, 0, +1
     int n, xchunk, ntiles, nchunks;
+    int useE;                   // the explicit operator is evaluated (stored when outE is set)
+    unsigned long long* fmax;   // max |f_impl + f_expl| over the launch, or null
 };
 
 // Workgroup b runs on XCD b % 8 (observed dispatch order; used for speed only): give every XCD a contiguous
@@ -125,6 +127,7 @@ __global__ __launch_bounds__(256, 4) void k_stencil3d(Stencil3Args a) {
         hrow = r + 1;
         hcol = side == 0 ? 0 : TZ + 1;
     }
+    double fmx = 0.0;
     size_t off[RPT];
 #pragma unroll
     for (int r = 0; r < RPT; ++r) off[r] = (size_t)(y0 + ty + r * TYB) * n + z0 + 2 * tz;
@@ -199,13 +202,18 @@ __global__ __launch_bounds__(256, 4) void k_stencil3d(Stencil3Args a) {
             res.y = (a.wI[0] * prev[r].y + a.wI[2] * nxt[r].y) + (a.wI[0] * ym1 + a.wI[2] * yp1) +
                     (a.wI[0] * c0 + a.wI[2] * zp) + cI * c1;
             if (oI) *reinterpret_cast<double2*>(oI + po + off[r]) = res;
-            if (oE) {
-                double2 re;
+            double2 re = double2{0.0, 0.0};
+            if (a.useE) {
                 re.x = (a.wE[0] * prev[r].x + a.wE[2] * nxt[r].x) + (a.wE[0] * ym0 + a.wE[2] * yp0) +
                        (a.wE[0] * zm + a.wE[2] * c1) + cE * c0;
                 re.y = (a.wE[0] * prev[r].y + a.wE[2] * nxt[r].y) + (a.wE[0] * ym1 + a.wE[2] * yp1) +
                        (a.wE[0] * c0 + a.wE[2] * zp) + cE * c1;
-                *reinterpret_cast<double2*>(oE + po + off[r]) = re;
+                if (oE) *reinterpret_cast<double2*>(oE + po + off[r]) = re;
+            }
+            if (a.fmax) {
+                const double s0 = fabs(res.x + re.x), s1 = fabs(res.y + re.y);
+                const double sm = (s0 > s1 || s0 != s0) ? s0 : s1;
+                fmx = (fmx > sm || fmx != fmx) ? fmx : sm;
             }
         }
         if (more) {
@@ -220,6 +228,10 @@ __global__ __launch_bounds__(256, 4) void k_stencil3d(Stencil3Args a) {
             hnxt = hnx2;
             hnx2 = hnn;
         }
+    }
+    if (a.fmax) {
+        fmx = wave_max(fmx);
+        if ((threadIdx.x & 63) == 0) atomic_max_abs(a.fmax, fmx);
     }
 }
 

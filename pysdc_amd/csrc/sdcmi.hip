@@ -108,6 +108,7 @@ static int run_stencil(sdc_ctx* c, int nf, const double* const* in, double* cons
             s3.wI[k] = c->st[0].w[k];
             s3.wE[k] = needE ? c->st[1].w[k] : 0.0;
         }
+        s3.useE = needE ? 1 : 0;
         s3.n = c->n;
         s3.xchunk = c->n >= 64 ? 64 : c->n;
         s3.nchunks = c->n / s3.xchunk;
@@ -929,6 +930,11 @@ static int launch_spread(sdc_ctx* c, int guess, double fill_u, double fill_f, bo
 // bring deferred real-space state up to date before it is read (or partially overwritten)
 static int materialize(sdc_ctx* c, bool need_u, bool need_f) {
     if (c->spread_pending && (need_u || need_f)) {
+        if (c->f0_pending) {  // the copies are copies of F[0]
+            c->f0_pending = false;
+            int rc0 = sdc_eval_f(c, c->U, c->gvals[0], c->F, c->ncomp == 2 ? c->F + c->N : nullptr);
+            if (rc0 != SDC_OK) return rc0;
+        }
         c->spread_pending = false;
         c->f_pending = false;
         return launch_spread(c, SDC_GUESS_SPREAD, 0.0, 0.0, false);
@@ -948,9 +954,18 @@ static int materialize(sdc_ctx* c, bool need_u, bool need_f) {
 
 int sdc_materialize(sdc_ctx* c, int slot, int m) {
     if (!c) return SDC_ERR_PARAM;
-    if (slot == SDC_SLOT_U && m == 0) {  // U[0] itself is never deferred, but a pending spread still reads it
-        if (!c->spread_pending) return SDC_OK;
-        return materialize(c, true, false);
+    if (slot == SDC_SLOT_U && m == 0) {
+        // U[0] itself is never deferred, but whoever gets its address may overwrite it: a pending spread and a
+        // pending F[0] = f(U[0]) refer to the value it holds NOW
+        if (c->spread_pending) {
+            int rc0 = materialize(c, true, false);
+            if (rc0 != SDC_OK) return rc0;
+        }
+        if (c->f0_pending) {
+            c->f0_pending = false;
+            return sdc_eval_f(c, c->U, c->gvals[0], c->F, c->ncomp == 2 ? c->F + c->N : nullptr);
+        }
+        return SDC_OK;
     }
     if (slot == SDC_SLOT_F && m == 0) {
         if (!c->f0_pending) return SDC_OK;
@@ -1114,16 +1129,47 @@ int sdc_predict(sdc_ctx* c, double t, double dt, int guess, double fill_u, doubl
     if (!c) return SDC_ERR_PARAM;
     if (!c->have_coeffs) return fail(c, SDC_ERR_STATE, "coefficients not set (sdc_set_coeffs)");
     if (guess < 0 || guess > 3) return fail(c, SDC_ERR_PARAM, "initial_guess option %d not implemented", guess);
-    int rc = sdc_eval_f(c, c->U, c->gvals[0], c->F, c->ncomp == 2 ? c->F + c->N : nullptr);
-    if (rc != SDC_OK) return rc;
     // all nodes equal u0 and f does not depend on t: every f_j equals f(u0), so the node residuals are
     // dt * |sum_j Q[m][j]| * max|f(u0)| and the fill kernel can reduce max|f(u0)| on the way
     const bool spread_res = guess == SDC_GUESS_SPREAD && c->expl_kind != SDC_EXPL_FORCING && !c->tau_active;
     if (spread_res) HIPCHK(c, hipMemsetAsync(c->res_dev, 0, sizeof(unsigned long long) * 8, c->stream));
     c->spread_pending = c->f_pending = c->u_pending = c->f0_pending = c->rfields_valid = false;
-    if (c->deferred && c->kind == 0 && guess == SDC_GUESS_SPREAD && c->expl_kind != SDC_EXPL_FORCING) {
+    const bool lazy_spread = c->deferred && c->kind == 0 && guess == SDC_GUESS_SPREAD && c->expl_kind != SDC_EXPL_FORCING;
+    // with the 3-D three-point kernel even f(u0) itself is not stored: one pass over u0 that only reduces max|f(u0)|
+    auto three = [](const Stencil& s) { return s.npts == 3 && s.off[0] == -1 && s.off[1] == 0 && s.off[2] == 1; };
+    const bool explS = c->expl_kind == SDC_EXPL_STENCIL;
+    const bool f0_by_norm = lazy_spread && spread_res && !c->spectral_op && c->ndim == 3 && c->n % 64 == 0 &&
+                            c->have_stencil[0] && three(c->st[0]) &&
+                            (c->expl_kind == SDC_EXPL_NONE || (explS && c->have_stencil[1] && three(c->st[1])));
+    int rc = SDC_OK;
+    if (f0_by_norm) {
+        constexpr int RPT = 4;
+        Stencil3Args s3;
+        memset(&s3, 0, sizeof s3);
+        s3.in[0] = c->U;
+        for (int k = 0; k < 3; ++k) {
+            s3.wI[k] = c->st[0].w[k];
+            s3.wE[k] = explS ? c->st[1].w[k] : 0.0;
+        }
+        s3.useE = explS ? 1 : 0;
+        s3.fmax = c->res_dev + 7;
+        s3.n = c->n;
+        s3.xchunk = 64;
+        s3.nchunks = c->n / s3.xchunk;
+        s3.ntiles = (c->n / 64) * (c->n / (8 * RPT));
+        {
+            LaunchTimer lt(c, "stencil_max");
+            hipLaunchKernelGGL((k_stencil3d<RPT>), dim3(s3.ntiles * s3.nchunks), dim3(256), 0, c->stream, s3);
+        }
+        HIPCHK(c, hipGetLastError());
+        c->f0_pending = true;
+    } else {
+        rc = sdc_eval_f(c, c->U, c->gvals[0], c->F, c->ncomp == 2 ? c->F + c->N : nullptr);
+        if (rc != SDC_OK) return rc;
+    }
+    if (lazy_spread) {
         // the node copies are not stored until somebody reads them (materialize); only max|f(u0)| is needed now
-        if (spread_res) {
+        if (spread_res && !f0_by_norm) {
             LaunchTimer lt(c, "amax");
             hipLaunchKernelGGL(k_amax_sum, dim3(grid_for(c->N, 256)), dim3(256), 0, c->stream, c->F,
                                c->ncomp == 2 ? c->F + c->N : nullptr, c->N, c->res_dev + 7);
