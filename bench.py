@@ -113,6 +113,8 @@ def main():
                     help='use the one-step-per-rank controller and torch.distributed even with one GPU (self test)')
     ap.add_argument('--no-spectral-reuse', action='store_true',
                     help='transform the gathered fields in every sweep instead of gathering on cached transforms')
+    ap.add_argument('--restol', type=float, default=-1.0,
+                    help='> 0: iterate to this residual instead of a fixed number of sweeps (maxiter 50); niter is reported')
     ap.add_argument('--eager-fields', action='store_true',
                     help='store F[1..M] and the predictor copies in every sweep / predict even when nothing reads them')
     args = ap.parse_args()
@@ -143,7 +145,7 @@ def main():
     from pysdc_amd.sweepers import generic_implicit, imex_1st_order
     from pysdc_amd.stats import get_sorted
 
-    M, K = args.nodes, args.sweeps
+    M, K = args.nodes, (args.sweeps if args.restol < 0 else 50)
     ncomp = 1
     fallback_note = ''
     if args.workload == 'heat':
@@ -161,7 +163,7 @@ def main():
         desc = dict(problem_class=heatNd_unforced, problem_params=dict(nvars=(n, n, n), nu=0.1, freq=2, order=2),
                     sweeper_class=generic_implicit,
                     sweeper_params=dict(num_nodes=M, quad_type='RADAU-RIGHT', QI=args.qi),
-                    level_params=dict(dt=dt, restol=-1.0, nsweeps=1), step_params=dict(maxiter=K))
+                    level_params=dict(dt=dt, restol=args.restol, nsweeps=1), step_params=dict(maxiter=K))
         wl = (f'heatNd_unforced {n}^3 periodic order-2 FD, nu=0.1, M={M} LEGENDRE RADAU-RIGHT, QI={args.qi}, '
               f'generic_implicit')
         unit = 'time-steps/s'
@@ -173,7 +175,7 @@ def main():
                     problem_params=dict(nvars=(n, n, n), nu=0.02, c=1.0, freq=2, order=2),
                     sweeper_class=imex_1st_order,
                     sweeper_params=dict(num_nodes=M, quad_type='RADAU-RIGHT', QI=args.qi, QE='EE'),
-                    level_params=dict(dt=dt, restol=-1.0, nsweeps=1), step_params=dict(maxiter=K))
+                    level_params=dict(dt=dt, restol=args.restol, nsweeps=1), step_params=dict(maxiter=K))
         wl = (f'advectiondiffusionNd_imex {n}^3 periodic order-2 FD, nu=0.02 (implicit), c=1 (explicit), M={M} '
               f'RADAU-RIGHT, QI={args.qi}, QE=EE, imex_1st_order')
         unit = 'time-steps/s'
@@ -187,7 +189,7 @@ def main():
                                         init_type='sphere'),
                     sweeper_class=imex_1st_order,
                     sweeper_params=dict(num_nodes=M, quad_type='RADAU-RIGHT', QI='LU', QE='EE'),
-                    level_params=dict(dt=dt, restol=-1.0, nsweeps=1), step_params=dict(maxiter=K),
+                    level_params=dict(dt=dt, restol=args.restol, nsweeps=1), step_params=dict(maxiter=K),
                     space_transfer_class=mesh_to_mesh, space_transfer_params=dict(iorder=6, rorder=2, periodic=True))
         wl = (f'allencahn_imex {n}^3 / {n // 2}^3 (pseudo-spectral, eps=0.04, sphere), two-level '
               f'{"PFASST" if world > 1 else "MLSDC"}, M={M} RADAU-RIGHT on both levels, QI=LU, QE=EE, '
@@ -201,7 +203,7 @@ def main():
         desc = dict(problem_class=vanderpol_ensemble,
                     problem_params=dict(ntraj=args.ntraj, u0=u0h, mu=5.0, newton_tol=1e-9, newton_maxiter=100),
                     sweeper_class=generic_implicit, sweeper_params=dict(num_nodes=M, quad_type='RADAU-RIGHT', QI='LU'),
-                    level_params=dict(dt=dt, restol=-1.0, nsweeps=1), step_params=dict(maxiter=K))
+                    level_params=dict(dt=dt, restol=args.restol, nsweeps=1), step_params=dict(maxiter=K))
         wl = f'vanderpol ensemble, {args.ntraj} trajectories, mu=5, M={M} RADAU-RIGHT, QI=LU, Newton tol 1e-9'
         unit = 'trajectory-steps/s'
         if world > 1:
@@ -250,6 +252,7 @@ def main():
     el = float(elt.item())
     niter = [v for _, v in get_sorted(stats, type='niter')]
     assert all(v <= K for v in niter) and len(niter) > 0, niter
+    sweeps_done = sum(niter)  # over the ranks' own steps; equals steps * K for a fixed number of sweeps
     finite = bool(np.isfinite(abs(uend)))
 
     def kernel_bytes(name, n_, M_):  # noqa: F811  (workload-aware wrapper)
@@ -262,7 +265,7 @@ def main():
 
     if rank == 0:
         steps_total = args.steps * world
-        sweeps_total = steps_total * K
+        sweeps_total = steps_total * K if args.restol < 0 else sweeps_done * world
         units = args.ntraj if args.workload == 'vdp' else 1
         # dominant kernel of the timed region, from HIP events on the engine's stream
         dom = max(prof.items(), key=lambda kv: kv[1][0]) if prof else (None, (0.0, 0))
@@ -294,11 +297,12 @@ def main():
             'value': units * steps_total / el, 'unit': unit, 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * el / args.steps, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': f'{wl}{fallback_note}, {K} sweeps/step (restol=-1, maxiter={K}), dt={dt:g}, '
+            'config': {'workload': f'{wl}{fallback_note}, ' + (f'{K} sweeps/step (restol=-1, maxiter={K})' if args.restol < 0 else f'restol={args.restol:g} (maxiter={K})') + f', dt={dt:g}, '
                                    f'solver=direct (Fourier), spectral_reuse={not args.no_spectral_reuse}, '
                                    f'deferred_node_fields={not args.eager_fields}',
                        'time_parallel': f'{world} time-slice(s), one per GPU, multi-step SDC (Jacobi)'},
             'sdc_iters_per_s': units * sweeps_total / el,
+            'niter': niter,
             'sweep_kernels_ms': sweep_ms,
             'sweep_floor_gbs': (8.0 * n**3 * ((3 if ncomp == 1 else 5) * M + 1) / sweep_ms / 1e6
                                 if sweep_ms and n else None),
