@@ -113,6 +113,9 @@ def main():
                     help='use the one-step-per-rank controller and torch.distributed even with one GPU (self test)')
     ap.add_argument('--no-spectral-reuse', action='store_true',
                     help='transform the gathered fields in every sweep instead of gathering on cached transforms')
+    ap.add_argument('--solver-type', default='direct', choices=['direct', 'CG'],
+                    help="heat: 'direct' = exact solve in Fourier space (headline); 'CG' = the reference's conjugate "
+                         "gradients (rtol 1e-12) on the device, node by node")
     ap.add_argument('--restol', type=float, default=-1.0,
                     help='> 0: iterate to this residual instead of a fixed number of sweeps (maxiter 50); niter is reported')
     ap.add_argument('--eager-fields', action='store_true',
@@ -160,7 +163,8 @@ def main():
                 fallback_note = f' [1024^3 needs {need / 1e9:.0f} GB, {free / 1e9:.0f} GB free: fell back to 512^3]'
 
         dt = 1e-3 * (512.0 / n) ** 2  # dt*nu*12/dx^2 ~ 315 at every size
-        desc = dict(problem_class=heatNd_unforced, problem_params=dict(nvars=(n, n, n), nu=0.1, freq=2, order=2),
+        desc = dict(problem_class=heatNd_unforced, problem_params=dict(nvars=(n, n, n), nu=0.1, freq=2, order=2, solver_type=args.solver_type,
+                                                                         lintol=1e-12, liniter=10000),
                     sweeper_class=generic_implicit,
                     sweeper_params=dict(num_nodes=M, quad_type='RADAU-RIGHT', QI=args.qi),
                     level_params=dict(dt=dt, restol=args.restol, nsweeps=1), step_params=dict(maxiter=K))
@@ -298,11 +302,12 @@ def main():
             'ms_per_step': 1e3 * el / args.steps, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': f'{wl}{fallback_note}, ' + (f'{K} sweeps/step (restol=-1, maxiter={K})' if args.restol < 0 else f'restol={args.restol:g} (maxiter={K})') + f', dt={dt:g}, '
-                                   f'solver=direct (Fourier), spectral_reuse={not args.no_spectral_reuse}, '
+                                   f'solver={"direct (Fourier)" if args.solver_type == "direct" else "CG rtol 1e-12 on the device"}, spectral_reuse={not args.no_spectral_reuse}, '
                                    f'deferred_node_fields={not args.eager_fields}',
                        'time_parallel': f'{world} time-slice(s), one per GPU, multi-step SDC (Jacobi)'},
             'sdc_iters_per_s': units * sweeps_total / el,
             'niter': niter,
+            'work_counters': {k: v.niter for k, v in L.prob.work_counters.items()},
             'sweep_kernels_ms': sweep_ms,
             'sweep_floor_gbs': (8.0 * n**3 * ((3 if ncomp == 1 else 5) * M + 1) / sweep_ms / 1e6
                                 if sweep_ms and n else None),

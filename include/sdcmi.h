@@ -175,7 +175,13 @@ int sdc_vec_amax(sdc_ctx* ctx, size_t n, const double* x, double* out); /* abs()
 int sdc_set_problem_vdp(sdc_ctx* ctx, double mu, double newton_tol, int newton_maxiter);
 /* out[0] = Newton iterations, out[1] = right-hand side evaluations, out[2] = failed solves (pending), summed
  * over trajectories since context creation (work_counters of Van_der_Pol_implicit.py:71-73). */
-int sdc_work_counters(sdc_ctx* ctx, unsigned long long* out);
+int sdc_work_counters(sdc_ctx* ctx, unsigned long long* out); /* out[4]; out[3] = CG iterations (sdc_set_solver) */
+/* solver_type of GenericNDimFinDiff (generic_ND_FD.py:238-262).  kind 0 ('direct'): the exact solve in Fourier space
+ * (default; satisfies any lintol).  kind 1 ('CG'): scipy.sparse.linalg.cg as the reference calls it - x0 = the previous
+ * node value, rtol = lintol, atol = 0, maxiter = liniter, every iteration counted (work_counters['CG']); sweeps then run
+ * node by node on the device like the reference's loop.  Dot products are reduced in a fixed order, so the counts are
+ * reproducible. */
+int sdc_set_solver(sdc_ctx* ctx, int kind, double rtol, int maxiter);
 
 /* ---- space transfer between two grids --------------------------------------------------------------------
  * mesh_to_mesh (transfer_classes/TransferMesh.py:9-218): Pspace / Rspace are Kronecker products of ONE 1-D

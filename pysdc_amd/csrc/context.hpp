@@ -48,6 +48,11 @@ struct sdc_ctx {
     bool deferred = true;
     bool spread_pending = false;  // U[1..M] = U[0], F[1..M] = F[0] not stored yet
     bool f_pending = false;       // F[1..M] = f(U[1..M]) not stored yet
+    int solver_kind = 0;          // 0: exact solve in Fourier space, 1: conjugate gradients (solver_type='CG')
+    double cg_rtol = 1e-12;
+    int cg_maxiter = 10000;
+    unsigned long long cg_iters = 0;
+    double* cgw = nullptr;        // r, p, q, A p + partial sums
     bool early_uend = false;      // sweeps produce UEND right after the spectral update (before the residual passes)
     hipEvent_t uend_ev = nullptr;  // recorded when UEND is complete
     bool uend_ev_recorded = false;

@@ -242,3 +242,68 @@ __global__ __launch_bounds__(256) void k_replace_u0(const double* __restrict__ s
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// conjugate gradients for (I - factor A) x = b, the reference's solver_type='CG' (generic_ND_FD.py:252-260 ->
+// scipy.sparse.linalg.cg: no preconditioner, stop when ||r|| < rtol ||b||).  Fused vector updates with
+// DETERMINISTIC dot products: every workgroup writes one partial sum, a single workgroup adds them in a fixed
+// order - iteration counts are observable (work_counters['CG']) and must not depend on scheduling.
+//   mode 0: o0 = a0 - a1 + s a2,            sum o0^2      (r = b - x + factor A x)
+//   mode 1: o0 = a0 + s o0                                (p = r + beta p)
+//   mode 2: o0 = a0 - s a1,                 sum a0 o0     (q = p - factor A p,  p.q)
+//   mode 3: o0 += s a0,  o1 -= s a1,        sum o1^2      (x += alpha p, r -= alpha q,  r.r)
+//   mode 4:                                 sum a0^2
+// ------------------------------------------------------------------------------------------------------
+struct CgArgs {
+    const double *a0, *a1, *a2;
+    double *o0, *o1;
+    double s;
+    size_t n;
+    double* part;
+    int mode;
+};
+
+__global__ __launch_bounds__(256) void k_cg(CgArgs a) {
+#pragma clang fp contract(off)
+    double acc = 0.0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < a.n; i += (size_t)gridDim.x * blockDim.x) {
+        if (a.mode == 0) {
+            const double v = (a.a0[i] - a.a1[i]) + a.s * a.a2[i];
+            a.o0[i] = v;
+            acc += v * v;
+        } else if (a.mode == 1) {
+            a.o0[i] = a.a0[i] + a.s * a.o0[i];
+        } else if (a.mode == 2) {
+            const double p = a.a0[i];
+            const double v = p - a.s * a.a1[i];
+            a.o0[i] = v;
+            acc += p * v;
+        } else if (a.mode == 3) {
+            a.o0[i] += a.s * a.a0[i];
+            const double v = a.o1[i] - a.s * a.a1[i];
+            a.o1[i] = v;
+            acc += v * v;
+        } else {
+            const double v = a.a0[i];
+            acc += v * v;
+        }
+    }
+    __shared__ double sh[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0 && a.part) a.part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+__global__ __launch_bounds__(256) void k_sum_parts(const double* __restrict__ part, int nb, double* __restrict__ out) {
+#pragma clang fp contract(off)
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nb; i += 256) acc += part[i];
+    __shared__ double sh[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+

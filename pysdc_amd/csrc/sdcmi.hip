@@ -738,6 +738,7 @@ int sdc_ctx_destroy(sdc_ctx* c) {
     (void)hipFree(c->UEND);
     (void)hipFree(c->W);
     (void)hipFree(c->W2);
+    (void)hipFree(c->cgw);
     if (c->uend_ev) (void)hipEventDestroy(c->uend_ev);
     (void)hipFree(c->S);
     (void)hipFree(c->S0);
@@ -813,6 +814,16 @@ int sdc_work_counters(sdc_ctx* c, unsigned long long* out) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (int k = 0; k < 3; ++k) out[k] = c->red_host[12 + k];
     out[1] += c->rhs_host;
+    out[3] = c->cg_iters;
+    return SDC_OK;
+}
+
+int sdc_set_solver(sdc_ctx* c, int kind, double rtol, int maxiter) {
+    if (!c) return SDC_ERR_PARAM;
+    if (kind != 0 && kind != 1) return fail(c, SDC_ERR_PARAM, "solver kind %d (0: direct, 1: CG)", kind);
+    c->solver_kind = kind;
+    c->cg_rtol = rtol;
+    c->cg_maxiter = maxiter;
     return SDC_OK;
 }
 
@@ -1194,17 +1205,26 @@ int sdc_predict(sdc_ctx* c, double t, double dt, int guess, double fill_u, doubl
 // whose implicit operator is given by its symbol only: the reference's loop (imex_1st_order.py:57-108 /
 // generic_implicit.py:51-103) with every step a kernel on the stream - gather for all nodes, then per node
 // right-hand side, solve (FFT pipeline), f evaluation (operator by FFT or stencil + explicit part).
-static int sweep_nodewise(sdc_ctx* c, double dt) {
+// keep_guess: an iterative solver starts from the previous node value (generic_ND_FD.py:252-260, x0 = u0), so the
+// right-hand sides are gathered into scratch instead of over the old iterate.
+static int sweep_nodewise(sdc_ctx* c, double dt, bool keep_guess = false) {
     const int M = c->M;
     const bool imex = c->ncomp == 2;
     int rcm = materialize(c, true, true);
     if (rcm != SDC_OK) return rcm;
+    double* G = nullptr;
+    if (keep_guess) {
+        rcm = ensure_work(c);
+        if (rcm != SDC_OK) return rcm;
+        G = reinterpret_cast<double*>(c->W);  // M spectra hold more than M real fields
+    }
     QuadArgs q;
     quad_base(c, q);
     q.u0 = c->U;
     q.tau = c->tau_active ? c->TAU : nullptr;
     for (int m = 0; m < M; ++m) {
-        q.out[m] = c->U + (size_t)(m + 1) * c->N;  // the old iterate is only a solver guess: reuse its storage
+        // without keep_guess the old iterate is only a solver guess: its storage takes the right-hand side
+        q.out[m] = keep_guess ? G + (size_t)m * c->N : c->U + (size_t)(m + 1) * c->N;
         for (int j = 0; j < M; ++j) {
             q.cI[m][j] = dt * (c->Q[m + 1][j + 1] - c->QI[m + 1][j + 1]);
             q.cE[m][j] = dt * (c->Q[m + 1][j + 1] - c->QE[m + 1][j + 1]);
@@ -1215,11 +1235,12 @@ static int sweep_nodewise(sdc_ctx* c, double dt) {
     c->spec_valid = c->spec_spread = false;
     for (int m = 0; m < M; ++m) {
         double* um = c->U + (size_t)(m + 1) * c->N;
+        double* rhs = keep_guess ? G + (size_t)m * c->N : um;
         if (m > 0) {
             LinArgs la;
             memset(&la, 0, sizeof la);
-            la.out = um;
-            la.base = um;
+            la.out = rhs;
+            la.base = rhs;
             la.n = c->N;
             for (int j = 0; j < m; ++j) {
                 const double ci = dt * c->QI[m + 1][j + 1], ce = dt * c->QE[m + 1][j + 1];
@@ -1239,8 +1260,11 @@ static int sweep_nodewise(sdc_ctx* c, double dt) {
             }
         }
         const double alpha = dt * c->QI[m + 1][m + 1];
-        if (alpha != 0.0) {
-            rc = sdc_solve(c, um, alpha, um, um);
+        if (alpha != 0.0 || (keep_guess && imex)) {  // imex_1st_order always solves (imex_1st_order.py:98-103)
+            rc = sdc_solve(c, rhs, alpha, um, um);
+            if (rc != SDC_OK) return rc;
+        } else if (keep_guess) {
+            rc = sdc_vec_copy(c, c->N, rhs, um);
             if (rc != SDC_OK) return rc;
         }
         rc = sdc_eval_f(c, um, c->gvals[m + 1], c->F + ((size_t)(m + 1) * c->ncomp) * c->N,
@@ -1298,6 +1322,7 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
     if (c->expl_kind == SDC_EXPL_STENCIL && !c->have_stencil[1])
         return fail(c, SDC_ERR_STATE, "explicit operator not set (sdc_set_stencil which=1)");
     if (c->expl_kind == SDC_EXPL_REACTION || c->spectral_op) return sweep_nodewise(c, dt);
+    if (c->solver_kind == 1) return sweep_nodewise(c, dt, true);
     const bool gather_once = c->force_gather;
     c->force_gather = false;
     if (c->reuse && !gather_once && !c->tau_active && c->expl_kind != SDC_EXPL_FORCING && c->have_stencil[0] &&
@@ -1428,6 +1453,70 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
     return eval_nodes(c, dt);
 }
 
+// scipy.sparse.linalg.cg as the reference calls it (generic_ND_FD.py:252-260): x0 = guess, rtol = lintol, atol = 0,
+// maxiter = liniter, no preconditioner; every iteration counts (the reference's callback).  rhs must not alias out.
+static int cg_solve(sdc_ctx* c, const double* b, double factor, const double* guess, double* x) {
+    if (!c->have_stencil[0]) return fail(c, SDC_ERR_STATE, "implicit operator not set (sdc_set_stencil)");
+    if (b == x) return fail(c, SDC_ERR_PARAM, "conjugate gradients: right-hand side and solution share storage");
+    constexpr int NB = 2048;
+    const size_t N = c->N;
+    if (!c->cgw) {
+        HIPCHK(c, hipMalloc((void**)&c->cgw, sizeof(double) * (4 * N + NB + 8)));
+        c->bytes += sizeof(double) * (4 * N + NB + 8);
+    }
+    double *r = c->cgw, *p = r + N, *q = p + N, *Ap = q + N, *part = Ap + N, *scal = part + NB;
+    const int nb = grid_for(N, 256) < NB ? grid_for(N, 256) : NB;
+    auto launch = [&](int mode, const double* a0, const double* a1, const double* a2, double* o0, double* o1, double s,
+                      double* result) -> int {
+        CgArgs a{a0, a1, a2, o0, o1, s, N, result ? part : nullptr, mode};
+        hipLaunchKernelGGL(k_cg, dim3(nb), dim3(256), 0, c->stream, a);
+        HIPCHK(c, hipGetLastError());
+        if (result) {
+            hipLaunchKernelGGL(k_sum_parts, dim3(1), dim3(256), 0, c->stream, part, nb, scal);
+            HIPCHK(c, hipMemcpyAsync(c->red_host + 15, scal, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            memcpy(result, &c->red_host[15], sizeof(double));
+        }
+        return SDC_OK;
+    };
+    auto matvec = [&](const double* v) -> int {  // Ap = A v
+        const double* in[1] = {v};
+        double* out[1] = {Ap};
+        return run_stencil(c, 1, in, out, nullptr, nullptr);
+    };
+    LaunchTimer lt(c, "cg_solve");
+    int rc;
+    if (!guess) HIPCHK(c, hipMemsetAsync(x, 0, N * sizeof(double), c->stream));
+    else if (guess != x) HIPCHK(c, hipMemcpyAsync(x, guess, N * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    double bb = 0.0, rr = 0.0;
+    if ((rc = launch(4, b, nullptr, nullptr, nullptr, nullptr, 0.0, &bb)) != SDC_OK) return rc;
+    if (bb == 0.0) {  // scipy returns b itself
+        HIPCHK(c, hipMemcpyAsync(x, b, N * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        return SDC_OK;
+    }
+    const double atol = c->cg_rtol * sqrt(bb);
+    if ((rc = matvec(x)) != SDC_OK) return rc;
+    if ((rc = launch(0, b, x, Ap, r, nullptr, factor, &rr)) != SDC_OK) return rc;
+    double rho_prev = 0.0;
+    for (int it = 0; it < c->cg_maxiter; ++it) {
+        if (sqrt(rr) < atol) break;
+        const double rho = rr;
+        if (it > 0) {
+            if ((rc = launch(1, r, nullptr, nullptr, p, nullptr, rho / rho_prev, nullptr)) != SDC_OK) return rc;
+        } else {
+            HIPCHK(c, hipMemcpyAsync(p, r, N * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        }
+        if ((rc = matvec(p)) != SDC_OK) return rc;
+        double pq = 0.0;
+        if ((rc = launch(2, p, Ap, nullptr, q, nullptr, factor, &pq)) != SDC_OK) return rc;
+        const double alpha = rho / pq;
+        if ((rc = launch(3, p, q, nullptr, x, r, alpha, &rr)) != SDC_OK) return rc;
+        rho_prev = rho;
+        c->cg_iters++;
+    }
+    return SDC_OK;
+}
+
 int sdc_solve(sdc_ctx* c, const double* rhs, double factor, const double* guess, double* out) {
     if (!c || !rhs || !out) return fail(c, SDC_ERR_PARAM, "null pointer");
     if (c->kind == 1) {
@@ -1440,6 +1529,7 @@ int sdc_solve(sdc_ctx* c, const double* rhs, double factor, const double* guess,
         HIPCHK(c, hipGetLastError());
         return vdp_check_failures(c);
     }
+    if (c->solver_kind == 1 && !c->spectral_op) return cg_solve(c, rhs, factor, guess, out);
     FieldPtrs p;
     memset(&p, 0, sizeof p);
     ZArgs z;

@@ -189,9 +189,13 @@ class SweepEngine:
         self._chk(self.lib.sdc_set_problem_vdp(self.ctx, float(mu), float(newton_tol), int(newton_maxiter)))
 
     def work_counters(self):
-        out = (C.c_ulonglong * 3)()
+        out = (C.c_ulonglong * 4)()
         self._chk(self.lib.sdc_work_counters(self.ctx, out))
-        return dict(newton=int(out[0]), rhs=int(out[1]), failed=int(out[2]))
+        return dict(newton=int(out[0]), rhs=int(out[1]), failed=int(out[2]), CG=int(out[3]))
+
+    def set_solver(self, kind, rtol=1e-12, maxiter=10000):
+        """'direct' (exact Fourier solve) or 'CG' (include/sdcmi.h: sdc_set_solver)"""
+        self._chk(self.lib.sdc_set_solver(self.ctx, {'direct': 0, 'CG': 1}[kind], float(rtol), int(maxiter)))
 
     # ---- vectors ----
     def vec_copy(self, n, x, y):

@@ -154,9 +154,13 @@ class GenericNDimFinDiff(Problem):
         self._makeAttributeAndRegister('nvars', 'stencil_type', 'order', 'bc', localVars=locals(), readOnly=True)
         self._makeAttributeAndRegister('freq', 'lintol', 'liniter', 'solver_type', localVars=locals())
         # Every solver_type the reference offers (generic_ND_FD.py:238-262) ends in the SAME system
-        # (I - factor*A) u = rhs; here it is always solved exactly in Fourier space, which satisfies any lintol.
-        # The iterative solvers' work counter exists (generic_ND_FD.py:158-159) and counts one "iteration" per solve.
-        if solver_type != 'direct':
+        # (I - factor*A) u = rhs.  'direct' is the exact solve in Fourier space; 'CG' runs the reference's conjugate
+        # gradients on the device (x0 = previous node value, rtol = lintol, iterations counted like the reference's
+        # callback, generic_ND_FD.py:158-159,252-260); 'GMRES' is served by the exact solve (which satisfies any
+        # lintol) and counts one "iteration" per solve.
+        if solver_type == 'CG':
+            self.work_counters['CG'] = _DeviceCounter(self, 'CG')
+        elif solver_type != 'direct':
             self.work_counters[solver_type] = WorkCounter()
 
     @property
@@ -184,6 +188,8 @@ class GenericNDimFinDiff(Problem):
 
     def configure_engine(self, engine):
         engine.set_stencil(0, *self._stencil)
+        if self.solver_type == 'CG':
+            engine.set_solver('CG', self.lintol, self.liniter)
 
     # ---- odd-extension staging for fields that are not slab views (dirichlet-zero) ----------------------------
     def _ext(self, k):
@@ -217,9 +223,10 @@ class GenericNDimFinDiff(Problem):
 
     def solve_system(self, rhs, factor, u0, t):
         sol = self.u_init
-        self.engine.solve(self._stage_in(rhs, 0), float(factor), self._out_ptr(1, sol))
+        guess = self._stage_in(u0, 2) if self.solver_type == 'CG' and u0 is not None else None
+        self.engine.solve(self._stage_in(rhs, 0), float(factor), self._out_ptr(1, sol), guess)
         self._stage_out(1, sol)
-        if self.solver_type != 'direct':
+        if self.solver_type == 'GMRES':
             self.work_counters[self.solver_type]()
         return sol
 

@@ -566,3 +566,27 @@ def relay_main():
 
 if __name__ == '__main__' and os.environ.get('GOLDEN_RELAY', '0') == '1':
     relay_main()
+
+
+def cg_main():
+    """solver_type='CG' (generic_ND_FD.py:252-260: scipy cg, rtol=lintol, atol=0, x0 = previous node value): sweeps
+    with the accumulated work_counters['CG'] after every sweep."""
+    RR = dict(quad_type='RADAU-RIGHT')
+    cases = []
+    cases.append(sweep_case('cg_heat3d_16', 'heat_unforced', dict(nvars=(16, 16, 16), nu=0.1, freq=2, solver_type='CG',
+                                                                  lintol=1e-12, liniter=1000),
+                            'generic_implicit', dict(num_nodes=3, QI='LU', **RR), 0.01, u0_kind='exact'))
+    cases.append(sweep_case('cg_heat2d_32_IE', 'heat_unforced', dict(nvars=(32, 32), nu=0.1, freq=2, solver_type='CG',
+                                                                     lintol=1e-10, liniter=1000),
+                            'generic_implicit', dict(num_nodes=5, QI='IE', **RR), 0.02, u0_kind='randn'))
+    cases.append(sweep_case('cg_heat1d_64_o4', 'heat_unforced', dict(nvars=64, nu=0.1, freq=2, order=4, solver_type='CG',
+                                                                     lintol=1e-12, liniter=1000),
+                            'generic_implicit', dict(num_nodes=3, QI='LU', **RR), 0.005, u0_kind='exact'))
+    cases.append(sweep_case('cg_forced2d_16', 'heat_forced', dict(nvars=(16, 16), nu=0.1, freq=2, solver_type='CG',
+                                                                  lintol=1e-12, liniter=1000),
+                            'imex_1st_order', dict(num_nodes=3, QI='LU', QE='EE', **RR), 0.02, u0_kind='exact'))
+    save('sweeps_cg.npz', cases)
+
+
+if __name__ == '__main__' and os.environ.get('GOLDEN_CG', '0') == '1':
+    cg_main()
