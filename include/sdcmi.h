@@ -175,6 +175,8 @@ int sdc_vec_amax(sdc_ctx* ctx, size_t n, const double* x, double* out); /* abs()
 int sdc_set_problem_vdp(sdc_ctx* ctx, double mu, double newton_tol, int newton_maxiter);
 /* out[0] = Newton iterations, out[1] = right-hand side evaluations, out[2] = failed solves (pending), summed
  * over trajectories since context creation (work_counters of Van_der_Pol_implicit.py:71-73). */
+/* out = (dg/du)^{-1} rhs at u for g(u) = u - dt f(u), every trajectory (Van_der_Pol_implicit.py:190-201). */
+int sdc_solve_jacobian(sdc_ctx* ctx, const double* rhs, double dt, const double* u, double* out);
 int sdc_work_counters(sdc_ctx* ctx, unsigned long long* out); /* out[4]; out[3] = CG iterations (sdc_set_solver) */
 /* solver_type of GenericNDimFinDiff (generic_ND_FD.py:238-262).  kind 0 ('direct'): the exact solve in Fourier space
  * (default; satisfies any lintol).  kind 1 ('CG'): scipy.sparse.linalg.cg as the reference calls it - x0 = the previous

@@ -412,6 +412,14 @@ class VanDerPol:
             raise RuntimeError('Newton did not converge after %i iterations, error is %s' % (n, res))
         return u
 
+    def solve_jacobian(self, rhs, dt, u):
+        """Van_der_Pol_implicit.py:190-201: (dg/du)^{-1} rhs with the closed-form 2x2 inverse"""
+        mu, u1, u2 = self.mu, u[0], u[1]
+        c = 1.0 / (-2 * dt**2 * mu * u1 * u2 - dt**2 - 1 + dt * mu * (1 - u1**2))
+        dg = c * np.array([[dt * mu * (1 - u1**2) - 1, -dt], [2 * dt * mu * u1 * u2 + dt, -1]])
+        self.work_counters['jacobian_solves']()
+        return np.dot(dg, rhs)
+
 
 # ----------------------------------------------------------------------------------------------
 # level state and sweepers

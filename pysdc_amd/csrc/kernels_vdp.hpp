@@ -182,3 +182,18 @@ __global__ void k_vdp_solve(const double* __restrict__ rhsv, const double* __res
     }
 }
 
+// (dg/du)^{-1} rhs for g(u) = u - dt f(u): the closed-form 2x2 inverse of Van_der_Pol_implicit.py:190-201, one
+// trajectory per lane
+__global__ void k_vdp_jac_solve(const double* __restrict__ rhs, const double* __restrict__ u, double* __restrict__ out,
+                                size_t T, double dt, double mu) {
+#pragma clang fp contract(off)
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < T; i += (size_t)gridDim.x * blockDim.x) {
+        const double u1 = u[i], u2 = u[T + i], r0 = rhs[i], r1 = rhs[T + i];
+        const double c = 1.0 / (-2 * dt * dt * mu * u1 * u2 - dt * dt - 1 + dt * mu * (1 - u1 * u1));
+        const double d00 = c * (dt * mu * (1 - u1 * u1) - 1), d01 = c * (-dt);
+        const double d10 = c * (2 * dt * mu * u1 * u2 + dt), d11 = c * (-1.0);
+        out[i] = d00 * r0 + d01 * r1;
+        out[T + i] = d10 * r0 + d11 * r1;
+    }
+}
+

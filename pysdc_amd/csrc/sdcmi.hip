@@ -1542,6 +1542,16 @@ int sdc_solve(sdc_ctx* c, const double* rhs, double factor, const double* guess,
     return fft_pipeline(c, 1, p, z);
 }
 
+int sdc_solve_jacobian(sdc_ctx* c, const double* rhs, double dt, const double* u, double* out) {
+    if (!c || !rhs || !u || !out) return fail(c, SDC_ERR_PARAM, "null pointer");
+    if (c->kind != 1) return fail(c, SDC_ERR_UNSUPPORTED, "solve_jacobian is the van der Pol ensemble's (sdc_set_problem_vdp)");
+    LaunchTimer lt(c, "vdp_jac_solve");
+    hipLaunchKernelGGL(k_vdp_jac_solve, dim3(grid_for(c->N / 2, 256)), dim3(256), 0, c->stream, rhs, u, out, c->N / 2, dt,
+                       c->vdp_mu);
+    HIPCHK(c, hipGetLastError());
+    return SDC_OK;
+}
+
 int sdc_residual(sdc_ctx* c, double dt, int type, double* node_norms, double* residual) {
     if (!c || !residual) return fail(c, SDC_ERR_PARAM, "null pointer");
     if (!c->have_coeffs) return fail(c, SDC_ERR_STATE, "coefficients not set (sdc_set_coeffs)");

@@ -42,6 +42,7 @@ PROTOTYPES = {
     'sdc_set_fused_residual': (C.c_int, [_vp, C.c_int]),
     'sdc_set_deferred': (C.c_int, [_vp, C.c_int]),
     'sdc_set_solver': (C.c_int, [_vp, C.c_int, C.c_double, C.c_int]),
+    'sdc_solve_jacobian': (C.c_int, [_vp, _vp, C.c_double, _vp, _vp]),
     'sdc_advance': (C.c_int, [_vp]),
     'sdc_defer_f0': (C.c_int, [_vp]),
     'sdc_set_keep_residual_fields': (C.c_int, [_vp, C.c_int]),

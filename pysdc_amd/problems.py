@@ -383,6 +383,23 @@ class advectiondiffusionNd_imex(GenericNDimFinDiff):
         return self._from_host(np.broadcast_to(sol * np.exp(-t * self.nu * rho), self.nvars))
 
 
+class _SumCounter:
+    """counter that reads as a device counter plus a host-side count"""
+
+    def __init__(self, base, extra):
+        self._base, self._extra = base, extra
+
+    @property
+    def niter(self):
+        return self._base.niter + self._extra()
+
+    def __call__(self, *args, **kwargs):
+        pass
+
+    def __str__(self):
+        return f'{self.niter}'
+
+
 class _DeviceCounter:
     """work counter whose value lives on the device (summed over trajectories); reading synchronises."""
 
@@ -431,6 +448,9 @@ class vanderpol_ensemble(Problem):
         self._u0 = u0
         self.work_counters['newton'] = _DeviceCounter(self, 'newton')
         self.work_counters['rhs'] = _DeviceCounter(self, 'rhs')
+        # every Newton step is one Jacobian solve (Van_der_Pol_implicit.py:171), plus the direct calls
+        self._jac_calls = 0
+        self.work_counters['jacobian_solves'] = _SumCounter(self.work_counters['newton'], lambda: self._jac_calls)
 
     @property
     def u0(self):
@@ -462,6 +482,14 @@ class vanderpol_ensemble(Problem):
         sol = self.u_init
         self.engine.solve(rhs.ptr, float(dt), sol.ptr, guess_ptr=u0.ptr)
         return sol
+
+    def solve_jacobian(self, rhs, dt, u, **kwargs):
+        """Van_der_Pol_implicit.py:190-201 for every trajectory of the ensemble"""
+        out = self.u_init
+        e = self.engine
+        L.check(e.lib.sdc_solve_jacobian(e.ctx, rhs.ptr, float(dt), u.ptr, out.ptr), e.ctx)
+        self._jac_calls += self.ntraj
+        return out
 
 
 class _SpectralLaplacianIMEX(Problem):

@@ -590,3 +590,26 @@ def cg_main():
 
 if __name__ == '__main__' and os.environ.get('GOLDEN_CG', '0') == '1':
     cg_main()
+
+
+def vdp_jacobian_main():
+    """vanderpol.solve_jacobian (Van_der_Pol_implicit.py:190-201) on random states and right-hand sides."""
+    from pySDC.implementations.problem_classes.Van_der_Pol_implicit import vanderpol
+
+    P = vanderpol(mu=5.0, u0=(2.0, 0.0), newton_tol=1e-9, newton_maxiter=100)
+    rng = np.random.default_rng(21)
+    U = rng.uniform(-2.0, 2.0, (2, 64))
+    Rh = rng.standard_normal((2, 64))
+    out = np.zeros((2, 64))
+    for i in range(64):
+        u = P.dtype_u(P.init)
+        u[:] = U[:, i]
+        r = P.dtype_u(P.init)
+        r[:] = Rh[:, i]
+        out[:, i] = np.asarray(P.solve_jacobian(r, 0.05, u))
+    np.savez_compressed(os.path.join(OUT, 'vdp_jacobian.npz'), u=U, rhs=Rh, dt=0.05, mu=5.0, out=out)
+    print('vdp_jacobian.npz')
+
+
+if __name__ == '__main__' and os.environ.get('GOLDEN_VDPJ', '0') == '1':
+    vdp_jacobian_main()

@@ -451,3 +451,19 @@ def test_cg_sweeps_vs_golden(name, fused):
         assert abs(L.status.residual - ref) <= 1e-7 * abs(ref) + 1e-11, k
         counts.append(L.prob.work_counters['CG'].niter)
     assert counts == list(case['work_CG']), (counts, list(case['work_CG']))
+
+
+def test_vdp_solve_jacobian_vs_reference():
+    """vanderpol_ensemble.solve_jacobian against the reference's vanderpol.solve_jacobian, 64 random states."""
+    import os
+    from pysdc_amd.problems import vanderpol_ensemble
+
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'vdp_jacobian.npz'))
+    P = vanderpol_ensemble(ntraj=g['u'].shape[1], u0=g['u'], mu=float(g['mu']))
+    u, r = P.u_init, P.u_init
+    u[:] = g['u']
+    r[:] = g['rhs']
+    before = P.work_counters['jacobian_solves'].niter
+    got = P.solve_jacobian(r, float(g['dt']), u).get()
+    assert np.max(np.abs(got - g['out'])) <= 1e-14 * np.max(np.abs(g['out']))
+    assert P.work_counters['jacobian_solves'].niter - before == g['u'].shape[1]

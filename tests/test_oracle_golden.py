@@ -124,3 +124,13 @@ def test_fd_stencil_known_answers():
     c, s = O.fd_stencil(1, 3, 'upwind')
     np.testing.assert_allclose(c, [1 / 6, -1, 1 / 2, 1 / 3], atol=1e-14)
     np.testing.assert_array_equal(s, [-2, -1, 0, 1])
+
+
+def test_vdp_solve_jacobian_vs_reference():
+    import os
+
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'vdp_jacobian.npz'))
+    P = O.VanDerPol(mu=float(g['mu']))
+    for i in range(g['u'].shape[1]):
+        got = P.solve_jacobian(g['rhs'][:, i], float(g['dt']), g['u'][:, i])
+        assert np.array_equal(got, g['out'][:, i])
