@@ -828,12 +828,40 @@ def interpolation_matrix_1d_periodic(fine_grid, coarse_grid, k):
     return sp.csc_matrix(M)
 
 
+def interpolation_matrix_1d_bounded(fine_grid, coarse_grid, k):
+    """helpers/transfer_helper.py:206-231 (non-periodic, equidist_nested, pad=1): the coarse grid is mirrored by one
+    point at each end (:250-273); odd fine points copy their coarse twin, even ones interpolate the k nearest
+    padded coarse points with barycentric Lagrange polynomials; the padding columns are dropped (:243-244)."""
+    from scipy.interpolate import BarycentricInterpolator
+
+    nc = coarse_grid.size
+    padded = np.concatenate([[2 * coarse_grid[0] - coarse_grid[1]], coarse_grid, [2 * coarse_grid[-1] - coarse_grid[-2]]])
+    M = np.zeros((fine_grid.size, nc + 2))
+    for i, p in enumerate(fine_grid):
+        if i % 2 != 0:
+            M[i, (i - 1) // 2 + 1] = 1.0
+            continue
+        nn = []
+        for j in range(k):
+            idx = i // 2 - k // 2 + 1 + j
+            if idx < 0:
+                idx += k
+            elif idx > nc + 1:
+                idx -= k
+            nn.append(idx)
+        nn = sorted(nn)
+        unit = np.asarray([1.0] + [0.0] * (k - 1))
+        with np.errstate(divide='ignore'):
+            M[i, nn] = np.asarray([BarycentricInterpolator(padded[nn], np.roll(unit, l))(p) for l in range(k)])
+    return sp.csc_matrix(M[:, 1:-1])
+
+
 class MeshToMesh:
     """transfer_classes/TransferMesh.py:25-146 (periodic): P = kron of 1-D interpolation matrices of order
     iorder, R = kron of restr_factor * (interpolation matrix of order rorder)^T; :148-218 restrict / prolong
     (component-wise for imex arrays of shape (2, *nvars))."""
 
-    def __init__(self, nvars_fine, nvars_coarse, iorder=2, rorder=2):
+    def __init__(self, nvars_fine, nvars_coarse, iorder=2, rorder=2, periodic=True):
         nf = (nvars_fine,) if isinstance(nvars_fine, int) else tuple(nvars_fine)
         nc = (nvars_coarse,) if isinstance(nvars_coarse, int) else tuple(nvars_coarse)
         self.nf, self.nc = nf, nc
@@ -843,11 +871,17 @@ class MeshToMesh:
                 P.append(sp.eye(nf[a]))
                 R.append(sp.eye(nc[a]))
                 continue
-            fg = np.array([j * (1.0 / nf[a]) for j in range(nf[a])])
-            cg = np.array([j * (1.0 / nc[a]) for j in range(nc[a])])
-            P.append(interpolation_matrix_1d_periodic(fg, cg, iorder))
+            if periodic:
+                fg = np.array([j * (1.0 / nf[a]) for j in range(nf[a])])
+                cg = np.array([j * (1.0 / nc[a]) for j in range(nc[a])])
+                build = interpolation_matrix_1d_periodic
+            else:  # dirichlet grids: dx = 1/(n+1), points (j+1) dx (TransferMesh.py:62-64)
+                fg = np.array([(j + 1) * (1.0 / (nf[a] + 1)) for j in range(nf[a])])
+                cg = np.array([(j + 1) * (1.0 / (nc[a] + 1)) for j in range(nc[a])])
+                build = interpolation_matrix_1d_bounded
+            P.append(build(fg, cg, iorder))
             factor = 0.5 if rorder > 0 else 1.0
-            R.append(factor * (P[-1] if iorder == rorder else interpolation_matrix_1d_periodic(fg, cg, rorder)).T)
+            R.append(factor * (P[-1] if iorder == rorder else build(fg, cg, rorder)).T)
         self.P, self.R = P[0], R[0]
         for a in range(1, len(nf)):
             self.P = sp.kron(self.P, P[a], format='csc')

@@ -344,7 +344,7 @@ class generic_implicit(Sweeper):
         self.QI = self.get_Qdelta_implicit(qd_type=self.params.QI)
 
     def integrate(self):
-        if self._fused():
+        if self._fused() and not self.level._view_offset():  # (odd-extended engine fields: use the views)
             return self._integrate_fused()
         return _quadrature(self, [self.coll.Qmat[m] for m in range(1, self.coll.num_nodes + 1)])
 
@@ -370,7 +370,7 @@ class imex_1st_order(Sweeper):
         self.QE = self.get_Qdelta_explicit(qd_type=self.params.QE)
 
     def integrate(self):
-        if self._fused():
+        if self._fused() and not self.level._view_offset():  # (odd-extended engine fields: use the views)
             return self._integrate_fused()
         return _quadrature(self, [self.coll.Qmat[m] for m in range(1, self.coll.num_nodes + 1)])
 

@@ -182,6 +182,31 @@ def interpolation_matrix_1d(fine_grid, coarse_grid, k=2):
     return M
 
 
+def interpolation_matrix_1d_bounded(fine_grid, coarse_grid, k=2):
+    """Dense (n_fine x n_coarse) interpolation matrix between nested non-periodic grids (n_fine = 2 n_coarse + 1,
+    zero boundary values outside): helpers/transfer_helper.py:206-244 with pad = 1 - fine points with an odd index
+    coincide with a coarse point, the others interpolate k points of the coarse grid extended by its mirror
+    image at either end (border_padding, :250-273); the two padding columns are cut off again."""
+    from scipy.interpolate import BarycentricInterpolator
+
+    nc = coarse_grid.size
+    ext = np.empty(nc + 2)
+    ext[1:-1] = coarse_grid
+    ext[0] = 2 * coarse_grid[0] - coarse_grid[1]
+    ext[-1] = 2 * coarse_grid[-1] - coarse_grid[-2]
+    M = np.zeros((fine_grid.size, nc + 2))
+    one = np.asarray([1.0] + [0.0] * (k - 1))
+    for i, p in enumerate(fine_grid):
+        if i % 2 == 1:
+            M[i, (i - 1) // 2 + 1] = 1.0
+            continue
+        first = i // 2 - k // 2 + 1
+        nn = sorted(q + k if q < 0 else (q - k if q > nc + 1 else q) for q in range(first, first + k))
+        with np.errstate(divide='ignore'):
+            M[i, nn] = np.asarray([BarycentricInterpolator(ext[nn], np.roll(one, l))(p) for l in range(k)])
+    return M[:, 1:-1]
+
+
 def _row_tables(M):
     """fixed-width (idx, w) rows of a dense 1-D operator, zero-padded."""
     width = max(1, int(np.max(np.count_nonzero(M, axis=1))))
@@ -212,20 +237,26 @@ class mesh_to_mesh:
         else:
             raise TransferError('unknow type of nvars for transfer, got %s' % (nf,))
         self.identity = nf == nc
+        periodic = bool(self.params.periodic)
         if not self.identity:
-            if not self.params.periodic or not self.params.equidist_nested:
-                raise TransferError('the MI355X transfer kernels implement periodic, equidistant, nested grids')
-            if any(f != 2 * c for f, c in zip(nf, nc)):
+            if not self.params.equidist_nested:
+                raise TransferError('the MI355X transfer kernels implement equidistant, nested grids')
+            if periodic and any(f != 2 * c for f, c in zip(nf, nc)):
                 raise TransferError(f'need coarsening by a factor of 2 per axis, got {nf} -> {nc}')
+            if not periodic and (len(nf) != 1 or nf[0] != 2 * nc[0] + 1):
+                raise TransferError('non-periodic transfer is built for 1-D grids with n_fine = 2 n_coarse + 1 '
+                                    f'(dirichlet-zero), got {nf} -> {nc}')
         self.ndim, self.nc, self.nf = len(nc), nc[0], nf[0]
         if not self.identity:
             import torch
 
-            fine_grid = np.array([j * fine_prob.dx for j in range(nf[0])])
-            coarse_grid = np.array([j * coarse_prob.dx for j in range(nc[0])])
-            P = interpolation_matrix_1d(fine_grid, coarse_grid, k=self.params.iorder)
+            first = 0 if periodic else 1  # TransferMesh.py:62-67: dirichlet grids start at dx
+            fine_grid = np.array([(j + first) * fine_prob.dx for j in range(nf[0])])
+            coarse_grid = np.array([(j + first) * coarse_prob.dx for j in range(nc[0])])
+            build = interpolation_matrix_1d if periodic else interpolation_matrix_1d_bounded
+            P = build(fine_grid, coarse_grid, k=self.params.iorder)
             restr_factor = 0.5 if self.params.rorder > 0 else 1.0
-            Pr = P if self.params.iorder == self.params.rorder else interpolation_matrix_1d(
+            Pr = P if self.params.iorder == self.params.rorder else build(
                 fine_grid, coarse_grid, k=self.params.rorder)
             R = restr_factor * Pr.T
             self._tab = {}

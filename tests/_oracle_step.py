@@ -114,7 +114,8 @@ class OracleMeshToMesh:
     """space_transfer_class for oracle-backed levels (same constructor signature as the product classes)."""
 
     def __init__(self, fine_prob, coarse_prob, params):
-        self.T = O.MeshToMesh(fine_prob.o.nvars, coarse_prob.o.nvars, params.get('iorder', 2), params.get('rorder', 2))
+        self.T = O.MeshToMesh(fine_prob.o.nvars, coarse_prob.o.nvars, params.get('iorder', 2), params.get('rorder', 2),
+                              periodic=params.get('periodic', True))
 
     def restrict(self, F):
         return np_mesh(self.T.restrict(np.asarray(F)))

@@ -613,3 +613,65 @@ def vdp_jacobian_main():
 
 if __name__ == '__main__' and os.environ.get('GOLDEN_VDPJ', '0') == '1':
     vdp_jacobian_main()
+
+
+def dirichlet_ml_main():
+    """non-periodic mesh_to_mesh (1-D dirichlet-zero, nested grids nf = 2 nc + 1) and the tutorials' multi-level
+    runs on it: step_4/C-like SDC vs 3-level MLSDC, step_6/A-like two-level PFASST with 1/2/4 processes."""
+    from pySDC.implementations.transfer_classes.TransferMesh import mesh_to_mesh
+
+    out = {}
+    rng = np.random.default_rng(8)
+    for tag, nf, nc, io, ro in (('d1_63_31_o2', 63, 31, 2, 2), ('d1_127_63_o6', 127, 63, 6, 2), ('d1_31_15_o4', 31, 15, 4, 4),
+                                ('d1_15_7_o6', 15, 7, 6, 2)):
+        pf = heatNd_unforced(nvars=nf, nu=0.1, freq=2, bc='dirichlet-zero')
+        pc = heatNd_unforced(nvars=nc, nu=0.1, freq=2, bc='dirichlet-zero')
+        T = mesh_to_mesh(pf, pc, dict(iorder=io, rorder=ro, periodic=False))
+        F = pf.dtype_u(pf.init)
+        F[:] = rng.standard_normal(pf.init[0])
+        G = pc.dtype_u(pc.init)
+        G[:] = rng.standard_normal(pc.init[0])
+        out[f'{tag}/fine'], out[f'{tag}/coarse'] = np.asarray(F).copy(), np.asarray(G).copy()
+        out[f'{tag}/restricted'] = np.asarray(T.restrict(F)).copy()
+        out[f'{tag}/prolonged'] = np.asarray(T.prolong(G)).copy()
+        out[f'{tag}/meta'] = np.array(json.dumps(dict(name=tag, nf=nf, nc=nc, iorder=io, rorder=ro)))
+    np.savez_compressed(os.path.join(OUT, 'transfer_dirichlet.npz'), **out)
+
+    def ml_run(name, pp, sw, lp, maxiter, t0, Tend, num_procs, cp=None, io=6, ro=2, prob='heat_unforced',
+               sweeper='generic_implicit'):
+        desc = dict(problem_class=PROBS[prob], problem_params=pp, sweeper_class=SWEEPERS[sweeper], sweeper_params=sw,
+                    level_params=lp, step_params=dict(maxiter=maxiter), space_transfer_class=mesh_to_mesh,
+                    space_transfer_params=dict(rorder=ro, iorder=io, periodic=False))
+        cpar = dict(logger_level=40)
+        cpar.update(cp or {})
+        C = controller_nonMPI(num_procs, cpar, desc)
+        P = C.MS[0].levels[0].prob
+        u0 = P.u_exact(t0)
+        uend, stats = C.run(u0, t0, Tend)
+        o = {'u0': np.asarray(u0).copy(), 'uend': np.asarray(uend).copy()}
+        niter = get_sorted(stats, type='niter', sortby='time')
+        o['niter_t'] = np.array([t for t, _ in niter])
+        o['niter'] = np.array([v for _, v in niter])
+        o['res'] = np.array([v for _, v in get_sorted(stats, type='residual_post_iteration', sortby='time')])
+        o['meta'] = np.array(json.dumps(dict(name=name, prob=prob, prob_params=pp, sweeper=sweeper, sweeper_params=sw,
+                                             level_params=lp, maxiter=maxiter, t0=t0, Tend=Tend, num_procs=num_procs,
+                                             controller_params=cp or {}, iorder=io, rorder=ro, periodic=False)))
+        return o
+
+    RR = dict(quad_type='RADAU-RIGHT')
+    cases = []
+    # tutorial step_4/C: heat 1-D dirichlet, M=5 LU, dt=0.1, restol 1e-9, three levels
+    cases.append(ml_run('t4c_mlsdc3', dict(nvars=[255, 127, 63], nu=0.1, freq=4, bc='dirichlet-zero'),
+                        dict(num_nodes=5, QI='LU', **RR), dict(dt=0.1, restol=1e-9), 50, 0.1, 0.2, 1, io=6, ro=2))
+    # tutorial step_6/A: two levels, M=3, dt=0.125, restol 5e-10, 8 steps
+    base = dict(pp=dict(nvars=[63, 31], nu=0.1, freq=2, bc='dirichlet-zero'), sw=dict(num_nodes=3, QI='LU', **RR),
+                lp=dict(dt=0.125, restol=5e-10), maxiter=50, t0=0.0, Tend=1.0, io=6, ro=2)
+    cases.append(ml_run('t6a_mlsdc', num_procs=1, **base))
+    for P_ in (2, 4):
+        cases.append(ml_run(f't6a_pfasst_P{P_}', num_procs=P_, cp=dict(predict_type='pfasst_burnin', all_to_done=True),
+                            **base))
+    save('runs_ml_dirichlet.npz', cases)
+
+
+if __name__ == '__main__' and os.environ.get('GOLDEN_DML', '0') == '1':
+    dirichlet_ml_main()

@@ -71,6 +71,24 @@ def test_fourier_transfer_kernels(name):
     assert rel_err(T.prolong(G).get(), c['prolonged']) < 1e-13
 
 
+@pytest.mark.parametrize('name', list(load_cases('transfer_dirichlet.npz')))
+def test_dirichlet_transfer_kernels(name):
+    """non-periodic mesh_to_mesh between 1-D dirichlet-zero grids on the device against the reference class."""
+    from pysdc_amd.problems import heatNd_unforced
+    from pysdc_amd.transfer import mesh_to_mesh
+
+    c = load_cases('transfer_dirichlet.npz')[name]
+    m = c['meta']
+    pf = heatNd_unforced(nvars=m['nf'], nu=0.1, freq=2, bc='dirichlet-zero')
+    pc = heatNd_unforced(nvars=m['nc'], nu=0.1, freq=2, bc='dirichlet-zero')
+    T = mesh_to_mesh(pf, pc, dict(iorder=m['iorder'], rorder=m['rorder'], periodic=False))
+    F, G = pf.u_init, pc.u_init
+    F[:] = c['fine']
+    G[:] = c['coarse']
+    assert rel_err(T.restrict(F).get(), c['restricted']) < 1e-14
+    assert rel_err(T.prolong(G).get(), c['prolonged']) < 1e-14
+
+
 @pytest.mark.parametrize('name', list(load_cases('fas.npz')))
 def test_fas_on_device(name):
     from pysdc_amd.level import Step
@@ -111,7 +129,8 @@ def test_fas_on_device(name):
 
 
 ML_RUNS = ([('runs_ml.npz', n) for n in load_cases('runs_ml.npz')] + [('runs_ac.npz', n) for n in load_cases('runs_ac.npz')]
-           + [('runs_ac_fft.npz', n) for n in load_cases('runs_ac_fft.npz')])
+           + [('runs_ac_fft.npz', n) for n in load_cases('runs_ac_fft.npz')]
+           + [('runs_ml_dirichlet.npz', n) for n in load_cases('runs_ml_dirichlet.npz')])
 
 
 @pytest.mark.parametrize('fname,name', ML_RUNS)
@@ -122,6 +141,8 @@ def test_mlsdc_pfasst_on_device(fname, name):
     case = load_cases(fname)[name]
     meta = case['meta']
     desc = _description(meta, meta['level_params'], meta.get('iorder', 6), meta.get('rorder', 2))
+    if not meta.get('periodic', True):
+        desc['space_transfer_params']['periodic'] = False
     if meta.get('transfer') == 'mesh_to_mesh_fft2d':
         from pysdc_amd.transfer import mesh_to_mesh_fft2d
 

@@ -105,7 +105,8 @@ def test_fas_restrict_prolong(name):
 
 
 ML_RUNS = ([('runs_ml.npz', n) for n in load_cases('runs_ml.npz')] + [('runs_ac.npz', n) for n in load_cases('runs_ac.npz')]
-           + [('runs_ac_fft.npz', n) for n in load_cases('runs_ac_fft.npz')])
+           + [('runs_ac_fft.npz', n) for n in load_cases('runs_ac_fft.npz')]
+           + [('runs_ml_dirichlet.npz', n) for n in load_cases('runs_ml_dirichlet.npz')])
 
 
 def _ml_description(meta, case):
@@ -118,7 +119,7 @@ def _ml_description(meta, case):
                     space_transfer_params={})
     return dict(step_class=OracleStep, oracle_level_factory=level_factories(meta, case, lp), level_params=lp,
                 step_params=dict(maxiter=meta['maxiter']), space_transfer_class=OracleMeshToMesh,
-                space_transfer_params=dict(iorder=meta['iorder'], rorder=meta['rorder']))
+                space_transfer_params=dict(iorder=meta['iorder'], rorder=meta['rorder'], periodic=meta.get('periodic', True)))
 
 
 @pytest.mark.parametrize('fname,name', ML_RUNS)
@@ -205,3 +206,21 @@ def test_hooks_stats_keys():
               'timing_step', 'timing_iteration', 'timing_sweep'):
         assert t in types, (t, types)
     assert len(get_sorted(C.return_stats(), type='timing_step')) == 2
+
+
+def test_dirichlet_transfer_oracle_and_product_matrices_vs_golden():
+    """non-periodic mesh_to_mesh: the oracle's operators and the product's host-built matrices (the device only
+    applies their rows) against vectors of the reference class."""
+    from pysdc_amd.transfer import interpolation_matrix_1d_bounded
+
+    for name, c in load_cases('transfer_dirichlet.npz').items():
+        m = c['meta']
+        T = O.MeshToMesh(m['nf'], m['nc'], m['iorder'], m['rorder'], periodic=False)
+        assert rel_err(T.restrict(c['fine']), c['restricted']) < 1e-15, name
+        assert rel_err(T.prolong(c['coarse']), c['prolonged']) < 1e-15, name
+        fg = np.array([(j + 1) / (m['nf'] + 1) for j in range(m['nf'])])
+        cg = np.array([(j + 1) / (m['nc'] + 1) for j in range(m['nc'])])
+        P = interpolation_matrix_1d_bounded(fg, cg, m['iorder'])
+        Pr = interpolation_matrix_1d_bounded(fg, cg, m['rorder'])
+        assert rel_err(P @ c['coarse'], c['prolonged']) < 1e-15, name
+        assert rel_err(0.5 * Pr.T @ c['fine'], c['restricted']) < 1e-15, name
