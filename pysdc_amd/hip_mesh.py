@@ -199,16 +199,25 @@ class hip_mesh:
         return self._axpby(-1.0, self, 0.0, None, self._new_like())
 
     def __iadd__(self, o):
+        self._axpby(1.0, self, 1.0, self._coerce(o), self)
         self._wrote()
-        return self._axpby(1.0, self, 1.0, self._coerce(o), self)
+        return self
 
     def __isub__(self, o):
+        self._axpby(1.0, self, -1.0, self._coerce(o), self)
         self._wrote()
-        return self._axpby(1.0, self, -1.0, self._coerce(o), self)
+        return self
 
     def __imul__(self, a):
+        self._axpby(float(a), self, 0.0, None, self)
         self._wrote()
-        return self._axpby(float(a), self, 0.0, None, self)
+        return self
+
+    def iaxpy(self, a, x):
+        """self += a * x in one pass (no temporary for a * x)"""
+        self._axpby(1.0, self, float(a), self._coerce(x), self)
+        self._wrote()
+        return self
 
     def __abs__(self):
         out = C.c_double()
@@ -313,6 +322,11 @@ class hip_imex_mesh:
         else:
             self.impl += o
             self.expl += o
+        return self
+
+    def iaxpy(self, a, x):
+        self.impl.iaxpy(a, x.impl if isinstance(x, hip_imex_mesh) else x)
+        self.expl.iaxpy(a, x.expl if isinstance(x, hip_imex_mesh) else x)
         return self
 
     def __isub__(self, o):

@@ -49,11 +49,25 @@ class BaseTransfer:
 
     # ---- helpers: node-space combinations with a small dense matrix ------------------------------------------
     @staticmethod
-    def _mix(matrix_row, fields):
+    def _add_scaled(acc, coeff, field):
+        """acc += coeff * field; terms with a zero coefficient leave acc as it is (x + 0*y = x for finite y), which is
+        most of them when both levels share their nodes (Pcoll = Rcoll = identity)"""
+        if coeff == 0.0:
+            return acc
+        if coeff == 1.0:
+            acc += field
+        elif hasattr(acc, 'iaxpy'):
+            acc.iaxpy(coeff, field)
+        else:
+            acc += coeff * field
+        return acc
+
+    @classmethod
+    def _mix(cls, matrix_row, fields):
         """sum_m matrix_row[m] * fields[m], accumulated left to right like the reference's loops."""
         acc = matrix_row[0] * fields[0]
         for coeff, field in zip(matrix_row[1:], fields[1:]):
-            acc += coeff * field
+            acc = cls._add_scaled(acc, coeff, field)
         return acc
 
     def _to_coarse_nodes(self, fine_fields):
@@ -86,7 +100,7 @@ class BaseTransfer:
             carried = [self.space_transfer.restrict(fine.tau[m]) for m in range(Mf)]
             for n in range(Mc):
                 for m in range(Mf):
-                    coarse.tau[n] += self.Rcoll[n, m] * carried[m]
+                    coarse.tau[n] = self._add_scaled(coarse.tau[n], self.Rcoll[n, m], carried[m])
 
         for n in range(1, Mc + 1):
             coarse.uold[n] = cprob.dtype_u(coarse.u[n])
@@ -106,7 +120,7 @@ class BaseTransfer:
         delta = self._coarse_correction(coarse.u, coarse.uold)
         for n in range(1, Mf + 1):
             for m in range(Mc):
-                fine.u[n] += self.Pcoll[n - 1, m] * delta[m]
+                fine.u[n] = self._add_scaled(fine.u[n], self.Pcoll[n - 1, m], delta[m])
         for n in range(1, Mf + 1):
             fine.f[n] = fine.prob.eval_f(fine.u[n], fine.time + fine.dt * fine.sweep.coll.nodes[n - 1])
 
@@ -120,8 +134,8 @@ class BaseTransfer:
         df = self._coarse_correction(coarse.f, coarse.fold)
         for n in range(1, Mf + 1):
             for m in range(Mc):
-                fine.u[n] += self.Pcoll[n - 1, m] * du[m]
-                fine.f[n] += self.Pcoll[n - 1, m] * df[m]
+                fine.u[n] = self._add_scaled(fine.u[n], self.Pcoll[n - 1, m], du[m])
+                fine.f[n] = self._add_scaled(fine.f[n], self.Pcoll[n - 1, m], df[m])
 
 
 class _SpacePars:
