@@ -16,19 +16,24 @@ struct XferArgs {
     int n_out, n_in, W;
 };
 
-// one axis of the tensor product: out[o][i][q] = sum_j w[i][j] * in[o][idx[i][j]][q]
-__global__ void k_xfer_axis(XferArgs a) {
-    const size_t total = a.outer * a.n_out * a.inner;
-    for (size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x; p < total; p += (size_t)gridDim.x * blockDim.x) {
-        const size_t q = p % a.inner;
-        const size_t r = p / a.inner;
-        const int i = (int)(r % a.n_out);
-        const size_t o = r / a.n_out;
-        const double* __restrict__ src = a.in + o * a.n_in * a.inner + q;
+// one axis of the tensor product: out[o][i][q] = sum_j w[i][j] * in[o][idx[i][j]][q].  IDX = unsigned when the
+// element count fits 32 bits (64-bit division is emulated on the GPU and dominated this kernel).
+template <class IDX>
+__global__ __launch_bounds__(256) void k_xfer_axis(XferArgs a) {
+    const IDX inner = (IDX)a.inner, n_out = (IDX)a.n_out;
+    const IDX total = (IDX)(a.outer * a.n_out * a.inner);
+    for (IDX p = blockIdx.x * (IDX)blockDim.x + threadIdx.x; p < total; p += (IDX)gridDim.x * blockDim.x) {
+        const IDX r = inner == 1 ? p : p / inner;
+        const IDX q = inner == 1 ? 0 : p - r * inner;
+        const IDX o = r / n_out;
+        const int i = (int)(r - o * n_out);
+        const double* __restrict__ src = a.in + ((size_t)o * a.n_in) * a.inner + q;
+        const int* __restrict__ ix = a.idx + i * a.W;
+        const double* __restrict__ wx = a.w + i * a.W;
         double acc = 0.0;
         for (int j = 0; j < a.W; ++j) {
-            const double wj = a.w[i * a.W + j];
-            if (wj != 0.0) acc += wj * src[(size_t)a.idx[i * a.W + j] * a.inner];
+            const double wj = wx[j];
+            if (wj != 0.0) acc += wj * src[(size_t)ix[j] * a.inner];
         }
         a.out[p] = acc;
     }

@@ -1811,7 +1811,11 @@ int sdc_transfer_apply(void* stream, int ndim, int n_out, int n_in, int width, c
         a.in = src;
         a.out = pass == ndim - 1 ? out : scratch[pass & 1];
         const size_t total = a.outer * (size_t)n_out * a.inner;
-        hipLaunchKernelGGL(k_xfer_axis, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, a);
+        const size_t in_total = a.outer * (size_t)n_in * a.inner;
+        if (total < 0xffffffffull && in_total < 0xffffffffull)
+            hipLaunchKernelGGL(k_xfer_axis<unsigned>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, a);
+        else
+            hipLaunchKernelGGL(k_xfer_axis<size_t>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, a);
         dims[axis] = n_out;
         src = a.out;
     }

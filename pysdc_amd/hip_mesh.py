@@ -57,7 +57,8 @@ class hip_mesh:
             self.shape = (int(shape),) if np.isscalar(shape) else tuple(int(s) for s in shape)
             self.size = int(np.prod(self.shape))
             self._alloc()
-            _chk(L.load().sdc_vec_fill(None, self.size, float(val), self.ptr))
+            if val is not None:  # val=None: contents undefined (the caller overwrites every element)
+                _chk(L.load().sdc_vec_fill(None, self.size, float(val), self.ptr))
             type(self).comm = init[1]
         else:
             raise NotImplementedError(type(init))

@@ -73,6 +73,13 @@ class Problem:
     def f_init(self):
         return self.dtype_f(self.init)
 
+    # outputs of eval_f / solve_system: every element is written by the engine, no zero fill needed
+    def _out_u(self):
+        return self.dtype_u(self.init, val=None)
+
+    def _out_f(self):
+        return self.dtype_f(self.init, val=None)
+
     def eval_f(self, u, t):
         raise NotImplementedError('ERROR: problem has to implement eval_f(self, u, t)')
 
@@ -216,13 +223,13 @@ class GenericNDimFinDiff(Problem):
         return self._ext(k).ptr if self.view_offset else dst.ptr
 
     def eval_f(self, u, t):
-        f = self.f_init
+        f = self._out_f()
         self.engine.eval_f(self._stage_in(u, 0), 0.0, self._out_ptr(1, f))
         self._stage_out(1, f)
         return f
 
     def solve_system(self, rhs, factor, u0, t):
-        sol = self.u_init
+        sol = self._out_u()
         guess = self._stage_in(u0, 2) if self.solver_type == 'CG' and u0 is not None else None
         self.engine.solve(self._stage_in(rhs, 0), float(factor), self._out_ptr(1, sol), guess)
         self._stage_out(1, sol)
@@ -231,7 +238,7 @@ class GenericNDimFinDiff(Problem):
         return sol
 
     def _from_host(self, values):
-        sol = self.u_init
+        sol = self._out_u()
         sol[:] = values
         return sol
 
@@ -305,7 +312,7 @@ class heatNd_forced(heatNd_unforced):
         return imex_1st_order
 
     def eval_f(self, u, t):
-        f = self.f_init
+        f = self._out_f()
         if self.view_offset:
             self.engine.eval_f(self._stage_in(u, 0), float(self.forcing_g(t)), self._ext(1).ptr, self._ext(2).ptr)
             n = self.nvars[0]
@@ -369,7 +376,7 @@ class advectiondiffusionNd_imex(GenericNDimFinDiff):
         return imex_1st_order
 
     def eval_f(self, u, t):
-        f = self.f_init
+        f = self._out_f()
         self.engine.eval_f(u.ptr, 0.0, f.impl.ptr, f.expl.ptr)
         return f
 
@@ -474,18 +481,18 @@ class vanderpol_ensemble(Problem):
         return me
 
     def eval_f(self, u, t):
-        f = self.f_init
+        f = self._out_f()
         self.engine.eval_f(u.ptr, 0.0, f.ptr)
         return f
 
     def solve_system(self, rhs, dt, u0, t):
-        sol = self.u_init
+        sol = self._out_u()
         self.engine.solve(rhs.ptr, float(dt), sol.ptr, guess_ptr=u0.ptr)
         return sol
 
     def solve_jacobian(self, rhs, dt, u, **kwargs):
         """Van_der_Pol_implicit.py:190-201 for every trajectory of the ensemble"""
-        out = self.u_init
+        out = self._out_u()
         e = self.engine
         L.check(e.lib.sdc_solve_jacobian(e.ctx, rhs.ptr, float(dt), u.ptr, out.ptr), e.ctx)
         self._jac_calls += self.ntraj
@@ -512,7 +519,7 @@ class _SpectralLaplacianIMEX(Problem):
         return imex_1st_order
 
     def eval_f(self, u, t):
-        f = self.f_init
+        f = self._out_f()
         self.engine.eval_f(u.ptr, 0.0, f.impl.ptr, f.expl.ptr)
         if 'rhs' in self.work_counters:
             self.work_counters['rhs']()
@@ -524,7 +531,7 @@ class _SpectralLaplacianIMEX(Problem):
         return me
 
     def _from_host(self, values):
-        sol = self.u_init
+        sol = self._out_u()
         sol[:] = values
         return sol
 

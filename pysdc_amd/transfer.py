@@ -298,11 +298,11 @@ class mesh_to_mesh:
     def restrict(self, F):
         """TransferMesh.py:148-183."""
         if isinstance(F, hip_imex_mesh):
-            G = hip_imex_mesh(self.coarse_prob.init)
+            G = hip_imex_mesh(self.coarse_prob.init, val=None)
             self._restrict(F.impl, G.impl)
             self._restrict(F.expl, G.expl)
         elif isinstance(F, hip_mesh):
-            G = hip_mesh(self.coarse_prob.init)
+            G = hip_mesh(self.coarse_prob.init, val=None)
             self._restrict(F, G)
         else:
             raise TransferError('Wrong data type for restriction, got %s' % type(F))
@@ -311,11 +311,11 @@ class mesh_to_mesh:
     def prolong(self, G):
         """TransferMesh.py:185-218."""
         if isinstance(G, hip_imex_mesh):
-            F = hip_imex_mesh(self.fine_prob.init)
+            F = hip_imex_mesh(self.fine_prob.init, val=None)
             self._prolong(G.impl, F.impl)
             self._prolong(G.expl, F.expl)
         elif isinstance(G, hip_mesh):
-            F = hip_mesh(self.fine_prob.init)
+            F = hip_mesh(self.fine_prob.init, val=None)
             self._prolong(G, F)
         else:
             raise TransferError('Wrong data type for prolongation, got %s' % type(G))
@@ -370,11 +370,11 @@ class _fourier_transfer:
 
     def restrict(self, F):
         if isinstance(F, hip_imex_mesh):
-            G = hip_imex_mesh(self.coarse_prob.init)
+            G = hip_imex_mesh(self.coarse_prob.init, val=None)
             self._inject(F.impl, G.impl)
             self._inject(F.expl, G.expl)
         elif isinstance(F, hip_mesh):
-            G = hip_mesh(self.coarse_prob.init)
+            G = hip_mesh(self.coarse_prob.init, val=None)
             self._inject(F, G)
         else:
             raise TransferError('Unknown data type, got %s' % type(F))
@@ -382,11 +382,11 @@ class _fourier_transfer:
 
     def prolong(self, G):
         if isinstance(G, hip_imex_mesh):
-            F = hip_imex_mesh(self.fine_prob.init)
+            F = hip_imex_mesh(self.fine_prob.init, val=None)
             self._pad(G.impl, F.impl)
             self._pad(G.expl, F.expl)
         elif isinstance(G, hip_mesh):
-            F = hip_mesh(self.fine_prob.init)
+            F = hip_mesh(self.fine_prob.init, val=None)
             self._pad(G, F)
         else:
             raise TransferError('Unknown data type, got %s' % type(G))
