@@ -193,6 +193,10 @@ int sdc_set_solver(sdc_ctx* ctx, int kind, double rtol, int maxiter);
  * levels are involved); errors are reported through sdc_last_error(NULL). */
 int sdc_transfer_apply(void* stream, int ndim, int n_out, int n_in, int width, const int* idx, const double* w,
                        const double* in, double* out);
+/* The same for nfields fields that lie one behind the other (in: nfields * n_in^ndim doubles, out likewise): the node
+ * values U[1..M] of a slab, a set of quadrature integrals - one launch per axis for all of them. */
+int sdc_transfer_apply_batch(void* stream, int nfields, int ndim, int n_out, int n_in, int width, const int* idx,
+                             const double* w, const double* in, double* out);
 
 /* Fourier prolongation between two periodic grids held by two contexts (the levels' engines):
  * mesh_to_mesh_fft (1-D, transfer_classes/TransferMesh_FFT.py:36-57: rfft, low modes + Nyquist copied, irfft,

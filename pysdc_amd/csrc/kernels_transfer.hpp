@@ -17,28 +17,34 @@ struct XferArgs {
 };
 
 // one axis of the tensor product: out[o][i][q] = sum_j w[i][j] * in[o][idx[i][j]][q].  IDX = unsigned when the
-// element count fits 32 bits (64-bit division is emulated on the GPU and dominated this kernel).
-template <class IDX>
+// element counts fit 32 bits (64-bit division is emulated on the GPU).  A thread owns one (o, q) and walks CH
+// consecutive output rows i: neighbouring rows read almost the same input rows, which then come from L1 instead
+// of being fetched once per output row (the planes of a strided axis do not fit L2 for long).
+template <class IDX, int CH>
 __global__ __launch_bounds__(256) void k_xfer_axis(XferArgs a) {
-    const IDX inner = (IDX)a.inner, n_out = (IDX)a.n_out;
-    const IDX total = (IDX)(a.outer * a.n_out * a.inner);
+    const IDX inner = (IDX)a.inner, outer = (IDX)a.outer;
+    const IDX nch = ((IDX)a.n_out + CH - 1) / CH;
+    const IDX total = outer * nch * inner;
     for (IDX p = blockIdx.x * (IDX)blockDim.x + threadIdx.x; p < total; p += (IDX)gridDim.x * blockDim.x) {
         const IDX r = inner == 1 ? p : p / inner;
         const IDX q = inner == 1 ? 0 : p - r * inner;
-        const IDX o = r / n_out;
-        const int i = (int)(r - o * n_out);
+        const IDX o = r / nch;
+        const int i0 = (int)(r - o * nch) * CH;
         const double* __restrict__ src = a.in + ((size_t)o * a.n_in) * a.inner + q;
-        const int* __restrict__ ix = a.idx + i * a.W;
-        const double* __restrict__ wx = a.w + i * a.W;
-        double acc = 0.0;
-        for (int j = 0; j < a.W; ++j) {
-            const double wj = wx[j];
-            if (wj != 0.0) acc += wj * src[(size_t)ix[j] * a.inner];
+        double* __restrict__ dst = a.out + ((size_t)o * a.n_out) * a.inner + q;
+#pragma unroll 1
+        for (int i = i0; i < i0 + CH && i < a.n_out; ++i) {
+            const int* __restrict__ ix = a.idx + i * a.W;
+            const double* __restrict__ wx = a.w + i * a.W;
+            double acc = 0.0;
+            for (int j = 0; j < a.W; ++j) {
+                const double wj = wx[j];
+                if (wj != 0.0) acc += wj * src[(size_t)ix[j] * a.inner];
+            }
+            dst[(size_t)i * a.inner] = acc;
         }
-        a.out[p] = acc;
     }
 }
-
 
 // ------------------------------------------------------------------------------------------------------
 // Fourier prolongation (mesh_to_mesh_fft, TransferMesh_FFT.py:36-57; mesh_to_mesh_fft2d,

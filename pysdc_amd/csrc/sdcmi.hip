@@ -12,6 +12,9 @@
 #ifndef SDC_T1024
 #define SDC_T1024 8
 #endif
+#ifndef SDC_XFER_CH
+#define SDC_XFER_CH 8
+#endif
 #ifndef SDC_FUSE_SPECZ
 #define SDC_FUSE_SPECZ 1
 #endif
@@ -892,6 +895,8 @@ int sdc_set_forcing_values(sdc_ctx* c, const double* g) {
 }
 
 extern "C" int sdc_invalidate_spectra(sdc_ctx* c, int which);
+extern "C" int sdc_transfer_apply_batch(void* stream, int nfields, int ndim, int n_out, int n_in, int width, const int* idx,
+                                        const double* w, const double* in, double* out);
 extern "C" int sdc_materialize(sdc_ctx* c, int slot, int m);
 extern "C" int sdc_solve(sdc_ctx* c, const double* rhs, double factor, const double* guess, double* out);
 extern "C" int sdc_eval_f(sdc_ctx* c, const double* u, double g_t, double* f_impl, double* f_expl);
@@ -1774,14 +1779,19 @@ int sdc_vec_amax(sdc_ctx* c, size_t n, const double* x, double* out) {
 
 int sdc_transfer_apply(void* stream, int ndim, int n_out, int n_in, int width, const int* idx, const double* w,
                        const double* in, double* out) {
-    if (ndim < 1 || ndim > 3 || n_out < 1 || n_in < 1 || width < 1 || !idx || !w || !in || !out)
+    return sdc_transfer_apply_batch(stream, 1, ndim, n_out, n_in, width, idx, w, in, out);
+}
+
+int sdc_transfer_apply_batch(void* stream, int nfields, int ndim, int n_out, int n_in, int width, const int* idx,
+                             const double* w, const double* in, double* out) {
+    if (nfields < 1 || ndim < 1 || ndim > 3 || n_out < 1 || n_in < 1 || width < 1 || !idx || !w || !in || !out)
         return fail(nullptr, SDC_ERR_PARAM, "bad transfer arguments");
     // separable: one pass per axis (cost ~ ndim * width per point instead of width^ndim), last axis first so that
     // intermediate fields stay as small as possible when prolonging; two scratch fields ping-pong in between
     static thread_local double* scratch[2] = {nullptr, nullptr};
     static thread_local size_t scratch_len = 0;
     const int nmax = n_out > n_in ? n_out : n_in;
-    size_t need = 1;
+    size_t need = (size_t)nfields;  // the fields are one more (outermost) dimension of every pass
     for (int d = 0; d < ndim; ++d) need *= (size_t)nmax;
     if (ndim > 1 && need > scratch_len) {
         for (int k = 0; k < 2; ++k) {
@@ -1804,7 +1814,7 @@ int sdc_transfer_apply(void* stream, int ndim, int n_out, int n_in, int width, c
         a.W = width;
         a.n_in = n_in;
         a.n_out = n_out;
-        a.outer = 1;
+        a.outer = (size_t)nfields;
         a.inner = 1;
         for (int d = 0; d < axis; ++d) a.outer *= (size_t)dims[d];
         for (int d = axis + 1; d < ndim; ++d) a.inner *= (size_t)dims[d];
@@ -1812,10 +1822,18 @@ int sdc_transfer_apply(void* stream, int ndim, int n_out, int n_in, int width, c
         a.out = pass == ndim - 1 ? out : scratch[pass & 1];
         const size_t total = a.outer * (size_t)n_out * a.inner;
         const size_t in_total = a.outer * (size_t)n_in * a.inner;
-        if (total < 0xffffffffull && in_total < 0xffffffffull)
-            hipLaunchKernelGGL(k_xfer_axis<unsigned>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, a);
-        else
-            hipLaunchKernelGGL(k_xfer_axis<size_t>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, a);
+        const bool small = total < 0xffffffffull && in_total < 0xffffffffull;
+        // contiguous axis, or coarsening (neighbouring output rows share at most one input row): one output per
+        // thread; refining along a strided axis: a thread walks SDC_XFER_CH output rows and re-reads from L1
+        if (a.inner == 1 || n_out <= n_in) {
+            if (small) hipLaunchKernelGGL((k_xfer_axis<unsigned, 1>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, a);
+            else hipLaunchKernelGGL((k_xfer_axis<size_t, 1>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, a);
+        } else {
+            constexpr int CH = SDC_XFER_CH;
+            const size_t threads = a.outer * (size_t)((n_out + CH - 1) / CH) * a.inner;
+            if (small) hipLaunchKernelGGL((k_xfer_axis<unsigned, CH>), dim3(grid_for(threads, 256)), dim3(256), 0, (hipStream_t)stream, a);
+            else hipLaunchKernelGGL((k_xfer_axis<size_t, CH>), dim3(grid_for(threads, 256)), dim3(256), 0, (hipStream_t)stream, a);
+        }
         dims[axis] = n_out;
         src = a.out;
     }

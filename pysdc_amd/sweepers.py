@@ -225,7 +225,13 @@ class Sweeper:
     def _integrate_fused(self):
         L = self.level
         P = L.prob
-        me = [P.dtype_u(P.init, val=0.0) for _ in range(self.coll.num_nodes)]
+        import torch
+        from pysdc_amd.hip_mesh import hip_mesh
+
+        # one buffer, the M integrals one behind the other (a transfer class can then restrict them together)
+        M, size = self.coll.num_nodes, L.engine.N
+        buf = torch.empty(M * size, dtype=torch.float64, device='cuda')
+        me = [hip_mesh.view(buf.data_ptr() + 8 * k * size, L._field_shape(), keep=buf) for k in range(M)]
         L.engine.integrate(L.dt, [x.ptr for x in me])
         return me
 

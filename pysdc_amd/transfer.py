@@ -72,7 +72,8 @@ class BaseTransfer:
 
     def _to_coarse_nodes(self, fine_fields):
         """space restriction of every fine-node field followed by the node restriction Rcoll."""
-        in_space = [self.space_transfer.restrict(x) for x in fine_fields]
+        many = getattr(self.space_transfer, 'restrict_many', None)
+        in_space = many(list(fine_fields)) if many else [self.space_transfer.restrict(x) for x in fine_fields]
         return [self._mix(self.Rcoll[n], in_space) for n in range(self.coarse.sweep.coll.num_nodes)]
 
     def restrict(self):
@@ -109,6 +110,17 @@ class BaseTransfer:
 
     def _coarse_correction(self, new_fields, old_fields):
         Mc = self.coarse.sweep.coll.num_nodes
+        many = getattr(self.space_transfer, 'prolong_many', None)
+        if many and all(type(new_fields[n]) is hip_mesh for n in range(1, Mc + 1)):
+            # the differences go into one buffer, one behind the other, so that they are prolonged together
+            import torch
+
+            size, shape = new_fields[1].size, new_fields[1].shape
+            buf = torch.empty(Mc * size, dtype=torch.float64, device='cuda')
+            diffs = [hip_mesh.view(buf.data_ptr() + 8 * k * size, shape, keep=buf) for k in range(Mc)]
+            for k in range(Mc):
+                diffs[k]._axpby(1.0, new_fields[k + 1], -1.0, old_fields[k + 1], diffs[k])
+            return many(diffs)
         return [self.space_transfer.prolong(new_fields[n] - old_fields[n]) for n in range(1, Mc + 1)]
 
     def prolong(self):
@@ -294,6 +306,33 @@ class mesh_to_mesh:
             fine[:] = coarse
         else:
             self._apply('P', coarse, fine)
+
+    def _many(self, key, fields, out_init):
+        """several plain fields that lie one behind the other in memory (slab views U[1..M], a batch of integrals): one
+        launch per axis for all of them; the results are views into one buffer.  None when that does not apply."""
+        if self.identity or len(fields) < 2 or not all(type(f) is hip_mesh for f in fields):
+            return None
+        step = 8 * fields[0].size
+        ptrs = [f.ptr for f in fields]
+        if any(p != ptrs[0] + k * step for k, p in enumerate(ptrs)):
+            return None
+        import torch
+
+        idx, w, width, (n_out, n_in) = self._tab[key]
+        shape = out_init[0] if not np.isscalar(out_init[0]) else (int(out_init[0]),)
+        osize = int(np.prod(shape))
+        buf = torch.empty(len(fields) * osize, dtype=torch.float64, device='cuda')
+        Lb.check(Lb.load().sdc_transfer_apply_batch(None, len(fields), self.ndim, n_out, n_in, width, idx.data_ptr(),
+                                                    w.data_ptr(), ptrs[0], buf.data_ptr()), None)
+        return [hip_mesh.view(buf.data_ptr() + 8 * k * osize, shape, keep=buf) for k in range(len(fields))]
+
+    def restrict_many(self, fields):
+        out = self._many('R', fields, self.coarse_prob.init)
+        return out if out is not None else [self.restrict(f) for f in fields]
+
+    def prolong_many(self, fields):
+        out = self._many('P', fields, self.fine_prob.init)
+        return out if out is not None else [self.prolong(f) for f in fields]
 
     def restrict(self, F):
         """TransferMesh.py:148-183."""
