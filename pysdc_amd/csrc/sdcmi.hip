@@ -32,6 +32,10 @@
 // host side
 // ------------------------------------------------------------------------------------------------------
 static int ensure_work(sdc_ctx* c);
+// the FFT kernels transform lines of length 2^p <= 1024 (2048 in 1-D)
+static inline bool fourier_ok(const sdc_ctx* c) {
+    return is_pow2(c->n) && (c->n <= 1024 || (c->n == 2048 && c->ndim == 1));
+}
 static inline int grid_for(size_t work, int block) {
     size_t g = (work + block - 1) / block;
     if (g > 4096) g = 4096;
@@ -1327,7 +1331,7 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
     if (c->expl_kind == SDC_EXPL_STENCIL && !c->have_stencil[1])
         return fail(c, SDC_ERR_STATE, "explicit operator not set (sdc_set_stencil which=1)");
     if (c->expl_kind == SDC_EXPL_REACTION || c->spectral_op) return sweep_nodewise(c, dt);
-    if (c->solver_kind == 1) return sweep_nodewise(c, dt, true);
+    if (c->solver_kind == 1 || !fourier_ok(c)) return sweep_nodewise(c, dt, true);
     const bool gather_once = c->force_gather;
     c->force_gather = false;
     if (c->reuse && !gather_once && !c->tau_active && c->expl_kind != SDC_EXPL_FORCING && c->have_stencil[0] &&
@@ -1535,6 +1539,31 @@ int sdc_solve(sdc_ctx* c, const double* rhs, double factor, const double* guess,
         return vdp_check_failures(c);
     }
     if (c->solver_kind == 1 && !c->spectral_op) return cg_solve(c, rhs, factor, guess, out);
+    if (!fourier_ok(c) && !c->spectral_op) {
+        // a grid the FFT kernels do not transform (n not a power of two, or too long): conjugate gradients to
+        // round-off instead of the exact solve - for symmetric operators only
+        const Stencil& s = c->st[0];
+        bool symmetric = c->have_stencil[0];
+        for (int a = 0; a < s.npts && symmetric; ++a) {
+            bool found = false;
+            for (int b = 0; b < s.npts; ++b)
+                if (s.off[b] == -s.off[a] && s.w[b] == s.w[a]) found = true;
+            symmetric = found;
+        }
+        if (!symmetric)
+            return fail(c, SDC_ERR_UNSUPPORTED,
+                        "n = %d is not a power of two (<= 1024; 2048 in 1-D) and the operator is not symmetric: no solver", c->n);
+        const double keep_rtol = c->cg_rtol;
+        const int keep_maxiter = c->cg_maxiter;
+        const unsigned long long keep_iters = c->cg_iters;
+        c->cg_rtol = 1e-14;
+        c->cg_maxiter = 100000;
+        int rcg = cg_solve(c, rhs, factor, guess, out);
+        c->cg_rtol = keep_rtol;
+        c->cg_maxiter = keep_maxiter;
+        c->cg_iters = keep_iters;  // not the user's solver: nothing to count
+        return rcg;
+    }
     FieldPtrs p;
     memset(&p, 0, sizeof p);
     ZArgs z;
