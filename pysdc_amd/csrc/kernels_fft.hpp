@@ -183,6 +183,7 @@ struct ZArgs {
     double invN;
     int nf, ndim, coupled;
     int apply;  // 1: multiply by the symbol (operator application) instead of dividing by 1 - alpha*symbol
+    int dup;    // 1: two fields out of ONE input (field 0): the solution and the operator applied to it
 };
 
 // forward FFT along the contiguous axis, node-coupled implicit solve in Fourier space, inverse FFT.
@@ -208,11 +209,12 @@ __global__ __launch_bounds__(z_lines_per_block<N>() * (N / fft_elems(N)) * MAXM,
     const size_t line = (size_t)blockIdx.x * LPB + l;
     const bool ok = line < nlines;
     cd* __restrict__ Wl = a.W + f * a.fstride + line * N;
+    const cd* __restrict__ Win = a.dup ? a.W + line * N : Wl;  // dup: every field starts from field 0's line
     cd r[E];
 #pragma unroll
-    for (int i = 0; i < E; ++i) r[i] = ok ? Wl[j + i * P] : cd{0.0, 0.0};
+    for (int i = 0; i < E; ++i) r[i] = ok ? Win[j + i * P] : cd{0.0, 0.0};
     fft_line<N, -1, LAY, (N / fft_elems(N)) <= 64>(r, j, c, lds, a.tw);
-    __syncthreads();  // the solve buffer aliases other waves' exchange planes
+    __syncthreads();  // the solve buffer aliases other waves' exchange planes (and all loads of a shared line are done)
 
     cd* buf = reinterpret_cast<cd*>(lds);  // [column][CH]
     const int nthreads = a.nf * LPB * P;
@@ -250,7 +252,8 @@ __global__ __launch_bounds__(z_lines_per_block<N>() * (N / fft_elems(N)) * MAXM,
                         }
                     }
                     const double al = a.alpha[m];
-                    u[m] = a.apply ? cmul(acc, lam) : cmul(acc, cinv_fast(cd{1.0 - al * lam.x, -al * lam.y}));
+                    if (a.dup && m == 1) u[m] = cmul(u[0], lam);  // the operator applied to the solution
+                    else u[m] = a.apply ? cmul(acc, lam) : cmul(acc, cinv_fast(cd{1.0 - al * lam.x, -al * lam.y}));
                     buf[(m * LPB + ll) * CH + kk] = cscale(u[m], a.invN);
                 }
             }

@@ -211,22 +211,23 @@ static int fft_pipeline_n(sdc_ctx* c, int nf, const FieldPtrs& p, ZArgs& z) {
     z.nf = nf;
     z.ndim = c->ndim;
     z.invN = 1.0 / (double)c->N;
+    const int nfi = z.dup ? 1 : nf;  // fields that are transformed forward
     size_t lines;
     if (c->ndim == 1) {
-        LaunchTimer lt(c, pname("promote", nf));
-        hipLaunchKernelGGL(k_promote, dim3(grid_for(c->N, 256), nf), dim3(256), 0, c->stream, p, c->W, c->N);
+        LaunchTimer lt(c, pname("promote", nfi));
+        hipLaunchKernelGGL(k_promote, dim3(grid_for(c->N, 256), nfi), dim3(256), 0, c->stream, p, c->W, c->N);
         lines = 1;
     } else {
         const int rest = (int)(c->N / n);
         const int tiles = (rest / 2 + T - 1) / T;
         {
-            LaunchTimer lt(c, pname("fft_x_fwd", nf));
-            hipLaunchKernelGGL((k_fftx_fwd<N, T>), dim3(tiles, nf), dim3(P * T), lds_str, c->stream, p, c->W, c->Nc,
+            LaunchTimer lt(c, pname("fft_x_fwd", nfi));
+            hipLaunchKernelGGL((k_fftx_fwd<N, T>), dim3(tiles, nfi), dim3(P * T), lds_str, c->stream, p, c->W, c->Nc,
                                rest, c->tw);
         }
         if (c->ndim == 3) {
-            LaunchTimer lt(c, pname("fft_y_fwd", nf));
-            hipLaunchKernelGGL((k_ffty<N, T, -1>), dim3((n + T - 1) / T, n / 2 + 1, nf), dim3(P * T), lds_str,
+            LaunchTimer lt(c, pname("fft_y_fwd", nfi));
+            hipLaunchKernelGGL((k_ffty<N, T, -1>), dim3((n + T - 1) / T, n / 2 + 1, nfi), dim3(P * T), lds_str,
                                c->stream, c->W, c->Nc, c->tw);
         }
         lines = (size_t)(n / 2 + 1) * (c->ndim == 3 ? n : 1);
@@ -1269,6 +1270,31 @@ static int sweep_nodewise(sdc_ctx* c, double dt, bool keep_guess = false) {
             }
         }
         const double alpha = dt * c->QI[m + 1][m + 1];
+        if (c->spectral_op && !keep_guess && c->solver_kind == 0 && c->M >= 2) {  // (two work spectra needed)
+            // operator given by its symbol: the solve and the evaluation of the implicit part at the new value share
+            // one forward transform (u_hat and symbol * u_hat leave the spectral pass together)
+            FieldPtrs p2;
+            memset(&p2, 0, sizeof p2);
+            ZArgs z2;
+            memset(&z2, 0, sizeof z2);
+            p2.in[0] = rhs;
+            p2.out[0] = um;
+            p2.out[1] = c->F + ((size_t)(m + 1) * c->ncomp) * c->N;
+            z2.alpha[0] = alpha;
+            z2.dup = 1;
+            rc = fft_pipeline(c, 2, p2, z2);
+            if (rc != SDC_OK) return rc;
+            if (imex) {
+                if (c->expl_kind != SDC_EXPL_REACTION)
+                    return fail(c, SDC_ERR_UNSUPPORTED, "explicit part of a symbol-only operator must be a reaction term");
+                LaunchTimer lt(c, "reaction");
+                hipLaunchKernelGGL(k_reaction, dim3(grid_for(c->N, 256)), dim3(256), 0, c->stream, um,
+                                   c->F + ((size_t)(m + 1) * c->ncomp + 1) * c->N, c->N, c->react_kind, c->react_p0,
+                                   c->react_p1, c->react_nu);
+                HIPCHK(c, hipGetLastError());
+            }
+            continue;
+        }
         if (alpha != 0.0 || (keep_guess && imex)) {  // imex_1st_order always solves (imex_1st_order.py:98-103)
             rc = sdc_solve(c, rhs, alpha, um, um);
             if (rc != SDC_OK) return rc;
