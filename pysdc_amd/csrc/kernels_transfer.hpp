@@ -46,6 +46,39 @@ __global__ __launch_bounds__(256) void k_xfer_axis(XferArgs a) {
     }
 }
 
+// The same pass for a strided axis (inner >= 2, even) with the output row taken from the block index: row index,
+// table row and weights are wave-uniform (scalar loads), every thread moves two neighbouring q (16-byte accesses)
+// and CH consecutive output rows whose input rows overlap (refinement) are served by L1.
+//   grid.x covers inner / 2, grid.y = outer * ceil(n_out / CH)
+template <int CH>
+__global__ __launch_bounds__(256) void k_xfer_axis_rows(XferArgs a) {
+    const unsigned nch = (unsigned)(a.n_out + CH - 1) / CH;
+    const unsigned o = blockIdx.y / nch, i0 = (blockIdx.y - o * nch) * CH;
+    const size_t q2 = blockIdx.x * (size_t)blockDim.x + threadIdx.x;  // pair index along the contiguous direction
+    if (2 * q2 >= a.inner) return;
+    const double2* __restrict__ src = reinterpret_cast<const double2*>(a.in + ((size_t)o * a.n_in) * a.inner) + q2;
+    double2* __restrict__ dst = reinterpret_cast<double2*>(a.out + ((size_t)o * a.n_out) * a.inner) + q2;
+    const size_t row = a.inner >> 1;
+#pragma unroll
+    for (int r = 0; r < CH; ++r) {
+        const int i = (int)i0 + r;
+        if (i < a.n_out) {
+            const int* __restrict__ ix = a.idx + i * a.W;
+            const double* __restrict__ wx = a.w + i * a.W;
+            double2 acc = double2{0.0, 0.0};
+            for (int j = 0; j < a.W; ++j) {
+                const double wj = wx[j];
+                if (wj != 0.0) {
+                    const double2 v = src[(size_t)ix[j] * row];
+                    acc.x += wj * v.x;
+                    acc.y += wj * v.y;
+                }
+            }
+            dst[(size_t)i * row] = acc;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // Fourier prolongation (mesh_to_mesh_fft, TransferMesh_FFT.py:36-57; mesh_to_mesh_fft2d,
 // TransferMesh_FFT2D.py:58-77): the coarse spectrum is copied into the low modes of a fine spectrum.  The

@@ -1878,9 +1878,16 @@ int sdc_transfer_apply_batch(void* stream, int nfields, int ndim, int n_out, int
         const size_t total = a.outer * (size_t)n_out * a.inner;
         const size_t in_total = a.outer * (size_t)n_in * a.inner;
         const bool small = total < 0xffffffffull && in_total < 0xffffffffull;
-        // contiguous axis, or coarsening (neighbouring output rows share at most one input row): one output per
-        // thread; refining along a strided axis: a thread walks SDC_XFER_CH output rows and re-reads from L1
-        if (a.inner == 1 || n_out <= n_in) {
+        // strided axis: output row from the block index (uniform table loads), 16-byte accesses along the contiguous
+        // direction, a few consecutive output rows per block when refining (their input rows overlap: L1)
+        const bool refine = n_out > n_in;
+        const size_t rows_y = a.outer * (size_t)(refine ? (n_out + 3) / 4 : n_out);
+        const bool aligned = (((uintptr_t)a.in | (uintptr_t)a.out) & 15) == 0;
+        if (a.inner >= 2 && a.inner % 2 == 0 && rows_y <= 65535 && aligned) {
+            const dim3 grid((unsigned)((a.inner / 2 + 255) / 256), (unsigned)rows_y);
+            if (refine) hipLaunchKernelGGL((k_xfer_axis_rows<4>), grid, dim3(256), 0, (hipStream_t)stream, a);
+            else hipLaunchKernelGGL((k_xfer_axis_rows<1>), grid, dim3(256), 0, (hipStream_t)stream, a);
+        } else if (a.inner == 1 || !refine) {
             if (small) hipLaunchKernelGGL((k_xfer_axis<unsigned, 1>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, a);
             else hipLaunchKernelGGL((k_xfer_axis<size_t, 1>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, a);
         } else {
