@@ -172,3 +172,24 @@ class LogWork(Hooks):
             self.add_to_stats(L.prob.work_counters[key].niter - before, process=step.status.slot,
                               process_sweeper=L.sweep.rank, time=L.time + L.dt, level=L.level_index,
                               iter=step.status.iter, sweep=L.status.sweep, type=f'work_{key}')
+
+
+class LogSolution(Hooks):
+    """hooks/log_solution.py:9-38: the end value of every step as statistic ``u``.  ``L.uend`` is a view into the
+    level's slab (it changes with the next step), so an owning device copy is stored."""
+
+    def post_step(self, step, level_number):
+        L = step.levels[level_number]
+        L.sweep.compute_end_point()
+        self.add_to_stats(L.prob.dtype_u(L.uend), process=step.status.slot, time=L.time + L.dt, level=L.level_index,
+                          iter=step.status.iter, sweep=L.status.sweep, type='u')
+
+
+class LogSolutionAfterIteration(Hooks):
+    """hooks/log_solution.py:41-70: the same after every iteration."""
+
+    def post_iteration(self, step, level_number):
+        L = step.levels[level_number]
+        L.sweep.compute_end_point()
+        self.add_to_stats(L.prob.dtype_u(L.uend), process=step.status.slot, time=L.time + L.dt, level=L.level_index,
+                          iter=step.status.iter, sweep=L.status.sweep, type='u')

@@ -503,3 +503,25 @@ def test_grids_without_fft_fall_back_to_cg(nvars):
         L.sweep.compute_residual()
         O.compute_residual(OL)
         assert abs(L.status.residual - OL.status_residual) <= 1e-7 * OL.status_residual + 1e-12
+
+
+def test_log_solution_hook_keeps_owning_copies():
+    """hooks/log_solution.py: 'u' per step; the stored values must not change when the slab is reused."""
+    from pysdc_amd.controller import controller_nonMPI
+    from pysdc_amd.hooks import LogSolution
+    from pysdc_amd.problems import heatNd_unforced
+    from pysdc_amd.stats import get_sorted
+    from pysdc_amd.sweepers import generic_implicit
+
+    desc = dict(problem_class=heatNd_unforced, problem_params=dict(nvars=(32, 32), nu=0.1, freq=2),
+                sweeper_class=generic_implicit, sweeper_params=dict(num_nodes=3, quad_type='RADAU-RIGHT', QI='LU'),
+                level_params=dict(dt=0.01, restol=1e-10), step_params=dict(maxiter=20))
+    C = controller_nonMPI(1, dict(logger_level=40, hook_class=[LogSolution]), desc)
+    P = C.MS[0].levels[0].prob
+    uend, stats = C.run(P.u_exact(0.0), 0.0, 0.03)
+    us = get_sorted(stats, type='u', sortby='time')
+    assert [round(t, 10) for t, _ in us] == [0.01, 0.02, 0.03]
+    assert np.array_equal(us[-1][1].get(), uend.get())
+    for (t, u) in us:
+        assert rel_err(u.get(), P.u_exact(t).get()) < 1e-4
+    assert np.max(np.abs(us[0][1].get() - us[1][1].get())) > 0
