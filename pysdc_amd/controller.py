@@ -353,8 +353,9 @@ class controller_dist(_ControllerBase):
     device.  ``description['step_class']`` may replace the Step implementation (CPU tests use an
     oracle-backed step under gloo)."""
 
-    def __init__(self, controller_params, description, comm=None):
-        import torch.distributed as dist
+    def __init__(self, controller_params, description, comm=None, dist=None):
+        if dist is None:  # anything with torch.distributed's surface will do (the tests drive several ranks on ONE
+            import torch.distributed as dist  # GPU through an in-process stand-in)
 
         super().__init__(controller_params, description)
         self.dist = dist
@@ -466,7 +467,7 @@ class controller_dist(_ControllerBase):
                 continue
             if self.rank == root:
                 uend[:] = S.levels[0].uend
-            uend.bcast(root=root, comm=self.comm)
+            self.dist.broadcast(uend.as_torch(), src=root, group=self.comm)
             active = time < Tend - eps10
             num_active = self._all_sum(active)
             if num_active > 0:

@@ -216,3 +216,124 @@ def test_allencahn_3d_vs_oracle():
         assert rel_err(f.expl.get(), fo[1]) < 1e-13
         sol = P.solve_system(u, 1e-3, u, 0.0)
         assert rel_err(sol.get(), Po.solve_system(Po.u_exact(0.0), 1e-3, None, 0.0)) < 1e-13
+
+
+def _rank_thread(world, rank, name, fname, out, errors):
+    import traceback
+
+    from tests import _fake_dist as FD
+
+    try:
+        FD.bind(world, rank)
+        from pysdc_amd.controller import controller_dist
+        from pysdc_amd.stats import get_sorted
+        from tests.test_gpu_plugin import description_from
+
+        case = load_cases(fname)[name]
+        meta = case['meta']
+        C = controller_dist(dict(logger_level=40, **meta['controller_params']), description_from(meta), dist=FD)
+        P = C.S.levels[0].prob
+        u0 = P.u_init
+        u0[:] = case['u0']
+        uend, stats = C.run(u0, meta['t0'], meta['Tend'])
+        niter = get_sorted(stats, type='niter', sortby='time')
+        out[rank] = dict(uend=uend.get(), t=[t for t, _ in niter], n=[v for _, v in niter], two_hop=C.two_hop_calls,
+                         overlap=C._overlap)
+    except Exception:  # noqa: BLE001
+        errors.append(traceback.format_exc())
+        try:
+            world.barrier.abort()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+@pytest.mark.parametrize('name,fname,size', [('fixedK_2d_P4', 'runs_relay.npz', 4), ('fixedK_2d_P3', 'runs_relay.npz', 3),
+                                             ('alltodone_2d_P4', 'runs_relay.npz', 4), ('fixedK_2d_P4_tail', 'runs_relay.npz', 4),
+                                             ('mssdc_P2_jac', 'runs.npz', 2), ('mssdc_P2_gs', 'runs.npz', 2),
+                                             ('mssdc_P4_jac', 'runs.npz', 4), ('fixedK_3d_P2', 'runs.npz', 2)])
+def test_time_parallel_controller_on_device_levels(name, fname, size):
+    """controller_dist with DEVICE levels and several ranks on one GPU: the ranks are threads, torch.distributed is
+    replaced by an in-process stand-in (tests/_fake_dist.py), everything else - early end value, hand-over posted on
+    a side stream, two-hop relay, replace_u0 with kept residual fields, deferred f[0], advance - is the code that
+    runs over RCCL.  Against golden serial runs of the reference."""
+    import threading
+
+    from tests import _fake_dist as FD
+
+    case = load_cases(fname)[name]
+    world = FD.World(size)
+    out, errors = {}, []
+    threads = [threading.Thread(target=_rank_thread, args=(world, r, name, fname, out, errors)) for r in range(size)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors[0]
+    assert len(out) == size
+    times = np.concatenate([out[r]['t'] for r in range(size)])
+    niter = np.concatenate([out[r]['n'] for r in range(size)])
+    order = np.argsort(times)
+    assert list(niter[order]) == list(case['niter'])
+    np.testing.assert_allclose(times[order], case['niter_t'], rtol=0, atol=1e-14)
+    for r in range(size):
+        assert rel_err(out[r]['uend'], case['uend']) < TOL
+    if name.startswith(('fixedK_2d', 'alltodone')):
+        assert all(out[r]['overlap'] for r in range(size))
+        if size > 2:
+            assert all(out[r]['two_hop'] > 0 for r in range(size))
+
+
+def test_time_parallel_controller_64cubed_matches_serial_emulation():
+    """three ranks on 64^3 (the fused spectral sweep kernel, norm passes, kept residual fields) through
+    controller_dist with the in-process stand-in, against controller_nonMPI emulating the three processes."""
+    import threading
+
+    from pysdc_amd.controller import controller_nonMPI
+    from pysdc_amd.stats import get_sorted
+    from tests import _fake_dist as FD
+
+    meta = dict(prob='heat_unforced', prob_params=dict(nvars=[64, 64, 64], nu=0.1, freq=2), sweeper='generic_implicit',
+                sweeper_params=dict(num_nodes=3, quad_type='RADAU-RIGHT', QI='IE'), level_params=dict(dt=2e-3, restol=-1),
+                maxiter=3, controller_params={}, t0=0.0, Tend=1.2e-2)
+    from pysdc_amd.synth import init_field
+    from tests.test_gpu_plugin import description_from
+
+    u0h = init_field((64, 64, 64), 2, 1e-2, 3)
+    C = controller_nonMPI(3, dict(logger_level=40), description_from(meta))
+    P = C.MS[0].levels[0].prob
+    u0 = P.u_init
+    u0[:] = u0h
+    ref, rstats = C.run(u0, meta['t0'], meta['Tend'])
+    ref = ref.get()
+    world = FD.World(3)
+    out, errors = {}, []
+
+    def rank_main(rank):
+        import traceback
+
+        try:
+            FD.bind(world, rank)
+            from pysdc_amd.controller import controller_dist
+
+            Cd = controller_dist(dict(logger_level=40), description_from(meta), dist=FD)
+            Pd = Cd.S.levels[0].prob
+            v = Pd.u_init
+            v[:] = u0h
+            uend, stats = Cd.run(v, meta['t0'], meta['Tend'])
+            out[rank] = (uend.get(), Cd.two_hop_calls, Cd._overlap)
+        except Exception:  # noqa: BLE001
+            errors.append(traceback.format_exc())
+            try:
+                world.barrier.abort()
+            except Exception:  # noqa: BLE001
+                pass
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors[0]
+    for r in range(3):
+        assert rel_err(out[r][0], ref) < 1e-12
+        assert out[r][1] > 0 and out[r][2]
