@@ -156,7 +156,8 @@ def main():
         if args.n is None:
             # 1024^3 with M = 5 needs ~26 fields of 8.6 GB (slabs, work + cached spectra, in/out buffers);
             # fall back to the largest configuration that fits if this GPU cannot hold it
-            need = 26.5 * 8.0 * n**3
+            # (time-parallel runs add an inbox, the relay staging and a spare work spectrum)
+            need = (26.5 if world == 1 else 29.5) * 8.0 * n**3
             free = torch.cuda.mem_get_info()[0]
             if free < need:
                 n = 512
