@@ -488,3 +488,50 @@ def test_deferred_state_machine_random_walk(prob, seed):
     close(a.download_f(), b.download_f(), trace)
     for e in engines:
         e.close()
+
+
+@pytest.mark.parametrize('n', [512, 1024])
+def test_fourier_space_steps_fullsize(n):
+    """BASELINE-size run of the bench's data flow - sweeps that never leave Fourier space, residual norms from the
+    residual's spectrum, end value from the last node only, hand-over with sdc_advance - on an eigenmode of the
+    discrete operator, where every node value, residual and end value is a known multiple of u0 (scalar SDC)."""
+    if _free_gb() < 8e-9 * n**3 * 25 + 4:
+        pytest.skip('not enough HBM')
+    M, nu = 5, 0.1
+    dt = 1e-3 * (512.0 / n) ** 2
+    e = G.engine_for('heat_unforced', dict(nvars=(n, n, n), nu=nu), M)
+    c, qi = _coeffs(M, 'IE')
+    e.set_coeffs(c.Qmat, qi, None, c.nodes, c.weights)
+    freq = (C.c_int * 3)(2, 2, 2)
+    L.check(e.lib.sdc_init_field(e.ctx, e.ptr(L.SLOT_U, 0), freq, 0.0, 0), e.ctx)
+    e.invalidate_spectra(1)
+    dx = 1.0 / n
+    lam = 3.0 * nu * (2.0 * np.cos(2.0 * np.pi / n) - 2.0) / dx**2
+    K = 4
+    scal = _scalar_sweeps(lam, dt, c, qi, K)
+
+    def scalar_residual(u):
+        return max(abs(1.0 + dt * sum(c.Qmat[m, j] * lam * u[j] for j in range(1, M + 1)) - u[m]) for m in range(1, M + 1))
+
+    amp = 1.0
+    for step in range(2):
+        e.predict(0.0, dt)
+        res, _ = e.residual(dt)                              # spread predictor: from max|f(u0)|
+        assert abs(res - amp * scalar_residual(np.ones(M + 1))) < 1e-11
+        for k in range(K):
+            e.sweep(0.0, dt)
+            res, norms = e.residual(dt)
+            assert abs(res - amp * scalar_residual(scal[k])) < 1e-11, (step, k)
+        e.end_point(dt, False)
+        amp *= scal[-1][M]
+        assert abs(e.vec_amax(e.N, e.lib.sdc_slot_ptr(e.ctx, L.SLOT_UEND, 0, 0)) - abs(amp)) < 1e-12
+        if step == 0:
+            e.advance()
+    # the node fields of the last step, brought back to real space on demand: c_m * u0 of that step
+    tmp = e.ptr(L.SLOT_UEND)
+    for m in (1, M):
+        e.vec_axpby(e.N, 1.0, e.ptr(L.SLOT_U, m), -scal[-1][m], e.ptr(L.SLOT_U, 0), tmp)
+        assert e.vec_amax(e.N, tmp) < 1e-12
+        e.vec_axpby(e.N, 1.0, e.ptr(L.SLOT_F, m), -lam * scal[-1][m], e.ptr(L.SLOT_U, 0), tmp)
+        assert e.vec_amax(e.N, tmp) < 1e-10 * abs(lam)
+    e.close()
