@@ -264,6 +264,7 @@ def main():
         if args.workload == 'vdp':
             T = args.ntraj
             return {'vdp_sweep': 8.0 * T * (2 + 2 * M_ + 2 * M_ + 4 * M_), 'vdp_eval': 8.0 * T * 4,
+                    'vdp_sweep_lazyf': 8.0 * T * (2 + 2 * M_ + 2 * M_),   # u0 + old nodes in, new nodes out (F deferred)
                     'residual': 8.0 * 2 * T * (1 + 2 * M_), 'spread': 8.0 * 2 * T * (2 + 2 * M_),
                     'copy': 8.0 * 2 * T * 2}.get(name.split('[')[0])
         return _kernel_bytes(name, n_, M_, ncomp)
@@ -292,7 +293,7 @@ def main():
         in_sweep = ('gather', 'fft_x_fwd', 'fft_y_fwd', 'fft_z_fwd', 'fft_z_solve', 'spec_point', 'spec_point_res', 'spec_z', 'spec_z_res', 'spec_z_spread', 'spec_z_res_spread',
                     'fft_x_norm', 'fft_x_inv_norm',
                     'fft_z_inv', 'fft_y_inv',
-                    'fft_x_inv', 'stencil', 'stencil_res', 'res_stencil', 'vdp_sweep')
+                    'fft_x_inv', 'stencil', 'stencil_res', 'res_stencil', 'vdp_sweep', 'vdp_sweep_lazyf')
         sweep_ms = sum(v[0] for k, v in prof.items() if k.split('[')[0] in in_sweep) / max(1, sweeps_total // world)
         out = {
             'metric': {'heat': 'time-steps/s (HeatND 3-D FD, M=5, implicit SDC sweeps)',

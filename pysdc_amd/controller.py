@@ -444,7 +444,10 @@ class controller_dist(_ControllerBase):
             # u[0] is replaced between sweeps and the residual is asked for again: keep the residual fields;
             # produce the end value early so that it can be sent while the residual is reduced
             S.levels[0].engine.set_keep_residual_fields(True)
-            if len(S.levels) == 1 and not S.levels[0]._view_offset() and os.environ.get('PYSDC_AMD_OVERLAP', '1') != '0':
+            # (only in lock-step runs, where every posted message is completed before the next sweep: the sweep then
+            # overwrites UEND early, which must not happen under a send that is still in flight)
+            if (self._uniform(self.size) and not S.levels[0]._view_offset()
+                    and os.environ.get('PYSDC_AMD_OVERLAP', '1') != '0'):
                 S.levels[0].engine.set_early_end_point(True)
                 self._overlap = True
         if self._uend_buf is None:   # lives as long as the controller: allocating 8.6 GB per run costs ~0.25 s

@@ -43,7 +43,10 @@ __device__ __forceinline__ bool vdp_newton(double& x1, double& x2, double r0, do
 }
 
 // one generic_implicit sweep (generic_implicit.py:51-103) for every trajectory, node values on the slabs
-template <int M>
+// LAZYF: the right-hand sides of the old iterate are recomputed from its node values (read anyway as Newton
+// guesses; f costs five flops, the same formula gives the same bits) and the new ones are not stored - the F slab
+// is brought up to date on demand (sdc_materialize).  Halves the bytes of the sweep.
+template <int M, bool LAZYF>
 __global__ __launch_bounds__(256) void k_vdp_sweep(VdpSweepArgs a) {
 #pragma clang fp contract(off)
     unsigned long long newton = 0, rhs = 0, failed = 0;
@@ -57,8 +60,15 @@ __global__ __launch_bounds__(256) void k_vdp_sweep(VdpSweepArgs a) {
         double f0[M], f1[M], g0[M], g1[M], un0[M], un1[M];
 #pragma unroll
         for (int m = 0; m < M; ++m) {
-            f0[m] = a.F[(size_t)(m + 1) * N + i];
-            f1[m] = a.F[(size_t)(m + 1) * N + T + i];
+            if (LAZYF) {
+                un0[m] = a.U[(size_t)(m + 1) * N + i];  // old node value: guess below, f here
+                un1[m] = a.U[(size_t)(m + 1) * N + T + i];
+                f0[m] = un1[m];
+                f1[m] = mu * (1 - un0[m] * un0[m]) * un1[m] - un0[m];
+            } else {
+                f0[m] = a.F[(size_t)(m + 1) * N + i];
+                f1[m] = a.F[(size_t)(m + 1) * N + T + i];
+            }
         }
 #pragma unroll
         for (int m = 0; m < M; ++m) {
@@ -91,7 +101,8 @@ __global__ __launch_bounds__(256) void k_vdp_sweep(VdpSweepArgs a) {
                 }
             }
             const double h = dt * a.QI[m][m];
-            double x1 = a.U[(size_t)(m + 1) * N + i], x2 = a.U[(size_t)(m + 1) * N + T + i];
+            double x1 = LAZYF ? un0[m] : a.U[(size_t)(m + 1) * N + i];
+            double x2 = LAZYF ? un1[m] : a.U[(size_t)(m + 1) * N + T + i];
             if (h == 0.0) {
                 x1 = r0;
                 x2 = r1;
@@ -104,8 +115,10 @@ __global__ __launch_bounds__(256) void k_vdp_sweep(VdpSweepArgs a) {
             un1[m] = x2;
             f0[m] = x2;
             f1[m] = mu * (1 - x1 * x1) * x2 - x1;
-            a.F[(size_t)(m + 1) * N + i] = f0[m];
-            a.F[(size_t)(m + 1) * N + T + i] = f1[m];
+            if (!LAZYF) {
+                a.F[(size_t)(m + 1) * N + i] = f0[m];
+                a.F[(size_t)(m + 1) * N + T + i] = f1[m];
+            }
             rhs += 1;
         }
         if (a.norms) {
@@ -159,6 +172,7 @@ __global__ void k_vdp_eval(const double* __restrict__ u, double* __restrict__ f,
         f[T + i] = mu * (1 - x1 * x1) * x2 - x1;
         rhs += 1;
     }
+    if (!counters) return;  // storing deferred values: those evaluations were counted by the sweep
     for (int o = 32; o > 0; o >>= 1) rhs += __shfl_xor(rhs, o, 64);
     if ((threadIdx.x & 63) == 0 && rhs) atomicAdd(counters + 1, rhs);
 }

@@ -185,6 +185,15 @@ static int eval_nodes(sdc_ctx* c, double dt) {
 static int eval_nodes_plain(sdc_ctx* c) {
     const int M = c->M;
     c->f_pending = false;
+    if (c->kind == 1) {  // van der Pol ensemble: node by node, not counted again
+        for (int m = 1; m <= M; ++m) {
+            LaunchTimer lt(c, "vdp_eval");
+            hipLaunchKernelGGL(k_vdp_eval, dim3(grid_for(c->N / 2, 256)), dim3(256), 0, c->stream, c->U + (size_t)m * c->N,
+                               c->F + (size_t)m * c->N, c->N / 2, c->vdp_mu, (unsigned long long*)nullptr);
+        }
+        HIPCHK(c, hipGetLastError());
+        return SDC_OK;
+    }
     const double* in[MAXM];
     double* oi[MAXM];
     double* oe[MAXM];
@@ -1338,10 +1347,21 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
                 a.QI[m][j] = c->QI[m + 1][j + 1];
             }
         const int grid = grid_for(a.T, 256);
+        // F[1..M] = f(U[1..M]) unless somebody overwrote an F field (force_gather): recompute instead of reading,
+        // and leave the new values to sdc_materialize
+        if (c->force_gather) {
+            int rcm = materialize(c, false, true);
+            if (rcm != SDC_OK) return rcm;
+        }
+        const bool lazyf = c->deferred && !c->force_gather;
+        c->force_gather = false;
         {
-            LaunchTimer lt(c, "vdp_sweep");
-#define VCASE(MM) \
-    case MM: hipLaunchKernelGGL((k_vdp_sweep<MM>), dim3(grid), dim3(256), 0, c->stream, a); break;
+            LaunchTimer lt(c, lazyf ? "vdp_sweep_lazyf" : "vdp_sweep");
+#define VCASE(MM)                                                                                       \
+    case MM:                                                                                            \
+        if (lazyf) hipLaunchKernelGGL((k_vdp_sweep<MM, true>), dim3(grid), dim3(256), 0, c->stream, a); \
+        else hipLaunchKernelGGL((k_vdp_sweep<MM, false>), dim3(grid), dim3(256), 0, c->stream, a);      \
+        break;
             switch (M) {
                 VCASE(1) VCASE(2) VCASE(3) VCASE(4) VCASE(5) VCASE(6) VCASE(7) VCASE(8)
             }
@@ -1352,6 +1372,7 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
             c->res_valid = true;
             c->res_dt = dt;
         }
+        c->f_pending = lazyf;
         return vdp_check_failures(c);
     }
     if (c->expl_kind == SDC_EXPL_STENCIL && !c->have_stencil[1])

@@ -75,6 +75,7 @@ def _put(kind, tensor, dst):
         ev = torch.cuda.Event()
         ev.record()
     _local.world.chan(kind, _local.rank, dst).put((snap, ev))
+    return ev
 
 
 def _get(kind, tensor, src):
@@ -126,8 +127,9 @@ def batch_isend_irecv(ops):
     works = []
     for op in ops:
         if op.op is isend:
-            _put('data', op.tensor, op.peer)
-            works.append(_Work())
+            ev = _put('data', op.tensor, op.peer)
+            # waiting for a send = the waiting stream may not touch the buffer before the snapshot was taken
+            works.append(_Work((lambda e=ev: torch.cuda.current_stream().wait_event(e)) if ev is not None else None))
     for op in ops:
         if op.op is irecv:
             works.append(_Work(lambda t=op.tensor, s=op.peer: _get('data', t, s)))
