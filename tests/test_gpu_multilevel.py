@@ -231,7 +231,17 @@ def _rank_thread(world, rank, name, fname, out, errors):
 
         case = load_cases(fname)[name]
         meta = case['meta']
-        C = controller_dist(dict(logger_level=40, **meta['controller_params']), description_from(meta), dist=FD)
+        if 'iorder' in meta or meta.get('transfer'):      # multi-level description
+            desc = _description(meta, meta['level_params'], meta.get('iorder', 6), meta.get('rorder', 2))
+            if not meta.get('periodic', True):
+                desc['space_transfer_params']['periodic'] = False
+            if meta.get('transfer') == 'mesh_to_mesh_fft2d':
+                from pysdc_amd.transfer import mesh_to_mesh_fft2d
+
+                desc['space_transfer_class'], desc['space_transfer_params'] = mesh_to_mesh_fft2d, {}
+        else:
+            desc = description_from(meta)
+        C = controller_dist(dict(logger_level=40, **meta['controller_params']), desc, dist=FD)
         P = C.S.levels[0].prob
         u0 = P.u_init
         u0[:] = case['u0']
@@ -250,7 +260,14 @@ def _rank_thread(world, rank, name, fname, out, errors):
 @pytest.mark.parametrize('name,fname,size', [('fixedK_2d_P4', 'runs_relay.npz', 4), ('fixedK_2d_P3', 'runs_relay.npz', 3),
                                              ('alltodone_2d_P4', 'runs_relay.npz', 4), ('fixedK_2d_P4_tail', 'runs_relay.npz', 4),
                                              ('mssdc_P2_jac', 'runs.npz', 2), ('mssdc_P2_gs', 'runs.npz', 2),
-                                             ('mssdc_P4_jac', 'runs.npz', 4), ('fixedK_3d_P2', 'runs.npz', 2)])
+                                             ('mssdc_P4_jac', 'runs.npz', 4), ('fixedK_3d_P2', 'runs.npz', 2),
+                                             ('pfasst_heat2d_P2', 'runs_ml.npz', 2), ('pfasst_heat2d_P4', 'runs_ml.npz', 4),
+                                             ('pfasst_heat2d_P4_all_to_done', 'runs_ml.npz', 4),
+                                             ('pfasst_heat2d_M53_P2', 'runs_ml.npz', 2), ('pfasst_forced2d_P2', 'runs_ml.npz', 2),
+                                             ('pfasst_heat3d_P2', 'runs_ml.npz', 2), ('ac2d_pfasst_P2', 'runs_ac.npz', 2),
+                                             ('ac2d_fft2d_pfasst_P2', 'runs_ac_fft.npz', 2),
+                                             ('t6a_pfasst_P2', 'runs_ml_dirichlet.npz', 2),
+                                             ('t6a_pfasst_P4', 'runs_ml_dirichlet.npz', 4)])
 def test_time_parallel_controller_on_device_levels(name, fname, size):
     """controller_dist with DEVICE levels and several ranks on one GPU: the ranks are threads, torch.distributed is
     replaced by an in-process stand-in (tests/_fake_dist.py), everything else - early end value, hand-over posted on
