@@ -413,6 +413,12 @@ __global__ __launch_bounds__(256) void k_spec_residual(SpecArgs a, int n, size_t
 }
 
 
+#ifndef SDC_SPECZ_WAVES
+#define SDC_SPECZ_WAVES 4
+#endif
+#ifndef SDC_SPECZ_CH
+#define SDC_SPECZ_CH 512
+#endif
 // Spectral sweep fused with the first inverse pass.  One workgroup owns the same LPB lines of all NF fields
 // as k_fftz_plain does (column c = f*LPB + l on threads [c*P, (c+1)*P)), i.e. a contiguous span of LPB*N
 // modes per field.  Phase 1 treats that span pointwise (one thread = one mode, all NF node values in
@@ -423,10 +429,10 @@ __global__ __launch_bounds__(256) void k_spec_residual(SpecArgs a, int n, size_t
 // MODE 0: sweep, the new iterate is transformed; 1: sweep, the residual spectrum is transformed (RES);
 // 2: no sweep - residual spectrum of the CACHED iterate against the current S0 (u[0] was replaced).
 template <int N, int NF, int MODE, bool HASE>
-__global__ __launch_bounds__(z_lines_per_block<N>() * (N / fft_elems(N)) * NF, 4) void k_spec_z(SpecArgs a, unsigned nlines) {
+__global__ __launch_bounds__(z_lines_per_block<N>() * (N / fft_elems(N)) * NF, SDC_SPECZ_WAVES) void k_spec_z(SpecArgs a, unsigned nlines) {
     constexpr bool RES = MODE >= 1, UPD = MODE <= 1;
     constexpr int E = fft_elems(N), P = N / E, LPB = z_lines_per_block<N>();
-    constexpr int SPAN = LPB * N, CH = SPAN > 512 ? 512 : SPAN, NCH = SPAN / CH, NT = LPB * P * NF;
+    constexpr int SPAN = LPB * N, CH = SPAN > SDC_SPECZ_CH ? SDC_SPECZ_CH : SPAN, NCH = SPAN / CH, NT = LPB * P * NF;
     constexpr int ITS = (CH + NT - 1) / NT;  // modes per thread and chunk
     using LAY = LayContig<N>;
     extern __shared__ __attribute__((aligned(16))) double lds[];

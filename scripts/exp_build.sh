@@ -7,5 +7,5 @@ python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/exp_$TAG.jso
 python - <<PY
 import json
 d=json.load(open("gpurun_out/exp_$TAG.json"))
-print("$TAG", round(d["value"],3), "steps/s", round(d["sweep_kernels_ms"],2), "ms/sweep", {k.split('[')[0]:round(v["ms_per_launch"],2) for k,v in d["kernels"].items() if v["launches"]>=8})
+print("$TAG", round(d["value"],3), "steps/s", round(d["sweep_kernels_ms"],2), "ms/sweep", {k.split('[')[0]:round(v["ms_per_launch"],2) for k,v in d["kernels"].items() if v["launches"]>=6})
 PY
