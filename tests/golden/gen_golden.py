@@ -6,6 +6,12 @@ Usage (build container only; the reference never travels to the GPU box):
       PYTHONPATH=/root/repo/oracle/qmat_shim:/root/repo:/root/reference \
       python /root/repo/tests/golden/gen_golden.py
 
+That regenerates the sweep / run / multi-level / Allen-Cahn / dirichlet files.  The files added later have their
+own entry points, switched on by environment variables (or call the function after ``runpy.run_path``):
+GOLDEN_FFT=1 fft_transfer_main (transfer_fft.npz, runs_ac_fft.npz), GOLDEN_RELAY=1 relay_main (runs_relay.npz),
+GOLDEN_CG=1 cg_main (sweeps_cg.npz), GOLDEN_VDPJ=1 vdp_jacobian_main (vdp_jacobian.npz), GOLDEN_DML=1
+dirichlet_ml_main (transfer_dirichlet.npz, runs_ml_dirichlet.npz); GOLDEN_ML=0 skips the multi-level block.
+
 ``qmat`` (third-party, absent here) is replaced by oracle/qmat_shim, which forwards to
 pysdc_amd.coeffs; the coefficient matrices that were actually used are stored with every case.
 Outputs: tests/golden/*.npz (inputs + expected outputs only - data, no reference source).
