@@ -1,0 +1,22 @@
+"""More seeds for the two random-walk tests (deferred engine / level against eager ones): run on the GPU box,
+   python scripts/fuzz_more.py   -> prints every failing (problem, seed) and the number of failures."""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import tests.test_gpu_fullsize as T
+import tests.test_gpu_plugin as P
+bad = 0
+for seed in range(100, 260):
+    for prob in ('heat_unforced', 'advdiff'):
+        try:
+            T.test_deferred_state_machine_random_walk.__wrapped__(prob, seed) if hasattr(T.test_deferred_state_machine_random_walk, '__wrapped__') else T.test_deferred_state_machine_random_walk(prob, seed)
+        except Exception as e:
+            bad += 1
+            print('ENGINE FAIL', prob, seed, str(e)[:400])
+for seed in range(100, 200):
+    try:
+        P.test_plugin_random_walk_deferred_vs_eager(seed)
+    except Exception as e:
+        bad += 1
+        print('PLUGIN FAIL', seed, str(e)[:400])
+print('failures', bad)
