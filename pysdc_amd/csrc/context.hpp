@@ -48,6 +48,8 @@ struct sdc_ctx {
     bool deferred = true;
     bool spread_pending = false;  // U[1..M] = U[0], F[1..M] = F[0] not stored yet
     bool f_pending = false;       // F[1..M] = f(U[1..M]) not stored yet
+    cd* SP = nullptr;             // transform of the forcing profile (heatNd_forced), valid while specP_valid
+    bool specP_valid = false;
     int solver_kind = 0;          // 0: exact solve in Fourier space, 1: conjugate gradients (solver_type='CG')
     double cg_rtol = 1e-12;
     int cg_maxiter = 10000;

@@ -316,6 +316,10 @@ struct SpecArgs {
     double gI[MAXM][MAXM], gE[MAXM][MAXM];  // dt (Q - QI), dt (Q - QE), inner MxM blocks
     double cI[MAXM][MAXM], cE[MAXM][MAXM], alpha[MAXM];
     double rQ[MAXM][MAXM];  // dt Q, inner MxM block (RES)
+    // u-independent forcing profile(x) * g(t) (heatNd_forced): its contribution to the right-hand side of node m and to
+    // the residual is cP[m] * profile with cP[m] = dt sum_j Q[m][j] g(t_j); SP = transform of the profile, or null
+    const cd* SP;
+    double cP[MAXM];
     double invN;
     int nf, ndim, coupled, spread;
 };
@@ -340,12 +344,13 @@ __global__ __launch_bounds__(256) void k_spec_point(SpecArgs a, int n, size_t nm
             if (a.lamE) mu = cadd(mu, a.lamE[ln]);
         }
         const cd u0h = a.S0[g];
+        const cd ph = a.SP ? a.SP[g] : cd{0.0, 0.0};
         cd old[NF], u[NF];
 #pragma unroll
         for (int q = 0; q < NF; ++q) old[q] = a.spread ? u0h : a.S[q * a.fstride + g];
 #pragma unroll
         for (int m = 0; m < NF; ++m) {
-            cd acc = u0h;
+            cd acc = cd{fma(a.cP[m], ph.x, u0h.x), fma(a.cP[m], ph.y, u0h.y)};
 #pragma unroll
             for (int q = 0; q < NF; ++q) {
                 const double gi = a.gI[m][q], ge = a.gE[m][q];
@@ -367,6 +372,7 @@ __global__ __launch_bounds__(256) void k_spec_point(SpecArgs a, int n, size_t nm
 #pragma unroll
             for (int m = 0; m < NF; ++m) {
                 cd acc = csub(u0h, u[m]);
+                acc = cd{fma(a.cP[m], ph.x, acc.x), fma(a.cP[m], ph.y, acc.y)};
 #pragma unroll
                 for (int q = 0; q < NF; ++q) {
                     const double rq = a.rQ[m][q];
@@ -396,12 +402,14 @@ __global__ __launch_bounds__(256) void k_spec_residual(SpecArgs a, int n, size_t
             if (a.lamE) sym = cadd(sym, a.lamE[ln]);
         }
         const cd u0h = a.S0[g];
+        const cd ph = a.SP ? a.SP[g] : cd{0.0, 0.0};
         cd u[NF];
 #pragma unroll
         for (int q = 0; q < NF; ++q) u[q] = a.S[q * a.fstride + g];
 #pragma unroll
         for (int m = 0; m < NF; ++m) {
             cd acc = csub(u0h, u[m]);
+            acc = cd{fma(a.cP[m], ph.x, acc.x), fma(a.cP[m], ph.y, acc.y)};
 #pragma unroll
             for (int q = 0; q < NF; ++q) {
                 const double rq = a.rQ[m][q];
@@ -446,13 +454,15 @@ __global__ __launch_bounds__(z_lines_per_block<N>() * (N / fft_elems(N)) * NF, S
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
         // all loads of this chunk first: (NF + 1) * ITS independent 16-byte loads per thread in flight
-        cd in0[ITS], inq[ITS][NF];
+        cd in0[ITS], inq[ITS][NF], inp[ITS];
 #pragma unroll
         for (int it = 0; it < ITS; ++it) {
             const int k = threadIdx.x + it * NT;
             const size_t g = span0 + (size_t)ch * CH + k;
+            inp[it] = cd{0.0, 0.0};
             if (k < CH && g < nmodes) {
                 in0[it] = a.S0[g];
+                if (a.SP) inp[it] = a.SP[g];
                 if (!UPD || !a.spread) {
 #pragma unroll
                     for (int q = 0; q < NF; ++q) inq[it][q] = a.S[q * a.fstride + g];
@@ -486,7 +496,7 @@ __global__ __launch_bounds__(z_lines_per_block<N>() * (N / fft_elems(N)) * NF, S
                         u[m] = old[m];
                         continue;
                     }
-                    cd acc = u0h;
+                    cd acc = cd{fma(a.cP[m], inp[it].x, u0h.x), fma(a.cP[m], inp[it].y, u0h.y)};
 #pragma unroll
                     for (int q = 0; q < NF; ++q) {
                         const double gi = a.gI[m][q];
@@ -518,6 +528,7 @@ __global__ __launch_bounds__(z_lines_per_block<N>() * (N / fft_elems(N)) * NF, S
 #pragma unroll
                     for (int m = 0; m < NF; ++m) {
                         cd acc = csub(u0h, u[m]);
+                        acc = cd{fma(a.cP[m], inp[it].x, acc.x), fma(a.cP[m], inp[it].y, acc.y)};
 #pragma unroll
                         for (int q = 0; q < NF; ++q) {
                             const double rq = a.rQ[m][q];

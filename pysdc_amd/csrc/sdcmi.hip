@@ -201,10 +201,13 @@ static int eval_nodes_plain(sdc_ctx* c) {
     for (int m = 0; m < M; ++m) {
         in[m] = c->U + (size_t)(m + 1) * c->N;
         oi[m] = c->F + ((size_t)(m + 1) * c->ncomp) * c->N;
-        oe[m] = (c->ncomp == 2 && c->expl_kind == SDC_EXPL_STENCIL) ? oi[m] + c->N : nullptr;
+        // (forcing: the explicit part is profile * g(t_m) whatever u is - stored again because a 'copy' predictor
+        // leaves g(t_0) at every node, imex_1st_order.py:105 re-evaluates it)
+        const bool has_expl = c->expl_kind == SDC_EXPL_STENCIL || c->expl_kind == SDC_EXPL_FORCING;
+        oe[m] = (c->ncomp == 2 && has_expl) ? oi[m] + c->N : nullptr;
         g[m] = c->gvals[m + 1];
     }
-    return run_stencil(c, M, in, oi, c->expl_kind == SDC_EXPL_STENCIL ? oe : nullptr, g);
+    return run_stencil(c, M, in, oi, (c->expl_kind == SDC_EXPL_STENCIL || c->expl_kind == SDC_EXPL_FORCING) ? oe : nullptr, g);
 }
 
 template <int N>
@@ -523,6 +526,31 @@ static int spec_residual_n(sdc_ctx* c, SpecArgs& a, unsigned long long* norms) {
     return inverse_passes_n<N>(c, nf, c->W, c->W, p, norms, a.invN);
 }
 static int fwd_transform(sdc_ctx* c, int nf, const FieldPtrs& p, cd* dst, size_t fstride);
+// u-independent forcing profile * g(t): SP = transform of the profile (cached), cP[m] = dt sum_j Q[m][j] g(t_j)
+static int forcing_spectrum(sdc_ctx* c, SpecArgs& a, double dt) {
+    if (c->expl_kind != SDC_EXPL_FORCING) return SDC_OK;
+    if (!c->profile) return fail(c, SDC_ERR_STATE, "forcing profile not set");
+    if (!c->SP) {
+        HIPCHK(c, hipMalloc((void**)&c->SP, sizeof(cd) * c->Nc));
+        c->bytes += sizeof(cd) * c->Nc;
+        c->specP_valid = false;
+    }
+    if (!c->specP_valid) {
+        FieldPtrs pp;
+        memset(&pp, 0, sizeof pp);
+        pp.in[0] = c->profile;
+        int rc = fwd_transform(c, 1, pp, c->SP, 0);
+        if (rc != SDC_OK) return rc;
+        c->specP_valid = true;
+    }
+    a.SP = c->SP;
+    for (int m = 0; m < c->M; ++m) {
+        double s = 0.0;
+        for (int j = 0; j < c->M; ++j) s += dt * c->Q[m + 1][j + 1] * c->gvals[j + 1];
+        a.cP[m] = s;
+    }
+    return SDC_OK;
+}
 static int spec_residual(sdc_ctx* c, double dt, unsigned long long* norms) {
     int rw = ensure_work(c);
     if (rw != SDC_OK) return rw;
@@ -536,6 +564,8 @@ static int spec_residual(sdc_ctx* c, double dt, unsigned long long* norms) {
     }
     SpecArgs a;
     memset(&a, 0, sizeof a);
+    int rcf = forcing_spectrum(c, a, dt);
+    if (rcf != SDC_OK) return rcf;
     a.S = c->S;
     a.fstride = c->Nc;
     a.S0 = c->S0;
@@ -756,6 +786,7 @@ int sdc_ctx_destroy(sdc_ctx* c) {
     (void)hipFree(c->W);
     (void)hipFree(c->W2);
     (void)hipFree(c->cgw);
+    (void)hipFree(c->SP);
     if (c->uend_ev) (void)hipEventDestroy(c->uend_ev);
     (void)hipFree(c->S);
     (void)hipFree(c->S0);
@@ -899,6 +930,7 @@ int sdc_set_forcing_profile(sdc_ctx* c, const double* host_profile) {
     HIPCHK(c, hipMemcpyAsync(c->profile, host_profile, c->N * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->expl_kind = SDC_EXPL_FORCING;
+    c->specP_valid = false;
     return SDC_OK;
 }
 
@@ -1047,6 +1079,9 @@ int sdc_invalidate_spectra(sdc_ctx* c, int which) {
     if (which & 2) {
         c->spec_valid = false;
         c->spec_spread = false;
+        // a node value was replaced but not (yet) its right-hand side: the reference's next sweep integrates the
+        // stored f (generic_implicit.py:75), so gather on the F slab instead of assuming F = f(U)
+        c->force_gather = true;
     }
     if (which & 4) c->force_gather = true;  // some F[m >= 1] no longer equals f(U[m]): gather on F itself
     if (which & 8) c->uend_gen = -1;        // UEND was overwritten
@@ -1215,6 +1250,9 @@ int sdc_predict(sdc_ctx* c, double t, double dt, int guess, double fill_u, doubl
     c->unlocked = true;
     c->res_valid = false;
     c->res_spread = spread_res;
+    // forcing: the transformed sweep takes the explicit values of node j to be profile * g(t_j), which the stored ones
+    // are after a spread predictor or any sweep - not after 'copy' / 'zero' / constant fills
+    if (c->expl_kind == SDC_EXPL_FORCING && guess != SDC_GUESS_SPREAD) c->force_gather = true;
     c->spec_valid = false;
     c->spec_spread = (guess == SDC_GUESS_SPREAD || guess == SDC_GUESS_COPY);  // all nodes equal U[0]
     return SDC_OK;
@@ -1381,7 +1419,7 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
     if (c->solver_kind == 1 || !fourier_ok(c)) return sweep_nodewise(c, dt, true);
     const bool gather_once = c->force_gather;
     c->force_gather = false;
-    if (c->reuse && !gather_once && !c->tau_active && c->expl_kind != SDC_EXPL_FORCING && c->have_stencil[0] &&
+    if (c->reuse && !gather_once && !c->tau_active && c->have_stencil[0] &&
         is_pow2(c->n) && (c->n <= 1024 || (c->n == 2048 && c->ndim == 1))) {
         // ---- spectral reuse: f is linear in u, so the gather happens on the cached transforms ----
         if (!c->S) {
@@ -1409,6 +1447,8 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
         }
         SpecArgs a;
         memset(&a, 0, sizeof a);
+        int rcf = forcing_spectrum(c, a, dt);
+        if (rcf != SDC_OK) return rcf;
         a.S = c->S;
         a.fstride = c->Nc;
         a.S0 = c->S0;

@@ -7,7 +7,7 @@ import tests.test_gpu_fullsize as T
 import tests.test_gpu_plugin as P
 bad = 0
 for seed in range(100, 260):
-    for prob in ('heat_unforced', 'advdiff'):
+    for prob in ('heat_unforced', 'advdiff', 'heat_forced'):
         try:
             T.test_deferred_state_machine_random_walk.__wrapped__(prob, seed) if hasattr(T.test_deferred_state_machine_random_walk, '__wrapped__') else T.test_deferred_state_machine_random_walk(prob, seed)
         except Exception as e:

@@ -377,7 +377,7 @@ def test_early_end_point_and_stream_wait():
 
 
 @pytest.mark.parametrize('seed', list(range(12)))
-@pytest.mark.parametrize('prob', ['heat_unforced', 'advdiff'])
+@pytest.mark.parametrize('prob', ['heat_unforced', 'advdiff', 'heat_forced'])
 def test_deferred_state_machine_random_walk(prob, seed):
     """random sequences of C-ABI calls on two engines - every deferral switched on (deferred node fields, kept
     residual fields, early end value) against everything eager: whatever is read back must agree."""
@@ -387,7 +387,7 @@ def test_deferred_state_machine_random_walk(prob, seed):
     dt = 0.05
     c, qi = _coeffs(M, 'LU')
     qe = None
-    if prob == 'advdiff':
+    if prob in ('advdiff', 'heat_forced'):
         from pysdc_amd.coeffs import QDELTA_GENERATORS
 
         qe = np.zeros_like(c.Qmat)
@@ -396,6 +396,9 @@ def test_deferred_state_machine_random_walk(prob, seed):
     for lazy in (True, False):
         e = G.engine_for(prob, dict(nvars=(n, n, n), nu=0.1), M)
         e.set_coeffs(c.Qmat, qi, qe, c.nodes, c.weights)
+        if prob == 'heat_forced':       # time-dependent factor of the forcing at t0 and the node times
+            e.set_forcing_values([np.cos(0.3 * k) for k in range(M + 1)])
+            e.set_spectral_reuse(lazy)  # eager engine: the general data flow (gather on the F slab)
         e.set_deferred(lazy)
         e.set_keep_residual_fields(lazy and seed % 2 == 0)
         e.set_early_end_point(lazy and seed % 2 == 1)
