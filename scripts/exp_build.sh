@@ -1,11 +1,12 @@
 #!/bin/bash
-# rebuild the library on the GPU box with experiment macros and run a short bench: scripts/exp_build.sh TAG [-D...]
-TAG=$1; shift
+# rebuild the library on the GPU box with experiment macros and run a short bench:
+#   scripts/exp_build.sh TAG N [-D...]
+TAG=$1; N=$2; shift; shift
 cd $GRAFT_REPO_ROOT
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC "$@" -o pysdc_amd/libsdcmi.so pysdc_amd/csrc/sdcmi.hip 2>/dev/null || { echo "build failed $TAG"; exit 1; }
-python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/exp_$TAG.json 2>/dev/null
+python bench.py --n $N --steps 4 --warmup 1 --no-cpu-baseline > gpurun_out/exp_$TAG.json 2>/dev/null
 python - <<PY
 import json
 d=json.load(open("gpurun_out/exp_$TAG.json"))
-print("$TAG", round(d["value"],3), "steps/s", round(d["sweep_kernels_ms"],2), "ms/sweep", {k.split('[')[0]:round(v["ms_per_launch"],2) for k,v in d["kernels"].items() if v["launches"]>=6})
+print("$TAG", round(d["value"],3), "steps/s", {k.split('[')[0]:round(v["ms_per_launch"],3) for k,v in d["kernels"].items() if v["launches"]>=4})
 PY

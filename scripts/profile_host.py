@@ -1,6 +1,11 @@
+"""cProfile of a bench.py run (host side): python scripts/profile_host.py [bench arguments]"""
 import cProfile, pstats, sys, io
-sys.argv=['bench.py','--workload','allencahn','--steps','10','--warmup','2','--no-cpu-baseline']
-sys.path.insert(0,'.')
+args = sys.argv[1:] or ['--workload', 'allencahn', '--steps', '10', '--warmup', '2']
+sys.argv = ['bench.py'] + args + ['--no-cpu-baseline']
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.chdir(ROOT)
 import runpy
 pr=cProfile.Profile()
 pr.enable()
