@@ -436,12 +436,13 @@ __global__ __launch_bounds__(256) void k_spec_residual(SpecArgs a, int n, size_t
 // Saves writing and re-reading NF spectra between k_spec_point and k_fftz_plain.
 // MODE 0: sweep, the new iterate is transformed; 1: sweep, the residual spectrum is transformed (RES);
 // 2: no sweep - residual spectrum of the CACHED iterate against the current S0 (u[0] was replaced).
-template <int N, int NF, int MODE, bool HASE>
+// EXPL 0: no explicit part, 1: explicit stencil (symbol lamE), 2: u-independent forcing (profile spectrum SP).
+template <int N, int NF, int MODE, int EXPL>
 // (several lines per workgroup, N < 1024: the elements a thread takes from the first chunk stay live while it works on
 // the second one - 2 waves / SIMD worth of registers instead of spilling; measured 5.7 -> 4.2 ms at 512^3)
 __global__ __launch_bounds__(z_lines_per_block<N>() * (N / fft_elems(N)) * NF,
                              z_lines_per_block<N>() > 1 ? 2 : SDC_SPECZ_WAVES) void k_spec_z(SpecArgs a, unsigned nlines) {
-    constexpr bool RES = MODE >= 1, UPD = MODE <= 1;
+    constexpr bool RES = MODE >= 1, UPD = MODE <= 1, HASE = EXPL == 1, HASP = EXPL == 2;
     constexpr int E = fft_elems(N), P = N / E, LPB = z_lines_per_block<N>();
     constexpr int SPAN = LPB * N, CH = SPAN > SDC_SPECZ_CH ? SDC_SPECZ_CH : SPAN, NCH = SPAN / CH, NT = LPB * P * NF;
     constexpr int ITS = (CH + NT - 1) / NT;  // modes per thread and chunk
@@ -462,10 +463,10 @@ __global__ __launch_bounds__(z_lines_per_block<N>() * (N / fft_elems(N)) * NF,
         for (int it = 0; it < ITS; ++it) {
             const int k = threadIdx.x + it * NT;
             const size_t g = span0 + (size_t)ch * CH + k;
-            inp[it] = cd{0.0, 0.0};
+            if (HASP) inp[it] = cd{0.0, 0.0};
             if (k < CH && g < nmodes) {
                 in0[it] = a.S0[g];
-                if (a.SP) inp[it] = a.SP[g];
+                if (HASP) inp[it] = a.SP[g];
                 if (!UPD || !a.spread) {
 #pragma unroll
                     for (int q = 0; q < NF; ++q) inq[it][q] = a.S[q * a.fstride + g];
@@ -499,7 +500,8 @@ __global__ __launch_bounds__(z_lines_per_block<N>() * (N / fft_elems(N)) * NF,
                         u[m] = old[m];
                         continue;
                     }
-                    cd acc = cd{fma(a.cP[m], inp[it].x, u0h.x), fma(a.cP[m], inp[it].y, u0h.y)};
+                    cd acc = u0h;
+                    if (HASP) acc = cd{fma(a.cP[m], inp[it].x, u0h.x), fma(a.cP[m], inp[it].y, u0h.y)};
 #pragma unroll
                     for (int q = 0; q < NF; ++q) {
                         const double gi = a.gI[m][q];
@@ -531,7 +533,7 @@ __global__ __launch_bounds__(z_lines_per_block<N>() * (N / fft_elems(N)) * NF,
 #pragma unroll
                     for (int m = 0; m < NF; ++m) {
                         cd acc = csub(u0h, u[m]);
-                        acc = cd{fma(a.cP[m], inp[it].x, acc.x), fma(a.cP[m], inp[it].y, acc.y)};
+                        if (HASP) acc = cd{fma(a.cP[m], inp[it].x, acc.x), fma(a.cP[m], inp[it].y, acc.y)};
 #pragma unroll
                         for (int q = 0; q < NF; ++q) {
                             const double rq = a.rQ[m][q];

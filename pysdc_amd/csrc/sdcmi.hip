@@ -390,17 +390,14 @@ static void launch_spec_z(sdc_ctx* c, SpecArgs& a, size_t lines, int mode) {
     size_t ldsz = (size_t)LayContig<N>::doubles(NF * LPB) * sizeof(double);
     if ((size_t)NF * CH * sizeof(cd) > ldsz) ldsz = (size_t)NF * CH * sizeof(cd);
     const dim3 grid((unsigned)((lines + LPB - 1) / LPB)), block(P * LPB * NF);
-    const bool hase = a.lamE != nullptr;
+    const int expl = a.lamE ? 1 : (a.SP ? 2 : 0);
 #define ZL(M_, E_) hipLaunchKernelGGL((k_spec_z<N, NF, M_, E_>), grid, block, ldsz, c->stream, a, (unsigned)lines)
-    if (hase) {
-        if (mode == 0) ZL(0, true);
-        else if (mode == 1) ZL(1, true);
-        else ZL(2, true);
-    } else {
-        if (mode == 0) ZL(0, false);
-        else if (mode == 1) ZL(1, false);
-        else ZL(2, false);
-    }
+#define ZM(E_)                   \
+    if (mode == 0) ZL(0, E_);    \
+    else if (mode == 1) ZL(1, E_); \
+    else ZL(2, E_);
+    if (expl == 1) { ZM(1) } else if (expl == 2) { ZM(2) } else { ZM(0) }
+#undef ZM
 #undef ZL
 }
 
