@@ -166,9 +166,9 @@ struct LayStrided {  // T columns interleaved: [pos][col]
 };
 
 // one Stockham stage on the registers of one thread: radix R, NS = product of the previous radices
-template <int N, int R, int NS, int DIR>
-DEVI void fft_butterflies(cd (&r)[fft_elems(N)], int j, const cd* __restrict__ tw) {
-    constexpr int E = fft_elems(N), P = N / E, NB = E / R;
+template <int N, int R, int NS, int DIR, int EE = fft_elems(N)>
+DEVI void fft_butterflies(cd (&r)[EE], int j, const cd* __restrict__ tw) {
+    constexpr int E = EE, P = N / E, NB = E / R;
 #pragma unroll
     for (int q = 0; q < NB; ++q) {
         cd x[R];
@@ -217,9 +217,9 @@ DEVI void fft_sync() {
 }
 
 // scatter the stage output through LDS and read back the strided set of the next stage
-template <int N, int R, int NS, class LAY, bool WAVE = false>
-DEVI void fft_exchange(cd (&r)[fft_elems(N)], int j, int col, double* lds) {
-    constexpr int E = fft_elems(N), P = N / E, NB = E / R;
+template <int N, int R, int NS, class LAY, bool WAVE = false, int EE = fft_elems(N)>
+DEVI void fft_exchange(cd (&r)[EE], int j, int col, double* lds) {
+    constexpr int E = EE, P = N / E, NB = E / R;
 #pragma unroll
     for (int part = 0; part < 2; ++part) {
 #pragma unroll
@@ -242,21 +242,23 @@ DEVI void fft_exchange(cd (&r)[fft_elems(N)], int j, int col, double* lds) {
     }
 }
 
-template <int N, int NS, int DIR, class LAY, bool WAVE>
-DEVI void fft_stages(cd (&r)[fft_elems(N)], int j, int col, double* lds, const cd* __restrict__ tw) {
+template <int N, int NS, int DIR, class LAY, bool WAVE, int EE = fft_elems(N)>
+DEVI void fft_stages(cd (&r)[EE], int j, int col, double* lds, const cd* __restrict__ tw) {
     constexpr int REM = N / NS;
-    constexpr int R = REM >= 16 ? 16 : REM;
-    fft_butterflies<N, R, NS, DIR>(r, j, tw);
+    constexpr int RMAX = EE < 16 ? EE : 16;  // a butterfly cannot be wider than the elements a thread holds
+    constexpr int R = REM >= RMAX ? RMAX : REM;
+    fft_butterflies<N, R, NS, DIR, EE>(r, j, tw);
     if constexpr (NS * R < N) {
-        fft_exchange<N, R, NS, LAY, WAVE>(r, j, col, lds);
-        fft_stages<N, NS * R, DIR, LAY, WAVE>(r, j, col, lds, tw);
+        fft_exchange<N, R, NS, LAY, WAVE, EE>(r, j, col, lds);
+        fft_stages<N, NS * R, DIR, LAY, WAVE, EE>(r, j, col, lds, tw);
     }
 }
 
 // Full length-N transform of the line held as r[i] <-> index j + i*P; result in the same arrangement.
 // All threads of the block must call this (it contains barriers when N > 16).  WAVE = true: the P threads
 // of a column sit in ONE wavefront (P <= 64, columns wave-aligned), so no block barrier is needed.
-template <int N, int DIR, class LAY, bool WAVE = false>
-DEVI void fft_line(cd (&r)[fft_elems(N)], int j, int col, double* lds, const cd* __restrict__ tw) {
-    fft_stages<N, 1, DIR, LAY, WAVE>(r, j, col, lds, tw);
+// EE: elements per thread (default min(16, N)); EE = 8 spreads a 512-line over a whole wavefront.
+template <int N, int DIR, class LAY, bool WAVE = false, int EE = fft_elems(N)>
+DEVI void fft_line(cd (&r)[EE], int j, int col, double* lds, const cd* __restrict__ tw) {
+    fft_stages<N, 1, DIR, LAY, WAVE, EE>(r, j, col, lds, tw);
 }

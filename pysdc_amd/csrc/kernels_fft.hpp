@@ -424,6 +424,9 @@ __global__ __launch_bounds__(256) void k_spec_residual(SpecArgs a, int n, size_t
 #ifndef SDC_SPECZ_WAVES
 #define SDC_SPECZ_WAVES 4
 #endif
+#ifndef SDC_SPECZ_E1024
+#define SDC_SPECZ_E1024 16
+#endif
 #ifndef SDC_SPECZ_CH
 #define SDC_SPECZ_CH 512
 #endif
@@ -436,14 +439,25 @@ __global__ __launch_bounds__(256) void k_spec_residual(SpecArgs a, int n, size_t
 // Saves writing and re-reading NF spectra between k_spec_point and k_fftz_plain.
 // MODE 0: sweep, the new iterate is transformed; 1: sweep, the residual spectrum is transformed (RES);
 // 2: no sweep - residual spectrum of the CACHED iterate against the current S0 (u[0] was replaced).
+// Elements per thread of the line transform inside the fused kernel: a 512-line uses 8, so that its 64 threads are one
+// wavefront and a workgroup owns ONE line per field like at 1024 (no second chunk whose work keeps the first chunk's
+// elements alive in registers).
+template <int N>
+constexpr int specz_elems() { return N == 512 ? 8 : (N == 1024 ? SDC_SPECZ_E1024 : fft_elems(N)); }
+template <int N>
+constexpr int specz_lines() {
+    constexpr int P = N / specz_elems<N>();
+    return P >= 64 ? 1 : 64 / P;
+}
+
 // EXPL 0: no explicit part, 1: explicit stencil (symbol lamE), 2: u-independent forcing (profile spectrum SP).
 template <int N, int NF, int MODE, int EXPL>
 // (several lines per workgroup, N < 1024: the elements a thread takes from the first chunk stay live while it works on
 // the second one - 2 waves / SIMD worth of registers instead of spilling; measured 5.7 -> 4.2 ms at 512^3)
-__global__ __launch_bounds__(z_lines_per_block<N>() * (N / fft_elems(N)) * NF,
-                             z_lines_per_block<N>() > 1 ? 2 : SDC_SPECZ_WAVES) void k_spec_z(SpecArgs a, unsigned nlines) {
+__global__ __launch_bounds__(specz_lines<N>() * (N / specz_elems<N>()) * NF,
+                             specz_lines<N>() > 1 ? 2 : SDC_SPECZ_WAVES) void k_spec_z(SpecArgs a, unsigned nlines) {
     constexpr bool RES = MODE >= 1, UPD = MODE <= 1, HASE = EXPL == 1, HASP = EXPL == 2;
-    constexpr int E = fft_elems(N), P = N / E, LPB = z_lines_per_block<N>();
+    constexpr int E = specz_elems<N>(), P = N / E, LPB = specz_lines<N>();
     constexpr int SPAN = LPB * N, CH = SPAN > SDC_SPECZ_CH ? SDC_SPECZ_CH : SPAN, NCH = SPAN / CH, NT = LPB * P * NF;
     constexpr int ITS = (CH + NT - 1) / NT;  // modes per thread and chunk
     using LAY = LayContig<N>;
@@ -555,7 +569,7 @@ __global__ __launch_bounds__(z_lines_per_block<N>() * (N / fft_elems(N)) * NF,
         }
         __syncthreads();  // the next chunk / the exchange planes of the transform overwrite the buffer
     }
-    fft_line<N, +1, LAY, (N / fft_elems(N)) <= 64>(r, j, c, lds, a.tw);
+    fft_line<N, +1, LAY, P <= 64, E>(r, j, c, lds, a.tw);
     if (ok) {
         cd* __restrict__ dst = a.W + f * a.fstride + line * N;
 #pragma unroll

@@ -385,7 +385,7 @@ static int early_end_point_n(sdc_ctx* c, bool norms_only) {
 
 template <int N, int NF>
 static void launch_spec_z(sdc_ctx* c, SpecArgs& a, size_t lines, int mode) {
-    constexpr int P = N / fft_elems(N), LPB = z_lines_per_block<N>();
+    constexpr int P = N / specz_elems<N>(), LPB = specz_lines<N>();
     constexpr int SPAN = LPB * N, CH = SPAN > SDC_SPECZ_CH ? SDC_SPECZ_CH : SPAN;
     size_t ldsz = (size_t)LayContig<N>::doubles(NF * LPB) * sizeof(double);
     if ((size_t)NF * CH * sizeof(cd) > ldsz) ldsz = (size_t)NF * CH * sizeof(cd);
