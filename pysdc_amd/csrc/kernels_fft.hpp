@@ -424,6 +424,9 @@ __global__ __launch_bounds__(256) void k_spec_residual(SpecArgs a, int n, size_t
 #ifndef SDC_SPECZ_WAVES
 #define SDC_SPECZ_WAVES 4
 #endif
+#ifndef SDC_SPECZ_E256
+#define SDC_SPECZ_E256 8
+#endif
 #ifndef SDC_SPECZ_E1024
 #define SDC_SPECZ_E1024 16
 #endif
@@ -443,7 +446,7 @@ __global__ __launch_bounds__(256) void k_spec_residual(SpecArgs a, int n, size_t
 // wavefront and a workgroup owns ONE line per field like at 1024 (no second chunk whose work keeps the first chunk's
 // elements alive in registers).
 template <int N>
-constexpr int specz_elems() { return N == 512 ? 8 : (N == 1024 ? SDC_SPECZ_E1024 : fft_elems(N)); }
+constexpr int specz_elems() { return N == 512 ? 8 : (N == 256 ? SDC_SPECZ_E256 : (N == 1024 ? SDC_SPECZ_E1024 : fft_elems(N))); }
 template <int N>
 constexpr int specz_lines() {
     constexpr int P = N / specz_elems<N>();
