@@ -150,7 +150,10 @@ DEVI void dft(cd (&x)[R]) {
     }
 }
 
-constexpr int fft_elems(int N) { return N < 16 ? N : 16; }
+#ifndef SDC_FFT_E
+#define SDC_FFT_E 16
+#endif
+constexpr int fft_elems(int N) { return N < SDC_FFT_E ? N : SDC_FFT_E; }
 
 // LDS index maps (in doubles).  The skew (pos >> 4) breaks the power-of-two strides of the stage-1 scatter.
 template <int N>
