@@ -73,6 +73,11 @@ __global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_fwd(FieldPtr
     }
 }
 
+// SDC_XINV_DIRECT=1: every thread fetches the mirrored rows itself instead of unpacking through LDS - measured slower
+// at 1024^3 (12.4 vs 10.2 ms for the norm pass), kept as a build-time variant
+#ifndef SDC_XINV_DIRECT
+#define SDC_XINV_DIRECT 0
+#endif
 // c2r along axis 0 (inverse of the above, unnormalised).  NORM: max |.| per field goes to norms[field] (the fields
 // are the collocation residuals of the spectral sweep); STORE: the real field is written to out[field].
 template <int N, int T, bool NORM, bool STORE>
@@ -88,6 +93,28 @@ __global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_inv(FieldPtr
     const int c = blockIdx.x * T + col;
     const bool ok = c < ncol;
     const cd* __restrict__ Wf = W + blockIdx.y * fstride;
+    cd r[E];
+#if SDC_XINV_DIRECT
+    // C[k] = A[k] + i B[k] (k <= N/2), C[N-k] = conj A[k] + i conj B[k]: every thread fetches the row it needs for each
+    // of its elements itself (rows 1 .. N/2-1 are read twice per workgroup, the second time from cache) - no trip
+    // through LDS before the transform
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+        const int k = j + i * P;
+        const bool up = k > N / 2;
+        const int kk = up ? N - k : k;
+        cd a = cd{0.0, 0.0}, b = cd{0.0, 0.0};
+        if (ok) {
+            const cd* src = Wf + (size_t)kk * rest + 2 * (size_t)c;
+            a = src[0];
+            b = src[1];
+        }
+        const bool edge = (k == 0) || (k == N / 2);
+        if (edge) r[i] = cd{a.x, b.x};
+        else if (!up) r[i] = cd{a.x - b.y, a.y + b.x};
+        else r[i] = cd{a.x + b.y, -a.y + b.x};
+    }
+#else
     cd A[E], B[E];
 #pragma unroll
     for (int i = 0; i < E; ++i) {
@@ -100,7 +127,6 @@ __global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_inv(FieldPtr
             A[i] = B[i] = cd{0.0, 0.0};
         }
     }
-    cd r[E];
     // C[k] = A[k] + i B[k] (k <= N/2), C[N-k] = conj A[k] + i conj B[k]
 #pragma unroll
     for (int part = 0; part < 2; ++part) {
@@ -130,6 +156,7 @@ __global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_inv(FieldPtr
         }
         __syncthreads();
     }
+#endif
     fft_line<N, +1, LAY>(r, j, col, lds, tw);
     if constexpr (NORM) {
         double m = 0.0;  // columns beyond the edge were transformed from zeros
