@@ -32,9 +32,9 @@
 // host side
 // ------------------------------------------------------------------------------------------------------
 static int ensure_work(sdc_ctx* c);
-// the FFT kernels transform lines of length 2^p <= 1024 (2048 in 1-D)
+// the FFT kernels transform lines of length 2^p <= 1024 (2048 in 1-D and 2-D)
 static inline bool fourier_ok(const sdc_ctx* c) {
-    return is_pow2(c->n) && (c->n <= 1024 || (c->n == 2048 && c->ndim == 1));
+    return is_pow2(c->n) && (c->n <= 1024 || (c->n == 2048 && c->ndim <= 2));
 }
 static inline int grid_for(size_t work, int block) {
     size_t g = (work + block - 1) / block;
@@ -592,9 +592,9 @@ static int inverse_from_cache(sdc_ctx* c, int first, int nf, const FieldPtrs& p)
 // (I - alpha_f A) out_f = in_f + sum_{j<f} (cI[f][j] A + cE[f][j] B) out_j for f = 0..nf-1
 static int fft_pipeline(sdc_ctx* c, int nf, const FieldPtrs& p, ZArgs& z) {
     if (!c->have_stencil[0]) return fail(c, SDC_ERR_STATE, "implicit operator not set (sdc_set_stencil)");
-    if (!is_pow2(c->n) || c->n > 2048 || (c->n > 1024 && c->ndim > 1))
+    if (!fourier_ok(c))
         return fail(c, SDC_ERR_UNSUPPORTED,
-                    "spectral solve needs n = 2^p <= 1024 per dimension (<= 2048 in 1-D), got %d", c->n);
+                    "spectral solve needs n = 2^p <= 1024 per dimension (<= 2048 in 1-D / 2-D), got %d", c->n);
     {
         int rw = ensure_work(c);
         if (rw != SDC_OK) return rw;
@@ -1417,7 +1417,7 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
     const bool gather_once = c->force_gather;
     c->force_gather = false;
     if (c->reuse && !gather_once && !c->tau_active && c->have_stencil[0] &&
-        is_pow2(c->n) && (c->n <= 1024 || (c->n == 2048 && c->ndim == 1))) {
+        fourier_ok(c)) {
         // ---- spectral reuse: f is linear in u, so the gather happens on the cached transforms ----
         if (!c->S) {
             HIPCHK(c, hipMalloc((void**)&c->S, sizeof(cd) * c->Nc * M));
@@ -1636,7 +1636,7 @@ int sdc_solve(sdc_ctx* c, const double* rhs, double factor, const double* guess,
         }
         if (!symmetric)
             return fail(c, SDC_ERR_UNSUPPORTED,
-                        "n = %d is not a power of two (<= 1024; 2048 in 1-D) and the operator is not symmetric: no solver", c->n);
+                        "n = %d is not a power of two (<= 1024; 2048 in 1-D / 2-D) and the operator is not symmetric: no solver", c->n);
         const double keep_rtol = c->cg_rtol;
         const int keep_maxiter = c->cg_maxiter;
         const unsigned long long keep_iters = c->cg_iters;

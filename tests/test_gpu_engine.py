@@ -70,7 +70,7 @@ def test_sweep_vs_golden(fname, name, reuse):
 
 
 @pytest.mark.parametrize('nvars,order', [((32,), 2), ((64, 64), 4), ((16, 16, 16), 2), ((32, 32, 32), 6),
-                                         ((128,), 8), ((256, 256), 2)])
+                                         ((128,), 8), ((256, 256), 2), ((2048,), 2), ((2048, 2048), 2)])
 def test_eval_f_and_solve_vs_oracle(nvars, order):
     from oracle import sdc_oracle as O
 
