@@ -1515,13 +1515,32 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
         q.out[m] = c->U + (size_t)(m + 1) * c->N;
         for (int j = 0; j < M; ++j) {
             q.cI[m][j] = dt * (c->Q[m + 1][j + 1] - c->QI[m + 1][j + 1]);
-            // u-independent forcing: the new explicit values equal the old ones, so the strictly lower
-            // QE add-back of imex_1st_order.py:94 folds into the gather
-            q.cE[m][j] = forcing ? dt * c->Q[m + 1][j + 1] : dt * (c->Q[m + 1][j + 1] - c->QE[m + 1][j + 1]);
+            q.cE[m][j] = dt * (c->Q[m + 1][j + 1] - c->QE[m + 1][j + 1]);
         }
     }
     int rc = launch_quad<0>(c, q, "gather");
     if (rc != SDC_OK) return rc;
+    if (forcing) {
+        // the strictly lower QE add-back of imex_1st_order.py:94 uses the NEW explicit values, which for a u-independent
+        // forcing are known before any solve: profile * g(t_j).  (The stored old ones may be something else - a
+        // 'copy' predictor leaves g(t_0) everywhere - so they only enter through the gather above.)
+        for (int m = 1; m < M; ++m) {
+            double cm = 0.0;
+            for (int j = 0; j < m; ++j) cm += dt * c->QE[m + 1][j + 1] * c->gvals[j + 1];
+            if (cm == 0.0) continue;
+            LinArgs la;
+            memset(&la, 0, sizeof la);
+            la.out = c->U + (size_t)(m + 1) * c->N;
+            la.base = la.out;
+            la.n = c->N;
+            la.x[0] = c->profile;
+            la.c[0] = cm;
+            la.nterms = 1;
+            LaunchTimer lt(c, "node_rhs");
+            hipLaunchKernelGGL(k_lincomb, dim3(grid_for(c->N / 2, 256)), dim3(256), 0, c->stream, la);
+        }
+        HIPCHK(c, hipGetLastError());
+    }
     // 2. node-coupled spectral solve
     FieldPtrs p;
     memset(&p, 0, sizeof p);

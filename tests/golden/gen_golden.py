@@ -10,7 +10,8 @@ That regenerates the sweep / run / multi-level / Allen-Cahn / dirichlet files.  
 own entry points, switched on by environment variables (or call the function after ``runpy.run_path``):
 GOLDEN_FFT=1 fft_transfer_main (transfer_fft.npz, runs_ac_fft.npz), GOLDEN_RELAY=1 relay_main (runs_relay.npz),
 GOLDEN_CG=1 cg_main (sweeps_cg.npz), GOLDEN_VDPJ=1 vdp_jacobian_main (vdp_jacobian.npz), GOLDEN_DML=1
-dirichlet_ml_main (transfer_dirichlet.npz, runs_ml_dirichlet.npz); GOLDEN_ML=0 skips the multi-level block.
+dirichlet_ml_main (transfer_dirichlet.npz, runs_ml_dirichlet.npz), GOLDEN_GUESS=1 guess_main (sweeps_guess.npz);
+GOLDEN_ML=0 skips the multi-level block.
 
 ``qmat`` (third-party, absent here) is replaced by oracle/qmat_shim, which forwards to
 pysdc_amd.coeffs; the coefficient matrices that were actually used are stored with every case.
@@ -681,3 +682,25 @@ def dirichlet_ml_main():
 
 if __name__ == '__main__' and os.environ.get('GOLDEN_DML', '0') == '1':
     dirichlet_ml_main()
+
+
+def guess_main():
+    """predictor variants on IMEX problems with a time-dependent forcing: 'copy' leaves f(t0) at every node, 'zero'
+    zeros - the first sweep then integrates exactly those stored values (core/sweeper.py:140-158)."""
+    RR = dict(quad_type='RADAU-RIGHT')
+    cases = []
+    for guess in ('copy', 'zero', 'spread'):
+        cases.append(sweep_case(f'forced2d_guess_{guess}', 'heat_forced', dict(nvars=(16, 16), nu=0.1, freq=2),
+                                'imex_1st_order', dict(num_nodes=3, QI='LU', QE='EE', initial_guess=guess, **RR), 0.05,
+                                u0_kind='exact'))
+    cases.append(sweep_case('forced3d_guess_copy', 'heat_forced', dict(nvars=(8, 8, 8), nu=0.1, freq=2),
+                            'imex_1st_order', dict(num_nodes=5, QI='IE', QE='EE', initial_guess='copy', **RR), 0.02,
+                            u0_kind='randn'))
+    cases.append(sweep_case('forced1d_guess_zero', 'heat_forced', dict(nvars=64, nu=0.1, freq=2),
+                            'imex_1st_order', dict(num_nodes=3, QI='LU', QE='PIC', initial_guess='zero', **RR), 0.01,
+                            u0_kind='exact'))
+    save('sweeps_guess.npz', cases)
+
+
+if __name__ == '__main__' and os.environ.get('GOLDEN_GUESS', '0') == '1':
+    guess_main()

@@ -23,7 +23,7 @@ def supported(case):
     return n & (n - 1) == 0
 
 
-SWEEP_FILES = ['sweeps_heat.npz', 'sweeps_imex.npz', 'sweeps_adv.npz']
+SWEEP_FILES = ['sweeps_heat.npz', 'sweeps_imex.npz', 'sweeps_adv.npz', 'sweeps_guess.npz']
 SWEEP_CASES = [(f, n) for f in SWEEP_FILES for n, c in load_cases(f).items() if supported(c)]
 
 

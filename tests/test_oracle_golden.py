@@ -10,7 +10,7 @@ from tests._cases import load_cases, make_oracle_problem, make_oracle_coll, rel_
 # agreement is at rounding level (Newton / CG paths included)
 TOL = 1e-13
 
-SWEEP_FILES = ['sweeps_heat.npz', 'sweeps_imex.npz', 'sweeps_adv.npz', 'sweeps_vdp.npz', 'sweeps_ac.npz', 'sweeps_cg.npz']
+SWEEP_FILES = ['sweeps_heat.npz', 'sweeps_imex.npz', 'sweeps_adv.npz', 'sweeps_vdp.npz', 'sweeps_ac.npz', 'sweeps_cg.npz', 'sweeps_guess.npz']
 SWEEP_CASES = [(f, n) for f in SWEEP_FILES for n in load_cases(f)]
 
 
