@@ -699,6 +699,16 @@ def guess_main():
     cases.append(sweep_case('forced1d_guess_zero', 'heat_forced', dict(nvars=64, nu=0.1, freq=2),
                             'imex_1st_order', dict(num_nodes=3, QI='LU', QE='PIC', initial_guess='zero', **RR), 0.01,
                             u0_kind='exact'))
+    for nm, prob, pp, sweeper, sw in (
+            ('heat2d_guess_random', 'heat_unforced', dict(nvars=(16, 16), nu=0.1, freq=2), 'generic_implicit',
+             dict(num_nodes=3, QI='LU', initial_guess='random', **RR)),
+            ('forced2d_guess_random', 'heat_forced', dict(nvars=(16, 16), nu=0.1, freq=2), 'imex_1st_order',
+             dict(num_nodes=3, QI='LU', QE='EE', initial_guess='random', **RR)),
+            ('advdiff1d_guess_random', 'advdiff', dict(nvars=64, nu=0.02, c=1.0, freq=2), 'imex_1st_order',
+             dict(num_nodes=3, QI='IE', QE='EE', initial_guess='random', **RR)),
+            ('advdiff2d_guess_copy', 'advdiff', dict(nvars=(16, 16), nu=0.02, c=1.0, freq=2), 'imex_1st_order',
+             dict(num_nodes=3, QI='IE', QE='EE', initial_guess='copy', **RR))):
+        cases.append(sweep_case(nm, prob, pp, sweeper, sw, 0.02, u0_kind='exact'))
     save('sweeps_guess.npz', cases)
 
 

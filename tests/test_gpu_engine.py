@@ -15,6 +15,8 @@ TOL = 1e-10
 def supported(case):
     meta = case['meta']
     pp = meta['prob_params']
+    if meta['sweeper_params'].get('initial_guess') == 'random':
+        return False              # drawn node by node on the host: covered through the plug-in classes
     if meta['prob'] == 'vanderpol':
         return False
     if pp.get('bc', 'periodic') != 'periodic':

@@ -525,3 +525,42 @@ def test_log_solution_hook_keeps_owning_copies():
     for (t, u) in us:
         assert rel_err(u.get(), P.u_exact(t).get()) < 1e-4
     assert np.max(np.abs(us[0][1].get() - us[1][1].get())) > 0
+
+
+@pytest.mark.parametrize('name', list(load_cases('sweeps_guess.npz')))
+@pytest.mark.parametrize('fused', [True, False])
+def test_predictor_variants_vs_golden(name, fused):
+    """initial_guess = spread / copy / zero / random on problems with and without explicit parts (a time-dependent
+    forcing, an explicit stencil): predictor state and three sweeps against the reference."""
+    from pysdc_amd.level import Step
+
+    case = load_cases('sweeps_guess.npz')[name]
+    meta = case['meta']
+    probs, sweeps = _classes()
+    pc = probs[meta['prob']]
+    if not fused:
+        pc = type(pc.__name__ + '_nodewise', (pc,), {'fused': False})
+    pp = dict(meta['prob_params'])
+    if isinstance(pp.get('nvars'), list):
+        pp['nvars'] = tuple(pp['nvars'])
+    S = Step(dict(problem_class=pc, problem_params=pp, sweeper_class=sweeps[meta['sweeper']],
+                  sweeper_params=dict(meta['sweeper_params']), level_params=dict(dt=meta['dt']),
+                  step_params=dict(maxiter=10)))
+    L = S.levels[0]
+    L.status.time = meta['t0']
+    u0 = L.prob.u_init
+    u0[:] = case['u0']
+    L.u[0] = u0
+    L.sweep.predict()
+
+    def check(tag):
+        assert rel_err(np.stack([np.asarray(x) for x in L.u]), case[f'{tag}_u']) < TOL, tag
+        assert rel_err(np.stack([np.asarray(x) for x in L.f]), case[f'{tag}_f']) < TOL, tag
+        L.sweep.compute_residual()
+        ref = float(case[f'{tag}_res_full_abs'])
+        assert abs(L.status.residual - ref) <= 1e-8 * abs(ref) + 1e-11, tag
+
+    check('k0')
+    for k in range(1, meta['nsweeps'] + 1):
+        L.sweep.update_nodes()
+        check(f'k{k}')

@@ -27,7 +27,7 @@ def test_sweep_case(fname, name):
         for m in range(coll.num_nodes):
             L.tau[m] = np.array(case['tau'][m])
     ig = meta['sweeper_params'].get('initial_guess', 'spread')
-    O.predict(L, ig)
+    O.predict(L, ig, rng=np.random.RandomState(meta['sweeper_params'].get('random_seed', 1984)) if ig == 'random' else None)
 
     def check(tag):
         got_u = np.stack(L.u)
