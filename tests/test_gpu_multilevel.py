@@ -354,3 +354,63 @@ def test_time_parallel_controller_64cubed_matches_serial_emulation():
     for r in range(3):
         assert rel_err(out[r][0], ref) < 1e-12
         assert out[r][1] > 0 and out[r][2]
+
+
+def test_config5_pfasst_four_ranks_match_serial_emulation():
+    """BASELINE config 5 at reduced size: Allen-Cahn 3-D (64^3 / 32^3, M = 3 on both levels), two-level PFASST with
+    burn-in over four time ranks - controller_dist on device levels with the in-process stand-in against
+    controller_nonMPI emulating the four processes (same iteration counts, same end value)."""
+    import threading
+
+    from pysdc_amd.controller import controller_nonMPI
+    from pysdc_amd.problems import allencahn_imex
+    from pysdc_amd.stats import get_sorted
+    from pysdc_amd.sweepers import imex_1st_order
+    from pysdc_amd.transfer import mesh_to_mesh
+    from tests import _fake_dist as FD
+
+    n, size = 64, 4
+    desc = dict(problem_class=allencahn_imex,
+                problem_params=dict(nvars=[(n, n, n), (n // 2, n // 2, n // 2)], eps=0.04, radius=0.25, init_type='sphere'),
+                sweeper_class=imex_1st_order, sweeper_params=dict(num_nodes=3, quad_type='RADAU-RIGHT', QI='LU', QE='EE'),
+                level_params=dict(dt=1e-3, restol=1e-8, nsweeps=1), step_params=dict(maxiter=20),
+                space_transfer_class=mesh_to_mesh, space_transfer_params=dict(iorder=6, rorder=2, periodic=True))
+    cp = dict(logger_level=40, predict_type='pfasst_burnin')
+    C = controller_nonMPI(size, dict(cp), desc)
+    P = C.MS[0].levels[0].prob
+    ref, rstats = C.run(P.u_exact(0.0), 0.0, 8e-3)
+    ref = ref.get()
+    ref_niter = [v for _, v in get_sorted(rstats, type='niter', sortby='time')]
+    world = FD.World(size)
+    out, errors = {}, []
+
+    def rank_main(rank):
+        import traceback
+
+        try:
+            FD.bind(world, rank)
+            from pysdc_amd.controller import controller_dist
+
+            Cd = controller_dist(dict(cp), desc, dist=FD)
+            Pd = Cd.S.levels[0].prob
+            uend, stats = Cd.run(Pd.u_exact(0.0), 0.0, 8e-3)
+            niter = get_sorted(stats, type='niter', sortby='time')
+            out[rank] = (uend.get(), [t for t, _ in niter], [v for _, v in niter])
+        except Exception:  # noqa: BLE001
+            errors.append(traceback.format_exc())
+            try:
+                world.barrier.abort()
+            except Exception:  # noqa: BLE001
+                pass
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(size)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not errors, errors[0]
+    times = np.concatenate([out[r][1] for r in range(size)])
+    niter = np.concatenate([out[r][2] for r in range(size)])
+    assert list(niter[np.argsort(times)]) == ref_niter
+    for r in range(size):
+        assert rel_err(out[r][0], ref) < 1e-11
