@@ -6,13 +6,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import tests.test_gpu_fullsize as T
 import tests.test_gpu_plugin as P
 bad = 0
-for seed in range(100, 260):
-    for prob in ('heat_unforced', 'advdiff', 'heat_forced'):
-        try:
-            T.test_deferred_state_machine_random_walk.__wrapped__(prob, seed) if hasattr(T.test_deferred_state_machine_random_walk, '__wrapped__') else T.test_deferred_state_machine_random_walk(prob, seed)
-        except Exception as e:
-            bad += 1
-            print('ENGINE FAIL', prob, seed, str(e)[:400])
+for n_, seeds in (('128', range(300, 330)), ('256', range(330, 345)), ('64', range(100, 260))):
+  os.environ['PYSDC_FUZZ_N'] = n_
+  for seed in seeds:
+      for prob in ('heat_unforced', 'advdiff', 'heat_forced'):
+          try:
+              T.test_deferred_state_machine_random_walk.__wrapped__(prob, seed) if hasattr(T.test_deferred_state_machine_random_walk, '__wrapped__') else T.test_deferred_state_machine_random_walk(prob, seed)
+          except Exception as e:
+              bad += 1
+              print('ENGINE FAIL', n_, prob, seed, str(e)[:400])
+os.environ['PYSDC_FUZZ_N'] = '64'
 for seed in range(100, 200):
     try:
         P.test_plugin_random_walk_deferred_vs_eager(seed)

@@ -381,10 +381,11 @@ def test_early_end_point_and_stream_wait():
 def test_deferred_state_machine_random_walk(prob, seed):
     """random sequences of C-ABI calls on two engines - every deferral switched on (deferred node fields, kept
     residual fields, early end value) against everything eager: whatever is read back must agree."""
+    import os
     import torch
 
-    n, M = 64, 3
-    dt = 0.05
+    n, M = int(os.environ.get('PYSDC_FUZZ_N', '64')), 3       # (scripts/fuzz_more.py also walks other sizes)
+    dt = 0.05 * (64.0 / n) ** 2
     c, qi = _coeffs(M, 'LU')
     qe = None
     if prob in ('advdiff', 'heat_forced'):
