@@ -101,6 +101,14 @@ class SlabList:
     def __iter__(self):
         return (self[m] for m in range(self._len))
 
+    def write(self, m, fill):
+        """let ``fill(view)`` produce field m in place (instead of assigning a temporary, which copies)"""
+        m = self._norm(m)
+        v = self._view(m)
+        fill(v)
+        self._valid[m] = True
+        self._L._touched(self._slot, m)
+
     def mark(self, ms, valid=True):
         for m in ms:
             self._valid[m] = valid

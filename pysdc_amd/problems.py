@@ -525,8 +525,14 @@ class _SpectralLaplacianIMEX(Problem):
             self.work_counters['rhs']()
         return f
 
+    def eval_f_into(self, u, t, out):
+        """eval_f with the result written into an existing imex field (a slab view): no temporary, no copy"""
+        self.engine.eval_f(u.ptr, 0.0, out.impl.ptr, out.expl.ptr)
+        if 'rhs' in self.work_counters:
+            self.work_counters['rhs']()
+
     def solve_system(self, rhs, factor, u0, t):
-        me = self.u_init
+        me = self._out_u()
         self.engine.solve(rhs.ptr, float(factor), me.ptr)
         return me
 

@@ -70,6 +70,15 @@ class BaseTransfer:
             acc = cls._add_scaled(acc, coeff, field)
         return acc
 
+    @staticmethod
+    def _refresh_f(L, n, t):
+        """L.f[n] = f(L.u[n], t); problems that can evaluate into an existing field fill the slab view directly"""
+        into = getattr(L.prob, 'eval_f_into', None)
+        if into is not None and hasattr(L.f, 'write'):
+            L.f.write(n, lambda view: into(L.u[n], t, view))
+        else:
+            L.f[n] = L.prob.eval_f(L.u[n], t)
+
     def _to_coarse_nodes(self, fine_fields):
         """space restriction of every fine-node field followed by the node restriction Rcoll."""
         many = getattr(self.space_transfer, 'restrict_many', None)
@@ -89,9 +98,9 @@ class BaseTransfer:
         coarse.u[0] = self.space_transfer.restrict(fine.u[0])
         for n, value in enumerate(self._to_coarse_nodes([fine.u[m] for m in range(1, Mf + 1)]), start=1):
             coarse.u[n] = value
-        coarse.f[0] = cprob.eval_f(coarse.u[0], coarse.time)
+        self._refresh_f(coarse, 0, coarse.time)
         for n in range(1, Mc + 1):
-            coarse.f[n] = cprob.eval_f(coarse.u[n], coarse.time + coarse.dt * coarse.sweep.coll.nodes[n - 1])
+            self._refresh_f(coarse, n, coarse.time + coarse.dt * coarse.sweep.coll.nodes[n - 1])
 
         quad_coarse = coarse.sweep.integrate()
         quad_fine_on_coarse = self._to_coarse_nodes(fine.sweep.integrate())
@@ -134,7 +143,7 @@ class BaseTransfer:
             for m in range(Mc):
                 fine.u[n] = self._add_scaled(fine.u[n], self.Pcoll[n - 1, m], delta[m])
         for n in range(1, Mf + 1):
-            fine.f[n] = fine.prob.eval_f(fine.u[n], fine.time + fine.dt * fine.sweep.coll.nodes[n - 1])
+            self._refresh_f(fine, n, fine.time + fine.dt * fine.sweep.coll.nodes[n - 1])
 
     def prolong_f(self):
         """variant that also interpolates the change of f instead of re-evaluating it (base_transfer.py:209-251)."""
