@@ -267,7 +267,9 @@ def _rank_thread(world, rank, name, fname, out, errors):
                                              ('pfasst_heat3d_P2', 'runs_ml.npz', 2), ('ac2d_pfasst_P2', 'runs_ac.npz', 2),
                                              ('ac2d_fft2d_pfasst_P2', 'runs_ac_fft.npz', 2),
                                              ('t6a_pfasst_P2', 'runs_ml_dirichlet.npz', 2),
-                                             ('t6a_pfasst_P4', 'runs_ml_dirichlet.npz', 4)])
+                                             ('t6a_pfasst_P4', 'runs_ml_dirichlet.npz', 4),
+                                             ('forced2d_run_P2', 'runs.npz', 2), ('mssdc_P4_gs', 'runs.npz', 4),
+                                             ('dirichlet_heat1d_P2', 'runs_dirichlet.npz', 2)])
 def test_time_parallel_controller_on_device_levels(name, fname, size):
     """controller_dist with DEVICE levels and several ranks on one GPU: the ranks are threads, torch.distributed is
     replaced by an in-process stand-in (tests/_fake_dist.py), everything else - early end value, hand-over posted on
