@@ -696,7 +696,9 @@ class controller_dist(_ControllerBase):
         L = S.levels[0]
         if self._posted is not None:
             self.handover_complete()      # posted right after the sweep (it_fine)
-        elif self._lockstep(size):
+        elif self._lockstep(size) or (self._overlap and self._uniform(size)):
+            # lock-step runs: every message is completed here, on both sides - the next sweep overwrites UEND early
+            # (sdc_set_early_end_point), so no send may stay in flight behind it
             self.exchange_two_hop(size)
         else:
             self.exchange(0)
