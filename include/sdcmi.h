@@ -188,8 +188,9 @@ int sdc_set_solver(sdc_ctx* ctx, int kind, double rtol, int maxiter);
 /* ---- space transfer between two grids --------------------------------------------------------------------
  * mesh_to_mesh (transfer_classes/TransferMesh.py:9-218): Pspace / Rspace are Kronecker products of ONE 1-D
  * sparse matrix (helpers/transfer_helper.py:140-242).  The host builds that 1-D matrix exactly as the reference
- * does and hands its rows over as fixed-width tables on the device: out[i] = sum_j w[i][j] * in[idx[i][j]] per
- * axis, zero-padded to `width`.  Applied as a tensor product over ndim axes in one launch.  Context-free (two
+ * does and hands its rows over as fixed-width tables on the device: out[i] = sum_j w[j][i] * in[idx[j][i]] per
+ * axis, zero-padded to `width` (entry-major: entry j of row i at [j * n_out + i]; padded entries carry weight 0 and
+ * any valid index).  Applied as a tensor product over ndim axes in one launch.  Context-free (two
  * levels are involved); errors are reported through sdc_last_error(NULL). */
 int sdc_transfer_apply(void* stream, int ndim, int n_out, int n_in, int width, const int* idx, const double* w,
                        const double* in, double* out);

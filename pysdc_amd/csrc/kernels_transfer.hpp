@@ -10,36 +10,70 @@
 struct XferArgs {
     const double* in;
     double* out;
-    const int* idx;     // [n_out][W] source indices along the axis (device)
-    const double* w;    // [n_out][W] weights (zero-padded)
+    const int* idx;     // [W][n_out] source indices along the axis (device), entry j of output row i at j * n_out + i
+    const double* w;    // [W][n_out] weights (zero-padded)
     size_t outer, inner;
     int n_out, n_in, W;
 };
 
-// one axis of the tensor product: out[o][i][q] = sum_j w[i][j] * in[o][idx[i][j]][q].  IDX = unsigned when the
-// element counts fit 32 bits (64-bit division is emulated on the GPU).  A thread owns one (o, q) and walks CH
-// consecutive output rows i: neighbouring rows read almost the same input rows, which then come from L1 instead
-// of being fetched once per output row (the planes of a strided axis do not fit L2 for long).
+// one axis of the tensor product: out[o][i][q] = sum_j w[j][i] * in[o][idx[j][i]][q].  IDX = unsigned when the
+// element counts fit 32 bits (64-bit division is emulated on the GPU).
+
+// The contiguous axis (inner == 1): neighbouring lanes own neighbouring output points i of one line, so the table
+// entries (entry-major tables) and the outputs are coalesced and the inputs of a wave lie within a few cache
+// lines.  All W table entries and inputs are loaded before the first is used (padded entries point at a valid
+// input and are left out of the sum by a select - same bits as skipping them).  WT: compile-time width, 0 = any.
+template <class IDX, int WT>
+__global__ __launch_bounds__(256) void k_xfer_line(XferArgs a) {
+    const IDX n_out = (IDX)a.n_out;
+    const IDX total = (IDX)a.outer * n_out;
+    const int W = WT ? WT : a.W;
+    for (IDX p = blockIdx.x * (IDX)blockDim.x + threadIdx.x; p < total; p += (IDX)gridDim.x * blockDim.x) {
+        const IDX o = p / n_out;
+        const IDX i = p - o * n_out;
+        const double* __restrict__ src = a.in + (size_t)o * a.n_in;
+        double acc = 0.0;
+        if (WT) {
+            double wv[WT ? WT : 1], v[WT ? WT : 1];
+#pragma unroll
+            for (int j = 0; j < WT; ++j) {
+                wv[j] = a.w[(size_t)j * n_out + i];
+                v[j] = src[a.idx[(size_t)j * n_out + i]];
+            }
+#pragma unroll
+            for (int j = 0; j < WT; ++j) acc = wv[j] != 0.0 ? acc + wv[j] * v[j] : acc;
+        } else {
+            for (int j = 0; j < W; ++j) {
+                const double wj = a.w[(size_t)j * n_out + i];
+                const double vj = src[a.idx[(size_t)j * n_out + i]];
+                acc = wj != 0.0 ? acc + wj * vj : acc;
+            }
+        }
+        a.out[p] = acc;
+    }
+}
+
+// A strided axis, one thread per (o, q) walking CH consecutive output rows i: neighbouring rows read almost the
+// same input rows, which then come from L1 instead of being fetched once per output row.  (Fallback for odd or
+// unaligned inner sizes; the usual strided pass is k_xfer_axis_rows.)
 template <class IDX, int CH>
 __global__ __launch_bounds__(256) void k_xfer_axis(XferArgs a) {
     const IDX inner = (IDX)a.inner, outer = (IDX)a.outer;
     const IDX nch = ((IDX)a.n_out + CH - 1) / CH;
     const IDX total = outer * nch * inner;
     for (IDX p = blockIdx.x * (IDX)blockDim.x + threadIdx.x; p < total; p += (IDX)gridDim.x * blockDim.x) {
-        const IDX r = inner == 1 ? p : p / inner;
-        const IDX q = inner == 1 ? 0 : p - r * inner;
+        const IDX r = p / inner;
+        const IDX q = p - r * inner;
         const IDX o = r / nch;
         const int i0 = (int)(r - o * nch) * CH;
         const double* __restrict__ src = a.in + ((size_t)o * a.n_in) * a.inner + q;
         double* __restrict__ dst = a.out + ((size_t)o * a.n_out) * a.inner + q;
 #pragma unroll 1
         for (int i = i0; i < i0 + CH && i < a.n_out; ++i) {
-            const int* __restrict__ ix = a.idx + i * a.W;
-            const double* __restrict__ wx = a.w + i * a.W;
             double acc = 0.0;
             for (int j = 0; j < a.W; ++j) {
-                const double wj = wx[j];
-                if (wj != 0.0) acc += wj * src[(size_t)ix[j] * a.inner];
+                const double wj = a.w[(size_t)j * a.n_out + i];
+                if (wj != 0.0) acc += wj * src[(size_t)a.idx[(size_t)j * a.n_out + i] * a.inner];
             }
             dst[(size_t)i * a.inner] = acc;
         }
@@ -47,14 +81,15 @@ __global__ __launch_bounds__(256) void k_xfer_axis(XferArgs a) {
 }
 
 // The same pass for a strided axis (inner >= 2, even) with the output row taken from the block index: row index,
-// table row and weights are wave-uniform (scalar loads), every thread moves two neighbouring q (16-byte accesses)
+// table entries and weights are wave-uniform (scalar loads), every thread moves two neighbouring q (16-byte accesses)
 // and CH consecutive output rows whose input rows overlap (refinement) are served by L1.
-//   grid.x covers inner / 2, grid.y = outer * ceil(n_out / CH)
+//   grid.x = nq * outer * ceil(n_out / CH) with nq blocks along inner / 2 (fastest)
 template <int CH>
-__global__ __launch_bounds__(256) void k_xfer_axis_rows(XferArgs a) {
+__global__ __launch_bounds__(256) void k_xfer_axis_rows(XferArgs a, unsigned nq) {
     const unsigned nch = (unsigned)(a.n_out + CH - 1) / CH;
-    const unsigned o = blockIdx.y / nch, i0 = (blockIdx.y - o * nch) * CH;
-    const size_t q2 = blockIdx.x * (size_t)blockDim.x + threadIdx.x;  // pair index along the contiguous direction
+    const unsigned by = blockIdx.x / nq, bx = blockIdx.x - by * nq;
+    const unsigned o = by / nch, i0 = (by - o * nch) * CH;
+    const size_t q2 = bx * (size_t)blockDim.x + threadIdx.x;  // pair index along the contiguous direction
     if (2 * q2 >= a.inner) return;
     const double2* __restrict__ src = reinterpret_cast<const double2*>(a.in + ((size_t)o * a.n_in) * a.inner) + q2;
     double2* __restrict__ dst = reinterpret_cast<double2*>(a.out + ((size_t)o * a.n_out) * a.inner) + q2;
@@ -63,13 +98,11 @@ __global__ __launch_bounds__(256) void k_xfer_axis_rows(XferArgs a) {
     for (int r = 0; r < CH; ++r) {
         const int i = (int)i0 + r;
         if (i < a.n_out) {
-            const int* __restrict__ ix = a.idx + i * a.W;
-            const double* __restrict__ wx = a.w + i * a.W;
             double2 acc = double2{0.0, 0.0};
             for (int j = 0; j < a.W; ++j) {
-                const double wj = wx[j];
+                const double wj = a.w[(size_t)j * a.n_out + i];
                 if (wj != 0.0) {
-                    const double2 v = src[(size_t)ix[j] * row];
+                    const double2 v = src[(size_t)a.idx[(size_t)j * a.n_out + i] * row];
                     acc.x += wj * v.x;
                     acc.y += wj * v.y;
                 }

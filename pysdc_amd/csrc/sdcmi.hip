@@ -1960,11 +1960,27 @@ int sdc_transfer_apply_batch(void* stream, int nfields, int ndim, int n_out, int
         const bool refine = n_out > n_in;
         const size_t rows_y = a.outer * (size_t)(refine ? (n_out + 3) / 4 : n_out);
         const bool aligned = (((uintptr_t)a.in | (uintptr_t)a.out) & 15) == 0;
-        if (a.inner >= 2 && a.inner % 2 == 0 && rows_y <= 65535 && aligned) {
-            const dim3 grid((unsigned)((a.inner / 2 + 255) / 256), (unsigned)rows_y);
-            if (refine) hipLaunchKernelGGL((k_xfer_axis_rows<4>), grid, dim3(256), 0, (hipStream_t)stream, a);
-            else hipLaunchKernelGGL((k_xfer_axis_rows<1>), grid, dim3(256), 0, (hipStream_t)stream, a);
-        } else if (a.inner == 1 || !refine) {
+        const size_t nq = (a.inner / 2 + 255) / 256;
+        if (a.inner >= 2 && a.inner % 2 == 0 && nq * rows_y < 0x7fffffffull && aligned) {
+            const dim3 grid((unsigned)(nq * rows_y));
+            if (refine) hipLaunchKernelGGL((k_xfer_axis_rows<4>), grid, dim3(256), 0, (hipStream_t)stream, a, (unsigned)nq);
+            else hipLaunchKernelGGL((k_xfer_axis_rows<1>), grid, dim3(256), 0, (hipStream_t)stream, a, (unsigned)nq);
+        } else if (a.inner == 1) {
+            const dim3 g(grid_for(total, 256));
+#define XL(WT_)                                                                                                \
+    if (small) hipLaunchKernelGGL((k_xfer_line<unsigned, WT_>), g, dim3(256), 0, (hipStream_t)stream, a);      \
+    else hipLaunchKernelGGL((k_xfer_line<size_t, WT_>), g, dim3(256), 0, (hipStream_t)stream, a)
+            switch (width) {
+            case 1: XL(1); break;
+            case 2: XL(2); break;
+            case 3: XL(3); break;
+            case 4: XL(4); break;
+            case 6: XL(6); break;
+            case 8: XL(8); break;
+            default: XL(0); break;
+            }
+#undef XL
+        } else if (!refine) {
             if (small) hipLaunchKernelGGL((k_xfer_axis<unsigned, 1>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, a);
             else hipLaunchKernelGGL((k_xfer_axis<size_t, 1>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, a);
         } else {

@@ -243,15 +243,17 @@ def interpolation_matrix_1d_bounded(fine_grid, coarse_grid, k=2):
 
 
 def _row_tables(M):
-    """fixed-width (idx, w) rows of a dense 1-D operator, zero-padded."""
+    """fixed-width (idx, w) rows of a dense 1-D operator, zero-padded, stored entry-major ([width][rows]: what
+    sdc_transfer_apply takes).  Padded entries repeat the row's first column (weight 0): a valid, nearby address."""
     width = max(1, int(np.max(np.count_nonzero(M, axis=1))))
     idx = np.zeros((M.shape[0], width), dtype=np.int32)
     w = np.zeros((M.shape[0], width))
     for i in range(M.shape[0]):
         cols = np.nonzero(M[i])[0]
+        idx[i, :] = cols[0] if len(cols) else 0
         idx[i, : len(cols)] = cols
         w[i, : len(cols)] = M[i, cols]
-    return idx, w, width
+    return np.ascontiguousarray(idx.T), np.ascontiguousarray(w.T), width
 
 
 class mesh_to_mesh:
