@@ -37,6 +37,7 @@ def _kernel_bytes(name, n, M, ncomp=1):
         'fft_z_solve': 2 * nf * spec,
         'spec_point': (1 + nf) * spec + nf * spec,      # S0 + S[1..M] in, S[1..M] out (in place)
         'spec_point_res': (1 + nf) * spec + 2 * nf * spec,  # ... + the residual spectra out
+        'spec_point_only': (1 + nf) * spec + nf * spec,
         'spec_z_res': (1 + nf) * spec + 2 * nf * spec,      # spectral sweep + first inverse pass in one launch:
         'spec_z': (1 + nf) * spec + 2 * nf * spec,          # S0 + S in, S and the line-transformed field out
         'spec_z_res_spread': (1 + 2 * nf) * spec,           # first sweep after a spread predictor: only S0 is read
@@ -120,6 +121,9 @@ def main():
                     help='> 0: iterate to this residual instead of a fixed number of sweeps (maxiter 50); niter is reported')
     ap.add_argument('--eager-fields', action='store_true',
                     help='store F[1..M] and the predictor copies in every sweep / predict even when nothing reads them')
+    ap.add_argument('--skip-residual', action='store_true',
+                    help="sweeper parameter skip_residual_computation for every stage (the reference's switch for runs with a "
+                         'fixed number of sweeps): no residual is computed; NOT the headline configuration')
     args = ap.parse_args()
 
     import numpy as np
@@ -213,6 +217,8 @@ def main():
         unit = 'trajectory-steps/s'
         if world > 1:
             raise SystemExit('the ensemble shards trivially over GPUs (independent trajectories); run --gpus 1')
+    if args.skip_residual:
+        desc['sweeper_params']['skip_residual_computation'] = ('IT_CHECK', 'IT_FINE', 'IT_DOWN', 'IT_UP', 'IT_COARSE')
     cparams = dict(logger_level=40)
     if args.workload == 'allencahn' and world > 1:
         cparams['predict_type'] = 'pfasst_burnin'
@@ -290,7 +296,7 @@ def main():
                     'frac': ach / HBM_PEAK_GBS, 'traffic': traffic,
                     'algorithmic_bytes_per_launch': kernel_bytes(dom[0], n, M),
                     'ms_per_launch': dom[1][0] / dom[1][1]}
-        in_sweep = ('gather', 'fft_x_fwd', 'fft_y_fwd', 'fft_z_fwd', 'fft_z_solve', 'spec_point', 'spec_point_res', 'spec_z', 'spec_z_res', 'spec_z_spread', 'spec_z_res_spread',
+        in_sweep = ('gather', 'fft_x_fwd', 'fft_y_fwd', 'fft_z_fwd', 'fft_z_solve', 'spec_point', 'spec_point_res', 'spec_point_only', 'spec_z', 'spec_z_res', 'spec_z_spread', 'spec_z_res_spread',
                     'fft_x_norm', 'fft_x_inv_norm',
                     'fft_z_inv', 'fft_y_inv',
                     'fft_x_inv', 'stencil', 'stencil_res', 'res_stencil', 'vdp_sweep', 'vdp_sweep_lazyf')
@@ -305,7 +311,8 @@ def main():
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': f'{wl}{fallback_note}, ' + (f'{K} sweeps/step (restol=-1, maxiter={K})' if args.restol < 0 else f'restol={args.restol:g} (maxiter={K})') + f', dt={dt:g}, '
                                    f'solver={"direct (Fourier)" if args.solver_type == "direct" else "CG rtol 1e-12 on the device"}, spectral_reuse={not args.no_spectral_reuse}, '
-                                   f'deferred_node_fields={not args.eager_fields}',
+                                   f'deferred_node_fields={not args.eager_fields}'
+                                   + (', skip_residual_computation=all stages' if args.skip_residual else ''),
                        'time_parallel': f'{world} time-slice(s), one per GPU, multi-step SDC (Jacobi)'},
             'sdc_iters_per_s': units * sweeps_total / el,
             'niter': niter,

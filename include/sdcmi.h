@@ -93,6 +93,11 @@ int sdc_set_spectral_reuse(sdc_ctx* ctx, int on);
 /* The 3-D sweep evaluates f at all nodes and the node norms of the collocation residual in ONE kernel; a
  * following sdc_residual with the same dt then returns those norms without another pass (default on). */
 int sdc_set_fused_residual(sdc_ctx* ctx, int on);
+/* The sweeper parameter skip_residual_computation (core/sweeper.py:176-179: compute_residual returns at once in the
+ * listed stages).  When it covers every stage that follows a sweep, nobody reads the residual of the new iterate:
+ * with on = 1 a sweep that gathers on the cached transforms then ONLY updates those transforms (one pointwise pass, no
+ * inverse transform at all).  A residual asked for later is still answered, from the cache (sdc_residual). */
+int sdc_set_skip_residual(sdc_ctx* ctx, int on);
 /* Deferred node fields (default on).  The spectral-reuse sweep reads neither F[1..M] nor the M copies a 'spread'
  * predictor makes (core/sweeper.py:140-146): the engine therefore leaves them unwritten until somebody needs
  * them.  sdc_slot_ptr / sdc_upload / sdc_download / sdc_integrate / sdc_end_point / sdc_residual and the

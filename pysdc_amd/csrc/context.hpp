@@ -43,6 +43,7 @@ struct sdc_ctx {
     int expl_kind = SDC_EXPL_NONE;
     bool res_spread = false;  // state = spread predictor of an autonomous f: residual_m = dt |sum_j Q[m][j]| max|f(u0)|
     bool fuse_residual = true;
+    bool skip_residual = false;  // nobody asks for the residual after sweeps (skip_residual_computation)
     // deferred real-space state (sdc_set_deferred): the spectral-reuse sweep reads neither F[1..M] nor the node
     // copies of a spread predictor, so they are only written when somebody asks for them (sdc_materialize)
     bool deferred = true;

@@ -403,12 +403,15 @@ static void launch_spec_z(sdc_ctx* c, SpecArgs& a, size_t lines, int mode) {
 
 // spectral sweep; then either the inverse passes into out[f], or (norms != null) only the node norms of the
 // collocation residual of the new iterate
+// spec_only: the cached transforms are updated and nothing else happens (no residual is wanted, node values stay
+// deferred) - one pointwise pass over the spectra
 template <int N>
-static int spec_sweep_n(sdc_ctx* c, int nf, SpecArgs& a, const FieldPtrs& p, unsigned long long* norms) {
+static int spec_sweep_n(sdc_ctx* c, int nf, SpecArgs& a, const FieldPtrs& p, unsigned long long* norms,
+                        bool spec_only) {
     const int n = c->n;
     const size_t lines = c->ndim == 1 ? 1 : (size_t)(n / 2 + 1) * (c->ndim == 3 ? n : 1);
     if constexpr (SDC_FUSE_SPECZ && N >= 64 && N <= 1024) {  // fused with the first inverse pass (M <= 5)
-        if (nf <= 5) {
+        if (nf <= 5 && !spec_only) {
             {
                 // after a spread predictor all nodes share S0: that launch does not read S (fewer bytes)
                 LaunchTimer lt(c, pname(norms ? (a.spread ? "spec_z_res_spread" : "spec_z_res")
@@ -425,7 +428,7 @@ static int spec_sweep_n(sdc_ctx* c, int nf, SpecArgs& a, const FieldPtrs& p, uns
         }
     }
     {
-        LaunchTimer lt(c, pname(norms ? "spec_point_res" : "spec_point", nf));
+        LaunchTimer lt(c, pname(norms ? "spec_point_res" : (spec_only ? "spec_point_only" : "spec_point"), nf));
         const size_t nmodes = lines * N;
         size_t gblocks = (nmodes + 255) / 256;
         if (gblocks > SDC_SPEC_GRID) gblocks = SDC_SPEC_GRID;
@@ -439,6 +442,7 @@ static int spec_sweep_n(sdc_ctx* c, int nf, SpecArgs& a, const FieldPtrs& p, uns
 #undef SCASE
     }
     HIPCHK(c, hipGetLastError());
+    if (spec_only) return early_end_point_n<N>(c, true);
     if (norms) {  // W holds the residual spectra: the contiguous-axis pass runs first, then the early end value
         constexpr int P = N / fft_elems(N), LPB = z_lines_per_block<N>();
         {
@@ -476,13 +480,14 @@ static int fwd_transform(sdc_ctx* c, int nf, const FieldPtrs& p, cd* dst, size_t
     N_DISPATCH(c, CALL)
 #undef CALL
 }
-static int spec_sweep(sdc_ctx* c, int nf, SpecArgs& a, const FieldPtrs& p, unsigned long long* norms) {
+static int spec_sweep(sdc_ctx* c, int nf, SpecArgs& a, const FieldPtrs& p, unsigned long long* norms,
+                      bool spec_only = false) {
     {
         int rw = ensure_work(c);
         if (rw != SDC_OK) return rw;
         a.W = c->W;
     }
-#define CALL(NN) spec_sweep_n<NN>(c, nf, a, p, norms)
+#define CALL(NN) spec_sweep_n<NN>(c, nf, a, p, norms, spec_only)
     N_DISPATCH(c, CALL)
 #undef CALL
 }
@@ -1092,6 +1097,12 @@ int sdc_set_fused_residual(sdc_ctx* c, int on) {
     return SDC_OK;
 }
 
+int sdc_set_skip_residual(sdc_ctx* c, int on) {
+    if (!c) return SDC_ERR_PARAM;
+    c->skip_residual = on != 0;
+    return SDC_OK;
+}
+
 int sdc_set_unlocked(sdc_ctx* c, int unlocked) {
     if (!c) return SDC_ERR_PARAM;
     c->unlocked = unlocked != 0;
@@ -1458,11 +1469,13 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
         a.ndim = c->ndim;
         a.spread = (!c->spec_valid && c->spec_spread) ? 1 : 0;
         bool coupled = false;
-        const bool norms_only = c->deferred && c->fuse_residual && c->ndim >= 2;
+        // nobody will ask for the residual of this iterate (sdc_set_skip_residual): only the cached transforms move
+        const bool spec_only = c->deferred && c->skip_residual && c->ndim >= 2 && M <= 8;
+        const bool norms_only = !spec_only && c->deferred && c->fuse_residual && c->ndim >= 2;
         for (int m = 0; m < M; ++m) {
             // norms only: nothing is stored in real space - unless the residual FIELDS are wanted (keep_rfields),
             // which then occupy the U[1..M] slab while the iterate itself lives in the cache
-            p.out[m] = (norms_only && !c->keep_rfields) ? nullptr : c->U + (size_t)(m + 1) * c->N;
+            p.out[m] = (spec_only || (norms_only && !c->keep_rfields)) ? nullptr : c->U + (size_t)(m + 1) * c->N;
             a.alpha[m] = dt * c->QI[m + 1][m + 1];
             for (int j = 0; j < M; ++j) {
                 a.gI[m][j] = dt * (c->Q[m + 1][j + 1] - c->QI[m + 1][j + 1]);
@@ -1483,11 +1496,17 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
             HIPCHK(c, hipMemsetAsync(c->res_dev, 0, sizeof(unsigned long long) * 8, c->stream));
         }
         c->spec_gen++;
-        int rc0 = spec_sweep(c, M, a, p, norms_only ? c->res_dev : nullptr);
+        int rc0 = spec_sweep(c, M, a, p, norms_only ? c->res_dev : nullptr, spec_only);
         if (rc0 != SDC_OK) return rc0;
         c->spec_valid = true;
         c->spec_spread = false;
         c->spread_pending = false;
+        if (spec_only) {  // a residual asked for after all comes from the cache (sdc_residual, spectral route)
+            c->u_pending = c->f_pending = true;
+            c->res_valid = false;
+            c->rfields_valid = false;
+            return SDC_OK;
+        }
         if (norms_only) {
             c->u_pending = c->f_pending = true;
             c->res_valid = true;

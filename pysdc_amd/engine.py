@@ -91,6 +91,10 @@ class SweepEngine:
     def set_fused_residual(self, on):
         self._chk(self.lib.sdc_set_fused_residual(self.ctx, int(bool(on))))
 
+    def set_skip_residual(self, on):
+        """no stage after a sweep computes the residual (sweeper parameter skip_residual_computation)"""
+        self._chk(self.lib.sdc_set_skip_residual(self.ctx, int(bool(on))))
+
     def set_deferred(self, on):
         """leave F[1..M] / the spread copies unwritten until they are read (include/sdcmi.h: sdc_set_deferred)"""
         self._chk(self.lib.sdc_set_deferred(self.ctx, int(bool(on))))

@@ -15,13 +15,17 @@ from pysdc_amd.coeffs import CollBase, QDELTA_GENERATORS
 from pysdc_amd.errors import ParameterError
 
 
+# every controller stage that asks for the residual after a sweep or a transfer (controller_nonMPI.py / controller_MPI.py)
+_STAGES_AFTER_SWEEP = {'IT_CHECK', 'IT_FINE', 'IT_DOWN', 'IT_UP', 'IT_COARSE'}
+
+
 class _Pars:
     """pySDC/core/sweeper.py:20-30."""
 
     def __init__(self, pars):
         self.do_coll_update = False
         self.initial_guess = 'spread'
-        self.skip_residual_computation = ()
+        self.skip_residual_computation = ()  # stages in which compute_residual returns at once
         for k, v in pars.items():
             if k != 'collocation_class':
                 setattr(self, k, v)
@@ -101,6 +105,7 @@ class Sweeper:
 
     # ---- engine plumbing ----------------------------------------------------------------------------------
     imex = False
+    _skip_sent = False
 
     def push_coeffs(self, engine):
         qe = getattr(self, 'QE', None)
@@ -243,6 +248,11 @@ class Sweeper:
             raise ParameterError('update_nodes needs values at all nodes (predict first)')
         self._push_forcing()
         L.engine.set_unlocked(True)
+        # skip_residual_computation covering every stage that follows a sweep: the engine then only moves the iterate
+        skip = _STAGES_AFTER_SWEEP <= set(self.params.skip_residual_computation)
+        if skip != self._skip_sent:
+            L.engine.set_skip_residual(skip)
+            self._skip_sent = skip
         L.engine.sweep(L.time, L.dt)
         L._res_cache = None
         L.status.updated = True

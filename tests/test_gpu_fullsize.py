@@ -417,8 +417,8 @@ def test_deferred_state_machine_random_walk(prob, seed):
 
     ops = ['sweep'] * 6 + ['residual'] * 3 + ['end_point', 'end_point_coll', 'get_u', 'get_f', 'put_u0', 'put_um',
                                                'replace_u0', 'advance', 'integrate', 'predict', 'predict_copy', 'get_f0',
-                                               'toggle_reuse', 'toggle_fused', 'tau_on', 'tau_off']
-    state = dict(reuse=True, fused=True)
+                                               'toggle_reuse', 'toggle_fused', 'toggle_skip', 'tau_on', 'tau_off']
+    state = dict(reuse=True, fused=True, skip=False)
     trace = []
     for step in range(60):
         op = ops[rng.integers(len(ops))]
@@ -479,6 +479,9 @@ def test_deferred_state_machine_random_walk(prob, seed):
             state['fused'] = not state['fused']
             for e in engines:
                 e.set_fused_residual(state['fused'])
+        elif op == 'toggle_skip':      # sweeps of the deferring engine stop producing the residual (it may still be asked)
+            state['skip'] = not state['skip']
+            a.set_skip_residual(state['skip'])
         elif op == 'tau_on':
             taus = [rng.standard_normal((n, n, n)) * 1e-3 for _ in range(M)]
             for e in engines:

@@ -218,7 +218,7 @@ def test_allencahn_3d_vs_oracle():
         assert rel_err(sol.get(), Po.solve_system(Po.u_exact(0.0), 1e-3, None, 0.0)) < 1e-13
 
 
-def _rank_thread(world, rank, name, fname, out, errors):
+def _rank_thread(world, rank, name, fname, out, errors, skip_residual=False):
     import traceback
 
     from tests import _fake_dist as FD
@@ -241,6 +241,8 @@ def _rank_thread(world, rank, name, fname, out, errors):
                 desc['space_transfer_class'], desc['space_transfer_params'] = mesh_to_mesh_fft2d, {}
         else:
             desc = description_from(meta)
+        if skip_residual:
+            desc['sweeper_params']['skip_residual_computation'] = ('IT_CHECK', 'IT_FINE', 'IT_DOWN', 'IT_UP', 'IT_COARSE')
         C = controller_dist(dict(logger_level=40, **meta['controller_params']), desc, dist=FD)
         P = C.S.levels[0].prob
         u0 = P.u_init
@@ -300,6 +302,34 @@ def test_time_parallel_controller_on_device_levels(name, fname, size):
         assert all(out[r]['overlap'] for r in range(size))
         if size > 2:
             assert all(out[r]['two_hop'] > 0 for r in range(size))
+
+
+@pytest.mark.parametrize('name,fname,size', [('fixedK_2d_P4', 'runs_relay.npz', 4), ('fixedK_2d_P3', 'runs_relay.npz', 3),
+                                             ('fixedK_3d_P2', 'runs.npz', 2)])
+def test_time_parallel_skip_residual_computation(name, fname, size):
+    """runs with a fixed number of sweeps and skip_residual_computation for every stage: the sweeps only move the cached
+    transforms (no residual, no kept residual fields), the hand-over still travels early - same end values as the
+    reference's run."""
+    import threading
+
+    from tests import _fake_dist as FD
+
+    case = load_cases(fname)[name]
+    world = FD.World(size)
+    out, errors = {}, []
+    threads = [threading.Thread(target=_rank_thread, args=(world, r, name, fname, out, errors, True)) for r in range(size)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors[0]
+    assert len(out) == size
+    times = np.concatenate([out[r]['t'] for r in range(size)])
+    niter = np.concatenate([out[r]['n'] for r in range(size)])
+    assert list(niter[np.argsort(times)]) == list(case['niter'])
+    for r in range(size):
+        assert rel_err(out[r]['uend'], case['uend']) < TOL
+        assert out[r]['overlap']
 
 
 def test_time_parallel_controller_64cubed_matches_serial_emulation():

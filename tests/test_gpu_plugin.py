@@ -564,3 +564,50 @@ def test_predictor_variants_vs_golden(name, fused):
     for k in range(1, meta['nsweeps'] + 1):
         L.sweep.update_nodes()
         check(f'k{k}')
+
+
+SKIP_ALL = ('IT_CHECK', 'IT_FINE', 'IT_DOWN', 'IT_UP', 'IT_COARSE')
+
+
+@pytest.mark.parametrize('kind', ['heat3d', 'heat2d', 'advdiff3d', 'forced2d'])
+def test_skip_residual_computation_moves_only_the_iterate(kind):
+    """skip_residual_computation for every stage (core/sweeper.py:176-179): the residual stays what it was, the
+    iterates and the end value are those of the run that computes it; the engine sweeps with one pointwise pass over
+    the cached transforms (no inverse transform); a residual asked for afterwards is still the right one."""
+    from pysdc_amd import problems as P, sweepers as S
+    from pysdc_amd.controller import controller_nonMPI
+    from pysdc_amd.stats import get_sorted
+
+    pc, sc, pp, sp = {
+        'heat3d': (P.heatNd_unforced, S.generic_implicit, dict(nvars=(32, 32, 32), nu=0.1, freq=(2, 2, 2)), dict(QI='LU')),
+        'heat2d': (P.heatNd_unforced, S.generic_implicit, dict(nvars=(64, 64), nu=0.1, freq=(2, 4)), dict(QI='IE')),
+        'advdiff3d': (P.advectiondiffusionNd_imex, S.imex_1st_order, dict(nvars=(32, 32, 32), nu=0.05, c=0.7, freq=(2, 2, 2)),
+                      dict(QI='LU', QE='EE')),
+        'forced2d': (P.heatNd_forced, S.imex_1st_order, dict(nvars=(64, 64), nu=0.1, freq=(2, 2)), dict(QI='LU', QE='EE')),
+    }[kind]
+    out = {}
+    for skip in (False, True):
+        desc = dict(problem_class=pc, problem_params=dict(pp), sweeper_class=sc,
+                    sweeper_params=dict(num_nodes=3, quad_type='RADAU-RIGHT',
+                                        skip_residual_computation=SKIP_ALL if skip else (), **sp),
+                    level_params=dict(dt=5e-3, restol=-1.0), step_params=dict(maxiter=4))
+        C = controller_nonMPI(1, dict(logger_level=40), desc)
+        L = C.MS[0].levels[0]
+        L.engine.profile_enable(True)
+        uend, stats = C.run(L.prob.u_exact(0.0), 0.0, 3 * 5e-3)
+        prof = L.engine.profile_read()
+        niter = [v for _, v in get_sorted(stats, type='niter', sortby='time')]
+        L.sweep.params.skip_residual_computation = ()
+        L._res_cache = None
+        L.sweep.compute_residual()   # of the last iterate, on demand
+        out[skip] = (uend.get(), niter, L.status.residual, [L.u[m].get() for m in range(1, 4)], prof)
+    a, b = out[False], out[True]
+    assert a[1] == b[1] == [4, 4, 4]
+    assert rel_err(b[0], a[0]) < 1e-13
+    for x, y in zip(a[3], b[3]):
+        assert rel_err(y, x) < 1e-13
+    assert abs(a[2] - b[2]) <= 1e-9 * abs(a[2]) + 1e-15
+    names = {k.split('[')[0] for k in b[4]}
+    assert 'spec_point_only' in names, names
+    assert not names & {'spec_z_res', 'spec_point_res', 'spec_z_res_spread', 'fft_x_norm'}, names
+    assert 'spec_point_only' not in {k.split('[')[0] for k in a[4]}
