@@ -96,6 +96,30 @@ def cpu_baseline(M, dt_ref_n, sample_n=64, target_n=1024, nsweeps=4):
     }
 
 
+def stream_reference(torch, eng, nbytes=1 << 32):
+    """what plain streaming operations reach on THIS GPU (GB/s), measured after the timed region, to read the
+    roofline fraction against: write-only fill, read-only max reduction, device-to-device copy (1 read : 1 write)"""
+    import ctypes as C
+    try:
+        n = nbytes // 8
+        x = torch.empty(n, dtype=torch.float64, device='cuda')
+        y = torch.empty(n, dtype=torch.float64, device='cuda')
+    except Exception:  # noqa: BLE001  (no room left beside the slabs)
+        return None
+    lib, out, res = eng.lib, C.c_double(), {}
+    for name, fn, moved in (('fill', lambda: lib.sdc_vec_fill(None, n, 1.0, x.data_ptr()), nbytes),
+                            ('amax', lambda: lib.sdc_vec_amax(None, n, x.data_ptr(), C.byref(out)), nbytes),
+                            ('copy', lambda: y.copy_(x), 2 * nbytes)):
+        fn()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        res[name] = moved * 5 / (time.perf_counter() - t) / 1e9
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -295,7 +319,8 @@ def main():
             roof = {'kernel': dom[0], 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                     'frac': ach / HBM_PEAK_GBS, 'traffic': traffic,
                     'algorithmic_bytes_per_launch': kernel_bytes(dom[0], n, M),
-                    'ms_per_launch': dom[1][0] / dom[1][1]}
+                    'ms_per_launch': dom[1][0] / dom[1][1],
+                    'stream_reference_gbs': stream_reference(torch, eng)}
         in_sweep = ('gather', 'fft_x_fwd', 'fft_y_fwd', 'fft_z_fwd', 'fft_z_solve', 'spec_point', 'spec_point_res', 'spec_point_only', 'spec_z', 'spec_z_res', 'spec_z_spread', 'spec_z_res_spread',
                     'fft_x_norm', 'fft_x_inv_norm',
                     'fft_z_inv', 'fft_y_inv',
