@@ -560,8 +560,12 @@ def vabs(x):
     return float(np.max(np.abs(x)))
 
 
-def compute_residual(L):
-    """core/sweeper.py:164-215."""
+def compute_residual(L, stage='', skip=()):
+    """core/sweeper.py:164-215; skip = the sweeper parameter skip_residual_computation (:176-179: in the listed stages
+    the residual keeps its value, 0.0 if there is none yet)."""
+    if stage in skip:
+        L.status_residual = 0.0 if L.status_residual is None else L.status_residual
+        return None
     c = L.coll
     res_norm = []
     L.residual = integrate(L)
@@ -618,7 +622,7 @@ def _converged(S):
 
 
 def run_sdc(make_level, u0, t0, Tend, num_procs=1, maxiter=50, mssdc_jac=True, do_coll_update=False,
-            initial_guess='spread', on_sweep=None):
+            initial_guess='spread', on_sweep=None, skip_residual_computation=()):
     """Single-level SDC (num_procs=1) or multi-step SDC (num_procs>1) exactly as the serial
     controller stages them: controller_nonMPI.py:85-167 (time loop, 10*eps guard), :180-224
     (restart_block), :226-295 (send/recv = compute_end_point + copy + f[0] re-evaluation),
@@ -668,9 +672,9 @@ def run_sdc(make_level, u0, t0, Tend, num_procs=1, maxiter=50, mssdc_jac=True, d
             S.L.u[0] = np.array(src.uend)
             S.L.f[0] = S.L.prob.eval_f(S.L.u[0], S.L.time)
 
-    def one_sweep(S):
+    def one_sweep(S, stage):
         sweep(S.L)
-        compute_residual(S.L)
+        compute_residual(S.L, stage, skip_residual_computation)
         if on_sweep is not None:
             on_sweep(S)
 
@@ -686,7 +690,7 @@ def run_sdc(make_level, u0, t0, Tend, num_procs=1, maxiter=50, mssdc_jac=True, d
             for S in running:
                 send(S)
                 recv(S)
-                compute_residual(S.L)
+                compute_residual(S.L, 'IT_CHECK', skip_residual_computation)
             for S in running:
                 if S.iter > 0:
                     S.reshist.append(S.L.status_residual)
@@ -716,13 +720,13 @@ def run_sdc(make_level, u0, t0, Tend, num_procs=1, maxiter=50, mssdc_jac=True, d
                     send(S)
                     recv(S)
                 for S in running:
-                    one_sweep(S)
+                    one_sweep(S, 'IT_FINE')
             for S in running:
                 S.stage = 'IT_CHECK'
         elif stage == 'IT_COARSE':
             for S in running:
                 recv(S)
-                one_sweep(S)
+                one_sweep(S, 'IT_COARSE')
                 send(S)
                 S.stage = 'IT_CHECK'
         else:

@@ -10,7 +10,7 @@ That regenerates the sweep / run / multi-level / Allen-Cahn / dirichlet files.  
 own entry points, switched on by environment variables (or call the function after ``runpy.run_path``):
 GOLDEN_FFT=1 fft_transfer_main (transfer_fft.npz, runs_ac_fft.npz), GOLDEN_RELAY=1 relay_main (runs_relay.npz),
 GOLDEN_CG=1 cg_main (sweeps_cg.npz), GOLDEN_VDPJ=1 vdp_jacobian_main (vdp_jacobian.npz), GOLDEN_DML=1
-dirichlet_ml_main (transfer_dirichlet.npz, runs_ml_dirichlet.npz), GOLDEN_GUESS=1 guess_main (sweeps_guess.npz);
+dirichlet_ml_main (transfer_dirichlet.npz, runs_ml_dirichlet.npz), GOLDEN_GUESS=1 guess_main (sweeps_guess.npz), GOLDEN_SKIP=1 skip_main (runs_skip.npz);
 GOLDEN_ML=0 skips the multi-level block.
 
 ``qmat`` (third-party, absent here) is replaced by oracle/qmat_shim, which forwards to
@@ -682,6 +682,40 @@ def dirichlet_ml_main():
 
 if __name__ == '__main__' and os.environ.get('GOLDEN_DML', '0') == '1':
     dirichlet_ml_main()
+
+
+def skip_main():
+    """runs with the sweeper parameter skip_residual_computation (core/sweeper.py:176-179): every stage (a fixed number
+    of sweeps, the residual stays 0.0) and single stages (the residual of the other stage decides)."""
+    RR = dict(quad_type='RADAU-RIGHT')
+    ALL = ('IT_CHECK', 'IT_FINE', 'IT_DOWN', 'IT_UP', 'IT_COARSE')
+    h2 = dict(nvars=(16, 16), nu=0.1, freq=2, bc='periodic')
+    h3 = dict(nvars=(8, 8, 8), nu=0.1, freq=2, bc='periodic')
+    ad = dict(nvars=64, nu=0.05, c=1.0, freq=2, bc='periodic')
+    cases = []
+    cases.append(run_case('skip_all_2d', 'heat_unforced', h2, 'generic_implicit',
+                          dict(num_nodes=3, QI='LU', skip_residual_computation=ALL, **RR), dict(dt=0.02, restol=-1), 4, 0.0,
+                          0.06, seed=1))
+    cases.append(run_case('skip_all_3d_M5', 'heat_unforced', h3, 'generic_implicit',
+                          dict(num_nodes=5, QI='IE', skip_residual_computation=ALL, **RR), dict(dt=0.01, restol=-1), 4, 0.0,
+                          0.03, seed=2))
+    cases.append(run_case('skip_all_imex', 'advdiff', ad, 'imex_1st_order',
+                          dict(num_nodes=3, QI='LU', QE='EE', skip_residual_computation=ALL, **RR), dict(dt=0.01, restol=-1), 3,
+                          0.0, 0.03, seed=3))
+    cases.append(run_case('skip_all_2d_P3', 'heat_unforced', h2, 'generic_implicit',
+                          dict(num_nodes=3, QI='LU', skip_residual_computation=ALL, **RR), dict(dt=0.02, restol=-1), 3, 0.0,
+                          0.12, num_procs=3, seed=4))
+    cases.append(run_case('skip_fine_2d', 'heat_unforced', h2, 'generic_implicit',
+                          dict(num_nodes=3, QI='LU', skip_residual_computation=('IT_FINE',), **RR), dict(dt=0.02, restol=1e-9), 50,
+                          0.0, 0.06, seed=5))
+    cases.append(run_case('skip_check_2d_P2', 'heat_unforced', h2, 'generic_implicit',
+                          dict(num_nodes=3, QI='LU', skip_residual_computation=('IT_CHECK',), **RR), dict(dt=0.02, restol=1e-9),
+                          50, 0.0, 0.08, num_procs=2, seed=6))
+    save('runs_skip.npz', cases)
+
+
+if __name__ == '__main__' and os.environ.get('GOLDEN_SKIP', '0') == '1':
+    skip_main()
 
 
 def guess_main():

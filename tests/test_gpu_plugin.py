@@ -23,12 +23,14 @@ def description_from(meta, problem_class=None):
     pp = dict(meta['prob_params'])
     if isinstance(pp.get('nvars'), list):
         pp['nvars'] = tuple(pp['nvars'])
+    sp = {k: tuple(v) if isinstance(v, list) else v for k, v in meta['sweeper_params'].items()}  # (lists mean levels)
     return dict(problem_class=problem_class or probs[meta['prob']], problem_params=pp,
-                sweeper_class=sweeps[meta['sweeper']], sweeper_params=dict(meta['sweeper_params']),
+                sweeper_class=sweeps[meta['sweeper']], sweeper_params=sp,
                 level_params=dict(meta['level_params']), step_params=dict(maxiter=meta['maxiter']))
 
 
-RUNS = [('runs.npz', n) for n in load_cases('runs.npz')] + [('runs_dirichlet.npz', n) for n in load_cases('runs_dirichlet.npz')]
+RUNS = ([('runs.npz', n) for n in load_cases('runs.npz')] + [('runs_dirichlet.npz', n) for n in load_cases('runs_dirichlet.npz')]
+        + [('runs_skip.npz', n) for n in load_cases('runs_skip.npz')])
 
 
 @pytest.mark.parametrize('fname,name', RUNS)

@@ -53,7 +53,8 @@ def test_sweep_case(fname, name):
         assert counter.niter == int(case[f'work_{key}'][-1]), key
 
 
-RUN_CASES = [('runs.npz', n) for n in load_cases('runs.npz')] + [('runs_dirichlet.npz', n) for n in load_cases('runs_dirichlet.npz')]
+RUN_CASES = ([('runs.npz', n) for n in load_cases('runs.npz')] + [('runs_dirichlet.npz', n) for n in load_cases('runs_dirichlet.npz')]
+             + [('runs_skip.npz', n) for n in load_cases('runs_skip.npz')])   # skip_residual_computation (core/sweeper.py:176-179)
 
 
 @pytest.mark.parametrize('fname,name', RUN_CASES)
@@ -70,7 +71,8 @@ def test_run_case(fname, name):
     shape = make_level().prob.nvars
     uend, stats = O.run_sdc(make_level, np.array(case['u0']).reshape(shape), meta['t0'], meta['Tend'],
                             num_procs=meta['num_procs'], maxiter=meta['maxiter'],
-                            mssdc_jac=meta['controller_params'].get('mssdc_jac', True))
+                            mssdc_jac=meta['controller_params'].get('mssdc_jac', True),
+                            skip_residual_computation=tuple(meta['sweeper_params'].get('skip_residual_computation', ())))
     assert [n for _, n in stats['niter']] == list(case['niter'])            # bit-exact iteration counts
     np.testing.assert_allclose([t for t, _ in stats['niter']], case['niter_t'], rtol=0, atol=1e-14)
     assert rel_err(uend, case['uend']) < TOL
