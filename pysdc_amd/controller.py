@@ -385,6 +385,7 @@ class controller_dist(_ControllerBase):
         self._overlap = False
         self.relay = os.environ.get('PYSDC_AMD_RELAY', '1') != '0'
         self.two_hop_calls = 0
+        self.bcast_two_hop_calls = 0
 
     # ---- host-side scalars (check_convergence.py:105-160; controller_MPI.py:90,120,142) ---------------------
     def _recv_target(self, L):
@@ -470,7 +471,7 @@ class controller_dist(_ControllerBase):
                 continue
             if self.rank == root:
                 uend[:] = S.levels[0].uend
-            self.dist.broadcast(uend.as_torch(), src=root, group=self.comm)
+            self.broadcast(uend, root)
             active = time < Tend - eps10
             num_active = self._all_sum(active)
             if num_active > 0:
@@ -540,6 +541,52 @@ class controller_dist(_ControllerBase):
         if do_recv:
             self._received(L, inbox)
         self._hook('post_comm', S, level)
+
+    def broadcast(self, buf, root):
+        """buf of rank `root` to every rank of the group (the end value of a block, controller_MPI.py:125-130).
+
+        More than two ranks: scatter + all-gather over the xGMI mesh instead of the library broadcast - the message is
+        cut into size-1 pieces, the root hands piece j to the j-th other rank (its links carry one piece each, all at
+        once), then those ranks exchange their pieces among themselves: two phases in which every link carries
+        1/(size-1) of the message, each one batched group of point-to-point operations.  Bit-identical to a copy."""
+        dist = self.dist
+        t = buf.as_torch()
+        P, r = self.size, self.rank
+        if not self.relay or P <= 2:
+            dist.broadcast(t, src=root, group=self.comm)
+            return
+        t = t.reshape(-1)
+        n = t.numel()
+        others = [k for k in range(P) if k != root]
+        csz = -(-n // len(others))
+
+        def piece(k):   # the piece that travels via rank k
+            j = others.index(k)
+            return t[j * csz:min(n, (j + 1) * csz)]
+
+        self.bcast_two_hop_calls += 1
+        tag = 7000
+        ops = []
+        if r == root:
+            ops = [dist.P2POp(dist.isend, piece(k), k, self.comm, tag) for k in others if piece(k).numel() > 0]
+        elif piece(r).numel() > 0:
+            ops = [dist.P2POp(dist.irecv, piece(r), root, self.comm, tag)]
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        if r == root:
+            return
+        ops = []
+        for k in others:
+            if k == r:
+                continue
+            if piece(r).numel() > 0:
+                ops.append(dist.P2POp(dist.isend, piece(r), k, self.comm, tag + 1))
+            if piece(k).numel() > 0:
+                ops.append(dist.P2POp(dist.irecv, piece(k), k, self.comm, tag + 1))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
 
     def _lockstep(self, size):
         """True when every active rank is known to run the same stage sequence with the same iteration count

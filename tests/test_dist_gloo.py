@@ -50,7 +50,8 @@ def _worker(rank, world, port, name, outdir, fname='runs.npz', relay='1'):
         uend, stats = C.run(u0, meta['t0'], meta['Tend'])
         niter = get_sorted(stats, type='niter', sortby='time')
         np.savez(os.path.join(outdir, f'r{rank}.npz'), uend=np.asarray(uend), t=[t for t, _ in niter],
-                 n=[v for _, v in niter], two_hop=getattr(C, 'two_hop_calls', 0))
+                 n=[v for _, v in niter], two_hop=getattr(C, 'two_hop_calls', 0),
+                 bcast=getattr(C, 'bcast_two_hop_calls', 0))
     finally:
         dist.destroy_process_group()
 
@@ -89,4 +90,5 @@ def test_lockstep_runs_with_two_hop_exchange(name, world, relay):
     for k in range(world):
         assert rel_err(r[k]['uend'], case['uend']) < 1e-13
         assert (int(r[k]['two_hop']) > 0) == (relay == '1')
+        assert (int(r[k]['bcast']) > 0) == (relay == '1')     # the end value of a block: scatter + all-gather
     assert all(np.array_equal(r[0]['uend'], x['uend']) for x in r[1:])

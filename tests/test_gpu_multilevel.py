@@ -249,7 +249,7 @@ def _rank_thread(world, rank, name, fname, out, errors, skip_residual=False):
         u0[:] = case['u0']
         uend, stats = C.run(u0, meta['t0'], meta['Tend'])
         niter = get_sorted(stats, type='niter', sortby='time')
-        out[rank] = dict(uend=uend.get(), t=[t for t, _ in niter], n=[v for _, v in niter], two_hop=C.two_hop_calls,
+        out[rank] = dict(uend=uend.get(), t=[t for t, _ in niter], n=[v for _, v in niter], two_hop=C.two_hop_calls, bcast=C.bcast_two_hop_calls,
                          overlap=C._overlap)
     except Exception:  # noqa: BLE001
         errors.append(traceback.format_exc())
@@ -303,6 +303,7 @@ def test_time_parallel_controller_on_device_levels(name, fname, size):
         assert all(out[r]['overlap'] for r in range(size))
         if size > 2:
             assert all(out[r]['two_hop'] > 0 for r in range(size))
+            assert all(out[r]['bcast'] > 0 for r in range(size))
 
 
 @pytest.mark.parametrize('name,fname,size', [('fixedK_2d_P4', 'runs_relay.npz', 4), ('fixedK_2d_P3', 'runs_relay.npz', 3),
