@@ -613,3 +613,51 @@ def test_skip_residual_computation_moves_only_the_iterate(kind):
     assert 'spec_point_only' in names, names
     assert not names & {'spec_z_res', 'spec_point_res', 'spec_z_res_spread', 'fft_x_norm'}, names
     assert 'spec_point_only' not in {k.split('[')[0] for k in a[4]}
+
+
+@pytest.mark.parametrize('M,quad,QI', [(1, 'RADAU-RIGHT', 'IE'), (2, 'RADAU-RIGHT', 'LU'), (2, 'LOBATTO', 'IE'), (4, 'GAUSS', 'LU'),
+                                       (3, 'RADAU-LEFT', 'LU'), (6, 'RADAU-RIGHT', 'LU'), (7, 'LOBATTO', 'IE'),
+                                       (8, 'RADAU-RIGHT', 'IE'), (8, 'GAUSS', 'LU')])
+@pytest.mark.parametrize('kind', ['heat2d', 'advdiff3d'])
+def test_node_counts_and_quadrature_types_vs_oracle(M, quad, QI, kind):
+    """the smallest and the largest node counts the engine takes (1 .. 8: above 5 the spectral sweep is the pointwise
+    kernel plus separate passes), nodes that include the left end (LOBATTO, RADAU-LEFT: first node = t0) or exclude the
+    right end (GAUSS, RADAU-LEFT: the end value is the collocation update): two steps of 3 sweeps against the oracle
+    driven with the same coefficients."""
+    from oracle import sdc_oracle as O
+    from pysdc_amd import problems as P, sweepers as S
+    from pysdc_amd.controller import controller_nonMPI
+    from pysdc_amd.stats import get_sorted
+    from tests._cases import make_oracle_problem
+
+    if kind == 'heat2d':
+        pc, sc, pp, extra, oname = P.heatNd_unforced, S.generic_implicit, dict(nvars=(32, 32), nu=0.1, freq=(2, 4)), {}, 'heat_unforced'
+    else:
+        pc, sc, pp, extra, oname = (P.advectiondiffusionNd_imex, S.imex_1st_order, dict(nvars=(16, 16, 16), nu=0.05, c=0.7, freq=(2, 2, 2)),
+                                    dict(QE='EE'), 'advdiff')
+    dt = 4e-3
+    desc = dict(problem_class=pc, problem_params=dict(pp), sweeper_class=sc,
+                sweeper_params=dict(num_nodes=M, quad_type=quad, QI=QI, **extra),
+                level_params=dict(dt=dt, restol=-1.0), step_params=dict(maxiter=3))
+    C = controller_nonMPI(1, dict(logger_level=40), desc)
+    L = C.MS[0].levels[0]
+    sw = L.sweep
+    u0 = L.prob.u_exact(0.0)
+    u0h = u0.get() + 1e-3 * np.random.default_rng(M).standard_normal(u0.get().shape)
+    u0[:] = u0h
+    uend, stats = C.run(u0, 0.0, 2 * dt)
+    res = [v for _, v in get_sorted(stats, type='residual_post_iteration', sortby='time')]
+
+    coll = O.Coll(sw.coll.nodes, sw.coll.weights, sw.coll.Qmat, sw.QI, getattr(sw, 'QE', None) if extra else None,
+                  right_is_node=sw.coll.right_is_node, left_is_node=sw.coll.left_is_node)
+    opp = dict(pp)
+    opp['freq'] = pp['freq']
+
+    def make_level():
+        return O.Level(make_oracle_problem(oname, opp), coll, dt, restol=-1.0)
+
+    ref, ostats = O.run_sdc(make_level, u0h, 0.0, 2 * dt, maxiter=3, do_coll_update=bool(sw.params.do_coll_update))
+    assert [n for _, n in ostats['niter']] == [v for _, v in get_sorted(stats, type='niter', sortby='time')] == [3, 3]
+    assert rel_err(uend.get(), ref) < TOL
+    ores = [r for _, hist in ostats['residuals'] for r in hist]
+    np.testing.assert_allclose(res, ores, rtol=1e-6, atol=1e-11)
