@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import tests.test_gpu_fullsize as T
 import tests.test_gpu_plugin as P
 bad = 0
-for n_, seeds in (('128', range(300, 330)), ('256', range(330, 345)), ('64', range(100, 260))):
+for n_, seeds in (("128", range(300, 310)), ("256", range(330, 335)), ("64", range(100, 140))):
   os.environ['PYSDC_FUZZ_N'] = n_
   for seed in seeds:
       for prob in ('heat_unforced', 'advdiff', 'heat_forced'):
@@ -16,6 +16,16 @@ for n_, seeds in (('128', range(300, 330)), ('256', range(330, 345)), ('64', ran
               bad += 1
               print('ENGINE FAIL', n_, prob, seed, str(e)[:400])
 os.environ['PYSDC_FUZZ_N'] = '64'
+for m_, seeds in (('2', range(400, 420)), ('5', range(420, 440)), ('6', range(440, 460)), ('8', range(460, 470))):
+    os.environ['PYSDC_FUZZ_M'] = m_
+    for seed in seeds:
+        for prob in ('heat_unforced', 'advdiff', 'heat_forced'):
+            try:
+                T.test_deferred_state_machine_random_walk(prob, seed)
+            except Exception as e:
+                bad += 1
+                print('ENGINE FAIL M', m_, prob, seed, str(e)[:400])
+os.environ.pop('PYSDC_FUZZ_M')
 for seed in range(100, 200):
     try:
         P.test_plugin_random_walk_deferred_vs_eager(seed)

@@ -384,7 +384,8 @@ def test_deferred_state_machine_random_walk(prob, seed):
     import os
     import torch
 
-    n, M = int(os.environ.get('PYSDC_FUZZ_N', '64')), 3       # (scripts/fuzz_more.py also walks other sizes)
+    n = int(os.environ.get('PYSDC_FUZZ_N', '64'))             # (scripts/fuzz_more.py also walks other sizes and node counts)
+    M = int(os.environ.get('PYSDC_FUZZ_M', '6' if seed >= 10 else '3'))   # above 5 nodes: pointwise spectral kernel + passes
     dt = 0.05 * (64.0 / n) ** 2
     c, qi = _coeffs(M, 'LU')
     qe = None
