@@ -145,6 +145,9 @@ def main():
                     help='> 0: iterate to this residual instead of a fixed number of sweeps (maxiter 50); niter is reported')
     ap.add_argument('--eager-fields', action='store_true',
                     help='store F[1..M] and the predictor copies in every sweep / predict even when nothing reads them')
+    ap.add_argument('--mssdc', default='jacobi', choices=['jacobi', 'gs'],
+                    help='multi-step SDC over the time ranks (--gpus > 1): Jacobi (mssdc_jac=True, the default of the '
+                         'reference: all slices sweep concurrently) or Gauss-Seidel (receive, sweep, blocking send)')
     ap.add_argument('--skip-residual', action='store_true',
                     help="sweeper parameter skip_residual_computation for every stage (the reference's switch for runs with a "
                          'fixed number of sweeps): no residual is computed; NOT the headline configuration')
@@ -243,7 +246,7 @@ def main():
             raise SystemExit('the ensemble shards trivially over GPUs (independent trajectories); run --gpus 1')
     if args.skip_residual:
         desc['sweeper_params']['skip_residual_computation'] = ('IT_CHECK', 'IT_FINE', 'IT_DOWN', 'IT_UP', 'IT_COARSE')
-    cparams = dict(logger_level=40)
+    cparams = dict(logger_level=40, mssdc_jac=args.mssdc == 'jacobi')
     if args.workload == 'allencahn' and world > 1:
         cparams['predict_type'] = 'pfasst_burnin'
     if not use_dist:
@@ -338,7 +341,8 @@ def main():
                                    f'solver={"direct (Fourier)" if args.solver_type == "direct" else "CG rtol 1e-12 on the device"}, spectral_reuse={not args.no_spectral_reuse}, '
                                    f'deferred_node_fields={not args.eager_fields}'
                                    + (', skip_residual_computation=all stages' if args.skip_residual else ''),
-                       'time_parallel': f'{world} time-slice(s), one per GPU, multi-step SDC (Jacobi)'},
+                       'time_parallel': f'{world} time-slice(s), one per GPU, multi-step SDC '
+                                        f'({"Jacobi" if args.mssdc == "jacobi" else "Gauss-Seidel"})'},
             'sdc_iters_per_s': units * sweeps_total / el,
             'niter': niter,
             'work_counters': {k: v.niter for k, v in L.prob.work_counters.items()},
