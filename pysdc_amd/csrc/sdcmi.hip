@@ -1939,8 +1939,17 @@ int sdc_transfer_apply_batch(void* stream, int nfields, int ndim, int n_out, int
         return fail(nullptr, SDC_ERR_PARAM, "bad transfer arguments");
     // separable: one pass per axis (cost ~ ndim * width per point instead of width^ndim), last axis first so that
     // intermediate fields stay as small as possible when prolonging; two scratch fields ping-pong in between
-    static thread_local double* scratch[2] = {nullptr, nullptr};
-    static thread_local size_t scratch_len = 0;
+    struct Scratch {  // per host thread (= per context user), released when the thread ends
+        double* p[2] = {nullptr, nullptr};
+        size_t len = 0;
+        ~Scratch() {
+            for (int k = 0; k < 2; ++k)
+                if (p[k]) (void)hipFree(p[k]);
+        }
+    };
+    static thread_local Scratch sc;
+    double** scratch = sc.p;
+    size_t& scratch_len = sc.len;
     const int nmax = n_out > n_in ? n_out : n_in;
     size_t need = (size_t)nfields;  // the fields are one more (outermost) dimension of every pass
     for (int d = 0; d < ndim; ++d) need *= (size_t)nmax;
