@@ -10,7 +10,7 @@ That regenerates the sweep / run / multi-level / Allen-Cahn / dirichlet files.  
 own entry points, switched on by environment variables (or call the function after ``runpy.run_path``):
 GOLDEN_FFT=1 fft_transfer_main (transfer_fft.npz, runs_ac_fft.npz), GOLDEN_RELAY=1 relay_main (runs_relay.npz),
 GOLDEN_CG=1 cg_main (sweeps_cg.npz), GOLDEN_VDPJ=1 vdp_jacobian_main (vdp_jacobian.npz), GOLDEN_DML=1
-dirichlet_ml_main (transfer_dirichlet.npz, runs_ml_dirichlet.npz), GOLDEN_GUESS=1 guess_main (sweeps_guess.npz), GOLDEN_SKIP=1 skip_main (runs_skip.npz);
+dirichlet_ml_main (transfer_dirichlet.npz, runs_ml_dirichlet.npz), GOLDEN_GUESS=1 guess_main (sweeps_guess.npz), GOLDEN_SKIP=1 skip_main (runs_skip.npz), GOLDEN_RELAY8=1 relay8_main (runs_relay8.npz);
 GOLDEN_ML=0 skips the multi-level block.
 
 ``qmat`` (third-party, absent here) is replaced by oracle/qmat_shim, which forwards to
@@ -682,6 +682,24 @@ def dirichlet_ml_main():
 
 if __name__ == '__main__' and os.environ.get('GOLDEN_DML', '0') == '1':
     dirichlet_ml_main()
+
+
+def relay8_main():
+    """eight time ranks (the node size the benchmark scales to): fixed number of sweeps, two blocks, the second one with
+    four active ranks only; and an all_to_done run."""
+    RR = dict(quad_type='RADAU-RIGHT')
+    h2 = dict(nvars=(16, 16), nu=0.1, freq=2, bc='periodic')
+    sw = dict(num_nodes=3, QI='LU', **RR)
+    cases = []
+    cases.append(run_case('fixedK_2d_P8', 'heat_unforced', h2, 'generic_implicit', sw, dict(dt=0.01, restol=-1), 3, 0.0,
+                          0.12, num_procs=8, seed=11))
+    cases.append(run_case('alltodone_2d_P8', 'heat_unforced', h2, 'generic_implicit', sw, dict(dt=0.01, restol=1e-8), 50,
+                          0.0, 0.08, num_procs=8, controller_params=dict(all_to_done=True), seed=12))
+    save('runs_relay8.npz', cases)
+
+
+if __name__ == '__main__' and os.environ.get('GOLDEN_RELAY8', '0') == '1':
+    relay8_main()
 
 
 def skip_main():

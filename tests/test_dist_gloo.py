@@ -92,3 +92,22 @@ def test_lockstep_runs_with_two_hop_exchange(name, world, relay):
         assert (int(r[k]['two_hop']) > 0) == (relay == '1')
         assert (int(r[k]['bcast']) > 0) == (relay == '1')     # the end value of a block: scatter + all-gather
     assert all(np.array_equal(r[0]['uend'], x['uend']) for x in r[1:])
+
+
+@pytest.mark.parametrize('name', ['fixedK_2d_P8', 'alltodone_2d_P8'])
+def test_eight_ranks_lockstep(name):
+    """eight processes (one node's worth of time ranks): two-hop hand-over with 8 pieces per message, the mesh broadcast
+    with 7, a second block with four active ranks - against the reference's serial run with num_procs=8."""
+    case = load_cases('runs_relay8.npz')[name]
+    world = 8
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(world, _free_port(), name, d, 'runs_relay8.npz', '1'), nprocs=world, join=True)
+        r = [np.load(os.path.join(d, f'r{k}.npz')) for k in range(world)]
+    times = np.concatenate([x['t'] for x in r])
+    niter = np.concatenate([x['n'] for x in r])
+    order = np.argsort(times)
+    assert list(niter[order]) == list(case['niter'])
+    np.testing.assert_allclose(times[order], case['niter_t'], rtol=0, atol=1e-14)
+    for k in range(world):
+        assert rel_err(r[k]['uend'], case['uend']) < 1e-13
+        assert int(r[k]['two_hop']) > 0 and int(r[k]['bcast']) > 0

@@ -272,7 +272,8 @@ def _rank_thread(world, rank, name, fname, out, errors, skip_residual=False):
                                              ('t6a_pfasst_P4', 'runs_ml_dirichlet.npz', 4),
                                              ('forced2d_run_P2', 'runs.npz', 2), ('mssdc_P4_gs', 'runs.npz', 4),
                                              ('dirichlet_heat1d_P2', 'runs_dirichlet.npz', 2),
-                                             ('skip_all_2d_P3', 'runs_skip.npz', 3), ('skip_check_2d_P2', 'runs_skip.npz', 2)])
+                                             ('skip_all_2d_P3', 'runs_skip.npz', 3), ('skip_check_2d_P2', 'runs_skip.npz', 2),
+                                             ('fixedK_2d_P8', 'runs_relay8.npz', 8), ('alltodone_2d_P8', 'runs_relay8.npz', 8)])
 def test_time_parallel_controller_on_device_levels(name, fname, size):
     """controller_dist with DEVICE levels and several ranks on one GPU: the ranks are threads, torch.distributed is
     replaced by an in-process stand-in (tests/_fake_dist.py), everything else - early end value, hand-over posted on
