@@ -335,9 +335,11 @@ def test_time_parallel_skip_residual_computation(name, fname, size):
         assert out[r]['overlap']
 
 
-def test_time_parallel_controller_64cubed_matches_serial_emulation():
-    """three ranks on 64^3 (the fused spectral sweep kernel, norm passes, kept residual fields) through
-    controller_dist with the in-process stand-in, against controller_nonMPI emulating the three processes."""
+@pytest.mark.parametrize('nranks,M', [(3, 3), (8, 5)])
+def test_time_parallel_controller_64cubed_matches_serial_emulation(nranks, M):
+    """three / eight ranks on 64^3 (the fused spectral sweep kernel, norm passes, kept residual fields) through
+    controller_dist with the in-process stand-in, against controller_nonMPI emulating the processes; two blocks, the
+    second one partially filled."""
     import threading
 
     from pysdc_amd.controller import controller_nonMPI
@@ -345,19 +347,20 @@ def test_time_parallel_controller_64cubed_matches_serial_emulation():
     from tests import _fake_dist as FD
 
     meta = dict(prob='heat_unforced', prob_params=dict(nvars=[64, 64, 64], nu=0.1, freq=2), sweeper='generic_implicit',
-                sweeper_params=dict(num_nodes=3, quad_type='RADAU-RIGHT', QI='IE'), level_params=dict(dt=2e-3, restol=-1),
-                maxiter=3, controller_params={}, t0=0.0, Tend=1.2e-2)
+                sweeper_params=dict(num_nodes=M, quad_type='RADAU-RIGHT', QI='IE'), level_params=dict(dt=2e-3, restol=-1),
+                maxiter=3, controller_params={}, t0=0.0, Tend=2e-3 * (2 * nranks - nranks // 2))
     from pysdc_amd.synth import init_field
     from tests.test_gpu_plugin import description_from
 
     u0h = init_field((64, 64, 64), 2, 1e-2, 3)
-    C = controller_nonMPI(3, dict(logger_level=40), description_from(meta))
+    C = controller_nonMPI(nranks, dict(logger_level=40), description_from(meta))
     P = C.MS[0].levels[0].prob
     u0 = P.u_init
     u0[:] = u0h
     ref, rstats = C.run(u0, meta['t0'], meta['Tend'])
     ref = ref.get()
-    world = FD.World(3)
+    del C, P, u0
+    world = FD.World(nranks)
     out, errors = {}, []
 
     def rank_main(rank):
@@ -380,13 +383,13 @@ def test_time_parallel_controller_64cubed_matches_serial_emulation():
             except Exception:  # noqa: BLE001
                 pass
 
-    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(3)]
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(nranks)]
     for t in threads:
         t.start()
     for t in threads:
         t.join(timeout=300)
     assert not errors, errors[0]
-    for r in range(3):
+    for r in range(nranks):
         assert rel_err(out[r][0], ref) < 1e-12
         assert out[r][1] > 0 and out[r][2]
 
