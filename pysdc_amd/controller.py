@@ -698,15 +698,22 @@ class controller_dist(_ControllerBase):
         finally:
             if ctx is not None:
                 ctx.__exit__(None, None, None)
-        self._posted = (reqs, inbox)
+        self._posted = (reqs, inbox, side_stream)
 
     def handover_complete(self):
         S = self.S
         L = S.levels[0]
-        reqs, inbox = self._posted
+        reqs, inbox, side_stream = self._posted
         self._posted = None
         for req in reqs:
             req.wait()
+        if side_stream:
+            # the first hop was completed on the side stream (its piece of the message landed in the inbox there):
+            # everything queued on that stream precedes what the engine's stream does next, whatever streams the
+            # communication library itself uses per peer
+            import torch
+
+            torch.cuda.current_stream().wait_stream(self._comm_stream)
         if self.rank >= 1:
             self._received(L, inbox)
         self._hook('post_comm', S, 0)

@@ -83,6 +83,10 @@ def _get(kind, tensor, src):
     if ev is not None:
         torch.cuda.current_stream().wait_event(ev)
     tensor.copy_(snap)
+    if snap.is_cuda:
+        # the snapshot was allocated on the SENDER's stream: its block must not be handed out again before the copy
+        # above, which runs on this stream, is done
+        snap.record_stream(torch.cuda.current_stream())
 
 
 def send(tensor, dst, group=None, tag=0):

@@ -335,24 +335,29 @@ def test_time_parallel_skip_residual_computation(name, fname, size):
         assert out[r]['overlap']
 
 
-@pytest.mark.parametrize('nranks,M', [(3, 3), (8, 5)])
-def test_time_parallel_controller_64cubed_matches_serial_emulation(nranks, M):
-    """three / eight ranks on 64^3 (the fused spectral sweep kernel, norm passes, kept residual fields) through
+@pytest.mark.parametrize('nranks,M,size', [(3, 3, 64), (8, 5, 64), (4, 5, 256)])
+def test_time_parallel_controller_64cubed_matches_serial_emulation(nranks, M, size):
+    """three / eight ranks on 64^3 and four on 256^3 (the fused spectral sweep kernel, norm passes, kept residual
+    fields; at 256^3 the kernels run long enough for ordering mistakes between the streams to show) through
     controller_dist with the in-process stand-in, against controller_nonMPI emulating the processes; two blocks, the
     second one partially filled."""
+    import os
     import threading
 
     from pysdc_amd.controller import controller_nonMPI
+
+    n = int(os.environ.get('PYSDC_TP_N', size))      # (one-off runs at other sizes: PYSDC_TP_N=512 pytest -k 64cubed;
+    #                                                   scripts/tp_check.py N RANKS M does the same from the shell)
     from pysdc_amd.stats import get_sorted
     from tests import _fake_dist as FD
 
-    meta = dict(prob='heat_unforced', prob_params=dict(nvars=[64, 64, 64], nu=0.1, freq=2), sweeper='generic_implicit',
+    meta = dict(prob='heat_unforced', prob_params=dict(nvars=[n, n, n], nu=0.1, freq=2), sweeper='generic_implicit',
                 sweeper_params=dict(num_nodes=M, quad_type='RADAU-RIGHT', QI='IE'), level_params=dict(dt=2e-3, restol=-1),
                 maxiter=3, controller_params={}, t0=0.0, Tend=2e-3 * (2 * nranks - nranks // 2))
     from pysdc_amd.synth import init_field
     from tests.test_gpu_plugin import description_from
 
-    u0h = init_field((64, 64, 64), 2, 1e-2, 3)
+    u0h = init_field((n, n, n), 2, 1e-2, 3)
     C = controller_nonMPI(nranks, dict(logger_level=40), description_from(meta))
     P = C.MS[0].levels[0].prob
     u0 = P.u_init
