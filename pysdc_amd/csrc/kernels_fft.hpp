@@ -378,18 +378,22 @@ __global__ __launch_bounds__(256) void k_spec_point(SpecArgs a, int n, size_t nm
 #pragma unroll
         for (int m = 0; m < NF; ++m) {
             cd acc = cd{fma(a.cP[m], ph.x, u0h.x), fma(a.cP[m], ph.y, u0h.y)};
+            // real-weighted node sums first, one multiplication by each symbol afterwards (as in k_spec_z)
+            cd tI = cd{0.0, 0.0}, tE = cd{0.0, 0.0};
 #pragma unroll
             for (int q = 0; q < NF; ++q) {
-                const double gi = a.gI[m][q], ge = a.gE[m][q];
-                acc = cfma(cd{gi * lam.x + ge * mu.x, gi * lam.y + ge * mu.y}, old[q], acc);
+                tI = cd{fma(a.gI[m][q], old[q].x, tI.x), fma(a.gI[m][q], old[q].y, tI.y)};
+                tE = cd{fma(a.gE[m][q], old[q].x, tE.x), fma(a.gE[m][q], old[q].y, tE.y)};
             }
             if (a.coupled) {
 #pragma unroll
                 for (int q = 0; q < m; ++q) {
-                    const double ci = a.cI[m][q], ce = a.cE[m][q];
-                    acc = cfma(cd{ci * lam.x + ce * mu.x, ci * lam.y + ce * mu.y}, u[q], acc);
+                    tI = cd{fma(a.cI[m][q], u[q].x, tI.x), fma(a.cI[m][q], u[q].y, tI.y)};
+                    tE = cd{fma(a.cE[m][q], u[q].x, tE.x), fma(a.cE[m][q], u[q].y, tE.y)};
                 }
             }
+            acc = cfma(lam, tI, acc);
+            if (a.lamE) acc = cfma(mu, tE, acc);
             const double al = a.alpha[m];
             u[m] = cmul(acc, cinv_fast(cd{1.0 - al * lam.x, -al * lam.y}));
             a.S[m * a.fstride + g] = u[m];
@@ -400,11 +404,10 @@ __global__ __launch_bounds__(256) void k_spec_point(SpecArgs a, int n, size_t nm
             for (int m = 0; m < NF; ++m) {
                 cd acc = csub(u0h, u[m]);
                 acc = cd{fma(a.cP[m], ph.x, acc.x), fma(a.cP[m], ph.y, acc.y)};
+                cd tR = cd{0.0, 0.0};
 #pragma unroll
-                for (int q = 0; q < NF; ++q) {
-                    const double rq = a.rQ[m][q];
-                    acc = cfma(cd{rq * sym.x, rq * sym.y}, u[q], acc);
-                }
+                for (int q = 0; q < NF; ++q) tR = cd{fma(a.rQ[m][q], u[q].x, tR.x), fma(a.rQ[m][q], u[q].y, tR.y)};
+                acc = cfma(sym, tR, acc);
                 a.W[m * a.fstride + g] = acc;
             }
         }
@@ -437,11 +440,10 @@ __global__ __launch_bounds__(256) void k_spec_residual(SpecArgs a, int n, size_t
         for (int m = 0; m < NF; ++m) {
             cd acc = csub(u0h, u[m]);
             acc = cd{fma(a.cP[m], ph.x, acc.x), fma(a.cP[m], ph.y, acc.y)};
+            cd tR = cd{0.0, 0.0};
 #pragma unroll
-            for (int q = 0; q < NF; ++q) {
-                const double rq = a.rQ[m][q];
-                acc = cfma(cd{rq * sym.x, rq * sym.y}, u[q], acc);
-            }
+            for (int q = 0; q < NF; ++q) tR = cd{fma(a.rQ[m][q], u[q].x, tR.x), fma(a.rQ[m][q], u[q].y, tR.y)};
+            acc = cfma(sym, tR, acc);
             a.W[m * a.fstride + g] = acc;
         }
     }
@@ -546,28 +548,23 @@ __global__ __launch_bounds__(specz_lines<N>() * (N / specz_elems<N>()) * NF,
                     }
                     cd acc = u0h;
                     if (HASP) acc = cd{fma(a.cP[m], inp[it].x, u0h.x), fma(a.cP[m], inp[it].y, u0h.y)};
+                    // the symbols do not depend on the node: form the real-weighted node sums first and multiply by
+                    // lam (mu) once - 2 fused multiply-adds per term instead of 6 operations
+                    cd tI = cd{0.0, 0.0}, tE = cd{0.0, 0.0};
 #pragma unroll
                     for (int q = 0; q < NF; ++q) {
-                        const double gi = a.gI[m][q];
-                        cd coef = cd{gi * lam.x, gi * lam.y};
-                        if (HASE) {
-                            const double ge = a.gE[m][q];
-                            coef = cd{fma(ge, mu.x, coef.x), fma(ge, mu.y, coef.y)};
-                        }
-                        acc = cfma(coef, old[q], acc);
+                        tI = cd{fma(a.gI[m][q], old[q].x, tI.x), fma(a.gI[m][q], old[q].y, tI.y)};
+                        if (HASE) tE = cd{fma(a.gE[m][q], old[q].x, tE.x), fma(a.gE[m][q], old[q].y, tE.y)};
                     }
                     if (a.coupled) {
 #pragma unroll
                         for (int q = 0; q < m; ++q) {
-                            const double ci = a.cI[m][q];
-                            cd coef = cd{ci * lam.x, ci * lam.y};
-                            if (HASE) {
-                                const double ce = a.cE[m][q];
-                                coef = cd{fma(ce, mu.x, coef.x), fma(ce, mu.y, coef.y)};
-                            }
-                            acc = cfma(coef, u[q], acc);
+                            tI = cd{fma(a.cI[m][q], u[q].x, tI.x), fma(a.cI[m][q], u[q].y, tI.y)};
+                            if (HASE) tE = cd{fma(a.cE[m][q], u[q].x, tE.x), fma(a.cE[m][q], u[q].y, tE.y)};
                         }
                     }
+                    acc = cfma(lam, tI, acc);
+                    if (HASE) acc = cfma(mu, tE, acc);
                     const double al = a.alpha[m];
                     u[m] = cmul(acc, cinv_fast(cd{1.0 - al * lam.x, -al * lam.y}));
                     a.S[m * a.fstride + g] = u[m];
@@ -578,11 +575,10 @@ __global__ __launch_bounds__(specz_lines<N>() * (N / specz_elems<N>()) * NF,
                     for (int m = 0; m < NF; ++m) {
                         cd acc = csub(u0h, u[m]);
                         if (HASP) acc = cd{fma(a.cP[m], inp[it].x, acc.x), fma(a.cP[m], inp[it].y, acc.y)};
+                        cd tR = cd{0.0, 0.0};
 #pragma unroll
-                        for (int q = 0; q < NF; ++q) {
-                            const double rq = a.rQ[m][q];
-                            acc = cfma(cd{rq * sym.x, rq * sym.y}, u[q], acc);
-                        }
+                        for (int q = 0; q < NF; ++q) tR = cd{fma(a.rQ[m][q], u[q].x, tR.x), fma(a.rQ[m][q], u[q].y, tR.y)};
+                        acc = cfma(sym, tR, acc);
                         rbuf[m * CH + k] = cscale(acc, a.invN);
                     }
                 } else {
