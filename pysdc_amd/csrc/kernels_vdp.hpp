@@ -12,7 +12,8 @@ struct VdpSweepArgs {
     size_t T;
     double mu, dt, tol;
     int maxiter;
-    double Q[MAXM][MAXM], QI[MAXM][MAXM];
+    double Q[MAXM][MAXM], QI[MAXM][MAXM];  // dt * Qmat, dt * QI (inner MxM blocks): the reference forms dt * Q[m][j]
+                                           // first and multiplies by f afterwards, so the product is made once on the host
     unsigned long long* counters;
     unsigned long long* norms;  // node-wise max of the collocation residual after the sweep, or null
 };
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(256) void k_vdp_sweep(VdpSweepArgs a) {
 #pragma unroll
     for (int m = 0; m < M; ++m) nmax[m] = 0.0;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < T; i += (size_t)gridDim.x * blockDim.x) {
-        const double mu = a.mu, dt = a.dt;
+        const double mu = a.mu;
         const double u00 = a.U[i], u01 = a.U[T + i];
         double f0[M], f1[M], g0[M], g1[M], un0[M], un1[M];
 #pragma unroll
@@ -75,13 +76,13 @@ __global__ __launch_bounds__(256) void k_vdp_sweep(VdpSweepArgs a) {
             double s0 = 0.0, s1 = 0.0;
 #pragma unroll
             for (int j = 0; j < M; ++j) {
-                s0 += dt * a.Q[m][j] * f0[j];
-                s1 += dt * a.Q[m][j] * f1[j];
+                s0 += a.Q[m][j] * f0[j];
+                s1 += a.Q[m][j] * f1[j];
             }
 #pragma unroll
             for (int j = 0; j < M; ++j) {
-                s0 -= dt * a.QI[m][j] * f0[j];
-                s1 -= dt * a.QI[m][j] * f1[j];
+                s0 -= a.QI[m][j] * f0[j];
+                s1 -= a.QI[m][j] * f1[j];
             }
             g0[m] = s0 + u00;
             g1[m] = s1 + u01;
@@ -96,11 +97,11 @@ __global__ __launch_bounds__(256) void k_vdp_sweep(VdpSweepArgs a) {
 #pragma unroll
             for (int j = 0; j < M; ++j) {
                 if (j < m) {
-                    r0 += dt * a.QI[m][j] * f0[j];
-                    r1 += dt * a.QI[m][j] * f1[j];
+                    r0 += a.QI[m][j] * f0[j];
+                    r1 += a.QI[m][j] * f1[j];
                 }
             }
-            const double h = dt * a.QI[m][m];
+            const double h = a.QI[m][m];
             double x1 = LAZYF ? un0[m] : a.U[(size_t)(m + 1) * N + i];
             double x2 = LAZYF ? un1[m] : a.U[(size_t)(m + 1) * N + T + i];
             if (h == 0.0) {
@@ -128,8 +129,8 @@ __global__ __launch_bounds__(256) void k_vdp_sweep(VdpSweepArgs a) {
                 double s0 = 0.0, s1 = 0.0;
 #pragma unroll
                 for (int j = 0; j < M; ++j) {
-                    s0 += dt * a.Q[m][j] * f0[j];
-                    s1 += dt * a.Q[m][j] * f1[j];
+                    s0 += a.Q[m][j] * f0[j];
+                    s1 += a.Q[m][j] * f1[j];
                 }
                 s0 += u00 - un0[m];
                 s1 += u01 - un1[m];

@@ -1389,8 +1389,8 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
         if (a.norms) HIPCHK(c, hipMemsetAsync(c->res_dev, 0, sizeof(unsigned long long) * 8, c->stream));
         for (int m = 0; m < M; ++m)
             for (int j = 0; j < M; ++j) {
-                a.Q[m][j] = c->Q[m + 1][j + 1];
-                a.QI[m][j] = c->QI[m + 1][j + 1];
+                a.Q[m][j] = dt * c->Q[m + 1][j + 1];
+                a.QI[m][j] = dt * c->QI[m + 1][j + 1];
             }
         const int grid = grid_for(a.T, 256);
         // F[1..M] = f(U[1..M]) unless somebody overwrote an F field (force_gather): recompute instead of reading,
