@@ -569,3 +569,39 @@ def test_2048_squared_fourier_sweeps_agree_with_general_path():
     assert np.max(np.abs(ua - ub)) <= 1e-12 * np.max(np.abs(ub))
     for e in engines:
         e.close()
+
+
+@pytest.mark.parametrize('prob', ['heat_unforced', 'advdiff'])
+@pytest.mark.parametrize('nvars', [(512,), (1024,), (512, 512), (1024, 1024), (128, 128, 128)])
+def test_fourier_space_sweeps_agree_with_general_path_in_every_dimension(nvars, prob):
+    """the line-transform kernels of the sizes the 3-D benchmarks use (512, 1024), driven as 1-D and 2-D problems: an
+    engine that defers everything and sweeps in Fourier space against one that stores every field and gathers on the F
+    slab - node values, right-hand sides, residuals and end values after three sweeps."""
+    M, dt = 5, 2e-4
+    c, qi = _coeffs(M, 'LU')
+    qe = None
+    if prob == 'advdiff':
+        from pysdc_amd.coeffs import QDELTA_GENERATORS
+
+        qe = np.zeros_like(c.Qmat)
+        qe[1:, 1:], qe[1:, 0] = QDELTA_GENERATORS['EE'](qGen=c.generator, tLeft=0).genCoeffs(dTau=True)
+    u0 = np.random.default_rng(len(nvars)).standard_normal(nvars)
+    got = []
+    for lazy in (True, False):
+        e = G.engine_for(prob, dict(nvars=nvars, nu=0.1), M)
+        e.set_coeffs(c.Qmat, qi, qe, c.nodes, c.weights)
+        e.set_deferred(lazy)
+        e.set_spectral_reuse(lazy)
+        e.upload(L.SLOT_U, 0, u0)
+        e.predict(0.0, dt)
+        res = []
+        for _ in range(3):
+            e.sweep(0.0, dt)
+            res.append(e.residual(dt, 'full_abs')[0])
+        e.end_point(dt, False)
+        got.append((e.download_u(), e.download_f(), np.array(res), e.download(L.SLOT_UEND)))
+        e.close()
+    a, b = got
+    for x, y in zip(a, b):
+        x, y = np.asarray(x), np.asarray(y)
+        assert np.max(np.abs(x - y)) <= 1e-11 * max(1.0, float(np.max(np.abs(y)))), nvars
