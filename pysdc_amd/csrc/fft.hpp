@@ -10,7 +10,7 @@ typedef double2 cd;
 #define DEVI __device__ __forceinline__
 
 // streaming accesses of the in-place middle-axis pass (every element is touched once): nontemporal loads / stores
-// measured 3 % faster there at 1024^3; slower for the norm pass and neutral for the fused sweep kernel
+// measured 3 % faster there at 1024^3; slower for the norm pass; the fused sweep kernel has its own switch (SDC_SPECZ_NT)
 #ifndef SDC_NT
 #define SDC_NT 1
 #endif

@@ -1,10 +1,10 @@
 #!/bin/bash
 # rebuild the library on the GPU box with experiment macros and run a short bench:
-#   scripts/exp_build.sh TAG N [-D...]
+#   scripts/exp_build.sh TAG N [-D...]        (BENCH_ARGS="--skip-residual" adds bench flags)
 TAG=$1; N=$2; shift; shift
 cd $GRAFT_REPO_ROOT
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC "$@" -o pysdc_amd/libsdcmi.so pysdc_amd/csrc/sdcmi.hip 2>/dev/null || { echo "build failed $TAG"; exit 1; }
-python bench.py --n $N --steps 4 --warmup 1 --no-cpu-baseline > gpurun_out/exp_$TAG.json 2>/dev/null
+python bench.py --n $N --steps 4 --warmup 1 --no-cpu-baseline ${BENCH_ARGS:-} > gpurun_out/exp_$TAG.json 2>/dev/null
 python - <<PY
 import json
 d=json.load(open("gpurun_out/exp_$TAG.json"))
