@@ -143,16 +143,21 @@ __global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_inv(FieldPtr
                     own = edge ? B[i].x : A[i].y + B[i].x;
                     mir = -A[i].y + B[i].x;
                 }
-                lds[LAY::idx(col, k)] = own;
+                // the thread's own rows stay in registers; only the mirrored half crosses threads (through LDS)
+                if (part == 0) r[i].x = own;
+                else r[i].y = own;
                 if (!edge) lds[LAY::idx(col, N - k)] = mir;
             }
         }
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < E; ++i) {
-            const double v = lds[LAY::idx(col, j + i * P)];
-            if (part == 0) r[i].x = v;
-            else r[i].y = v;
+            const int k = j + i * P;
+            if (k > N / 2) {
+                const double v = lds[LAY::idx(col, k)];
+                if (part == 0) r[i].x = v;
+                else r[i].y = v;
+            }
         }
         __syncthreads();
     }
