@@ -151,7 +151,7 @@ class GenericNDimFinDiff(Problem):
         if solver_type not in ('direct', 'CG', 'GMRES'):
             raise ProblemError(f'solver type "{solver_type}" not known in generic advection-diffusion implementation!')
         super().__init__(init=(nvars[0] if ndim == 1 else nvars, None, np.dtype('float64')))
-        dx, xvalues = fd.get_1d_grid(size=nvars[0], bc=bc, left_boundary=0.0, right_boundary=1.0)
+        dx, xvalues = fd.grid_1d(size=nvars[0], bc=bc, left_boundary=0.0, right_boundary=1.0)
         self._stencil = fd.periodic_operator_stencil(derivative, order, stencil_type, dx, coeff)
         self.xvalues = xvalues
         # dirichlet-zero: the engine works on the odd extension of length 2(n+1) (include/sdcmi.h: sdc_odd_mirror)

@@ -6,7 +6,7 @@ sys.path.insert(0, '.')
 from pysdc_amd import lib as L
 from pysdc_amd.engine import SweepEngine
 from pysdc_amd.coeffs import CollBase, QDELTA_GENERATORS
-from pysdc_amd.fd import periodic_operator_stencil, get_1d_grid
+from pysdc_amd.fd import periodic_operator_stencil, grid_1d
 print('imports', time.time() - t0, flush=True)
 
 
@@ -18,7 +18,7 @@ def mk(nvars, M=5, QI='IE'):
     qi = np.zeros_like(c.Qmat)
     qi[1:, 1:] = QDELTA_GENERATORS[QI](qGen=c.generator, tLeft=0).genCoeffs()
     e.set_coeffs(c.Qmat, qi, None, c.nodes, c.weights)
-    dx, _ = get_1d_grid(nvars[0], 'periodic')
+    dx, _ = grid_1d(nvars[0], 'periodic')
     t = time.time()
     e.set_stencil(0, *periodic_operator_stencil(2, 2, 'center', dx, 0.1))
     print('  set_stencil', time.time() - t, flush=True)

@@ -3,7 +3,7 @@ import numpy as np
 
 from pysdc_amd import lib as L
 from pysdc_amd.engine import SweepEngine
-from pysdc_amd.fd import periodic_operator_stencil, get_1d_grid
+from pysdc_amd.fd import periodic_operator_stencil, grid_1d
 
 
 def norm_nvars(nv):
@@ -14,7 +14,7 @@ def profile_for(nvars, freq):
     """prod_i sin(pi k_i x_i) on the reference's grid orientation (generic_ND_FD.py:171-180)."""
     ndim = len(nvars)
     freq = (freq,) * ndim if isinstance(freq, int) else tuple(freq)
-    _, x = get_1d_grid(nvars[0], 'periodic')
+    _, x = grid_1d(nvars[0], 'periodic')
     if ndim == 1:
         return np.sin(np.pi * freq[0] * x)
     if ndim == 2:
@@ -31,7 +31,7 @@ def forcing_g(nu, freq, ndim, t):
 def engine_for(prob, pp, M):
     """engine configured for one of the oracle problem kinds (periodic only)."""
     nvars = norm_nvars(pp['nvars'])
-    dx, _ = get_1d_grid(nvars[0], 'periodic')
+    dx, _ = grid_1d(nvars[0], 'periodic')
     order = pp.get('order', 2)
     if prob == 'heat_unforced':
         e = SweepEngine(nvars, M, 1)

@@ -10,7 +10,8 @@ That regenerates the sweep / run / multi-level / Allen-Cahn / dirichlet files.  
 own entry points, switched on by environment variables (or call the function after ``runpy.run_path``):
 GOLDEN_FFT=1 fft_transfer_main (transfer_fft.npz, runs_ac_fft.npz), GOLDEN_RELAY=1 relay_main (runs_relay.npz),
 GOLDEN_CG=1 cg_main (sweeps_cg.npz), GOLDEN_VDPJ=1 vdp_jacobian_main (vdp_jacobian.npz), GOLDEN_DML=1
-dirichlet_ml_main (transfer_dirichlet.npz, runs_ml_dirichlet.npz), GOLDEN_GUESS=1 guess_main (sweeps_guess.npz), GOLDEN_SKIP=1 skip_main (runs_skip.npz), GOLDEN_RELAY8=1 relay8_main (runs_relay8.npz);
+dirichlet_ml_main (transfer_dirichlet.npz, runs_ml_dirichlet.npz), GOLDEN_GUESS=1 guess_main (sweeps_guess.npz), GOLDEN_SKIP=1 skip_main (runs_skip.npz), GOLDEN_RELAY8=1 relay8_main (runs_relay8.npz),
+GOLDEN_BIG3D=1 big3d_main (sweeps_big3d.npz), GOLDEN_CFG5=1 cfg5_main (runs_cfg5.npz);
 GOLDEN_ML=0 skips the multi-level block.
 
 ``qmat`` (third-party, absent here) is replaced by oracle/qmat_shim, which forwards to
@@ -766,3 +767,66 @@ def guess_main():
 
 if __name__ == '__main__' and os.environ.get('GOLDEN_GUESS', '0') == '1':
     guess_main()
+
+
+def _subsample(a):
+    """every 4th point per axis at staggered offsets: 16^3 of a 64^3 field (keeps a big-grid fixture small)"""
+    a = np.asarray(a)
+    return a[..., 1::4, 2::4, 3::4].copy()
+
+
+def big3d_main():
+    """the bench's data flow pinned to the reference at a size where the fused kernels run (n >= 64): heat 3-D 64^3,
+    M=5, IE, solver_type='CG' (generic_ND_FD.py:252-260; the reference's SuperLU solve is not feasible at this size),
+    stiffness dt*nu*12/dx^2 = 315 like the headline workload.  Full fields would be 20 MB per snapshot, so node values
+    are stored on a 16^3 subsample together with the max / l2 norms of the full fields; u0 and the end values are full.
+    Plus a two-step run to restol (iteration counts) with QI=LU."""
+    RR = dict(quad_type='RADAU-RIGHT')
+    nv = (64, 64, 64)
+    pp = dict(nvars=nv, nu=0.1, freq=2, order=2, bc='periodic', solver_type='CG', lintol=1e-12, liniter=1000)
+    dt = 1e-3 * (512 / 64) ** 2
+    full = sweep_case('cg64_heat3d_M5_IE', 'heat_unforced', pp, 'generic_implicit', dict(num_nodes=5, QI='IE', **RR),
+                      dt, t0=0.0, nsweeps=3, seed=0, u0_kind='exact')
+    out = {}
+    for k, v in full.items():
+        if k.endswith('_u') or k.endswith('_f'):
+            out[k + '_sub'] = _subsample(v)
+            out[k + '_max'] = np.max(np.abs(v.reshape(v.shape[0], -1)), axis=1)
+            out[k + '_l2'] = np.sqrt(np.sum(v.reshape(v.shape[0], -1) ** 2, axis=1))
+        elif '_uend_' in k and k != 'k3_uend_0':
+            out[k + '_sub'] = _subsample(v)
+        else:
+            out[k] = v
+    cases = [out]
+    run = run_case('cg64_heat3d_run_LU', 'heat_unforced', pp, 'generic_implicit', dict(num_nodes=5, QI='LU', **RR),
+                   dict(dt=dt, restol=1e-9), 50, 0.0, 2 * dt, seed=0)
+    assert np.array_equal(run['u0'], full['u0'])
+    del run['u0']  # same input as the sweep case
+    cases.append(run)
+    save('sweeps_big3d.npz', cases)
+
+
+if __name__ == '__main__' and os.environ.get('GOLDEN_BIG3D', '0') == '1':
+    big3d_main()
+
+
+def cfg5_main():
+    """BASELINE config 5 at its stated resolution, pinned through the reference's 2-D problem: allencahn2d_imex
+    256^2 / 128^2, two levels, M=3 on both, mesh_to_mesh iorder 6 / rorder 2, dt=1e-3 - MLSDC (1 process) and PFASST with 8
+    processes (controller_nonMPI, pfasst_burnin).  A 3-D run whose initial value does not depend on z must reproduce
+    these planes (the 3-D spectral Laplacian and the tensor-product transfer act as their 2-D counterparts on it)."""
+    from pySDC.implementations.problem_classes.AllenCahn_2D_FFT import allencahn2d_imex
+
+    PROBS['allencahn2d'] = allencahn2d_imex
+    RR = dict(quad_type='RADAU-RIGHT')
+    pp = dict(nvars=[(256, 256), (128, 128)], nu=2, eps=0.04, radius=0.25)
+    base = dict(prob='allencahn2d', pp=pp, sweeper='imex_1st_order', sw=dict(num_nodes=3, QI='LU', QE='EE', **RR),
+                lp=dict(dt=1e-3, restol=1e-8, nsweeps=1), maxiter=50, t0=0.0, seed=5)
+    cases = [ml_run_case('cfg5_ac2d_mlsdc', num_procs=1, Tend=2e-3, **base),
+             ml_run_case('cfg5_ac2d_pfasst_P8', num_procs=8, Tend=8e-3,
+                         controller_params=dict(predict_type='pfasst_burnin'), **base)]
+    save('runs_cfg5.npz', cases)
+
+
+if __name__ == '__main__' and os.environ.get('GOLDEN_CFG5', '0') == '1':
+    cfg5_main()

@@ -1,8 +1,7 @@
 """Host-side coefficient module (pysdc_amd/coeffs.py) against the property tests the reference applies at
 the qmat boundary: tests/test_collocation.py:15-120, tests/test_sweepers/test_preconditioners.py:15-207,
 tests/test_Q_transfer.py, and closed-form Radau-IIA tableaux / the literal node values in
-tutorial/step_7/D_pySDC_with_PyTorch.py:46.  Also checks the values against the coefficient matrices
-stored in the golden files."""
+tutorial/step_7/D_pySDC_with_PyTorch.py:46.  Literal tableaux from the literature pin the values independently of this repository."""
 import numpy as np
 import pytest
 
@@ -120,7 +119,59 @@ def test_interpolation_matrix_order():
             assert np.max(np.abs(R @ fine.nodes**p - coarse.nodes**p)) < 5e-15
 
 
-def test_matches_golden_coefficients():
+def test_literal_tableaux():
+    """closed-form collocation tableaux from the literature (Hairer & Wanner, Solving ODEs II, IV.5: Gauss = Kuntzmann-
+    Butcher, Radau IIA, Lobatto IIIA) - values no part of this repository computed."""
+    s3, s15 = np.sqrt(3), np.sqrt(15)
+    tol = dict(rtol=0, atol=5e-16)
+    c = CollBase(2, 0, 1, 'LEGENDRE', 'RADAU-RIGHT')
+    np.testing.assert_allclose(c.nodes, [1 / 3, 1], **tol)
+    np.testing.assert_allclose(c.Qmat[1:, 1:], [[5 / 12, -1 / 12], [3 / 4, 1 / 4]], **tol)
+    np.testing.assert_allclose(qd(c, 'LU'), [[5 / 12, 0], [3 / 4, 2 / 5]], **tol)  # U^T of Q^T = L U
+    np.testing.assert_allclose(qd(c, 'IE'), [[1 / 3, 0], [1 / 3, 2 / 3]], **tol)
+    np.testing.assert_allclose(qd(c, 'IEpar'), [[1 / 3, 0], [0, 1]], **tol)
+    c = CollBase(2, 0, 1, 'LEGENDRE', 'GAUSS')
+    np.testing.assert_allclose(c.nodes, [1 / 2 - s3 / 6, 1 / 2 + s3 / 6], **tol)
+    np.testing.assert_allclose(c.Qmat[1:, 1:], [[1 / 4, 1 / 4 - s3 / 6], [1 / 4 + s3 / 6, 1 / 4]], **tol)
+    np.testing.assert_allclose(c.weights, [1 / 2, 1 / 2], **tol)
+    assert c.order == 4 and not c.right_is_node and not c.left_is_node
+    c = CollBase(3, 0, 1, 'LEGENDRE', 'GAUSS')
+    np.testing.assert_allclose(c.nodes, [1 / 2 - s15 / 10, 1 / 2, 1 / 2 + s15 / 10], **tol)
+    np.testing.assert_allclose(c.Qmat[1:, 1:], [[5 / 36, 2 / 9 - s15 / 15, 5 / 36 - s15 / 30],
+                                                [5 / 36 + s15 / 24, 2 / 9, 5 / 36 - s15 / 24],
+                                                [5 / 36 + s15 / 30, 2 / 9 + s15 / 15, 5 / 36]], **tol)
+    np.testing.assert_allclose(c.weights, [5 / 18, 4 / 9, 5 / 18], **tol)
+    c = CollBase(3, 0, 1, 'LEGENDRE', 'LOBATTO')
+    np.testing.assert_allclose(c.nodes, [0, 1 / 2, 1], **tol)
+    np.testing.assert_allclose(c.Qmat[1:, 1:], [[0, 0, 0], [5 / 24, 1 / 3, -1 / 24], [1 / 6, 2 / 3, 1 / 6]], **tol)
+    assert c.order == 4 and c.right_is_node and c.left_is_node
+    s5 = np.sqrt(5)
+    c = CollBase(4, 0, 1, 'LEGENDRE', 'LOBATTO')
+    np.testing.assert_allclose(c.nodes, [0, (5 - s5) / 10, (5 + s5) / 10, 1], **tol)
+    np.testing.assert_allclose(c.Qmat[1:, 1:], [[0, 0, 0, 0],
+                                                [(11 + s5) / 120, (25 - s5) / 120, (25 - 13 * s5) / 120, (-1 + s5) / 120],
+                                                [(11 - s5) / 120, (25 + 13 * s5) / 120, (25 + s5) / 120, (-1 - s5) / 120],
+                                                [1 / 12, 5 / 12, 5 / 12, 1 / 12]], **tol)
+    c = CollBase(2, 0, 1, 'LEGENDRE', 'RADAU-LEFT')
+    np.testing.assert_allclose(c.nodes, [0, 2 / 3], **tol)
+    np.testing.assert_allclose(c.Qmat[1:, 1:], [[0, 0], [1 / 3, 1 / 3]], **tol)
+    np.testing.assert_allclose(c.weights, [1 / 4, 3 / 4], **tol)
+    # the five Radau IIA nodes of the headline configuration (RADAU5-family tables, ten digits)
+    c = CollBase(5, 0, 1, 'LEGENDRE', 'RADAU-RIGHT')
+    np.testing.assert_allclose(c.nodes, [0.0571041961, 0.2768430136, 0.5835904324, 0.8602401357, 1.0], rtol=0,
+                               atol=5e-11)
+    np.testing.assert_allclose(c.weights, [0.1437135608, 0.2813560151, 0.3118265230, 0.2231039011, 0.04], rtol=0,
+                               atol=5e-11)
+    assert c.order == 9
+    # equidistant (Newton-Cotes) nodes: Simpson's rule
+    c = CollBase(3, 0, 1, 'EQUID', 'LOBATTO')
+    np.testing.assert_allclose(c.weights, [1 / 6, 2 / 3, 1 / 6], **tol)
+
+
+def test_golden_files_carry_the_coefficients_they_were_made_with():
+    """not a pin of coeffs.py (the goldens' matrices came through it, as the qmat stand-in of the generating run) - a
+    guard that a later change to coeffs.py does not silently drift from the matrices the stored reference outputs
+    belong to."""
     for fname in ('sweeps_heat.npz', 'sweeps_imex.npz', 'runs.npz'):
         for name, case in load_cases(fname).items():
             sp = case['meta']['sweeper_params']

@@ -137,3 +137,65 @@ def test_vdp_solve_jacobian_vs_reference():
     for i in range(g['u'].shape[1]):
         got = P.solve_jacobian(g['rhs'][:, i], float(g['dt']), g['u'][:, i])
         assert np.array_equal(got, g['out'][:, i])
+
+
+def _big3d_level(case, spectral):
+    meta = case['meta']
+    pp = dict(meta['prob_params'])
+    pp['nvars'] = tuple(pp['nvars'])
+    if spectral:
+        pp.pop('solver_type')
+
+        class Prob(O.HeatUnforced):  # exact solve in Fourier space (what the device does; SuperLU is minutes at 64^3)
+            def solve_system(self, rhs, factor, u0, t):
+                return O.spectral_solve(self, rhs, factor)
+
+        prob = Prob(**pp)
+    else:
+        prob = O.HeatUnforced(**pp)
+    return prob, make_oracle_coll(case)
+
+
+@pytest.mark.parametrize('spectral', [False, True])
+def test_big3d_sweeps_vs_reference(spectral):
+    """64^3, M=5, stiffness of the headline workload: the oracle with the reference's CG follows the reference to
+    rounding (CG counts identical); with the exact Fourier solve it differs by the reference's CG error only - the
+    budget the GPU tests of the fused kernels (tests/test_gpu_configs.py) have to allow for."""
+    case = load_cases('sweeps_big3d.npz')['cg64_heat3d_M5_IE']
+    meta = case['meta']
+    prob, coll = _big3d_level(case, spectral)
+    L = O.Level(prob, coll, meta['dt'])
+    L.time = meta['t0']
+    L.u[0] = np.array(case['u0'])
+    O.predict(L, 'spread')
+    tol_u, tol_f = (1e-10, 1e-9) if spectral else (1e-12, 1e-11)
+    sub = lambda a: np.asarray(a)[..., 1::4, 2::4, 3::4]  # noqa: E731
+    for k in range(0, meta['nsweeps'] + 1):
+        if k:
+            O.sweep(L)
+        u, f = np.stack(L.u), np.stack(L.f)
+        assert rel_err(sub(u), case[f'k{k}_u_sub']) < tol_u, k
+        assert rel_err(sub(f), case[f'k{k}_f_sub']) < tol_f, k
+        np.testing.assert_allclose(np.sqrt(np.sum(u.reshape(6, -1) ** 2, axis=1)), case[f'k{k}_u_l2'], rtol=tol_u)
+        O.compute_residual(L)
+        ref = float(case[f'k{k}_res_full_abs'])
+        assert abs(L.status_residual - ref) <= 1e-8 * abs(ref), k
+    O.compute_end_point(L, False)
+    assert rel_err(L.uend, case['k3_uend_0']) < tol_u
+    if not spectral:
+        assert prob.work_counters['CG'].niter == int(case['work_CG'][-1])
+
+
+def test_big3d_run_vs_reference_with_exact_solve():
+    """two steps to restol 1e-9 at 64^3: the exact Fourier solve reproduces the iteration counts of the reference's
+    CG(1e-12) run and its end value to the CG error (what tests/test_gpu_configs.py asks of the device path)."""
+    cases = load_cases('sweeps_big3d.npz')
+    rc = cases['cg64_heat3d_run_LU']
+    meta = rc['meta']
+    prob, coll = _big3d_level(rc, True)
+    uend, stats = O.run_sdc(lambda: O.Level(prob, coll, meta['level_params']['dt'], restol=meta['level_params']['restol']),
+                            np.array(cases['cg64_heat3d_M5_IE']['u0']), meta['t0'], meta['Tend'], maxiter=meta['maxiter'])
+    assert [n for _, n in stats['niter']] == list(rc['niter'])
+    assert rel_err(uend, rc['uend']) < 1e-11
+    res = [r for _, hist in stats['residuals'] for r in hist]
+    np.testing.assert_allclose(res, rc['res'], rtol=1e-5, atol=5e-12)
