@@ -81,7 +81,10 @@ def test_fused_3d_sweep_vs_reference_64(deferred):
             e.end_point(dt, False)
             assert rel_err(_sub(e.download(L.SLOT_UEND)), case[f'k{k}_uend_0_sub']) < TOL
     names = {k.split('[')[0] for k in e.profile_read()}
-    assert {'spec_z_res', 'fft_y_inv', 'fft_x_norm'} <= names, names      # the fused Fourier-space kernels did run
+    if deferred:
+        assert {'spec_z_res', 'fft_y_inv', 'fft_x_norm'} <= names, names  # the fused Fourier-space kernels did run
+    else:
+        assert {'fft_y_inv', 'fft_x_inv'} <= names and 'fft_x_fwd[5]' not in e.profile_read(), names  # spectral reuse
     for k in (meta['nsweeps'],):
         check_fields(f'k{k}')           # node fields brought back to real space on demand (or stored, eager)
         e.end_point(dt, True)           # collocation update
