@@ -167,21 +167,27 @@ class hip_mesh:
         tmp[:] = other
         return tmp
 
+    def _constant(self, value):
+        """a field filled with one value, made on the device (no host array, no PCIe)"""
+        tmp = self._new_like()
+        _chk(L.load().sdc_vec_fill(None, self.size, float(value), tmp.ptr))
+        return tmp
+
     def __add__(self, o):
         if np.isscalar(o):
-            o = self._coerce(np.full(self.shape, float(o)))
+            o = self._constant(o)
         return self._axpby(1.0, self, 1.0, self._coerce(o), self._new_like())
 
     __radd__ = __add__
 
     def __sub__(self, o):
         if np.isscalar(o):
-            o = self._coerce(np.full(self.shape, float(o)))
+            o = self._constant(o)
         return self._axpby(1.0, self, -1.0, self._coerce(o), self._new_like())
 
     def __rsub__(self, o):
         if np.isscalar(o):
-            o = self._coerce(np.full(self.shape, float(o)))
+            o = self._constant(o)
         return self._axpby(-1.0, self, 1.0, self._coerce(o), self._new_like())
 
     def __mul__(self, a):

@@ -117,7 +117,162 @@ class SlabList:
         self._valid = [False] * self._len
 
 
-class Level:
+class DeviceBacked:
+    """Device side of one level: the SweepEngine, the slab-backed ``u / f / tau`` lists, the end-value view and the
+    caches the sweeper keeps.  ``Level`` below IS one; for a level object of another framework (the reference's own
+    ``pySDC.core.level.Level``: plain Python lists, frozen attribute set, core/level.py:42-131) the sweeper keeps a
+    ``ForeignLevelState`` beside it."""
+
+    def _init_device_state(self):
+        self._engine_obj = None
+        self._u = self._f = self._tau = None
+        self._uend_valid = False
+        self._uend_view = None
+        self._res_cache = None
+
+    # what the two flavours provide
+    def _db_prob(self):
+        raise NotImplementedError
+
+    def _db_sweep(self):
+        raise NotImplementedError
+
+    @property
+    def engine(self):
+        if self._engine_obj is None:
+            P, M = self._db_prob(), self._db_sweep().coll.num_nodes
+            nvars = getattr(P, 'nvars', None)
+            if nvars is None:
+                raise ParameterError('problem does not define nvars: cannot create device slabs')
+            self._engine_obj = SweepEngine(getattr(P, 'engine_nvars', nvars), M, getattr(P, 'ncomp', 1))
+            P.bind_engine(self._engine_obj)
+            self._db_sweep().push_coeffs(self._engine_obj)
+        return self._engine_obj
+
+    def _lists(self):
+        if self._u is None:
+            M = self._db_sweep().coll.num_nodes
+            imex = getattr(self._db_prob(), 'ncomp', 1) == 2
+            self._u = SlabList(self, Lb.SLOT_U, M + 1)
+            self._f = SlabList(self, Lb.SLOT_F, M + 1, imex=imex)
+            self._tau = SlabList(self, Lb.SLOT_TAU, M)
+
+    def _uend_slab_view(self):
+        if self._uend_view is None:
+            e = self.engine
+            self._uend_view = hip_mesh.view(e.ptr(Lb.SLOT_UEND) + 8 * self._view_offset(), self._field_shape(), keep=e,
+                                            on_write=lambda: self._touched(Lb.SLOT_UEND, 0))
+        return self._uend_view
+
+    def _field_shape(self):
+        shape = self._db_prob().init[0]
+        return (int(shape),) if np.isscalar(shape) else tuple(shape)
+
+    def _view_offset(self):
+        return int(getattr(self._db_prob(), 'view_offset', 0))
+
+    def _activate_tau(self):
+        e = self.engine
+        e.set_tau_active(True)
+        e.vec_fill(e.N * e.M, 0.0, e.ptr(Lb.SLOT_TAU, 0))
+
+    def _touched(self, slot=None, m=None):
+        """device state was written outside the engine's own sweep calls: drop the cached residual and tell
+        the engine which cached transforms are stale (include/sdcmi.h: sdc_invalidate_spectra)."""
+        self._res_cache = None
+        e = self._engine_obj
+        if e is None:
+            return
+        if self._view_offset() and slot is not None:
+            # dirichlet-zero: the interior was written through a view - rebuild the odd extension of that field
+            n = self._field_shape()[0]
+            comps = range(e.ncomp) if slot == Lb.SLOT_F else (0,)
+            for comp in comps:
+                Lb.check(e.lib.sdc_odd_mirror(e.ctx, e.ptr(slot, m if slot != Lb.SLOT_UEND else 0, comp), n), e.ctx)
+        if slot == Lb.SLOT_U:
+            e.invalidate_spectra(1 if m == 0 else 2)
+        elif slot == Lb.SLOT_F:
+            if m != 0:
+                e.invalidate_spectra(4)
+        elif slot == Lb.SLOT_TAU:
+            # a changed FAS correction changes the residual and the gathered right-hand sides, whoever wrote it
+            e.invalidate_spectra(16)
+        elif slot == Lb.SLOT_UEND:
+            e.invalidate_spectra(8)
+        elif slot is None:
+            e.invalidate_spectra(15)
+
+    # hooks of the fused sweeper methods (the foreign flavour re-adopts the host's lists here)
+    def sync_in(self):
+        return self
+
+    def publish_uend(self):
+        self._uend_valid = True
+
+    def publish_residual_norms(self, norms):
+        self.residual = list(norms)
+
+
+class ForeignLevelState(DeviceBacked):
+    """Device state kept by a pysdc_amd sweeper for a level object that is NOT a pysdc_amd.level.Level - in
+    particular the reference's ``pySDC.core.level.Level`` inside the reference's ``Step`` / controllers.
+
+    That level owns plain lists ``u, f, tau`` which ``reset_level`` replaces at every block (core/level.py:110-131),
+    and the controller / transfer classes assign owning datatype objects into them (``core/step.py:271``,
+    ``controller_nonMPI.py:282-284``, ``core/base_transfer.py:93-251``).  ``sync_in`` - called first thing by every
+    fused sweeper method - replaces a plain list it finds by the slab-backed list (ordinary attribute assignment,
+    allowed on the frozen class because the attribute exists) after copying the entries the host has put there
+    into the slab; from then on assignments through ``L.u[m] = x`` land in device slabs like on a product Level.
+    ``L.uend`` receives an OWNING copy (stock hooks keep references to it, hooks/log_solution.py:34-60)."""
+
+    def __init__(self, host, sweeper):
+        self.host = host
+        self._sweeper = sweeper
+        self._init_device_state()
+
+    def _db_prob(self):
+        return self.host.prob
+
+    def _db_sweep(self):
+        return self._sweeper
+
+    @property
+    def u(self):
+        return self.sync_in()._u
+
+    @property
+    def f(self):
+        return self.sync_in()._f
+
+    @property
+    def tau(self):
+        return self.sync_in()._tau
+
+    def sync_in(self):
+        H = self.host
+        self._lists()
+        for name, sl in (('u', self._u), ('f', self._f), ('tau', self._tau)):
+            cur = getattr(H, name)
+            if cur is sl:
+                continue
+            sl.invalidate()
+            self._res_cache = None
+            if name == 'tau' and self._engine_obj is not None:
+                self._engine_obj.set_tau_active(False)
+            for m, v in enumerate(cur):
+                if v is not None:
+                    sl[m] = v
+            setattr(H, name, sl)
+        return self
+
+    def publish_uend(self):
+        self.host.uend = hip_mesh(self._uend_slab_view())
+
+    def publish_residual_norms(self, norms):
+        self.host.residual = list(norms)
+
+
+class Level(DeviceBacked):
     """pySDC/core/level.py:42-191."""
 
     def __init__(self, problem_class, problem_params, sweeper_class, sweeper_params, level_params, level_index):
@@ -127,39 +282,21 @@ class Level:
         self.__prob = problem_class(**problem_params)
         self.level_index = level_index
         M = self.__sweep.coll.num_nodes
-        self.__engine = None
-        self._u = self._f = self._tau = None
-        self._uend_valid = False
-        self._uend_view = None
+        self._init_device_state()
         self.uold = [None] * (M + 1)
         self.fold = [None] * (M + 1)
         self.u_avg = [None] * M
         self.residual = [None] * M
         self.increment = [None] * M
         self.__tag = None
-        self._res_cache = None
+
+    def _db_prob(self):
+        return self.__prob
+
+    def _db_sweep(self):
+        return self.__sweep
 
     # ---- device state ----------------------------------------------------------------------------------
-    @property
-    def engine(self):
-        if self.__engine is None:
-            P, M = self.__prob, self.__sweep.coll.num_nodes
-            nvars = getattr(P, 'nvars', None)
-            if nvars is None:
-                raise ParameterError('problem does not define nvars: cannot create device slabs')
-            self.__engine = SweepEngine(getattr(P, 'engine_nvars', nvars), M, getattr(P, 'ncomp', 1))
-            P.bind_engine(self.__engine)
-            self.__sweep.push_coeffs(self.__engine)
-        return self.__engine
-
-    def _lists(self):
-        if self._u is None:
-            M = self.__sweep.coll.num_nodes
-            imex = getattr(self.__prob, 'ncomp', 1) == 2
-            self._u = SlabList(self, Lb.SLOT_U, M + 1)
-            self._f = SlabList(self, Lb.SLOT_F, M + 1, imex=imex)
-            self._tau = SlabList(self, Lb.SLOT_TAU, M)
-
     @property
     def u(self):
         self._lists()
@@ -179,11 +316,7 @@ class Level:
     def uend(self):
         if not self._uend_valid:
             return None
-        if self._uend_view is None:
-            e = self.engine
-            self._uend_view = hip_mesh.view(e.ptr(Lb.SLOT_UEND) + 8 * self._view_offset(), self._field_shape(), keep=e,
-                                            on_write=lambda: self._touched(Lb.SLOT_UEND, 0))
-        return self._uend_view
+        return self._uend_slab_view()
 
     @uend.setter
     def uend(self, value):
@@ -194,41 +327,6 @@ class Level:
         v = self.uend
         if value is not v:
             v[:] = value
-
-    def _field_shape(self):
-        shape = self.__prob.init[0]
-        return (int(shape),) if np.isscalar(shape) else tuple(shape)
-
-    def _view_offset(self):
-        return int(getattr(self.__prob, 'view_offset', 0))
-
-    def _activate_tau(self):
-        e = self.engine
-        e.set_tau_active(True)
-        e.vec_fill(e.N * e.M, 0.0, e.ptr(Lb.SLOT_TAU, 0))
-
-    def _touched(self, slot=None, m=None):
-        """device state was written outside the engine's own sweep calls: drop the cached residual and tell
-        the engine which cached transforms are stale (include/sdcmi.h: sdc_invalidate_spectra)."""
-        self._res_cache = None
-        e = self.__engine
-        if e is None:
-            return
-        if self._view_offset() and slot is not None:
-            # dirichlet-zero: the interior was written through a view - rebuild the odd extension of that field
-            n = self._field_shape()[0]
-            comps = range(e.ncomp) if slot == Lb.SLOT_F else (0,)
-            for comp in comps:
-                Lb.check(e.lib.sdc_odd_mirror(e.ctx, e.ptr(slot, m if slot != Lb.SLOT_UEND else 0, comp), n), e.ctx)
-        if slot == Lb.SLOT_U:
-            e.invalidate_spectra(1 if m == 0 else 2)
-        elif slot == Lb.SLOT_F:
-            if m != 0:
-                e.invalidate_spectra(4)
-        elif slot == Lb.SLOT_UEND:
-            e.invalidate_spectra(8)
-        elif slot is None:
-            e.invalidate_spectra(15)
 
     def replace_u0(self, src):
         """u[0] <- src (a device field of this level's shape), e.g. the value received from the previous time slice;
@@ -243,8 +341,8 @@ class Level:
     def refresh_f0(self):
         """f[0] = f(u[0]) after u[0] was replaced (controller_MPI.py:233, controller_nonMPI.py:284).  Nothing on
         the sweep path reads f[0]; an engine-backed problem evaluates it when it is asked for."""
-        if getattr(self.prob, 'fused', False) and self.__engine is not None:
-            Lb.check(self.__engine.lib.sdc_defer_f0(self.__engine.ctx), self.__engine.ctx)
+        if getattr(self.prob, 'fused', False) and self._engine_obj is not None:
+            Lb.check(self._engine_obj.lib.sdc_defer_f0(self._engine_obj.ctx), self._engine_obj.ctx)
             self._f.mark([0])
         else:
             self.f[0] = self.prob.eval_f(self.u[0], self.time)
@@ -264,8 +362,8 @@ class Level:
         self._u.invalidate()
         self._f.invalidate()
         self._tau.invalidate()
-        if self.__engine is not None:
-            self.__engine.set_tau_active(False)
+        if self._engine_obj is not None:
+            self._engine_obj.set_tau_active(False)
         self.uold = [None] * (M + 1)
         self.fold = [None] * (M + 1)
         self.u_avg = [None] * M

@@ -101,11 +101,12 @@ class Sweeper:
             self.QE = self.get_Qdelta_explicit(type(self.genQE).__name__, k=k)
             changed = True
         if changed and self._fused():
-            self.push_coeffs(self.level.engine)
+            self.push_coeffs(self._dev().engine)
 
     # ---- engine plumbing ----------------------------------------------------------------------------------
     imex = False
     _skip_sent = False
+    _foreign = None
 
     def push_coeffs(self, engine):
         qe = getattr(self, 'QE', None)
@@ -113,6 +114,18 @@ class Sweeper:
             qe = np.zeros_like(self.coll.Qmat)
         engine.set_coeffs(self.coll.Qmat, self.QI, qe if engine.ncomp == 2 else None, self.coll.nodes,
                           self.coll.weights)
+
+    def _dev(self):
+        """the device state of this sweeper's level: the level itself when it is a pysdc_amd.level.Level, else a
+        ForeignLevelState kept here for a level object of another framework (the reference's pySDC Level)"""
+        from pysdc_amd.level import DeviceBacked, ForeignLevelState
+
+        L = self.level
+        if isinstance(L, DeviceBacked):
+            return L
+        if self._foreign is None or self._foreign.host is not L:
+            self._foreign = ForeignLevelState(L, self)
+        return self._foreign.sync_in()
 
     def _fused(self):
         L = self.level
@@ -130,7 +143,7 @@ class Sweeper:
     def _push_forcing(self):
         P = self.level.prob
         if hasattr(P, 'forcing_g'):
-            self.level.engine.set_forcing_values([float(P.forcing_g(t)) for t in self._node_times()])
+            self._dev().engine.set_forcing_values([float(P.forcing_g(t)) for t in self._node_times()])
 
     # ---- predict (pySDC/core/sweeper.py:125-162) ------------------------------------------------------------
     def predict(self):
@@ -141,7 +154,8 @@ class Sweeper:
         if guess not in ('spread', 'copy', 'zero', 'random'):
             raise ParameterError(f'initial_guess option {guess} not implemented')
         if self._fused():
-            e = L.engine
+            D = self._dev()
+            e = D.engine
             self._push_forcing()
             fu = ff = 0.0
             if guess == 'random':
@@ -149,9 +163,9 @@ class Sweeper:
                 # nodes with one pair, so draw node by node on the generic path instead
                 return self._predict_generic()
             e.predict(L.time, L.dt, guess, fu, ff)
-            L.u.mark(range(M + 1))
-            L.f.mark(range(M + 1))
-            L._res_cache = None
+            D.u.mark(range(M + 1))
+            D.f.mark(range(M + 1))
+            D._res_cache = None
         else:
             return self._predict_generic()
         L.status.unlocked = True
@@ -192,13 +206,14 @@ class Sweeper:
         if self._fused():
             # the device state is unchanged since the last evaluation -> same value, no second pass
             # (the controller calls this twice per iteration)
-            if L._res_cache is not None and L._res_cache[0] == (rt, L.dt):
-                L.status.residual = L._res_cache[1]
+            D = self._dev()
+            if D._res_cache is not None and D._res_cache[0] == (rt, L.dt):
+                L.status.residual = D._res_cache[1]
             else:
-                res, norms = L.engine.residual(L.dt, rt)
+                res, norms = D.engine.residual(L.dt, rt)
                 L.status.residual = res
-                L._res_cache = ((rt, L.dt), res)
-                L.residual = list(norms)  # node-wise max norms; the M residual vectors are not materialised
+                D._res_cache = ((rt, L.dt), res)
+                D.publish_residual_norms(norms)  # node-wise max norms; the M residual vectors are not materialised
         else:
             res_norm = []
             L.residual = self.integrate()
@@ -229,39 +244,40 @@ class Sweeper:
 
     def _integrate_fused(self):
         L = self.level
-        P = L.prob
-        import torch
         from pysdc_amd.hip_mesh import hip_mesh
 
         # one buffer, the M integrals one behind the other (a transfer class can then restrict them together)
-        M, size = self.coll.num_nodes, L.engine.N
-        buf = torch.empty(M * size, dtype=torch.float64, device='cuda')
-        me = [hip_mesh.view(buf.data_ptr() + 8 * k * size, L._field_shape(), keep=buf) for k in range(M)]
-        L.engine.integrate(L.dt, [x.ptr for x in me])
+        D = self._dev()
+        M, size = self.coll.num_nodes, D.engine.N
+        buf = hip_mesh(((M * size,), None, np.dtype('float64')), val=None)
+        me = [hip_mesh.view(buf.ptr + 8 * k * size, D._field_shape(), keep=buf) for k in range(M)]
+        D.engine.integrate(L.dt, [x.ptr for x in me])
         return me
 
     def _update_nodes_fused(self):
         L = self.level
         assert L.status.unlocked
         M = self.coll.num_nodes
-        if not all(L.u[m] is not None for m in range(M + 1)):
+        D = self._dev()
+        if not all(D.u[m] is not None for m in range(M + 1)):
             raise ParameterError('update_nodes needs values at all nodes (predict first)')
         self._push_forcing()
-        L.engine.set_unlocked(True)
+        D.engine.set_unlocked(True)
         # skip_residual_computation covering every stage that follows a sweep: the engine then only moves the iterate
         skip = _STAGES_AFTER_SWEEP <= set(self.params.skip_residual_computation)
         if skip != self._skip_sent:
-            L.engine.set_skip_residual(skip)
+            D.engine.set_skip_residual(skip)
             self._skip_sent = skip
-        L.engine.sweep(L.time, L.dt)
-        L._res_cache = None
+        D.engine.sweep(L.time, L.dt)
+        D._res_cache = None
         L.status.updated = True
 
     def _end_point_fused(self):
         L = self.level
         dcu = not (self.coll.right_is_node and not self.params.do_coll_update)
-        L.engine.end_point(L.dt, dcu)
-        L._uend_valid = True
+        D = self._dev()
+        D.engine.end_point(L.dt, dcu)
+        D.publish_uend()
 
     @property
     def level(self):
@@ -269,9 +285,9 @@ class Sweeper:
 
     @level.setter
     def level(self, L):
-        from pysdc_amd.level import Level
-
-        assert isinstance(L, Level)
+        # the reference asserts its own Level class here (core/sweeper.py:245-256); this sweeper serves any object with
+        # that surface: a pysdc_amd.level.Level (device slabs built in) or the reference's Level (ForeignLevelState)
+        assert all(hasattr(L, a) for a in ('u', 'f', 'tau', 'uend', 'status', 'params', 'prob', 'dt', 'time'))
         self.__level = L
 
     @property
@@ -360,7 +376,7 @@ class generic_implicit(Sweeper):
         self.QI = self.get_Qdelta_implicit(qd_type=self.params.QI)
 
     def integrate(self):
-        if self._fused() and not self.level._view_offset():  # (odd-extended engine fields: use the views)
+        if self._fused() and not self._dev()._view_offset():  # (odd-extended engine fields: use the views)
             return self._integrate_fused()
         return _quadrature(self, [self.coll.Qmat[m] for m in range(1, self.coll.num_nodes + 1)])
 
@@ -386,7 +402,7 @@ class imex_1st_order(Sweeper):
         self.QE = self.get_Qdelta_explicit(qd_type=self.params.QE)
 
     def integrate(self):
-        if self._fused() and not self.level._view_offset():  # (odd-extended engine fields: use the views)
+        if self._fused() and not self._dev()._view_offset():  # (odd-extended engine fields: use the views)
             return self._integrate_fused()
         return _quadrature(self, [self.coll.Qmat[m] for m in range(1, self.coll.num_nodes + 1)])
 

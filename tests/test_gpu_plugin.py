@@ -661,3 +661,83 @@ def test_node_counts_and_quadrature_types_vs_oracle(M, quad, QI, kind):
     assert rel_err(uend.get(), ref) < TOL
     ores = [r for _, hist in ostats['residuals'] for r in hist]
     np.testing.assert_allclose(res, ores, rtol=1e-6, atol=1e-11)
+
+
+FOREIGN = ['config1', 'mssdc_P2_jac', 'mssdc_P4_gs', 'fixedK_3d', 'fixedK_3d_P2', 'forced2d_run', 'forced2d_run_P2']
+
+
+@pytest.mark.parametrize('name', FOREIGN)
+def test_foreign_level_runs_vs_golden(name):
+    """the product sweeper / problem classes inside a Level that is NOT pysdc_amd.level.Level (tests/_plain_level.py:
+    plain lists replaced by reset_level, frozen attribute set - the semantics of the reference's core/level.py): the
+    sweeper keeps a ForeignLevelState, adopts the lists block after block, and the fused kernels run as usual."""
+    from pysdc_amd.controller import controller_nonMPI
+    from pysdc_amd.hip_mesh import hip_mesh
+    from pysdc_amd.level import SlabList, ForeignLevelState
+    from pysdc_amd.stats import get_sorted
+    from tests._plain_level import PlainStep, PlainLevel
+
+    case = load_cases('runs.npz')[name]
+    meta = case['meta']
+    desc = description_from(meta)
+    desc['step_class'] = PlainStep
+    C = controller_nonMPI(meta['num_procs'], dict(logger_level=40, **meta['controller_params']), desc)
+    Lv = C.MS[0].levels[0]
+    assert type(Lv) is PlainLevel and type(Lv.u) is list
+    u0 = Lv.prob.u_init
+    u0[:] = case['u0']
+    uend, stats = C.run(u0, meta['t0'], meta['Tend'])
+    assert isinstance(Lv.sweep._dev(), ForeignLevelState) and isinstance(Lv.u, SlabList) and isinstance(uend, hip_mesh)
+    niter = get_sorted(stats, type='niter', sortby='time')
+    assert [v for _, v in niter] == list(case['niter'])
+    assert rel_err(uend.get(), case['uend']) < TOL
+    res = [v for _, v in get_sorted(stats, type='residual_post_iteration', sortby='time')]
+    np.testing.assert_allclose(res, case['res'], rtol=1e-6, atol=1e-11 * max(1.0, float(np.max(np.abs(case['u0'])))))
+
+
+def test_foreign_level_tau_and_uend_semantics():
+    """a FAS correction assigned into the host's plain list after reset_level reaches the sweep; L.uend is an owning
+    object that survives later sweeps (stock hooks keep references to it)."""
+    from pysdc_amd.sweepers import generic_implicit
+    from pysdc_amd.problems import heatNd_unforced
+    from pysdc_amd.level import Step
+    from tests._plain_level import PlainStep
+
+    case = load_cases('sweeps_heat.npz')['heat3d_tau']
+    meta = case['meta']
+    pp = dict(meta['prob_params'])
+    pp['nvars'] = tuple(pp['nvars'])
+    desc = dict(problem_class=heatNd_unforced, problem_params=pp, sweeper_class=generic_implicit,
+                sweeper_params=dict(meta['sweeper_params']), level_params=dict(dt=meta['dt']), step_params=dict(maxiter=9))
+    for step_class in (PlainStep, Step):
+        S = step_class(desc)
+        Lv = S.levels[0]
+        Lv.status.time = meta['t0']
+        S.init_step(_field(Lv.prob, case['u0']))
+        for m in range(len(case['tau'])):
+            Lv.tau[m] = _field(Lv.prob, case['tau'][m])
+        Lv.sweep.predict()
+        kept = []
+        for k in range(1, meta['nsweeps'] + 1):
+            Lv.sweep.update_nodes()
+            Lv.sweep.compute_residual()
+            assert abs(Lv.status.residual - float(case[f'k{k}_res_full_abs'])) <= 1e-8 * float(case[f'k{k}_res_full_abs']) + 1e-11
+            assert rel_err(np.stack([np.asarray(x) for x in Lv.u]), case[f'k{k}_u']) < TOL
+            Lv.sweep.compute_end_point()
+            kept.append(Lv.uend)
+            assert rel_err(Lv.uend.get(), case[f'k{k}_uend_0']) < TOL
+        if step_class is PlainStep:   # earlier end values were not overwritten by later sweeps
+            for k, v in enumerate(kept, 1):
+                assert rel_err(v.get(), case[f'k{k}_uend_0']) < TOL
+        # a tau changed alone (no U write) must invalidate the cached residual
+        Lv.sweep.compute_residual()
+        r0 = Lv.status.residual
+        Lv.tau[0] += 1.0
+        Lv.sweep.compute_residual()
+        assert abs(Lv.status.residual - r0) > 0.5
+
+
+def _field(prob, values):
+    x = prob.u_init
+    x[:] = values
+    return x

@@ -1,0 +1,97 @@
+"""Build-container test of the drop-in boundary: the REFERENCE's own ``Step``, ``Level``, ``controller_nonMPI``, hooks and
+convergence controllers (imported from /root/reference) run around the PRODUCT's sweeper / problem / datatype classes,
+named in the description dict exactly as INTEGRATION.md says.  There is no GPU here, so the device is replaced by
+tests/_host_engine.py (host memory + oracle numerics); what is under test is the host-side plumbing: the sweeper
+accepting the reference's frozen Level, ForeignLevelState adopting its plain lists, ``L.uend`` / ``L.status`` /
+``work_counters`` as the stock controller, hooks and convergence controllers read them.  Results are compared with the
+golden runs of the pure reference (tests/golden/runs.npz).  Skipped where /root/reference does not exist (GPU box)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from tests._cases import load_cases, rel_err
+from tests._host_engine import host_device
+
+REF = '/root/reference'
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, 'pySDC')), reason='reference not present')
+
+
+@pytest.fixture(scope='module')
+def ref():
+    sys.dont_write_bytecode = True
+    shim = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle', 'qmat_shim')
+    for p in (REF, shim):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import pySDC.core.level as core_level
+    from pySDC.helpers.stats_helper import get_sorted
+    from pySDC.implementations.controller_classes.controller_nonMPI import controller_nonMPI
+
+    return dict(controller=controller_nonMPI, get_sorted=get_sorted, Level=core_level.Level)
+
+
+def _description(meta):
+    from pysdc_amd import problems as P, sweepers as S
+
+    probs = {'heat_unforced': P.heatNd_unforced, 'heat_forced': P.heatNd_forced, 'advdiff': P.advectiondiffusionNd_imex}
+    sweeps = {'generic_implicit': S.generic_implicit, 'imex_1st_order': S.imex_1st_order}
+    pp = dict(meta['prob_params'])
+    if isinstance(pp.get('nvars'), list):
+        pp['nvars'] = tuple(pp['nvars'])
+    return dict(problem_class=probs[meta['prob']], problem_params=pp, sweeper_class=sweeps[meta['sweeper']],
+                sweeper_params=dict(meta['sweeper_params']), level_params=dict(meta['level_params']),
+                step_params=dict(maxiter=meta['maxiter']))
+
+
+@pytest.mark.parametrize('name', ['config1', 'mssdc_P2_jac', 'mssdc_P4_gs', 'fixedK_3d', 'forced2d_run', 'forced2d_run_P2'])
+def test_reference_controller_drives_product_classes(ref, name):
+    case = load_cases('runs.npz')[name]
+    meta = case['meta']
+    with host_device():
+        from pysdc_amd.hip_mesh import hip_mesh
+        from pysdc_amd.level import SlabList
+
+        C = ref['controller'](meta['num_procs'], dict(logger_level=40, **meta['controller_params']), _description(meta))
+        L = C.MS[0].levels[0]
+        assert type(L) is ref['Level']                      # the reference's frozen Level, not pysdc_amd.level.Level
+        assert type(L.u) is list                            # ... with its plain lists, until the sweeper adopts them
+        u0 = L.prob.u_init
+        u0[:] = case['u0']
+        uend, stats = C.run(u0, meta['t0'], meta['Tend'])
+        assert isinstance(uend, hip_mesh) and isinstance(L.u, SlabList)
+        eng = L.sweep._dev().engine
+        assert {'predict', 'sweep', 'residual', 'end_point'} <= set(eng.calls)   # the fused entry points were used
+        niter = ref['get_sorted'](stats, type='niter', sortby='time')
+        assert [v for _, v in niter] == list(case['niter'])
+        assert rel_err(uend.get(), case['uend']) < 1e-10
+        res = [v for _, v in ref['get_sorted'](stats, type='residual_post_iteration', sortby='time')]
+        np.testing.assert_allclose(res, case['res'], rtol=1e-6, atol=1e-11)
+        # stock hooks did run on the device datatype: timings and the restart log are in the statistics
+        types = {k.type for k in stats}
+        assert {'timing_run', 'timing_step', 'timing_sweep', 'restart'} <= types, types
+
+
+def test_reference_hooks_and_convergence_controllers_on_device_datatype(ref):
+    """stock LogSolution / LogWork hooks and a stock optional convergence controller (fixed-iteration override
+    through CheckConvergence parameters is the always-on one; here: EstimateEmbeddedError-free, the cheap
+    'CheckIterationEstimator'-free set) see the product's datatype through the reference's own interfaces."""
+    from pySDC.implementations.hooks.log_solution import LogSolution
+    from pySDC.implementations.hooks.log_work import LogWork
+
+    case = load_cases('runs.npz')['mssdc_P2_jac']
+    meta = case['meta']
+    with host_device():
+        desc = _description(meta)
+        C = ref['controller'](2, dict(logger_level=40, hook_class=[LogSolution, LogWork], mssdc_jac=True), desc)
+        u0 = C.MS[0].levels[0].prob.u_init
+        u0[:] = case['u0']
+        uend, stats = C.run(u0, meta['t0'], meta['Tend'])
+        sol = ref['get_sorted'](stats, type='u', sortby='time')
+        assert len(sol) == len(case['niter'])
+        # every logged solution is an OWNING object that kept its value (the last one equals the run's end value,
+        # earlier ones differ from it: they were not overwritten by later steps)
+        assert rel_err(sol[-1][1].get(), case['uend']) < 1e-10
+        assert all(rel_err(s.get(), case['uend']) > 1e-6 for _, s in sol[:-1])
+        assert [v for _, v in ref['get_sorted'](stats, type='niter', sortby='time')] == list(case['niter'])
