@@ -30,7 +30,8 @@ enum sdc_status {
     SDC_ERR_STATE = -3,    /* level not unlocked, coefficients / operator not set (assert L.status.unlocked) */
     SDC_ERR_UNSUPPORTED = -4,
     SDC_ERR_NOMEM = -5,
-    SDC_ERR_NEWTON = -6    /* Newton failure: pySDC raises ProblemError (Van_der_Pol_implicit.py:179-186) */
+    SDC_ERR_NEWTON = -6,   /* Newton failure: pySDC raises ProblemError (Van_der_Pol_implicit.py:179-186) */
+    SDC_ERR_COMM = -7      /* RCCL failure / librccl missing: CommunicationError (core/errors.py) */
 };
 
 enum sdc_slot { SDC_SLOT_U = 0, SDC_SLOT_F = 1, SDC_SLOT_TAU = 2, SDC_SLOT_UEND = 3, SDC_SLOT_WORK = 4 };
@@ -87,7 +88,8 @@ int sdc_set_tau_active(sdc_ctx* ctx, int active); /* L.tau[m] is None  <->  0 */
  * of U[1..M] between sweeps and gathers on them instead of re-transforming M fields every sweep.  Anything
  * that writes a U field behind the engine's back (datatype operations on slab views, RCCL receives) must say
  * so: which = 1: U[0] changed, 2: some U[m >= 1] changed, 4: some F[m >= 1] was overwritten (the next sweep then
- * gathers on the F slab like the reference does); bits combine.  sdc_upload / sdc_predict do it themselves. */
+ * gathers on the F slab like the reference does), 8: UEND was overwritten, 16: some TAU[m] changed (every call drops
+ * the cached residual norms); bits combine.  sdc_upload / sdc_predict do it themselves. */
 int sdc_invalidate_spectra(sdc_ctx* ctx, int which);
 int sdc_set_spectral_reuse(sdc_ctx* ctx, int on);
 /* The 3-D sweep evaluates f at all nodes and the node norms of the collocation residual in ONE kernel; a
@@ -126,6 +128,33 @@ int sdc_set_keep_residual_fields(sdc_ctx* ctx, int on);
 int sdc_set_early_end_point(sdc_ctx* ctx, int on);
 int sdc_stream_wait_uend(sdc_ctx* ctx, void* other_stream);
 int sdc_replace_u0(sdc_ctx* ctx, const double* src);
+
+/* ---- time-rank communication over RCCL (xGMI) --------------------------------------------------------------
+ * The forward transfer uend -> u[0] of the next time rank (controller_MPI.py:218-305 send_full / recv_full; mesh.py:85-125
+ * isend / irecv / bcast) and the end-of-block broadcast (controller_MPI.py:125-130), modelled on the reference's NCCL
+ * wrapper helpers/NCCL_communicator.py:12-20 (unique id made by rank 0 and distributed by the host-side communicator,
+ * one NCCL communicator per process) and :128-135 (Bcast).  One process per GPU; librccl is bound at run time on the
+ * first call.  Messages travel on a stream of their own, ordered against the engine's stream by events only (no host
+ * block): a send starts once UEND is complete (sdc_end_point, or the early end value of sdc_set_early_end_point) and
+ * UEND is not rewritten before it has left; a received value lands in an inbox and reaches the level through
+ * sdc_replace_u0 on the engine's stream.  MPI tags (level*100 + iter) are replaced by the strict order of the calls.
+ *   sdc_comm_unique_id(out)          128 bytes, called on ONE rank; ship them to the others on the host side
+ *   sdc_comm_init(ctx, uid, P, r)    ncclCommInitRank on the context's device (collective over the P ranks)
+ *   sdc_comm_exchange(ctx, to, from) send UEND to rank `to` and / or receive the new u[0] from rank `from` as ONE
+ *                                    group (both directions progress together); a peer < 0 skips that direction
+ *   sdc_send_uend / sdc_recv_u0      the two halves on their own
+ *   sdc_bcast(ctx, slot, m, root)    one slab field of rank `root` to all, in place
+ *   sdc_comm_set_chunk(ctx, n)       cut every message into pieces of n doubles inside its group (0 = one piece)
+ *   sdc_comm_sync(ctx)               host waits for the messages posted so far */
+int sdc_comm_unique_id(char* out128);
+int sdc_comm_init(sdc_ctx* ctx, const char* uid128, int nranks, int rank);
+int sdc_comm_destroy(sdc_ctx* ctx);
+int sdc_comm_exchange(sdc_ctx* ctx, int send_peer, int recv_peer);
+int sdc_send_uend(sdc_ctx* ctx, int peer);
+int sdc_recv_u0(sdc_ctx* ctx, int peer);
+int sdc_bcast(sdc_ctx* ctx, int slot, int m, int root);
+int sdc_comm_set_chunk(sdc_ctx* ctx, size_t doubles_per_piece);
+int sdc_comm_sync(sdc_ctx* ctx);
 /* L.status.unlocked: set by sdc_predict; a coarse level is unlocked by the restriction instead
  * (pySDC/core/base_transfer.py:166) - the host mirrors that here. */
 int sdc_set_unlocked(sdc_ctx* ctx, int unlocked); /* default on; 0 = transform the gathered fields every sweep */

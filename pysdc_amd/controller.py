@@ -58,7 +58,10 @@ class _ControllerBase:
         for h in hook_class:
             self.add_hook(h)
         if description.get('convergence_controllers'):
-            raise ParameterError('optional convergence controllers are host-side pySDC plug-ins outside this engine')
+            raise ParameterError(
+                'convergence controllers are plug-ins of the reference\'s controllers: run them by handing this description '
+                '(pysdc_amd sweeper_class / problem_class) to pySDC\'s own controller_nonMPI - the sweepers serve its Level '
+                'objects (INTEGRATION.md); pysdc_amd.controller implements the always-on residual / maxiter rule only')
 
     def add_hook(self, hook):
         if hook not in [type(h) for h in self.hooks]:
@@ -128,7 +131,10 @@ class controller_nonMPI(_ControllerBase):
             self.restart_block(active_slots, time, uend)
         for S in self.MS:
             self._hook('post_run', S)
-        return uend, self.return_stats()
+        # a fresh object per run, like the reference (controller_nonMPI.py:148,167): neither the persistent buffer nor a
+        # view into a level's UEND slab leaves the controller (one copy per run, not per block)
+        P = self.MS[0].levels[0].prob
+        return P.dtype_u(uend), self.return_stats()
 
     # controller_nonMPI.py:169-224
     def restart_block(self, active_slots, time, u0):
@@ -360,6 +366,12 @@ class controller_dist(_ControllerBase):
         super().__init__(controller_params, description)
         self.dist = dist
         self.comm = comm
+        world = getattr(getattr(dist, 'group', None), 'WORLD', None)
+        if comm is not None and comm is not world and dist.get_world_size(comm) != dist.get_world_size():
+            # peers below are group-local ranks, which torch.distributed reads as GLOBAL ranks in P2POp / send / recv /
+            # broadcast, and the gloo side group spans the world: only the world group carries a run
+            raise ParameterError('controller_dist runs over the WORLD group (one time step per process of the job); '
+                                 'space-time parallel sub-groups are not supported')
         self.rank = dist.get_rank(comm)
         self.size = dist.get_world_size(comm)
         self._flag_device = 'cpu'
@@ -447,7 +459,9 @@ class controller_dist(_ControllerBase):
             S.levels[0].engine.set_keep_residual_fields(True)
             # (only in lock-step runs, where every posted message is completed before the next sweep: the sweep then
             # overwrites UEND early, which must not happen under a send that is still in flight)
-            if (self._uniform(self.size) and not S.levels[0]._view_offset()
+            # and only with ONE sweep per iteration: with nsweeps > 1 it_fine posts a lone send between sweeps, which
+            # stays in flight on the communication stream while the next sweep would already rewrite UEND
+            if (self._uniform(self.size) and not S.levels[0]._view_offset() and self.nsweeps[0] == 1
                     and os.environ.get('PYSDC_AMD_OVERLAP', '1') != '0'):
                 S.levels[0].engine.set_early_end_point(True)
                 self._overlap = True
@@ -477,7 +491,8 @@ class controller_dist(_ControllerBase):
             if num_active > 0:
                 self.restart_block(num_active, time, uend, active)
         self._hook('post_run', S)
-        return uend, self.return_stats()
+        # the reference hands out a fresh dtype_u per run (controller_MPI.py:125-130); the persistent buffer stays inside
+        return P.dtype_u(uend), self.return_stats()
 
     # controller_MPI.py:170-216
     def restart_block(self, size, time, u0, active):

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "../../include/sdcmi.h"
@@ -27,7 +28,10 @@ struct ProfEntry {
     int calls = 0;
 };
 
+struct CommState;  // comm.hpp: RCCL communicator, message stream, inbox
+
 struct sdc_ctx {
+    CommState* comm = nullptr;
     int device = 0, ndim = 0, n = 0, M = 0, ncomp = 1;
     size_t N = 0;       // n^ndim
     size_t Nc = 0;      // complex entries of one spectrum field
@@ -90,6 +94,9 @@ struct sdc_ctx {
     std::vector<std::string> prof_names;
     std::string err;
 };
+
+static int uend_write_fence(sdc_ctx* c);  // comm.hpp: a send that still reads UEND goes first
+static void comm_free(sdc_ctx* c);
 
 static thread_local std::string g_create_err;
 
@@ -156,6 +163,8 @@ static inline int is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
 // profile names that carry the number of fields of the launch, e.g. "fft_x_fwd[5]" (interned, static lifetime)
 static const char* pname(const char* base, int nf) {
     static std::map<std::string, std::string> table;
+    static std::mutex guard;  // contexts of several host threads (in-process ranks of the tests) intern concurrently
+    std::lock_guard<std::mutex> lock(guard);
     std::string key = std::string(base) + "[" + std::to_string(nf) + "]";
     auto it = table.find(key);
     if (it == table.end()) it = table.emplace(key, key).first;

@@ -367,6 +367,10 @@ static int inverse_passes_n(sdc_ctx* c, int nf, const cd* src, cd* work, const F
 template <int N>
 static int early_end_point_n(sdc_ctx* c, bool norms_only) {
     if (!c->early_uend || !norms_only) return SDC_OK;
+    {
+        int rcf = uend_write_fence(c);
+        if (rcf != SDC_OK) return rcf;
+    }
     if (!c->W2) {
         HIPCHK(c, hipMalloc((void**)&c->W2, sizeof(cd) * c->Nc));
         c->bytes += sizeof(cd) * c->Nc;
@@ -780,6 +784,7 @@ int sdc_ctx_create(sdc_ctx** out, int device, int ndim, int n, int num_nodes, in
 
 int sdc_ctx_destroy(sdc_ctx* c) {
     if (!c) return SDC_OK;
+    comm_free(c);
     (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->U);
     (void)hipFree(c->F);
@@ -1063,7 +1068,10 @@ void* sdc_slot_ptr(sdc_ctx* c, int slot, int m, int comp) {
     // whoever asks for the address of a node field is about to read or write it
     if ((slot == SDC_SLOT_U || slot == SDC_SLOT_F) && sdc_materialize(c, slot, m) != SDC_OK) return nullptr;
     if (slot == SDC_SLOT_TAU && ensure_tau(c) != SDC_OK) return nullptr;
-    if (slot == SDC_SLOT_UEND) c->uend_gen = -1;  // the holder may write it
+    if (slot == SDC_SLOT_UEND) {
+        c->uend_gen = -1;  // the holder may write it
+        if (uend_write_fence(c) != SDC_OK) return nullptr;
+    }
     if (slot == SDC_SLOT_WORK) return c->W;
     return slot_ptr(c, slot, m, comp);
 }
@@ -1778,6 +1786,12 @@ int sdc_end_point(sdc_ctx* c, double dt, int do_coll_update) {
     if (!do_coll_update) {
         if (c->u_pending && !c->spread_pending && c->uend_gen >= 0 && c->uend_gen == c->spec_gen)
             return SDC_OK;  // the sweep already produced it (sdc_set_early_end_point)
+    }
+    {
+        int rcf = uend_write_fence(c);
+        if (rcf != SDC_OK) return rcf;
+    }
+    if (!do_coll_update) {
         c->uend_gen = -1;
         if (c->u_pending && !c->spread_pending) {  // only the last node is needed: transform it straight into UEND
             FieldPtrs p;
@@ -2126,3 +2140,5 @@ int sdc_profile_read(sdc_ctx* c, int cap, const char** names, double* ms, int* c
 }
 
 }  // extern "C"
+
+#include "comm.hpp"

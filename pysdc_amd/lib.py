@@ -3,7 +3,7 @@ call fails this raises - the product path never computes on the CPU."""
 import ctypes as C
 import os
 
-from pysdc_amd.errors import EngineError, ParameterError, ProblemError, UnlockError
+from pysdc_amd.errors import CommunicationError, EngineError, ParameterError, ProblemError, UnlockError
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libsdcmi.so')
@@ -13,7 +13,7 @@ RES_TYPES = {'full_abs': 0, 'last_abs': 1, 'full_rel': 2, 'last_rel': 3}
 GUESS = {'spread': 0, 'copy': 1, 'zero': 2, 'random': 3}
 EXPL_NONE, EXPL_STENCIL, EXPL_FORCING, EXPL_REACTION = 0, 1, 2, 3
 
-ERR_PARAM, ERR_HIP, ERR_STATE, ERR_UNSUPPORTED, ERR_NOMEM, ERR_NEWTON = -1, -2, -3, -4, -5, -6
+ERR_PARAM, ERR_HIP, ERR_STATE, ERR_UNSUPPORTED, ERR_NOMEM, ERR_NEWTON, ERR_COMM = -1, -2, -3, -4, -5, -6, -7
 
 _dp = C.POINTER(C.c_double)
 _vp = C.c_void_p
@@ -50,6 +50,15 @@ PROTOTYPES = {
     'sdc_set_early_end_point': (C.c_int, [_vp, C.c_int]),
     'sdc_stream_wait_uend': (C.c_int, [_vp, _vp]),
     'sdc_replace_u0': (C.c_int, [_vp, _vp]),
+    'sdc_comm_unique_id': (C.c_int, [C.c_char_p]),
+    'sdc_comm_init': (C.c_int, [_vp, C.c_char_p, C.c_int, C.c_int]),
+    'sdc_comm_destroy': (C.c_int, [_vp]),
+    'sdc_comm_exchange': (C.c_int, [_vp, C.c_int, C.c_int]),
+    'sdc_send_uend': (C.c_int, [_vp, C.c_int]),
+    'sdc_recv_u0': (C.c_int, [_vp, C.c_int]),
+    'sdc_bcast': (C.c_int, [_vp, C.c_int, C.c_int, C.c_int]),
+    'sdc_comm_set_chunk': (C.c_int, [_vp, C.c_size_t]),
+    'sdc_comm_sync': (C.c_int, [_vp]),
     'sdc_fft_prolong': (C.c_int, [_vp, _vp, _vp, _vp, C.c_double]),
     'sdc_materialize': (C.c_int, [_vp, C.c_int, C.c_int]),
     'sdc_init_field': (C.c_int, [_vp, _vp, C.POINTER(C.c_int), C.c_double, C.c_ulonglong]),
@@ -125,4 +134,6 @@ def check(rc, ctx=None):
         raise NotImplementedError(msg)
     if rc == ERR_NOMEM:
         raise MemoryError(msg)
+    if rc == ERR_COMM:
+        raise CommunicationError(msg)
     raise EngineError(msg)
