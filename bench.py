@@ -61,10 +61,10 @@ def _kernel_bytes(name, n, M, ncomp=1):
     return table.get(base)
 
 
-def cpu_baseline(M, dt_ref_n, sample_n=64, target_n=1024, nsweeps=4):
-    """The oracle (NumPy/SciPy restatement of the reference's path, oracle/sdc_oracle.py) timed on one host
-    core on a bounded sample: heat 3-D sample_n^3, M nodes, 1 time step = 4 sweeps, CG(rtol 1e-12) like the
-    reference's feasible 3-D configuration.  kind = "port"."""
+def _cpu_sample(sample_n, M, dt_ref_n, target_n, nsweeps):
+    """one bounded sample of the oracle (NumPy/SciPy restatement of the reference's path, oracle/sdc_oracle.py): heat 3-D
+    sample_n^3, M nodes, 1 time step = nsweeps sweeps, CG(rtol 1e-12) like the reference's feasible 3-D configuration
+    (BASELINE.md 3), same dt*nu/dx^2 stiffness as the GPU workload.  Runs in a child interpreter (no GPU, no torch)."""
     import numpy as np
 
     from oracle import sdc_oracle as O
@@ -76,7 +76,7 @@ def cpu_baseline(M, dt_ref_n, sample_n=64, target_n=1024, nsweeps=4):
     QI[1:, 1:] = QDELTA_GENERATORS['IE'](qGen=c.generator, tLeft=0).genCoeffs()
     coll = O.Coll(c.nodes, c.weights, c.Qmat, QI)
     nv = (sample_n,) * 3
-    dt = dt_ref_n * (target_n / sample_n) ** 2  # same dt*nu/dx^2 stiffness as the GPU workload
+    dt = dt_ref_n * (target_n / sample_n) ** 2
     t0 = time.perf_counter()
     prob = O.HeatUnforced(nv, 0.1, 2, solver_type='CG', lintol=1e-12)
     setup = time.perf_counter() - t0
@@ -84,15 +84,62 @@ def cpu_baseline(M, dt_ref_n, sample_n=64, target_n=1024, nsweeps=4):
     t0 = time.perf_counter()
     O.run_sdc(lambda: O.Level(prob, coll, dt, restol=-1.0), u0, 0.0, dt, maxiter=nsweeps)
     el = time.perf_counter() - t0
-    raw = 1.0 / el
-    scale = (sample_n / target_n) ** 3
+    return {'n': sample_n, 'seconds': el, 'setup_seconds': setup, 'sweeps': nsweeps,
+            'cg_iterations': prob.work_counters['CG'].niter}
+
+
+def _spawn_cpu_sample(sample_n, M, dt_ref_n, target_n, nsweeps):
+    """a fresh interpreter per sample (a child process, never an exec of this one: the GPU is initialised here);
+    single-threaded BLAS / OpenMP so that `cores` means what it says"""
+    import subprocess
+
+    env = dict(os.environ, OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1', MKL_NUM_THREADS='1', HIP_VISIBLE_DEVICES='')
+    code = (f'import sys, json; sys.path.insert(0, {ROOT!r}); import bench; '
+            f'print(json.dumps(bench._cpu_sample({sample_n}, {M}, {dt_ref_n!r}, {target_n}, {nsweeps})))')
+    return subprocess.Popen([sys.executable, '-c', code], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env,
+                            cwd='/tmp')
+
+
+def _collect(proc, timeout=600):
+    out, _ = proc.communicate(timeout=timeout)
+    return json.loads(out.decode().strip().splitlines()[-1])
+
+
+def cpu_baseline(M, dt_ref_n, target_n=1024, nsweeps=4, max_workers=32):
+    """kind = "port": the oracle timed on the GPU box's host cores, on bounded samples of the same workload.
+      * one core, 64^3, one time step (4 sweeps), and - beside it - one core, 128^3, ONE sweep: shows what the
+        linear-in-DOF extrapolation to the target size leaves out (CG iteration counts grow with the grid);
+      * all host cores: `cores` independent copies of the 64^3 sample at once (the reference's NumPy / SciPy path is
+        single-threaded, so throughput over cores = independent time steps), value = cores / slowest copy.
+    `value` = the all-cores figure scaled to the target size by DOF (optimistic for the CPU)."""
+    ncpu = os.cpu_count() or 1
+    r64 = _collect(_spawn_cpu_sample(64, M, dt_ref_n, target_n, nsweeps))   # alone on the host: clean one-core figure
+    r128 = _collect(_spawn_cpu_sample(128, M, dt_ref_n, target_n, 1))
+    workers = max(1, min(ncpu, max_workers))
+    t0 = time.perf_counter()
+    procs = [_spawn_cpu_sample(64, M, dt_ref_n, target_n, nsweeps) for _ in range(workers)]
+    rs = [_collect(p) for p in procs]
+    wall = time.perf_counter() - t0
+    slowest = max(r['seconds'] for r in rs)
+    scale = (64.0 / target_n) ** 3
+    raw_all = workers / slowest                       # time steps/s at 64^3 over all workers
+    raw_one = 1.0 / r64['seconds']
+    per_sweep_dof_64 = r64['seconds'] / (nsweeps * 64**3)
+    per_sweep_dof_128 = r128['seconds'] / (1 * 128**3)
     return {
-        'value': raw * scale, 'unit': 'time-steps/s', 'cores': 1, 'kind': 'port',
-        'sample': f'heat 3-D {sample_n}^3 f64, M={M}, 1 time step = {nsweeps} sweeps, CG rtol 1e-12 '
-                  f'({prob.work_counters["CG"].niter} CG iterations), {el:.1f} s on 1 core (+{setup:.1f} s matrix '
-                  f'setup, not counted); value = measured {raw:.4f} steps/s x ({sample_n}/{target_n})^3 '
-                  f'(linear-in-DOF extrapolation, optimistic for the CPU)',
-        'raw_value': raw, 'raw_unit': f'time-steps/s at {sample_n}^3',
+        'value': raw_all * scale, 'unit': 'time-steps/s', 'cores': workers, 'kind': 'port',
+        'sample': f'{workers} concurrent copies (host has {ncpu} cores) of: heat 3-D 64^3 f64, M={M}, 1 time step = '
+                  f'{nsweeps} sweeps, CG rtol 1e-12 ({r64["cg_iterations"]} CG iterations); slowest copy {slowest:.1f} s '
+                  f'(+{r64["setup_seconds"]:.1f} s matrix setup each, not counted; {wall:.0f} s wall incl. start-up); value = '
+                  f'{raw_all:.3f} steps/s at 64^3 x (64/{target_n})^3 (linear-in-DOF extrapolation, optimistic for the CPU)',
+        'raw_value': raw_all, 'raw_unit': 'time-steps/s at 64^3, all workers',
+        'one_core': {'value': raw_one * scale, 'raw_value': raw_one, 'seconds': r64['seconds'],
+                     'cg_iterations': r64['cg_iterations']},
+        'second_sample_128': {'seconds_per_sweep': r128['seconds'], 'cg_iterations_per_sweep': r128['cg_iterations'],
+                              'seconds_per_sweep_per_dof': per_sweep_dof_128,
+                              'ratio_to_64_per_dof': per_sweep_dof_128 / per_sweep_dof_64,
+                              'note': 'one sweep at 128^3 on one core; a ratio > 1 means the per-DOF cost grows with the '
+                                      'grid, i.e. the DOF-scaled value above overstates the CPU at the target size'},
     }
 
 
@@ -120,55 +167,11 @@ def stream_reference(torch, eng, nbytes=1 << 32):
     return res
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--workload', default='heat', choices=['heat', 'advdiff', 'vdp', 'allencahn'],
-                    help='heat = BASELINE metric (default); advdiff = config 3 (IMEX); vdp = config 4 (ensemble); '
-                         'allencahn = config 5 (two-level MLSDC / PFASST)')
-    ap.add_argument('--n', type=int, default=None, help='grid points per dimension (heat: 1024 = BASELINE metric; advdiff: 512)')
-    ap.add_argument('--ntraj', type=int, default=10_000_000)
-    ap.add_argument('--nodes', type=int, default=5)
-    ap.add_argument('--sweeps', type=int, default=4)
-    ap.add_argument('--qi', default='IE')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--force-dist', action='store_true',
-                    help='use the one-step-per-rank controller and torch.distributed even with one GPU (self test)')
-    ap.add_argument('--no-spectral-reuse', action='store_true',
-                    help='transform the gathered fields in every sweep instead of gathering on cached transforms')
-    ap.add_argument('--solver-type', default='direct', choices=['direct', 'CG'],
-                    help="heat: 'direct' = exact solve in Fourier space (headline); 'CG' = the reference's conjugate "
-                         "gradients (rtol 1e-12) on the device, node by node")
-    ap.add_argument('--restol', type=float, default=-1.0,
-                    help='> 0: iterate to this residual instead of a fixed number of sweeps (maxiter 50); niter is reported')
-    ap.add_argument('--eager-fields', action='store_true',
-                    help='store F[1..M] and the predictor copies in every sweep / predict even when nothing reads them')
-    ap.add_argument('--mssdc', default='jacobi', choices=['jacobi', 'gs'],
-                    help='multi-step SDC over the time ranks (--gpus > 1): Jacobi (mssdc_jac=True, the default of the '
-                         'reference: all slices sweep concurrently) or Gauss-Seidel (receive, sweep, blocking send)')
-    ap.add_argument('--skip-residual', action='store_true',
-                    help="sweeper parameter skip_residual_computation for every stage (the reference's switch for runs with a "
-                         'fixed number of sweeps): no residual is computed; NOT the headline configuration')
-    args = ap.parse_args()
-
+def run_workload(args, world, rank, use_dist, with_stream_reference=True):
+    """one measured run of one workload; returns the record on rank 0 (None elsewhere)"""
     import numpy as np
     import torch
     import torch.distributed as dist
-
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
-    torch.cuda.set_device(local_rank)
-    use_dist = world > 1 or args.force_dist
-    if use_dist:
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29531')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
 
     import ctypes as C
 
@@ -275,6 +278,10 @@ def main():
 
     block = dt * world  # one bench step advances `world` time steps
     uend, _ = ctrl.run(u0, 0.0, block * args.warmup) if args.warmup > 0 else (u0, None)
+    # run() hands out a fresh end-value object per call like the reference; let the caching allocator hold a block of that
+    # size already, so that the timed region contains the run and not a first-time 8.6 GB hipMalloc (set-up, not work)
+    spare = torch.empty(int(np.prod(uend.shape)), dtype=torch.float64, device='cuda')
+    del spare
     sync()
     eng.profile_enable(True)
     t0 = time.perf_counter()
@@ -284,6 +291,7 @@ def main():
     prof = eng.profile_read()
     eng.profile_enable(False)
 
+    el_own = el
     elt = torch.tensor([el], dtype=torch.float64, device='cuda')
     if use_dist:
         dist.all_reduce(elt, op=dist.ReduceOp.MAX)
@@ -302,6 +310,18 @@ def main():
                     'copy': 8.0 * 2 * T * 2}.get(name.split('[')[0])
         return _kernel_bytes(name, n_, M_, ncomp)
 
+    per_rank = None
+    if use_dist:
+        # every rank's own view, so that a scaling run explains itself: wall time, iterations, time spent in the
+        # hand-over (hooks: pre_comm .. post_comm, host clock), device time of its kernels
+        comm_s = sum(v for _, v in get_sorted(stats, type='timing_comm'))
+        mine = {'rank': rank, 'seconds': el_own, 'niter': niter, 'ms_per_iteration': 1e3 * el_own / max(1, sum(niter)),
+                'comm_ms_per_iteration': 1e3 * comm_s / max(1, sum(niter)),
+                'kernel_ms_per_iteration': sum(v[0] for v in prof.values()) / max(1, sum(niter)),
+                'two_hop_exchanges': getattr(ctrl, 'two_hop_calls', None),
+                'message_bytes': 8 * int(np.prod(uend.shape))}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     if rank == 0:
         steps_total = args.steps * world
         sweeps_total = steps_total * K if args.restol < 0 else sweeps_done * world
@@ -323,7 +343,7 @@ def main():
                     'frac': ach / HBM_PEAK_GBS, 'traffic': traffic,
                     'algorithmic_bytes_per_launch': kernel_bytes(dom[0], n, M),
                     'ms_per_launch': dom[1][0] / dom[1][1],
-                    'stream_reference_gbs': stream_reference(torch, eng)}
+                    'stream_reference_gbs': stream_reference(torch, eng) if with_stream_reference else None}
         in_sweep = ('gather', 'fft_x_fwd', 'fft_y_fwd', 'fft_z_fwd', 'fft_z_solve', 'spec_point', 'spec_point_res', 'spec_point_only', 'spec_z', 'spec_z_res', 'spec_z_spread', 'spec_z_res_spread',
                     'fft_x_norm', 'fft_x_inv_norm',
                     'fft_z_inv', 'fft_y_inv',
@@ -351,10 +371,141 @@ def main():
                                 if sweep_ms and n else None),
             'roofline': roof, 'kernels': kern, 'finite': finite,
             'device_bytes_per_gpu': eng.device_bytes,
+            'params': {'M': M, 'dt': dt, 'n': n},
         }
+        if per_rank is not None:
+            out['per_rank'] = per_rank
+        return out
+    return None
+
+
+def extras(args):
+    """short runs of the other BASELINE configurations and of the headline workload's variants, in this process, so
+    that they are measured by the same command the driver times (sub-records of the one JSON line)"""
+    import argparse as ap
+    import gc
+
+    import torch
+
+    plan = [('heat 1024^3, every sweep stores U and F like the reference\'s update_nodes (--eager-fields)',
+             dict(eager_fields=True, steps=3, warmup=1)),
+            ('heat 1024^3, iterate to restol 1e-10 (maxiter 50)', dict(restol=1e-10, steps=2, warmup=1)),
+            ('BASELINE config 2: heat 512^3', dict(n=512, steps=10, warmup=2)),
+            ('BASELINE config 3: advection-diffusion IMEX 512^3', dict(workload='advdiff', n=512, steps=10, warmup=2)),
+            ('BASELINE config 4: van der Pol, 1e7 trajectories', dict(workload='vdp', steps=10, warmup=2)),
+            ('BASELINE config 5: Allen-Cahn 256^3 / 128^3 two-level MLSDC on one GPU',
+             dict(workload='allencahn', steps=10, warmup=2))]
+    recs = []
+    for title, over in plan:
+        gc.collect()
+        torch.cuda.empty_cache()
+        a = ap.Namespace(**{**vars(args), **over})
+        try:
+            r = run_workload(a, 1, 0, False, with_stream_reference=False)
+            top = dict(list(r['kernels'].items())[:4])
+            recs.append({'title': title, 'metric': r['metric'], 'value': r['value'], 'unit': r['unit'], 'steps': r['steps'],
+                         'warmup': r['warmup'], 'ms_per_step': r['ms_per_step'], 'sdc_iters_per_s': r['sdc_iters_per_s'],
+                         'niter': r['niter'], 'workload': r['config']['workload'], 'sweep_kernels_ms': r['sweep_kernels_ms'],
+                         'sweep_floor_gbs': r['sweep_floor_gbs'], 'roofline': r['roofline'], 'kernels_top': top,
+                         'work_counters': r['work_counters'], 'finite': r['finite']})
+        except Exception as e:  # noqa: BLE001  a sub-record must never take the headline line down
+            recs.append({'title': title, 'error': repr(e)})
+    gc.collect()
+    torch.cuda.empty_cache()
+    return recs
+
+
+def preflight(torch, dist, rank, world):
+    """before any 8.6 GB buffer exists: a collective and a neighbour message of 64 MB over RCCL, so that a broken
+    fabric / IPC set-up ends the job here (non-zero exit) instead of hanging the timed run"""
+    t = torch.ones(1, device='cuda')
+    dist.all_reduce(t)
+    if int(t.item()) != world:
+        raise RuntimeError(f'all_reduce returned {t.item()} on {world} ranks')
+    if world > 1:
+        buf = torch.full((1 << 23,), float(rank), dtype=torch.float64, device='cuda')
+        inbox = torch.empty_like(buf)
+        ops = [dist.P2POp(dist.isend, buf, (rank + 1) % world), dist.P2POp(dist.irecv, inbox, (rank - 1) % world)]
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        torch.cuda.synchronize()
+        if float(inbox[0].item()) != float((rank - 1) % world) or float(inbox[-1].item()) != float((rank - 1) % world):
+            raise RuntimeError('neighbour message arrived corrupted')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--workload', default='heat', choices=['heat', 'advdiff', 'vdp', 'allencahn'],
+                    help='heat = BASELINE metric (default); advdiff = config 3 (IMEX); vdp = config 4 (ensemble); '
+                         'allencahn = config 5 (two-level MLSDC / PFASST)')
+    ap.add_argument('--n', type=int, default=None, help='grid points per dimension (heat: 1024 = BASELINE metric; advdiff: 512)')
+    ap.add_argument('--ntraj', type=int, default=10_000_000)
+    ap.add_argument('--nodes', type=int, default=5)
+    ap.add_argument('--sweeps', type=int, default=4)
+    ap.add_argument('--qi', default='IE')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--force-dist', action='store_true',
+                    help='use the one-step-per-rank controller and torch.distributed even with one GPU (self test)')
+    ap.add_argument('--no-spectral-reuse', action='store_true',
+                    help='transform the gathered fields in every sweep instead of gathering on cached transforms')
+    ap.add_argument('--solver-type', default='direct', choices=['direct', 'CG'],
+                    help="heat: 'direct' = exact solve in Fourier space (headline); 'CG' = the reference's conjugate "
+                         "gradients (rtol 1e-12) on the device, node by node")
+    ap.add_argument('--restol', type=float, default=-1.0,
+                    help='> 0: iterate to this residual instead of a fixed number of sweeps (maxiter 50); niter is reported')
+    ap.add_argument('--eager-fields', action='store_true',
+                    help='store F[1..M] and the predictor copies in every sweep / predict even when nothing reads them')
+    ap.add_argument('--mssdc', default='jacobi', choices=['jacobi', 'gs'],
+                    help='multi-step SDC over the time ranks (--gpus > 1): Jacobi (mssdc_jac=True, the default of the '
+                         'reference: all slices sweep concurrently) or Gauss-Seidel (receive, sweep, blocking send)')
+    ap.add_argument('--skip-residual', action='store_true',
+                    help="sweeper parameter skip_residual_computation for every stage (the reference's switch for runs with a "
+                         'fixed number of sweeps): no residual is computed; NOT the headline configuration')
+    ap.add_argument('--no-extras', action='store_true',
+                    help='only the headline record (default at one GPU: the line also carries short sub-records of the other '
+                         'BASELINE configurations and of the eager / restol variants, measured in the same process)')
+    ap.add_argument('--p2p-chunk-mb', type=float, default=0.0,
+                    help='time-parallel runs: cut the forward message into pieces of this size (0 = one piece)')
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
+    torch.cuda.set_device(local_rank)
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29531')
+        import datetime
+
+        try:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank),
+                                    timeout=datetime.timedelta(seconds=180))
+            preflight(torch, dist, rank, world)
+        except Exception as e:  # noqa: BLE001  fail fast and loudly: no hang, no partial line
+            print(json.dumps({'error': f'rank {rank}: RCCL preflight failed: {e!r}'}), flush=True)
+            raise SystemExit(3)
+        if args.p2p_chunk_mb > 0:
+            os.environ['PYSDC_AMD_P2P_CHUNK'] = str(int(args.p2p_chunk_mb * (1 << 20) // 8))
+
+    out = run_workload(args, world, rank, use_dist)
+    if rank == 0:
+        if world == 1 and not args.no_extras and args.workload == 'heat' and args.n is None and not args.force_dist:
+            out['sub_records'] = extras(args)
         if world == 1 and not args.no_cpu_baseline and args.workload == 'heat':
             try:
-                out['cpu_baseline'] = cpu_baseline(M, dt, target_n=n)
+                pr = out['params']
+                out['cpu_baseline'] = cpu_baseline(pr['M'], pr['dt'], target_n=pr['n'])
             except Exception as e:  # pragma: no cover
                 out['cpu_baseline'] = {'error': repr(e)}
         print(json.dumps(out), flush=True)

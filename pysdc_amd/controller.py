@@ -396,6 +396,8 @@ class controller_dist(_ControllerBase):
         self._comm_stream = None
         self._overlap = False
         self.relay = os.environ.get('PYSDC_AMD_RELAY', '1') != '0'
+        # > 0: every direct message is cut into pieces of this many values, all posted in the same batched group
+        self.p2p_chunk = int(os.environ.get('PYSDC_AMD_P2P_CHUNK', '0'))
         self.two_hop_calls = 0
         self.bcast_two_hop_calls = 0
 
@@ -536,12 +538,13 @@ class controller_dist(_ControllerBase):
                 self.req_send[level] = None
             L.sweep.compute_end_point()
             if not S.status.last:
-                ops.append(self.dist.P2POp(self.dist.isend, L.uend.as_torch(), self.rank + 1, self.comm, tag))
+                for piece in self._pieces(L.uend.as_torch()):
+                    ops.append(self.dist.P2POp(self.dist.isend, piece, self.rank + 1, self.comm, tag))
         do_recv = recv and not S.status.first and not S.status.prev_done
         inbox = self._recv_target(L) if do_recv else None
         if do_recv:
-            ops.append(self.dist.P2POp(self.dist.irecv, (inbox if inbox is not None else L.u[0]).as_torch(),
-                                       self.rank - 1, self.comm, tag))
+            for piece in self._pieces((inbox if inbox is not None else L.u[0]).as_torch()):
+                ops.append(self.dist.P2POp(self.dist.irecv, piece, self.rank - 1, self.comm, tag))
         if ops:
             # one batched launch (ncclGroupStart/End under RCCL): depending on the torch version this returns one
             # work object per operation or a single one for the whole group, so a group that contains the
@@ -556,6 +559,13 @@ class controller_dist(_ControllerBase):
         if do_recv:
             self._received(L, inbox)
         self._hook('post_comm', S, level)
+
+    def _pieces(self, t):
+        """the message as it is posted: whole, or cut into p2p_chunk-sized pieces (same cut on both sides; the pieces of
+        one message travel in order inside one group)"""
+        if self.p2p_chunk <= 0 or t.numel() <= self.p2p_chunk:
+            return [t]
+        return list(t.reshape(-1).split(self.p2p_chunk))
 
     def broadcast(self, buf, root):
         """buf of rank `root` to every rank of the group (the end value of a block, controller_MPI.py:125-130).

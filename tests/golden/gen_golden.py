@@ -11,7 +11,7 @@ own entry points, switched on by environment variables (or call the function aft
 GOLDEN_FFT=1 fft_transfer_main (transfer_fft.npz, runs_ac_fft.npz), GOLDEN_RELAY=1 relay_main (runs_relay.npz),
 GOLDEN_CG=1 cg_main (sweeps_cg.npz), GOLDEN_VDPJ=1 vdp_jacobian_main (vdp_jacobian.npz), GOLDEN_DML=1
 dirichlet_ml_main (transfer_dirichlet.npz, runs_ml_dirichlet.npz), GOLDEN_GUESS=1 guess_main (sweeps_guess.npz), GOLDEN_SKIP=1 skip_main (runs_skip.npz), GOLDEN_RELAY8=1 relay8_main (runs_relay8.npz),
-GOLDEN_BIG3D=1 big3d_main (sweeps_big3d.npz), GOLDEN_CFG5=1 cfg5_main (runs_cfg5.npz);
+GOLDEN_BIG3D=1 big3d_main (sweeps_big3d.npz), GOLDEN_CFG5=1 cfg5_main (runs_cfg5.npz), GOLDEN_ML8=1 ml8_main (runs_ml8.npz);
 GOLDEN_ML=0 skips the multi-level block.
 
 ``qmat`` (third-party, absent here) is replaced by oracle/qmat_shim, which forwards to
@@ -830,3 +830,23 @@ def cfg5_main():
 
 if __name__ == '__main__' and os.environ.get('GOLDEN_CFG5', '0') == '1':
     cfg5_main()
+
+
+def ml8_main():
+    """two-level PFASST with EIGHT processes (one node's worth of time ranks, BASELINE config 5's layout) through the
+    reference's serial controller: heat 2-D 16^2 / 8^2 with burn-in predictor, 16 steps = two blocks; and IMEX forced heat."""
+    RR = dict(quad_type='RADAU-RIGHT')
+    heat2 = dict(nvars=[(16, 16), (8, 8)], nu=0.1, freq=2, bc='periodic')
+    cases = []
+    base = dict(prob='heat_unforced', pp=heat2, sweeper='generic_implicit', sw=dict(num_nodes=3, QI='LU', **RR),
+                lp=dict(dt=0.02, restol=1e-9), maxiter=50, t0=0.0, Tend=0.32)
+    cases.append(ml_run_case('pfasst_heat2d_P8', num_procs=8, controller_params=dict(predict_type='pfasst_burnin'), **base))
+    forced = dict(prob='heat_forced', pp=heat2, sweeper='imex_1st_order', sw=dict(num_nodes=3, QI='LU', QE='EE', **RR),
+                  lp=dict(dt=0.05, restol=1e-9), maxiter=50, t0=0.0, Tend=0.4)
+    cases.append(ml_run_case('pfasst_forced2d_P8', num_procs=8, controller_params=dict(predict_type='pfasst_burnin'),
+                             **forced))
+    save('runs_ml8.npz', cases)
+
+
+if __name__ == '__main__' and os.environ.get('GOLDEN_ML8', '0') == '1':
+    ml8_main()

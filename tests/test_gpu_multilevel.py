@@ -128,7 +128,7 @@ def test_fas_on_device(name):
     check('d')
 
 
-ML_RUNS = ([('runs_ml.npz', n) for n in load_cases('runs_ml.npz')] + [('runs_ac.npz', n) for n in load_cases('runs_ac.npz')]
+ML_RUNS = ([('runs_ml.npz', n) for n in load_cases('runs_ml.npz')] + [('runs_ml8.npz', n) for n in load_cases('runs_ml8.npz')] + [('runs_ac.npz', n) for n in load_cases('runs_ac.npz')]
            + [('runs_ac_fft.npz', n) for n in load_cases('runs_ac_fft.npz')]
            + [('runs_ml_dirichlet.npz', n) for n in load_cases('runs_ml_dirichlet.npz')])
 

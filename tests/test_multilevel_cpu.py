@@ -104,7 +104,7 @@ def test_fas_restrict_prolong(name):
     check('d')
 
 
-ML_RUNS = ([('runs_ml.npz', n) for n in load_cases('runs_ml.npz')] + [('runs_ac.npz', n) for n in load_cases('runs_ac.npz')]
+ML_RUNS = ([('runs_ml.npz', n) for n in load_cases('runs_ml.npz')] + [('runs_ml8.npz', n) for n in load_cases('runs_ml8.npz')] + [('runs_ac.npz', n) for n in load_cases('runs_ac.npz')]
            + [('runs_ac_fft.npz', n) for n in load_cases('runs_ac_fft.npz')]
            + [('runs_ml_dirichlet.npz', n) for n in load_cases('runs_ml_dirichlet.npz')])
 
@@ -149,9 +149,10 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, name, outdir):
+def _worker(rank, world, port, name, outdir, fname='runs_ml.npz', chunk='0'):
     import torch.distributed as dist
 
+    os.environ['PYSDC_AMD_P2P_CHUNK'] = chunk
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -160,7 +161,7 @@ def _worker(rank, world, port, name, outdir):
         from pysdc_amd.stats import get_sorted
         from tests._oracle_step import np_mesh
 
-        case = load_cases('runs_ml.npz')[name]
+        case = load_cases(fname)[name]
         meta = case['meta']
         C = controller_dist(dict(logger_level=40, **meta['controller_params']), _ml_description(meta, case))
         shape = C.S.levels[0].o.prob.nvars
@@ -184,6 +185,25 @@ def test_pfasst_two_ranks_gloo(name):
     order = np.argsort(times)
     assert list(niter[order]) == list(case['niter'])
     for k in range(2):
+        assert rel_err(r[k]['uend'], case['uend']) < 1e-12
+
+
+@pytest.mark.parametrize('name,chunk', [('pfasst_heat2d_P8', '0'), ('pfasst_heat2d_P8', '50'), ('pfasst_forced2d_P8', '0')])
+def test_pfasst_eight_ranks_gloo(name, chunk):
+    """TWO-LEVEL PFASST with eight processes (BASELINE config 5's layout: one time slice per GPU of a node) under gloo:
+    burn-in predictor, fine and coarse forward messages per iteration, done-flag chain, two blocks with the block
+    broadcast in between - against the reference's serial controller with num_procs=8.  chunk: every forward message
+    cut into pieces of that many values (256 values per fine field here), all posted in one batched group."""
+    case = load_cases('runs_ml8.npz')[name]
+    world = 8
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(world, _free_port(), name, d, 'runs_ml8.npz', chunk), nprocs=world, join=True)
+        r = [np.load(os.path.join(d, f'r{k}.npz')) for k in range(world)]
+    times = np.concatenate([x['t'] for x in r])
+    niter = np.concatenate([x['n'] for x in r])
+    order = np.argsort(times)
+    assert list(niter[order]) == list(case['niter'])
+    for k in range(world):
         assert rel_err(r[k]['uend'], case['uend']) < 1e-12
 
 
