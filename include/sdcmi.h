@@ -81,6 +81,11 @@ int sdc_set_forcing_values(sdc_ctx* ctx, const double* g);
 /* Device pointer of one field: U[m] (m = 0..M), F[m][comp], TAU[m] (m = 0..M-1), UEND.  Non-owning; valid
  * until sdc_ctx_destroy.  These back the L.u[m] / L.f[m] views (SURVEY 8b "Level/data surface"). */
 void* sdc_slot_ptr(sdc_ctx* ctx, int slot, int m, int comp);
+/* Address of the buffer that holds (or will hold) the end value RIGHT NOW, without the side effects of sdc_slot_ptr
+ * (which assumes its caller may write and therefore forgets that UEND is the transform of the last node).  The end
+ * value alternates between two buffers from step to step (sdc_advance), so the address is only good until the next
+ * sdc_advance; writers must report through sdc_invalidate_spectra(ctx, 8). */
+void* sdc_uend_address(sdc_ctx* ctx);
 int sdc_upload(sdc_ctx* ctx, int slot, int m, int comp, const double* host);
 int sdc_download(sdc_ctx* ctx, int slot, int m, int comp, double* host);
 int sdc_set_tau_active(sdc_ctx* ctx, int active); /* L.tau[m] is None  <->  0 */

@@ -39,6 +39,15 @@ struct sdc_ctx {
     double *U = nullptr, *F = nullptr, *TAU = nullptr, *UEND = nullptr, *profile = nullptr;
     cd* W = nullptr;
     cd *S = nullptr, *S0 = nullptr;  // spectral cache: transforms of U[1..M] and of U[0] (lazy)
+    // The transform of the LAST node and the transform of u[0] trade places from one time step to the next (the end
+    // value of a step is the start value of the following one, sdc_advance): S0 and SL are, in either order, the last
+    // slot of the S block and the separately allocated spectrum Sx.  Fields 0..M-2 are S + m*Nc, field M-1 is SL.
+    cd *SL = nullptr, *Sx = nullptr;
+    // Same for the real-space pair: UEND and UEND2 alternate as the end-value buffer; after sdc_advance the start value
+    // of the new step is still where the old step left its end value (u0_src) and reaches the U[0] slab only when
+    // somebody needs it THERE (ensure_u0); read-only consumers take it where it lies (u0r).
+    double* UEND2 = nullptr;
+    const double* u0_src = nullptr;
     bool spec_valid = false, spec0_valid = false, spec_spread = false, reuse = true, force_gather = false;
     cd *tw = nullptr, *lamI = nullptr, *lamE = nullptr;
     unsigned long long* red = nullptr;  // reduction slots (device)

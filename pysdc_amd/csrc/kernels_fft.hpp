@@ -184,6 +184,110 @@ __global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_inv(FieldPtr
     }
 }
 
+// cos / sin (pi i / 16), i = 0..15
+__device__ static const double kCosPiOver[16] = {1.0, 0.98078528040323044913, 0.92387953251128675613, 0.83146961230254523708,
+                                                 0.70710678118654752440, 0.55557023301960222474, 0.38268343236508977173,
+                                                 0.19509032201612826785, 0.0, -0.19509032201612826785, -0.38268343236508977173,
+                                                 -0.55557023301960222474, -0.70710678118654752440, -0.83146961230254523708,
+                                                 -0.92387953251128675613, -0.98078528040323044913};
+__device__ static const double kSinPiOver[16] = {0.0, 0.19509032201612826785, 0.38268343236508977173, 0.55557023301960222474,
+                                                 0.70710678118654752440, 0.83146961230254523708, 0.92387953251128675613,
+                                                 0.98078528040323044913, 1.0, 0.98078528040323044913, 0.92387953251128675613,
+                                                 0.83146961230254523708, 0.70710678118654752440, 0.55557023301960222474,
+                                                 0.38268343236508977173, 0.19509032201612826785};
+#ifndef SDC_XHALF
+#define SDC_XHALF 0  // 1: norm-only c2r pass by the half-length transform (below) for N = 256, 512, 1024 - measured SLOWER
+                     // at 1024^3 (12.9 ms against 10.2 ms of the two-for-one kernel), kept as an experiment switch
+#endif
+#ifndef SDC_XHALF_MIRROR
+#define SDC_XHALF_MIRROR 1
+#endif
+#ifndef SDC_XHALF_T
+#define SDC_XHALF_T 8
+#endif
+#ifndef SDC_XHALF_WAVES
+#define SDC_XHALF_WAVES 4
+#endif
+// c2r along axis 0, norm only, by the half-length transform: with H = N/2 and the Hermitian rows X[0..H] of a column,
+//   Z[k] = (X[k] + conj X[H-k]) + i e^{+2 pi i k/N} (X[k] - conj X[H-k]),  k = 0..H-1,
+// the H-point inverse transform z = IFFT_H(Z) holds the real line as z[m] = x[2m] + i x[2m+1].  One column is ONE
+// complex line of length H instead of half of a packed line of length N, so every input byte costs half the LDS
+// traffic of the two-for-one kernel above (k_fftx_inv: ~10 bytes through LDS per byte from HBM, which is what bounds
+// it at 1024^3) and the mirrored half needs no trip through LDS either: a thread fetches row H-k itself (the second
+// request for a row comes from a thread of the same workgroup and is served from cache).  tw: e^{-2 pi i k/N}, k < N;
+// twh: the table of the H-point transform.
+template <int N, int T>
+__global__ __launch_bounds__((N / 2 / fft_elems(N / 2)) * T, SDC_XHALF_WAVES) void k_fftx_norm_half(
+    const cd* __restrict__ W, size_t fstride, int rest, const cd* __restrict__ tw, const cd* __restrict__ twh,
+    unsigned long long* __restrict__ norms) {
+    constexpr int H = N / 2, E = fft_elems(H), P = H / E;
+    using LAY = LayStrided<H, T>;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int col = threadIdx.x % T, j = threadIdx.x / T;
+    const int c = blockIdx.x * T + col;
+    const bool ok = c < rest;
+    const cd* __restrict__ Wf = W + blockIdx.y * fstride + c;
+    // pre-twiddle e^{+2 pi i k/N}, k = j + i P: one table look-up (k = j) times the constant e^{+i pi i/E}
+    const cd wj = ok ? tw[j] : cd{1.0, 0.0};
+    auto pre = [&](int i, cd x, cd y) {
+        const int k = j + i * P;
+        if (k == 0) x.y = y.y = 0.0;  // rows 0 and H of a real line are real (c2r convention: imaginary parts dropped)
+        const cd e = cd{x.x + y.x, x.y - y.y};  // X[k] + conj X[H-k]
+        const cd d = cd{x.x - y.x, x.y + y.y};  // X[k] - conj X[H-k]
+        const double ci = kCosPiOver[(i * 16) / E], si = kSinPiOver[(i * 16) / E];
+        const cd w = cd{wj.x * ci + wj.y * si, wj.x * si - wj.y * ci};  // conj(tw[j]) * e^{+i pi i/E} = (c, s): real, imag
+        const cd o = cd{d.x * w.x - d.y * w.y, d.x * w.y + d.y * w.x};
+        return cd{e.x - o.y, e.y + o.x};
+    };
+    cd r[E];
+#if SDC_XHALF_MIRROR
+    // own rows from memory, the mirrored ones from the threads that loaded them (through LDS, one plane at a time);
+    // row H, the partner of row 0, is fetched by the thread that owns row 0
+#pragma unroll
+    for (int i = 0; i < E; ++i) r[i] = ok ? Wf[(size_t)(j + i * P) * rest] : cd{0.0, 0.0};
+    cd top = cd{0.0, 0.0};
+    if (j == 0 && ok) top = Wf[(size_t)H * rest];
+    double bx[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i) lds[LAY::idx(col, j + i * P)] = r[i].x;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+        const int k = j + i * P;
+        bx[i] = k == 0 ? top.x : lds[LAY::idx(col, H - k)];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < E; ++i) lds[LAY::idx(col, j + i * P)] = r[i].y;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+        const int k = j + i * P;
+        const double by = k == 0 ? top.y : lds[LAY::idx(col, H - k)];
+        r[i] = pre(i, r[i], cd{bx[i], by});
+    }
+    __syncthreads();
+#else
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+        const int k = j + i * P;
+        const cd x = ok ? Wf[(size_t)k * rest] : cd{0.0, 0.0};
+        const cd y = ok ? Wf[(size_t)(H - k) * rest] : cd{0.0, 0.0};
+        r[i] = pre(i, x, y);
+    }
+#endif
+    fft_line<H, +1, LAY>(r, j, col, lds, twh);
+    double m = 0.0;  // columns beyond the edge were transformed from zeros
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+        const double v0 = fabs(r[i].x), v1 = fabs(r[i].y);
+        const double v = (v0 > v1 || v0 != v0) ? v0 : v1;
+        m = (m > v || m != m) ? m : v;
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomic_max_abs(norms + blockIdx.y, m);
+}
+
 // c2c in place along the middle axis of W[f][kx][y][z] (3-D only): tile = all y x T z-columns
 template <int N, int T, int DIR>
 __global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_ffty(cd* __restrict__ W, size_t fstride,
@@ -311,7 +415,7 @@ __global__ __launch_bounds__(z_lines_per_block<N>() * (N / fft_elems(N)) * MAXM,
 template <int N, int DIR>
 __global__ __launch_bounds__(z_lines_per_block<N>() * (N / fft_elems(N)) * MAXM, 4) void k_fftz_plain(
     const cd* __restrict__ src, cd* __restrict__ dst, size_t fstride, const cd* __restrict__ tw, unsigned nlines,
-    double scale) {
+    double scale, const cd* __restrict__ src_one = nullptr, int one = -1) {
     constexpr int E = fft_elems(N), P = N / E, LPB = z_lines_per_block<N>();
     using LAY = LayContig<N>;
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -321,8 +425,10 @@ __global__ __launch_bounds__(z_lines_per_block<N>() * (N / fft_elems(N)) * MAXM,
     const bool ok = line < nlines;
     const size_t base = f * fstride + line * N;
     cd r[E];
+    // (source field `one` may live outside the strided block: the last node's spectrum, SpecArgs::SL)
+    const cd* __restrict__ in = (f == one) ? src_one + line * N : src + base;
 #pragma unroll
-    for (int i = 0; i < E; ++i) r[i] = ok ? src[base + j + i * P] : cd{0.0, 0.0};
+    for (int i = 0; i < E; ++i) r[i] = ok ? in[j + i * P] : cd{0.0, 0.0};
     if (scale != 1.0) {
 #pragma unroll
         for (int i = 0; i < E; ++i) r[i] = cscale(r[i], scale);
@@ -334,6 +440,10 @@ __global__ __launch_bounds__(z_lines_per_block<N>() * (N / fft_elems(N)) * MAXM,
     }
 }
 
+// field q of the spectral cache: the last one lives behind its own pointer (see SpecArgs::SL); q is a compile-time
+// constant wherever this is used (unrolled loops), so the choice costs nothing at run time
+#define SPEC_FIELD(a, q, NF_) ((q) == (NF_) - 1 ? (a).SL : (a).S + (size_t)(q) * (a).fstride)
+
 // Sweep in the transformed domain (DESIGN.md "spectral reuse").  For linear f(u) = A u (+ B u) the gathered
 // right-hand side of node m is  u0 + dt sum_j (Q-QI)[m][j] A u_j^k (+ explicit part): its transform follows
 // from the transforms of u0 and of the previous iterate, which the previous sweep left in S.  One launch
@@ -341,6 +451,7 @@ __global__ __launch_bounds__(z_lines_per_block<N>() * (N / fft_elems(N)) * MAXM,
 // their inverse transform along the contiguous axis to W (input of the inverse y / x passes).
 struct SpecArgs {
     cd* S;
+    cd* SL;  // spectrum of the LAST node: S + (nf-1)*fstride, or the buffer it swaps with S0 from step to step (sdc_advance)
     size_t fstride;
     const cd* S0;
     cd* W;
@@ -379,7 +490,7 @@ __global__ __launch_bounds__(256) void k_spec_point(SpecArgs a, int n, size_t nm
         const cd ph = a.SP ? a.SP[g] : cd{0.0, 0.0};
         cd old[NF], u[NF];
 #pragma unroll
-        for (int q = 0; q < NF; ++q) old[q] = a.spread ? u0h : a.S[q * a.fstride + g];
+        for (int q = 0; q < NF; ++q) old[q] = a.spread ? u0h : SPEC_FIELD(a, q, NF)[g];
 #pragma unroll
         for (int m = 0; m < NF; ++m) {
             cd acc = cd{fma(a.cP[m], ph.x, u0h.x), fma(a.cP[m], ph.y, u0h.y)};
@@ -401,7 +512,7 @@ __global__ __launch_bounds__(256) void k_spec_point(SpecArgs a, int n, size_t nm
             if (a.lamE) acc = cfma(mu, tE, acc);
             const double al = a.alpha[m];
             u[m] = cmul(acc, cinv_fast(cd{1.0 - al * lam.x, -al * lam.y}));
-            a.S[m * a.fstride + g] = u[m];  // (nontemporal stores measured slower here: 18.5 vs 17.4 ms at 1024^3)
+            SPEC_FIELD(a, m, NF)[g] = u[m];  // (nontemporal stores measured slower here: 18.5 vs 17.4 ms at 1024^3)
         }
         if constexpr (RES) {
             const cd sym = cadd(lam, mu);
@@ -440,7 +551,7 @@ __global__ __launch_bounds__(256) void k_spec_residual(SpecArgs a, int n, size_t
         const cd ph = a.SP ? a.SP[g] : cd{0.0, 0.0};
         cd u[NF];
 #pragma unroll
-        for (int q = 0; q < NF; ++q) u[q] = a.S[q * a.fstride + g];
+        for (int q = 0; q < NF; ++q) u[q] = SPEC_FIELD(a, q, NF)[g];
 #pragma unroll
         for (int m = 0; m < NF; ++m) {
             cd acc = csub(u0h, u[m]);
@@ -523,7 +634,7 @@ __global__ __launch_bounds__(specz_lines<N>() * (N / specz_elems<N>()) * NF,
                 if (HASP) inp[it] = a.SP[g];
                 if (!UPD || !a.spread) {
 #pragma unroll
-                    for (int q = 0; q < NF; ++q) inq[it][q] = a.S[q * a.fstride + g];
+                    for (int q = 0; q < NF; ++q) inq[it][q] = SPEC_FIELD(a, q, NF)[g];
                 }
             }
         }
@@ -576,10 +687,10 @@ __global__ __launch_bounds__(specz_lines<N>() * (N / specz_elems<N>()) * NF,
                     const double al = a.alpha[m];
                     u[m] = cmul(acc, cinv_fast(cd{1.0 - al * lam.x, -al * lam.y}));
 #if SDC_SPECZ_NT & 1
-                    __builtin_nontemporal_store(u[m].x, &a.S[m * a.fstride + g].x);
-                    __builtin_nontemporal_store(u[m].y, &a.S[m * a.fstride + g].y);
+                    __builtin_nontemporal_store(u[m].x, &SPEC_FIELD(a, m, NF)[g].x);
+                    __builtin_nontemporal_store(u[m].y, &SPEC_FIELD(a, m, NF)[g].y);
 #else
-                    a.S[m * a.fstride + g] = u[m];
+                    SPEC_FIELD(a, m, NF)[g] = u[m];
 #endif
                 }
                 if constexpr (RES) {

@@ -43,6 +43,22 @@ static inline int grid_for(size_t work, int block) {
     return (int)g;
 }
 
+// the start value where it lies (read-only consumers) / brought home to the U[0] slab (everybody else)
+static inline const double* u0r(sdc_ctx* c) { return c->u0_src ? c->u0_src : c->U; }
+static int ensure_u0(sdc_ctx* c) {
+    if (c->u0_src) {
+        const double* src = c->u0_src;
+        c->u0_src = nullptr;
+        HIPCHK(c, hipMemcpyAsync(c->U, src, c->N * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    }
+    return SDC_OK;
+}
+#define ENSURE_U0(c)                       \
+    do {                                   \
+        int rcu_ = ensure_u0(c);           \
+        if (rcu_ != SDC_OK) return rcu_;   \
+    } while (0)
+
 static double* slot_ptr(sdc_ctx* c, int slot, int m, int comp) {
     switch (slot) {
         case SDC_SLOT_U: return (m >= 0 && m <= c->M) ? c->U + (size_t)m * c->N : nullptr;
@@ -332,8 +348,15 @@ static int inverse_tail_n(sdc_ctx* c, int nf, cd* work, const FieldPtrs& p, unsi
                                    work, c->Nc, rest, c->tw, norms);
             } else {
                 LaunchTimer lt(c, pname("fft_x_norm", nf));
-                hipLaunchKernelGGL((k_fftx_inv<N, T, true, false>), dim3(tiles, nf), dim3(P * T), lds_str, c->stream, p,
-                                   work, c->Nc, rest, c->tw, norms);
+                if constexpr (SDC_XHALF && (N == 256 || N == 512 || N == 1024)) {
+                    constexpr int H = N / 2, TH = SDC_XHALF_T, PH = H / fft_elems(H);
+                    const size_t lds_half = (size_t)LayStrided<H, TH>::doubles(TH) * sizeof(double);
+                    hipLaunchKernelGGL((k_fftx_norm_half<N, TH>), dim3((rest + TH - 1) / TH, nf), dim3(PH * TH), lds_half,
+                                       c->stream, work, c->Nc, rest, c->tw, c->tw + N, norms);
+                } else {
+                    hipLaunchKernelGGL((k_fftx_inv<N, T, true, false>), dim3(tiles, nf), dim3(P * T), lds_str, c->stream,
+                                       p, work, c->Nc, rest, c->tw, norms);
+                }
             }
         } else {
             LaunchTimer lt(c, pname("fft_x_inv", nf));
@@ -349,7 +372,7 @@ static int inverse_tail_n(sdc_ctx* c, int nf, cd* work, const FieldPtrs& p, unsi
 // (work may equal src: in place) into the real fields out[f] - or, with norms != null, into max |.| per field
 template <int N>
 static int inverse_passes_n(sdc_ctx* c, int nf, const cd* src, cd* work, const FieldPtrs& p, unsigned long long* norms,
-                            double scale) {
+                            double scale, const cd* src_one = nullptr, int one = -1) {
     constexpr int P = N / fft_elems(N), LPB = z_lines_per_block<N>();
     const int n = c->n;
     const size_t lines = c->ndim == 1 ? 1 : (size_t)(n / 2 + 1) * (c->ndim == 3 ? n : 1);
@@ -357,7 +380,7 @@ static int inverse_passes_n(sdc_ctx* c, int nf, const cd* src, cd* work, const F
         LaunchTimer lt(c, pname("fft_z_inv", nf));
         const size_t ldsz = (size_t)LayContig<N>::doubles(nf * LPB) * sizeof(double);
         hipLaunchKernelGGL((k_fftz_plain<N, +1>), dim3((unsigned)((lines + LPB - 1) / LPB)), dim3(P * LPB * nf), ldsz,
-                           c->stream, src, work, c->Nc, c->tw, (unsigned)lines, scale);
+                           c->stream, src, work, c->Nc, c->tw, (unsigned)lines, scale, src_one, one);
     }
     return inverse_tail_n<N>(c, nf, work, p, norms);
 }
@@ -379,7 +402,7 @@ static int early_end_point_n(sdc_ctx* c, bool norms_only) {
     FieldPtrs pe;
     memset(&pe, 0, sizeof pe);
     pe.out[0] = c->UEND;
-    int rc = inverse_passes_n<N>(c, 1, c->S + (size_t)(c->M - 1) * c->Nc, c->W2, pe, nullptr, 1.0 / (double)c->N);
+    int rc = inverse_passes_n<N>(c, 1, c->SL, c->W2, pe, nullptr, 1.0 / (double)c->N);
     if (rc != SDC_OK) return rc;
     c->uend_gen = c->spec_gen;
     HIPCHK(c, hipEventRecord(c->uend_ev, c->stream));
@@ -460,7 +483,7 @@ static int spec_sweep_n(sdc_ctx* c, int nf, SpecArgs& a, const FieldPtrs& p, uns
         if (rce != SDC_OK) return rce;
         return inverse_tail_n<N>(c, nf, c->W, p, norms);
     }
-    return inverse_passes_n<N>(c, nf, c->S, c->W, p, norms, a.invN);
+    return inverse_passes_n<N>(c, nf, c->S, c->W, p, norms, a.invN, c->SL, nf - 1);
 }
 
 #define N_DISPATCH(c, CALL)                                                                                 \
@@ -563,7 +586,7 @@ static int spec_residual(sdc_ctx* c, double dt, unsigned long long* norms) {
     if (!c->spec0_valid) {
         FieldPtrs p0;
         memset(&p0, 0, sizeof p0);
-        p0.in[0] = c->U;
+        p0.in[0] = u0r(c);
         int rc0 = fwd_transform(c, 1, p0, c->S0, 0);
         if (rc0 != SDC_OK) return rc0;
         c->spec0_valid = true;
@@ -573,6 +596,7 @@ static int spec_residual(sdc_ctx* c, double dt, unsigned long long* norms) {
     int rcf = forcing_spectrum(c, a, dt);
     if (rcf != SDC_OK) return rcf;
     a.S = c->S;
+    a.SL = c->SL;
     a.fstride = c->Nc;
     a.S0 = c->S0;
     a.W = c->W;
@@ -593,7 +617,10 @@ static int inverse_from_cache(sdc_ctx* c, int first, int nf, const FieldPtrs& p)
     int rw = ensure_work(c);
     if (rw != SDC_OK) return rw;
     const double invN = 1.0 / (double)c->N;
-#define CALL(NN) inverse_passes_n<NN>(c, nf, c->S + (size_t)first * c->Nc, c->W, p, nullptr, invN)
+    // (the last node's spectrum lives behind its own pointer)
+    const bool has_last = first + nf == c->M;
+#define CALL(NN) \
+    inverse_passes_n<NN>(c, nf, c->S + (size_t)first * c->Nc, c->W, p, nullptr, invN, has_last ? c->SL : nullptr, has_last ? nf - 1 : -1)
     N_DISPATCH(c, CALL)
 #undef CALL
 }
@@ -768,8 +795,10 @@ int sdc_ctx_create(sdc_ctx** out, int device, int ndim, int n, int num_nodes, in
                 const long double ang = 2.0L * 3.14159265358979323846264338327950288L * (long double)m / (long double)n;
                 tw[m] = cd{(double)cosl(ang), (double)(-sinl(ang))};
             }
-            HIPCHK(nullptr, hipMalloc((void**)&c->tw, sizeof(cd) * n));
-            HIPCHK(nullptr, hipMemcpyAsync(c->tw, tw.data(), sizeof(cd) * n, hipMemcpyHostToDevice, c->stream));
+            // behind it the table of the half-length transform (k_fftx_norm_half): e^{-2 pi i m/(n/2)}, m < n/2
+            for (int m = 0; m < n / 2; ++m) tw.push_back(tw[2 * m]);
+            HIPCHK(nullptr, hipMalloc((void**)&c->tw, sizeof(cd) * tw.size()));
+            HIPCHK(nullptr, hipMemcpyAsync(c->tw, tw.data(), sizeof(cd) * tw.size(), hipMemcpyHostToDevice, c->stream));
         }
         HIPCHK(nullptr, hipStreamSynchronize(c->stream));
         return SDC_OK;
@@ -796,7 +825,8 @@ int sdc_ctx_destroy(sdc_ctx* c) {
     (void)hipFree(c->SP);
     if (c->uend_ev) (void)hipEventDestroy(c->uend_ev);
     (void)hipFree(c->S);
-    (void)hipFree(c->S0);
+    (void)hipFree(c->Sx);
+    (void)hipFree(c->UEND2);
     (void)hipFree(c->tw);
     (void)hipFree(c->lamI);
     (void)hipFree(c->lamE);
@@ -971,10 +1001,26 @@ static int ensure_tau(sdc_ctx* c) {
     return SDC_OK;
 }
 
+static int ensure_spec_cache(sdc_ctx* c) {
+    if (!c->S) {
+        HIPCHK(c, hipMalloc((void**)&c->S, sizeof(cd) * c->Nc * c->M));
+        HIPCHK(c, hipMalloc((void**)&c->Sx, sizeof(cd) * c->Nc));
+        c->S0 = c->Sx;
+        c->SL = c->S + (size_t)(c->M - 1) * c->Nc;
+        c->bytes += sizeof(cd) * c->Nc * (c->M + 1);
+        c->spec_valid = c->spec0_valid = false;
+    }
+    if (!c->UEND2) {  // the second end-value buffer of sdc_advance, allocated with the cache (not inside a time loop)
+        HIPCHK(c, hipMalloc((void**)&c->UEND2, c->N * sizeof(double)));
+        c->bytes += c->N * sizeof(double);
+    }
+    return SDC_OK;
+}
+
 static int launch_spread(sdc_ctx* c, int guess, double fill_u, double fill_f, bool reduce_f0) {
     SpreadArgs a;
     memset(&a, 0, sizeof a);
-    a.u0 = c->U;
+    a.u0 = u0r(c);
     a.f0 = c->F;
     a.profile = c->profile;
     a.U = c->U;
@@ -1001,7 +1047,7 @@ static int materialize(sdc_ctx* c, bool need_u, bool need_f) {
     if (c->spread_pending && (need_u || need_f)) {
         if (c->f0_pending) {  // the copies are copies of F[0]
             c->f0_pending = false;
-            int rc0 = sdc_eval_f(c, c->U, c->gvals[0], c->F, c->ncomp == 2 ? c->F + c->N : nullptr);
+            int rc0 = sdc_eval_f(c, u0r(c), c->gvals[0], c->F, c->ncomp == 2 ? c->F + c->N : nullptr);
             if (rc0 != SDC_OK) return rc0;
         }
         c->spread_pending = false;
@@ -1024,8 +1070,9 @@ static int materialize(sdc_ctx* c, bool need_u, bool need_f) {
 int sdc_materialize(sdc_ctx* c, int slot, int m) {
     if (!c) return SDC_ERR_PARAM;
     if (slot == SDC_SLOT_U && m == 0) {
-        // U[0] itself is never deferred, but whoever gets its address may overwrite it: a pending spread and a
-        // pending F[0] = f(U[0]) refer to the value it holds NOW
+        // whoever gets the address of U[0] may read or overwrite it: the start value has to BE there, and a pending
+        // spread and a pending F[0] = f(U[0]) refer to the value it holds NOW
+        ENSURE_U0(c);
         if (c->spread_pending) {
             int rc0 = materialize(c, true, false);
             if (rc0 != SDC_OK) return rc0;
@@ -1039,8 +1086,9 @@ int sdc_materialize(sdc_ctx* c, int slot, int m) {
     if (slot == SDC_SLOT_F && m == 0) {
         if (!c->f0_pending) return SDC_OK;
         c->f0_pending = false;
-        return sdc_eval_f(c, c->U, c->gvals[0], c->F, c->ncomp == 2 ? c->F + c->N : nullptr);
+        return sdc_eval_f(c, u0r(c), c->gvals[0], c->F, c->ncomp == 2 ? c->F + c->N : nullptr);
     }
+    if (slot < 0) ENSURE_U0(c);  // "everything": all of the real-space state is about to be used as it is stored
     if (slot < 0 && c->f0_pending) {
         c->f0_pending = false;
         int rc0 = sdc_eval_f(c, c->U, c->gvals[0], c->F, c->ncomp == 2 ? c->F + c->N : nullptr);
@@ -1062,6 +1110,8 @@ int sdc_defer_f0(sdc_ctx* c) {
     c->f0_pending = true;
     return c->deferred ? SDC_OK : sdc_materialize(c, SDC_SLOT_F, 0);
 }
+
+void* sdc_uend_address(sdc_ctx* c) { return c ? (void*)c->UEND : nullptr; }
 
 void* sdc_slot_ptr(sdc_ctx* c, int slot, int m, int comp) {
     if (!c) return nullptr;
@@ -1216,6 +1266,7 @@ int sdc_predict(sdc_ctx* c, double t, double dt, int guess, double fill_u, doubl
     if (spread_res) HIPCHK(c, hipMemsetAsync(c->res_dev, 0, sizeof(unsigned long long) * 8, c->stream));
     c->spread_pending = c->f_pending = c->u_pending = c->f0_pending = c->rfields_valid = false;
     const bool lazy_spread = c->deferred && c->kind == 0 && guess == SDC_GUESS_SPREAD && c->expl_kind != SDC_EXPL_FORCING;
+    if (!lazy_spread) ENSURE_U0(c);  // (the deferred spread only READS the start value: wherever it lies)
     // with the 3-D three-point kernel even f(u0) itself is not stored: one pass over u0 that only reduces max|f(u0)|
     auto three = [](const Stencil& s) { return s.npts == 3 && s.off[0] == -1 && s.off[1] == 0 && s.off[2] == 1; };
     const bool explS = c->expl_kind == SDC_EXPL_STENCIL;
@@ -1227,7 +1278,7 @@ int sdc_predict(sdc_ctx* c, double t, double dt, int guess, double fill_u, doubl
         constexpr int RPT = 4;
         Stencil3Args s3;
         memset(&s3, 0, sizeof s3);
-        s3.in[0] = c->U;
+        s3.in[0] = u0r(c);
         for (int k = 0; k < 3; ++k) {
             s3.wI[k] = c->st[0].w[k];
             s3.wE[k] = explS ? c->st[1].w[k] : 0.0;
@@ -1245,7 +1296,7 @@ int sdc_predict(sdc_ctx* c, double t, double dt, int guess, double fill_u, doubl
         HIPCHK(c, hipGetLastError());
         c->f0_pending = true;
     } else {
-        rc = sdc_eval_f(c, c->U, c->gvals[0], c->F, c->ncomp == 2 ? c->F + c->N : nullptr);
+        rc = sdc_eval_f(c, u0r(c), c->gvals[0], c->F, c->ncomp == 2 ? c->F + c->N : nullptr);
         if (rc != SDC_OK) return rc;
     }
     if (lazy_spread) {
@@ -1431,6 +1482,14 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
     }
     if (c->expl_kind == SDC_EXPL_STENCIL && !c->have_stencil[1])
         return fail(c, SDC_ERR_STATE, "explicit operator not set (sdc_set_stencil which=1)");
+    {
+        // only a sweep that stays in Fourier space and stores nothing in real space leaves the start value where it
+        // lies (u0_src); every other data flow reads the U[0] slab
+        const bool fourier_only = c->reuse && !c->force_gather && !c->tau_active && c->have_stencil[0] && fourier_ok(c) &&
+                                  c->expl_kind != SDC_EXPL_REACTION && !c->spectral_op && c->solver_kind == 0 &&
+                                  c->deferred && c->ndim >= 2 && (c->skip_residual || c->fuse_residual);
+        if (!fourier_only) ENSURE_U0(c);
+    }
     if (c->expl_kind == SDC_EXPL_REACTION || c->spectral_op) return sweep_nodewise(c, dt);
     if (c->solver_kind == 1 || !fourier_ok(c)) return sweep_nodewise(c, dt, true);
     const bool gather_once = c->force_gather;
@@ -1438,16 +1497,14 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
     if (c->reuse && !gather_once && !c->tau_active && c->have_stencil[0] &&
         fourier_ok(c)) {
         // ---- spectral reuse: f is linear in u, so the gather happens on the cached transforms ----
-        if (!c->S) {
-            HIPCHK(c, hipMalloc((void**)&c->S, sizeof(cd) * c->Nc * M));
-            HIPCHK(c, hipMalloc((void**)&c->S0, sizeof(cd) * c->Nc));
-            c->bytes += sizeof(cd) * c->Nc * (M + 1);
-            c->spec_valid = c->spec0_valid = false;
+        {
+            int rca = ensure_spec_cache(c);
+            if (rca != SDC_OK) return rca;
         }
         FieldPtrs p;
         memset(&p, 0, sizeof p);
         if (!c->spec0_valid) {
-            p.in[0] = c->U;
+            p.in[0] = u0r(c);
             int rc0 = fwd_transform(c, 1, p, c->S0, 0);
             if (rc0 != SDC_OK) return rc0;
             c->spec0_valid = true;
@@ -1455,9 +1512,17 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
         if (!c->spec_valid && !c->spec_spread) {
             int rcm = materialize(c, true, false);
             if (rcm != SDC_OK) return rcm;
-            for (int m = 0; m < M; ++m) p.in[m] = c->U + (size_t)(m + 1) * c->N;
-            int rc0 = fwd_transform(c, M, p, c->S, c->Nc);
-            if (rc0 != SDC_OK) return rc0;
+            // the first M-1 nodes into the strided block, the last one to wherever its spectrum lives right now
+            for (int m = 0; m < M - 1; ++m) p.in[m] = c->U + (size_t)(m + 1) * c->N;
+            if (M > 1) {
+                int rc0 = fwd_transform(c, M - 1, p, c->S, c->Nc);
+                if (rc0 != SDC_OK) return rc0;
+            }
+            memset(&p, 0, sizeof p);
+            p.in[0] = c->U + (size_t)M * c->N;
+            int rc1 = fwd_transform(c, 1, p, c->SL, 0);
+            if (rc1 != SDC_OK) return rc1;
+            memset(&p, 0, sizeof p);
             c->spec_gen++;
             c->spec_valid = true;
         }
@@ -1466,6 +1531,7 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
         int rcf = forcing_spectrum(c, a, dt);
         if (rcf != SDC_OK) return rcf;
         a.S = c->S;
+        a.SL = c->SL;
         a.fstride = c->Nc;
         a.S0 = c->S0;
         a.W = c->W;
@@ -1737,6 +1803,7 @@ int sdc_residual(sdc_ctx* c, double dt, int type, double* node_norms, double* re
         int rcs = spec_residual(c, dt, c->red);
         if (rcs != SDC_OK) return rcs;
     } else {
+        ENSURE_U0(c);
         int rcm = materialize(c, true, true);
         if (rcm != SDC_OK) return rcm;
         QuadArgs q;
@@ -1752,7 +1819,7 @@ int sdc_residual(sdc_ctx* c, double dt, int type, double* node_norms, double* re
     }
     if (type >= SDC_RES_FULL_REL) {
         LaunchTimer lt(c, "amax");
-        hipLaunchKernelGGL(k_amax, dim3(grid_for(c->N, 256)), dim3(256), 0, c->stream, c->U, c->N, c->red + 8);
+        hipLaunchKernelGGL(k_amax, dim3(grid_for(c->N, 256)), dim3(256), 0, c->stream, u0r(c), c->N, c->red + 8);
     }
     HIPCHK(c, hipMemcpyAsync(c->red_host, c->red, sizeof(unsigned long long) * 16, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1802,9 +1869,10 @@ int sdc_end_point(sdc_ctx* c, double dt, int do_coll_update) {
             return rci;
         }
         // a pending spread means U[M] equals U[0]
-        return sdc_vec_copy(c, c->N, c->U + (c->spread_pending ? 0 : (size_t)c->M * c->N), c->UEND);
+        return sdc_vec_copy(c, c->N, c->spread_pending ? u0r(c) : c->U + (size_t)c->M * c->N, c->UEND);
     }
     c->uend_gen = -1;
+    ENSURE_U0(c);
     int rcm = materialize(c, false, true);
     if (rcm != SDC_OK) return rcm;
     QuadArgs q;
@@ -1822,14 +1890,34 @@ int sdc_advance(sdc_ctx* c) {
     if (!c) return SDC_ERR_PARAM;
     int rcm = materialize(c, c->spread_pending, false);  // pending copies of the OLD u[0] are stored first
     if (rcm != SDC_OK) return rcm;
-    HIPCHK(c, hipMemcpyAsync(c->U, c->UEND, c->N * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     c->res_valid = false;
     c->res_spread = false;
     c->spec_spread = false;
-    if (c->S && c->spec_valid && c->uend_gen >= 0 && c->uend_gen == c->spec_gen) {
-        // UEND is the inverse transform of S[M-1]: that spectrum is the transform of the new u[0]
-        HIPCHK(c, hipMemcpyAsync(c->S0, c->S + (size_t)(c->M - 1) * c->Nc, sizeof(cd) * c->Nc, hipMemcpyDeviceToDevice,
-                                 c->stream));
+    // UEND is the inverse transform of the last node's spectrum: that spectrum is the transform of the new u[0]
+    const bool handover = c->S && c->spec_valid && c->uend_gen >= 0 && c->uend_gen == c->spec_gen;
+    if (handover && c->kind == 0 && c->deferred) {
+        // Fourier-space data flow: nothing is copied.  The spectrum of the last node and the spectrum of u[0] trade
+        // places (the first sweep after the predictor rewrites every node spectrum), the end-value buffer becomes the
+        // place where the new start value lies, and the other buffer of the pair takes the next end value.
+        if (!c->UEND2) {
+            HIPCHK(c, hipMalloc((void**)&c->UEND2, c->N * sizeof(double)));
+            c->bytes += c->N * sizeof(double);
+        }
+        int rcf = uend_write_fence(c);  // (a send that still reads the old end value of the buffer we are about to reuse)
+        if (rcf != SDC_OK) return rcf;
+        c->u0_src = c->UEND;
+        std::swap(c->UEND, c->UEND2);
+        std::swap(c->S0, c->SL);
+        c->spec0_valid = true;
+        c->spec_valid = false;  // the node values of the step that just ended are gone (reset_level, core/level.py:110-131)
+        c->u_pending = c->f_pending = c->rfields_valid = false;
+        c->uend_gen = -1;       // UEND now names the other buffer
+        return SDC_OK;
+    }
+    c->u0_src = nullptr;  // U[0] is overwritten as a whole
+    HIPCHK(c, hipMemcpyAsync(c->U, c->UEND, c->N * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    if (handover) {
+        HIPCHK(c, hipMemcpyAsync(c->S0, c->SL, sizeof(cd) * c->Nc, hipMemcpyDeviceToDevice, c->stream));
         c->spec0_valid = true;
     } else {
         c->spec0_valid = false;
@@ -1864,6 +1952,7 @@ int sdc_set_keep_residual_fields(sdc_ctx* c, int on) {
 
 int sdc_replace_u0(sdc_ctx* c, const double* src) {
     if (!c || !src) return fail(c, SDC_ERR_PARAM, "null pointer");
+    ENSURE_U0(c);  // (the update of the kept residual fields reads the old start value)
     int rcm = materialize(c, c->spread_pending, false);  // pending copies of the OLD u[0] are stored first
     if (rcm != SDC_OK) return rcm;
     const bool fast = c->rfields_valid && c->res_valid && c->u_pending && !c->tau_active;

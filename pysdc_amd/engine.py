@@ -138,6 +138,10 @@ class SweepEngine:
             raise ParameterError(f'bad slot ({slot}, {m}, {comp})')
         return p
 
+    def uend_address(self):
+        """where the end value lies right now (include/sdcmi.h: sdc_uend_address; changes with every advance())"""
+        return self.lib.sdc_uend_address(self.ctx)
+
     def upload(self, slot, m, host, comp=0):
         h = np.ascontiguousarray(host, dtype=np.float64).reshape(-1)
         if h.size != self.N:

@@ -158,9 +158,12 @@ class DeviceBacked:
             self._tau = SlabList(self, Lb.SLOT_TAU, M)
 
     def _uend_slab_view(self):
-        if self._uend_view is None:
-            e = self.engine
-            self._uend_view = hip_mesh.view(e.ptr(Lb.SLOT_UEND) + 8 * self._view_offset(), self._field_shape(), keep=e,
+        # the end value alternates between two device buffers from step to step (sdc_advance): the view is rebuilt
+        # whenever the address has moved; it reports writes (on_write), so the plain address is enough
+        e = self.engine
+        addr = e.uend_address() + 8 * self._view_offset()
+        if self._uend_view is None or self._uend_view._p != addr:
+            self._uend_view = hip_mesh.view(addr, self._field_shape(), keep=e,
                                             on_write=lambda: self._touched(Lb.SLOT_UEND, 0))
         return self._uend_view
 
@@ -353,6 +356,7 @@ class Level(DeviceBacked):
         self.engine.advance()
         self._u.mark([0])
         self._res_cache = None
+        self._uend_valid = False  # (the end-value buffer of the finished step now holds this step's start value)
 
     def reset_level(self, reset_status=True):
         """pySDC/core/level.py:110-131."""

@@ -6,7 +6,8 @@ import os
 from pysdc_amd.errors import CommunicationError, EngineError, ParameterError, ProblemError, UnlockError
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libsdcmi.so')
+# (PYSDC_AMD_LIB: another build of the same library, e.g. one compiled with experiment macros - scripts/README.md)
+LIB_PATH = os.environ.get('PYSDC_AMD_LIB') or os.path.join(_HERE, 'libsdcmi.so')
 
 SLOT_U, SLOT_F, SLOT_TAU, SLOT_UEND, SLOT_WORK = 0, 1, 2, 3, 4
 RES_TYPES = {'full_abs': 0, 'last_abs': 1, 'full_rel': 2, 'last_rel': 3}
@@ -33,6 +34,7 @@ PROTOTYPES = {
     'sdc_set_forcing_profile': (C.c_int, [_vp, _dp]),
     'sdc_set_forcing_values': (C.c_int, [_vp, _dp]),
     'sdc_slot_ptr': (_vp, [_vp, C.c_int, C.c_int, C.c_int]),
+    'sdc_uend_address': (_vp, [_vp]),
     'sdc_upload': (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _dp]),
     'sdc_download': (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _dp]),
     'sdc_set_tau_active': (C.c_int, [_vp, C.c_int]),

@@ -169,6 +169,9 @@ class HostEngine:
     def ptr(self, slot, m=0, comp=0):
         return self._slab(slot, m, comp).ctypes.data
 
+    def uend_address(self):
+        return self.UEND.ctypes.data
+
     def upload(self, slot, m, host, comp=0):
         self._slab(slot, m, comp)[:] = np.asarray(host, dtype=float).reshape(-1)
 
