@@ -240,10 +240,12 @@ def run_workload(args, world, rank, use_dist, with_stream_reference=True):
         rng = np.random.default_rng(0)
         u0h = rng.uniform(-2.0, 2.0, (2, args.ntraj))
         desc = dict(problem_class=vanderpol_ensemble,
-                    problem_params=dict(ntraj=args.ntraj, u0=u0h, mu=5.0, newton_tol=1e-9, newton_maxiter=100),
+                    problem_params=dict(ntraj=args.ntraj, u0=u0h, mu=5.0, newton_tol=1e-9, newton_maxiter=100,
+                                        block_solver='mfma' if getattr(args, 'mfma', False) else 'closed_form'),
                     sweeper_class=generic_implicit, sweeper_params=dict(num_nodes=M, quad_type='RADAU-RIGHT', QI='LU'),
                     level_params=dict(dt=dt, restol=args.restol, nsweeps=1), step_params=dict(maxiter=K))
-        wl = f'vanderpol ensemble, {args.ntraj} trajectories, mu=5, M={M} RADAU-RIGHT, QI=LU, Newton tol 1e-9'
+        wl = (f'vanderpol ensemble, {args.ntraj} trajectories, mu=5, M={M} RADAU-RIGHT, QI=LU, Newton tol 1e-9, block solver '
+              + ('MFMA (v_mfma_f64_4x4x4)' if getattr(args, 'mfma', False) else 'closed form (VALU)'))
         unit = 'trajectory-steps/s'
         if world > 1:
             raise SystemExit('the ensemble shards trivially over GPUs (independent trajectories); run --gpus 1')
@@ -306,6 +308,7 @@ def run_workload(args, world, rank, use_dist, with_stream_reference=True):
             T = args.ntraj
             return {'vdp_sweep': 8.0 * T * (2 + 2 * M_ + 2 * M_ + 4 * M_), 'vdp_eval': 8.0 * T * 4,
                     'vdp_sweep_lazyf': 8.0 * T * (2 + 2 * M_ + 2 * M_),   # u0 + old nodes in, new nodes out (F deferred)
+                    'vdp_sweep_mfma': 8.0 * T * (2 + 2 * M_ + 2 * M_),
                     'residual': 8.0 * 2 * T * (1 + 2 * M_), 'spread': 8.0 * 2 * T * (2 + 2 * M_),
                     'copy': 8.0 * 2 * T * 2}.get(name.split('[')[0])
         return _kernel_bytes(name, n_, M_, ncomp)
@@ -347,7 +350,7 @@ def run_workload(args, world, rank, use_dist, with_stream_reference=True):
         in_sweep = ('gather', 'fft_x_fwd', 'fft_y_fwd', 'fft_z_fwd', 'fft_z_solve', 'spec_point', 'spec_point_res', 'spec_point_only', 'spec_z', 'spec_z_res', 'spec_z_spread', 'spec_z_res_spread',
                     'fft_x_norm', 'fft_x_inv_norm',
                     'fft_z_inv', 'fft_y_inv',
-                    'fft_x_inv', 'stencil', 'stencil_res', 'res_stencil', 'vdp_sweep', 'vdp_sweep_lazyf')
+                    'fft_x_inv', 'stencil', 'stencil_res', 'res_stencil', 'vdp_sweep', 'vdp_sweep_lazyf', 'vdp_sweep_mfma')
         sweep_ms = sum(v[0] for k, v in prof.items() if k.split('[')[0] in in_sweep) / max(1, sweeps_total // world)
         out = {
             'metric': {'heat': 'time-steps/s (HeatND 3-D FD, M=5, implicit SDC sweeps)',
@@ -464,6 +467,9 @@ def main():
     ap.add_argument('--skip-residual', action='store_true',
                     help="sweeper parameter skip_residual_computation for every stage (the reference's switch for runs with a "
                          'fixed number of sweeps): no residual is computed; NOT the headline configuration')
+    ap.add_argument('--mfma', action='store_true',
+                    help='vdp: apply the 2x2 Newton block inverses on the matrix cores (v_mfma_f64_4x4x4, two trajectories per '
+                         'block) instead of the vector ALUs')
     ap.add_argument('--no-extras', action='store_true',
                     help='only the headline record (default at one GPU: the line also carries short sub-records of the other '
                          'BASELINE configurations and of the eager / restol variants, measured in the same process)')

@@ -212,6 +212,11 @@ int sdc_vec_amax(sdc_ctx* ctx, size_t n, const double* x, double* out); /* abs()
  * integrate are the generic kernels.  A failed Newton solve makes the call return SDC_ERR_NEWTON
  * (ProblemError in the reference, Van_der_Pol_implicit.py:179-186). */
 int sdc_set_problem_vdp(sdc_ctx* ctx, double mu, double newton_tol, int newton_maxiter);
+/* How the Newton step applies the inverse of the dense local Jacobian block (I - dt J), 2x2 per trajectory
+ * (Van_der_Pol_implicit.py:190-201 solve_jacobian): 0 = closed form on the vector ALUs (default), 1 = the same inverse
+ * applied on the matrix cores, two trajectories per 4x4 block of v_mfma_f64_4x4x4_4b_f64 (BASELINE.json north_star).
+ * Same Newton iteration, same stopping rule; the products are fused multiply-adds on the matrix path. */
+int sdc_set_vdp_block_solver(sdc_ctx* ctx, int kind);
 /* out[0] = Newton iterations, out[1] = right-hand side evaluations, out[2] = failed solves (pending), summed
  * over trajectories since context creation (work_counters of Van_der_Pol_implicit.py:71-73). */
 /* out = (dg/du)^{-1} rhs at u for g(u) = u - dt f(u), every trajectory (Van_der_Pol_implicit.py:190-201). */

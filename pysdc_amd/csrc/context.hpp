@@ -88,6 +88,7 @@ struct sdc_ctx {
     int kind = 0;  // 0: periodic finite differences, 1: van der Pol ensemble (N = 2 * ntraj, SoA)
     double vdp_mu = 0, vdp_tol = 1e-9;
     int vdp_maxiter = 100;
+    int vdp_block_solver = 0;  // 0: closed-form 2x2 inverse applied on the vector ALUs, 1: applied on the matrix cores (MFMA)
     unsigned long long* counters = nullptr;  // device: [0] newton, [1] rhs, [2] failed solves
     unsigned long long rhs_host = 0;         // evaluations the reference would have made where the engine copies
     double Q[MAXM + 1][MAXM + 1], QI[MAXM + 1][MAXM + 1], QE[MAXM + 1][MAXM + 1], nodes[MAXM], weights[MAXM];

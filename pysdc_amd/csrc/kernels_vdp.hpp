@@ -163,6 +163,199 @@ __global__ __launch_bounds__(256) void k_vdp_sweep(VdpSweepArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// MFMA variant of the Newton step (BASELINE.json north_star: "MFMA used only for the small dense (I - dt Qdiag J)
+// block solves").  The 2x2 inverse is still the reference's closed form (Van_der_Pol_implicit.py:190-201); its
+// application  delta = (dg/du)^{-1} g  runs on the matrix cores: v_mfma_f64_4x4x4_4b_f64 multiplies four independent
+// 4x4 blocks per instruction, each block carrying TWO trajectories as diag(D_a, D_b) times the column (g_a, g_b).
+// Operand layout on gfx950 (scripts/probes/mfma_f64_4x4x4_layout.hip): with k = lane / 16, blk = (lane % 16) / 4,
+//   A[blk][i][k] sits in lane 16 k + 4 blk + i,  B[blk][k][j] in lane 16 k + 4 blk + j,  D[blk][i][j] in lane 16 i + 4 blk + j.
+// A wave holds 64 trajectories (one per lane), so one Newton step of the wave is 8 instructions of 8 trajectories,
+// with the operands redistributed through LDS (6 values out, 2 back per trajectory).  Only one column of B and the
+// two diagonal 2x2 blocks of A carry data: 1/8 of the instruction's multiply-adds are useful.  The loop is made
+// wave-uniform (lanes that have converged keep their values and contribute zeros).
+// MEASURED (profiles/r02): slower than the closed-form VALU kernel - see DESIGN.md; selected by sdc_set_vdp_block_solver.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// wl: this wave's LDS area, 64 x 8 doubles in (d00 d01 d10 d11 e0 e1 . .), then 64 x 2 doubles out
+__device__ __forceinline__ bool vdp_newton_mfma(double& x1, double& x2, double r0, double r1, double h, double mu, double tol,
+                                                int maxiter, unsigned long long& newton, double* wl, bool valid) {
+#pragma clang fp contract(off)
+    const int lane = threadIdx.x & 63;
+    const int k = lane >> 4, blk = (lane & 15) >> 2, ij = lane & 3;
+    double* out = wl + 64 * 8;
+    int it = 0;
+    double res = 99.0;
+    bool running = valid;
+    while (__builtin_amdgcn_ballot_w64(running) != 0) {
+        double d00 = 0.0, d01 = 0.0, d10 = 0.0, d11 = 0.0, e0 = 0.0, e1 = 0.0;
+        if (running && !(it < maxiter)) running = false;
+        if (running) {
+            e0 = x1 - h * x2 - r0;
+            e1 = x2 - h * (mu * (1 - x1 * x1) * x2 - x1) - r1;
+            res = fmax(fabs(e0), fabs(e1));
+            if (e0 != e0 || e1 != e1) res = e0 + e1;  // NaN
+            if (res < tol || res != res) running = false;
+        }
+        if (running) {
+            const double c = 1.0 / (-2 * h * h * mu * x1 * x2 - h * h - 1 + h * mu * (1 - x1 * x1));
+            d00 = c * (h * mu * (1 - x1 * x1) - 1);
+            d01 = c * (-h);
+            d10 = c * (2 * h * mu * x1 * x2 + h);
+            d11 = c * (-1.0);
+        } else {
+            e0 = e1 = 0.0;
+        }
+        double* mine = wl + lane * 8;
+        mine[0] = d00;
+        mine[1] = d01;
+        mine[2] = d10;
+        mine[3] = d11;
+        mine[4] = e0;
+        mine[5] = e1;
+        wave_lds_sync();
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+            // A[blk][i][k]: rows 0,1 <- trajectory a = 8n + 2 blk, rows 2,3 <- trajectory a + 1 (block diagonal)
+            const int ha = ij >> 1;
+            const double av = (k >> 1) == ha ? wl[(8 * n + 2 * blk + ha) * 8 + 2 * (ij & 1) + (k & 1)] : 0.0;
+            // B[blk][k][j]: column 0 = (g_a, g_b)
+            const double bv = ij == 0 ? wl[(8 * n + 2 * blk + (k >> 1)) * 8 + 4 + (k & 1)] : 0.0;
+            const double dv = __builtin_amdgcn_mfma_f64_4x4x4f64(av, bv, 0.0, 0, 0, 0);
+            // D[blk][i][0] (i = lane / 16): component i & 1 of trajectory 8n + 2 blk + i / 2
+            if (ij == 0) out[(8 * n + 2 * blk + (k >> 1)) * 2 + (k & 1)] = dv;
+        }
+        wave_lds_sync();
+        if (running) {
+            const double nx1 = x1 - out[lane * 2], nx2 = x2 - out[lane * 2 + 1];
+            x1 = nx1;
+            x2 = nx2;
+            ++it;
+            ++newton;
+        }
+        wave_lds_sync();
+    }
+    return !valid || !(res != res || it == maxiter);
+}
+
+template <int M>
+__global__ __launch_bounds__(256) void k_vdp_sweep_mfma(VdpSweepArgs a) {
+#pragma clang fp contract(off)
+    extern __shared__ __attribute__((aligned(16))) double vdp_lds[];
+    double* wl = vdp_lds + (threadIdx.x >> 6) * (64 * 10);
+    unsigned long long newton = 0, rhs = 0, failed = 0;
+    const size_t T = a.T, N = 2 * a.T;
+    double nmax[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) nmax[m] = 0.0;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t rounds = (T + stride - 1) / stride;  // every lane takes part in every round (wave-uniform MFMA)
+    for (size_t rd = 0; rd < rounds; ++rd) {
+        const size_t i = rd * stride + blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+        const bool valid = i < T;
+        const size_t ii = valid ? i : 0;
+        const double mu = a.mu;
+        const double u00 = a.U[ii], u01 = a.U[T + ii];
+        double f0[M], f1[M], g0[M], g1[M], un0[M], un1[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            un0[m] = a.U[(size_t)(m + 1) * N + ii];
+            un1[m] = a.U[(size_t)(m + 1) * N + T + ii];
+            f0[m] = un1[m];
+            f1[m] = mu * (1 - un0[m] * un0[m]) * un1[m] - un0[m];
+        }
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                s0 += a.Q[m][j] * f0[j];
+                s1 += a.Q[m][j] * f1[j];
+            }
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                s0 -= a.QI[m][j] * f0[j];
+                s1 -= a.QI[m][j] * f1[j];
+            }
+            g0[m] = s0 + u00;
+            g1[m] = s1 + u01;
+            if (a.tau) {
+                g0[m] += a.tau[(size_t)m * N + ii];
+                g1[m] += a.tau[(size_t)m * N + T + ii];
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            double r0 = g0[m], r1 = g1[m];
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                if (j < m) {
+                    r0 += a.QI[m][j] * f0[j];
+                    r1 += a.QI[m][j] * f1[j];
+                }
+            }
+            const double h = a.QI[m][m];
+            double x1 = un0[m], x2 = un1[m];
+            if (h == 0.0) {
+                x1 = r0;
+                x2 = r1;
+            } else if (!vdp_newton_mfma(x1, x2, r0, r1, h, mu, a.tol, a.maxiter, newton, wl, valid)) {
+                failed += 1;
+            }
+            if (valid) {
+                a.U[(size_t)(m + 1) * N + i] = x1;
+                a.U[(size_t)(m + 1) * N + T + i] = x2;
+                rhs += 1;
+            }
+            un0[m] = x1;
+            un1[m] = x2;
+            f0[m] = x2;
+            f1[m] = mu * (1 - x1 * x1) * x2 - x1;
+        }
+        if (a.norms && valid) {
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                for (int j = 0; j < M; ++j) {
+                    s0 += a.Q[m][j] * f0[j];
+                    s1 += a.Q[m][j] * f1[j];
+                }
+                s0 += u00 - un0[m];
+                s1 += u01 - un1[m];
+                if (a.tau) {
+                    s0 += a.tau[(size_t)m * N + i];
+                    s1 += a.tau[(size_t)m * N + T + i];
+                }
+                const double r0 = fabs(s0), r1 = fabs(s1);
+                const double r = (r0 > r1 || r0 != r0) ? r0 : r1;
+                nmax[m] = (nmax[m] > r || nmax[m] != nmax[m]) ? nmax[m] : r;
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        newton += __shfl_xor(newton, o, 64);
+        rhs += __shfl_xor(rhs, o, 64);
+        failed += __shfl_xor(failed, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(a.counters + 0, newton);
+        atomicAdd(a.counters + 1, rhs);
+        atomicAdd(a.counters + 2, failed);
+    }
+    if (a.norms) {
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const double v = wave_max(nmax[m]);
+            if ((threadIdx.x & 63) == 0) atomic_max_abs(a.norms + m, v);
+        }
+    }
+}
+
 __global__ void k_vdp_eval(const double* __restrict__ u, double* __restrict__ f, size_t T, double mu,
                            unsigned long long* counters) {
 #pragma clang fp contract(off)

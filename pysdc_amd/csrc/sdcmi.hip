@@ -893,6 +893,13 @@ int sdc_set_problem_vdp(sdc_ctx* c, double mu, double newton_tol, int newton_max
     return SDC_OK;
 }
 
+int sdc_set_vdp_block_solver(sdc_ctx* c, int kind) {
+    if (!c) return SDC_ERR_PARAM;
+    if (kind != 0 && kind != 1) return fail(c, SDC_ERR_PARAM, "block solver %d: 0 = closed form on the vector ALUs, 1 = MFMA", kind);
+    c->vdp_block_solver = kind;
+    return SDC_OK;
+}
+
 int sdc_work_counters(sdc_ctx* c, unsigned long long* out) {
     if (!c || !out) return SDC_ERR_PARAM;
     HIPCHK(c, hipMemcpyAsync(c->red_host + 12, c->counters, sizeof(unsigned long long) * 3, hipMemcpyDeviceToHost, c->stream));
@@ -1460,7 +1467,16 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
         }
         const bool lazyf = c->deferred && !c->force_gather;
         c->force_gather = false;
-        {
+        if (c->vdp_block_solver == 1 && lazyf) {
+            LaunchTimer lt(c, "vdp_sweep_mfma");
+            const size_t ldsv = (size_t)4 * 64 * 10 * sizeof(double);
+#define VMCASE(MM) \
+    case MM: hipLaunchKernelGGL((k_vdp_sweep_mfma<MM>), dim3(grid), dim3(256), ldsv, c->stream, a); break;
+            switch (M) {
+                VMCASE(1) VMCASE(2) VMCASE(3) VMCASE(4) VMCASE(5) VMCASE(6) VMCASE(7) VMCASE(8)
+            }
+#undef VMCASE
+        } else {
             LaunchTimer lt(c, lazyf ? "vdp_sweep_lazyf" : "vdp_sweep");
 #define VCASE(MM)                                                                                       \
     case MM:                                                                                            \

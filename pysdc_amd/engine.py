@@ -196,6 +196,10 @@ class SweepEngine:
     def set_problem_vdp(self, mu, newton_tol, newton_maxiter):
         self._chk(self.lib.sdc_set_problem_vdp(self.ctx, float(mu), float(newton_tol), int(newton_maxiter)))
 
+    def set_vdp_block_solver(self, kind):
+        """'closed_form' (vector ALUs) or 'mfma' (matrix cores): include/sdcmi.h sdc_set_vdp_block_solver"""
+        self._chk(self.lib.sdc_set_vdp_block_solver(self.ctx, {'closed_form': 0, 'mfma': 1}[kind]))
+
     def work_counters(self):
         out = (C.c_ulonglong * 4)()
         self._chk(self.lib.sdc_work_counters(self.ctx, out))

@@ -76,6 +76,7 @@ PROTOTYPES = {
     'sdc_vec_axpby': (C.c_int, [_vp, C.c_size_t, C.c_double, _vp, C.c_double, _vp, _vp]),
     'sdc_vec_amax': (C.c_int, [_vp, C.c_size_t, _vp, _dp]),
     'sdc_set_problem_vdp': (C.c_int, [_vp, C.c_double, C.c_double, C.c_int]),
+    'sdc_set_vdp_block_solver': (C.c_int, [_vp, C.c_int]),
     'sdc_work_counters': (C.c_int, [_vp, C.POINTER(C.c_ulonglong)]),
     'sdc_transfer_apply_batch': (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     'sdc_transfer_apply': (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),

@@ -436,11 +436,13 @@ class vanderpol_ensemble(Problem):
     fused = True
 
     def __init__(self, ntraj=1, u0=None, mu=5.0, newton_maxiter=100, newton_tol=1e-9, stop_at_nan=True,
-                 crash_at_maxiter=True, relative_tolerance=False):
+                 crash_at_maxiter=True, relative_tolerance=False, block_solver='closed_form'):
         if relative_tolerance:
             raise ProblemError('relative_tolerance is not available in the ensemble kernels')
         if not (stop_at_nan and crash_at_maxiter):
             raise ProblemError('the ensemble kernels always report Newton failures (stop_at_nan / crash_at_maxiter)')
+        if block_solver not in ('closed_form', 'mfma'):
+            raise ProblemError(f"block_solver must be 'closed_form' or 'mfma', got {block_solver!r}")
         ntraj = int(ntraj)
         if u0 is None:
             u0 = (2.0, 0.0)
@@ -453,7 +455,7 @@ class vanderpol_ensemble(Problem):
         nvars = (2 * ntraj,)
         self._makeAttributeAndRegister('nvars', 'ntraj', localVars=locals(), readOnly=True)
         self._makeAttributeAndRegister('mu', 'newton_maxiter', 'newton_tol', 'stop_at_nan', 'crash_at_maxiter',
-                                       'relative_tolerance', localVars=locals())
+                                       'relative_tolerance', 'block_solver', localVars=locals())
         self._u0 = u0
         self.work_counters['newton'] = _DeviceCounter(self, 'newton')
         self.work_counters['rhs'] = _DeviceCounter(self, 'rhs')
@@ -473,6 +475,7 @@ class vanderpol_ensemble(Problem):
 
     def configure_engine(self, engine):
         engine.set_problem_vdp(self.mu, self.newton_tol, self.newton_maxiter)
+        engine.set_vdp_block_solver(self.block_solver)
 
     def u_exact(self, t, u_init=None, t_init=None):
         if t > 0.0:
