@@ -16,5 +16,5 @@ python3 $GRAFT_REPO_ROOT/scripts/make_traffic.py $OUT $N
 find $OUT -name "*kernel_trace.csv" -size +2M -delete
 find $OUT -name "*counter_collection.csv" -size +2M -delete
 cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/n${N}_kernel_stats.csv
-tail -1 $OUT/bench_stats.log > $OUT/bench_under_rocprof.json
+grep "^{" $OUT/bench_stats.log | tail -1 > $OUT/bench_under_rocprof.json
 ls -la $OUT
