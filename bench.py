@@ -188,10 +188,11 @@ def run_workload(args, world, rank, use_dist, with_stream_reference=True):
     if args.workload == 'heat':
         n = args.n or 1024
         if args.n is None:
-            # 1024^3 with M = 5 needs ~26 fields of 8.6 GB (slabs, work + cached spectra, in/out buffers);
-            # fall back to the largest configuration that fits if this GPU cannot hold it
-            # (time-parallel runs add an inbox, the relay staging and a spare work spectrum)
-            need = (26.5 if world == 1 else 29.5) * 8.0 * n**3
+            # 1024^3 with M = 5 needs ~30 fields of 8.6 GB (slabs U 6, F 6, end values 2, work + cached spectra 11,
+            # start / end value objects of the runs 5); fall back to the largest configuration that fits if this GPU
+            # cannot hold it (time-parallel runs: no second end-value buffer, but an inbox, the relay staging and a
+            # spare work spectrum)
+            need = (30.5 if world == 1 else 32.5) * 8.0 * n**3
             free = torch.cuda.mem_get_info()[0]
             if free < need:
                 n = 512
@@ -282,8 +283,10 @@ def run_workload(args, world, rank, use_dist, with_stream_reference=True):
     uend, _ = ctrl.run(u0, 0.0, block * args.warmup) if args.warmup > 0 else (u0, None)
     # run() hands out a fresh end-value object per call like the reference; let the caching allocator hold a block of that
     # size already, so that the timed region contains the run and not a first-time 8.6 GB hipMalloc (set-up, not work)
-    spare = torch.empty(int(np.prod(uend.shape)), dtype=torch.float64, device='cuda')
-    del spare
+    if world == 1:
+        spare = torch.empty(int(np.prod(uend.shape)), dtype=torch.float64, device='cuda')
+        del spare
+    del u0
     sync()
     eng.profile_enable(True)
     t0 = time.perf_counter()

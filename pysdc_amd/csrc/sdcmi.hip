@@ -1017,7 +1017,9 @@ static int ensure_spec_cache(sdc_ctx* c) {
         c->bytes += sizeof(cd) * c->Nc * (c->M + 1);
         c->spec_valid = c->spec0_valid = false;
     }
-    if (!c->UEND2) {  // the second end-value buffer of sdc_advance, allocated with the cache (not inside a time loop)
+    // the second end-value buffer of sdc_advance, allocated with the cache (not inside a time loop) - unless this is a
+    // time-parallel level (keep_rfields is switched on before its first sweep): those never advance in place
+    if (!c->UEND2 && !c->keep_rfields) {
         HIPCHK(c, hipMalloc((void**)&c->UEND2, c->N * sizeof(double)));
         c->bytes += c->N * sizeof(double);
     }

@@ -44,6 +44,15 @@ def _worker(rank, world, port, name, outdir, fname='runs.npz', relay='1'):
 
         desc = dict(step_class=OracleStep, oracle_level_factory=factory, level_params=lp,
                     step_params=dict(maxiter=meta['maxiter']))
+        if world > 1:   # only the world group carries a run (peers are global ranks): sub-groups are refused, on every rank
+            from pysdc_amd.errors import ParameterError
+
+            sub = dist.new_group(ranks=[0])
+            try:
+                controller_dist(dict(logger_level=40), desc, comm=sub)
+                raise AssertionError('sub-group accepted')
+            except ParameterError:
+                pass
         C = controller_dist(dict(logger_level=40, **meta['controller_params']), desc)
         shape = factory().prob.nvars
         u0 = np_mesh(np.array(case['u0']).reshape(shape))

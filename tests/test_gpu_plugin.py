@@ -781,3 +781,25 @@ def _field(prob, values):
     x = prob.u_init
     x[:] = values
     return x
+
+
+def test_consecutive_runs_return_independent_objects():
+    """controller.run hands out a fresh end-value object per call (controller_nonMPI.py:148,167): the result of an earlier
+    run keeps its value when the controller runs again, with one step per block (advance path) and with two"""
+    from pysdc_amd.controller import controller_nonMPI
+
+    case = load_cases('runs.npz')['mssdc_P2_jac']
+    meta = case['meta']
+    for procs in (1, 2):
+        C = controller_nonMPI(procs, dict(logger_level=40), description_from(meta))
+        dt = meta['level_params']['dt']
+        u0 = C.MS[0].levels[0].prob.u_init
+        u0[:] = case['u0']
+        u1, _ = C.run(u0, 0.0, 2 * dt)
+        snap = u1.get()
+        u2, _ = C.run(u1, 2 * dt, 4 * dt)
+        assert u1 is not u2 and u1.ptr != u2.ptr
+        assert np.array_equal(u1.get(), snap)
+        assert not np.array_equal(u2.get(), snap)
+        # the level's own end value is still readable after the run and equals what was returned
+        assert np.array_equal(C.MS[-1 if procs == 2 else 0].levels[0].uend.get(), u2.get())
