@@ -105,7 +105,7 @@ def _collect(proc, timeout=600):
     return json.loads(out.decode().strip().splitlines()[-1])
 
 
-def cpu_baseline(M, dt_ref_n, target_n=1024, nsweeps=4, max_workers=32):
+def cpu_baseline(M, dt_ref_n, target_n=1024, nsweeps=4, max_workers=64):
     """kind = "port": the oracle timed on the GPU box's host cores, on bounded samples of the same workload.
       * one core, 64^3, one time step (4 sweeps), and - beside it - one core, 128^3, ONE sweep: shows what the
         linear-in-DOF extrapolation to the target size leaves out (CG iteration counts grow with the grid);

@@ -50,6 +50,7 @@ struct sdc_ctx {
     const double* u0_src = nullptr;
     bool spec_valid = false, spec0_valid = false, spec_spread = false, reuse = true, force_gather = false;
     cd *tw = nullptr, *lamI = nullptr, *lamE = nullptr;
+    bool sym_real[2] = {false, false};  // the stencil is symmetric: its Fourier symbol is real (imaginary parts stored as 0)
     unsigned long long* red = nullptr;  // reduction slots (device)
     unsigned long long* red_host = nullptr;
     bool tau_active = false, have_coeffs = false, have_stencil[2] = {false, false}, unlocked = false;

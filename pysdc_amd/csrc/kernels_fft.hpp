@@ -465,12 +465,26 @@ struct SpecArgs {
     double cP[MAXM];
     double invN;
     int nf, ndim, coupled, spread;
+    int real_sym;  // the implicit symbol is real (symmetric stencil: heat): half the multiplications per node (wave-uniform branch)
 };
 
 // one thread per Fourier mode: gather on the cached transforms + node-coupled solve, S updated in place.
 // RES: the transform of the collocation residual of the NEW iterate, u0 - u_m + dt sum_j Q[m][j] f(u_j)
 // (core/sweeper.py:186-199 with f(u) = (A + B) u), goes to W[m]; its inverse transform only has to be reduced
 // to a max norm, so neither U[1..M] nor F[1..M] are needed in real space to continue sweeping.
+// acc + lam * t  and  acc / (1 - al * lam)  with the short forms for a real symbol (wave-uniform choice)
+DEVI cd sym_fma(cd lam, cd t, cd acc, int real_sym) {
+    if (real_sym) return cd{fma(lam.x, t.x, acc.x), fma(lam.x, t.y, acc.y)};
+    return cfma(lam, t, acc);
+}
+DEVI cd node_divide(cd acc, cd lam, double al, int real_sym) {
+    if (real_sym) {
+        const double inv = fast_rcp(1.0 - al * lam.x);
+        return cd{acc.x * inv, acc.y * inv};
+    }
+    return cmul(acc, cinv_fast(cd{1.0 - al * lam.x, -al * lam.y}));
+}
+
 template <int NF, bool RES>
 __global__ __launch_bounds__(256) void k_spec_point(SpecArgs a, int n, size_t nmodes) {
     for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < nmodes; g += (size_t)gridDim.x * blockDim.x) {
@@ -508,10 +522,9 @@ __global__ __launch_bounds__(256) void k_spec_point(SpecArgs a, int n, size_t nm
                     tE = cd{fma(a.cE[m][q], u[q].x, tE.x), fma(a.cE[m][q], u[q].y, tE.y)};
                 }
             }
-            acc = cfma(lam, tI, acc);
+            acc = sym_fma(lam, tI, acc, a.real_sym);
             if (a.lamE) acc = cfma(mu, tE, acc);
-            const double al = a.alpha[m];
-            u[m] = cmul(acc, cinv_fast(cd{1.0 - al * lam.x, -al * lam.y}));
+            u[m] = node_divide(acc, lam, a.alpha[m], a.real_sym);
             SPEC_FIELD(a, m, NF)[g] = u[m];  // (nontemporal stores measured slower here: 18.5 vs 17.4 ms at 1024^3)
         }
         if constexpr (RES) {
@@ -523,7 +536,7 @@ __global__ __launch_bounds__(256) void k_spec_point(SpecArgs a, int n, size_t nm
                 cd tR = cd{0.0, 0.0};
 #pragma unroll
                 for (int q = 0; q < NF; ++q) tR = cd{fma(a.rQ[m][q], u[q].x, tR.x), fma(a.rQ[m][q], u[q].y, tR.y)};
-                acc = cfma(sym, tR, acc);
+                acc = sym_fma(sym, tR, acc, a.real_sym && !a.lamE);
                 a.W[m * a.fstride + g] = acc;
             }
         }
@@ -682,10 +695,9 @@ __global__ __launch_bounds__(specz_lines<N>() * (N / specz_elems<N>()) * NF,
                             if (HASE) tE = cd{fma(a.cE[m][q], u[q].x, tE.x), fma(a.cE[m][q], u[q].y, tE.y)};
                         }
                     }
-                    acc = cfma(lam, tI, acc);
+                    acc = sym_fma(lam, tI, acc, a.real_sym);
                     if (HASE) acc = cfma(mu, tE, acc);
-                    const double al = a.alpha[m];
-                    u[m] = cmul(acc, cinv_fast(cd{1.0 - al * lam.x, -al * lam.y}));
+                    u[m] = node_divide(acc, lam, a.alpha[m], a.real_sym);
 #if SDC_SPECZ_NT & 1
                     __builtin_nontemporal_store(u[m].x, &SPEC_FIELD(a, m, NF)[g].x);
                     __builtin_nontemporal_store(u[m].y, &SPEC_FIELD(a, m, NF)[g].y);
@@ -702,7 +714,7 @@ __global__ __launch_bounds__(specz_lines<N>() * (N / specz_elems<N>()) * NF,
                         cd tR = cd{0.0, 0.0};
 #pragma unroll
                         for (int q = 0; q < NF; ++q) tR = cd{fma(a.rQ[m][q], u[q].x, tR.x), fma(a.rQ[m][q], u[q].y, tR.y)};
-                        acc = cfma(sym, tR, acc);
+                        acc = sym_fma(sym, tR, acc, a.real_sym && !HASE);
                         rbuf[m * CH + k] = cscale(acc, a.invN);
                     }
                 } else {

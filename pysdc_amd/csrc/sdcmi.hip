@@ -597,6 +597,7 @@ static int spec_residual(sdc_ctx* c, double dt, unsigned long long* norms) {
     if (rcf != SDC_OK) return rcf;
     a.S = c->S;
     a.SL = c->SL;
+    a.real_sym = c->sym_real[0] ? 1 : 0;
     a.fstride = c->Nc;
     a.S0 = c->S0;
     a.W = c->W;
@@ -655,6 +656,15 @@ static int build_symbol(sdc_ctx* c, int which) {
     const int n = c->n;
     std::vector<cd> lam(n);
     const Stencil& s = c->st[which];
+    // a symmetric stencil (w_{-o} = w_o: the heat operator) has a real symbol; say so exactly instead of leaving the
+    // 1e-20 the two sine terms of a pair do not cancel to in floating point
+    bool symmetric = true;
+    for (int q = 0; q < s.npts && symmetric; ++q) {
+        bool found = s.off[q] == 0;
+        for (int r = 0; r < s.npts && !found; ++r) found = s.off[r] == -s.off[q] && s.w[r] == s.w[q];
+        symmetric = found;
+    }
+    c->sym_real[which] = symmetric;
     for (int k = 0; k < n; ++k) {
         long double re = 0, im = 0;
         for (int q = 0; q < s.npts; ++q) {
@@ -665,7 +675,7 @@ static int build_symbol(sdc_ctx* c, int which) {
             re += (long double)s.w[q] * cosl(ang);
             im += (long double)s.w[q] * sinl(ang);
         }
-        lam[k] = cd{(double)re, (double)im};
+        lam[k] = cd{(double)re, symmetric ? 0.0 : (double)im};
     }
     cd** dst = which == 0 ? &c->lamI : &c->lamE;
     if (!*dst) {
@@ -933,6 +943,7 @@ static int vdp_check_failures(sdc_ctx* c) {
 
 int sdc_set_symbol(sdc_ctx* c, int which, const double* table) {
     if (!c || which < 0 || which > 1 || !table) return fail(c, SDC_ERR_PARAM, "bad symbol table");
+    c->sym_real[which] = false;  // (a user-given table is used as it is)
     cd** dst = which == 0 ? &c->lamI : &c->lamE;
     if (!*dst) {
         HIPCHK(c, hipMalloc((void**)dst, sizeof(cd) * c->n));
@@ -1550,6 +1561,7 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
         if (rcf != SDC_OK) return rcf;
         a.S = c->S;
         a.SL = c->SL;
+        a.real_sym = c->sym_real[0] ? 1 : 0;
         a.fstride = c->Nc;
         a.S0 = c->S0;
         a.W = c->W;
