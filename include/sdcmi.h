@@ -257,6 +257,12 @@ int sdc_fft_prolong(sdc_ctx* coarse, sdc_ctx* fine, const double* src, double* d
  * (the Fourier solve becomes the sine-transform solve).  This rebuilds the end points and the mirrored half of
  * one field after its interior was written.  ctx may be NULL. */
 int sdc_odd_mirror(sdc_ctx* ctx, double* field, int n_interior);
+/* The same idea in 2-D / 3-D (generic_ND_FD.py:99-133 'dirichlet-zero', order 2; helpers/problem_helper.py:143-224): the
+ * interior n^ndim values are not contiguous inside their odd extension of (2(n+1))^ndim points, so fields stay compact and
+ * are packed into / extracted from an extension-sized scratch field around eval_f and solve (problem level: the sweep then
+ * runs node by node).  interior: n^ndim doubles, ext: (2(n+1))^ndim doubles, axis order as stored (last axis fastest). */
+int sdc_odd_extend(sdc_ctx* ctx, const double* interior, double* ext, int n_interior, int ndim);
+int sdc_odd_extract(sdc_ctx* ctx, const double* ext, double* interior, int n_interior, int ndim);
 
 /* ---- stream / timing ------------------------------------------------------------------------------------ */
 int sdc_sync(sdc_ctx* ctx);

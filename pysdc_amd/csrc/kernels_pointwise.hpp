@@ -127,6 +127,47 @@ __global__ void k_odd_mirror(double* __restrict__ f, int n) {
     }
 }
 
+// odd extension in every axis of an n^ndim interior field into a (2(n+1))^ndim array (dirichlet-zero in 2-D / 3-D: the
+// Dirichlet operator on the interior is the periodic one on the extension), and the way back.  One thread per element of
+// the extension: coordinate e of an axis maps to interior index e-1 (1 <= e <= n), to 2n+1-e with a sign flip
+// (n+2 <= e <= 2n+1), or to the boundary value zero (e = 0, n+1).
+__global__ void k_odd_extend_nd(const double* __restrict__ interior, double* __restrict__ ext, int n, int ndim) {
+    const int m = 2 * (n + 1);
+    size_t total = 1;
+    for (int d = 0; d < ndim; ++d) total *= (size_t)m;
+    for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+        size_t rem = g, src = 0, stride = 1;
+        double sign = 1.0;
+        bool zero = false;
+        for (int d = 0; d < ndim; ++d) {  // fastest axis first
+            const int e = (int)(rem % m);
+            rem /= m;
+            int i;
+            if (e == 0 || e == n + 1) { zero = true; i = 0; }
+            else if (e <= n) i = e - 1;
+            else { i = 2 * n + 1 - e; sign = -sign; }
+            src += (size_t)i * stride;
+            stride *= (size_t)n;
+        }
+        ext[g] = zero ? 0.0 : sign * interior[src];
+    }
+}
+__global__ void k_odd_extract_nd(const double* __restrict__ ext, double* __restrict__ interior, int n, int ndim) {
+    const int m = 2 * (n + 1);
+    size_t total = 1;
+    for (int d = 0; d < ndim; ++d) total *= (size_t)n;
+    for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+        size_t rem = g, src = 0, stride = 1;
+        for (int d = 0; d < ndim; ++d) {
+            const int i = (int)(rem % n);
+            rem /= n;
+            src += (size_t)(i + 1) * stride;
+            stride *= (size_t)m;
+        }
+        interior[g] = ext[src];
+    }
+}
+
 __global__ void k_amax(const double* __restrict__ x, size_t n, unsigned long long* slot) {
     double m = 0.0;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {

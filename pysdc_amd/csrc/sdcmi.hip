@@ -2209,6 +2209,26 @@ int sdc_odd_mirror(sdc_ctx* c, double* field, int n_interior) {
     return SDC_OK;
 }
 
+int sdc_odd_extend(sdc_ctx* c, const double* interior, double* ext, int n_interior, int ndim) {
+    CTX_OR_DEFAULT(c);
+    if (!interior || !ext || n_interior < 1 || ndim < 1 || ndim > 3) return fail(c, SDC_ERR_PARAM, "bad odd-extension arguments");
+    size_t total = 1;
+    for (int d = 0; d < ndim; ++d) total *= (size_t)(2 * (n_interior + 1));
+    hipLaunchKernelGGL(k_odd_extend_nd, dim3(grid_for(total, 256)), dim3(256), 0, c->stream, interior, ext, n_interior, ndim);
+    HIPCHK(c, hipGetLastError());
+    return SDC_OK;
+}
+
+int sdc_odd_extract(sdc_ctx* c, const double* ext, double* interior, int n_interior, int ndim) {
+    CTX_OR_DEFAULT(c);
+    if (!interior || !ext || n_interior < 1 || ndim < 1 || ndim > 3) return fail(c, SDC_ERR_PARAM, "bad odd-extension arguments");
+    size_t total = 1;
+    for (int d = 0; d < ndim; ++d) total *= (size_t)n_interior;
+    hipLaunchKernelGGL(k_odd_extract_nd, dim3(grid_for(total, 256)), dim3(256), 0, c->stream, ext, interior, n_interior, ndim);
+    HIPCHK(c, hipGetLastError());
+    return SDC_OK;
+}
+
 int sdc_sync(sdc_ctx* c) {
     if (!c) return SDC_ERR_PARAM;
     HIPCHK(c, hipStreamSynchronize(c->stream));

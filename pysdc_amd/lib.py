@@ -81,6 +81,8 @@ PROTOTYPES = {
     'sdc_transfer_apply_batch': (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     'sdc_transfer_apply': (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     'sdc_odd_mirror': (C.c_int, [_vp, _vp, C.c_int]),
+    'sdc_odd_extend': (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int]),
+    'sdc_odd_extract': (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int]),
     'sdc_sync': (C.c_int, [_vp]),
     'sdc_timer_begin': (C.c_int, [_vp]),
     'sdc_timer_end': (C.c_int, [_vp, _dp]),

@@ -104,7 +104,7 @@ class Problem:
         if self._engine is None:
             from pysdc_amd.engine import SweepEngine
 
-            self.bind_engine(SweepEngine(self.nvars, 1, self.ncomp))
+            self.bind_engine(SweepEngine(getattr(self, 'engine_nvars', self.nvars), 1, self.ncomp))
         return self._engine
 
 
@@ -143,10 +143,10 @@ class GenericNDimFinDiff(Problem):
             raise ProblemError('need a square domain, got %s' % (nvars,))
         if bc not in ('periodic', 'dirichlet-zero'):
             raise ProblemError(f'the MI355X engine implements periodic and dirichlet-zero boundaries, got bc={bc!r}')
-        if bc == 'dirichlet-zero' and (ndim != 1 or order != 2 or derivative != 2 or stencil_type != 'center'):
+        if bc == 'dirichlet-zero' and (order != 2 or derivative != 2 or stencil_type != 'center'):
             raise ProblemError(
-                'dirichlet-zero is available for the 1-D second-order centred second derivative (odd extension); '
-                f'got ndim={ndim}, order={order}, derivative={derivative}'
+                'dirichlet-zero is available for the second-order centred second derivative (odd extension; the shifted '
+                f'boundary stencils of higher orders are not built); got order={order}, derivative={derivative}'
             )
         if solver_type not in ('direct', 'CG', 'GMRES'):
             raise ProblemError(f'solver type "{solver_type}" not known in generic advection-diffusion implementation!')
@@ -161,9 +161,16 @@ class GenericNDimFinDiff(Problem):
         dx, xvalues = fd.grid_1d(size=nvars[0], bc=bc, left_boundary=0.0, right_boundary=1.0)
         self._stencil = fd.periodic_operator_stencil(derivative, order, stencil_type, dx, coeff)
         self.xvalues = xvalues
-        # dirichlet-zero: the engine works on the odd extension of length 2(n+1) (include/sdcmi.h: sdc_odd_mirror)
-        self.view_offset = 1 if bc == 'dirichlet-zero' else 0
-        self.engine_nvars = (2 * (nvars[0] + 1),) if bc == 'dirichlet-zero' else nvars
+        # dirichlet-zero: the engine works on the odd extension of length 2(n+1) per axis.  1-D: the interior is a
+        # contiguous part of it, so level fields ARE views into extended slab fields (include/sdcmi.h: sdc_odd_mirror).
+        # 2-D / 3-D: the interior is strided inside the extension, so fields stay compact and are packed into / extracted
+        # from extension-sized scratch around eval_f and solve_system (sdc_odd_extend / sdc_odd_extract); the sweep then
+        # runs node by node on datatype operations (fused = False).
+        self.view_offset = 1 if (bc == 'dirichlet-zero' and ndim == 1) else 0
+        self.odd_nd = bc == 'dirichlet-zero' and ndim > 1
+        self.engine_nvars = (2 * (nvars[0] + 1),) * ndim if bc == 'dirichlet-zero' else nvars
+        if self.odd_nd:
+            self.fused = False
         self._scratch = None
         self._makeAttributeAndRegister('nvars', 'stencil_type', 'order', 'bc', localVars=locals(), readOnly=True)
         self._makeAttributeAndRegister('freq', 'lintol', 'liniter', 'solver_type', localVars=locals())
@@ -205,12 +212,16 @@ class GenericNDimFinDiff(Problem):
     # ---- odd-extension staging for fields that are not slab views (dirichlet-zero) ----------------------------
     def _ext(self, k):
         if self._scratch is None:
-            n2 = self.engine_nvars[0]
+            n2 = int(np.prod(self.engine_nvars))
             self._scratch = [hip_mesh(((n2,), None, np.dtype('float64'))) for _ in range(3)]
         return self._scratch[k]
 
     def _stage_in(self, u, k):
         """pointer the engine can read: the field itself (periodic) or its odd extension in scratch k"""
+        if self.odd_nd:
+            e = self._ext(k)
+            L.check(self.engine.lib.sdc_odd_extend(self.engine.ctx, u.ptr, e.ptr, self.nvars[0], self.ndim), self.engine.ctx)
+            return e.ptr
         if not self.view_offset:
             return u.ptr
         e = self._ext(k)
@@ -220,11 +231,14 @@ class GenericNDimFinDiff(Problem):
         return e.ptr
 
     def _stage_out(self, k, dst):
-        if self.view_offset:
+        if self.odd_nd:
+            L.check(self.engine.lib.sdc_odd_extract(self.engine.ctx, self._ext(k).ptr, dst.ptr, self.nvars[0], self.ndim),
+                    self.engine.ctx)
+        elif self.view_offset:
             self.engine.vec_copy(self.nvars[0], self._ext(k).ptr + 8, dst.ptr)
 
     def _out_ptr(self, k, dst):
-        return self._ext(k).ptr if self.view_offset else dst.ptr
+        return self._ext(k).ptr if (self.view_offset or self.odd_nd) else dst.ptr
 
     def eval_f(self, u, t):
         f = self._out_f()
@@ -301,9 +315,18 @@ class heatNd_forced(heatNd_unforced):
 
     def configure_engine(self, engine):
         super().configure_engine(engine)
-        if self.view_offset:  # the sine profile continued over the odd extension is the same sine
-            x = np.arange(self.engine_nvars[0]) * self.dx
-            engine.set_forcing_profile(np.sin(np.pi * self.freq[0] * x))
+        if self.view_offset or self.odd_nd:  # the sine profile continued over the odd extension is the same sine
+            x = np.arange(self.engine_nvars[0]) * self.dx   # extension index e <-> x = e dx (interior point i is e = i + 1)
+            if self.ndim == 1:
+                g = [x]
+            elif self.ndim == 2:
+                g = [x[None, :], x[:, None]]                 # orientation of self.grids (generic_ND_FD.py:172-180)
+            else:
+                g = [x[None, :, None], x[:, None, None], x[None, None, :]]
+            p = np.sin(np.pi * self.freq[0] * g[0])
+            for i in range(1, self.ndim):
+                p = p * np.sin(np.pi * self.freq[i] * g[i])
+            engine.set_forcing_profile(np.broadcast_to(p, self.engine_nvars))
         else:
             engine.set_forcing_profile(self._profile())
 
@@ -315,7 +338,12 @@ class heatNd_forced(heatNd_unforced):
 
     def eval_f(self, u, t):
         f = self._out_f()
-        if self.view_offset:
+        if self.odd_nd:
+            e = self.engine
+            e.eval_f(self._stage_in(u, 0), float(self.forcing_g(t)), self._ext(1).ptr, self._ext(2).ptr)
+            for k, part in ((1, f.impl), (2, f.expl)):
+                L.check(e.lib.sdc_odd_extract(e.ctx, self._ext(k).ptr, part.ptr, self.nvars[0], self.ndim), e.ctx)
+        elif self.view_offset:
             self.engine.eval_f(self._stage_in(u, 0), float(self.forcing_g(t)), self._ext(1).ptr, self._ext(2).ptr)
             n = self.nvars[0]
             self.engine.vec_copy(n, self._ext(1).ptr + 8, f.impl.ptr)

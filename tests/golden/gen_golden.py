@@ -11,7 +11,7 @@ own entry points, switched on by environment variables (or call the function aft
 GOLDEN_FFT=1 fft_transfer_main (transfer_fft.npz, runs_ac_fft.npz), GOLDEN_RELAY=1 relay_main (runs_relay.npz),
 GOLDEN_CG=1 cg_main (sweeps_cg.npz), GOLDEN_VDPJ=1 vdp_jacobian_main (vdp_jacobian.npz), GOLDEN_DML=1
 dirichlet_ml_main (transfer_dirichlet.npz, runs_ml_dirichlet.npz), GOLDEN_GUESS=1 guess_main (sweeps_guess.npz), GOLDEN_SKIP=1 skip_main (runs_skip.npz), GOLDEN_RELAY8=1 relay8_main (runs_relay8.npz),
-GOLDEN_BIG3D=1 big3d_main (sweeps_big3d.npz), GOLDEN_CFG5=1 cfg5_main (runs_cfg5.npz), GOLDEN_ML8=1 ml8_main (runs_ml8.npz);
+GOLDEN_BIG3D=1 big3d_main (sweeps_big3d.npz), GOLDEN_CFG5=1 cfg5_main (runs_cfg5.npz), GOLDEN_ML8=1 ml8_main (runs_ml8.npz), GOLDEN_DND=1 dirichlet_nd_main (sweeps_dirichlet_nd.npz, runs_dirichlet_nd.npz);
 GOLDEN_ML=0 skips the multi-level block.
 
 ``qmat`` (third-party, absent here) is replaced by oracle/qmat_shim, which forwards to
@@ -850,3 +850,31 @@ def ml8_main():
 
 if __name__ == '__main__' and os.environ.get('GOLDEN_ML8', '0') == '1':
     ml8_main()
+
+
+def dirichlet_nd_main():
+    """dirichlet-zero in 2-D / 3-D (generic_ND_FD.py:99-133, helpers/problem_helper.py:143-224; order 2): sweeps of the
+    implicit and the IMEX sweeper and a run to restol, by the reference."""
+    RR = dict(quad_type='RADAU-RIGHT')
+    cases = []
+    cases.append(sweep_case('heat2d_dirichlet', 'heat_unforced', dict(nvars=(15, 15), nu=0.1, freq=(1, 2), bc='dirichlet-zero'),
+                            'generic_implicit', dict(num_nodes=3, QI='LU', **RR), 2e-2))
+    cases.append(sweep_case('heat3d_dirichlet', 'heat_unforced', dict(nvars=(7, 7, 7), nu=0.1, freq=(1, 1, 2), bc='dirichlet-zero'),
+                            'generic_implicit', dict(num_nodes=5, QI='IE', **RR), 1e-2))
+    cases.append(sweep_case('forced2d_dirichlet', 'heat_forced', dict(nvars=(15, 15), nu=0.1, freq=(1, 3), bc='dirichlet-zero'),
+                            'imex_1st_order', dict(num_nodes=3, QI='LU', QE='EE', **RR), 2e-2, u0_kind='exact'))
+    cases.append(sweep_case('forced3d_dirichlet', 'heat_forced', dict(nvars=(7, 7, 7), nu=0.1, freq=(1, 2, 1), bc='dirichlet-zero'),
+                            'imex_1st_order', dict(num_nodes=3, QI='IE', QE='EE', **RR), 1e-2, u0_kind='exact'))
+    save('sweeps_dirichlet_nd.npz', cases)
+    cases = []
+    cases.append(run_case('heat2d_dirichlet_run', prob='heat_unforced', prob_params=dict(nvars=(31, 31), nu=0.1, freq=(1, 1), bc='dirichlet-zero'),
+                          sweeper='generic_implicit', sweeper_params=dict(num_nodes=3, QI='LU', **RR),
+                          level_params=dict(dt=0.05, restol=1e-9), maxiter=50, t0=0.0, Tend=0.15))
+    cases.append(run_case('forced3d_dirichlet_run_P2', prob='heat_forced', prob_params=dict(nvars=(7, 7, 7), nu=0.1, freq=(1, 1, 1), bc='dirichlet-zero'),
+                          sweeper='imex_1st_order', sweeper_params=dict(num_nodes=3, QI='LU', QE='EE', **RR),
+                          level_params=dict(dt=0.05, restol=1e-9), maxiter=50, t0=0.0, Tend=0.2, num_procs=2))
+    save('runs_dirichlet_nd.npz', cases)
+
+
+if __name__ == '__main__' and os.environ.get('GOLDEN_DND', '0') == '1':
+    dirichlet_nd_main()

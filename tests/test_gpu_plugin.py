@@ -20,9 +20,7 @@ def _classes():
 
 def description_from(meta, problem_class=None):
     probs, sweeps = _classes()
-    pp = dict(meta['prob_params'])
-    if isinstance(pp.get('nvars'), list):
-        pp['nvars'] = tuple(pp['nvars'])
+    pp = {k: tuple(v) if isinstance(v, list) else v for k, v in meta['prob_params'].items()}
     sp = {k: tuple(v) if isinstance(v, list) else v for k, v in meta['sweeper_params'].items()}  # (lists mean levels)
     return dict(problem_class=problem_class or probs[meta['prob']], problem_params=pp,
                 sweeper_class=sweeps[meta['sweeper']], sweeper_params=sp,
@@ -30,6 +28,7 @@ def description_from(meta, problem_class=None):
 
 
 RUNS = ([('runs.npz', n) for n in load_cases('runs.npz')] + [('runs_dirichlet.npz', n) for n in load_cases('runs_dirichlet.npz')]
+        + [('runs_dirichlet_nd.npz', n) for n in load_cases('runs_dirichlet_nd.npz')]
         + [('runs_skip.npz', n) for n in load_cases('runs_skip.npz')])
 
 
@@ -277,19 +276,28 @@ def test_bench_single_rank_distributed_path():
     assert ref.returncode == 0, ref.stderr[-2000:]
 
 
-@pytest.mark.parametrize('fname,name', [('sweeps_heat.npz', 'heat1d_dirichlet'), ('sweeps_imex.npz', 'forced1d_dirichlet')])
+DIRICHLET_SWEEPS = ([('sweeps_heat.npz', 'heat1d_dirichlet'), ('sweeps_imex.npz', 'forced1d_dirichlet')]
+                    + [('sweeps_dirichlet_nd.npz', n) for n in load_cases('sweeps_dirichlet_nd.npz')])
+
+
+@pytest.mark.parametrize('fname,name', DIRICHLET_SWEEPS)
 @pytest.mark.parametrize('fused', [True, False])
-def test_dirichlet_1d_sweeps_vs_golden(fname, name, fused):
-    """dirichlet-zero in 1-D (odd extension inside the engine) against golden sweeps of the reference."""
+def test_dirichlet_sweeps_vs_golden(fname, name, fused):
+    """dirichlet-zero against golden sweeps of the reference: 1-D (odd extension inside the engine, fused sweeps) and 2-D /
+    3-D (fields packed into their odd extension around eval_f / solve_system, node-by-node sweeps)."""
     from pysdc_amd.level import Step
 
     case = load_cases(fname)[name]
     meta = case['meta']
     probs, sweeps = _classes()
     pc = probs[meta['prob']]
-    if not fused:
+    pp = {k: tuple(v) if isinstance(v, list) else v for k, v in meta['prob_params'].items()}
+    if len(pp['nvars']) > 1 if isinstance(pp['nvars'], tuple) else False:
+        if fused:
+            pytest.skip('2-D / 3-D dirichlet levels sweep node by node')
+    elif not fused:
         pc = type(pc.__name__ + '_nodewise', (pc,), {'fused': False})
-    S = Step(dict(problem_class=pc, problem_params=dict(meta['prob_params']), sweeper_class=sweeps[meta['sweeper']],
+    S = Step(dict(problem_class=pc, problem_params=pp, sweeper_class=sweeps[meta['sweeper']],
                   sweeper_params=dict(meta['sweeper_params']), level_params=dict(dt=meta['dt']),
                   step_params=dict(maxiter=10)))
     L = S.levels[0]
