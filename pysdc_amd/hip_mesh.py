@@ -30,6 +30,24 @@ class _CAI:
         self._keep = keep
 
 
+class device_buffer:
+    """raw device allocation holding the bytes of a host array (index / weight tables of the transfer kernels)"""
+
+    def __init__(self, host):
+        h = np.ascontiguousarray(host)
+        self.nbytes = int(h.nbytes)
+        self._alloc()
+        self._upload(h)
+
+    def _alloc(self):
+        torch = _torch()
+        self._buf = torch.empty(max(self.nbytes, 1), dtype=torch.uint8, device='cuda')
+        self.ptr = self._buf.data_ptr()
+
+    def _upload(self, h):
+        _check_hip(_hip().hipMemcpy(C.c_void_p(self.ptr), h.ctypes.data_as(C.c_void_p), self.nbytes, 1))
+
+
 class hip_mesh:
     comm = None
     xp = None

@@ -434,6 +434,8 @@ class Step:
     """pySDC/core/step.py:47-331: one time step with its level hierarchy (list-valued parameters = one entry per
     level, step.py:175-199) and the transfer operators between neighbouring levels (step.py:201-253)."""
 
+    level_class = None  # the container of one level; None = pysdc_amd.level.Level (tests substitute a foreign one)
+
     def __init__(self, description):
         from pysdc_amd.transfer import BaseTransfer
 
@@ -463,8 +465,8 @@ class Step:
         if len(descr_list) > 1 and not descr_new['space_transfer_class']:
             raise ParameterError('need space_transfer_class to instantiate step, only got %s' % str(descr_new.keys()))
         for l, d in enumerate(descr_list):
-            L = Level(d['problem_class'], dict(d['problem_params']), d['sweeper_class'], dict(d['sweeper_params']),
-                      dict(d['level_params']), l)
+            L = (self.level_class or Level)(d['problem_class'], dict(d['problem_params']), d['sweeper_class'],
+                                            dict(d['sweeper_params']), dict(d['level_params']), l)
             self.levels.append(L)
             if l > 0:
                 self.connect_levels(descr_new['base_transfer_class'], d['base_transfer_params'],

@@ -13,7 +13,7 @@ import numpy as np
 from pysdc_amd import lib as Lb
 from pysdc_amd.coeffs import LagrangeApproximation
 from pysdc_amd.errors import TransferError, UnlockError
-from pysdc_amd.hip_mesh import hip_mesh, hip_imex_mesh
+from pysdc_amd.hip_mesh import device_buffer, hip_mesh, hip_imex_mesh
 
 
 class _BasePars:
@@ -122,11 +122,9 @@ class BaseTransfer:
         many = getattr(self.space_transfer, 'prolong_many', None)
         if many and all(type(new_fields[n]) is hip_mesh for n in range(1, Mc + 1)):
             # the differences go into one buffer, one behind the other, so that they are prolonged together
-            import torch
-
             size, shape = new_fields[1].size, new_fields[1].shape
-            buf = torch.empty(Mc * size, dtype=torch.float64, device='cuda')
-            diffs = [hip_mesh.view(buf.data_ptr() + 8 * k * size, shape, keep=buf) for k in range(Mc)]
+            buf = hip_mesh(((Mc * size,), None, np.dtype('float64')), val=None)
+            diffs = [hip_mesh.view(buf.ptr + 8 * k * size, shape, keep=buf) for k in range(Mc)]
             for k in range(Mc):
                 diffs[k]._axpby(1.0, new_fields[k + 1], -1.0, old_fields[k + 1], diffs[k])
             return many(diffs)
@@ -285,8 +283,6 @@ class mesh_to_mesh:
                                     f'(dirichlet-zero), got {nf} -> {nc}')
         self.ndim, self.nc, self.nf = len(nc), nc[0], nf[0]
         if not self.identity:
-            import torch
-
             first = 0 if periodic else 1  # TransferMesh.py:62-67: dirichlet grids start at dx
             fine_grid = np.array([(j + first) * fine_prob.dx for j in range(nf[0])])
             coarse_grid = np.array([(j + first) * coarse_prob.dx for j in range(nc[0])])
@@ -299,12 +295,11 @@ class mesh_to_mesh:
             self._tab = {}
             for key, Mx in (('P', P), ('R', R)):
                 idx, w, width = _row_tables(Mx)
-                self._tab[key] = (torch.from_numpy(idx).cuda(), torch.from_numpy(w).cuda(), width, Mx.shape)
+                self._tab[key] = (device_buffer(idx), device_buffer(w), width, Mx.shape)
 
     def _apply(self, key, src, dst):
         idx, w, width, (n_out, n_in) = self._tab[key]
-        Lb.check(Lb.load().sdc_transfer_apply(None, self.ndim, n_out, n_in, width, idx.data_ptr(), w.data_ptr(),
-                                              src.ptr, dst.ptr), None)
+        Lb.check(Lb.load().sdc_transfer_apply(None, self.ndim, n_out, n_in, width, idx.ptr, w.ptr, src.ptr, dst.ptr), None)
 
     def _restrict(self, fine, coarse):
         if self.identity:
@@ -327,15 +322,13 @@ class mesh_to_mesh:
         ptrs = [f.ptr for f in fields]
         if any(p != ptrs[0] + k * step for k, p in enumerate(ptrs)):
             return None
-        import torch
-
         idx, w, width, (n_out, n_in) = self._tab[key]
         shape = out_init[0] if not np.isscalar(out_init[0]) else (int(out_init[0]),)
         osize = int(np.prod(shape))
-        buf = torch.empty(len(fields) * osize, dtype=torch.float64, device='cuda')
-        Lb.check(Lb.load().sdc_transfer_apply_batch(None, len(fields), self.ndim, n_out, n_in, width, idx.data_ptr(),
-                                                    w.data_ptr(), ptrs[0], buf.data_ptr()), None)
-        return [hip_mesh.view(buf.data_ptr() + 8 * k * osize, shape, keep=buf) for k in range(len(fields))]
+        buf = hip_mesh(((len(fields) * osize,), None, np.dtype('float64')), val=None)
+        Lb.check(Lb.load().sdc_transfer_apply_batch(None, len(fields), self.ndim, n_out, n_in, width, idx.ptr, w.ptr,
+                                                    ptrs[0], buf.ptr), None)
+        return [hip_mesh.view(buf.ptr + 8 * k * osize, shape, keep=buf) for k in range(len(fields))]
 
     def restrict_many(self, fields):
         out = self._many('R', fields, self.coarse_prob.init)
@@ -405,14 +398,11 @@ class _fourier_transfer:
 
     def _inject(self, fine, coarse):
         if self._tab is None:
-            import torch
-
             idx = (np.arange(self.nc, dtype=np.int32) * self.ratio).reshape(self.nc, 1)
-            self._tab = (torch.from_numpy(np.ascontiguousarray(idx)).cuda(),
-                         torch.ones((self.nc, 1), dtype=torch.float64, device='cuda'))
+            self._tab = (device_buffer(idx), device_buffer(np.ones((self.nc, 1))))
         idx, w = self._tab
-        Lb.check(Lb.load().sdc_transfer_apply(None, self.ndim, self.nc, self.nf, 1, idx.data_ptr(), w.data_ptr(),
-                                              fine.ptr, coarse.ptr), None)
+        Lb.check(Lb.load().sdc_transfer_apply(None, self.ndim, self.nc, self.nf, 1, idx.ptr, w.ptr, fine.ptr, coarse.ptr),
+                 None)
 
     def _pad(self, coarse, fine):
         ec, ef = self.coarse_prob.engine, self.fine_prob.engine

@@ -57,6 +57,25 @@ class HostLib:
     def sdc_last_error(self, ctx):
         return b'host stand-in'
 
+    # space transfer (include/sdcmi.h: sdc_transfer_apply[_batch]): the 1-D operator given as fixed-width rows, stored
+    # entry-major ([width][n_out]), applied along every axis
+    def sdc_transfer_apply_batch(self, stream, nfields, ndim, n_out, n_in, width, idx, w, src, dst):
+        ix = np.ctypeslib.as_array((C.c_int32 * (width * n_out)).from_address(_addr(idx))).reshape(width, n_out)
+        wt = _arr(w, width * n_out).reshape(width, n_out)
+        M = np.zeros((n_out, n_in))
+        for k in range(width):
+            for i in range(n_out):
+                M[i, ix[k, i]] += wt[k, i]
+        fin = _arr(src, nfields * n_in**ndim).reshape((nfields,) + (n_in,) * ndim)
+        out = fin
+        for ax in range(1, ndim + 1):
+            out = np.moveaxis(np.tensordot(M, out, axes=([1], [ax])), 0, ax)
+        _arr(dst, nfields * n_out**ndim)[:] = out.reshape(-1)
+        return 0
+
+    def sdc_transfer_apply(self, stream, ndim, n_out, n_in, width, idx, w, src, dst):
+        return self.sdc_transfer_apply_batch(stream, 1, ndim, n_out, n_in, width, idx, w, src, dst)
+
 
 class _Prob:
     """oracle-style problem (eval_f / solve_system on ndarrays) built from what the engine was configured with"""
@@ -260,6 +279,16 @@ def host_device():
     from pysdc_amd import engine as E, hip_mesh as HM, level as LV, lib as LB
 
     saved = (LB.load, HM.hip_mesh._alloc, HM.hip_mesh.get, HM.hip_mesh.set, E.SweepEngine, LV.SweepEngine)
+    saved_buf = (HM.device_buffer._alloc, HM.device_buffer._upload)
+
+    def _balloc(self):
+        self._buf = np.zeros(max(self.nbytes, 1), dtype=np.uint8)
+        self.ptr = self._buf.ctypes.data
+
+    def _bupload(self, h):
+        self._buf[:self.nbytes] = np.frombuffer(h.tobytes(), dtype=np.uint8)
+
+    HM.device_buffer._alloc, HM.device_buffer._upload = _balloc, _bupload
     hostlib = HostLib()
 
     def _alloc(self):
@@ -280,3 +309,4 @@ def host_device():
         yield
     finally:
         LB.load, HM.hip_mesh._alloc, HM.hip_mesh.get, HM.hip_mesh.set, E.SweepEngine, LV.SweepEngine = saved
+        HM.device_buffer._alloc, HM.device_buffer._upload = saved_buf

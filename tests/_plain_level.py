@@ -52,24 +52,14 @@ class PlainLevel(_Frozen):
     dt = property(lambda self: self.params.dt)
 
 
-class PlainStep(_Frozen):
-    """single-level step (what the foreign-level tests need)"""
+from pysdc_amd.level import Step as _ProductStep
 
-    def __init__(self, description):
-        self.params = StepParams(description.get('step_params', {}))
-        self.status = StepStatus()
-        self.levels = [PlainLevel(description['problem_class'], dict(description.get('problem_params', {})),
-                                  description['sweeper_class'], dict(description['sweeper_params']),
-                                  dict(description['level_params']), 0)]
-        self.prev = None
-        self._frozen = True
 
-    time = property(lambda self: self.levels[0].time)
-    dt = property(lambda self: self.levels[0].dt)
+class PlainStep(_ProductStep):
+    """the product's Step logic (level hierarchy from list-valued parameters, transfer operators between neighbours) over
+    PlainLevel containers; init_step assigns a copy-constructed datatype object like core/step.py:256-271"""
 
-    def reset_step(self):
-        for lvl in self.levels:
-            lvl.reset_level()
+    level_class = PlainLevel
 
     def init_step(self, u0):
         P = self.levels[0].prob

@@ -457,3 +457,31 @@ def test_config5_pfasst_four_ranks_match_serial_emulation():
     assert list(niter[np.argsort(times)]) == ref_niter
     for r in range(size):
         assert rel_err(out[r][0], ref) < 1e-11
+
+
+@pytest.mark.parametrize('fname,name', [('runs_ml.npz', 'mlsdc_heat2d'), ('runs_ml.npz', 'pfasst_heat2d_P4'),
+                                        ('runs_ml.npz', 'pfasst_forced2d_P2'), ('runs_ml.npz', 'mlsdc_heat2d_M53'),
+                                        ('runs_ml.npz', 'pfasst_heat3d_P2'), ('runs_ac.npz', 'ac2d_pfasst_P2')])
+def test_multilevel_runs_inside_foreign_levels(fname, name):
+    """MLSDC / PFASST with level containers that are NOT pysdc_amd.level.Level (tests/_plain_level.py: plain lists that
+    reset_level replaces, frozen attribute set - the semantics of the reference's core/level.py): the sweepers keep a
+    ForeignLevelState per level and adopt the lists the FAS transfer writes into (u, f, tau, uold, fold)."""
+    from pysdc_amd.controller import controller_nonMPI
+    from pysdc_amd.level import ForeignLevelState
+    from pysdc_amd.stats import get_sorted
+    from tests._plain_level import PlainStep, PlainLevel
+
+    case = load_cases(fname)[name]
+    meta = case['meta']
+    desc = _description(meta, meta['level_params'], meta.get('iorder', 6), meta.get('rorder', 2))
+    desc['step_class'] = PlainStep
+    C = controller_nonMPI(meta['num_procs'], dict(logger_level=40, **meta['controller_params']), desc)
+    assert all(type(L) is PlainLevel for L in C.MS[0].levels)
+    P = C.MS[0].levels[0].prob
+    u0 = P.u_init
+    u0[:] = case['u0']
+    uend, stats = C.run(u0, meta['t0'], meta['Tend'])
+    assert all(isinstance(L.sweep._dev(), ForeignLevelState) for L in C.MS[0].levels)
+    niter = get_sorted(stats, type='niter', sortby='time')
+    assert [v for _, v in niter] == list(case['niter'])
+    assert rel_err(uend.get(), case['uend']) < TOL

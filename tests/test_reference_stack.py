@@ -95,3 +95,31 @@ def test_reference_hooks_and_convergence_controllers_on_device_datatype(ref):
         assert rel_err(sol[-1][1].get(), case['uend']) < 1e-10
         assert all(rel_err(s.get(), case['uend']) > 1e-6 for _, s in sol[:-1])
         assert [v for _, v in ref['get_sorted'](stats, type='niter', sortby='time')] == list(case['niter'])
+
+
+@pytest.mark.parametrize('name', ['mlsdc_heat2d', 'pfasst_heat2d_P2', 'pfasst_heat2d_P4', 'mlsdc_forced2d', 'pfasst_forced2d_P2',
+                                  'mlsdc_heat2d_M53'])
+def test_reference_multilevel_stack_drives_product_classes(ref, name):
+    """two levels inside the REFERENCE's Step: its BaseTransfer (FAS restriction / prolongation on datatype operations,
+    core/base_transfer.py:93-251) and its MLSDC / PFASST stages around the product's sweepers, problems, datatype and
+    space transfer class (mesh_to_mesh), against the golden runs of the pure reference."""
+    from pysdc_amd.transfer import mesh_to_mesh
+
+    case = load_cases('runs_ml.npz')[name]
+    meta = case['meta']
+    with host_device():
+        desc = _description(meta)
+        desc['problem_params'] = dict(desc['problem_params'], nvars=[tuple(v) for v in meta['prob_params']['nvars']])
+        desc['space_transfer_class'] = mesh_to_mesh
+        desc['space_transfer_params'] = dict(iorder=meta['iorder'], rorder=meta['rorder'], periodic=True)
+        C = ref['controller'](meta['num_procs'], dict(logger_level=40, **meta['controller_params']), desc)
+        assert len(C.MS[0].levels) == 2 and type(C.MS[0].levels[1]) is ref['Level']
+        assert type(C.MS[0].base_transfer).__module__.startswith('pySDC.')      # the reference's FAS code, not ours
+        u0 = C.MS[0].levels[0].prob.u_init
+        u0[:] = case['u0']
+        uend, stats = C.run(u0, meta['t0'], meta['Tend'])
+        niter = ref['get_sorted'](stats, type='niter', sortby='time')
+        assert [v for _, v in niter] == list(case['niter'])
+        assert rel_err(uend.get(), case['uend']) < 1e-10
+        res = [v for _, v in ref['get_sorted'](stats, type='residual_post_iteration', sortby='time')]
+        np.testing.assert_allclose(res, case['res'], rtol=1e-6, atol=1e-11)
