@@ -493,6 +493,9 @@ def main():
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        # one node by contract: rendezvous and the gloo side group (1-byte flags) on the loopback interface - the container's
+        # host name may not resolve, which gloo would otherwise try
+        os.environ.setdefault('GLOO_SOCKET_IFNAME', 'lo')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29531')
         import datetime
