@@ -105,12 +105,15 @@ def _collect(proc, timeout=600):
     return json.loads(out.decode().strip().splitlines()[-1])
 
 
-def cpu_baseline(M, dt_ref_n, target_n=1024, nsweeps=4, max_workers=64):
+def cpu_baseline(M, dt_ref_n, target_n=1024, nsweeps=4, max_workers=32):
     """kind = "port": the oracle timed on the GPU box's host cores, on bounded samples of the same workload.
       * one core, 64^3, one time step (4 sweeps), and - beside it - one core, 128^3, ONE sweep: shows what the
         linear-in-DOF extrapolation to the target size leaves out (CG iteration counts grow with the grid);
-      * all host cores: `cores` independent copies of the 64^3 sample at once (the reference's NumPy / SciPy path is
-        single-threaded, so throughput over cores = independent time steps), value = cores / slowest copy.
+      * many host cores: `cores` independent copies of the 64^3 sample at once (the reference's NumPy / SciPy path is
+        single-threaded, so throughput over cores = independent time steps), value = cores / slowest copy.  At most 32:
+        the sparse mat-vecs are bound by host memory bandwidth - on the 256-core GPU box 32 copies run 3 x slower each
+        than one alone (4.9 steps/s together) and 64 copies 10 x slower (2.9 steps/s together), so more copies would
+        make the CPU look worse, not better.
     `value` = the all-cores figure scaled to the target size by DOF (optimistic for the CPU)."""
     ncpu = os.cpu_count() or 1
     r64 = _collect(_spawn_cpu_sample(64, M, dt_ref_n, target_n, nsweeps))   # alone on the host: clean one-core figure
