@@ -1561,7 +1561,11 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
         if (rcf != SDC_OK) return rcf;
         a.S = c->S;
         a.SL = c->SL;
+#ifdef SDC_NO_REALSYM
+        a.real_sym = 0;
+#else
         a.real_sym = c->sym_real[0] ? 1 : 0;
+#endif
         a.fstride = c->Nc;
         a.S0 = c->S0;
         a.W = c->W;
