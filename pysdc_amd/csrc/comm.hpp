@@ -135,9 +135,12 @@ extern "C" int sdc_comm_init(sdc_ctx* c, const char* uid128, int nranks, int ran
         comm_free(c);
         return fail(c, SDC_ERR_COMM, "ncclCommInitRank(rank %d of %d): %s", rank, nranks, api->GetErrorString(r));
     }
-    HIPCHK(c, hipStreamCreateWithFlags(&cs->stream, hipStreamNonBlocking));
-    HIPCHK(c, hipEventCreateWithFlags(&cs->ready, hipEventDisableTiming));
-    HIPCHK(c, hipEventCreateWithFlags(&cs->done, hipEventDisableTiming));
+    if (hipStreamCreateWithFlags(&cs->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&cs->ready, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&cs->done, hipEventDisableTiming) != hipSuccess) {
+        comm_free(c);  // (the communicator and whatever was created are released again)
+        return fail(c, SDC_ERR_HIP, "cannot create the message stream / events");
+    }
     return SDC_OK;
 }
 
