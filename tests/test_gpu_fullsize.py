@@ -417,7 +417,7 @@ def test_deferred_state_machine_random_walk(prob, seed):
         assert np.max(np.abs(x - y)) <= 1e-12 * max(1.0, np.max(np.abs(y))), ' '.join(what)
 
     ops = ['sweep'] * 6 + ['residual'] * 3 + ['end_point', 'end_point_coll', 'get_u', 'get_f', 'put_u0', 'put_um',
-                                               'replace_u0', 'advance', 'integrate', 'predict', 'predict_copy', 'get_f0',
+                                               'replace_u0', 'advance', 'advance', 'get_u0', 'integrate', 'predict', 'predict_copy', 'get_f0',
                                                'toggle_reuse', 'toggle_fused', 'toggle_skip', 'tau_on', 'tau_off']
     state = dict(reuse=True, fused=True, skip=False)
     trace = []
@@ -444,6 +444,8 @@ def test_deferred_state_machine_random_walk(prob, seed):
                 close(a.download(L.SLOT_F, m, comp), b.download(L.SLOT_F, m, comp), trace)
         elif op == 'get_f0':
             close(a.download(L.SLOT_F, 0), b.download(L.SLOT_F, 0), trace)
+        elif op == 'get_u0':   # (after an advance the start value may still lie in the old end-value buffer)
+            close(a.download(L.SLOT_U, 0), b.download(L.SLOT_U, 0), trace)
         elif op in ('put_u0', 'put_um'):
             x = rng.standard_normal((n, n, n)) * 0.1
             for e in engines:
