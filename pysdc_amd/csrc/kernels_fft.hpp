@@ -166,11 +166,11 @@ __global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_inv(FieldPtr
     if constexpr (NORM) {
         double m = 0.0;  // columns beyond the edge were transformed from zeros
 #pragma unroll
-        for (int i = 0; i < E; ++i) {
-            const double v0 = fabs(r[i].x), v1 = fabs(r[i].y);
-            const double v = (v0 > v1 || v0 != v0) ? v0 : v1;
-            m = (m > v || m != m) ? m : v;
-        }
+        for (int i = 0; i < E; ++i) m = fmax(m, fmax(fabs(r[i].x), fabs(r[i].y)));
+        // fmax drops NaNs, np.max does not: every output of the transform is a sum over ALL inputs of its column pair (the
+        // real parts of output 0 over the real parts only, its imaginary part over the imaginary ones), so a NaN anywhere
+        // in the pair shows in one output of every thread - looking at one element is an exact test
+        if (r[0].x != r[0].x || r[0].y != r[0].y) m = r[0].x + r[0].y;
         m = wave_max(m);
         if ((threadIdx.x & 63) == 0) atomic_max_abs(norms + blockIdx.y, m);
     }

@@ -141,3 +141,36 @@ def test_error_paths():
     back = e.download(L.SLOT_U, 1) - 0.1 * e.download(L.SLOT_F, 1)          # (I - 0.1 A) x
     assert np.max(np.abs(back - e.download(L.SLOT_U, 0))) < 1e-12
     e.close()
+
+
+@pytest.mark.parametrize('where', ['u0', 'u0_after_sweep'])
+def test_residual_propagates_nan_like_np_max(where):
+    """mesh.__abs__ is np.max(np.abs(.)): a NaN in a residual field makes the residual NaN (the controllers' convergence
+    test then fails loudly).  The Fourier-space sweeps reduce the norm in the last inverse pass with fmax (which drops
+    NaNs - a plain fmax chain would report 0 here) plus a test on one output per thread, which is exact because every
+    output of a transform is a sum over all inputs of its column."""
+    from pysdc_amd.coeffs import CollBase, QDELTA_GENERATORS
+
+    M, n, dt = 5, 64, 1e-2
+    e = G.engine_for('heat_unforced', dict(nvars=(n, n, n), nu=0.1), M)
+    c = CollBase(M, 0, 1, 'LEGENDRE', 'RADAU-RIGHT')
+    qi = np.zeros_like(c.Qmat)
+    qi[1:, 1:] = QDELTA_GENERATORS['IE'](qGen=c.generator, tLeft=0).genCoeffs()
+    e.set_coeffs(c.Qmat, qi, None, c.nodes, c.weights)
+    u0 = np.random.default_rng(0).standard_normal((n, n, n))
+    bad = u0.copy()
+    bad[5, 6, 7] = np.nan
+    e.upload(L.SLOT_U, 0, bad if where == 'u0' else u0)
+    e.predict(0.0, dt)
+    e.profile_enable(True)
+    e.sweep(0.0, dt)
+    res, norms = e.residual(dt)
+    if where == 'u0':
+        assert np.isnan(res) and np.all(np.isnan(norms))
+    else:
+        assert np.isfinite(res)
+        e.upload(L.SLOT_U, 0, bad)     # a poisoned value arrives as the new u[0] (a receive): residual of the cached iterate
+        res, norms = e.residual(dt)
+        assert np.isnan(res) and np.all(np.isnan(norms))
+    assert any(k.startswith('fft_x_norm') for k in e.profile_read())
+    e.close()
