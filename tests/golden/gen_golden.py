@@ -11,7 +11,7 @@ own entry points, switched on by environment variables (or call the function aft
 GOLDEN_FFT=1 fft_transfer_main (transfer_fft.npz, runs_ac_fft.npz), GOLDEN_RELAY=1 relay_main (runs_relay.npz),
 GOLDEN_CG=1 cg_main (sweeps_cg.npz), GOLDEN_VDPJ=1 vdp_jacobian_main (vdp_jacobian.npz), GOLDEN_DML=1
 dirichlet_ml_main (transfer_dirichlet.npz, runs_ml_dirichlet.npz), GOLDEN_GUESS=1 guess_main (sweeps_guess.npz), GOLDEN_SKIP=1 skip_main (runs_skip.npz), GOLDEN_RELAY8=1 relay8_main (runs_relay8.npz),
-GOLDEN_BIG3D=1 big3d_main (sweeps_big3d.npz), GOLDEN_CFG5=1 cfg5_main (runs_cfg5.npz), GOLDEN_ML8=1 ml8_main (runs_ml8.npz), GOLDEN_DND=1 dirichlet_nd_main (sweeps_dirichlet_nd.npz, runs_dirichlet_nd.npz);
+GOLDEN_BIG3D=1 big3d_main (sweeps_big3d.npz), GOLDEN_CFG5=1 cfg5_main (runs_cfg5.npz), GOLDEN_ML8=1 ml8_main (runs_ml8.npz), GOLDEN_DND=1 dirichlet_nd_main (sweeps_dirichlet_nd.npz, runs_dirichlet_nd.npz), GOLDEN_NSW2=1 nsweeps2_main (runs_nsweeps2.npz);
 GOLDEN_ML=0 skips the multi-level block.
 
 ``qmat`` (third-party, absent here) is replaced by oracle/qmat_shim, which forwards to
@@ -878,3 +878,21 @@ def dirichlet_nd_main():
 
 if __name__ == '__main__' and os.environ.get('GOLDEN_DND', '0') == '1':
     dirichlet_nd_main()
+
+
+def nsweeps2_main():
+    """lock-step multi-step SDC with TWO sweeps per iteration (level_params nsweeps=2): between the sweeps of an iteration
+    it_fine sends again (controller_MPI.py:736-768) - the setting in which a send left in flight must not meet an early
+    rewrite of the end value (controller_dist: side-stream posting only with one sweep per iteration)."""
+    RR = dict(quad_type='RADAU-RIGHT')
+    h2 = dict(nvars=(16, 16), nu=0.1, freq=2, bc='periodic')
+    sw = dict(num_nodes=3, QI='LU', **RR)
+    cases = [run_case('fixedK_2d_P3_nsweeps2', 'heat_unforced', h2, 'generic_implicit', sw, dict(dt=0.02, restol=-1, nsweeps=2),
+                      3, 0.0, 0.12, num_procs=3, seed=6),
+             run_case('fixedK_2d_P2_nsweeps2', 'heat_unforced', h2, 'generic_implicit', sw, dict(dt=0.02, restol=-1, nsweeps=2),
+                      3, 0.0, 0.08, num_procs=2, seed=7)]
+    save('runs_nsweeps2.npz', cases)
+
+
+if __name__ == '__main__' and os.environ.get('GOLDEN_NSW2', '0') == '1':
+    nsweeps2_main()

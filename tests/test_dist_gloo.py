@@ -120,3 +120,19 @@ def test_eight_ranks_lockstep(name):
     for k in range(world):
         assert rel_err(r[k]['uend'], case['uend']) < 1e-13
         assert int(r[k]['two_hop']) > 0 and int(r[k]['bcast']) > 0
+
+
+@pytest.mark.parametrize('name,world', [('fixedK_2d_P3_nsweeps2', 3), ('fixedK_2d_P2_nsweeps2', 2)])
+def test_two_sweeps_per_iteration(name, world):
+    """level_params nsweeps=2 in a lock-step run: it_fine exchanges between the two sweeps of an iteration as well
+    (controller_MPI.py:736-768); golden serial runs of the reference."""
+    case = load_cases('runs_nsweeps2.npz')[name]
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(world, _free_port(), name, d, 'runs_nsweeps2.npz', '1'), nprocs=world, join=True)
+        r = [np.load(os.path.join(d, f'r{k}.npz')) for k in range(world)]
+    times = np.concatenate([x['t'] for x in r])
+    niter = np.concatenate([x['n'] for x in r])
+    order = np.argsort(times)
+    assert list(niter[order]) == list(case['niter'])
+    for k in range(world):
+        assert rel_err(r[k]['uend'], case['uend']) < 1e-13

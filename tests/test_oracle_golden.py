@@ -57,6 +57,7 @@ def test_sweep_case(fname, name):
 RUN_CASES = ([('runs.npz', n) for n in load_cases('runs.npz')] + [('runs_dirichlet.npz', n) for n in load_cases('runs_dirichlet.npz')]
              + [('runs_dirichlet_nd.npz', n) for n in load_cases('runs_dirichlet_nd.npz')]
              + [('runs_skip.npz', n) for n in load_cases('runs_skip.npz')]
+             + [('runs_nsweeps2.npz', n) for n in load_cases('runs_nsweeps2.npz')]
              + [('runs_relay8.npz', n) for n in load_cases('runs_relay8.npz') if 'alltodone' not in n])  # (run_sdc has no all_to_done)   # skip_residual_computation (core/sweeper.py:176-179)
 
 
