@@ -86,6 +86,11 @@ void* sdc_slot_ptr(sdc_ctx* ctx, int slot, int m, int comp);
  * value alternates between two buffers from step to step (sdc_advance), so the address is only good until the next
  * sdc_advance; writers must report through sdc_invalidate_spectra(ctx, 8). */
 void* sdc_uend_address(sdc_ctx* ctx);
+/* NOTE: while sweeps stay in Fourier space sdc_end_point may put the inverse transform of the last node off until the
+ * end value is read (sdc_slot_ptr / sdc_download / sdc_stream_wait_uend / sdc_materialize(ctx, SDC_SLOT_UEND, 0) do it); a
+ * reader that holds the plain address calls sdc_materialize(ctx, SDC_SLOT_UEND, 0) first.  sdc_advance then hands the
+ * spectrum over without ever producing the field, and the predictor's residual takes max |f(u0)| from the norm-only
+ * inverse transform of symbol x spectrum. */
 int sdc_upload(sdc_ctx* ctx, int slot, int m, int comp, const double* host);
 int sdc_download(sdc_ctx* ctx, int slot, int m, int comp, double* host);
 int sdc_set_tau_active(sdc_ctx* ctx, int active); /* L.tau[m] is None  <->  0 */

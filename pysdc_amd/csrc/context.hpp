@@ -48,6 +48,11 @@ struct sdc_ctx {
     // somebody needs it THERE (ensure_u0); read-only consumers take it where it lies (u0r).
     double* UEND2 = nullptr;
     const double* u0_src = nullptr;
+    // One step further: while sweeps stay in Fourier space the end value is not even transformed back until somebody reads
+    // it (uend_pending: UEND = inverse transform of SL, valid while uend_gen == spec_gen), and after sdc_advance the start
+    // value of the new step may exist as its spectrum S0 only (u0_spec_only) - the predictor's residual then takes
+    // max |f(u0)| from the norm-only inverse transform of symbol * S0 instead of a stencil pass over u0.
+    bool uend_pending = false, u0_spec_only = false;
     bool spec_valid = false, spec0_valid = false, spec_spread = false, reuse = true, force_gather = false;
     cd *tw = nullptr, *lamI = nullptr, *lamE = nullptr;
     bool sym_real[2] = {false, false};  // the stencil is symmetric: its Fourier symbol is real (imaginary parts stored as 0)

@@ -415,7 +415,8 @@ __global__ __launch_bounds__(z_lines_per_block<N>() * (N / fft_elems(N)) * MAXM,
 template <int N, int DIR>
 __global__ __launch_bounds__(z_lines_per_block<N>() * (N / fft_elems(N)) * MAXM, 4) void k_fftz_plain(
     const cd* __restrict__ src, cd* __restrict__ dst, size_t fstride, const cd* __restrict__ tw, unsigned nlines,
-    double scale, const cd* __restrict__ src_one = nullptr, int one = -1) {
+    double scale, const cd* __restrict__ src_one = nullptr, int one = -1, const cd* __restrict__ lamI = nullptr,
+    const cd* __restrict__ lamE = nullptr, int ndim = 0) {
     constexpr int E = fft_elems(N), P = N / E, LPB = z_lines_per_block<N>();
     using LAY = LayContig<N>;
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -432,6 +433,26 @@ __global__ __launch_bounds__(z_lines_per_block<N>() * (N / fft_elems(N)) * MAXM,
     if (scale != 1.0) {
 #pragma unroll
         for (int i = 0; i < E; ++i) r[i] = cscale(r[i], scale);
+    }
+    if (lamI) {
+        // operator applied in Fourier space before the inverse pass: multiply mode (kx, ky, kz) by the sum of the 1-D
+        // symbols of the implicit (and explicit) stencils - the spectrum of f(u) for the linear right-hand sides
+        cd sxy = cd{0.0, 0.0};
+        if (ndim == 3) {
+            const int kx = (int)(line / N), ky = (int)(line % N);
+            sxy = cadd(lamI[kx], lamI[ky]);
+            if (lamE) sxy = cadd(sxy, cadd(lamE[kx], lamE[ky]));
+        } else if (ndim == 2) {
+            sxy = lamI[line];
+            if (lamE) sxy = cadd(sxy, lamE[line]);
+        }
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            const int kz = j + i * P;
+            cd sym = cadd(sxy, lamI[kz]);
+            if (lamE) sym = cadd(sym, lamE[kz]);
+            r[i] = ok ? cmul(r[i], sym) : r[i];
+        }
     }
     fft_line<N, DIR, LAY, (N / fft_elems(N)) <= 64>(r, j, c, lds, tw);
     if (ok) {

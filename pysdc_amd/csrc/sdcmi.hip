@@ -44,8 +44,12 @@ static inline int grid_for(size_t work, int block) {
 }
 
 // the start value where it lies (read-only consumers) / brought home to the U[0] slab (everybody else)
-static inline const double* u0r(sdc_ctx* c) { return c->u0_src ? c->u0_src : c->U; }
+static int spectrum_to_field(sdc_ctx* c, const cd* src, double* out);  // inverse transform of ONE cached spectrum
 static int ensure_u0(sdc_ctx* c) {
+    if (c->u0_spec_only) {  // the start value exists as its transform only (sdc_advance after a deferred end value)
+        c->u0_spec_only = false;
+        return spectrum_to_field(c, c->S0, c->U);
+    }
     if (c->u0_src) {
         const double* src = c->u0_src;
         c->u0_src = nullptr;
@@ -53,10 +57,26 @@ static int ensure_u0(sdc_ctx* c) {
     }
     return SDC_OK;
 }
+static inline const double* u0r(sdc_ctx* c) {
+    if (c->u0_spec_only) (void)ensure_u0(c);  // (a failure here is a HIP failure the very next launch reports)
+    return c->u0_src ? c->u0_src : c->U;
+}
 #define ENSURE_U0(c)                       \
     do {                                   \
         int rcu_ = ensure_u0(c);           \
         if (rcu_ != SDC_OK) return rcu_;   \
+    } while (0)
+// the end value for real: transform the last node's spectrum now if that was put off (sdc_end_point)
+static int materialize_uend(sdc_ctx* c) {
+    if (!c->uend_pending) return SDC_OK;
+    c->uend_pending = false;
+    if (!(c->uend_gen >= 0 && c->uend_gen == c->spec_gen)) return SDC_OK;  // (its spectrum is gone: nothing to deliver)
+    return spectrum_to_field(c, c->SL, c->UEND);
+}
+#define MATERIALIZE_UEND(c)                \
+    do {                                   \
+        int rcv_ = materialize_uend(c);    \
+        if (rcv_ != SDC_OK) return rcv_;   \
     } while (0)
 
 static double* slot_ptr(sdc_ctx* c, int slot, int m, int comp) {
@@ -626,6 +646,45 @@ static int inverse_from_cache(sdc_ctx* c, int first, int nf, const FieldPtrs& p)
 #undef CALL
 }
 
+static int spectrum_to_field(sdc_ctx* c, const cd* src, double* out) {
+    int rw = ensure_work(c);
+    if (rw != SDC_OK) return rw;
+    FieldPtrs p;
+    memset(&p, 0, sizeof p);
+    p.out[0] = out;
+    const double invN = 1.0 / (double)c->N;
+#define CALL(NN) inverse_passes_n<NN>(c, 1, src, c->W, p, nullptr, invN)
+    N_DISPATCH(c, CALL)
+#undef CALL
+}
+
+// max |f(u)| of the field whose transform is src, for right-hand sides that are linear with a stencil symbol: norm-only
+// inverse transform of (symbol * src) - three passes over ONE spectrum, nothing stored in real space
+template <int N>
+static int symbol_norm_n(sdc_ctx* c, const cd* src, unsigned long long* slot) {
+    constexpr int P = N / fft_elems(N), LPB = z_lines_per_block<N>();
+    const int n = c->n;
+    const size_t lines = (size_t)(n / 2 + 1) * (c->ndim == 3 ? n : 1);
+    {
+        LaunchTimer lt(c, pname("fft_z_sym", 1));
+        const size_t ldsz = (size_t)LayContig<N>::doubles(LPB) * sizeof(double);
+        hipLaunchKernelGGL((k_fftz_plain<N, +1>), dim3((unsigned)((lines + LPB - 1) / LPB)), dim3(P * LPB), ldsz, c->stream, src,
+                           c->W, c->Nc, c->tw, (unsigned)lines, 1.0 / (double)c->N, (const cd*)nullptr, -1, c->lamI,
+                           c->expl_kind == SDC_EXPL_STENCIL ? c->lamE : (const cd*)nullptr, c->ndim);
+    }
+    HIPCHK(c, hipGetLastError());
+    FieldPtrs p;
+    memset(&p, 0, sizeof p);
+    return inverse_tail_n<N>(c, 1, c->W, p, slot);
+}
+static int symbol_norm(sdc_ctx* c, const cd* src, unsigned long long* slot) {
+    int rw = ensure_work(c);
+    if (rw != SDC_OK) return rw;
+#define CALL(NN) symbol_norm_n<NN>(c, src, slot)
+    N_DISPATCH(c, CALL)
+#undef CALL
+}
+
 // (I - alpha_f A) out_f = in_f + sum_{j<f} (cI[f][j] A + cE[f][j] B) out_j for f = 0..nf-1
 static int fft_pipeline(sdc_ctx* c, int nf, const FieldPtrs& p, ZArgs& z) {
     if (!c->have_stencil[0]) return fail(c, SDC_ERR_STATE, "implicit operator not set (sdc_set_stencil)");
@@ -1089,6 +1148,8 @@ static int materialize(sdc_ctx* c, bool need_u, bool need_f) {
 
 int sdc_materialize(sdc_ctx* c, int slot, int m) {
     if (!c) return SDC_ERR_PARAM;
+    if (slot == SDC_SLOT_UEND) return materialize_uend(c);  // (readers of the end value: views, sends)
+    if (slot < 0) MATERIALIZE_UEND(c);
     if (slot == SDC_SLOT_U && m == 0) {
         // whoever gets the address of U[0] may read or overwrite it: the start value has to BE there, and a pending
         // spread and a pending F[0] = f(U[0]) refer to the value it holds NOW
@@ -1139,6 +1200,7 @@ void* sdc_slot_ptr(sdc_ctx* c, int slot, int m, int comp) {
     if ((slot == SDC_SLOT_U || slot == SDC_SLOT_F) && sdc_materialize(c, slot, m) != SDC_OK) return nullptr;
     if (slot == SDC_SLOT_TAU && ensure_tau(c) != SDC_OK) return nullptr;
     if (slot == SDC_SLOT_UEND) {
+        if (materialize_uend(c) != SDC_OK) return nullptr;
         c->uend_gen = -1;  // the holder may write it
         if (uend_write_fence(c) != SDC_OK) return nullptr;
     }
@@ -1164,7 +1226,10 @@ int sdc_invalidate_spectra(sdc_ctx* c, int which) {
         c->force_gather = true;
     }
     if (which & 4) c->force_gather = true;  // some F[m >= 1] no longer equals f(U[m]): gather on F itself
-    if (which & 8) c->uend_gen = -1;        // UEND was overwritten
+    if (which & 8) {  // UEND was overwritten
+        c->uend_gen = -1;
+        c->uend_pending = false;
+    }
     return SDC_OK;
 }
 
@@ -1294,7 +1359,12 @@ int sdc_predict(sdc_ctx* c, double t, double dt, int guess, double fill_u, doubl
                             c->have_stencil[0] && three(c->st[0]) &&
                             (c->expl_kind == SDC_EXPL_NONE || (explS && c->have_stencil[1] && three(c->st[1])));
     int rc = SDC_OK;
-    if (f0_by_norm) {
+    if (f0_by_norm && c->u0_spec_only && c->spec0_valid && c->S0 && c->expl_kind != SDC_EXPL_FORCING) {
+        // the start value exists as its transform only: max |f(u0)| from the norm-only inverse transform of symbol * S0
+        rc = symbol_norm(c, c->S0, c->res_dev + 7);
+        if (rc != SDC_OK) return rc;
+        c->f0_pending = true;
+    } else if (f0_by_norm) {
         constexpr int RPT = 4;
         Stencil3Args s3;
         memset(&s3, 0, sizeof s3);
@@ -1511,6 +1581,7 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
     }
     if (c->expl_kind == SDC_EXPL_STENCIL && !c->have_stencil[1])
         return fail(c, SDC_ERR_STATE, "explicit operator not set (sdc_set_stencil which=1)");
+    MATERIALIZE_UEND(c);  // (a put-off end value belongs to the iterate this sweep is about to replace)
     {
         // only a sweep that stays in Fourier space and stores nothing in real space leaves the start value where it
         // lies (u0_src); every other data flow reads the U[0] slab
@@ -1894,8 +1965,16 @@ int sdc_end_point(sdc_ctx* c, double dt, int do_coll_update) {
     }
     if (!do_coll_update) {
         c->uend_gen = -1;
-        if (c->u_pending && !c->spread_pending) {  // only the last node is needed: transform it straight into UEND
-            FieldPtrs p;
+        c->uend_pending = false;
+        if (c->u_pending && !c->spread_pending) {  // only the last node is needed
+            if (c->deferred && c->kind == 0 && !c->early_uend && !c->keep_rfields && c->ndim >= 2) {
+                // ... and not even that until somebody reads it: the end value IS the inverse transform of SL
+                // (materialize_uend); a following sdc_advance hands the spectrum over and never needs it in real space
+                c->uend_pending = true;
+                c->uend_gen = c->spec_gen;
+                return SDC_OK;
+            }
+            FieldPtrs p;  // transform it straight into UEND
             memset(&p, 0, sizeof p);
             p.out[0] = c->UEND;
             int rci = inverse_from_cache(c, c->M - 1, 1, p);
@@ -1906,6 +1985,7 @@ int sdc_end_point(sdc_ctx* c, double dt, int do_coll_update) {
         return sdc_vec_copy(c, c->N, c->spread_pending ? u0r(c) : c->U + (size_t)c->M * c->N, c->UEND);
     }
     c->uend_gen = -1;
+    c->uend_pending = false;
     ENSURE_U0(c);
     int rcm = materialize(c, false, true);
     if (rcm != SDC_OK) return rcm;
@@ -1929,6 +2009,19 @@ int sdc_advance(sdc_ctx* c) {
     c->spec_spread = false;
     // UEND is the inverse transform of the last node's spectrum: that spectrum is the transform of the new u[0]
     const bool handover = c->S && c->spec_valid && c->uend_gen >= 0 && c->uend_gen == c->spec_gen;
+    if (handover && c->uend_pending && c->kind == 0 && c->deferred) {
+        // the end value was never transformed back: the start value of the new step exists as its transform only
+        std::swap(c->S0, c->SL);
+        c->spec0_valid = true;
+        c->spec_valid = false;
+        c->u_pending = c->f_pending = c->rfields_valid = false;
+        c->uend_pending = false;
+        c->uend_gen = -1;
+        c->u0_src = nullptr;
+        c->u0_spec_only = true;
+        return SDC_OK;
+    }
+    MATERIALIZE_UEND(c);
     if (handover && c->kind == 0 && c->deferred) {
         // Fourier-space data flow: nothing is copied.  The spectrum of the last node and the spectrum of u[0] trade
         // places (the first sweep after the predictor rewrites every node spectrum), the end-value buffer becomes the
@@ -1949,6 +2042,7 @@ int sdc_advance(sdc_ctx* c) {
         return SDC_OK;
     }
     c->u0_src = nullptr;  // U[0] is overwritten as a whole
+    c->u0_spec_only = false;
     HIPCHK(c, hipMemcpyAsync(c->U, c->UEND, c->N * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     if (handover) {
         HIPCHK(c, hipMemcpyAsync(c->S0, c->SL, sizeof(cd) * c->Nc, hipMemcpyDeviceToDevice, c->stream));
@@ -1967,6 +2061,7 @@ int sdc_set_early_end_point(sdc_ctx* c, int on) {
 
 int sdc_stream_wait_uend(sdc_ctx* c, void* other_stream) {
     if (!c) return SDC_ERR_PARAM;
+    MATERIALIZE_UEND(c);
     if (!c->uend_ev) HIPCHK(c, hipEventCreateWithFlags(&c->uend_ev, hipEventDisableTiming));
     if (!(c->uend_ev_recorded && c->uend_gen >= 0 && c->uend_gen == c->spec_gen)) {
         // UEND was written by the latest work on the engine's stream (sdc_end_point): everything so far

@@ -163,8 +163,10 @@ class DeviceBacked:
         e = self.engine
         addr = e.uend_address() + 8 * self._view_offset()
         if self._uend_view is None or self._uend_view._p != addr:
+            # (the engine may not have transformed the end value back yet: reading through the view makes it do so)
             self._uend_view = hip_mesh.view(addr, self._field_shape(), keep=e,
-                                            on_write=lambda: self._touched(Lb.SLOT_UEND, 0))
+                                            on_write=lambda: self._touched(Lb.SLOT_UEND, 0),
+                                            on_access=lambda: e.materialize(Lb.SLOT_UEND, 0))
         return self._uend_view
 
     def _field_shape(self):
