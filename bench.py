@@ -47,6 +47,7 @@ def _kernel_bytes(name, n, M, ncomp=1):
         'spec_z_resid': (1 + nf) * spec + nf * spec,        # residual spectrum of the cached iterate, no update
         'replace_u0': (3 + nf) * field,                 # new + old u0 in, u0 out, M residual fields in                        # half spectra in, max norms out
         'fft_z_inv': 2 * nf * spec,
+        'fft_z_sym': 2 * nf * spec,                     # the same pass with the operator symbol multiplied in
         'fft_y_inv': 2 * nf * spec,
         'fft_x_inv': nf * (field + spec),
         'stencil': 2 * nf * field if ncomp == 1 else 3 * nf * field,  # IMEX: one read, impl + expl written

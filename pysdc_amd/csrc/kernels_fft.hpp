@@ -412,7 +412,9 @@ __global__ __launch_bounds__(z_lines_per_block<N>() * (N / fft_elems(N)) * MAXM,
 
 // plain transform along the contiguous axis, src -> dst (may alias), optionally scaled: forward to bring u0 /
 // node values into the fully transformed domain of the spectral cache, inverse after the spectral sweep
-template <int N, int DIR>
+// SYM: the operator symbol (lamI [+ lamE]) is multiplied in before the transform (own instantiation: the plain pass keeps
+// its code)
+template <int N, int DIR, bool SYM = false>
 __global__ __launch_bounds__(z_lines_per_block<N>() * (N / fft_elems(N)) * MAXM, 4) void k_fftz_plain(
     const cd* __restrict__ src, cd* __restrict__ dst, size_t fstride, const cd* __restrict__ tw, unsigned nlines,
     double scale, const cd* __restrict__ src_one = nullptr, int one = -1, const cd* __restrict__ lamI = nullptr,
@@ -434,7 +436,7 @@ __global__ __launch_bounds__(z_lines_per_block<N>() * (N / fft_elems(N)) * MAXM,
 #pragma unroll
         for (int i = 0; i < E; ++i) r[i] = cscale(r[i], scale);
     }
-    if (lamI) {
+    if constexpr (SYM) {
         // operator applied in Fourier space before the inverse pass: multiply mode (kx, ky, kz) by the sum of the 1-D
         // symbols of the implicit (and explicit) stencils - the spectrum of f(u) for the linear right-hand sides
         cd sxy = cd{0.0, 0.0};

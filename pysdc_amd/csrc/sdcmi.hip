@@ -668,7 +668,7 @@ static int symbol_norm_n(sdc_ctx* c, const cd* src, unsigned long long* slot) {
     {
         LaunchTimer lt(c, pname("fft_z_sym", 1));
         const size_t ldsz = (size_t)LayContig<N>::doubles(LPB) * sizeof(double);
-        hipLaunchKernelGGL((k_fftz_plain<N, +1>), dim3((unsigned)((lines + LPB - 1) / LPB)), dim3(P * LPB), ldsz, c->stream, src,
+        hipLaunchKernelGGL((k_fftz_plain<N, +1, true>), dim3((unsigned)((lines + LPB - 1) / LPB)), dim3(P * LPB), ldsz, c->stream, src,
                            c->W, c->Nc, c->tw, (unsigned)lines, 1.0 / (double)c->N, (const cd*)nullptr, -1, c->lamI,
                            c->expl_kind == SDC_EXPL_STENCIL ? c->lamE : (const cd*)nullptr, c->ndim);
     }

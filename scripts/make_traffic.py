@@ -32,7 +32,8 @@ NAMES = [(r'k_spec_z<\d+, \d+, 1, \d+>', 'spec_z_res'), (r'k_spec_z<\d+, \d+, 0,
          (r'k_ffty<\d+, \d+, 1>', 'fft_y_inv'), (r'k_ffty<\d+, \d+, -1>', 'fft_y_fwd'),
          (r'k_fftx_inv<\d+, \d+, true, false>', 'fft_x_norm'), (r'k_fftx_norm_half', 'fft_x_norm'),
          (r'k_fftx_inv<\d+, \d+, false, true>', 'fft_x_inv'), (r'k_fftx_inv<\d+, \d+, true, true>', 'fft_x_inv_norm'),
-         (r'k_fftx_fwd', 'fft_x_fwd'), (r'k_fftz_plain<\d+, 1>', 'fft_z_inv'), (r'k_fftz_plain<\d+, -1>', 'fft_z_fwd'),
+         (r'k_fftx_fwd', 'fft_x_fwd'), (r'k_fftz_plain<\d+, 1, true>', 'fft_z_sym'), (r'k_fftz_plain<\d+, 1(, false)?>', 'fft_z_inv'),
+         (r'k_fftz_plain<\d+, -1(, false)?>', 'fft_z_fwd'),
          (r'k_stencil3d<4>', 'stencil_max'), (r'k_stencil3d_res', 'stencil_res'), (r'k_spec_point', 'spec_point')]
 traffic = {}
 for kname in set(fetch) | set(write):
