@@ -18,7 +18,7 @@ import os
 import numpy as np
 
 from pysdc_amd.errors import CommunicationError, ControllerError, ParameterError
-from pysdc_amd.hooks import CPUTimings, DefaultHooks, Hooks
+from pysdc_amd.hooks import CPUTimings, DefaultHooks
 from pysdc_amd.level import Step
 
 

@@ -5,7 +5,6 @@ host logic drives device levels (``pysdc_amd.level.Level``) and, in the CPU test
 ``mesh_to_mesh`` is the device version of pySDC/implementations/transfer_classes/TransferMesh.py:9-218 for
 periodic, equidistant, nested grids (coarsening factor 2 per axis): the interpolation matrices of
 pySDC/helpers/transfer_helper.py:153-186 are applied matrix-free by ``sdc_transfer_prolong / _restrict``."""
-import ctypes as C
 import logging
 
 import numpy as np
