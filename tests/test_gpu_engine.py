@@ -174,3 +174,35 @@ def test_residual_propagates_nan_like_np_max(where):
         assert np.isnan(res) and np.all(np.isnan(norms))
     assert any(k.startswith('fft_x_norm') for k in e.profile_read())
     e.close()
+
+
+@pytest.mark.parametrize('fname,name', [('sweeps_heat.npz', 'heat3d_o2_M5_IE_dt0.1'), ('sweeps_heat.npz', 'heat2d_o4_M3_IE_dt0.001'),
+                                        ('sweeps_imex.npz', 'advdiff3d_M5'), ('sweeps_imex.npz', 'forced2d_M3')])
+def test_integrate_vs_golden_node_values(fname, name):
+    """Sweeper.integrate (generic_implicit.py:29-49 / imex_1st_order.py:37-55): dt * sum_j Qmat[m+1, j] * f[j], accumulated
+    left to right - from the reference's own f values at the nodes (golden), after the predictor and after every sweep."""
+    import torch
+
+    case = load_cases(fname)[name]
+    meta = case['meta']
+    M = len(case['coll_nodes'])
+    dt, t0 = meta['dt'], meta['t0']
+    e = G.engine_for(meta['prob'], meta['prob_params'], M)
+    G.set_case_coeffs(e, case)
+    G.set_forcing_times(e, meta, t0, dt, case['coll_nodes'])
+    e.upload(L.SLOT_U, 0, case['u0'])
+    e.predict(t0, dt, 'spread')
+    out = torch.empty(M * e.N, dtype=torch.float64, device='cuda')
+    for k in range(0, meta['nsweeps'] + 1):
+        if k:
+            e.sweep(t0, dt)
+        e.integrate(dt, [out.data_ptr() + 8 * m * e.N for m in range(M)])
+        got = out.cpu().numpy().reshape((M,) + e.nvars)
+        f = case[f'k{k}_f']
+        fsum = f if f.ndim == got.ndim else f[:, 0] + f[:, 1]          # IMEX: impl + expl
+        for m in range(M):
+            ref = np.zeros(e.nvars)
+            for j in range(1, M + 1):
+                ref += dt * case['coll_Qmat'][m + 1, j] * fsum[j]
+            assert rel_err(got[m], ref) < TOL, (k, m)
+    e.close()
