@@ -130,6 +130,20 @@ def test_literal_tableaux():
     np.testing.assert_allclose(qd(c, 'LU'), [[5 / 12, 0], [3 / 4, 2 / 5]], **tol)  # U^T of Q^T = L U
     np.testing.assert_allclose(qd(c, 'IE'), [[1 / 3, 0], [1 / 3, 2 / 3]], **tol)
     np.testing.assert_allclose(qd(c, 'IEpar'), [[1 / 3, 0], [0, 1]], **tol)
+    np.testing.assert_allclose(qd(c, 'MIN-SR-NS'), [[1 / 6, 0], [0, 1 / 2]], **tol)          # nodes / M
+    np.testing.assert_allclose(qd(c, 'Qpar'), [[5 / 12, 0], [0, 1 / 4]], **tol)              # diagonal of Q
+    np.testing.assert_allclose(qd(c, 'PIC'), [[0, 0], [0, 0]], **tol)
+    EE, dtau = QDELTA_GENERATORS['EE'](qGen=c.generator, tLeft=0).genCoeffs(dTau=True)
+    np.testing.assert_allclose(EE, [[0, 0], [2 / 3, 0]], **tol)                              # strictly lower: node spacings
+    np.testing.assert_allclose(dtau, [1 / 3, 1 / 3], **tol)                                  # first node - left end
+    # LU of the three-node Radau IIA matrix, by hand: Q^T = L U, QDelta = U^T (entries from the closed-form tableau)
+    c3 = CollBase(3, 0, 1, 'LEGENDRE', 'RADAU-RIGHT')
+    A = c3.Qmat[1:, 1:]
+    U = np.array(A.T)
+    for i in range(3):
+        for r in range(i + 1, 3):
+            U[r] -= U[r, i] / U[i, i] * U[i]
+    np.testing.assert_allclose(qd(c3, 'LU'), np.triu(U).T, rtol=0, atol=1e-15)
     c = CollBase(2, 0, 1, 'LEGENDRE', 'GAUSS')
     np.testing.assert_allclose(c.nodes, [1 / 2 - s3 / 6, 1 / 2 + s3 / 6], **tol)
     np.testing.assert_allclose(c.Qmat[1:, 1:], [[1 / 4, 1 / 4 - s3 / 6], [1 / 4 + s3 / 6, 1 / 4]], **tol)
