@@ -400,6 +400,9 @@ def extras(args):
     plan = [('heat 1024^3, every sweep stores U and F like the reference\'s update_nodes (--eager-fields)',
              dict(eager_fields=True, steps=3, warmup=1)),
             ('heat 1024^3, iterate to restol 1e-10 (maxiter 50)', dict(restol=1e-10, steps=2, warmup=1)),
+            ('heat 1024^3, diagonal QDelta MIN-SR-S (node-parallel preconditioner; SURVEY 8d)', dict(qi='MIN-SR-S', steps=3, warmup=1)),
+            ("heat 256^3 with the reference's CG (rtol 1e-12) on the device instead of the exact Fourier solve",
+             dict(n=256, solver_type='CG', steps=2, warmup=1)),
             ('BASELINE config 2: heat 512^3', dict(n=512, steps=10, warmup=2)),
             ('BASELINE config 3: advection-diffusion IMEX 512^3', dict(workload='advdiff', n=512, steps=10, warmup=2)),
             ('BASELINE config 4: van der Pol, 1e7 trajectories', dict(workload='vdp', steps=10, warmup=2)),
