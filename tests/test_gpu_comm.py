@@ -95,7 +95,11 @@ def test_two_ranks_over_xgmi():
     procs = [ctx.Process(target=_two_rank_worker, args=(r, 29611, out)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted(out.get(timeout=300) for _ in range(2))
-    for p in procs:
-        p.join(60)
+    try:
+        res = sorted(out.get(timeout=180) for _ in range(2))
+    finally:
+        for p in procs:
+            p.join(30)
+            if p.is_alive():   # never leave a rank behind that may hold the GPUs
+                p.kill()
     assert res == [(0, 0.0, 2.0), (1, 1.0, 2.0)]
