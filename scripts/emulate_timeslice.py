@@ -62,6 +62,7 @@ for keep in ('overlap', True, False):
         else:
             e.residual(dt)                  # IT_FINE
             e.end_point(dt, False)          # what is sent
+            e.materialize(L.SLOT_UEND, 0)   # (a raw pointer is read below: the end value has to be there for real)
             for _ in range(copies):
                 inbox.copy_(uend)
         e.replace_u0(inbox.data_ptr())      # what arrives
