@@ -86,6 +86,9 @@ void* sdc_slot_ptr(sdc_ctx* ctx, int slot, int m, int comp);
  * value alternates between two buffers from step to step (sdc_advance), so the address is only good until the next
  * sdc_advance; writers must report through sdc_invalidate_spectra(ctx, 8). */
 void* sdc_uend_address(sdc_ctx* ctx);
+/* > 0 while the end value still is the last node of the cached iterate (sdc_advance could hand it over without copies);
+ * a new value after every sweep; -1 otherwise. */
+long long sdc_end_value_generation(sdc_ctx* ctx);
 /* NOTE: while sweeps stay in Fourier space sdc_end_point may put the inverse transform of the last node off until the
  * end value is read (sdc_slot_ptr / sdc_download / sdc_stream_wait_uend / sdc_materialize(ctx, SDC_SLOT_UEND, 0) do it); a
  * reader that holds the plain address calls sdc_materialize(ctx, SDC_SLOT_UEND, 0) first.  sdc_advance then hands the

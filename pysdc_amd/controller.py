@@ -99,7 +99,16 @@ class controller_nonMPI(_ControllerBase):
         if not any(active):
             raise ControllerError('Nothing to do, check t0, dt and Tend.')
         active_slots = list(itertools.compress(slots, active))
-        self.restart_block(active_slots, time, u0)
+        # u0 is the untouched object the previous run() on this controller returned, and the level's engine still holds
+        # exactly that state: the new run continues like the next block of the old one (Level.advance: no copy of u0 in,
+        # no transform of it)
+        L0 = self.MS[0].levels[0]
+        lineage = getattr(u0, '_lineage', None)
+        if (num_procs == 1 and lineage is not None and hasattr(L0, 'advance') and getattr(L0, '_engine_obj', None) is not None
+                and lineage == (id(L0._engine_obj), L0._engine_obj.end_value_generation())):
+            self.restart_block(active_slots, time, None)
+        else:
+            self.restart_block(active_slots, time, u0)
         for hook in self.hooks:
             hook.post_setup(step=None, level_number=None)
         for S in self.MS:
@@ -134,7 +143,13 @@ class controller_nonMPI(_ControllerBase):
         # a fresh object per run, like the reference (controller_nonMPI.py:148,167): neither the persistent buffer nor a
         # view into a level's UEND slab leaves the controller (one copy per run, not per block)
         P = self.MS[0].levels[0].prob
-        return P.dtype_u(uend), self.return_stats()
+        out = P.dtype_u(uend)
+        eng = getattr(self.MS[-1].levels[0], '_engine_obj', None) if num_procs == 1 else None
+        if eng is not None and hasattr(eng, 'end_value_generation'):
+            gen = eng.end_value_generation()
+            if gen > 0:
+                out._lineage = (id(eng), gen)   # (cleared by any write to `out`: hip_mesh._wrote)
+        return out, self.return_stats()
 
     # controller_nonMPI.py:169-224
     def restart_block(self, active_slots, time, u0):

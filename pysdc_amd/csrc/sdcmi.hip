@@ -1194,6 +1194,14 @@ int sdc_defer_f0(sdc_ctx* c) {
 
 void* sdc_uend_address(sdc_ctx* c) { return c ? (void*)c->UEND : nullptr; }
 
+long long sdc_end_value_generation(sdc_ctx* c) {
+    // > 0 while the end value (UEND, or its put-off transform) still IS the last node of the cached iterate, i.e. while
+    // sdc_advance could hand it over; changes with every sweep.  A caller that gave a COPY of the end value away can tell
+    // later whether the engine still holds exactly that state (pysdc_amd/controller.py: consecutive run() calls).
+    if (!c || !c->S || !c->spec_valid || c->uend_gen < 0 || c->uend_gen != c->spec_gen) return -1;
+    return c->spec_gen + 1;
+}
+
 void* sdc_slot_ptr(sdc_ctx* c, int slot, int m, int comp) {
     if (!c) return nullptr;
     // whoever asks for the address of a node field is about to read or write it

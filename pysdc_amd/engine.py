@@ -142,6 +142,10 @@ class SweepEngine:
         """where the end value lies right now (include/sdcmi.h: sdc_uend_address; changes with every advance())"""
         return self.lib.sdc_uend_address(self.ctx)
 
+    def end_value_generation(self):
+        """> 0 while the end value still is the last node of the cached iterate (include/sdcmi.h)"""
+        return int(self.lib.sdc_end_value_generation(self.ctx))
+
     def upload(self, slot, m, host, comp=0):
         h = np.ascontiguousarray(host, dtype=np.float64).reshape(-1)
         if h.size != self.N:

@@ -53,6 +53,8 @@ class hip_mesh:
     xp = None
     __array_priority__ = 1000  # ndarray * hip_mesh -> hip_mesh.__rmul__
 
+    _lineage = None  # (engine, generation) of the end value this object is an unmodified copy of, or None
+
     def __init__(self, init=None, val=0.0, *, _ptr=None, _shape=None, _keep=None, _on_write=None, _on_access=None):
         self._buf = None
         self._keep = _keep
@@ -91,6 +93,7 @@ class hip_mesh:
     def ptr(self):
         if self._on_access is not None:
             self._on_access()
+        self._lineage = None  # the raw address leaves this object: it may be written behind our back
         return self._p
 
     @ptr.setter
@@ -102,6 +105,7 @@ class hip_mesh:
         return cls(_ptr=ptr, _shape=shape, _keep=keep, _on_write=on_write, _on_access=on_access)
 
     def _wrote(self):
+        self._lineage = None  # (no longer the value an engine handed out: see controller_nonMPI.run)
         if self._on_write is not None:
             self._on_write()
 
@@ -137,6 +141,7 @@ class hip_mesh:
 
     def as_torch(self):
         """torch tensor aliasing this buffer (for torch.distributed send/recv over RCCL)."""
+        self._lineage = None  # whoever holds the tensor may write through it
         if self._buf is not None:
             return self._buf
         torch = _torch()

@@ -35,6 +35,7 @@ PROTOTYPES = {
     'sdc_set_forcing_values': (C.c_int, [_vp, _dp]),
     'sdc_slot_ptr': (_vp, [_vp, C.c_int, C.c_int, C.c_int]),
     'sdc_uend_address': (_vp, [_vp]),
+    'sdc_end_value_generation': (C.c_longlong, [_vp]),
     'sdc_upload': (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _dp]),
     'sdc_download': (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _dp]),
     'sdc_set_tau_active': (C.c_int, [_vp, C.c_int]),

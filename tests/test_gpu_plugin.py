@@ -811,3 +811,43 @@ def test_consecutive_runs_return_independent_objects():
         assert not np.array_equal(u2.get(), snap)
         # the level's own end value is still readable after the run and equals what was returned
         assert np.array_equal(C.MS[-1 if procs == 2 else 0].levels[0].uend.get(), u2.get())
+
+
+def test_consecutive_runs_continue_without_reloading_the_start_value():
+    """u, _ = C.run(u, t, t + T) repeated: when u is the untouched object the previous run returned and the engine still
+    holds that state, the next run starts like the next block of the old one (no copy in, no forward transform) - same
+    numbers as one long run and as runs from a modified / foreign start value, which take the ordinary path."""
+    from pysdc_amd.controller import controller_nonMPI
+    from pysdc_amd.stats import get_sorted
+    from tests.test_gpu_plugin import description_from
+
+    case = load_cases('sweeps_big3d.npz')['cg64_heat3d_run_LU']
+    meta = dict(case['meta'])
+    meta['prob_params'] = {k: v for k, v in meta['prob_params'].items() if k != 'solver_type'}
+    dt = meta['level_params']['dt']
+    u0h = load_cases('sweeps_big3d.npz')['cg64_heat3d_M5_IE']['u0']
+
+    def fresh():
+        C = controller_nonMPI(1, dict(logger_level=40), description_from(meta))
+        u = C.MS[0].levels[0].prob.u_init
+        u[:] = u0h
+        return C, u
+
+    C, u = fresh()
+    ref, _ = C.run(u, 0.0, 4 * dt)                                  # one long run
+    C, u = fresh()
+    eng = C.MS[0].levels[0].engine
+    eng.profile_enable(True)
+    u, _ = C.run(u, 0.0, 2 * dt)
+    assert u._lineage is not None
+    fwd_before = eng.profile_read().get('fft_x_fwd[1]', (0, 0))[1]
+    u, st = C.run(u, 2 * dt, 4 * dt)                                # continues: no forward transform of the start value
+    assert eng.profile_read().get('fft_x_fwd[1]', (0, 0))[1] == fwd_before
+    assert np.array_equal(u.get(), ref.get())
+    # a start value that was touched takes the ordinary path and gives the same numbers
+    C, u = fresh()
+    u, _ = C.run(u, 0.0, 2 * dt)
+    u *= 1.0                                                        # (any write clears the lineage)
+    assert u._lineage is None
+    u, _ = C.run(u, 2 * dt, 4 * dt)
+    assert rel_err(u.get(), ref.get()) < 1e-13
