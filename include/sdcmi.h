@@ -113,6 +113,14 @@ int sdc_set_fused_residual(sdc_ctx* ctx, int on);
  * with on = 1 a sweep that gathers on the cached transforms then ONLY updates those transforms (one pointwise pass, no
  * inverse transform at all).  A residual asked for later is still answered, from the cache (sdc_residual). */
 int sdc_set_skip_residual(sdc_ctx* ctx, int on);
+/* Iterates that are not stored.  After a 'spread' predictor (core/sweeper.py:129-143: every node starts from u[0]) the
+ * iterate of a linear problem is a function of the transform of u[0] alone, and so is every later one while u[0] and the
+ * coefficients stay what they are (generic_implicit.py:51-103 applied to the same data again and again).  A sweep that
+ * stays in Fourier space then reads the transform of u[0] only, repeats the earlier sweeps of the step in registers and
+ * stores nothing but what the residual norm needs; whoever needs the iterate itself (node values, the end value, a new
+ * u[0], other coefficients) has it written out first.  max_sweeps: sweeps per step that may be repeated that way before
+ * the iterate is stored after all (arithmetic grows with each; default 8), 0: every sweep stores its iterate. */
+int sdc_set_virtual_sweeps(sdc_ctx* ctx, int max_sweeps);
 /* Deferred node fields (default on).  The spectral-reuse sweep reads neither F[1..M] nor the M copies a 'spread'
  * predictor makes (core/sweeper.py:140-146): the engine therefore leaves them unwritten until somebody needs
  * them.  sdc_slot_ptr / sdc_upload / sdc_download / sdc_integrate / sdc_end_point / sdc_residual and the

@@ -17,6 +17,11 @@
 // ------------------------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------------------------
+// coefficients of a sweep in the transformed domain (inner M x M blocks, scaled by dt; see SpecArgs)
+struct SpecCoef {
+    double gI[MAXM][MAXM], gE[MAXM][MAXM], cI[MAXM][MAXM], cE[MAXM][MAXM], alpha[MAXM];
+    int coupled, real_sym, has_e, pad_;
+};
 struct Stencil {
     int npts = 0;
     int off[MAXSTEN];
@@ -54,6 +59,12 @@ struct sdc_ctx {
     // max |f(u0)| from the norm-only inverse transform of symbol * S0 instead of a stencil pass over u0.
     bool uend_pending = false, u0_spec_only = false;
     bool spec_valid = false, spec0_valid = false, spec_spread = false, reuse = true, force_gather = false;
+    // Iterates that are not stored: spec_virtual > 0 (while spec_valid) = the cached iterate is the result of that many
+    // sweeps with the coefficients vcoef, started from "all nodes equal u0" - a function of S0 alone, recomputed by whoever
+    // needs it (store_spectra).  sl_stored: the last node's spectrum has been written to SL all the same.
+    int spec_virtual = 0, virt_max = 8;
+    bool sl_stored = false;
+    SpecCoef vcoef;
     cd *tw = nullptr, *lamI = nullptr, *lamE = nullptr;
     bool sym_real[2] = {false, false};  // the stencil is symmetric: its Fourier symbol is real (imaginary parts stored as 0)
     unsigned long long* red = nullptr;  // reduction slots (device)

@@ -489,6 +489,11 @@ struct SpecArgs {
     double invN;
     int nf, ndim, coupled, spread;
     int real_sym;  // the implicit symbol is real (symmetric stencil: heat): half the multiplications per node (wave-uniform branch)
+    // Iterates that are not stored (DESIGN.md "sweeps recomputed from the start value"): after a spread predictor every
+    // iterate of a linear problem is a function of the transform of u0 alone.  replay = number of earlier sweeps this
+    // launch repeats in registers (same coefficients) before it does its own; virt: the new spectra are not stored
+    // either; last_only: only the last node's spectrum is stored.
+    int replay, virt, last_only;
 };
 
 // one thread per Fourier mode: gather on the cached transforms + node-coupled solve, S updated in place.
@@ -506,6 +511,107 @@ DEVI cd node_divide(cd acc, cd lam, double al, int real_sym) {
         return cd{acc.x * inv, acc.y * inv};
     }
     return cmul(acc, cinv_fast(cd{1.0 - al * lam.x, -al * lam.y}));
+}
+
+// Iterates that are not stored.  From "all nodes equal u0" every iterate of a linear problem is u_m = g_m * u0 per mode,
+// with node multipliers g_m that depend on the symbols only: a sweep maps them as
+//   g_m <- (1 + lam sum_q gI[m][q] g_q(old) + lam sum_{q<m} cI[m][q] g_q(new) [+ mu (...)]) / (1 - alpha_m lam),
+// real arithmetic for a real symbol without explicit part (heat): 9 fused multiply-adds per node and sweep on average
+// instead of ~40 on the transformed values themselves.  The residual of the result is h_m * u0 with
+//   h_m = 1 - g_m + (lam + mu) sum_j rQ[m][j] g_j.
+template <int NF>
+DEVI void virt_multipliers_real(const SpecArgs& a, double lam, int nsweeps, double (&g)[NF]) {
+    double inv[NF];
+#pragma unroll
+    for (int m = 0; m < NF; ++m) {
+        inv[m] = fast_rcp(1.0 - a.alpha[m] * lam);
+        g[m] = 1.0;
+    }
+    for (int s = 0; s < nsweeps; ++s) {
+        double o[NF];
+#pragma unroll
+        for (int q = 0; q < NF; ++q) o[q] = g[q];
+#pragma unroll
+        for (int m = 0; m < NF; ++m) {
+            double t = 0.0;
+#pragma unroll
+            for (int q = 0; q < NF; ++q) t = fma(a.gI[m][q], o[q], t);
+            if (a.coupled) {
+#pragma unroll
+                for (int q = 0; q < m; ++q) t = fma(a.cI[m][q], g[q], t);
+            }
+            g[m] = fma(lam, t, 1.0) * inv[m];
+        }
+    }
+}
+template <int NF, bool HASE>
+DEVI void virt_multipliers(const SpecArgs& a, cd lam, cd mu, int nsweeps, cd (&g)[NF]) {
+    cd inv[NF];
+#pragma unroll
+    for (int m = 0; m < NF; ++m) {
+        inv[m] = cinv_fast(cd{1.0 - a.alpha[m] * lam.x, -a.alpha[m] * lam.y});
+        g[m] = cd{1.0, 0.0};
+    }
+    for (int s = 0; s < nsweeps; ++s) {
+        cd o[NF];
+#pragma unroll
+        for (int q = 0; q < NF; ++q) o[q] = g[q];
+#pragma unroll
+        for (int m = 0; m < NF; ++m) {
+            cd tI = cd{0.0, 0.0}, tE = cd{0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < NF; ++q) {
+                tI = cd{fma(a.gI[m][q], o[q].x, tI.x), fma(a.gI[m][q], o[q].y, tI.y)};
+                if (HASE) tE = cd{fma(a.gE[m][q], o[q].x, tE.x), fma(a.gE[m][q], o[q].y, tE.y)};
+            }
+            if (a.coupled) {
+#pragma unroll
+                for (int q = 0; q < m; ++q) {
+                    tI = cd{fma(a.cI[m][q], g[q].x, tI.x), fma(a.cI[m][q], g[q].y, tI.y)};
+                    if (HASE) tE = cd{fma(a.cE[m][q], g[q].x, tE.x), fma(a.cE[m][q], g[q].y, tE.y)};
+                }
+            }
+            cd acc = cfma(lam, tI, cd{1.0, 0.0});
+            if (HASE) acc = cfma(mu, tE, acc);
+            g[m] = cmul(acc, inv[m]);
+        }
+    }
+}
+// u[m] = g_m u0 (and, RES, r[m] = h_m u0) for the iterate after nsweeps sweeps
+template <int NF, bool HASE, bool RES>
+DEVI void virt_iterate(const SpecArgs& a, cd lam, cd mu, cd u0h, int nsweeps, cd (&u)[NF], cd (&r)[NF]) {
+    if (!HASE && a.real_sym) {
+        double g[NF];
+        virt_multipliers_real<NF>(a, lam.x, nsweeps, g);
+#pragma unroll
+        for (int m = 0; m < NF; ++m) u[m] = cd{g[m] * u0h.x, g[m] * u0h.y};
+        if constexpr (RES) {
+#pragma unroll
+            for (int m = 0; m < NF; ++m) {
+                double t = 0.0;
+#pragma unroll
+                for (int q = 0; q < NF; ++q) t = fma(a.rQ[m][q], g[q], t);
+                const double h = fma(lam.x, t, 1.0 - g[m]);
+                r[m] = cd{h * u0h.x, h * u0h.y};
+            }
+        }
+    } else {
+        cd g[NF];
+        virt_multipliers<NF, HASE>(a, lam, mu, nsweeps, g);
+#pragma unroll
+        for (int m = 0; m < NF; ++m) u[m] = cmul(g[m], u0h);
+        if constexpr (RES) {
+            const cd sym = HASE ? cadd(lam, mu) : lam;
+#pragma unroll
+            for (int m = 0; m < NF; ++m) {
+                cd t = cd{0.0, 0.0};
+#pragma unroll
+                for (int q = 0; q < NF; ++q) t = cd{fma(a.rQ[m][q], g[q].x, t.x), fma(a.rQ[m][q], g[q].y, t.y)};
+                const cd h = cfma(sym, t, cd{1.0 - g[m].x, -g[m].y});
+                r[m] = cmul(h, u0h);
+            }
+        }
+    }
 }
 
 template <int NF, bool RES>
@@ -563,6 +669,34 @@ __global__ __launch_bounds__(256) void k_spec_point(SpecArgs a, int n, size_t nm
                 a.W[m * a.fstride + g] = acc;
             }
         }
+    }
+}
+
+// the spectra of an iterate that was never stored (store_spectra): S[m] = g_m * S0 after nsweeps sweeps, all nodes or
+// (last_only) only the last one
+template <int NF>
+__global__ __launch_bounds__(256) void k_spec_store(SpecArgs a, int n, size_t nmodes, int nsweeps) {
+    const int lg = 31 - __builtin_clz(n);  // (n = 2^p on every path that gets here)
+    for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < nmodes; g += (size_t)gridDim.x * blockDim.x) {
+        const int kz = (int)(g & (size_t)(n - 1));
+        const size_t ln = g >> lg;
+        cd lam = a.lamI[kz], mu = cd{0.0, 0.0};
+        if (a.lamE) mu = a.lamE[kz];
+        if (a.ndim == 3) {
+            const int kx = (int)(ln >> lg), ky = (int)(ln & (size_t)(n - 1));
+            lam = cadd(lam, cadd(a.lamI[kx], a.lamI[ky]));
+            if (a.lamE) mu = cadd(mu, cadd(a.lamE[kx], a.lamE[ky]));
+        } else if (a.ndim == 2) {
+            lam = cadd(lam, a.lamI[ln]);
+            if (a.lamE) mu = cadd(mu, a.lamE[ln]);
+        }
+        const cd u0h = a.S0[g];
+        cd u[NF], r[NF];
+        if (a.lamE) virt_iterate<NF, true, false>(a, lam, mu, u0h, nsweeps, u, r);
+        else virt_iterate<NF, false, false>(a, lam, mu, u0h, nsweeps, u, r);
+#pragma unroll
+        for (int m = 0; m < NF; ++m)
+            if (!a.last_only || m == NF - 1) SPEC_FIELD(a, m, NF)[g] = u[m];
     }
 }
 
@@ -626,25 +760,43 @@ __global__ __launch_bounds__(256) void k_spec_residual(SpecArgs a, int n, size_t
 // Saves writing and re-reading NF spectra between k_spec_point and k_fftz_plain.
 // MODE 0: sweep, the new iterate is transformed; 1: sweep, the residual spectrum is transformed (RES);
 // 2: no sweep - residual spectrum of the CACHED iterate against the current S0 (u[0] was replaced).
+// 3: like 1, but the iterate is a function of S0 alone (spread predictor, then a.replay sweeps that were never stored):
+// reads S0 only, repeats those sweeps in registers, does its own, stores NOTHING but the transformed residual lines.
 // Elements per thread of the line transform inside the fused kernel: a 512-line uses 8, so that its 64 threads are one
 // wavefront and a workgroup owns ONE line per field like at 1024 (no second chunk whose work keeps the first chunk's
 // elements alive in registers).
-template <int N>
-constexpr int specz_elems() { return N == 512 ? 8 : (N == 256 ? SDC_SPECZ_E256 : (N == 1024 ? SDC_SPECZ_E1024 : fft_elems(N))); }
-template <int N>
+#ifndef SDC_SPECZ_VE1024
+#define SDC_SPECZ_VE1024 16  // ... of the launch that recomputes the iterate (MODE 3)
+#endif
+#ifndef SDC_SPECZ_VWAVES
+#define SDC_SPECZ_VWAVES SDC_SPECZ_WAVES
+#endif
+#ifndef SDC_SPECZ_VHOIST
+#define SDC_SPECZ_VHOIST 1  // MODE 3: the S0 loads of all chunks are issued before the first chunk is worked on
+#endif
+template <int N, bool V = false>
+constexpr int specz_elems() {
+    return N == 512 ? 8 : (N == 256 ? SDC_SPECZ_E256 : (N == 1024 ? (V ? SDC_SPECZ_VE1024 : SDC_SPECZ_E1024) : fft_elems(N)));
+}
+template <int N, bool V = false>
 constexpr int specz_lines() {
-    constexpr int P = N / specz_elems<N>();
+    constexpr int P = N / specz_elems<N, V>();
     return P >= 64 ? 1 : 64 / P;
 }
 
+template <int N, int NF, bool V>
+constexpr int specz_threads() { return specz_lines<N, V>() * (N / specz_elems<N, V>()) * NF; }
+template <int N, bool V>
+constexpr int specz_min_waves() { return specz_lines<N, V>() > 1 ? 2 : (V ? SDC_SPECZ_VWAVES : SDC_SPECZ_WAVES); }
 // EXPL 0: no explicit part, 1: explicit stencil (symbol lamE), 2: u-independent forcing (profile spectrum SP).
 template <int N, int NF, int MODE, int EXPL>
 // (several lines per workgroup, N < 1024: the elements a thread takes from the first chunk stay live while it works on
 // the second one - 2 waves / SIMD worth of registers instead of spilling; measured 5.7 -> 4.2 ms at 512^3)
-__global__ __launch_bounds__(specz_lines<N>() * (N / specz_elems<N>()) * NF,
-                             specz_lines<N>() > 1 ? 2 : SDC_SPECZ_WAVES) void k_spec_z(SpecArgs a, unsigned nlines) {
-    constexpr bool RES = MODE >= 1, UPD = MODE <= 1, HASE = EXPL == 1, HASP = EXPL == 2;
-    constexpr int E = specz_elems<N>(), P = N / E, LPB = specz_lines<N>();
+__global__ __launch_bounds__((specz_threads<N, NF, (MODE == 3)>()), (specz_min_waves<N, (MODE == 3)>()))
+void k_spec_z(SpecArgs a, unsigned nlines) {
+    constexpr bool RES = MODE >= 1, UPD = MODE <= 1 || MODE == 3, VIRT = MODE == 3, HASE = EXPL == 1, HASP = EXPL == 2;
+    static_assert(!(VIRT && HASP), "a forced iterate is not a function of the start value alone");
+    constexpr int E = specz_elems<N, (MODE == 3)>(), P = N / E, LPB = specz_lines<N, (MODE == 3)>();
     constexpr int SPAN = LPB * N, CH = SPAN > SDC_SPECZ_CH ? SDC_SPECZ_CH : SPAN, NCH = SPAN / CH, NT = LPB * P * NF;
     constexpr int ITS = (CH + NT - 1) / NT;  // modes per thread and chunk
     using LAY = LayContig<N>;
@@ -656,21 +808,37 @@ __global__ __launch_bounds__(specz_lines<N>() * (N / specz_elems<N>()) * NF,
     const bool ok = line < nlines;
     const size_t span0 = (size_t)blockIdx.x * SPAN, nmodes = (size_t)nlines * N;
     cd r[E];
+    constexpr bool HOIST = VIRT && SDC_SPECZ_VHOIST;
+    cd in0all[HOIST ? NCH : 1][ITS];
+    if constexpr (HOIST) {
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+            for (int it = 0; it < ITS; ++it) {
+                const int k = threadIdx.x + it * NT;
+                const size_t g = span0 + (size_t)ch * CH + k;
+                if (k < CH && g < nmodes) in0all[ch][it] = a.S0[g];
+            }
+    }
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
         // all loads of this chunk first: (NF + 1) * ITS independent 16-byte loads per thread in flight
-        cd in0[ITS], inq[ITS][NF], inp[ITS];
+        cd in0[ITS], inq[ITS][VIRT ? 1 : NF], inp[ITS];
 #pragma unroll
         for (int it = 0; it < ITS; ++it) {
             const int k = threadIdx.x + it * NT;
             const size_t g = span0 + (size_t)ch * CH + k;
             if (HASP) inp[it] = cd{0.0, 0.0};
-            if (k < CH && g < nmodes) {
+            if constexpr (HOIST) {
+                in0[it] = in0all[ch][it];
+            } else if (k < CH && g < nmodes) {
                 in0[it] = a.S0[g];
                 if (HASP) inp[it] = a.SP[g];
-                if (!UPD || !a.spread) {
+                if constexpr (!VIRT) {
+                    if (!UPD || !a.spread) {
 #pragma unroll
-                    for (int q = 0; q < NF; ++q) inq[it][q] = SPEC_FIELD(a, q, NF)[g];
+                        for (int q = 0; q < NF; ++q) inq[it][q] = SPEC_FIELD(a, q, NF)[g];
+                    }
                 }
             }
         }
@@ -693,10 +861,18 @@ __global__ __launch_bounds__(specz_lines<N>() * (N / specz_elems<N>()) * NF,
                 }
                 const cd u0h = in0[it];
                 cd old[NF], u[NF];
+                if constexpr (VIRT) {
+                    cd rr[NF];
+                    virt_iterate<NF, HASE, true>(a, lam, mu, u0h, a.replay + 1, u, rr);
 #pragma unroll
-                for (int q = 0; q < NF; ++q) old[q] = (UPD && a.spread) ? u0h : inq[it][q];
+                    for (int m = 0; m < NF; ++m) rbuf[m * CH + k] = cscale(rr[m], a.invN);
+                }
+#pragma unroll
+                for (int q = 0; q < NF; ++q)
+                    if constexpr (!VIRT) old[q] = (UPD && a.spread) ? u0h : inq[it][q];
 #pragma unroll
                 for (int m = 0; m < NF; ++m) {
+                    if constexpr (VIRT) continue;
                     if constexpr (!UPD) {
                         u[m] = old[m];
                         continue;
@@ -728,7 +904,8 @@ __global__ __launch_bounds__(specz_lines<N>() * (N / specz_elems<N>()) * NF,
                     SPEC_FIELD(a, m, NF)[g] = u[m];
 #endif
                 }
-                if constexpr (RES) {
+                if constexpr (VIRT) {
+                } else if constexpr (RES) {
                     const cd sym = HASE ? cadd(lam, mu) : lam;
 #pragma unroll
                     for (int m = 0; m < NF; ++m) {

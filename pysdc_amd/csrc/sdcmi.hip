@@ -45,6 +45,12 @@ static inline int grid_for(size_t work, int block) {
 
 // the start value where it lies (read-only consumers) / brought home to the U[0] slab (everybody else)
 static int spectrum_to_field(sdc_ctx* c, const cd* src, double* out);  // inverse transform of ONE cached spectrum
+static int store_spectra(sdc_ctx* c, bool last_only);               // spectra of an iterate that was never stored
+#define STORE_SPECTRA(c, last)                  \
+    do {                                        \
+        int rcs_ = store_spectra(c, last);      \
+        if (rcs_ != SDC_OK) return rcs_;        \
+    } while (0)
 static int ensure_u0(sdc_ctx* c) {
     if (c->u0_spec_only) {  // the start value exists as its transform only (sdc_advance after a deferred end value)
         c->u0_spec_only = false;
@@ -71,6 +77,8 @@ static int materialize_uend(sdc_ctx* c) {
     if (!c->uend_pending) return SDC_OK;
     c->uend_pending = false;
     if (!(c->uend_gen >= 0 && c->uend_gen == c->spec_gen)) return SDC_OK;  // (its spectrum is gone: nothing to deliver)
+    int rcs = store_spectra(c, true);
+    if (rcs != SDC_OK) return rcs;
     return spectrum_to_field(c, c->SL, c->UEND);
 }
 #define MATERIALIZE_UEND(c)                \
@@ -430,22 +438,32 @@ static int early_end_point_n(sdc_ctx* c, bool norms_only) {
     return SDC_OK;
 }
 
-template <int N, int NF>
-static void launch_spec_z(sdc_ctx* c, SpecArgs& a, size_t lines, int mode) {
-    constexpr int P = N / specz_elems<N>(), LPB = specz_lines<N>();
+template <int N, int NF, bool V>
+static void launch_spec_z_cfg(sdc_ctx* c, SpecArgs& a, size_t lines, int mode) {
+    constexpr int P = N / specz_elems<N, V>(), LPB = specz_lines<N, V>();
     constexpr int SPAN = LPB * N, CH = SPAN > SDC_SPECZ_CH ? SDC_SPECZ_CH : SPAN;
     size_t ldsz = (size_t)LayContig<N>::doubles(NF * LPB) * sizeof(double);
     if ((size_t)NF * CH * sizeof(cd) > ldsz) ldsz = (size_t)NF * CH * sizeof(cd);
     const dim3 grid((unsigned)((lines + LPB - 1) / LPB)), block(P * LPB * NF);
     const int expl = a.lamE ? 1 : (a.SP ? 2 : 0);
 #define ZL(M_, E_) hipLaunchKernelGGL((k_spec_z<N, NF, M_, E_>), grid, block, ldsz, c->stream, a, (unsigned)lines)
+    if constexpr (V) {  // (iterate recomputed from S0: not with a forcing term)
+        if (expl == 1) ZL(3, 1);
+        else ZL(3, 0);
+    } else {
 #define ZM(E_)                   \
     if (mode == 0) ZL(0, E_);    \
     else if (mode == 1) ZL(1, E_); \
     else ZL(2, E_);
-    if (expl == 1) { ZM(1) } else if (expl == 2) { ZM(2) } else { ZM(0) }
+        if (expl == 1) { ZM(1) } else if (expl == 2) { ZM(2) } else { ZM(0) }
 #undef ZM
+    }
 #undef ZL
+}
+template <int N, int NF>
+static void launch_spec_z(sdc_ctx* c, SpecArgs& a, size_t lines, int mode) {
+    if (mode == 3) launch_spec_z_cfg<N, NF, true>(c, a, lines, mode);
+    else launch_spec_z_cfg<N, NF, false>(c, a, lines, mode);
 }
 
 // spectral sweep; then either the inverse passes into out[f], or (norms != null) only the node norms of the
@@ -461,10 +479,13 @@ static int spec_sweep_n(sdc_ctx* c, int nf, SpecArgs& a, const FieldPtrs& p, uns
         if (nf <= 5 && !spec_only) {
             {
                 // after a spread predictor all nodes share S0: that launch does not read S (fewer bytes)
-                LaunchTimer lt(c, pname(norms ? (a.spread ? "spec_z_res_spread" : "spec_z_res")
-                                              : (a.spread ? "spec_z_spread" : "spec_z"), nf));
+                static const char* const vnames[] = {"spec_z_res_v0", "spec_z_res_v1", "spec_z_res_v2", "spec_z_res_v3",
+                                                     "spec_z_res_v4", "spec_z_res_v5", "spec_z_res_v6", "spec_z_res_v7+"};
+                LaunchTimer lt(c, pname(a.virt ? vnames[a.replay < 7 ? a.replay : 7]
+                                               : norms ? (a.spread ? "spec_z_res_spread" : "spec_z_res")
+                                                       : (a.spread ? "spec_z_spread" : "spec_z"), nf));
 #define ZCASE(MM) \
-    case MM: launch_spec_z<N, MM>(c, a, lines, norms ? 1 : 0); break;
+    case MM: launch_spec_z<N, MM>(c, a, lines, a.virt ? 3 : (norms ? 1 : 0)); break;
                 switch (nf) { ZCASE(1) ZCASE(2) ZCASE(3) ZCASE(4) ZCASE(5) }
 #undef ZCASE
             }
@@ -603,6 +624,7 @@ static int forcing_spectrum(sdc_ctx* c, SpecArgs& a, double dt) {
 static int spec_residual(sdc_ctx* c, double dt, unsigned long long* norms) {
     int rw = ensure_work(c);
     if (rw != SDC_OK) return rw;
+    STORE_SPECTRA(c, false);  // (before S0 is replaced: an iterate that was not stored is a function of the OLD one)
     if (!c->spec0_valid) {
         FieldPtrs p0;
         memset(&p0, 0, sizeof p0);
@@ -633,10 +655,54 @@ static int spec_residual(sdc_ctx* c, double dt, unsigned long long* norms) {
     N_DISPATCH(c, CALL)
 #undef CALL
 }
+// Iterates that were never stored (c->spec_virtual sweeps since a spread predictor, all with the coefficients c->vcoef):
+// write the spectra of the current one to S / SL now - all of them, or only the last node's (the end value).  Everything
+// that reads the cache, and everything that is about to change S0, comes through here first.
+static int store_spectra(sdc_ctx* c, bool last_only) {
+    if (!c->spec_valid || c->spec_virtual <= 0) return SDC_OK;
+    if (last_only && c->sl_stored) return SDC_OK;
+    SpecArgs a;
+    memset(&a, 0, sizeof a);
+    const SpecCoef& v = c->vcoef;
+    memcpy(a.gI, v.gI, sizeof a.gI);
+    memcpy(a.gE, v.gE, sizeof a.gE);
+    memcpy(a.cI, v.cI, sizeof a.cI);
+    memcpy(a.cE, v.cE, sizeof a.cE);
+    memcpy(a.alpha, v.alpha, sizeof a.alpha);
+    a.coupled = v.coupled;
+    a.real_sym = v.real_sym;
+    a.lamE = v.has_e ? c->lamE : nullptr;
+    a.S = c->S;
+    a.SL = c->SL;
+    a.fstride = c->Nc;
+    a.S0 = c->S0;
+    a.lamI = c->lamI;
+    a.nf = c->M;
+    a.ndim = c->ndim;
+    a.last_only = last_only ? 1 : 0;
+    const int n = c->n;
+    const size_t lines = c->ndim == 1 ? 1 : (size_t)(n / 2 + 1) * (c->ndim == 3 ? n : 1);
+    const size_t nmodes = lines * n;
+    size_t gblocks = (nmodes + 255) / 256;
+    if (gblocks > SDC_SPEC_GRID) gblocks = SDC_SPEC_GRID;
+    {
+        LaunchTimer lt(c, pname(last_only ? "spec_store_last" : "spec_store", c->M));
+#define SCASE(MM) \
+    case MM: hipLaunchKernelGGL((k_spec_store<MM>), dim3((unsigned)gblocks), dim3(256), 0, c->stream, a, n, nmodes, c->spec_virtual); break;
+        switch (c->M) { SCASE(1) SCASE(2) SCASE(3) SCASE(4) SCASE(5) SCASE(6) SCASE(7) SCASE(8) }
+#undef SCASE
+    }
+    HIPCHK(c, hipGetLastError());
+    c->sl_stored = true;
+    if (!last_only) c->spec_virtual = 0;
+    return SDC_OK;
+}
+
 // real fields out[f] from the cached spectra S[first .. first + nf)
 static int inverse_from_cache(sdc_ctx* c, int first, int nf, const FieldPtrs& p) {
     int rw = ensure_work(c);
     if (rw != SDC_OK) return rw;
+    STORE_SPECTRA(c, first == c->M - 1 && nf == 1);
     const double invN = 1.0 / (double)c->N;
     // (the last node's spectrum lives behind its own pointer)
     const bool has_last = first + nf == c->M;
@@ -939,6 +1005,7 @@ int sdc_set_coeffs(sdc_ctx* c, const double* Qmat, const double* QI, const doubl
 int sdc_set_stencil(sdc_ctx* c, int which, int npts, const int* offsets, const double* weights) {
     if (!c || which < 0 || which > 1 || npts < 1 || npts > MAXSTEN || !offsets || !weights)
         return fail(c, SDC_ERR_PARAM, "bad stencil (npts must be 1..%d)", MAXSTEN);
+    STORE_SPECTRA(c, false);  // (an iterate that was not stored is a function of the OLD symbol)
     Stencil& s = c->st[which];
     s.npts = npts;
     for (int k = 0; k < npts; ++k) {
@@ -1002,6 +1069,7 @@ static int vdp_check_failures(sdc_ctx* c) {
 
 int sdc_set_symbol(sdc_ctx* c, int which, const double* table) {
     if (!c || which < 0 || which > 1 || !table) return fail(c, SDC_ERR_PARAM, "bad symbol table");
+    STORE_SPECTRA(c, false);
     c->sym_real[which] = false;  // (a user-given table is used as it is)
     cd** dst = which == 0 ? &c->lamI : &c->lamE;
     if (!*dst) {
@@ -1245,6 +1313,13 @@ int sdc_set_fused_residual(sdc_ctx* c, int on) {
     if (!c) return SDC_ERR_PARAM;
     c->fuse_residual = on != 0;
     c->res_valid = false;
+    return SDC_OK;
+}
+
+int sdc_set_virtual_sweeps(sdc_ctx* c, int max_sweeps) {
+    if (!c || max_sweeps < 0) return fail(c, SDC_ERR_PARAM, "bad number of sweeps");
+    if (max_sweeps == 0) STORE_SPECTRA(c, false);
+    c->virt_max = max_sweeps;
     return SDC_OK;
 }
 
@@ -1611,7 +1686,9 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
         }
         FieldPtrs p;
         memset(&p, 0, sizeof p);
+        if (!c->spec_valid) c->spec_virtual = 0;
         if (!c->spec0_valid) {
+            STORE_SPECTRA(c, false);  // (an iterate that was not stored is a function of the OLD S0)
             p.in[0] = u0r(c);
             int rc0 = fwd_transform(c, 1, p, c->S0, 0);
             if (rc0 != SDC_OK) return rc0;
@@ -1675,6 +1752,51 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
             }
         }
         a.coupled = coupled;
+        // Iterates that are not stored.  After a spread predictor the iterate of a linear problem is a function of the
+        // transform of u0 alone, and so is every later one while u0 and the coefficients stay what they are: a sweep
+        // then reads S0 only, repeats the earlier sweeps in registers (a.replay), and stores nothing but the residual
+        // lines - 6 instead of 16 spectrum passes.  store_spectra writes the iterate out when somebody needs it.
+        {
+            const bool fused_z = SDC_FUSE_SPECZ && c->n >= 64 && c->n <= 1024 && M <= 5;
+            bool go = c->virt_max > 0 && c->deferred && !c->keep_rfields && !c->early_uend && c->ndim >= 2 &&
+                      c->expl_kind != SDC_EXPL_FORCING && (spec_only || (norms_only && fused_z));
+            SpecCoef now;
+            memset(&now, 0, sizeof now);
+            memcpy(now.gI, a.gI, sizeof now.gI);
+            memcpy(now.gE, a.gE, sizeof now.gE);
+            memcpy(now.cI, a.cI, sizeof now.cI);
+            memcpy(now.cE, a.cE, sizeof now.cE);
+            memcpy(now.alpha, a.alpha, sizeof now.alpha);
+            now.coupled = a.coupled;
+            now.real_sym = a.real_sym;
+            now.has_e = a.lamE ? 1 : 0;
+            if (go && a.spread) {
+                memcpy(&c->vcoef, &now, sizeof now);
+                a.replay = 0;
+            } else if (go && c->spec_valid && c->spec_virtual > 0 && c->spec_virtual < c->virt_max &&
+                       memcmp(&now, &c->vcoef, sizeof now) == 0) {
+                a.replay = c->spec_virtual;
+                a.spread = 1;
+            } else {
+                go = false;
+                STORE_SPECTRA(c, false);
+            }
+            if (go) {
+                a.virt = 1;
+                c->spec_virtual = a.replay + 1;
+                c->sl_stored = false;
+                if (spec_only) {  // no residual wanted: nothing to launch at all - the sweep is remembered
+                    c->spec_gen++;
+                    c->spec_valid = true;
+                    c->spec_spread = false;
+                    c->spread_pending = false;
+                    c->u_pending = c->f_pending = true;
+                    c->res_valid = false;
+                    c->rfields_valid = false;
+                    return SDC_OK;
+                }
+            }
+        }
         // nothing downstream needs the node values in real space to keep sweeping: only the node norms of the
         // residual are produced (from its transform), U and F stay deferred
         if (norms_only) {
@@ -2017,6 +2139,7 @@ int sdc_advance(sdc_ctx* c) {
     c->spec_spread = false;
     // UEND is the inverse transform of the last node's spectrum: that spectrum is the transform of the new u[0]
     const bool handover = c->S && c->spec_valid && c->uend_gen >= 0 && c->uend_gen == c->spec_gen;
+    if (handover) STORE_SPECTRA(c, c->kind == 0 && c->deferred);  // (SL has to BE there; S0 changes below)
     if (handover && c->uend_pending && c->kind == 0 && c->deferred) {
         // the end value was never transformed back: the start value of the new step exists as its transform only
         std::swap(c->S0, c->SL);

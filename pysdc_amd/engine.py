@@ -95,6 +95,10 @@ class SweepEngine:
         """no stage after a sweep computes the residual (sweeper parameter skip_residual_computation)"""
         self._chk(self.lib.sdc_set_skip_residual(self.ctx, int(bool(on))))
 
+    def set_virtual_sweeps(self, max_sweeps):
+        """sweeps per step whose iterate is not stored but recomputed from the transform of u[0] (0: off)"""
+        self._chk(self.lib.sdc_set_virtual_sweeps(self.ctx, int(max_sweeps)))
+
     def set_deferred(self, on):
         """leave F[1..M] / the spread copies unwritten until they are read (include/sdcmi.h: sdc_set_deferred)"""
         self._chk(self.lib.sdc_set_deferred(self.ctx, int(bool(on))))

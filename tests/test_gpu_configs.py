@@ -38,10 +38,11 @@ def _sub(a):
 # ---------------------------------------------------------------------------------------------------------------
 # the bench's data flow at 64^3 against the reference
 # ---------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('deferred', [True, False])
-def test_fused_3d_sweep_vs_reference_64(deferred):
+@pytest.mark.parametrize('deferred,virtual', [(True, 8), (True, 2), (True, 0), (False, 0)])
+def test_fused_3d_sweep_vs_reference_64(deferred, virtual):
     """engine level, default data flow of the bench (spectral reuse, fused k_spec_z, norm-only last pass; node fields
-    deferred or stored).  The reference solved with CG(rtol 1e-12): its node values carry ~1e-12 of solver error."""
+    deferred or stored; iterates recomputed from the transform of u[0] - virtual sweeps, the default - or their transforms
+    stored by every sweep).  The reference solved with CG(rtol 1e-12): its node values carry ~1e-12 of solver error."""
     case = load_cases('sweeps_big3d.npz')['cg64_heat3d_M5_IE']
     meta = case['meta']
     M, dt, t0 = len(case['coll_nodes']), meta['dt'], meta['t0']
@@ -49,6 +50,7 @@ def test_fused_3d_sweep_vs_reference_64(deferred):
     pp.pop('solver_type')
     e = G.engine_for('heat_unforced', pp, M)
     e.set_deferred(deferred)
+    e.set_virtual_sweeps(virtual)
     G.set_case_coeffs(e, case)
     e.upload(L.SLOT_U, 0, case['u0'])
     e.profile_enable(True)
@@ -81,8 +83,9 @@ def test_fused_3d_sweep_vs_reference_64(deferred):
             e.end_point(dt, False)
             assert rel_err(_sub(e.download(L.SLOT_UEND)), case[f'k{k}_uend_0_sub']) < TOL
     names = {k.split('[')[0] for k in e.profile_read()}
-    if deferred:
-        assert {'spec_z_res', 'fft_y_inv', 'fft_x_norm'} <= names, names  # the fused Fourier-space kernels did run
+    if deferred:   # the fused Fourier-space kernels did run
+        assert {'spec_z_res_v0' if virtual else 'spec_z_res', 'fft_y_inv', 'fft_x_norm'} <= names, names
+        assert ('spec_z_res' in names) == (virtual < meta['nsweeps']) and ('spec_z_res_v1' in names) == (virtual > 1), names
     else:
         assert {'fft_y_inv', 'fft_x_inv'} <= names and 'fft_x_fwd[5]' not in e.profile_read(), names  # spectral reuse
     for k in (meta['nsweeps'],):
@@ -138,7 +141,7 @@ def test_fused_3d_run_vs_reference_64():
     res = [v for _, v in get_sorted(stats, type='residual_post_iteration', sortby='time')]
     np.testing.assert_allclose(res, case['res'], rtol=1e-5, atol=5e-12)   # (the reference's CG noise: 2e-3 of 3e-10)
     names = {k.split('[')[0] for k in Lv.engine.profile_read()}
-    assert {'spec_z_res', 'fft_y_inv', 'fft_x_norm'} <= names, names
+    assert {'spec_z_res_v0', 'spec_z_res_v7+', 'spec_z_res', 'fft_y_inv', 'fft_x_norm'} <= names, names
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -175,8 +178,9 @@ def _grid_max_of_real_part(z, n):
     return float(np.max(np.abs(z.real * np.cos(t) - z.imag * np.sin(t))))
 
 
+@pytest.mark.parametrize('virtual', [8, 0])
 @pytest.mark.parametrize('n', [128, 512])
-def test_config3_advdiff_imex_eigenmode(n):
+def test_config3_advdiff_imex_eigenmode(n, virtual):
     """BASELINE config 3 (imex_1st_order, 3-D advection-diffusion, M=5) at 512^3 through the bench's data flow
     (k_spec_z<512,5,1,1> with the explicit symbol riding along): u0 = Re e^{i k.x}, k = 2 pi (3, 5, 2)."""
     import torch
@@ -193,6 +197,7 @@ def test_config3_advdiff_imex_eigenmode(n):
     QI[1:, 1:] = QDELTA_GENERATORS['IE'](qGen=coll.generator, tLeft=0).genCoeffs()
     QE[1:, 1:] = QDELTA_GENERATORS['EE'](qGen=coll.generator, tLeft=0).genCoeffs()
     e.set_coeffs(coll.Qmat, QI, QE, coll.nodes, coll.weights)
+    e.set_virtual_sweeps(virtual)
     kvec = (3, 5, 2)
     idx = np.arange(n)
     phase = (2.0 * np.pi / n) * ((kvec[0] * idx)[:, None, None] + (kvec[1] * idx)[None, :, None]
@@ -231,7 +236,7 @@ def test_config3_advdiff_imex_eigenmode(n):
         assert abs(res - max(ref)) < 1e-8 * max(ref) + 1e-11, (k, res, max(ref))
     names = {k_.split('[')[0] for k_ in e.profile_read()}
     if n >= 64:
-        assert 'spec_z_res' in names and 'fft_x_norm' in names, names
+        assert ('spec_z_res_v0' if virtual else 'spec_z_res') in names and 'fft_x_norm' in names, names
     e.end_point(dt, False)
     assert deviation(e.ptr(L.SLOT_UEND), scal[-1][M]) < 1e-12
     for m in range(1, M + 1):

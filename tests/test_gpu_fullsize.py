@@ -13,6 +13,7 @@ import pytest
 
 from pysdc_amd import lib as L
 from tests import _gpu as G
+from tests._cases import rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -177,10 +178,14 @@ def test_fused_residual_matches_separate_kernels(n, prob):
         e.close()
 
 
+@pytest.mark.parametrize('virtual', [0, 8, 2])
 @pytest.mark.parametrize('n,prob', [(64, 'heat_unforced'), (128, 'heat_unforced'), (64, 'advdiff')])
-def test_deferred_node_fields_match_eager(n, prob):
+def test_deferred_node_fields_match_eager(n, prob, virtual):
     """sdc_set_deferred: the sweep that does not store F[1..M] / the predictor that does not store the node
-    copies must hand out the same bits as the eager engine once the fields are asked for, at every stage."""
+    copies must hand out the same bits as the eager engine once the fields are asked for, at every stage.
+    virtual > 0 (sdc_set_virtual_sweeps, the default): sweeps that follow a spread predictor do not even store the
+    transforms of their iterate - it is recomputed from the transform of u[0] through node multipliers, which rounds
+    differently: same values to 1e-13 of the field's size instead of the same bits."""
     M, dt = 5, 1e-3 * (512.0 / n) ** 2
     c, qi = _coeffs(M, 'IE')
     qe = None
@@ -194,17 +199,21 @@ def test_deferred_node_fields_match_eager(n, prob):
         e = G.engine_for(prob, dict(nvars=(n, n, n), nu=0.1), M)
         e.set_coeffs(c.Qmat, qi, qe, c.nodes, c.weights)
         e.set_deferred(deferred)
+        e.set_virtual_sweeps(virtual)
         freq = (C.c_int * 3)(2, 4, 2)
         L.check(e.lib.sdc_init_field(e.ctx, e.ptr(L.SLOT_U, 0), freq, 0.3, 5), e.ctx)
         e.invalidate_spectra(1)
         engines.append(e)
     a, b = engines
 
+    def eq(x, y):
+        return np.array_equal(x, y) if virtual == 0 else rel_err(x, y) < 1e-13
+
     def same(stage, slots=('u', 'f')):
         if 'u' in slots:
-            assert np.array_equal(a.download_u(), b.download_u()), stage
+            assert eq(a.download_u(), b.download_u()), stage
         if 'f' in slots:
-            assert np.array_equal(a.download_f(), b.download_f()), stage
+            assert eq(a.download_f(), b.download_f()), stage
 
     for e in engines:
         e.predict(0.0, dt)
@@ -222,13 +231,13 @@ def test_deferred_node_fields_match_eager(n, prob):
     for e in engines:
         e.sweep(0.0, dt)
         e.end_point(dt, True)                       # the collocation update integrates F
-    assert np.array_equal(a.download(L.SLOT_UEND), b.download(L.SLOT_UEND))
+    assert eq(a.download(L.SLOT_UEND), b.download(L.SLOT_UEND))
     for e in engines:
         e.sweep(0.0, dt)
     for e in engines:
         e.integrate(dt, [e.ptr(L.SLOT_TAU, m) for m in range(M)])
     for m in range(M):
-        assert np.array_equal(a.download(L.SLOT_TAU, m), b.download(L.SLOT_TAU, m))
+        assert eq(a.download(L.SLOT_TAU, m), b.download(L.SLOT_TAU, m))
     same('sweep 3')
     # u[0] replaced after a sweep (what a receive from the previous time slice does): the residual of the
     # cached iterate against the NEW u[0] is reduced from its transform; the node fields stay what they were
@@ -349,6 +358,7 @@ def test_early_end_point_and_stream_wait():
         e = G.engine_for('heat_unforced', dict(nvars=(n, n, n), nu=0.1), M)
         e.set_coeffs(c.Qmat, qi, None, c.nodes, c.weights)
         e.set_early_end_point(early)
+        e.set_virtual_sweeps(0)       # (same bits wanted below: both engines store the transforms of every iterate)
         freq = (C.c_int * 3)(2, 4, 2)
         L.check(e.lib.sdc_init_field(e.ctx, e.ptr(L.SLOT_U, 0), freq, 0.3, 5), e.ctx)
         e.invalidate_spectra(1)
@@ -607,3 +617,76 @@ def test_fourier_space_sweeps_agree_with_general_path_in_every_dimension(nvars, 
     for x, y in zip(a, b):
         x, y = np.asarray(x), np.asarray(y)
         assert np.max(np.abs(x - y)) <= 1e-11 * max(1.0, float(np.max(np.abs(y)))), nvars
+
+
+@pytest.mark.parametrize('vmax', [8, 2, 1])
+@pytest.mark.parametrize('n,ndim,prob,qd', [(64, 3, 'heat_unforced', 'IE'), (128, 3, 'heat_unforced', 'LU'),
+                                           (64, 3, 'advdiff', 'LU'), (256, 2, 'heat_unforced', 'LU'),
+                                           (64, 3, 'heat_unforced', 'MIN-SR-S')])
+def test_iterates_recomputed_from_the_start_value(n, ndim, prob, qd, vmax):
+    """sdc_set_virtual_sweeps: sweeps after a spread predictor read the transform of u[0] only, repeat the earlier sweeps of
+    the step in registers (node multipliers) and store no iterate - against the engine that stores every iterate's
+    transforms: residual norms after every sweep, the end value, the node values on demand, three steps handed over through
+    sdc_advance, more sweeps per step than vmax (the iterate is then stored and the sweeps go on as before), and a new
+    u[0] in the middle of a step (what a receive does)."""
+    from pysdc_amd.coeffs import QDELTA_GENERATORS
+
+    M, dt = 5, 1e-3 * (512.0 / n) ** 2
+    c, qi = _coeffs(M, qd)
+    qe = None
+    if prob == 'advdiff':
+        qe = np.zeros_like(c.Qmat)
+        qe[1:, 1:], qe[1:, 0] = QDELTA_GENERATORS['EE'](qGen=c.generator, tLeft=0).genCoeffs(dTau=True)
+    engines = []
+    for v in (vmax, 0):
+        e = G.engine_for(prob, dict(nvars=(n,) * ndim, nu=0.1), M)
+        e.set_coeffs(c.Qmat, qi, qe, c.nodes, c.weights)
+        e.set_virtual_sweeps(v)
+        freq = (C.c_int * 3)(2, 4, 2)
+        L.check(e.lib.sdc_init_field(e.ctx, e.ptr(L.SLOT_U, 0), freq, 0.3, 5), e.ctx)
+        e.invalidate_spectra(1)
+        e.profile_enable(True)
+        engines.append(e)
+    a, b = engines
+    scale = float(np.max(np.abs(b.download(L.SLOT_U, 0))))
+
+    def residuals_agree(tag):
+        ra, rb = a.residual(dt), b.residual(dt)
+        assert np.all(np.abs(ra[1] - rb[1]) <= 1e-9 * rb[1] + 1e-13 * scale), (tag, ra, rb)
+
+    for step in range(3):
+        for e in engines:
+            e.predict(0.0, dt)
+        residuals_agree((step, 'predict'))
+        for k in range(4):
+            for e in engines:
+                e.sweep(0.0, dt)
+            residuals_agree((step, k))
+        if step == 1:      # somebody looks at a node value in the middle of the step; the sweeps go on afterwards
+            assert rel_err(a.download(L.SLOT_U, 2), b.download(L.SLOT_U, 2)) < 1e-12
+            assert rel_err(a.download(L.SLOT_F, M), b.download(L.SLOT_F, M)) < 1e-12
+            for e in engines:
+                e.sweep(0.0, dt)
+            residuals_agree((step, 'after a look'))
+        if step == 2:      # a new u[0] arrives: the residual of the OLD iterate against it, then sweeps from the new one
+            new_u0 = b.download(L.SLOT_U, 0) * 1.001 + 1e-4
+            for e in engines:
+                e.upload(L.SLOT_U, 0, new_u0)
+            residuals_agree((step, 'new u0'))
+            for e in engines:
+                e.sweep(0.0, dt)
+            residuals_agree((step, 'sweep from the new u0'))
+        for e in engines:
+            e.end_point(dt, False)
+        if step == 0:      # the end value is read before the step is handed over ...
+            assert rel_err(a.download(L.SLOT_UEND), b.download(L.SLOT_UEND)) < 1e-12
+        for e in engines:  # ... or it is not (steps 1 and 2): sdc_advance takes the last node's transform
+            L.check(e.lib.sdc_advance(e.ctx), e.ctx)
+    assert rel_err(a.download(L.SLOT_U, 0), b.download(L.SLOT_U, 0)) < 1e-12
+    names = {k.split('[')[0] for k in a.profile_read()}
+    if n <= 1024 and ndim >= 2:
+        assert 'spec_z_res_v0' in names and ('spec_z_res_v1' in names) == (vmax > 1), names
+        assert names & {'spec_store', 'spec_store_last'}, names
+    assert not {k.split('[')[0] for k in b.profile_read()} & {'spec_z_res_v0', 'spec_store', 'spec_store_last'}
+    for e in engines:
+        e.close()
