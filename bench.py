@@ -273,6 +273,8 @@ def run_workload(args, world, rank, use_dist, with_stream_reference=True):
     eng = L.engine  # allocates the device slabs
     eng.set_spectral_reuse(not args.no_spectral_reuse)
     eng.set_deferred(not args.eager_fields)
+    if args.virtual_sweeps is not None and hasattr(eng, 'set_virtual_sweeps'):
+        eng.set_virtual_sweeps(args.virtual_sweeps)
     if args.workload in ('vdp', 'allencahn'):
         u0 = L.prob.u_exact(0.0)
     else:
@@ -488,6 +490,9 @@ def main():
     ap.add_argument('--mssdc', default='jacobi', choices=['jacobi', 'gs'],
                     help='multi-step SDC over the time ranks (--gpus > 1): Jacobi (mssdc_jac=True, the default of the '
                          'reference: all slices sweep concurrently) or Gauss-Seidel (receive, sweep, blocking send)')
+    ap.add_argument('--virtual-sweeps', type=int, default=None,
+                    help='sdc_set_virtual_sweeps: sweeps per step whose iterate is recomputed from the transform of u0 instead '
+                         'of stored (0: every sweep stores its iterate, the round-1 data flow; default: the library\'s)')
     ap.add_argument('--skip-residual', action='store_true',
                     help="sweeper parameter skip_residual_computation for every stage (the reference's switch for runs with a "
                          'fixed number of sweeps): no residual is computed; NOT the headline configuration')

@@ -119,7 +119,7 @@ int sdc_set_skip_residual(sdc_ctx* ctx, int on);
  * stays in Fourier space then reads the transform of u[0] only, repeats the earlier sweeps of the step in registers and
  * stores nothing but what the residual norm needs; whoever needs the iterate itself (node values, the end value, a new
  * u[0], other coefficients) has it written out first.  max_sweeps: sweeps per step that may be repeated that way before
- * the iterate is stored after all (arithmetic grows with each; default 8), 0: every sweep stores its iterate. */
+ * the iterate is stored after all (arithmetic grows with each; default 16), 0: every sweep stores its iterate. */
 int sdc_set_virtual_sweeps(sdc_ctx* ctx, int max_sweeps);
 /* Deferred node fields (default on).  The spectral-reuse sweep reads neither F[1..M] nor the M copies a 'spread'
  * predictor makes (core/sweeper.py:140-146): the engine therefore leaves them unwritten until somebody needs

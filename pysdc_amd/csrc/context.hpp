@@ -62,7 +62,7 @@ struct sdc_ctx {
     // Iterates that are not stored: spec_virtual > 0 (while spec_valid) = the cached iterate is the result of that many
     // sweeps with the coefficients vcoef, started from "all nodes equal u0" - a function of S0 alone, recomputed by whoever
     // needs it (store_spectra).  sl_stored: the last node's spectrum has been written to SL all the same.
-    int spec_virtual = 0, virt_max = 8;
+    int spec_virtual = 0, virt_max = 16;
     bool sl_stored = false;
     SpecCoef vcoef;
     cd *tw = nullptr, *lamI = nullptr, *lamE = nullptr;

@@ -700,6 +700,32 @@ __global__ __launch_bounds__(256) void k_spec_store(SpecArgs a, int n, size_t nm
     }
 }
 
+// ... for a real symmetric symbol (heat): the modes kz and n - kz of a line share lam and hence the multipliers.  One
+// thread per pair (p, n - p), p in [0, n/2); the thread with p = 0 also takes the unpaired mode n/2.
+template <int NF>
+__global__ __launch_bounds__(256) void k_spec_store_pairs(SpecArgs a, int n, size_t npairs, int nsweeps) {
+    const int lg = 31 - __builtin_clz(n);
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < npairs; idx += (size_t)gridDim.x * blockDim.x) {
+        const int p_ = (int)(idx & (size_t)(n / 2 - 1));
+        const size_t ln = idx >> (lg - 1);
+        double lxy = 0.0;
+        if (a.ndim == 3) lxy = a.lamI[ln >> lg].x + a.lamI[ln & (size_t)(n - 1)].x;
+        else if (a.ndim == 2) lxy = a.lamI[ln].x;
+        const size_t base = ln << lg;
+        const size_t ilo = base + p_, ihi = base + (p_ ? n - p_ : n / 2);
+        const cd lo = a.S0[ilo], hi = a.S0[ihi];
+        double g[NF];
+        virt_multipliers_real<NF>(a, a.lamI[p_].x + lxy, nsweeps, g);
+#pragma unroll
+        for (int m = 0; m < NF; ++m)
+            if (!a.last_only || m == NF - 1) SPEC_FIELD(a, m, NF)[ilo] = cd{g[m] * lo.x, g[m] * lo.y};
+        if (p_ == 0) virt_multipliers_real<NF>(a, a.lamI[n / 2].x + lxy, nsweeps, g);
+#pragma unroll
+        for (int m = 0; m < NF; ++m)
+            if (!a.last_only || m == NF - 1) SPEC_FIELD(a, m, NF)[ihi] = cd{g[m] * hi.x, g[m] * hi.y};
+    }
+}
+
 // transform of the collocation residual of the CACHED iterate against the current S0 (u[0] was replaced after
 // the sweep, e.g. by a receive): W[m] = S0 - S[m] + dt sum_j Q[m][j] (lam + mu) S[j]
 template <int NF>
@@ -792,11 +818,13 @@ constexpr int specz_min_waves() { return specz_lines<N, V>() > 1 ? 2 : (V ? SDC_
 template <int N, int NF, int MODE, int EXPL>
 // (several lines per workgroup, N < 1024: the elements a thread takes from the first chunk stay live while it works on
 // the second one - 2 waves / SIMD worth of registers instead of spilling; measured 5.7 -> 4.2 ms at 512^3)
-__global__ __launch_bounds__((specz_threads<N, NF, (MODE == 3)>()), (specz_min_waves<N, (MODE == 3)>()))
+__global__ __launch_bounds__((specz_threads<N, NF, (MODE >= 3)>()), (specz_min_waves<N, (MODE >= 3)>()))
 void k_spec_z(SpecArgs a, unsigned nlines) {
-    constexpr bool RES = MODE >= 1, UPD = MODE <= 1 || MODE == 3, VIRT = MODE == 3, HASE = EXPL == 1, HASP = EXPL == 2;
+    constexpr bool RES = MODE >= 1, UPD = MODE <= 1 || MODE >= 3, VIRT = MODE >= 3, PAIR = MODE == 4, HASE = EXPL == 1,
+                   HASP = EXPL == 2;
     static_assert(!(VIRT && HASP), "a forced iterate is not a function of the start value alone");
-    constexpr int E = specz_elems<N, (MODE == 3)>(), P = N / E, LPB = specz_lines<N, (MODE == 3)>();
+    constexpr int E = specz_elems<N, (MODE >= 3)>(), P = N / E, LPB = specz_lines<N, (MODE >= 3)>();
+    static_assert(!PAIR || (LPB == 1 && !HASE), "mode pairs: one line per field and workgroup, real symbol only");
     constexpr int SPAN = LPB * N, CH = SPAN > SDC_SPECZ_CH ? SDC_SPECZ_CH : SPAN, NCH = SPAN / CH, NT = LPB * P * NF;
     constexpr int ITS = (CH + NT - 1) / NT;  // modes per thread and chunk
     using LAY = LayContig<N>;
@@ -808,7 +836,69 @@ void k_spec_z(SpecArgs a, unsigned nlines) {
     const bool ok = line < nlines;
     const size_t span0 = (size_t)blockIdx.x * SPAN, nmodes = (size_t)nlines * N;
     cd r[E];
-    constexpr bool HOIST = VIRT && SDC_SPECZ_VHOIST;
+    if constexpr (PAIR) {
+        // Real symmetric symbol: the modes kz and N - kz of a line share lam, hence the node multipliers.  One item
+        // p in [0, N/2] per thread and round: multipliers once, both modes scaled by them.  (LPB == 1: the workgroup's
+        // span is ONE line, kx and ky are the same for all of it.)
+        constexpr int NI = N / 2 + 1, IT2 = (NI + NT - 1) / NT;
+        const size_t base = (size_t)blockIdx.x * N;
+        cd lo[IT2], hi[IT2];
+        double lz[IT2];
+#pragma unroll
+        for (int it = 0; it < IT2; ++it) {
+            const int p_ = threadIdx.x + it * NT;
+            lo[it] = hi[it] = cd{0.0, 0.0};
+            lz[it] = 0.0;
+            if (p_ < NI && ok) {
+                lo[it] = a.S0[base + p_];
+                if (p_ >= 1 && p_ < N / 2) hi[it] = a.S0[base + N - p_];
+                lz[it] = a.lamI[p_].x;
+            }
+        }
+        double lxy = 0.0;
+        if (a.ndim == 3) lxy = a.lamI[blockIdx.x / N].x + a.lamI[blockIdx.x % N].x;
+        else if (a.ndim == 2) lxy = a.lamI[blockIdx.x].x;
+        double hm[IT2][NF];
+#pragma unroll
+        for (int it = 0; it < IT2; ++it) {
+            const double lam = lz[it] + lxy;
+            double g[NF];
+            virt_multipliers_real<NF>(a, lam, a.replay + 1, g);
+#pragma unroll
+            for (int m = 0; m < NF; ++m) {
+                double t = 0.0;
+#pragma unroll
+                for (int q = 0; q < NF; ++q) t = fma(a.rQ[m][q], g[q], t);
+                hm[it][m] = fma(lam, t, 1.0 - g[m]) * a.invN;
+            }
+        }
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+#pragma unroll
+            for (int it = 0; it < IT2; ++it) {
+                const int p_ = threadIdx.x + it * NT;
+                if (p_ < NI) {
+                    if (p_ / CH == ch) {
+#pragma unroll
+                        for (int m = 0; m < NF; ++m) rbuf[m * CH + (p_ % CH)] = cscale(lo[it], hm[it][m]);
+                    }
+                    const int q_ = N - p_;
+                    if (p_ >= 1 && p_ < N / 2 && q_ / CH == ch) {
+#pragma unroll
+                        for (int m = 0; m < NF; ++m) rbuf[m * CH + (q_ % CH)] = cscale(hi[it], hm[it][m]);
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < E; ++i) {
+                const int o = j + i * P;
+                if (o / CH == ch) r[i] = ok ? rbuf[f * CH + (o % CH)] : cd{0.0, 0.0};
+            }
+            __syncthreads();
+        }
+    }
+    constexpr bool HOIST = VIRT && !PAIR && SDC_SPECZ_VHOIST;
     cd in0all[HOIST ? NCH : 1][ITS];
     if constexpr (HOIST) {
 #pragma unroll
@@ -821,7 +911,7 @@ void k_spec_z(SpecArgs a, unsigned nlines) {
             }
     }
 #pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) {
+    for (int ch = 0; ch < (PAIR ? 0 : NCH); ++ch) {
         // all loads of this chunk first: (NF + 1) * ITS independent 16-byte loads per thread in flight
         cd in0[ITS], inq[ITS][VIRT ? 1 : NF], inp[ITS];
 #pragma unroll

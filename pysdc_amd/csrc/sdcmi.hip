@@ -18,6 +18,9 @@
 #ifndef SDC_FUSE_SPECZ
 #define SDC_FUSE_SPECZ 1
 #endif
+#ifndef SDC_SPECZ_PAIRS
+#define SDC_SPECZ_PAIRS 1
+#endif
 #ifndef SDC_SPEC_GRID
 #define SDC_SPEC_GRID 4096
 #endif
@@ -447,9 +450,13 @@ static void launch_spec_z_cfg(sdc_ctx* c, SpecArgs& a, size_t lines, int mode) {
     const dim3 grid((unsigned)((lines + LPB - 1) / LPB)), block(P * LPB * NF);
     const int expl = a.lamE ? 1 : (a.SP ? 2 : 0);
 #define ZL(M_, E_) hipLaunchKernelGGL((k_spec_z<N, NF, M_, E_>), grid, block, ldsz, c->stream, a, (unsigned)lines)
-    if constexpr (V) {  // (iterate recomputed from S0: not with a forcing term)
-        if (expl == 1) ZL(3, 1);
-        else ZL(3, 0);
+    if constexpr (V) {  // (iterate recomputed from S0: real symbol, no explicit part - sdc_sweep sees to that)
+        (void)expl;
+        if constexpr (LPB == 1 && SDC_SPECZ_PAIRS) {
+            // real symmetric symbol: the modes kz and N - kz of a line share their node multipliers
+            if (a.real_sym) ZL(4, 0);
+            else ZL(3, 0);
+        } else ZL(3, 0);
     } else {
 #define ZM(E_)                   \
     if (mode == 0) ZL(0, E_);    \
@@ -687,10 +694,20 @@ static int store_spectra(sdc_ctx* c, bool last_only) {
     if (gblocks > SDC_SPEC_GRID) gblocks = SDC_SPEC_GRID;
     {
         LaunchTimer lt(c, pname(last_only ? "spec_store_last" : "spec_store", c->M));
+        if (a.real_sym && !a.lamE && c->ndim >= 2 && n >= 4 && SDC_SPECZ_PAIRS) {
+            const size_t npairs = lines * (size_t)(n / 2);
+            size_t pb = (npairs + 255) / 256;
+            if (pb > SDC_SPEC_GRID) pb = SDC_SPEC_GRID;
+#define SCASE(MM) \
+    case MM: hipLaunchKernelGGL((k_spec_store_pairs<MM>), dim3((unsigned)pb), dim3(256), 0, c->stream, a, n, npairs, c->spec_virtual); break;
+            switch (c->M) { SCASE(1) SCASE(2) SCASE(3) SCASE(4) SCASE(5) SCASE(6) SCASE(7) SCASE(8) }
+#undef SCASE
+        } else {
 #define SCASE(MM) \
     case MM: hipLaunchKernelGGL((k_spec_store<MM>), dim3((unsigned)gblocks), dim3(256), 0, c->stream, a, n, nmodes, c->spec_virtual); break;
-        switch (c->M) { SCASE(1) SCASE(2) SCASE(3) SCASE(4) SCASE(5) SCASE(6) SCASE(7) SCASE(8) }
+            switch (c->M) { SCASE(1) SCASE(2) SCASE(3) SCASE(4) SCASE(5) SCASE(6) SCASE(7) SCASE(8) }
 #undef SCASE
+        }
     }
     HIPCHK(c, hipGetLastError());
     c->sl_stored = true;
@@ -802,6 +819,8 @@ static int build_symbol(sdc_ctx* c, int which) {
         }
         lam[k] = cd{(double)re, symmetric ? 0.0 : (double)im};
     }
+    if (symmetric)  // ... and an even one, to the last bit (modes k and n - k share their node multipliers in k_spec_z)
+        for (int k = n / 2 + 1; k < n; ++k) lam[k].x = lam[n - k].x;
     cd** dst = which == 0 ? &c->lamI : &c->lamE;
     if (!*dst) {
         HIPCHK(c, hipMalloc((void**)dst, sizeof(cd) * n));
@@ -1758,8 +1777,12 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
         // lines - 6 instead of 16 spectrum passes.  store_spectra writes the iterate out when somebody needs it.
         {
             const bool fused_z = SDC_FUSE_SPECZ && c->n >= 64 && c->n <= 1024 && M <= 5;
+            // (with a residual to deliver this pays for a REAL symbol without explicit part - heat: real multipliers, and
+            // the modes kz / N - kz of a line share them; complex multipliers cost more than reading the stored iterate:
+            // advection-diffusion 512^3 3.2 -> 3.4 ms per launch)
             bool go = c->virt_max > 0 && c->deferred && !c->keep_rfields && !c->early_uend && c->ndim >= 2 &&
-                      c->expl_kind != SDC_EXPL_FORCING && (spec_only || (norms_only && fused_z));
+                      c->expl_kind != SDC_EXPL_FORCING &&
+                      (spec_only || (norms_only && fused_z && a.real_sym && !a.lamE));
             SpecCoef now;
             memset(&now, 0, sizeof now);
             memcpy(now.gI, a.gI, sizeof now.gI);

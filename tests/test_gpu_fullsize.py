@@ -684,9 +684,11 @@ def test_iterates_recomputed_from_the_start_value(n, ndim, prob, qd, vmax):
             L.check(e.lib.sdc_advance(e.ctx), e.ctx)
     assert rel_err(a.download(L.SLOT_U, 0), b.download(L.SLOT_U, 0)) < 1e-12
     names = {k.split('[')[0] for k in a.profile_read()}
-    if n <= 1024 and ndim >= 2:
+    if prob == 'heat_unforced':   # (real symbol; with complex multipliers reading the stored iterate is cheaper)
         assert 'spec_z_res_v0' in names and ('spec_z_res_v1' in names) == (vmax > 1), names
         assert names & {'spec_store', 'spec_store_last'}, names
+    else:
+        assert 'spec_z_res_v0' not in names and 'spec_z_res' in names, names
     assert not {k.split('[')[0] for k in b.profile_read()} & {'spec_z_res_v0', 'spec_store', 'spec_store_last'}
     for e in engines:
         e.close()
