@@ -44,6 +44,7 @@ def _kernel_bytes(name, n, M, ncomp=1):
         'spec_z_spread': (1 + 2 * nf) * spec,
         # iterate recomputed from the transform of u0 (virtual sweeps): S0 in, the residual's transformed lines out
         **{f'spec_z_res_v{r}': (1 + nf) * spec for r in ('0', '1', '2', '3', '4', '5', '6', '7+')},
+        **{f'spec_z_v{r}': (1 + nf) * spec for r in ('0', '1', '2', '3', '4', '5', '6', '7+')},   # (the iterate itself out)
         'spec_store': (1 + nf) * spec,                      # ... and its transforms written out when somebody needs them
         'spec_store_last': 2 * spec,                        # (only the last node's: the end value / next start value)
         'fft_x_norm': nf * spec,
@@ -347,7 +348,7 @@ def run_workload(args, world, rank, use_dist, with_stream_reference=True):
         merged = {}
         for k, v in prof.items():
             base = k.split('[')[0]
-            key = ('spec_z_res_v*' + k[len(base):]) if base.startswith('spec_z_res_v') else k
+            key = ('spec_z_res_v*' + k[len(base):]) if base.startswith(('spec_z_res_v', 'spec_z_v')) else k
             t, c_ = merged.get(key, (0.0, 0))
             merged[key] = (t + v[0], c_ + v[1])
         dom = max(merged.items(), key=lambda kv: kv[1][0]) if merged else (None, (0.0, 0))
@@ -371,6 +372,7 @@ def run_workload(args, world, rank, use_dist, with_stream_reference=True):
                     'stream_reference_gbs': stream_reference(torch, eng) if with_stream_reference else None}
         in_sweep = ('gather', 'fft_x_fwd', 'fft_y_fwd', 'fft_z_fwd', 'fft_z_solve', 'spec_point', 'spec_point_res', 'spec_point_only', 'spec_z', 'spec_z_res', 'spec_z_spread', 'spec_z_res_spread',
                     'spec_z_res_v0', 'spec_z_res_v1', 'spec_z_res_v2', 'spec_z_res_v3', 'spec_z_res_v4', 'spec_z_res_v5', 'spec_z_res_v6', 'spec_z_res_v7+', 'spec_store',
+                    'spec_z_v0', 'spec_z_v1', 'spec_z_v2', 'spec_z_v3', 'spec_z_v4', 'spec_z_v5', 'spec_z_v6', 'spec_z_v7+',
                     'fft_x_norm', 'fft_x_inv_norm',
                     'fft_z_inv', 'fft_y_inv',
                     'fft_x_inv', 'stencil', 'stencil_res', 'res_stencil', 'vdp_sweep', 'vdp_sweep_lazyf', 'vdp_sweep_mfma')

@@ -492,7 +492,8 @@ struct SpecArgs {
     // Iterates that are not stored (DESIGN.md "sweeps recomputed from the start value"): after a spread predictor every
     // iterate of a linear problem is a function of the transform of u0 alone.  replay = number of earlier sweeps this
     // launch repeats in registers (same coefficients) before it does its own; virt: the new spectra are not stored
-    // either; last_only: only the last node's spectrum is stored.
+    // either (2: ... and the line transform gets the iterate itself instead of its residual); last_only: only the last
+    // node's spectrum is stored.
     int replay, virt, last_only;
 };
 
@@ -864,12 +865,17 @@ void k_spec_z(SpecArgs a, unsigned nlines) {
             const double lam = lz[it] + lxy;
             double g[NF];
             virt_multipliers_real<NF>(a, lam, a.replay + 1, g);
+            if (a.virt == 2) {  // the iterate itself is wanted in real space (node values stored by every sweep)
 #pragma unroll
-            for (int m = 0; m < NF; ++m) {
-                double t = 0.0;
+                for (int m = 0; m < NF; ++m) hm[it][m] = g[m] * a.invN;
+            } else {
 #pragma unroll
-                for (int q = 0; q < NF; ++q) t = fma(a.rQ[m][q], g[q], t);
-                hm[it][m] = fma(lam, t, 1.0 - g[m]) * a.invN;
+                for (int m = 0; m < NF; ++m) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int q = 0; q < NF; ++q) t = fma(a.rQ[m][q], g[q], t);
+                    hm[it][m] = fma(lam, t, 1.0 - g[m]) * a.invN;
+                }
             }
         }
 #pragma unroll

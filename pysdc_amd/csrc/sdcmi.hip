@@ -488,7 +488,10 @@ static int spec_sweep_n(sdc_ctx* c, int nf, SpecArgs& a, const FieldPtrs& p, uns
                 // after a spread predictor all nodes share S0: that launch does not read S (fewer bytes)
                 static const char* const vnames[] = {"spec_z_res_v0", "spec_z_res_v1", "spec_z_res_v2", "spec_z_res_v3",
                                                      "spec_z_res_v4", "spec_z_res_v5", "spec_z_res_v6", "spec_z_res_v7+"};
-                LaunchTimer lt(c, pname(a.virt ? vnames[a.replay < 7 ? a.replay : 7]
+                static const char* const inames[] = {"spec_z_v0", "spec_z_v1", "spec_z_v2", "spec_z_v3",
+                                                     "spec_z_v4", "spec_z_v5", "spec_z_v6", "spec_z_v7+"};
+                LaunchTimer lt(c, pname(a.virt == 2 ? inames[a.replay < 7 ? a.replay : 7]
+                                        : a.virt ? vnames[a.replay < 7 ? a.replay : 7]
                                                : norms ? (a.spread ? "spec_z_res_spread" : "spec_z_res")
                                                        : (a.spread ? "spec_z_spread" : "spec_z"), nf));
 #define ZCASE(MM) \
@@ -1780,9 +1783,12 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
             // (with a residual to deliver this pays for a REAL symbol without explicit part - heat: real multipliers, and
             // the modes kz / N - kz of a line share them; complex multipliers cost more than reading the stored iterate:
             // advection-diffusion 512^3 3.2 -> 3.4 ms per launch)
-            bool go = c->virt_max > 0 && c->deferred && !c->keep_rfields && !c->early_uend && c->ndim >= 2 &&
+            // (a sweep that stores the node values - eager fields - hands the iterate itself to the transform: mode pairs only)
+            const bool pairs_z = SDC_SPECZ_PAIRS && fused_z && c->n >= 512 && a.real_sym && !a.lamE;
+            const bool iter_out = !spec_only && !norms_only && pairs_z;
+            bool go = c->virt_max > 0 && (c->deferred || iter_out) && !c->keep_rfields && !c->early_uend && c->ndim >= 2 &&
                       c->expl_kind != SDC_EXPL_FORCING &&
-                      (spec_only || (norms_only && fused_z && a.real_sym && !a.lamE));
+                      (spec_only || iter_out || (norms_only && fused_z && a.real_sym && !a.lamE));
             SpecCoef now;
             memset(&now, 0, sizeof now);
             memcpy(now.gI, a.gI, sizeof now.gI);
@@ -1805,7 +1811,7 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
                 STORE_SPECTRA(c, false);
             }
             if (go) {
-                a.virt = 1;
+                a.virt = iter_out ? 2 : 1;
                 c->spec_virtual = a.replay + 1;
                 c->sl_stored = false;
                 if (spec_only) {  // no residual wanted: nothing to launch at all - the sweep is remembered

@@ -692,3 +692,46 @@ def test_iterates_recomputed_from_the_start_value(n, ndim, prob, qd, vmax):
     assert not {k.split('[')[0] for k in b.profile_read()} & {'spec_z_res_v0', 'spec_store', 'spec_store_last'}
     for e in engines:
         e.close()
+
+
+@pytest.mark.parametrize('n,ndim', [(1024, 2), (512, 2), (512, 3)])
+def test_eager_sweeps_recompute_the_iterate_too(n, ndim):
+    """every sweep stores U and F in real space (sdc_set_deferred off, the reference's update_nodes): the launch that
+    transforms the new iterate back reads the transform of u[0] only as well (node multipliers, mode pairs: lines of 512
+    and 1024) - against the engine that stores and reads the transforms of every iterate."""
+    M, dt = 5, 1e-3 * (512.0 / n) ** 2
+    c, qi = _coeffs(M, 'IE')
+    engines = []
+    for v in (16, 0):
+        e = G.engine_for('heat_unforced', dict(nvars=(n,) * ndim, nu=0.1), M)
+        e.set_coeffs(c.Qmat, qi, None, c.nodes, c.weights)
+        e.set_deferred(False)
+        e.set_virtual_sweeps(v)
+        freq = (C.c_int * 3)(2, 4, 2)
+        L.check(e.lib.sdc_init_field(e.ctx, e.ptr(L.SLOT_U, 0), freq, 0.3, 5), e.ctx)
+        e.invalidate_spectra(1)
+        e.profile_enable(True)
+        engines.append(e)
+    a, b = engines
+    for step in range(2):
+        for e in engines:
+            e.predict(0.0, dt)
+        for k in range(3):
+            for e in engines:
+                e.sweep(0.0, dt)
+            ra, rb = a.residual(dt), b.residual(dt)
+            assert np.allclose(ra[1], rb[1], rtol=1e-9, atol=1e-13), (step, k)
+            for m in (1, M):
+                assert rel_err(a.download(L.SLOT_U, m), b.download(L.SLOT_U, m)) < 1e-12, (step, k, m)
+            # (f = A u amplifies the round-off of the grid-scale components of u by up to 12 nu n^2)
+            assert rel_err(a.download(L.SLOT_F, M), b.download(L.SLOT_F, M)) < 1e-10, (step, k)
+        for e in engines:
+            e.end_point(dt, False)
+        assert rel_err(a.download(L.SLOT_UEND), b.download(L.SLOT_UEND)) < 1e-12
+        for e in engines:
+            e.advance()
+    names = {k.split('[')[0] for k in a.profile_read()}
+    assert {'spec_z_v0', 'spec_z_v1', 'spec_z_v2'} <= names and 'spec_z' not in names, names
+    assert 'spec_z_v0' not in {k.split('[')[0] for k in b.profile_read()}
+    for e in engines:
+        e.close()
