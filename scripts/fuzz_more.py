@@ -32,4 +32,14 @@ for seed in range(100, 200):
     except Exception as e:
         bad += 1
         print('PLUGIN FAIL', seed, str(e)[:400])
+for v in ('1', '2', '3'):   # the limit on virtual sweeps low enough for the walks to cross it
+    os.environ['PYSDC_FUZZ_VIRTUAL'] = v
+    for seed in range(500, 560):
+        for prob in ('heat_unforced',):
+            try:
+                T.test_deferred_state_machine_random_walk(prob, seed)
+            except Exception as e:
+                bad += 1
+                print('ENGINE FAIL VIRTUAL', v, prob, seed, str(e)[:400])
+os.environ.pop('PYSDC_FUZZ_VIRTUAL')
 print('failures', bad)

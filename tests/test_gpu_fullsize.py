@@ -412,8 +412,12 @@ def test_deferred_state_machine_random_walk(prob, seed):
             e.set_forcing_values([np.cos(0.3 * k) for k in range(M + 1)])
             e.set_spectral_reuse(lazy)  # eager engine: the general data flow (gather on the F slab)
         e.set_deferred(lazy)
-        e.set_keep_residual_fields(lazy and seed % 2 == 0)
-        e.set_early_end_point(lazy and seed % 2 == 1)
+        # a third of the walks each: residual fields kept / end value produced early (time-parallel levels) / neither -
+        # only then are iterates recomputed from the transform of u[0] (sdc_set_virtual_sweeps; PYSDC_FUZZ_VIRTUAL: its limit)
+        e.set_keep_residual_fields(lazy and seed % 3 == 0)
+        e.set_early_end_point(lazy and seed % 3 == 1)
+        if os.environ.get('PYSDC_FUZZ_VIRTUAL') is not None:
+            e.set_virtual_sweeps(int(os.environ['PYSDC_FUZZ_VIRTUAL']))
         freq = (C.c_int * 3)(2, 2, 4)
         L.check(e.lib.sdc_init_field(e.ctx, e.ptr(L.SLOT_U, 0), freq, 0.2, 17), e.ctx)
         e.invalidate_spectra(1)
