@@ -626,7 +626,10 @@ def test_fourier_space_sweeps_agree_with_general_path_in_every_dimension(nvars, 
 @pytest.mark.parametrize('vmax', [8, 2, 1])
 @pytest.mark.parametrize('n,ndim,prob,qd', [(64, 3, 'heat_unforced', 'IE'), (128, 3, 'heat_unforced', 'LU'),
                                            (64, 3, 'advdiff', 'LU'), (256, 2, 'heat_unforced', 'LU'),
-                                           (64, 3, 'heat_unforced', 'MIN-SR-S')])
+                                           (64, 3, 'heat_unforced', 'MIN-SR-S'),
+                                           # lines of 512 and 1024: one multiplier evaluation per mode pair (MODE 4)
+                                           (512, 3, 'heat_unforced', 'IE'), (1024, 2, 'heat_unforced', 'LU'),
+                                           (512, 2, 'heat_unforced', 'MIN-SR-S')])
 def test_iterates_recomputed_from_the_start_value(n, ndim, prob, qd, vmax):
     """sdc_set_virtual_sweeps: sweeps after a spread predictor read the transform of u[0] only, repeat the earlier sweeps of
     the step in registers (node multipliers) and store no iterate - against the engine that stores every iterate's
@@ -668,7 +671,8 @@ def test_iterates_recomputed_from_the_start_value(n, ndim, prob, qd, vmax):
             residuals_agree((step, k))
         if step == 1:      # somebody looks at a node value in the middle of the step; the sweeps go on afterwards
             assert rel_err(a.download(L.SLOT_U, 2), b.download(L.SLOT_U, 2)) < 1e-12
-            assert rel_err(a.download(L.SLOT_F, M), b.download(L.SLOT_F, M)) < 1e-12
+            # (f = A u amplifies the round-off of the grid-scale components of u by up to 12 nu n^2)
+            assert rel_err(a.download(L.SLOT_F, M), b.download(L.SLOT_F, M)) < 1e-10
             for e in engines:
                 e.sweep(0.0, dt)
             residuals_agree((step, 'after a look'))
