@@ -2168,7 +2168,7 @@ int sdc_advance(sdc_ctx* c) {
     c->spec_spread = false;
     // UEND is the inverse transform of the last node's spectrum: that spectrum is the transform of the new u[0]
     const bool handover = c->S && c->spec_valid && c->uend_gen >= 0 && c->uend_gen == c->spec_gen;
-    if (handover) STORE_SPECTRA(c, c->kind == 0 && c->deferred);  // (SL has to BE there; S0 changes below)
+    if (handover) STORE_SPECTRA(c, true);  // (SL has to BE there; S0 changes below)
     if (handover && c->uend_pending && c->kind == 0 && c->deferred) {
         // the end value was never transformed back: the start value of the new step exists as its transform only
         std::swap(c->S0, c->SL);
@@ -2207,6 +2207,10 @@ int sdc_advance(sdc_ctx* c) {
     if (handover) {
         HIPCHK(c, hipMemcpyAsync(c->S0, c->SL, sizeof(cd) * c->Nc, hipMemcpyDeviceToDevice, c->stream));
         c->spec0_valid = true;
+        if (c->spec_virtual > 0) {  // an iterate that was never stored was a function of the OLD S0: gone with it (the
+            c->spec_valid = false;  // node values themselves are in U - this path is not the deferred one)
+            c->spec_virtual = 0;
+        }
     } else {
         c->spec0_valid = false;
     }
