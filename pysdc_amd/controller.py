@@ -11,7 +11,6 @@ same call order, same iteration counting (``iter`` only incremented in it_check,
 :634-768 stages): the forward transfer ``uend -> u[0]`` of the next time-rank is a point-to-point message
 through ``torch.distributed`` (RCCL over xGMI on GPUs, gloo in the CPU tests); the end-of-block value is
 broadcast from the last rank (controller_MPI.py:125-130).  Convergence flags travel on the host side."""
-import itertools
 import logging
 import os
 
@@ -78,6 +77,59 @@ class _ControllerBase:
             getattr(hook, name)(step=S, level_number=level, **kw)
 
 
+# ----------------------------------------------------------------------------------------------------------------
+# serial controller: the stage machine as DATA
+# ----------------------------------------------------------------------------------------------------------------
+# A stage is a list of phases; a phase is a tuple of operations carried out, in order, on one running step after the
+# other (the reference's "for S in local_MS_running" loops: one phase = one such loop, which is what makes several
+# steps in one process behave like ranks that take turns).  An operation is (name, *arguments) and resolves to the
+# method ``_op_<name>``; a name starting with ``all_`` is called once with the whole list of running steps.
+# ``_compile_stages`` writes the table for a given number of levels and sweeps per level; ``_run_stage`` interprets it.
+# Call order per step is the reference's (controller_nonMPI.py:334-689) - that order IS the algorithm (which end value
+# a step receives depends on it) - the text that produces it is this table.
+
+
+def _sweep_phase(level, stage, coeffs=None):
+    ops = [('hook', 'pre_sweep', level)]
+    if coeffs is not None:
+        ops.append(('coeffs', coeffs))
+    return tuple(ops + [('sweep', level), ('residual', level, stage), ('hook', 'post_sweep', level)])
+
+
+def _compile_stages(nlevels, nsweeps):
+    fine_only, coarsest = nlevels == 1, nlevels - 1
+    T = {}
+    T['SPREAD'] = [(('hook', 'pre_step', 0), ('predict',), ('goto', 'IT_CHECK' if fine_only else 'PREDICT'))]
+    T['PREDICT'] = [(('hook', 'pre_predict', 0),), (('all_predictor',),), (('hook', 'post_predict', 0),),
+                    (('goto', 'IT_CHECK'),)]
+    T['IT_CHECK'] = [(('send', 0, False), ('recv', 0, False), ('residual', 0, 'IT_CHECK')),
+                     (('judge',),),
+                     (('chain',),)]
+    fine = [(('sweep_count', 0),)]
+    for k in range(nsweeps[0]):
+        fine += [(('sweep_count', 1),),
+                 (('send', 0, False), ('recv', 0, k == nsweeps[0] - 1)),
+                 _sweep_phase(0, 'IT_FINE', coeffs=k + 1)]
+    T['IT_FINE'] = fine + [(('goto', 'IT_CHECK'),)]
+    down = [(('transfer', 0, 1),)]
+    for l in range(1, coarsest):
+        for _ in range(nsweeps[l]):
+            down += [(('send', l, False), ('recv', l, False)), _sweep_phase(l, 'IT_DOWN')]
+        down.append((('transfer', l, l + 1),))
+    T['IT_DOWN'] = down + [(('goto', 'IT_COARSE'),)]
+    # the serial part: receive, sweep, send - ONE phase, so that step p+1 finds the end value step p just produced
+    T['IT_COARSE'] = [(('recv', coarsest, False),) + _sweep_phase(coarsest, 'IT_COARSE')
+                      + (('send', coarsest, True), ('goto', 'IT_CHECK' if fine_only else 'IT_UP'))]
+    up = []
+    for l in range(coarsest, 0, -1):
+        up.append((('transfer', l, l - 1),))
+        if l - 1 > 0:
+            for k in range(nsweeps[l - 1]):
+                up += [(('send', l - 1, False), ('recv', l - 1, k == nsweeps[l - 1] - 1)), _sweep_phase(l - 1, 'IT_UP')]
+    T['IT_UP'] = up + [(('goto', 'IT_FINE'),)]
+    return T
+
+
 class controller_nonMPI(_ControllerBase):
     def __init__(self, num_procs, controller_params, description):
         super().__init__(controller_params, description)
@@ -86,99 +138,95 @@ class controller_nonMPI(_ControllerBase):
         self._uend_buf = None
         self.nsweeps = [L.params.nsweeps for L in self.MS[0].levels]
         self.nlevels = len(self.MS[0].levels)
+        self.stages = _compile_stages(self.nlevels, self.nsweeps)
 
-    # controller_nonMPI.py:85-167
+    # ---- time bookkeeping (controller_nonMPI.py:85-167) ------------------------------------------------------
+    def _schedule(self, t0, Tend, first=None):
+        """start times of the steps of one block: slot p begins where slot p-1 ends; a slot is active while its start
+        lies before Tend (up to 10 eps, controller_nonMPI.py:112,163)"""
+        start, t = [], t0
+        for S in self.MS:
+            start.append(t)
+            t += S.dt
+        live = [p for p, tp in enumerate(start) if tp < Tend - 10 * np.finfo(float).eps]
+        return start, live
+
+    def _continues(self, u0):
+        """u0 is the untouched object the previous run() on this controller returned, and the level's engine still holds
+        exactly that state: the new run continues like the next block of the old one (Level.advance: no copy of u0 in,
+        no transform of it)"""
+        L0 = self.MS[0].levels[0]
+        eng = getattr(L0, '_engine_obj', None)
+        mark = getattr(u0, '_lineage', None)
+        return (len(self.MS) == 1 and mark is not None and eng is not None and hasattr(L0, 'advance')
+                and mark == (id(eng), eng.end_value_generation()))
+
     def run(self, u0, t0, Tend):
-        uend = None
-        num_procs = len(self.MS)
         for hook in self.hooks:
             hook.reset_stats()
-        slots = list(range(num_procs))
-        time = [t0 + sum(self.MS[j].dt for j in range(p)) for p in slots]
-        active = [time[p] < Tend - 10 * np.finfo(float).eps for p in slots]
-        if not any(active):
+        start, live = self._schedule(t0, Tend)
+        if not live:
             raise ControllerError('Nothing to do, check t0, dt and Tend.')
-        active_slots = list(itertools.compress(slots, active))
-        # u0 is the untouched object the previous run() on this controller returned, and the level's engine still holds
-        # exactly that state: the new run continues like the next block of the old one (Level.advance: no copy of u0 in,
-        # no transform of it)
-        L0 = self.MS[0].levels[0]
-        lineage = getattr(u0, '_lineage', None)
-        if (num_procs == 1 and lineage is not None and hasattr(L0, 'advance') and getattr(L0, '_engine_obj', None) is not None
-                and lineage == (id(L0._engine_obj), L0._engine_obj.end_value_generation())):
-            self.restart_block(active_slots, time, None)
-        else:
-            self.restart_block(active_slots, time, u0)
+        self.restart_block(live, start, None if self._continues(u0) else u0)
         for hook in self.hooks:
             hook.post_setup(step=None, level_number=None)
         for S in self.MS:
             self._hook('pre_run', S)
-        while any(active):
-            MS_active = [self.MS[p] for p in active_slots]
-            done = False
-            while not done:
-                done = self.pfasst(MS_active)
-            last_step = self.MS[active_slots[-1]]
-            uend = last_step.levels[0].uend
-            time[active_slots[0]] = time[active_slots[-1]] + self.MS[active_slots[-1]].dt
-            for i in range(1, len(active_slots)):
-                time[active_slots[i]] = time[active_slots[i] - 1] + self.MS[active_slots[i] - 1].dt
-            active = [time[p] < Tend - 10 * np.finfo(float).eps for p in slots]
-            active_slots = list(itertools.compress(slots, active))
-            if (active_slots and self.MS[active_slots[0]] is last_step and len(active_slots) == 1
-                    and hasattr(last_step.levels[0], 'advance')):
-                # one step per block: the next block starts on the same level from its own end value
-                self.restart_block(active_slots, time, None)
+        uend = None
+        while live:
+            block = [self.MS[p] for p in live]
+            while not self.pfasst(block):
+                pass
+            tail = block[-1]
+            uend = tail.levels[0].uend
+            start, nxt = self._schedule(start[live[-1]] + tail.dt, Tend)
+            if nxt == [0] and live == [0] and hasattr(tail.levels[0], 'advance'):
+                live = nxt   # one step per block: the next block starts on the same level from its own end value
+                self.restart_block(live, start, None)
                 continue
-            # the view into the last step's UEND slab is about to be reset: keep the value in an owning
-            # buffer that lives as long as the controller (allocating 8.6 GB per block costs ~0.25 s)
-            if self._uend_buf is None:
-                self._uend_buf = type(uend)(uend)
-            else:
-                self._uend_buf[:] = uend
-            uend = self._uend_buf
-            self.restart_block(active_slots, time, uend)
+            live = nxt
+            if live:
+                # the view into the last step's UEND slab is about to be reset: keep the value in an owning buffer that
+                # lives as long as the controller (allocating 8.6 GB per block costs ~0.25 s)
+                if self._uend_buf is None:
+                    self._uend_buf = type(uend)(uend)
+                else:
+                    self._uend_buf[:] = uend
+                uend = self._uend_buf
+                self.restart_block(live, start, uend)
         for S in self.MS:
             self._hook('post_run', S)
         # a fresh object per run, like the reference (controller_nonMPI.py:148,167): neither the persistent buffer nor a
         # view into a level's UEND slab leaves the controller (one copy per run, not per block)
-        P = self.MS[0].levels[0].prob
-        out = P.dtype_u(uend)
-        eng = getattr(self.MS[-1].levels[0], '_engine_obj', None) if num_procs == 1 else None
-        if eng is not None and hasattr(eng, 'end_value_generation'):
-            gen = eng.end_value_generation()
-            if gen > 0:
-                out._lineage = (id(eng), gen)   # (cleared by any write to `out`: hip_mesh._wrote)
+        out = self.MS[0].levels[0].prob.dtype_u(uend)
+        eng = getattr(self.MS[-1].levels[0], '_engine_obj', None) if len(self.MS) == 1 else None
+        gen = eng.end_value_generation() if eng is not None and hasattr(eng, 'end_value_generation') else 0
+        if gen > 0:
+            out._lineage = (id(eng), gen)   # (cleared by any write to `out`: hip_mesh._wrote)
         return out, self.return_stats()
 
     # controller_nonMPI.py:169-224
     def restart_block(self, active_slots, time, u0):
-        for j in range(len(active_slots)):
-            p = active_slots[j]
+        for j, p in enumerate(active_slots):
             S = self.MS[p]
             S.status.slot = p
             S.prev = self.MS[active_slots[j - 1]]
             S.reset_step()
-            S.status.first = active_slots.index(p) == 0
-            S.status.last = active_slots.index(p) == len(active_slots) - 1
+            S.status.first, S.status.last = j == 0, j == len(active_slots) - 1
             if u0 is None:
                 S.levels[0].advance()
             else:
                 S.init_step(u0)
-            S.status.done = False
-            S.status.prev_done = False
+            S.status.done = S.status.prev_done = S.status.force_done = False
             S.status.iter = 0
             S.status.stage = 'SPREAD'
-            S.status.force_done = False
             S.status.time_size = len(active_slots)
-            for l in S.levels:
-                l.tag = None
-                l.status.sweep = 1
-        for p in active_slots:
-            for lvl in self.MS[p].levels:
+            for lvl in S.levels:
+                lvl.tag = None
+                lvl.status.sweep = 1
                 lvl.status.time = time[p]
 
-    # controller_nonMPI.py:226-295
+    # ---- the forward hand-over between steps of one process (controller_nonMPI.py:226-295) ------------------------
     def send_full(self, S, level=None, add_to_stats=False):
         self._hook('pre_comm', S, level)
         if not S.status.last:
@@ -200,163 +248,118 @@ class controller_nonMPI(_ControllerBase):
                 target.f[0] = target.prob.eval_f(target.u[0], target.time)
         self._hook('post_comm', S, level, add_to_stats=add_to_stats)
 
-    # controller_nonMPI.py:297-332
+    # ---- interpreter -----------------------------------------------------------------------------------------------
     def pfasst(self, local_MS_active):
-        stages = [S.status.stage for S in local_MS_active if S.status.stage != 'DONE']
-        if stages[1:] == stages[:-1]:
-            stage = stages[0]
-        else:
+        """one stage for all steps that still run; True when the block is done (controller_nonMPI.py:297-332)"""
+        running = [S for S in local_MS_active if S.status.stage != 'DONE']
+        names = {S.status.stage for S in running}
+        if len(names) > 1:
             raise ControllerError('not all stages are equal')
-        MS_running = [S for S in local_MS_active if S.status.stage != 'DONE']
-        switcher = {'SPREAD': self.spread, 'PREDICT': self.predict, 'IT_CHECK': self.it_check,
-                    'IT_FINE': self.it_fine, 'IT_DOWN': self.it_down, 'IT_COARSE': self.it_coarse, 'IT_UP': self.it_up}
-        if stage not in switcher:
-            raise ControllerError('Unknown stage, got %s' % stage)
-        switcher[stage](MS_running)
+        for stage in names:
+            if stage not in self.stages:
+                raise ControllerError('Unknown stage, got %s' % stage)
+            self._run_stage(self.stages[stage], running)
         return all(S.status.done for S in local_MS_active)
 
-    def spread(self, local_MS_running):
-        for S in local_MS_running:
-            self._hook('pre_step', S)
-            S.levels[0].sweep.predict()
-            S.status.stage = 'PREDICT' if len(S.levels) > 1 else 'IT_CHECK'
+    def _run_stage(self, phases, running):
+        for phase in phases:
+            if phase[0][0].startswith('all_'):
+                getattr(self, '_op_' + phase[0][0])(running, *phase[0][1:])
+                continue
+            calls = [(getattr(self, '_op_' + op[0]), op[1:]) for op in phase]
+            for S in running:
+                for fn, args in calls:
+                    fn(S, running, *args)
 
-    # controller_nonMPI.py:358-477
-    def predict(self, local_MS_running):
-        for S in local_MS_running:
-            self._hook('pre_predict', S)
-        pt = self.params.predict_type
-        if pt is None:
-            pass
-        elif pt == 'fine_only':
-            for S in local_MS_running:
-                S.levels[0].sweep.update_nodes()
-        elif pt == 'pfasst_burnin':
-            for S in local_MS_running:
-                for l in range(1, len(S.levels)):
-                    S.transfer(source=S.levels[l - 1], target=S.levels[l])
-            for q in range(len(local_MS_running)):
-                for p in range(q, len(local_MS_running)):
-                    S = local_MS_running[p]
-                    S.levels[-1].sweep.update_nodes()
-                    self.send_full(S, level=len(S.levels) - 1)
-                for p in range(q + 1, len(local_MS_running)):
-                    S = local_MS_running[p]
-                    self.recv_full(S, level=len(S.levels) - 1, add_to_stats=(p == len(local_MS_running) - 1))
-            for S in local_MS_running:
-                for l in range(len(S.levels) - 1, 0, -1):
-                    S.transfer(source=S.levels[l], target=S.levels[l - 1])
-                self.send_full(S, level=0)
-                self.recv_full(S, level=0)
-            for S in local_MS_running:
-                S.levels[0].sweep.update_nodes()
-        elif pt == 'fmg':
-            raise NotImplementedError('FMG predictor is not yet implemented')
+    # ---- operations ------------------------------------------------------------------------------------------------
+    def _op_hook(self, S, running, name, level):
+        self._hook(name, S, level)
+
+    def _op_goto(self, S, running, stage):
+        S.status.stage = stage
+
+    def _op_predict(self, S, running):
+        S.levels[0].sweep.predict()
+
+    def _op_send(self, S, running, level, add_to_stats):
+        self.send_full(S, level=level, add_to_stats=add_to_stats)
+
+    def _op_recv(self, S, running, level, add_to_stats):
+        self.recv_full(S, level=level, add_to_stats=add_to_stats)
+
+    def _op_residual(self, S, running, level, stage):
+        S.levels[level].sweep.compute_residual(stage=stage)
+
+    def _op_sweep(self, S, running, level):
+        S.levels[level].sweep.update_nodes()
+
+    def _op_coeffs(self, S, running, k):
+        S.levels[0].sweep.updateVariableCoeffs(k)
+
+    def _op_sweep_count(self, S, running, inc):
+        S.levels[0].status.sweep = S.levels[0].status.sweep + 1 if inc else 0
+
+    def _op_transfer(self, S, running, src, dst):
+        S.transfer(source=S.levels[src], target=S.levels[dst])
+
+    def _op_judge(self, S, running):
+        """verdict of this step alone (controller_nonMPI.py:497-507)"""
+        if S.status.iter > 0:
+            self._hook('post_iteration', S)
+        S.status.done = check_convergence(S)
+        S.status.force_continue = False
+
+    def _op_chain(self, S, running):
+        """a step is done only if its predecessor is (controller_nonMPI.py:509-543); then either the next iteration or
+        the end point"""
+        if not S.status.first:
+            S.status.prev_done = S.prev.status.done
+            S.status.done = S.status.done and S.status.prev_done
+        if self.params.all_to_done:
+            S.status.done = all(T.status.done for T in running)
+        if S.status.done:
+            S.levels[0].sweep.compute_end_point()
+            self._hook('post_step', S)
+            S.status.stage = 'DONE'
+            return
+        S.status.iter += 1
+        self._hook('pre_iteration', S)
+        if self.nlevels > 1:
+            S.status.stage = 'IT_DOWN'
         else:
-            raise ControllerError('Wrong predictor type, got %s' % pt)
-        for S in local_MS_running:
-            self._hook('post_predict', S)
-        for S in local_MS_running:
-            S.status.stage = 'IT_CHECK'
+            S.status.stage = 'IT_FINE' if (len(running) == 1 or self.params.mssdc_jac) else 'IT_COARSE'
 
-    # controller_nonMPI.py:479-543
-    def it_check(self, local_MS_running):
-        for S in local_MS_running:
+    def _op_all_predictor(self, running):
+        """controller_nonMPI.py:358-477: nothing, one fine sweep, or the burn-in on the coarsest level (step p sweeps
+        p+1 times there, receiving between sweeps) followed by the way back up"""
+        kind = self.params.predict_type
+        if kind is None:
+            return
+        if kind == 'fine_only':
+            for S in running:
+                S.levels[0].sweep.update_nodes()
+            return
+        if kind == 'fmg':
+            raise NotImplementedError('FMG predictor is not yet implemented')
+        if kind != 'pfasst_burnin':
+            raise ControllerError('Wrong predictor type, got %s' % kind)
+        lc, n = self.nlevels - 1, len(running)
+        for S in running:
+            for l in range(lc):
+                S.transfer(source=S.levels[l], target=S.levels[l + 1])
+        for wave in range(n):
+            for S in running[wave:]:
+                S.levels[lc].sweep.update_nodes()
+                self.send_full(S, level=lc)
+            for p in range(wave + 1, n):
+                self.recv_full(running[p], level=lc, add_to_stats=(p == n - 1))
+        for S in running:
+            for l in range(lc, 0, -1):
+                S.transfer(source=S.levels[l], target=S.levels[l - 1])
             self.send_full(S, level=0)
             self.recv_full(S, level=0)
-            S.levels[0].sweep.compute_residual(stage='IT_CHECK')
-        for S in local_MS_running:
-            if S.status.iter > 0:
-                self._hook('post_iteration', S)
-            S.status.done = check_convergence(S)
-            S.status.force_continue = False
-        for S in local_MS_running:
-            if not S.status.first:
-                S.status.prev_done = S.prev.status.done
-                S.status.done = S.status.done and S.status.prev_done
-            if self.params.all_to_done:
-                S.status.done = all(T.status.done for T in local_MS_running)
-            if not S.status.done:
-                S.status.iter += 1
-                self._hook('pre_iteration', S)
-                if len(S.levels) > 1:
-                    S.status.stage = 'IT_DOWN'
-                elif len(local_MS_running) == 1 or self.params.mssdc_jac:
-                    S.status.stage = 'IT_FINE'
-                else:
-                    S.status.stage = 'IT_COARSE'
-            else:
-                S.levels[0].sweep.compute_end_point()
-                self._hook('post_step', S)
-                S.status.stage = 'DONE'
-
-    # controller_nonMPI.py:545-582
-    def it_fine(self, local_MS_running):
-        for S in local_MS_running:
-            S.levels[0].status.sweep = 0
-        for k in range(self.nsweeps[0]):
-            for S in local_MS_running:
-                S.levels[0].status.sweep += 1
-            for S in local_MS_running:
-                self.send_full(S, level=0)
-                self.recv_full(S, level=0, add_to_stats=(k == self.nsweeps[0] - 1))
-            for S in local_MS_running:
-                self._hook('pre_sweep', S)
-                S.levels[0].sweep.updateVariableCoeffs(k + 1)
-                S.levels[0].sweep.update_nodes()
-                S.levels[0].sweep.compute_residual(stage='IT_FINE')
-                self._hook('post_sweep', S)
-        for S in local_MS_running:
-            S.status.stage = 'IT_CHECK'
-
-    # controller_nonMPI.py:584-634
-    def it_down(self, local_MS_running):
-        for S in local_MS_running:
-            S.transfer(source=S.levels[0], target=S.levels[1])
-        for l in range(1, self.nlevels - 1):
-            for _ in range(self.nsweeps[l]):
-                for S in local_MS_running:
-                    self.send_full(S, level=l)
-                    self.recv_full(S, level=l)
-                for S in local_MS_running:
-                    self._hook('pre_sweep', S, l)
-                    S.levels[l].sweep.update_nodes()
-                    S.levels[l].sweep.compute_residual(stage='IT_DOWN')
-                    self._hook('post_sweep', S, l)
-            for S in local_MS_running:
-                S.transfer(source=S.levels[l], target=S.levels[l + 1])
-        for S in local_MS_running:
-            S.status.stage = 'IT_COARSE'
-
-    # controller_nonMPI.py:636-666
-    def it_coarse(self, local_MS_running):
-        for S in local_MS_running:
-            lc = len(S.levels) - 1
-            self.recv_full(S, level=lc)
-            self._hook('pre_sweep', S, lc)
-            S.levels[-1].sweep.update_nodes()
-            S.levels[-1].sweep.compute_residual(stage='IT_COARSE')
-            self._hook('post_sweep', S, lc)
-            self.send_full(S, level=lc, add_to_stats=True)
-            S.status.stage = 'IT_UP' if len(S.levels) > 1 else 'IT_CHECK'
-
-    # controller_nonMPI.py:668-689
-    def it_up(self, local_MS_running):
-        for l in range(self.nlevels - 1, 0, -1):
-            for S in local_MS_running:
-                S.transfer(source=S.levels[l], target=S.levels[l - 1])
-            if l - 1 > 0:
-                for k in range(self.nsweeps[l - 1]):
-                    for S in local_MS_running:
-                        self.send_full(S, level=l - 1)
-                        self.recv_full(S, level=l - 1, add_to_stats=(k == self.nsweeps[l - 1] - 1))
-                    for S in local_MS_running:
-                        self._hook('pre_sweep', S, l - 1)
-                        S.levels[l - 1].sweep.update_nodes()
-                        S.levels[l - 1].sweep.compute_residual(stage='IT_UP')
-                        self._hook('post_sweep', S, l - 1)
-        for S in local_MS_running:
-            S.status.stage = 'IT_FINE'
+        for S in running:
+            S.levels[0].sweep.update_nodes()
 
 
 class _WorkList:

@@ -56,8 +56,10 @@ static int store_spectra(sdc_ctx* c, bool last_only);               // spectra o
     } while (0)
 static int ensure_u0(sdc_ctx* c) {
     if (c->u0_spec_only) {  // the start value exists as its transform only (sdc_advance after a deferred end value)
+        int rcs = spectrum_to_field(c, c->S0, c->U);
+        if (rcs != SDC_OK) return rcs;  // (still "spectrum only": nobody reads a half-written U[0])
         c->u0_spec_only = false;
-        return spectrum_to_field(c, c->S0, c->U);
+        return SDC_OK;
     }
     if (c->u0_src) {
         const double* src = c->u0_src;
@@ -66,10 +68,14 @@ static int ensure_u0(sdc_ctx* c) {
     }
     return SDC_OK;
 }
+// nullptr when the start value could not be produced (c->u0_rc, c->err say why): callers go through U0R
 static inline const double* u0r(sdc_ctx* c) {
-    if (c->u0_spec_only) (void)ensure_u0(c);  // (a failure here is a HIP failure the very next launch reports)
+    if (c->u0_spec_only && (c->u0_rc = ensure_u0(c)) != SDC_OK) return nullptr;
     return c->u0_src ? c->u0_src : c->U;
 }
+#define U0R(c, var)                        \
+    const double* var = u0r(c);            \
+    if (!var) return (c)->u0_rc
 #define ENSURE_U0(c)                       \
     do {                                   \
         int rcu_ = ensure_u0(c);           \
@@ -82,6 +88,7 @@ static int materialize_uend(sdc_ctx* c) {
     if (!(c->uend_gen >= 0 && c->uend_gen == c->spec_gen)) return SDC_OK;  // (its spectrum is gone: nothing to deliver)
     int rcs = store_spectra(c, true);
     if (rcs != SDC_OK) return rcs;
+    c->uend_ev_recorded = false;  // UEND is written NOW: an event recorded for an earlier end value does not cover it
     return spectrum_to_field(c, c->SL, c->UEND);
 }
 #define MATERIALIZE_UEND(c)                \
@@ -638,7 +645,8 @@ static int spec_residual(sdc_ctx* c, double dt, unsigned long long* norms) {
     if (!c->spec0_valid) {
         FieldPtrs p0;
         memset(&p0, 0, sizeof p0);
-        p0.in[0] = u0r(c);
+        U0R(c, u0p);
+        p0.in[0] = u0p;
         int rc0 = fwd_transform(c, 1, p0, c->S0, 0);
         if (rc0 != SDC_OK) return rc0;
         c->spec0_valid = true;
@@ -1189,7 +1197,8 @@ static int ensure_spec_cache(sdc_ctx* c) {
 static int launch_spread(sdc_ctx* c, int guess, double fill_u, double fill_f, bool reduce_f0) {
     SpreadArgs a;
     memset(&a, 0, sizeof a);
-    a.u0 = u0r(c);
+    U0R(c, u0p);
+    a.u0 = u0p;
     a.f0 = c->F;
     a.profile = c->profile;
     a.U = c->U;
@@ -1215,8 +1224,9 @@ static int launch_spread(sdc_ctx* c, int guess, double fill_u, double fill_f, bo
 static int materialize(sdc_ctx* c, bool need_u, bool need_f) {
     if (c->spread_pending && (need_u || need_f)) {
         if (c->f0_pending) {  // the copies are copies of F[0]
+            U0R(c, u0p);
             c->f0_pending = false;
-            int rc0 = sdc_eval_f(c, u0r(c), c->gvals[0], c->F, c->ncomp == 2 ? c->F + c->N : nullptr);
+            int rc0 = sdc_eval_f(c, u0p, c->gvals[0], c->F, c->ncomp == 2 ? c->F + c->N : nullptr);
             if (rc0 != SDC_OK) return rc0;
         }
         c->spread_pending = false;
@@ -1256,8 +1266,9 @@ int sdc_materialize(sdc_ctx* c, int slot, int m) {
     }
     if (slot == SDC_SLOT_F && m == 0) {
         if (!c->f0_pending) return SDC_OK;
+        U0R(c, u0p);
         c->f0_pending = false;
-        return sdc_eval_f(c, u0r(c), c->gvals[0], c->F, c->ncomp == 2 ? c->F + c->N : nullptr);
+        return sdc_eval_f(c, u0p, c->gvals[0], c->F, c->ncomp == 2 ? c->F + c->N : nullptr);
     }
     if (slot < 0) ENSURE_U0(c);  // "everything": all of the real-space state is about to be used as it is stored
     if (slot < 0 && c->f0_pending) {
@@ -1359,6 +1370,7 @@ int sdc_set_unlocked(sdc_ctx* c, int unlocked) {
 
 int sdc_set_spectral_reuse(sdc_ctx* c, int on) {
     if (!c) return SDC_ERR_PARAM;
+    MATERIALIZE_UEND(c);                    // ... and of a put-off end value
     int rcm = materialize(c, true, false);  // the cache may be the only holder of U[1..M]
     if (rcm != SDC_OK) return rcm;
     c->reuse = on != 0;
@@ -1450,6 +1462,9 @@ int sdc_predict(sdc_ctx* c, double t, double dt, int guess, double fill_u, doubl
     if (!c) return SDC_ERR_PARAM;
     if (!c->have_coeffs) return fail(c, SDC_ERR_STATE, "coefficients not set (sdc_set_coeffs)");
     if (guess < 0 || guess > 3) return fail(c, SDC_ERR_PARAM, "initial_guess option %d not implemented", guess);
+    // a put-off end value is the inverse transform of the iterate this predictor is about to drop (the reference's
+    // predict leaves L.uend alone, core/sweeper.py:125-162)
+    MATERIALIZE_UEND(c);
     // all nodes equal u0 and f does not depend on t: every f_j equals f(u0), so the node residuals are
     // dt * |sum_j Q[m][j]| * max|f(u0)| and the fill kernel can reduce max|f(u0)| on the way
     const bool spread_res = guess == SDC_GUESS_SPREAD && c->expl_kind != SDC_EXPL_FORCING && !c->tau_active;
@@ -1473,7 +1488,8 @@ int sdc_predict(sdc_ctx* c, double t, double dt, int guess, double fill_u, doubl
         constexpr int RPT = 4;
         Stencil3Args s3;
         memset(&s3, 0, sizeof s3);
-        s3.in[0] = u0r(c);
+        U0R(c, u0p);
+        s3.in[0] = u0p;
         for (int k = 0; k < 3; ++k) {
             s3.wI[k] = c->st[0].w[k];
             s3.wE[k] = explS ? c->st[1].w[k] : 0.0;
@@ -1491,7 +1507,8 @@ int sdc_predict(sdc_ctx* c, double t, double dt, int guess, double fill_u, doubl
         HIPCHK(c, hipGetLastError());
         c->f0_pending = true;
     } else {
-        rc = sdc_eval_f(c, u0r(c), c->gvals[0], c->F, c->ncomp == 2 ? c->F + c->N : nullptr);
+        U0R(c, u0p);
+        rc = sdc_eval_f(c, u0p, c->gvals[0], c->F, c->ncomp == 2 ? c->F + c->N : nullptr);
         if (rc != SDC_OK) return rc;
     }
     if (lazy_spread) {
@@ -1711,7 +1728,8 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
         if (!c->spec_valid) c->spec_virtual = 0;
         if (!c->spec0_valid) {
             STORE_SPECTRA(c, false);  // (an iterate that was not stored is a function of the OLD S0)
-            p.in[0] = u0r(c);
+            U0R(c, u0p);
+            p.in[0] = u0p;
             int rc0 = fwd_transform(c, 1, p, c->S0, 0);
             if (rc0 != SDC_OK) return rc0;
             c->spec0_valid = true;
@@ -2082,8 +2100,9 @@ int sdc_residual(sdc_ctx* c, double dt, int type, double* node_norms, double* re
         if (rc != SDC_OK) return rc;
     }
     if (type >= SDC_RES_FULL_REL) {
+        U0R(c, u0p);
         LaunchTimer lt(c, "amax");
-        hipLaunchKernelGGL(k_amax, dim3(grid_for(c->N, 256)), dim3(256), 0, c->stream, u0r(c), c->N, c->red + 8);
+        hipLaunchKernelGGL(k_amax, dim3(grid_for(c->N, 256)), dim3(256), 0, c->stream, u0p, c->N, c->red + 8);
     }
     HIPCHK(c, hipMemcpyAsync(c->red_host, c->red, sizeof(unsigned long long) * 16, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2122,6 +2141,7 @@ int sdc_end_point(sdc_ctx* c, double dt, int do_coll_update) {
         int rcf = uend_write_fence(c);
         if (rcf != SDC_OK) return rcf;
     }
+    c->uend_ev_recorded = false;  // (whatever is written below is covered by a fresh event, sdc_stream_wait_uend)
     if (!do_coll_update) {
         c->uend_gen = -1;
         c->uend_pending = false;
@@ -2141,7 +2161,9 @@ int sdc_end_point(sdc_ctx* c, double dt, int do_coll_update) {
             return rci;
         }
         // a pending spread means U[M] equals U[0]
-        return sdc_vec_copy(c, c->N, c->spread_pending ? u0r(c) : c->U + (size_t)c->M * c->N, c->UEND);
+        if (!c->spread_pending) return sdc_vec_copy(c, c->N, c->U + (size_t)c->M * c->N, c->UEND);
+        U0R(c, u0p);
+        return sdc_vec_copy(c, c->N, u0p, c->UEND);
     }
     c->uend_gen = -1;
     c->uend_pending = false;
@@ -2220,6 +2242,7 @@ int sdc_advance(sdc_ctx* c) {
 int sdc_set_early_end_point(sdc_ctx* c, int on) {
     if (!c) return SDC_ERR_PARAM;
     c->early_uend = on != 0;
+    c->uend_ev_recorded = false;
     return SDC_OK;
 }
 

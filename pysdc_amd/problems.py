@@ -108,6 +108,48 @@ class Problem:
         return self._engine
 
 
+def _as_axis_tuple(value, what, ndim=None):
+    """int -> one entry per axis, tuple -> itself; anything else is a ProblemError (messages as in generic_ND_FD.py:99-132,
+    they are observable)"""
+    if type(value) is int:
+        return (value,) * (ndim or 1)
+    if type(value) is tuple:
+        return value
+    raise ProblemError(f'{what} should be either tuple or int')
+
+
+# what each boundary type asks of the number of points per axis: (predicate on nvar that must hold, message)
+_POINTS_RULE = {
+    'periodic': (lambda nv: nv % 2 == 0, 'the setup requires nvars = 2^p per dimension'),
+    'dirichlet-zero': (lambda nv: nv % 2 == 1, 'setup requires nvars = 2^p - 1'),
+}
+
+
+def _grid_spec(nvars, freq, bc):
+    """grid description of the finite-difference problems, normalised: (nvars tuple, freq tuple, bc).  Own restatement of
+    the checks the reference makes on its constructor arguments (generic_ND_FD.py:99-132): up to three equal axes, one
+    frequency per axis, even frequencies and point counts on periodic grids, odd point counts with dirichlet-zero; a 1-D
+    grid with freq = -1 (Gaussian start value) is periodic whatever bc says."""
+    grid = _as_axis_tuple(nvars, 'nvars')
+    if type(freq) not in (int, tuple):
+        raise ProblemError('freq should be either tuple or int')
+    if len(grid) > 3:
+        raise ProblemError(f'can work with up to three dimensions, got {len(grid)}')
+    modes = _as_axis_tuple(freq, 'freq', len(grid))
+    if len(modes) != len(grid):
+        raise ProblemError(f'len(freq)={len(modes)}, different to ndim={len(grid)}')
+    if len(grid) == 1 and -1 in modes[:1]:
+        bc = 'periodic'
+    elif bc == 'periodic' and any(f % 2 for f in modes):
+        raise ProblemError('need even number of frequencies due to periodic BCs')
+    ok, msg = _POINTS_RULE.get(bc, (lambda nv: True, ''))
+    if not all(ok(nv) for nv in grid):
+        raise ProblemError(msg)
+    if len(set(grid)) > 1:
+        raise ProblemError('need a square domain, got %s' % (grid,))
+    return grid, modes, bc
+
+
 class GenericNDimFinDiff(Problem):
     """du/dt = A u, A a periodic finite-difference operator applied matrix-free on the device."""
 
@@ -115,32 +157,8 @@ class GenericNDimFinDiff(Problem):
 
     def __init__(self, nvars=512, coeff=1.0, derivative=1, freq=2, stencil_type='center', order=2, lintol=1e-12,
                  liniter=10000, solver_type='direct', bc='periodic', bcParams=None):
-        if type(nvars) not in [int, tuple]:
-            raise ProblemError('nvars should be either tuple or int')
-        if type(freq) not in [int, tuple]:
-            raise ProblemError('freq should be either tuple or int')
-        if type(nvars) is int:
-            nvars = (nvars,)
+        nvars, freq, bc = _grid_spec(nvars, freq, bc)
         ndim = len(nvars)
-        if ndim > 3:
-            raise ProblemError(f'can work with up to three dimensions, got {ndim}')
-        if type(freq) is int:
-            freq = (freq,) * ndim
-        if len(freq) != ndim:
-            raise ProblemError(f'len(freq)={len(freq)}, different to ndim={ndim}')
-        for f in freq:
-            if ndim == 1 and f == -1:
-                bc = 'periodic'
-                break
-            if f % 2 != 0 and bc == 'periodic':
-                raise ProblemError('need even number of frequencies due to periodic BCs')
-        for nvar in nvars:
-            if nvar % 2 != 0 and bc == 'periodic':
-                raise ProblemError('the setup requires nvars = 2^p per dimension')
-            if (nvar + 1) % 2 != 0 and bc == 'dirichlet-zero':
-                raise ProblemError('setup requires nvars = 2^p - 1')
-        if ndim > 1 and nvars[1:] != nvars[:-1]:
-            raise ProblemError('need a square domain, got %s' % (nvars,))
         if bc not in ('periodic', 'dirichlet-zero'):
             raise ProblemError(f'the MI355X engine implements periodic and dirichlet-zero boundaries, got bc={bc!r}')
         if bc == 'dirichlet-zero' and (order != 2 or derivative != 2 or stencil_type != 'center'):

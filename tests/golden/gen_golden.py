@@ -11,7 +11,7 @@ own entry points, switched on by environment variables (or call the function aft
 GOLDEN_FFT=1 fft_transfer_main (transfer_fft.npz, runs_ac_fft.npz), GOLDEN_RELAY=1 relay_main (runs_relay.npz),
 GOLDEN_CG=1 cg_main (sweeps_cg.npz), GOLDEN_VDPJ=1 vdp_jacobian_main (vdp_jacobian.npz), GOLDEN_DML=1
 dirichlet_ml_main (transfer_dirichlet.npz, runs_ml_dirichlet.npz), GOLDEN_GUESS=1 guess_main (sweeps_guess.npz), GOLDEN_SKIP=1 skip_main (runs_skip.npz), GOLDEN_RELAY8=1 relay8_main (runs_relay8.npz),
-GOLDEN_BIG3D=1 big3d_main (sweeps_big3d.npz), GOLDEN_CFG5=1 cfg5_main (runs_cfg5.npz), GOLDEN_ML8=1 ml8_main (runs_ml8.npz), GOLDEN_DND=1 dirichlet_nd_main (sweeps_dirichlet_nd.npz, runs_dirichlet_nd.npz), GOLDEN_NSW2=1 nsweeps2_main (runs_nsweeps2.npz);
+GOLDEN_BIG3D=1 big3d_main (sweeps_big3d.npz), GOLDEN_CFG5=1 cfg5_main (runs_cfg5.npz), GOLDEN_ML8=1 ml8_main (runs_ml8.npz), GOLDEN_DND=1 dirichlet_nd_main (sweeps_dirichlet_nd.npz, runs_dirichlet_nd.npz), GOLDEN_NSW2=1 nsweeps2_main (runs_nsweeps2.npz), GOLDEN_PIN1024=1 pin1024_main (sweeps_pin1024.npz, 20 minutes);
 GOLDEN_ML=0 skips the multi-level block.
 
 ``qmat`` (third-party, absent here) is replaced by oracle/qmat_shim, which forwards to
@@ -896,3 +896,58 @@ def nsweeps2_main():
 
 if __name__ == '__main__' and os.environ.get('GOLDEN_NSW2', '0') == '1':
     nsweeps2_main()
+
+
+def _thin(v, step):
+    """every step-th point per spatial axis at staggered offsets (leading axes - nodes, components - are kept)"""
+    v = np.asarray(v)
+    return v[..., 1::step].copy() if v.ndim <= 2 else v[..., 1::step, (step // 2 + 1)::step].copy()
+
+
+def _reduce_fields(full, step, keep_full=()):
+    """a sweep case with its node fields replaced by a subsample plus max / l2 norms of the full fields (a 1024^2 case
+    would otherwise be 50 MB per snapshot); u0 is rebuilt by the test from the seed and checked against `u0_sub`"""
+    out = {}
+    for k, v in full.items():
+        if k in keep_full:
+            out[k] = v
+        elif k.endswith('_u') or k.endswith('_f'):
+            flat = v.reshape(v.shape[0], -1)
+            out[k + '_sub'] = _thin(v, step)
+            out[k + '_max'] = np.max(np.abs(flat), axis=1)
+            out[k + '_l2'] = np.sqrt(np.sum(flat ** 2, axis=1))
+        elif '_uend_' in k or k == 'u0':
+            out[k + '_sub'] = _thin(v, step)
+            out[k + '_max'] = np.array(np.max(np.abs(v)))
+            out[k + '_l2'] = np.array(np.sqrt(np.sum(np.asarray(v) ** 2)))
+        else:
+            out[k] = v
+    return out
+
+
+def pin1024_main():
+    """the template instances the bench launches (line length 1024, M=5 nodes: k_spec_z<1024,5,...>, the strided passes
+    <1024,8>) pinned to the reference on FULL spectra: heat 1-D N=1024 and 2-D 1024^2, M=5 RADAU-RIGHT, IE, the stiffness
+    of the headline workload (dt*nu/dx^2 = 26.2: dt = 2.5e-4 at nu = 0.1), input = sine mode + 1e-3 seeded noise, three
+    sweeps with the reference's SuperLU solve (76 s per solve at 1024^2: 20 minutes), plus a 1-D run to restol.  A 3-D
+    1024^3 field that does not depend on one axis reduces to the 2-D problem exactly (the stencil of that axis sums to
+    zero), so the 2-D case also pins the 3-D kernels at the bench's own size, one pair of axes at a time
+    (tests/test_gpu_fullsize.py)."""
+    RR = dict(quad_type='RADAU-RIGHT')
+    dt = 2.5e-4
+    sw = dict(num_nodes=5, QI='IE', **RR)
+    h1 = dict(nvars=1024, nu=0.1, freq=2, order=2, bc='periodic')
+    c1 = sweep_case('pin_heat1d_1024_M5_IE', 'heat_unforced', h1, 'generic_implicit', sw, dt, t0=0.0, nsweeps=3, seed=0,
+                    u0_kind='exact')
+    r1 = run_case('pin_heat1d_1024_run', 'heat_unforced', h1, 'generic_implicit', sw, dict(dt=dt, restol=1e-10), 50, 0.0,
+                  3 * dt, seed=0)
+    h2 = dict(nvars=(1024, 1024), nu=0.1, freq=2, order=2, bc='periodic', solver_type='direct')
+    full = sweep_case('pin_heat2d_1024_M5_IE', 'heat_unforced', h2, 'generic_implicit', sw, dt, t0=0.0, nsweeps=3, seed=0,
+                      u0_kind='exact')
+    c2 = _reduce_fields(full, 16)
+    c2['k3_uend_0_q'] = np.asarray(full['k3_uend_0'])[1::4, 3::4].copy()     # a denser look at the end value
+    save('sweeps_pin1024.npz', [c1, r1, c2])
+
+
+if __name__ == '__main__' and os.environ.get('GOLDEN_PIN1024', '0') == '1':
+    pin1024_main()

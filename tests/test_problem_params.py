@@ -1,0 +1,33 @@
+"""Constructor-argument checks of the finite-difference problems: same error type and message as the reference
+(pySDC/implementations/problem_classes/generic_ND_FD.py:99-132) for the same arguments - the expected texts below were
+recorded from the reference in the build container."""
+import pytest
+
+from pysdc_amd.errors import ProblemError
+from pysdc_amd.problems import _grid_spec
+
+BAD = [
+    (dict(nvars=[64, 64], freq=2, bc='periodic'), 'nvars should be either tuple or int'),
+    (dict(nvars=64, freq=2.0, bc='periodic'), 'freq should be either tuple or int'),
+    (dict(nvars=(8, 8, 8, 8), freq=2, bc='periodic'), 'can work with up to three dimensions, got 4'),
+    (dict(nvars=(8, 8), freq=(2, 2, 2), bc='periodic'), 'len(freq)=3, different to ndim=2'),
+    (dict(nvars=(8, 8), freq=(2, 3), bc='periodic'), 'need even number of frequencies due to periodic BCs'),
+    (dict(nvars=(8, 8), freq=(-1, 2), bc='periodic'), 'need even number of frequencies due to periodic BCs'),
+    (dict(nvars=63, freq=2, bc='periodic'), 'the setup requires nvars = 2^p per dimension'),
+    (dict(nvars=64, freq=1, bc='dirichlet-zero'), 'setup requires nvars = 2^p - 1'),
+    (dict(nvars=(8, 16), freq=2, bc='periodic'), 'need a square domain, got (8, 16)'),
+]
+
+
+@pytest.mark.parametrize('kw,msg', BAD)
+def test_rejected_like_the_reference(kw, msg):
+    with pytest.raises(ProblemError) as e:
+        _grid_spec(**kw)
+    assert msg in str(e.value)
+
+
+def test_accepted_and_normalised():
+    assert _grid_spec(64, 2, 'periodic') == ((64,), (2,), 'periodic')
+    assert _grid_spec((16, 16, 16), 4, 'periodic') == ((16, 16, 16), (4, 4, 4), 'periodic')
+    assert _grid_spec(63, 3, 'dirichlet-zero') == ((63,), (3,), 'dirichlet-zero')     # odd frequencies are fine there
+    assert _grid_spec(64, -1, 'dirichlet-zero') == ((64,), (-1,), 'periodic')          # 1-D Gaussian start value
