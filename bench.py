@@ -1,7 +1,14 @@
 """Benchmark of the SDC sweep path (BASELINE.json metric): time-steps/s and SDC-iterations/s of the 3-D heat
 equation, finite differences, M=5 Gauss-Radau nodes, implicit (generic_implicit) sweeps, f64.
 
-  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1 starts by itself: the parent process - before anything touches a GPU - starts one rank process per GPU (RANK /
+LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment), passes rank 0's JSON line on and exits non-zero with a JSON
+`error` line if a rank fails or the job times out.  Launched under torch.distributed.run (WORLD_SIZE already in the
+environment) every process is a rank right away.  `--backend gloo --same-device` puts all ranks on GPU 0 with the
+shared-memory wire of the C-ABI communicator (RCCL refuses two ranks on one device): the whole multi-rank path rehearsed
+on a one-GPU box.
 
 One "step" = one block of N time steps (one time-slice per GPU; N = 1: one time step): predict, then 4 SDC
 iterations (update_nodes + compute_residual + convergence check each) and the end point, all through the
@@ -268,6 +275,7 @@ def run_workload(args, world, rank, use_dist, with_stream_reference=True):
         ctrl = controller_nonMPI(1, cparams, desc)
         step = ctrl.MS[0]
     else:
+        cparams['comm_wire'] = args.wire
         ctrl = controller_dist(cparams, desc)
         step = ctrl.S
     L = step.levels[0]
@@ -308,7 +316,7 @@ def run_workload(args, world, rank, use_dist, with_stream_reference=True):
     eng.profile_enable(False)
 
     el_own = el
-    elt = torch.tensor([el], dtype=torch.float64, device='cuda')
+    elt = torch.tensor([el], dtype=torch.float64)   # (host tensor: the process group is gloo)
     if use_dist:
         dist.all_reduce(elt, op=dist.ReduceOp.MAX)
     el = float(elt.item())
@@ -336,6 +344,8 @@ def run_workload(args, world, rank, use_dist, with_stream_reference=True):
                 'comm_ms_per_iteration': 1e3 * comm_s / max(1, sum(niter)),
                 'kernel_ms_per_iteration': sum(v[0] for v in prof.values()) / max(1, sum(niter)),
                 'two_hop_exchanges': getattr(ctrl, 'two_hop_calls', None),
+                'mesh_broadcasts': getattr(ctrl, 'bcast_two_hop_calls', None),
+                'wire': (ctrl._comms[0].info()['wire'] if getattr(ctrl, '_comms', None) else None),
                 'message_bytes': 8 * int(np.prod(uend.shape))}
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
@@ -403,7 +413,13 @@ def run_workload(args, world, rank, use_dist, with_stream_reference=True):
         }
         if per_rank is not None:
             out['per_rank'] = per_rank
+        if args.dump_end_value:
+            np.save(args.dump_end_value, uend.get())
+        if hasattr(ctrl, 'close'):
+            ctrl.close()
         return out
+    if hasattr(ctrl, 'close'):
+        ctrl.close()
     return None
 
 
@@ -446,22 +462,103 @@ def extras(args):
     return recs
 
 
-def preflight(torch, dist, rank, world):
-    """before any 8.6 GB buffer exists: a collective and a neighbour message of 64 MB over RCCL, so that a broken
-    fabric / IPC set-up ends the job here (non-zero exit) instead of hanging the timed run"""
-    t = torch.ones(1, device='cuda')
+def preflight(torch, dist, rank, world, wire):
+    """before any 8.6 GB buffer exists: a host collective, then a neighbour hand-over and a broadcast of a small field
+    through the C-ABI communicator on the chosen wire, so that a broken fabric / IPC set-up ends the job here (non-zero
+    exit) instead of hanging the timed run"""
+    import numpy as np
+
+    from pysdc_amd import lib as Lb
+    from pysdc_amd.comm import DeviceComm, torch_host_bcast
+    from pysdc_amd.engine import SweepEngine
+
+    t = torch.ones(1)
     dist.all_reduce(t)
     if int(t.item()) != world:
         raise RuntimeError(f'all_reduce returned {t.item()} on {world} ranks')
     if world > 1:
-        buf = torch.full((1 << 23,), float(rank), dtype=torch.float64, device='cuda')
-        inbox = torch.empty_like(buf)
-        ops = [dist.P2POp(dist.isend, buf, (rank + 1) % world), dist.P2POp(dist.irecv, inbox, (rank - 1) % world)]
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
-        torch.cuda.synchronize()
-        if float(inbox[0].item()) != float((rank - 1) % world) or float(inbox[-1].item()) != float((rank - 1) % world):
-            raise RuntimeError('neighbour message arrived corrupted')
+        e = SweepEngine((64, 64, 64), 1, 1)
+        comm = DeviceComm(e, world, rank, wire=wire, host_bcast=lambda uid: torch_host_bcast(uid, 0, None, dist))
+        e.upload(Lb.SLOT_UEND, 0, np.full(e.nvars, float(rank + 1)))
+        e.upload(Lb.SLOT_U, 0, np.zeros(e.nvars))
+        comm.handover_post(world)
+        comm.handover_complete()
+        got = e.download(Lb.SLOT_U, 0)
+        want = float(rank) if rank >= 1 else 0.0
+        if got.min() != want or got.max() != want:
+            raise RuntimeError(f'neighbour message arrived corrupted on rank {rank}: [{got.min()}, {got.max()}], expected {want}')
+        comm.bcast(Lb.SLOT_UEND, 0, root=world - 1)
+        got = e.download(Lb.SLOT_UEND)
+        if got.min() != float(world) or got.max() != float(world):
+            raise RuntimeError(f'broadcast arrived corrupted on rank {rank}')
+        info = comm.info()
+        comm.close()
+        e.close()
+        return info
+    return None
+
+
+def launch_ranks(args, argv):
+    """the parent of a multi-GPU run: it never touches a GPU (no torch.cuda call, no HIP library loaded); it starts one
+    fresh interpreter per rank, relays rank 0's standard output (the JSON line) and turns any failure - a rank that exits
+    non-zero, a job that exceeds --job-timeout - into ONE JSON error line and a non-zero exit code"""
+    import socket
+    import subprocess
+    import tempfile
+
+    with socket.socket() as sk:   # a free port for the rendezvous on the loopback interface
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    def die_with_parent():   # a rank never outlives the launcher (e.g. when the launcher itself is killed on a timeout)
+        import ctypes
+        import signal
+
+        ctypes.CDLL('libc.so.6').prctl(1, signal.SIGKILL)   # PR_SET_PDEATHSIG
+
+    procs, logs = [], []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0', GLOO_SOCKET_IFNAME='lo',
+                   PYSDC_BENCH_CHILD='1')
+        log = tempfile.TemporaryFile(mode='w+')
+        logs.append(log)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else log, stderr=log, text=True,
+                                      start_new_session=True, preexec_fn=die_with_parent))
+    deadline = time.time() + args.job_timeout
+    out0, failed = None, None
+    try:
+        out0, _ = procs[0].communicate(timeout=max(1.0, deadline - time.time()))
+        for r, p in enumerate(procs):
+            p.wait(timeout=max(1.0, deadline - time.time()))
+            if p.returncode != 0 and failed is None:
+                failed = f'rank {r} exited with code {p.returncode}'
+    except subprocess.TimeoutExpired:
+        failed = f'job exceeded --job-timeout {args.job_timeout:.0f} s'
+    finally:
+        for p in procs:   # never leave a rank behind that may hold a GPU (each one is its own process group)
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, 9)
+                except OSError:
+                    pass
+    line = None
+    for ln in (out0 or '').splitlines():
+        if ln.startswith('{'):
+            line = ln
+    if failed is None and line is None:
+        failed = 'rank 0 printed no JSON line'
+    if failed is None and 'error' in json.loads(line) and 'metric' not in json.loads(line):
+        failed = json.loads(line)['error']
+    if failed is not None:
+        tails = {}
+        for r, log in enumerate(logs):
+            log.seek(0)
+            tails[f'rank{r}'] = log.read()[-1500:]
+        print(json.dumps({'error': failed, 'n_gpus': args.gpus, 'rank_output_tails': tails}), flush=True)
+        return 1
+    print(line, flush=True)
+    return 0
 
 
 def main():
@@ -506,7 +603,24 @@ def main():
                          'BASELINE configurations and of the eager / restol variants, measured in the same process)')
     ap.add_argument('--p2p-chunk-mb', type=float, default=0.0,
                     help='time-parallel runs: cut the forward message into pieces of this size (0 = one piece)')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help="--gpus > 1: 'nccl' = state vectors over RCCL / xGMI (one GPU per rank); 'gloo' = over the "
+                         'shared-memory wire of the C-ABI communicator (host staging; needed with --same-device).  The '
+                         'torch.distributed process group itself (rendezvous, flags, counts) is gloo in both cases')
+    ap.add_argument('--same-device', action='store_true',
+                    help='all ranks on GPU 0 (rehearsal of the multi-rank path on a one-GPU box; needs --backend gloo)')
+    ap.add_argument('--job-timeout', type=float, default=1500.0,
+                    help='--gpus > 1 started without a launcher: seconds after which the parent ends the job with an error')
+    ap.add_argument('--dump-end-value', default=None,
+                    help='rank 0 saves the end value of the timed run to this .npy file (tests)')
     args = ap.parse_args()
+    args.wire = 'rccl' if args.backend == 'nccl' else 'shm'
+    if args.same_device and args.backend != 'gloo':
+        print(json.dumps({'error': '--same-device needs --backend gloo (RCCL refuses two ranks on one device)'}), flush=True)
+        raise SystemExit(2)
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # not under a launcher: be the launcher - BEFORE anything in this process initialises the GPU
+        raise SystemExit(launch_ranks(args, sys.argv[1:]))
 
     import numpy as np
     import torch
@@ -516,8 +630,9 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
-    torch.cuda.set_device(local_rank)
+        print(json.dumps({'error': f'--gpus {args.gpus} but WORLD_SIZE={world} in the environment'}), flush=True)
+        raise SystemExit(2)
+    torch.cuda.set_device(0 if args.same_device else local_rank)
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
@@ -528,12 +643,14 @@ def main():
         os.environ.setdefault('MASTER_PORT', '29531')
         import datetime
 
+        os.environ.setdefault('SDC_COMM_TIMEOUT', '300')
         try:
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank),
-                                    timeout=datetime.timedelta(seconds=180))
-            preflight(torch, dist, rank, world)
+            # the process group only carries host data (rendezvous, unique id, 1-byte flags, counts): gloo; the state
+            # vectors travel through the C-ABI communicator (RCCL or the shared-memory wire)
+            dist.init_process_group('gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
+            preflight(torch, dist, rank, world, args.wire)
         except Exception as e:  # noqa: BLE001  fail fast and loudly: no hang, no partial line
-            print(json.dumps({'error': f'rank {rank}: RCCL preflight failed: {e!r}'}), flush=True)
+            print(json.dumps({'error': f'rank {rank}: preflight of the {args.wire} wire failed: {e!r}'}), flush=True)
             raise SystemExit(3)
         if args.p2p_chunk_mb > 0:
             os.environ['PYSDC_AMD_P2P_CHUNK'] = str(int(args.p2p_chunk_mb * (1 << 20) // 8))

@@ -150,7 +150,7 @@ int sdc_set_early_end_point(sdc_ctx* ctx, int on);
 int sdc_stream_wait_uend(sdc_ctx* ctx, void* other_stream);
 int sdc_replace_u0(sdc_ctx* ctx, const double* src);
 
-/* ---- time-rank communication over RCCL (xGMI) --------------------------------------------------------------
+/* ---- time-rank communication (RCCL over xGMI; host mailboxes as the rehearsal wire) --------------------------
  * The forward transfer uend -> u[0] of the next time rank (controller_MPI.py:218-305 send_full / recv_full; mesh.py:85-125
  * isend / irecv / bcast) and the end-of-block broadcast (controller_MPI.py:125-130), modelled on the reference's NCCL
  * wrapper helpers/NCCL_communicator.py:12-20 (unique id made by rank 0 and distributed by the host-side communicator,
@@ -159,22 +159,46 @@ int sdc_replace_u0(sdc_ctx* ctx, const double* src);
  * block): a send starts once UEND is complete (sdc_end_point, or the early end value of sdc_set_early_end_point) and
  * UEND is not rewritten before it has left; a received value lands in an inbox and reaches the level through
  * sdc_replace_u0 on the engine's stream.  MPI tags (level*100 + iter) are replaced by the strict order of the calls.
+ * A unique id that starts with "shm:" selects the second wire instead: single-slot mailboxes in POSIX shared memory
+ * named after the rest of the id (same calls, same stream ordering, data staged through host memory, host-blocking) -
+ * for ranks that RCCL cannot connect: several ranks on ONE GPU, ranks that are threads of one process.
  *   sdc_comm_unique_id(out)          128 bytes, called on ONE rank; ship them to the others on the host side
  *   sdc_comm_init(ctx, uid, P, r)    ncclCommInitRank on the context's device (collective over the P ranks)
+ *   sdc_comm_attach(ctx, owner)      a coarser level of the same time rank shares the owner's communicator and stream
  *   sdc_comm_exchange(ctx, to, from) send UEND to rank `to` and / or receive the new u[0] from rank `from` as ONE
  *                                    group (both directions progress together); a peer < 0 skips that direction
  *   sdc_send_uend / sdc_recv_u0      the two halves on their own
- *   sdc_bcast(ctx, slot, m, root)    one slab field of rank `root` to all, in place
+ *   sdc_comm_handover_post(ctx, P)   lock-step runs: the hand-over uend(r) -> u[0](r+1) of ALL P active ranks, posted behind
+ *                                    the completion of UEND only (it travels while the residual passes run); with more than
+ *                                    two ranks every message is cut into P pieces that travel over two hops through all
+ *                                    ranks (each xGMI link carries 1/P per phase) unless sdc_comm_set_relay(ctx, 0)
+ *   sdc_comm_handover_complete(ctx)  the engine's stream waits for that hand-over; the received value becomes u[0]
+ *   sdc_bcast(ctx, slot, m, root)    one slab field of rank `root` to all, in place (more than two ranks and relay on:
+ *                                    scatter + all-gather over the mesh, same bits)
+ *   sdc_comm_bcast_buffer(ctx, p, n, root)  the same for any device buffer of n doubles
  *   sdc_comm_set_chunk(ctx, n)       cut every message into pieces of n doubles inside its group (0 = one piece)
- *   sdc_comm_sync(ctx)               host waits for the messages posted so far */
+ *   sdc_comm_set_relay(ctx, on)      two-hop hand-over / mesh broadcast for more than two ranks (default on)
+ *   sdc_comm_info(ctx, ...)          rank, size, counts of two-hop hand-overs and mesh broadcasts, wire kind ("rccl" / "shm")
+ *   sdc_comm_sync(ctx)               host waits for the messages posted so far
+ *   sdc_comm_selftest(job, P, r, n, what, arg, rounds)   the exchange patterns (0 direct, 1 two-hop among the first `arg`
+ *                                    ranks; 2 mesh broadcast from rank `arg`) on plain HOST buffers over a mailbox wire named
+ *                                    `job`, called by P threads or processes; checks every received value.  No GPU needed. */
 int sdc_comm_unique_id(char* out128);
 int sdc_comm_init(sdc_ctx* ctx, const char* uid128, int nranks, int rank);
+int sdc_comm_attach(sdc_ctx* ctx, sdc_ctx* owner);
 int sdc_comm_destroy(sdc_ctx* ctx);
 int sdc_comm_exchange(sdc_ctx* ctx, int send_peer, int recv_peer);
 int sdc_send_uend(sdc_ctx* ctx, int peer);
 int sdc_recv_u0(sdc_ctx* ctx, int peer);
+int sdc_comm_handover_post(sdc_ctx* ctx, int nactive);
+int sdc_comm_handover_complete(sdc_ctx* ctx);
 int sdc_bcast(sdc_ctx* ctx, int slot, int m, int root);
+int sdc_comm_bcast_buffer(sdc_ctx* ctx, double* buf, size_t n, int root);
 int sdc_comm_set_chunk(sdc_ctx* ctx, size_t doubles_per_piece);
+int sdc_comm_set_relay(sdc_ctx* ctx, int on);
+int sdc_comm_info(sdc_ctx* ctx, int* rank, int* size, unsigned long long* two_hop_calls, unsigned long long* mesh_bcast_calls,
+                  char* kind16);
+int sdc_comm_selftest(const char* job, int nranks, int rank, size_t n, int what, int arg, int rounds);
 int sdc_comm_sync(sdc_ctx* ctx);
 /* L.status.unlocked: set by sdc_predict; a coarse level is unlocked by the restriction instead
  * (pySDC/core/base_transfer.py:166) - the host mirrors that here. */

@@ -1,46 +1,78 @@
-"""RCCL transport of the time-parallel hand-over through the C-ABI (include/sdcmi.h: sdc_comm_*).
+"""Transport of the time-parallel hand-over through the C-ABI (include/sdcmi.h: sdc_comm_*).
 
 The role of the reference's ``NCCLComm`` (pySDC/helpers/NCCL_communicator.py:7-20: an MPI communicator whose data
-calls go to NCCL) for the one exchange this path has: rank 0 makes the unique id, a HOST-side communicator ships its
+calls go to NCCL) for the exchanges this path has: rank 0 makes the unique id, a HOST-side communicator ships its
 128 bytes to the other ranks (``host_bcast``; mpi4py ``comm.bcast`` in the reference, ``torch.distributed`` over gloo
-here), every rank then joins with ``ncclCommInitRank`` on its own GPU.  Messages are posted on a stream of the
-engine's own and ordered against its kernels by events; nothing here blocks the host."""
+here), every rank then joins on its own GPU.  Two wires behind the same calls: RCCL over xGMI (one process per GPU), and
+host mailboxes in shared memory for ranks RCCL cannot connect (several ranks on one GPU, ranks that are threads of one
+process) - chosen by the unique id (``rccl_unique_id`` / ``shm_unique_id``).  Messages are posted on a stream of the
+engine's own and ordered against its kernels by events."""
 import ctypes as C
+import os
+import secrets
 
 from pysdc_amd import lib as L
 from pysdc_amd.errors import ParameterError
 
 
-def unique_id():
-    """128 bytes identifying a new communicator; call on ONE rank and ship the result to the others"""
+def rccl_unique_id():
+    """128 bytes identifying a new RCCL communicator; call on ONE rank and ship the result to the others"""
     buf = C.create_string_buffer(128)
     L.check(L.load().sdc_comm_unique_id(buf), None)
     return buf.raw
 
 
-def torch_host_bcast(uid, root=0, group=None):
+unique_id = rccl_unique_id
+
+
+def shm_unique_id():
+    """128 bytes naming a fresh set of shared-memory mailboxes (the second wire); call on ONE rank"""
+    name = f'shm:{os.getpid()}-{secrets.token_hex(8)}'.encode()
+    return name + b'\0' * (128 - len(name))
+
+
+def make_unique_id(wire):
+    if wire == 'rccl':
+        return rccl_unique_id()
+    if wire == 'shm':
+        return shm_unique_id()
+    raise ParameterError(f"wire must be 'rccl' or 'shm', got {wire!r}")
+
+
+def torch_host_bcast(uid, root=0, group=None, dist=None):
     """ship the id with torch.distributed (any backend that moves host objects, e.g. gloo)"""
-    import torch.distributed as dist
+    if dist is None:
+        import torch.distributed as dist
 
     box = [uid]
     dist.broadcast_object_list(box, src=root, group=group)
     return box[0]
 
 
-class RcclComm:
-    """one time rank's end of the communicator, bound to that rank's SweepEngine (fine level)"""
+class DeviceComm:
+    """one time rank's end of the communicator, bound to one level's SweepEngine.  The fine level owns the
+    communicator (``DeviceComm(engine, P, r, ...)``); the coarser levels of the same rank share it (``attach``)."""
 
-    def __init__(self, engine, nranks, rank, uid=None, host_bcast=None):
+    def __init__(self, engine, nranks, rank, uid=None, host_bcast=None, wire='rccl', _owner=None):
+        self.engine = engine
+        if _owner is not None:
+            self.size, self.rank = _owner.size, _owner.rank
+            L.check(engine.lib.sdc_comm_attach(engine.ctx, _owner.engine.ctx), engine.ctx)
+            return
         if uid is None:
             if nranks > 1 and host_bcast is None:
                 raise ParameterError('more than one rank: pass the unique id or a host_bcast(uid_or_None) -> uid callable')
-            uid = unique_id() if rank == 0 else None
+            uid = make_unique_id(wire) if rank == 0 else None
             if host_bcast is not None:
                 uid = host_bcast(uid)
         if len(uid) != 128:
             raise ParameterError('the unique id has 128 bytes')
-        self.engine, self.size, self.rank = engine, int(nranks), int(rank)
+        self.size, self.rank = int(nranks), int(rank)
         L.check(engine.lib.sdc_comm_init(engine.ctx, uid, self.size, self.rank), engine.ctx)
+
+    @classmethod
+    def attach(cls, engine, owner):
+        return cls(engine, owner.size, owner.rank, _owner=owner)
 
     def _e(self, rc):
         L.check(rc, self.engine.ctx)
@@ -57,12 +89,35 @@ class RcclComm:
     def recv_u0(self, peer):
         self._e(self.engine.lib.sdc_recv_u0(self.engine.ctx, int(peer)))
 
+    def handover_post(self, nactive):
+        """lock-step runs: uend(r) -> u[0](r + 1) for all ``nactive`` ranks, posted behind the end value only"""
+        self._e(self.engine.lib.sdc_comm_handover_post(self.engine.ctx, int(nactive)))
+
+    def handover_complete(self):
+        self._e(self.engine.lib.sdc_comm_handover_complete(self.engine.ctx))
+
     def bcast(self, slot, m=0, root=0):
         """one slab field of rank ``root`` to all ranks, in place (controller_MPI.py:125-130)"""
         self._e(self.engine.lib.sdc_bcast(self.engine.ctx, int(slot), int(m), int(root)))
 
+    def bcast_buffer(self, ptr, n, root=0):
+        """any device buffer of n doubles, in place"""
+        self._e(self.engine.lib.sdc_comm_bcast_buffer(self.engine.ctx, ptr, int(n), int(root)))
+
     def set_chunk(self, doubles_per_piece):
         self._e(self.engine.lib.sdc_comm_set_chunk(self.engine.ctx, int(doubles_per_piece)))
+
+    def set_relay(self, on):
+        self._e(self.engine.lib.sdc_comm_set_relay(self.engine.ctx, int(bool(on))))
+
+    def info(self):
+        rank, size = C.c_int(), C.c_int()
+        hops, mesh = C.c_ulonglong(), C.c_ulonglong()
+        kind = C.create_string_buffer(16)
+        self._e(self.engine.lib.sdc_comm_info(self.engine.ctx, C.byref(rank), C.byref(size), C.byref(hops), C.byref(mesh),
+                                              kind))
+        return dict(rank=rank.value, size=size.value, two_hop_handovers=hops.value, mesh_broadcasts=mesh.value,
+                    wire=kind.value.decode())
 
     def sync(self):
         self._e(self.engine.lib.sdc_comm_sync(self.engine.ctx))
@@ -71,3 +126,6 @@ class RcclComm:
         if self.engine is not None and self.engine.ctx:
             self.engine.lib.sdc_comm_destroy(self.engine.ctx)
         self.engine = None
+
+
+RcclComm = DeviceComm  # (the name of the first version: one wire)

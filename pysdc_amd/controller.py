@@ -372,10 +372,14 @@ class _WorkList:
 
 
 class controller_dist(_ControllerBase):
-    """One time step per rank (= per GPU).  ``comm``: torch.distributed group carrying the state vectors
-    (RCCL on GPUs); 1-byte convergence flags and step counts use a gloo side group so they never touch the
-    device.  ``description['step_class']`` may replace the Step implementation (CPU tests use an
-    oracle-backed step under gloo)."""
+    """One time step per rank (= per GPU).
+
+    Device levels hand their state vectors over through the C-ABI (``pysdc_amd.comm.DeviceComm`` -> sdc_comm_*: RCCL over
+    xGMI, or the shared-memory mailbox wire for ranks on one GPU - controller parameter ``comm_wire`` / environment
+    PYSDC_AMD_WIRE, 'rccl' or 'shm'); torch.distributed (``comm`` / ``dist``) then only carries the rendezvous, the unique
+    id, the 1-byte convergence flags and the step counts, all on the host.  Steps without a device engine
+    (``description['step_class']``: the CPU tests use an oracle-backed step under gloo) send their arrays through
+    torch.distributed itself."""
 
     def __init__(self, controller_params, description, comm=None, dist=None):
         if dist is None:  # anything with torch.distributed's surface will do (the tests drive several ranks on ONE
@@ -413,11 +417,51 @@ class controller_dist(_ControllerBase):
         self._posted = None
         self._comm_stream = None
         self._overlap = False
+        self._abi = False
         self.relay = os.environ.get('PYSDC_AMD_RELAY', '1') != '0'
         # > 0: every direct message is cut into pieces of this many values, all posted in the same batched group
         self.p2p_chunk = int(os.environ.get('PYSDC_AMD_P2P_CHUNK', '0'))
-        self.two_hop_calls = 0
-        self.bcast_two_hop_calls = 0
+        self._two_hop_calls = 0
+        self._bcast_two_hop_calls = 0
+        self.wire = controller_params.get('comm_wire', os.environ.get('PYSDC_AMD_WIRE', 'rccl'))
+        self._comms = None  # one DeviceComm per level once device levels run on more than one rank
+
+    # ---- the C-ABI transport of device levels ---------------------------------------------------------------------
+    @property
+    def on_device(self):
+        return all(hasattr(L, 'engine') and hasattr(L, 'received_u0') for L in self.S.levels)
+
+    def _device_comms(self):
+        """communicator of the fine level (unique id from rank 0 over the host group) shared by the coarser levels"""
+        if self._comms is None:
+            from pysdc_amd.comm import DeviceComm, torch_host_bcast
+
+            owner = DeviceComm(self.S.levels[0].engine, self.size, self.rank, wire=self.wire,
+                               host_bcast=lambda uid: torch_host_bcast(uid, 0, self.host_comm, self.dist))
+            owner.set_relay(self.relay)
+            if self.p2p_chunk > 0:
+                owner.set_chunk(self.p2p_chunk)
+            self._comms = [owner] + [DeviceComm.attach(L.engine, owner) for L in self.S.levels[1:]]
+        return self._comms
+
+    @property
+    def two_hop_calls(self):
+        if self._comms is not None:
+            return self._comms[0].info()['two_hop_handovers']
+        return self._two_hop_calls
+
+    @property
+    def bcast_two_hop_calls(self):
+        if self._comms is not None:
+            return self._comms[0].info()['mesh_broadcasts']
+        return self._bcast_two_hop_calls
+
+    def close(self):
+        """release the communicators (collective: every rank calls it)"""
+        if self._comms is not None:
+            for cm in reversed(self._comms):
+                cm.close()
+            self._comms = None
 
     # ---- host-side scalars (check_convergence.py:105-160; controller_MPI.py:90,120,142) ---------------------
     def _recv_target(self, L):
@@ -473,6 +517,9 @@ class controller_dist(_ControllerBase):
             raise ControllerError('Nothing to do, check t0, dt and Tend!')
         P = S.levels[0].prob
         self._overlap = False
+        self._abi = self.size > 1 and self.on_device
+        if self._abi:
+            self._device_comms()
         if self.size > 1 and hasattr(S.levels[0], 'replace_u0') and hasattr(S.levels[0], 'engine'):
             # u[0] is replaced between sweeps and the residual is asked for again: keep the residual fields;
             # produce the end value early so that it can be sent while the residual is reduced
@@ -548,6 +595,20 @@ class controller_dist(_ControllerBase):
         S = self.S
         L = S.levels[level]
         self._hook('pre_comm', S, level)
+        if self._abi:
+            # one group on the message stream of the C-ABI communicator: the send waits (on the device) for UEND, UEND is
+            # not rewritten before it has left (write fence inside the library), the received value reaches the level
+            # through sdc_replace_u0 - nothing for the host to wait for, so a "blocking" send needs no extra step
+            if send:
+                L.sweep.compute_end_point()
+            do_recv = recv and not S.status.first and not S.status.prev_done
+            self._comms[level].exchange(send_to=self.rank + 1 if send and not S.status.last else None,
+                                        recv_from=self.rank - 1 if do_recv else None)
+            if do_recv:
+                L.received_u0()
+                L.refresh_f0()
+            self._hook('post_comm', S, level)
+            return
         ops = []
         tag = level * 100 + S.status.iter
         if send:
@@ -592,6 +653,11 @@ class controller_dist(_ControllerBase):
         cut into size-1 pieces, the root hands piece j to the j-th other rank (its links carry one piece each, all at
         once), then those ranks exchange their pieces among themselves: two phases in which every link carries
         1/(size-1) of the message, each one batched group of point-to-point operations.  Bit-identical to a copy."""
+        if getattr(self, '_abi', False):
+            self._comms[0].bcast_buffer(buf.ptr, buf.size, root)   # (mesh scatter + all-gather inside the library)
+            if self.rank != root:
+                buf._wrote()
+            return
         dist = self.dist
         t = buf.as_torch()
         P, r = self.size, self.rank
@@ -607,7 +673,7 @@ class controller_dist(_ControllerBase):
             j = others.index(k)
             return t[j * csz:min(n, (j + 1) * csz)]
 
-        self.bcast_two_hop_calls += 1
+        self._bcast_two_hop_calls += 1
         tag = 7000
         ops = []
         if r == root:
@@ -653,7 +719,7 @@ class controller_dist(_ControllerBase):
 
         dist = self.dist
         r, P = self.rank, size
-        self.two_hop_calls += 1
+        self._two_hop_calls += 1
         src = L.uend.as_torch().reshape(-1)
         dst = (inbox if inbox is not None else L.u[0]).as_torch().reshape(-1)
         n = src.numel()
@@ -712,6 +778,11 @@ class controller_dist(_ControllerBase):
         S, dist = self.S, self.dist
         L = S.levels[0]
         self._hook('pre_comm', S, 0)
+        if self._abi:
+            L.sweep.compute_end_point()  # free when the sweep produced UEND early
+            self._comms[0].handover_post(size)   # (its own stream, behind UEND only; two hops for more than two ranks)
+            self._posted = ([], None, False)
+            return
         if self.req_send[0] is not None:
             self.req_send[0].wait()
             self.req_send[0] = None
@@ -748,6 +819,13 @@ class controller_dist(_ControllerBase):
         L = S.levels[0]
         reqs, inbox, side_stream = self._posted
         self._posted = None
+        if self._abi:
+            self._comms[0].handover_complete()
+            if self.rank >= 1:
+                L.received_u0()
+                L.refresh_f0()
+            self._hook('post_comm', S, 0)
+            return
         for req in reqs:
             req.wait()
         if side_stream:
@@ -793,7 +871,7 @@ class controller_dist(_ControllerBase):
         L = S.levels[0]
         if self._posted is not None:
             self.handover_complete()      # posted right after the sweep (it_fine)
-        elif self._lockstep(size) or (self._overlap and self._uniform(size)):
+        elif self._lockstep(size) or (self._overlap and self._uniform(size)) or (self._abi and self._uniform(size)):
             # lock-step runs: every message is completed here, on both sides - the next sweep overwrites UEND early
             # (sdc_set_early_end_point), so no send may stay in flight behind it
             self.exchange_two_hop(size)

@@ -1,16 +1,30 @@
-// RCCL point-to-point transport of the time-parallel hand-over behind the C-ABI: the forward transfer
-// uend -> u[0] of the next time rank (controller_MPI.py:218-305 send_full / recv_full, mesh.py:85-125 isend / irecv /
-// bcast) and the end-of-block broadcast (controller_MPI.py:125-130), modelled on the reference's NCCL wrapper
-// (helpers/NCCL_communicator.py:12-20: unique id from rank 0, one communicator per process; :128-135 Bcast).
+// Transport of the time-parallel hand-over behind the C-ABI: the forward transfer uend -> u[0] of the next time rank
+// (controller_MPI.py:218-305 send_full / recv_full, mesh.py:85-125 isend / irecv / bcast) and the end-of-block broadcast
+// (controller_MPI.py:125-130), modelled on the reference's NCCL wrapper (helpers/NCCL_communicator.py:12-20: unique id
+// from rank 0, one communicator per process; :128-135 Bcast).
 //
-// librccl is bound at run time (dlopen) the first time a communicator is asked for: single-GPU runs never load it,
-// and a process in which torch.distributed has already loaded its librccl shares that copy.  Messages travel on a
-// stream of their own: a send waits (on the device) for the event that marks UEND complete, a receive lands in an
-// inbox and is handed to the level through sdc_replace_u0 on the engine's stream once it has arrived, so residual
-// passes and messages overlap and the host never blocks.
+// Two wires carry the same protocol:
+//   * RCCL over xGMI (one process per GPU).  librccl is bound at run time (dlopen) the first time a communicator is asked
+//     for: single-GPU runs never load it, and a process in which torch.distributed has already loaded its librccl shares
+//     that copy.
+//   * host mailboxes in POSIX shared memory ("shm:" ids): ranks that cannot have an RCCL communicator - several ranks on
+//     ONE GPU (RCCL refuses duplicate devices), ranks that are threads of one process (tests), or no GPU at all (the
+//     protocol's piece arithmetic is exercised on plain host buffers by sdc_comm_selftest in the CPU suite).  Same calls,
+//     same ordering against the engine's stream; the data makes a round trip through host memory.
+// Messages travel on a stream of their own: a send waits (on the device) for the event that marks UEND complete, a
+// receive lands in an inbox and is handed to the level through sdc_replace_u0 on the engine's stream once it has
+// arrived, so residual passes and messages overlap and the host never blocks (RCCL wire).
 #pragma once
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <rccl/rccl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <atomic>
+#include <chrono>
+#include <memory>
 
 struct RcclApi {
     void* handle = nullptr;
@@ -60,21 +74,340 @@ static RcclApi* rccl_api(std::string* why) {
     return &api;
 }
 
-#define RCCLCHK(c, api, call)                                                                       \
-    do {                                                                                            \
-        ncclResult_t r_ = (call);                                                                   \
-        if (r_ != ncclSuccess) return fail(c, SDC_ERR_COMM, "%s: %s", #call, (api)->GetErrorString(r_)); \
-    } while (0)
+// ------------------------------------------------------------------------------------------------------------------
+// wires
+// ------------------------------------------------------------------------------------------------------------------
+// One rank's end of a communicator.  Point-to-point operations are issued between group_begin / group_end (one group =
+// operations that must progress together, ncclGroupStart / End); everything is ordered on `stream`.  `c` only receives
+// error texts (may be null).
+struct Wire {
+    int rank = 0, size = 1;
+    hipStream_t stream = nullptr;  // device wires: where the messages are ordered
+    size_t chunk = 0;              // > 0: messages are cut into pieces of this many doubles (one group)
+    virtual ~Wire() {}
+    virtual const char* kind() const = 0;
+    virtual int group_begin(sdc_ctx* c) = 0;
+    virtual int send(sdc_ctx* c, const double* buf, size_t n, int peer) = 0;
+    virtual int recv(sdc_ctx* c, double* buf, size_t n, int peer) = 0;
+    virtual int group_end(sdc_ctx* c) = 0;
+    virtual int bcast(sdc_ctx* c, double* buf, size_t n, int root) = 0;
+    virtual int sync(sdc_ctx* c) = 0;  // host waits for everything posted so far
+};
 
-struct CommState {
+struct RcclWire : Wire {
+    RcclApi* api = nullptr;
     ncclComm_t comm = nullptr;
-    hipStream_t stream = nullptr;   // messages travel here, not on the engine's stream
+    ncclResult_t first_err = ncclSuccess;
+    const char* kind() const override { return "rccl"; }
+    ~RcclWire() override {
+        if (stream) (void)hipStreamSynchronize(stream);
+        if (comm && api) (void)api->CommDestroy(comm);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+    int group_begin(sdc_ctx* c) override {
+        first_err = ncclSuccess;
+        ncclResult_t r = api->GroupStart();
+        if (r != ncclSuccess) return fail(c, SDC_ERR_COMM, "ncclGroupStart: %s", api->GetErrorString(r));
+        return SDC_OK;
+    }
+    int send(sdc_ctx*, const double* buf, size_t n, int peer) override {
+        const size_t step = chunk ? chunk : n;
+        for (size_t o = 0; o < n && first_err == ncclSuccess; o += step)
+            first_err = api->Send(buf + o, std::min(step, n - o), ncclDouble, peer, comm, stream);
+        return SDC_OK;  // (reported by group_end: the group has to be closed whatever happened inside)
+    }
+    int recv(sdc_ctx*, double* buf, size_t n, int peer) override {
+        const size_t step = chunk ? chunk : n;
+        for (size_t o = 0; o < n && first_err == ncclSuccess; o += step)
+            first_err = api->Recv(buf + o, std::min(step, n - o), ncclDouble, peer, comm, stream);
+        return SDC_OK;
+    }
+    int group_end(sdc_ctx* c) override {
+        ncclResult_t re = api->GroupEnd();
+        if (first_err != ncclSuccess || re != ncclSuccess)
+            return fail(c, SDC_ERR_COMM, "send/recv group: %s", api->GetErrorString(first_err != ncclSuccess ? first_err : re));
+        return SDC_OK;
+    }
+    int bcast(sdc_ctx* c, double* buf, size_t n, int root) override {
+        ncclResult_t r = api->Broadcast(buf, buf, n, ncclDouble, root, comm, stream);
+        if (r != ncclSuccess) return fail(c, SDC_ERR_COMM, "ncclBroadcast: %s", api->GetErrorString(r));
+        return SDC_OK;
+    }
+    int sync(sdc_ctx* c) override {
+        HIPCHK(c, hipStreamSynchronize(stream));
+        return SDC_OK;
+    }
+};
+
+// Mailboxes in POSIX shared memory: one single-slot box per ordered pair (src, dst), file /dev/shm/<job>.<src>.<dst>,
+// created by whoever gets there first (a fresh file is zero-filled: both counters start at 0).  The sender waits until the
+// box is free (consumed == posted), copies its data in and bumps `posted`; the receiver waits for posted > consumed,
+// copies out, bumps `consumed`.  A group collects its operations and carries them out at group_end - all sends, then
+// all receives - so that the ranks of a group never wait for each other in a cycle (a send only waits for the
+// receiver to have taken the PREVIOUS message of that pair, which it does in a group it entered earlier).  Blocks the
+// host (that is what makes it a rehearsal wire, not a fast one); waits end with SDC_ERR_COMM after `timeout_s`.
+struct ShmWire : Wire {
+    struct Head {
+        std::atomic<unsigned long long> posted, consumed;
+        unsigned long long bytes;
+        char pad[40];
+    };
+    struct Box {
+        int fd = -1;
+        unsigned char* base = nullptr;
+        size_t map_bytes = 0;
+        Head* head() const { return reinterpret_cast<Head*>(base); }
+        unsigned char* data() const { return base + sizeof(Head); }
+    };
+    struct Op {
+        bool is_send;
+        double* buf;
+        size_t n;
+        int peer;
+    };
+    std::string job;
+    size_t cap = 0;        // largest message, doubles
+    bool device = true;    // buffers are device memory (hipMemcpy through `stream`); false: plain host memory
+    double timeout_s = 120.0;
+    std::map<std::pair<int, int>, Box> boxes;
+    std::vector<Op> ops;
+    const char* kind() const override { return "shm"; }
+    static_assert(sizeof(Head) == 64, "mailbox header");
+
+    std::string path(int src, int dst) const { return "/" + job + "." + std::to_string(src) + "." + std::to_string(dst); }
+    ~ShmWire() override {
+        if (device && stream) (void)hipStreamSynchronize(stream);
+        for (auto& kv : boxes) {
+            // a box this rank filled is only removed once its message has been taken: the receiver may not even have
+            // opened it yet, and would otherwise create an empty one of the same name and wait for ever
+            if (kv.first.first == rank && kv.second.base) {
+                Head* h = kv.second.head();
+                for (int spin = 0; spin < 100000 && h->consumed.load(std::memory_order_acquire) != h->posted.load(); ++spin)
+                    usleep(50);
+            }
+            if (kv.second.base) munmap(kv.second.base, kv.second.map_bytes);
+            if (kv.second.fd >= 0) close(kv.second.fd);
+            shm_unlink(path(kv.first.first, kv.first.second).c_str());  // (the peer's mapping stays valid until it goes too)
+        }
+        if (device && stream) (void)hipStreamDestroy(stream);
+    }
+    int box(sdc_ctx* c, int src, int dst, Box** out) {
+        auto key = std::make_pair(src, dst);
+        auto it = boxes.find(key);
+        if (it == boxes.end()) {
+            Box b;
+            const std::string p = path(src, dst);
+            b.fd = shm_open(p.c_str(), O_CREAT | O_RDWR, 0600);
+            if (b.fd < 0) return fail(c, SDC_ERR_COMM, "shm_open(%s): %s", p.c_str(), strerror(errno));
+            b.map_bytes = sizeof(Head) + cap * sizeof(double);
+            if (ftruncate(b.fd, (off_t)b.map_bytes) != 0) {
+                close(b.fd);
+                return fail(c, SDC_ERR_COMM, "ftruncate(%s, %zu): %s", p.c_str(), b.map_bytes, strerror(errno));
+            }
+            void* m = mmap(nullptr, b.map_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, b.fd, 0);
+            if (m == MAP_FAILED) {
+                close(b.fd);
+                return fail(c, SDC_ERR_COMM, "mmap(%s): %s", p.c_str(), strerror(errno));
+            }
+            b.base = static_cast<unsigned char*>(m);
+            it = boxes.emplace(key, b).first;
+        }
+        *out = &it->second;
+        return SDC_OK;
+    }
+    template <class Pred>
+    int wait_for(sdc_ctx* c, Pred ready, const char* what, int peer) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spin = 0; !ready(); ++spin) {
+            if (spin < 2000) sched_yield();
+            else usleep(50);
+            if ((spin & 1023) == 1023 &&
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s)
+                return fail(c, SDC_ERR_COMM, "rank %d: %s rank %d timed out after %.0f s (shm wire %s)", rank, what, peer,
+                            timeout_s, job.c_str());
+        }
+        return SDC_OK;
+    }
+    int copy(sdc_ctx* c, void* dst, const void* src, size_t bytes, bool to_host) {
+        if (!device) {
+            memcpy(dst, src, bytes);
+            return SDC_OK;
+        }
+        HIPCHK(c, hipMemcpyAsync(dst, src, bytes, to_host ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice, stream));
+        return SDC_OK;
+    }
+    int drain(sdc_ctx* c) {
+        if (device) HIPCHK(c, hipStreamSynchronize(stream));
+        return SDC_OK;
+    }
+    int put(sdc_ctx* c, const double* buf, size_t n, int dst) {
+        if (n > cap) return fail(c, SDC_ERR_COMM, "message of %zu doubles exceeds the mailbox (%zu)", n, cap);
+        Box* b;
+        int rc = box(c, rank, dst, &b);
+        if (rc != SDC_OK) return rc;
+        Head* h = b->head();
+        rc = wait_for(c, [h] { return h->consumed.load(std::memory_order_acquire) == h->posted.load(std::memory_order_relaxed); },
+                      "waiting for the previous message to be taken by", dst);
+        if (rc != SDC_OK) return rc;
+        h->bytes = n * sizeof(double);
+        return copy(c, b->data(), buf, n * sizeof(double), true);
+    }
+    int take(sdc_ctx* c, double* buf, size_t n, int src) {
+        Box* b;
+        int rc = box(c, src, rank, &b);
+        if (rc != SDC_OK) return rc;
+        Head* h = b->head();
+        rc = wait_for(c, [h] { return h->posted.load(std::memory_order_acquire) > h->consumed.load(std::memory_order_relaxed); },
+                      "waiting for a message from", src);
+        if (rc != SDC_OK) return rc;
+        if (h->bytes != n * sizeof(double))
+            return fail(c, SDC_ERR_COMM, "rank %d expected %zu bytes from rank %d, the message has %llu", rank,
+                        n * sizeof(double), src, h->bytes);
+        return copy(c, buf, b->data(), n * sizeof(double), false);
+    }
+    int group_begin(sdc_ctx*) override {
+        ops.clear();
+        return SDC_OK;
+    }
+    int send(sdc_ctx*, const double* buf, size_t n, int peer) override {
+        ops.push_back(Op{true, const_cast<double*>(buf), n, peer});
+        return SDC_OK;
+    }
+    int recv(sdc_ctx*, double* buf, size_t n, int peer) override {
+        ops.push_back(Op{false, buf, n, peer});
+        return SDC_OK;
+    }
+    int group_end(sdc_ctx* c) override {
+        int rc = SDC_OK;
+        for (const Op& o : ops)
+            if (o.is_send && (rc = put(c, o.buf, o.n, o.peer)) != SDC_OK) return rc;
+        if ((rc = drain(c)) != SDC_OK) return rc;  // the data is in the boxes: tell the receivers
+        for (const Op& o : ops)
+            if (o.is_send) boxes[std::make_pair(rank, o.peer)].head()->posted.fetch_add(1, std::memory_order_release);
+        for (const Op& o : ops)
+            if (!o.is_send && (rc = take(c, o.buf, o.n, o.peer)) != SDC_OK) return rc;
+        if ((rc = drain(c)) != SDC_OK) return rc;
+        for (const Op& o : ops)
+            if (!o.is_send) boxes[std::make_pair(o.peer, rank)].head()->consumed.fetch_add(1, std::memory_order_release);
+        ops.clear();
+        return SDC_OK;
+    }
+    int bcast(sdc_ctx* c, double* buf, size_t n, int root) override {
+        int rc = group_begin(c);
+        if (rank == root) {
+            for (int k = 0; k < size && rc == SDC_OK; ++k)
+                if (k != root) rc = send(c, buf, n, k);
+        } else {
+            rc = recv(c, buf, n, root);
+        }
+        return rc == SDC_OK ? group_end(c) : rc;
+    }
+    int sync(sdc_ctx* c) override { return drain(c); }
+};
+
+// ------------------------------------------------------------------------------------------------------------------
+// the exchange patterns (any wire, any buffers of that wire's kind)
+// ------------------------------------------------------------------------------------------------------------------
+// piece j of a message of n values cut into `parts` pieces: offset and length (the last ones may be short or empty)
+static inline void msg_piece(size_t n, int parts, int j, size_t* off, size_t* len) {
+    const size_t csz = (n + (size_t)parts - 1) / (size_t)parts;
+    const size_t lo = std::min(n, (size_t)j * csz), hi = std::min(n, (size_t)(j + 1) * csz);
+    *off = lo;
+    *len = hi - lo;
+}
+// values this rank relays per message in a two-hop hand-over over P ranks (size of one staging slot)
+static inline size_t two_hop_slot(size_t n, int P, int r) {
+    size_t off, len;
+    msg_piece(n, P, r, &off, &len);
+    return len;
+}
+
+// The forward hand-over src(rank) -> dst(rank + 1) of ALL P active ranks at once, over two hops.
+//
+// xGMI is a full mesh of point-to-point links: a direct message uses one of a GPU's seven links while six idle.  Every
+// message is cut into P pieces; piece j travels via rank j (phase 1: owner -> relay, phase 2: relay -> destination; the
+// pieces whose relay is the owner or the destination go directly).  Each link then carries 1/P of a message per phase:
+// 2/P of the direct transfer time.  Both phases are one group in which every active rank takes part, which is why the
+// caller must have established lock step.  stage: (P - 1) slots of two_hop_slot() values.  Bit-identical to a copy.
+static int two_hop_handover(Wire* w, sdc_ctx* c, int P, const double* src, double* dst, double* stage, size_t n) {
+    const int r = w->rank;
+    size_t off, len, moff, mine;
+    msg_piece(n, P, r, &moff, &mine);
+    int rc = w->group_begin(c);  // phase 1: owners hand piece j to rank j (the destination's own piece lands in place)
+    if (rc != SDC_OK) return rc;
+    if (r <= P - 2)
+        for (int j = 0; j < P; ++j) {
+            msg_piece(n, P, j, &off, &len);
+            if (j != r && len > 0) w->send(c, src + off, len, j);
+        }
+    if (mine > 0)
+        for (int origin = 0; origin < P - 1; ++origin)
+            if (origin != r) w->recv(c, origin == r - 1 ? dst + moff : stage + (size_t)origin * mine, mine, origin);
+    if ((rc = w->group_end(c)) != SDC_OK) return rc;
+    if ((rc = w->group_begin(c)) != SDC_OK) return rc;  // phase 2: relays forward to the destinations
+    if (mine > 0)
+        for (int d = 1; d < P; ++d)
+            if (d != r) {
+                const int origin = d - 1;
+                w->send(c, origin == r ? src + moff : stage + (size_t)origin * mine, mine, d);
+            }
+    if (r >= 1)
+        for (int j = 0; j < P; ++j) {
+            msg_piece(n, P, j, &off, &len);
+            if (j != r && len > 0) w->recv(c, dst + off, len, j);
+        }
+    return w->group_end(c);
+}
+
+// buf of rank `root` to every rank, as scatter + all-gather over the mesh instead of the library broadcast: the message
+// is cut into size-1 pieces, the root hands piece j to the j-th other rank (its links carry one piece each, all at
+// once), then those ranks exchange their pieces among themselves - two phases in which every link carries 1/(size-1)
+// of the message.  Bit-identical to a copy.
+static int mesh_bcast(Wire* w, sdc_ctx* c, double* buf, size_t n, int root) {
+    const int P = w->size, r = w->rank;
+    if (P <= 2) return w->bcast(c, buf, n, root);
+    auto slot_of = [root](int k) { return k < root ? k : k - 1; };  // position of rank k among the non-root ranks
+    size_t off, len, moff = 0, mine = 0;
+    if (r != root) msg_piece(n, P - 1, slot_of(r), &moff, &mine);
+    int rc = w->group_begin(c);
+    if (rc != SDC_OK) return rc;
+    if (r == root) {
+        for (int k = 0; k < P; ++k) {
+            if (k == root) continue;
+            msg_piece(n, P - 1, slot_of(k), &off, &len);
+            if (len > 0) w->send(c, buf + off, len, k);
+        }
+    } else if (mine > 0) {
+        w->recv(c, buf + moff, mine, root);
+    }
+    if ((rc = w->group_end(c)) != SDC_OK) return rc;
+    if (r == root) return SDC_OK;
+    if ((rc = w->group_begin(c)) != SDC_OK) return rc;
+    for (int k = 0; k < P; ++k) {
+        if (k == root || k == r) continue;
+        if (mine > 0) w->send(c, buf + moff, mine, k);
+        msg_piece(n, P - 1, slot_of(k), &off, &len);
+        if (len > 0) w->recv(c, buf + off, len, k);
+    }
+    return w->group_end(c);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// per-context state
+// ------------------------------------------------------------------------------------------------------------------
+struct CommState {
+    std::shared_ptr<Wire> wire;     // shared by the levels of one time rank (sdc_comm_attach)
+    hipEvent_t inbox_free = nullptr;  // engine stream -> message stream: the inbox has been read (sdc_replace_u0)
     hipEvent_t ready = nullptr;     // engine stream -> message stream: the buffers a message touches are settled
     hipEvent_t done = nullptr;      // message stream -> engine stream: the last message has completed
+    bool inbox_busy = false;        // ... an event is recorded that the next receive has to wait for
     double* inbox = nullptr;        // where a received u[0] lands before sdc_replace_u0 hands it to the level
+    double* stage = nullptr;        // staging slots of the two-hop hand-over
+    size_t stage_len = 0;
     bool send_pending = false;      // a send may still be reading UEND
-    int rank = 0, size = 1;
-    size_t chunk = 0;               // > 0: messages are cut into pieces of this many doubles (one group)
+    bool relay = true;              // more than two ranks: two-hop hand-over / mesh broadcast instead of direct messages
+    int posted_recv = -1;           // sdc_comm_handover_post: 1 = a receive is under way, 0 = only a send, -1 = nothing posted
+    unsigned long long two_hop_calls = 0, mesh_bcast_calls = 0;
 };
 
 // UEND is about to be overwritten: a send that reads it has to be through first (device-side wait, no host block)
@@ -90,17 +423,39 @@ static int uend_write_fence(sdc_ctx* c) {
 static void comm_free(sdc_ctx* c) {
     CommState* cs = c->comm;
     if (!cs) return;
-    if (cs->stream) (void)hipStreamSynchronize(cs->stream);
-    if (cs->comm) {
-        RcclApi* api = rccl_api(nullptr);
-        if (api) (void)api->CommDestroy(cs->comm);
-    }
+    if (cs->wire) (void)cs->wire->sync(nullptr);
+    cs->wire.reset();
     if (cs->ready) (void)hipEventDestroy(cs->ready);
     if (cs->done) (void)hipEventDestroy(cs->done);
-    if (cs->stream) (void)hipStreamDestroy(cs->stream);
+    if (cs->inbox_free) (void)hipEventDestroy(cs->inbox_free);
     (void)hipFree(cs->inbox);
+    (void)hipFree(cs->stage);
     delete cs;
     c->comm = nullptr;
+}
+
+static int comm_events(sdc_ctx* c, CommState* cs) {
+    if (hipEventCreateWithFlags(&cs->ready, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&cs->done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&cs->inbox_free, hipEventDisableTiming) != hipSuccess)
+        return fail(c, SDC_ERR_HIP, "cannot create the message events");
+    return SDC_OK;
+}
+
+static std::shared_ptr<Wire> make_shm_wire(const char* uid128, int nranks, int rank, size_t cap, bool device) {
+    auto w = std::make_shared<ShmWire>();
+    char name[129];
+    memcpy(name, uid128, 128);
+    name[128] = 0;
+    w->job = std::string("sdcmi.") + (name + 4);
+    for (char& ch : w->job)
+        if (!(isalnum((unsigned char)ch) || ch == '.' || ch == '_' || ch == '-')) ch = '_';
+    w->rank = rank;
+    w->size = nranks;
+    w->cap = cap;
+    w->device = device;
+    if (const char* t = getenv("SDC_COMM_TIMEOUT")) w->timeout_s = atof(t) > 0 ? atof(t) : w->timeout_s;
+    return w;
 }
 
 extern "C" int sdc_comm_unique_id(char* out128) {
@@ -109,7 +464,8 @@ extern "C" int sdc_comm_unique_id(char* out128) {
     RcclApi* api = rccl_api(&why);
     if (!api) return fail(nullptr, SDC_ERR_COMM, "%s", why.c_str());
     ncclUniqueId id;
-    RCCLCHK(nullptr, api, api->GetUniqueId(&id));
+    ncclResult_t r = api->GetUniqueId(&id);
+    if (r != ncclSuccess) return fail(nullptr, SDC_ERR_COMM, "ncclGetUniqueId: %s", api->GetErrorString(r));
     static_assert(sizeof(id) == 128, "ncclUniqueId");
     memcpy(out128, &id, sizeof id);
     return SDC_OK;
@@ -119,29 +475,60 @@ extern "C" int sdc_comm_init(sdc_ctx* c, const char* uid128, int nranks, int ran
     if (!c || !uid128) return fail(c, SDC_ERR_PARAM, "null pointer");
     if (nranks < 1 || rank < 0 || rank >= nranks) return fail(c, SDC_ERR_PARAM, "rank %d of %d", rank, nranks);
     if (c->comm) return fail(c, SDC_ERR_STATE, "communicator exists already (sdc_comm_destroy first)");
-    std::string why;
-    RcclApi* api = rccl_api(&why);
-    if (!api) return fail(c, SDC_ERR_COMM, "%s", why.c_str());
     HIPCHK(c, hipSetDevice(c->device));
-    CommState* cs = new CommState;
-    c->comm = cs;
-    cs->rank = rank;
-    cs->size = nranks;
-    ncclUniqueId id;
-    memcpy(&id, uid128, sizeof id);
-    ncclResult_t r = api->CommInitRank(&cs->comm, nranks, id, rank);
-    if (r != ncclSuccess) {
-        cs->comm = nullptr;
+    std::unique_ptr<CommState> cs(new CommState);
+    if (strncmp(uid128, "shm:", 4) == 0) {
+        // the largest message of this rank's levels: a field, or (later) its half spectrum
+        auto w = make_shm_wire(uid128, nranks, rank, std::max(c->N, 2 * c->Nc) + 8, true);
+        if (hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) != hipSuccess)
+            return fail(c, SDC_ERR_HIP, "cannot create the message stream");
+        cs->wire = w;
+    } else {
+        std::string why;
+        RcclApi* api = rccl_api(&why);
+        if (!api) return fail(c, SDC_ERR_COMM, "%s", why.c_str());
+        auto w = std::make_shared<RcclWire>();
+        w->api = api;
+        w->rank = rank;
+        w->size = nranks;
+        ncclUniqueId id;
+        memcpy(&id, uid128, sizeof id);
+        ncclResult_t r = api->CommInitRank(&w->comm, nranks, id, rank);
+        if (r != ncclSuccess) {
+            w->comm = nullptr;
+            return fail(c, SDC_ERR_COMM, "ncclCommInitRank(rank %d of %d): %s", rank, nranks, api->GetErrorString(r));
+        }
+        if (hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) != hipSuccess)
+            return fail(c, SDC_ERR_HIP, "cannot create the message stream");
+        cs->wire = w;
+    }
+    int rc = comm_events(c, cs.get());
+    if (rc != SDC_OK) {
+        c->comm = cs.release();
         comm_free(c);
-        return fail(c, SDC_ERR_COMM, "ncclCommInitRank(rank %d of %d): %s", rank, nranks, api->GetErrorString(r));
+        return rc;
     }
-    if (hipStreamCreateWithFlags(&cs->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&cs->ready, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&cs->done, hipEventDisableTiming) != hipSuccess) {
-        comm_free(c);  // (the communicator and whatever was created are released again)
-        return fail(c, SDC_ERR_HIP, "cannot create the message stream / events");
-    }
+    c->comm = cs.release();
     return SDC_OK;
+}
+
+// a further level of the same time rank (MLSDC / PFASST: controller_MPI.py sends on every level) shares the owner's
+// communicator and message stream; messages of all levels are matched by their order, like the tags level*100 + iter do
+extern "C" int sdc_comm_attach(sdc_ctx* c, sdc_ctx* owner) {
+    if (!c || !owner) return fail(c, SDC_ERR_PARAM, "null pointer");
+    if (!owner->comm) return fail(c, SDC_ERR_STATE, "the owner has no communicator (sdc_comm_init)");
+    if (c->comm) return fail(c, SDC_ERR_STATE, "communicator exists already (sdc_comm_destroy first)");
+    if (c->device != owner->device) return fail(c, SDC_ERR_PARAM, "levels of one time rank live on one device");
+    if (ShmWire* sw = dynamic_cast<ShmWire*>(owner->comm->wire.get()))
+        if (std::max(c->N, 2 * c->Nc) + 8 > sw->cap)
+            return fail(c, SDC_ERR_PARAM, "attach the smaller level to the larger one (mailbox capacity)");
+    std::unique_ptr<CommState> cs(new CommState);
+    cs->wire = owner->comm->wire;
+    cs->relay = owner->comm->relay;
+    int rc = comm_events(c, cs.get());
+    c->comm = cs.release();
+    if (rc != SDC_OK) comm_free(c);
+    return rc;
 }
 
 extern "C" int sdc_comm_destroy(sdc_ctx* c) {
@@ -150,65 +537,88 @@ extern "C" int sdc_comm_destroy(sdc_ctx* c) {
     return SDC_OK;
 }
 
+#define NEED_COMM(c)                                                                   \
+    if (!(c) || !(c)->comm) return fail(c, SDC_ERR_STATE, "no communicator (sdc_comm_init)"); \
+    CommState* cs = (c)->comm;                                                         \
+    Wire* w = cs->wire.get()
+
 extern "C" int sdc_comm_set_chunk(sdc_ctx* c, size_t doubles_per_piece) {
-    if (!c || !c->comm) return fail(c, SDC_ERR_STATE, "no communicator (sdc_comm_init)");
-    c->comm->chunk = doubles_per_piece;
+    NEED_COMM(c);
+    w->chunk = doubles_per_piece;
     return SDC_OK;
 }
 
-// pieces of one message inside the open group (all pieces of a message go to / come from the same peer, in order)
-static ncclResult_t put(RcclApi* api, CommState* cs, const double* buf, size_t n, int peer) {
-    const size_t step = cs->chunk ? cs->chunk : n;
-    for (size_t o = 0; o < n; o += step) {
-        ncclResult_t r = api->Send(buf + o, std::min(step, n - o), ncclDouble, peer, cs->comm, cs->stream);
-        if (r != ncclSuccess) return r;
-    }
-    return ncclSuccess;
+extern "C" int sdc_comm_set_relay(sdc_ctx* c, int on) {
+    NEED_COMM(c);
+    (void)w;
+    cs->relay = on != 0;
+    return SDC_OK;
 }
-static ncclResult_t get(RcclApi* api, CommState* cs, double* buf, size_t n, int peer) {
-    const size_t step = cs->chunk ? cs->chunk : n;
-    for (size_t o = 0; o < n; o += step) {
-        ncclResult_t r = api->Recv(buf + o, std::min(step, n - o), ncclDouble, peer, cs->comm, cs->stream);
-        if (r != ncclSuccess) return r;
+
+extern "C" int sdc_comm_info(sdc_ctx* c, int* rank, int* size, unsigned long long* two_hop_calls,
+                             unsigned long long* mesh_bcast_calls, char* kind16) {
+    NEED_COMM(c);
+    if (rank) *rank = w->rank;
+    if (size) *size = w->size;
+    if (two_hop_calls) *two_hop_calls = cs->two_hop_calls;
+    if (mesh_bcast_calls) *mesh_bcast_calls = cs->mesh_bcast_calls;
+    if (kind16) {
+        strncpy(kind16, w->kind(), 15);
+        kind16[15] = 0;
     }
-    return ncclSuccess;
+    return SDC_OK;
+}
+
+static int ensure_inbox(sdc_ctx* c, CommState* cs) {
+    if (!cs->inbox) {
+        HIPCHK(c, hipMalloc((void**)&cs->inbox, c->N * sizeof(double)));
+        c->bytes += c->N * sizeof(double);
+    }
+    return SDC_OK;
+}
+// the message stream may write the inbox once the sdc_replace_u0 of the previous receive has read it - and waits for
+// nothing that was queued on the engine's stream after that
+static int inbox_writable(sdc_ctx* c, CommState* cs, Wire* w) {
+    if (cs->inbox_busy) {
+        HIPCHK(c, hipStreamWaitEvent(w->stream, cs->inbox_free, 0));
+        cs->inbox_busy = false;
+    }
+    return SDC_OK;
+}
+static int deliver_inbox(sdc_ctx* c, CommState* cs) {
+    int rc = sdc_replace_u0(c, cs->inbox);
+    if (rc != SDC_OK) return rc;
+    HIPCHK(c, hipEventRecord(cs->inbox_free, c->stream));
+    cs->inbox_busy = true;
+    return SDC_OK;
 }
 
 // send UEND to send_peer and / or receive the new u[0] from recv_peer as ONE group (ncclGroupStart / End): the two
 // directions progress concurrently instead of unwinding rank by rank.  A peer < 0 skips that direction (first /
 // last rank, or a predecessor that is done: controller_MPI.py:235-305).
 extern "C" int sdc_comm_exchange(sdc_ctx* c, int send_peer, int recv_peer) {
-    if (!c || !c->comm) return fail(c, SDC_ERR_STATE, "no communicator (sdc_comm_init)");
-    CommState* cs = c->comm;
-    RcclApi* api = rccl_api(nullptr);
-    if (send_peer >= cs->size || recv_peer >= cs->size) return fail(c, SDC_ERR_PARAM, "peer out of range");
+    NEED_COMM(c);
+    if (send_peer >= w->size || recv_peer >= w->size) return fail(c, SDC_ERR_PARAM, "peer out of range");
+    if (cs->posted_recv >= 0) return fail(c, SDC_ERR_STATE, "a posted hand-over is still open (sdc_comm_handover_complete)");
     if (send_peer < 0 && recv_peer < 0) return SDC_OK;
+    int rc;
     if (send_peer >= 0) {  // behind the point where UEND is complete, and behind nothing queued later
-        int rc = sdc_stream_wait_uend(c, cs->stream);
-        if (rc != SDC_OK) return rc;
-    }
-    if (recv_peer >= 0 && !cs->inbox) {
-        HIPCHK(c, hipMalloc((void**)&cs->inbox, c->N * sizeof(double)));
-        c->bytes += c->N * sizeof(double);
+        if ((rc = sdc_stream_wait_uend(c, w->stream)) != SDC_OK) return rc;
     }
     if (recv_peer >= 0) {
-        // the inbox may still be read by the sdc_replace_u0 of the previous receive
-        HIPCHK(c, hipEventRecord(cs->ready, c->stream));
-        HIPCHK(c, hipStreamWaitEvent(cs->stream, cs->ready, 0));
+        if ((rc = ensure_inbox(c, cs)) != SDC_OK) return rc;
+        if ((rc = inbox_writable(c, cs, w)) != SDC_OK) return rc;
     }
-    RCCLCHK(c, api, api->GroupStart());
-    ncclResult_t r = ncclSuccess;
-    if (send_peer >= 0) r = put(api, cs, c->UEND, c->N, send_peer);
-    if (r == ncclSuccess && recv_peer >= 0) r = get(api, cs, cs->inbox, c->N, recv_peer);
-    ncclResult_t re = api->GroupEnd();
-    if (r != ncclSuccess || re != ncclSuccess)
-        return fail(c, SDC_ERR_COMM, "send/recv group: %s", api->GetErrorString(r != ncclSuccess ? r : re));
-    HIPCHK(c, hipEventRecord(cs->done, cs->stream));
+    if ((rc = w->group_begin(c)) != SDC_OK) return rc;
+    if (send_peer >= 0) w->send(c, c->UEND, c->N, send_peer);
+    if (recv_peer >= 0) w->recv(c, cs->inbox, c->N, recv_peer);
+    if ((rc = w->group_end(c)) != SDC_OK) return rc;
+    HIPCHK(c, hipEventRecord(cs->done, w->stream));
     if (send_peer >= 0) cs->send_pending = true;
     if (recv_peer >= 0) {
         HIPCHK(c, hipStreamWaitEvent(c->stream, cs->done, 0));
         cs->send_pending = false;  // the engine's stream now runs behind the whole group
-        return sdc_replace_u0(c, cs->inbox);
+        return deliver_inbox(c, cs);
     }
     return SDC_OK;
 }
@@ -216,29 +626,165 @@ extern "C" int sdc_comm_exchange(sdc_ctx* c, int send_peer, int recv_peer) {
 extern "C" int sdc_send_uend(sdc_ctx* c, int peer) { return sdc_comm_exchange(c, peer, -1); }
 extern "C" int sdc_recv_u0(sdc_ctx* c, int peer) { return sdc_comm_exchange(c, -1, peer); }
 
+// Lock-step runs (every active rank iterates in step: single level, Jacobi-type multi-step SDC, fixed number of sweeps
+// or all_to_done): the hand-over uend(r) -> u[0](r + 1) of ALL `nactive` ranks, posted now and completed later.  The
+// message stream waits for UEND only (sdc_set_early_end_point: the sweep produced it before its residual passes), so
+// the message travels while the engine's stream still reduces the residual; sdc_comm_handover_complete then makes the
+// engine's stream wait for the message and hands the received value to the level (sdc_replace_u0).  More than two
+// ranks (and sdc_comm_set_relay on): two hops over the whole mesh instead of one link per message.
+extern "C" int sdc_comm_handover_post(sdc_ctx* c, int nactive) {
+    NEED_COMM(c);
+    if (nactive < 1 || nactive > w->size) return fail(c, SDC_ERR_PARAM, "%d active ranks of %d", nactive, w->size);
+    if (cs->posted_recv >= 0) return fail(c, SDC_ERR_STATE, "a posted hand-over is still open (sdc_comm_handover_complete)");
+    const int r = w->rank;
+    if (r >= nactive) return SDC_OK;
+    const bool sending = r < nactive - 1, receiving = r >= 1;
+    const bool two_hop = cs->relay && nactive > 2;
+    int rc;
+    if (sending) {  // (a relay that does not send never reads its own UEND)
+        if ((rc = sdc_stream_wait_uend(c, w->stream)) != SDC_OK) return rc;
+    }
+    if (receiving) {
+        if ((rc = ensure_inbox(c, cs)) != SDC_OK) return rc;
+        if ((rc = inbox_writable(c, cs, w)) != SDC_OK) return rc;
+    }
+    if (two_hop) {
+        const size_t slot = two_hop_slot(c->N, nactive, r), need = slot * (size_t)(nactive - 1);
+        if (need > cs->stage_len) {
+            if (cs->stage) {
+                HIPCHK(c, hipStreamSynchronize(w->stream));
+                (void)hipFree(cs->stage);
+                c->bytes -= cs->stage_len * sizeof(double);
+                cs->stage = nullptr;
+            }
+            HIPCHK(c, hipMalloc((void**)&cs->stage, std::max<size_t>(need, 1) * sizeof(double)));
+            cs->stage_len = std::max<size_t>(need, 1);
+            c->bytes += cs->stage_len * sizeof(double);
+        }
+        cs->two_hop_calls++;
+        if ((rc = two_hop_handover(w, c, nactive, c->UEND, cs->inbox, cs->stage, c->N)) != SDC_OK) return rc;
+    } else {
+        if ((rc = w->group_begin(c)) != SDC_OK) return rc;
+        if (sending) w->send(c, c->UEND, c->N, r + 1);
+        if (receiving) w->recv(c, cs->inbox, c->N, r - 1);
+        if ((rc = w->group_end(c)) != SDC_OK) return rc;
+    }
+    HIPCHK(c, hipEventRecord(cs->done, w->stream));
+    cs->send_pending = sending;
+    cs->posted_recv = receiving ? 1 : 0;
+    return SDC_OK;
+}
+
+extern "C" int sdc_comm_handover_complete(sdc_ctx* c) {
+    NEED_COMM(c);
+    (void)w;
+    if (cs->posted_recv < 0) return SDC_OK;
+    const bool receiving = cs->posted_recv == 1;
+    cs->posted_recv = -1;
+    HIPCHK(c, hipStreamWaitEvent(c->stream, cs->done, 0));
+    cs->send_pending = false;
+    return receiving ? deliver_inbox(c, cs) : SDC_OK;
+}
+
+// a device buffer of rank `root` to every rank, in place, ordered on the engine's stream on both sides
+static int bcast_buffer(sdc_ctx* c, CommState* cs, Wire* w, double* buf, size_t n, int root) {
+    if (root < 0 || root >= w->size) return fail(c, SDC_ERR_PARAM, "root out of range");
+    HIPCHK(c, hipEventRecord(cs->ready, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(w->stream, cs->ready, 0));
+    int rc;
+    if (cs->relay && w->size > 2) {
+        cs->mesh_bcast_calls++;
+        rc = mesh_bcast(w, c, buf, n, root);
+    } else {
+        rc = w->bcast(c, buf, n, root);
+    }
+    if (rc != SDC_OK) return rc;
+    HIPCHK(c, hipEventRecord(cs->done, w->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, cs->done, 0));
+    return SDC_OK;
+}
+
 // one slab field of rank `root` to every rank, in place (the end value of a block: controller_MPI.py:125-130 bcast
 // of uend; mesh.py:113-125)
 extern "C" int sdc_bcast(sdc_ctx* c, int slot, int m, int root) {
-    if (!c || !c->comm) return fail(c, SDC_ERR_STATE, "no communicator (sdc_comm_init)");
-    CommState* cs = c->comm;
-    RcclApi* api = rccl_api(nullptr);
-    if (root < 0 || root >= cs->size) return fail(c, SDC_ERR_PARAM, "root out of range");
+    NEED_COMM(c);
     double* buf = (double*)sdc_slot_ptr(c, slot, m, 0);  // (stores deferred node fields; marks UEND as rewritten)
     if (!buf) return fail(c, SDC_ERR_PARAM, "bad slot (%d, %d)", slot, m);
     int rc = uend_write_fence(c);
     if (rc != SDC_OK) return rc;
-    HIPCHK(c, hipEventRecord(cs->ready, c->stream));
-    HIPCHK(c, hipStreamWaitEvent(cs->stream, cs->ready, 0));
-    RCCLCHK(c, api, api->Broadcast(buf, buf, c->N, ncclDouble, root, cs->comm, cs->stream));
-    HIPCHK(c, hipEventRecord(cs->done, cs->stream));
-    HIPCHK(c, hipStreamWaitEvent(c->stream, cs->done, 0));
-    if (cs->rank != root && slot == SDC_SLOT_U) return sdc_invalidate_spectra(c, m == 0 ? 1 : 2);
+    if ((rc = bcast_buffer(c, cs, w, buf, c->N, root)) != SDC_OK) return rc;
+    if (w->rank != root && slot == SDC_SLOT_U) return sdc_invalidate_spectra(c, m == 0 ? 1 : 2);
     return SDC_OK;
+}
+
+// any device buffer of n doubles (the controller's own copy of the end value)
+extern "C" int sdc_comm_bcast_buffer(sdc_ctx* c, double* buf, size_t n, int root) {
+    NEED_COMM(c);
+    if (!buf) return fail(c, SDC_ERR_PARAM, "null pointer");
+    if (ShmWire* sw = dynamic_cast<ShmWire*>(w))
+        if (n > sw->cap) return fail(c, SDC_ERR_PARAM, "buffer of %zu doubles exceeds the mailbox (%zu)", n, sw->cap);
+    return bcast_buffer(c, cs, w, buf, n, root);
 }
 
 // host waits until every message posted so far has completed
 extern "C" int sdc_comm_sync(sdc_ctx* c) {
-    if (!c || !c->comm) return fail(c, SDC_ERR_STATE, "no communicator (sdc_comm_init)");
-    HIPCHK(c, hipStreamSynchronize(c->comm->stream));
+    NEED_COMM(c);
+    (void)cs;
+    return w->sync(c);
+}
+
+// The exchange patterns on plain host buffers over a host-mode shm wire: rank `rank` of `nranks` (threads or processes
+// that call this with the same job name) fills a message with a pattern only it can have made, runs
+//   what = 0: direct hand-over r -> r + 1 among the first `arg` ranks (0: all), 1: the same over two hops,
+//   what = 2: mesh broadcast from rank `arg`
+// `rounds` times over the same mailboxes, and checks every value it received.  No GPU involved: this is how the CPU suite covers the piece arithmetic and the
+// mailbox protocol.  Returns SDC_OK, or SDC_ERR_COMM with the first mismatch in sdc_last_error(NULL).
+extern "C" int sdc_comm_selftest(const char* job, int nranks, int rank, size_t n, int what, int arg, int rounds) {
+    if (!job || nranks < 1 || rank < 0 || rank >= nranks || rounds < 1) return fail(nullptr, SDC_ERR_PARAM, "bad self-test arguments");
+    char uid[128];
+    memset(uid, 0, sizeof uid);
+    snprintf(uid, sizeof uid, "shm:%s", job);
+    auto w = make_shm_wire(uid, nranks, rank, n + 8, false);
+    auto value = [](int origin, int round, size_t i) { return (double)origin * 1e6 + (double)round * 1e3 + (double)(i % 997) + 0.25; };
+    std::vector<double> src(std::max<size_t>(n, 1)), dst(std::max<size_t>(n, 1)), stage;
+    for (int round = 0; round < rounds; ++round) {
+        for (size_t i = 0; i < n; ++i) {
+            src[i] = value(rank, round, i);
+            dst[i] = -1.0;
+        }
+        int rc = SDC_OK;
+        int expect_from = -1;
+        if (what == 0 || what == 1) {
+            const int P = arg > 0 ? arg : nranks;  // active ranks
+            if (rank < P) {
+                if (what == 1 && P > 2) {
+                    stage.assign(std::max<size_t>(two_hop_slot(n, P, rank) * (size_t)(P - 1), 1), -2.0);
+                    rc = two_hop_handover(w.get(), nullptr, P, src.data(), dst.data(), stage.data(), n);
+                } else {
+                    rc = w->group_begin(nullptr);
+                    if (rank < P - 1) w->send(nullptr, src.data(), n, rank + 1);
+                    if (rank >= 1) w->recv(nullptr, dst.data(), n, rank - 1);
+                    if (rc == SDC_OK) rc = w->group_end(nullptr);
+                }
+                if (rank >= 1) expect_from = rank - 1;
+            }
+        } else if (what == 2) {
+            const int root = arg;
+            std::vector<double>& buf = rank == root ? src : dst;
+            rc = mesh_bcast(w.get(), nullptr, buf.data(), n, root);
+            if (rank != root) expect_from = root;
+        } else {
+            return fail(nullptr, SDC_ERR_PARAM, "self-test %d", what);
+        }
+        if (rc != SDC_OK) return rc;
+        if (expect_from >= 0)
+            for (size_t i = 0; i < n; ++i)
+                if (dst[i] != value(expect_from, round, i))
+                    return fail(nullptr, SDC_ERR_COMM, "rank %d, round %d: value %zu is %.17g, expected %.17g (from rank %d)", rank,
+                                round, i, dst[i], value(expect_from, round, i), expect_from);
+        for (size_t i = 0; i < n; ++i)
+            if (src[i] != value(rank, round, i) && !(what == 2 && rank != arg))
+                return fail(nullptr, SDC_ERR_COMM, "rank %d, round %d: the message itself was modified at %zu", rank, round, i);
+    }
     return SDC_OK;
 }

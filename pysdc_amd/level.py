@@ -343,6 +343,12 @@ class Level(DeviceBacked):
         self._u.mark([0])
         self._res_cache = None
 
+    def received_u0(self):
+        """the engine has taken a new u[0] from its communicator (sdc_comm_*: inbox -> sdc_replace_u0 inside the library)"""
+        self._lists()
+        self._u.mark([0])
+        self._res_cache = None
+
     def refresh_f0(self):
         """f[0] = f(u[0]) after u[0] was replaced (controller_MPI.py:233, controller_nonMPI.py:284).  Nothing on
         the sweep path reads f[0]; an engine-backed problem evaluates it when it is asked for."""

@@ -56,12 +56,20 @@ PROTOTYPES = {
     'sdc_replace_u0': (C.c_int, [_vp, _vp]),
     'sdc_comm_unique_id': (C.c_int, [C.c_char_p]),
     'sdc_comm_init': (C.c_int, [_vp, C.c_char_p, C.c_int, C.c_int]),
+    'sdc_comm_attach': (C.c_int, [_vp, _vp]),
     'sdc_comm_destroy': (C.c_int, [_vp]),
     'sdc_comm_exchange': (C.c_int, [_vp, C.c_int, C.c_int]),
     'sdc_send_uend': (C.c_int, [_vp, C.c_int]),
     'sdc_recv_u0': (C.c_int, [_vp, C.c_int]),
     'sdc_bcast': (C.c_int, [_vp, C.c_int, C.c_int, C.c_int]),
+    'sdc_comm_handover_post': (C.c_int, [_vp, C.c_int]),
+    'sdc_comm_handover_complete': (C.c_int, [_vp]),
+    'sdc_comm_bcast_buffer': (C.c_int, [_vp, _vp, C.c_size_t, C.c_int]),
     'sdc_comm_set_chunk': (C.c_int, [_vp, C.c_size_t]),
+    'sdc_comm_set_relay': (C.c_int, [_vp, C.c_int]),
+    'sdc_comm_info': (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_ulonglong),
+                                C.POINTER(C.c_ulonglong), C.c_char_p]),
+    'sdc_comm_selftest': (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int]),
     'sdc_comm_sync': (C.c_int, [_vp]),
     'sdc_fft_prolong': (C.c_int, [_vp, _vp, _vp, _vp, C.c_double]),
     'sdc_materialize': (C.c_int, [_vp, C.c_int, C.c_int]),

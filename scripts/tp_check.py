@@ -41,7 +41,7 @@ out, errors = {}, []
 def rank_main(rank):
     try:
         FD.bind(world, rank)
-        Cd = controller_dist(dict(logger_level=40), description_from(meta), dist=FD)
+        Cd = controller_dist(dict(logger_level=40, comm_wire='shm'), description_from(meta), dist=FD)
         v = Cd.S.levels[0].prob.u_init
         v[:] = u0h
         uend, stats = Cd.run(v, meta['t0'], meta['Tend'])

@@ -1,7 +1,9 @@
 """In-process stand-in for the part of torch.distributed that pysdc_amd.controller.controller_dist uses: every rank is
-a THREAD of one process, all ranks share one GPU.  Point-to-point operations hand over a snapshot of the sender's
-tensor (what RCCL's staging buffers do) with stream-ordered events, so side streams, early posting and the two-hop
-relay of the controller run exactly as they would over RCCL - only the wire is a device copy."""
+a THREAD of one process, all ranks share one GPU.  Device levels hand their state over through the C-ABI communicator
+itself (controller parameter comm_wire='shm': the shared-memory mailbox wire of sdc_comm_*, which works between threads
+like between processes), so this stand-in only carries what torch.distributed carries in a real run: the unique id,
+convergence flags, step counts, barriers.  (Its point-to-point operations - snapshots with stream-ordered events - still
+serve controllers whose levels are not device levels.)"""
 import queue
 import threading
 
@@ -118,6 +120,17 @@ def broadcast(tensor, src, group=None):
         tensor.copy_(w.bc['v'])
         if tensor.is_cuda:
             torch.cuda.current_stream().synchronize()
+    w.barrier.wait()
+
+
+def broadcast_object_list(box, src=0, group=None):
+    """host objects (the unique id of the C-ABI communicator) from rank `src` to every rank"""
+    w = _local.world
+    if _local.rank == src:
+        w.bc['obj'] = list(box)
+    w.barrier.wait()
+    if _local.rank != src:
+        box[:] = w.bc['obj']
     w.barrier.wait()
 
 

@@ -1,8 +1,10 @@
-"""GPU: the RCCL transport behind the C-ABI (include/sdcmi.h sdc_comm_*, pysdc_amd/comm.py).  On the one-GPU box a
-communicator of ONE rank carries the hand-over to itself (ncclSend / ncclRecv to the own rank inside one group): that
-drives librccl binding, communicator setup, the message stream, the event ordering against the engine's stream, the
-inbox -> sdc_replace_u0 path and the UEND write fence on real hardware.  The two-rank test needs two GPUs (it is
-skipped on the one-GPU box and runs wherever the suite is given a multi-GPU node)."""
+"""GPU: the transport behind the C-ABI (include/sdcmi.h sdc_comm_*, pysdc_amd/comm.py).  On the one-GPU box a
+communicator of ONE rank carries the hand-over to itself over RCCL (ncclSend / ncclRecv to the own rank inside one
+group): that drives librccl binding, communicator setup, the message stream, the event ordering against the engine's
+stream, the inbox -> sdc_replace_u0 path and the UEND write fence on real hardware.  Several ranks on the one GPU - as
+threads and as separate processes - run the same calls over the shared-memory wire: direct and two-hop hand-over, mesh
+broadcast, levels that share a communicator, and `bench.py --gpus 2` from its self-launching parent down to the JSON
+line.  The two-rank RCCL test needs two GPUs (skipped on the one-GPU box, runs wherever the suite is given more)."""
 import numpy as np
 import pytest
 
@@ -25,10 +27,11 @@ def _engine(n=32, M=3):
 
 @pytest.mark.parametrize('chunk', [0, 1000])
 def test_single_rank_handover_through_rccl(chunk):
-    from pysdc_amd.comm import RcclComm
+    from pysdc_amd.comm import DeviceComm
 
     e = _engine()
-    comm = RcclComm(e, 1, 0)
+    comm = DeviceComm(e, 1, 0)
+    assert comm.info()['wire'] == 'rccl'
     if chunk:
         comm.set_chunk(chunk)
     rng = np.random.default_rng(1)
@@ -69,10 +72,10 @@ def _two_rank_worker(rank, port, out):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
     torch.cuda.set_device(rank)
     dist.init_process_group('gloo', rank=rank, world_size=2)
-    from pysdc_amd.comm import RcclComm, torch_host_bcast
+    from pysdc_amd.comm import DeviceComm, torch_host_bcast
 
     e = _engine()
-    comm = RcclComm(e, 2, rank, host_bcast=torch_host_bcast)
+    comm = DeviceComm(e, 2, rank, host_bcast=torch_host_bcast)
     val = np.full(e.nvars, float(rank + 1))
     e.upload(L.SLOT_UEND, 0, val)
     e.upload(L.SLOT_U, 0, np.zeros(e.nvars))
@@ -103,3 +106,158 @@ def test_two_ranks_over_xgmi():
             if p.is_alive():   # never leave a rank behind that may hold the GPUs
                 p.kill()
     assert res == [(0, 0.0, 2.0), (1, 1.0, 2.0)]
+
+
+def _thread_ranks(P, body):
+    """P ranks as threads of this process on the one GPU; body(rank, uid) -> result"""
+    import threading
+    import traceback
+
+    from pysdc_amd.comm import shm_unique_id
+
+    uid = shm_unique_id()
+    out, errors = [None] * P, []
+
+    def run(r):
+        try:
+            out[r] = body(r, uid)
+        except Exception:  # noqa: BLE001
+            errors.append(traceback.format_exc())
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(P)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(240)
+    assert not errors, errors[0]
+    return out
+
+
+@pytest.mark.parametrize('P,relay,active', [(2, True, 2), (3, True, 3), (4, True, 4), (4, False, 4), (5, True, 3), (8, True, 8)])
+def test_lockstep_handover_and_broadcast_between_ranks_on_one_device(P, relay, active):
+    """uend(r) -> u[0](r + 1) for all active ranks at once (sdc_comm_handover_post / _complete: direct for two ranks, two
+    hops through all ranks beyond), three rounds over the same mailboxes, then the end-of-block broadcast from the last
+    active rank (mesh scatter + all-gather beyond two ranks): every value bit for bit, counters as expected"""
+    from pysdc_amd.comm import DeviceComm
+
+    n = 24  # 24^3 = 13824 values: not a multiple of 5 or 7, so pieces of unequal length occur
+
+    def field(r, k):
+        return np.random.default_rng(100 * k + r).standard_normal((n, n, n))
+
+    def body(r, uid):
+        e = _engine(n=n)
+        comm = DeviceComm(e, P, r, uid=uid)
+        comm.set_relay(relay)
+        assert comm.info()['wire'] == 'shm'
+        got = []
+        for k in range(3):
+            e.upload(L.SLOT_UEND, 0, field(r, k))
+            e.upload(L.SLOT_U, 0, np.zeros((n, n, n)))
+            comm.handover_post(active)
+            comm.handover_complete()
+            got.append(e.download(L.SLOT_U, 0))
+        e.upload(L.SLOT_UEND, 0, field(r, 9))
+        comm.bcast(L.SLOT_UEND, 0, root=active - 1)
+        end = e.download(L.SLOT_UEND)
+        info = comm.info()
+        comm.sync()
+        comm.close()
+        e.close()
+        return got, end, info
+
+    res = _thread_ranks(P, body)
+    for r, (got, end, info) in enumerate(res):
+        for k in range(3):
+            want = field(r - 1, k) if 1 <= r < active else np.zeros((n, n, n))
+            assert np.array_equal(got[k], want), (r, k)
+        assert np.array_equal(end, field(active - 1, 9)), r
+        assert info['two_hop_handovers'] == (3 if relay and active > 2 and r < active else 0)
+        assert info['mesh_broadcasts'] == (1 if relay and P > 2 else 0)
+
+
+def test_levels_of_one_rank_share_a_communicator():
+    """two levels per rank (fine owns, coarse attaches: PFASST sends on every level, controller_MPI.py:702-768): messages of
+    both levels travel over the one communicator in the order they are posted"""
+    from pysdc_amd.comm import DeviceComm
+
+    def body(r, uid):
+        fine, coarse = _engine(n=32), _engine(n=16)
+        cf = DeviceComm(fine, 2, r, uid=uid)
+        cc = DeviceComm.attach(coarse, cf)
+        for e, v in ((fine, 1.0 + r), (coarse, 10.0 + r)):
+            e.upload(L.SLOT_UEND, 0, np.full(e.nvars, v))
+            e.upload(L.SLOT_U, 0, np.zeros(e.nvars))
+        to, frm = (1, None) if r == 0 else (None, 0)
+        cf.exchange(send_to=to, recv_from=frm)      # fine first ...
+        cc.exchange(send_to=to, recv_from=frm)      # ... then coarse: a lone send each on rank 0, both in flight together
+        out = float(fine.download(L.SLOT_U, 0).max()), float(coarse.download(L.SLOT_U, 0).max())
+        cc.close()
+        cf.close()
+        fine.close()
+        coarse.close()
+        return out
+
+    assert _thread_ranks(2, body) == [(0.0, 0.0), (1.0, 10.0)]
+
+
+def test_bench_two_ranks_on_one_gpu_end_to_end(tmp_path):
+    """`python bench.py --gpus 2` as the driver starts it (no launcher, no environment): the parent starts the rank
+    processes, they rendezvous over gloo, the state vectors travel through the C-ABI communicator (shared-memory wire,
+    both ranks on GPU 0), rank 0's JSON line comes back.  The end value equals controller_nonMPI emulating the two
+    ranks; every rank reports its own iterations."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    from pysdc_amd.controller import controller_nonMPI
+    from pysdc_amd.problems import heatNd_unforced
+    from pysdc_amd.sweepers import generic_implicit
+    from pysdc_amd.stats import get_sorted
+    import ctypes as C
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n, steps, warmup = 256, 2, 1
+    dump = str(tmp_path / 'uend.npy')
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--n', str(n), '--backend', 'gloo', '--same-device',
+           '--steps', str(steps), '--warmup', str(warmup), '--dump-end-value', dump, '--job-timeout', '600']
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=env, cwd=root)
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith('{')]
+    assert res.returncode == 0 and lines, (res.returncode, res.stdout[-2000:], res.stderr[-2000:])
+    rec = json.loads(lines[-1])
+    assert 'error' not in rec, rec
+    assert rec['n_gpus'] == 2 and rec['steps'] == steps and rec['scaling'] == 'weak'
+    assert rec['value'] == pytest.approx(2 * steps / (rec['ms_per_step'] * 1e-3 * steps), rel=1e-6)
+    assert len(rec['per_rank']) == 2 and [p['rank'] for p in rec['per_rank']] == [0, 1]
+    assert all(p['niter'] == [4] * steps and p['wire'] == 'shm' for p in rec['per_rank'])
+    assert rec['niter'] == [4] * steps and rec['finite']
+    # the same six time steps by the serial controller emulating two ranks
+    dt = 1e-3 * (512.0 / n) ** 2
+    desc = dict(problem_class=heatNd_unforced, problem_params=dict(nvars=(n, n, n), nu=0.1, freq=2, order=2),
+                sweeper_class=generic_implicit, sweeper_params=dict(num_nodes=5, quad_type='RADAU-RIGHT', QI='IE'),
+                level_params=dict(dt=dt, restol=-1.0, nsweeps=1), step_params=dict(maxiter=4))
+    ctrl = controller_nonMPI(2, dict(logger_level=40), desc)
+    lvl = ctrl.MS[0].levels[0]
+    u0 = lvl.prob.u_init
+    L.check(lvl.engine.lib.sdc_init_field(lvl.engine.ctx, u0.ptr, (C.c_int * 3)(2, 2, 2), 1e-3, 0), lvl.engine.ctx)
+    ref, stats = ctrl.run(u0, 0.0, 2 * dt * (warmup + steps))
+    assert [v for _, v in get_sorted(stats, type='niter')] == [4] * (2 * (warmup + steps))
+    ref, got = ref.get(), np.load(dump)
+    assert np.max(np.abs(got - ref)) <= 1e-12 * np.max(np.abs(ref))
+
+
+def test_bench_reports_a_failed_launch_as_json(tmp_path):
+    """a multi-rank job that cannot start (two ranks on one GPU over RCCL is refused before anything runs) ends with ONE
+    JSON error line and a non-zero exit code - no hang, no partial output"""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--n', '64', '--same-device'],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120, cwd=root)
+    assert res.returncode != 0
+    assert 'error' in json.loads(res.stdout.strip().splitlines()[-1])

@@ -243,7 +243,7 @@ def _rank_thread(world, rank, name, fname, out, errors, skip_residual=False):
             desc = description_from(meta)
         if skip_residual:
             desc['sweeper_params']['skip_residual_computation'] = ('IT_CHECK', 'IT_FINE', 'IT_DOWN', 'IT_UP', 'IT_COARSE')
-        C = controller_dist(dict(logger_level=40, **meta['controller_params']), desc, dist=FD)
+        C = controller_dist(dict(logger_level=40, comm_wire='shm', **meta['controller_params']), desc, dist=FD)
         P = C.S.levels[0].prob
         u0 = P.u_init
         u0[:] = case['u0']
@@ -379,7 +379,7 @@ def test_time_parallel_controller_64cubed_matches_serial_emulation(nranks, M, si
             FD.bind(world, rank)
             from pysdc_amd.controller import controller_dist
 
-            Cd = controller_dist(dict(logger_level=40), description_from(meta), dist=FD)
+            Cd = controller_dist(dict(logger_level=40, comm_wire='shm'), description_from(meta), dist=FD)
             Pd = Cd.S.levels[0].prob
             v = Pd.u_init
             v[:] = u0h
@@ -438,7 +438,7 @@ def test_config5_pfasst_four_ranks_match_serial_emulation():
             FD.bind(world, rank)
             from pysdc_amd.controller import controller_dist
 
-            Cd = controller_dist(dict(cp), desc, dist=FD)
+            Cd = controller_dist(dict(cp, comm_wire='shm'), desc, dist=FD)
             Pd = Cd.S.levels[0].prob
             uend, stats = Cd.run(Pd.u_exact(0.0), 0.0, 8e-3)
             niter = get_sorted(stats, type='niter', sortby='time')
