@@ -101,8 +101,8 @@ int sdc_set_tau_active(sdc_ctx* ctx, int active); /* L.tau[m] is None  <->  0 */
  * of U[1..M] between sweeps and gathers on them instead of re-transforming M fields every sweep.  Anything
  * that writes a U field behind the engine's back (datatype operations on slab views, RCCL receives) must say
  * so: which = 1: U[0] changed, 2: some U[m >= 1] changed, 4: some F[m >= 1] was overwritten (the next sweep then
- * gathers on the F slab like the reference does), 8: UEND was overwritten, 16: some TAU[m] changed (every call drops
- * the cached residual norms); bits combine.  sdc_upload / sdc_predict do it themselves. */
+ * gathers on the F slab like the reference does), 8: UEND was overwritten, 16: some TAU[m] changed (every bit but 8
+ * drops the cached residual norms); bits combine.  sdc_upload / sdc_predict do it themselves. */
 int sdc_invalidate_spectra(sdc_ctx* ctx, int which);
 int sdc_set_spectral_reuse(sdc_ctx* ctx, int on);
 /* The 3-D sweep evaluates f at all nodes and the node norms of the collocation residual in ONE kernel; a
@@ -149,6 +149,23 @@ int sdc_set_keep_residual_fields(sdc_ctx* ctx, int on);
 int sdc_set_early_end_point(sdc_ctx* ctx, int on);
 int sdc_stream_wait_uend(sdc_ctx* ctx, void* other_stream);
 int sdc_replace_u0(sdc_ctx* ctx, const double* src);
+/* Start and end values as SPECTRA.  Between levels that sweep in Fourier space (periodic finite differences, exact solve,
+ * deferred node fields: sdc_spectral_handover_ok) the forward hand-over of a time-parallel run (controller_MPI.py:218-305)
+ * needs neither the inverse transform of the sender's last node nor the forward transform of the receiver's new u[0]: the
+ * last node's half spectrum (Nc = (n/2+1) n^(ndim-1) complex values) IS the message.
+ *   sdc_end_spectrum(ctx, stream)    device address of the spectrum of the end value (after sdc_end_point); `stream`, if not
+ *                                    null, is made to wait until it is complete - right after the first launch of the sweep
+ *                                    with sdc_set_early_end_point - and for nothing queued on the engine's stream later
+ *   sdc_spectrum_inbox(ctx)          device address a received spectrum is to be written to
+ *   sdc_replace_u0_spectrum(ctx)     u[0] <- the field whose spectrum lies in the inbox (the buffers trade places, nothing is
+ *                                    copied; U[0] itself is produced when somebody reads it).  If the last sweep only reduced
+ *                                    the residual norms, the norms against the new u[0] come from ONE more field through the
+ *                                    inverse passes: r_m changes by new - old for every node m (core/sweeper.py:186-199). */
+int sdc_spectral_handover_ok(sdc_ctx* ctx);
+int sdc_set_wire_spectral(sdc_ctx* ctx, int on); /* the engine side of sdc_comm_set_format, for callers that move the spectra themselves */
+void* sdc_end_spectrum(sdc_ctx* ctx, void* stream);
+void* sdc_spectrum_inbox(sdc_ctx* ctx);
+int sdc_replace_u0_spectrum(sdc_ctx* ctx);
 
 /* ---- time-rank communication (RCCL over xGMI; host mailboxes as the rehearsal wire) --------------------------
  * The forward transfer uend -> u[0] of the next time rank (controller_MPI.py:218-305 send_full / recv_full; mesh.py:85-125
@@ -177,6 +194,8 @@ int sdc_replace_u0(sdc_ctx* ctx, const double* src);
  *                                    scatter + all-gather over the mesh, same bits)
  *   sdc_comm_bcast_buffer(ctx, p, n, root)  the same for any device buffer of n doubles
  *   sdc_comm_set_chunk(ctx, n)       cut every message into pieces of n doubles inside its group (0 = one piece)
+ *   sdc_comm_set_format(ctx, 1)      lock-step hand-overs carry half spectra instead of fields (sdc_end_spectrum ->
+ *                                    sdc_spectrum_inbox -> sdc_replace_u0_spectrum); same choice on every rank
  *   sdc_comm_set_relay(ctx, on)      two-hop hand-over / mesh broadcast for more than two ranks (default on)
  *   sdc_comm_info(ctx, ...)          rank, size, counts of two-hop hand-overs and mesh broadcasts, wire kind ("rccl" / "shm")
  *   sdc_comm_sync(ctx)               host waits for the messages posted so far
@@ -196,6 +215,7 @@ int sdc_bcast(sdc_ctx* ctx, int slot, int m, int root);
 int sdc_comm_bcast_buffer(sdc_ctx* ctx, double* buf, size_t n, int root);
 int sdc_comm_set_chunk(sdc_ctx* ctx, size_t doubles_per_piece);
 int sdc_comm_set_relay(sdc_ctx* ctx, int on);
+int sdc_comm_set_format(sdc_ctx* ctx, int spectra);
 int sdc_comm_info(sdc_ctx* ctx, int* rank, int* size, unsigned long long* two_hop_calls, unsigned long long* mesh_bcast_calls,
                   char* kind16);
 int sdc_comm_selftest(const char* job, int nranks, int rank, size_t n, int what, int arg, int rounds);

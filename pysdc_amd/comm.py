@@ -107,6 +107,10 @@ class DeviceComm:
     def set_chunk(self, doubles_per_piece):
         self._e(self.engine.lib.sdc_comm_set_chunk(self.engine.ctx, int(doubles_per_piece)))
 
+    def set_format(self, spectra):
+        """lock-step hand-overs carry half spectra instead of fields (levels that sweep in Fourier space)"""
+        self._e(self.engine.lib.sdc_comm_set_format(self.engine.ctx, int(bool(spectra))))
+
     def set_relay(self, on):
         self._e(self.engine.lib.sdc_comm_set_relay(self.engine.ctx, int(bool(on))))
 

@@ -418,6 +418,7 @@ class controller_dist(_ControllerBase):
         self._comm_stream = None
         self._overlap = False
         self._abi = False
+        self.spectral_wire = False
         self.relay = os.environ.get('PYSDC_AMD_RELAY', '1') != '0'
         # > 0: every direct message is cut into pieces of this many values, all posted in the same batched group
         self.p2p_chunk = int(os.environ.get('PYSDC_AMD_P2P_CHUNK', '0'))
@@ -521,16 +522,25 @@ class controller_dist(_ControllerBase):
         if self._abi:
             self._device_comms()
         if self.size > 1 and hasattr(S.levels[0], 'replace_u0') and hasattr(S.levels[0], 'engine'):
-            # u[0] is replaced between sweeps and the residual is asked for again: keep the residual fields;
-            # produce the end value early so that it can be sent while the residual is reduced
-            S.levels[0].engine.set_keep_residual_fields(True)
-            # (only in lock-step runs, where every posted message is completed before the next sweep: the sweep then
-            # overwrites UEND early, which must not happen under a send that is still in flight)
-            # and only with ONE sweep per iteration: with nsweeps > 1 it_fine posts a lone send between sweeps, which
-            # stays in flight on the communication stream while the next sweep would already rewrite UEND
-            if (self._uniform(self.size) and not S.levels[0]._view_offset() and self.nsweeps[0] == 1
-                    and os.environ.get('PYSDC_AMD_OVERLAP', '1') != '0'):
-                S.levels[0].engine.set_early_end_point(True)
+            eng = S.levels[0].engine
+            lockstep = (self._uniform(self.size) and not S.levels[0]._view_offset() and self.nsweeps[0] == 1
+                        and os.environ.get('PYSDC_AMD_OVERLAP', '1') != '0')
+            spectra = (self._abi and lockstep and eng.spectral_handover_ok()
+                       and os.environ.get('PYSDC_AMD_SPECTRAL_WIRE', '1') != '0')
+            if self._abi:
+                self._comms[0].set_format(spectra)
+            self.spectral_wire = spectra
+            # u[0] is replaced between sweeps and the residual is asked for again.  Levels that sweep in Fourier space
+            # hand over SPECTRA (no inverse transform on the sending side, no forward transform on the receiving one) and
+            # update the node norms from the residual lines the sweep left in its work spectra; everybody else keeps the
+            # residual FIELDS and updates them in real space (sdc_replace_u0)
+            eng.set_keep_residual_fields(not spectra)
+            # the end value (its spectrum) is produced early so that it can be sent while the residual is reduced -
+            # only in lock-step runs, where every posted message is completed before the next sweep (the sweep
+            # overwrites what the message reads), and only with ONE sweep per iteration: with nsweeps > 1 it_fine posts a
+            # lone send between sweeps, which stays in flight while the next sweep would already rewrite UEND
+            if lockstep:
+                eng.set_early_end_point(True)
                 self._overlap = True
         if self._uend_buf is None:   # lives as long as the controller: allocating 8.6 GB per run costs ~0.25 s
             self._uend_buf = P.dtype_u(u0)
@@ -781,6 +791,10 @@ class controller_dist(_ControllerBase):
         if self._abi:
             L.sweep.compute_end_point()  # free when the sweep produced UEND early
             self._comms[0].handover_post(size)   # (its own stream, behind UEND only; two hops for more than two ranks)
+            if self.spectral_wire:
+                # the end value left as its spectrum; as a field it was never produced, and nobody asks for it before the
+                # next compute_end_point - the engine is told not to transform it back on the next sweep's account
+                L.uend = None
             self._posted = ([], None, False)
             return
         if self.req_send[0] is not None:
@@ -865,12 +879,28 @@ class controller_dist(_ControllerBase):
         else:
             raise ControllerError('Unknown stage, got %s' % stage)
 
+    def _nothing_new_to_hand_over(self):
+        """Iteration 0 of a single-level block: every rank started from the SAME value (restart_block hands the broadcast
+        end value of the previous block, or the user's u0, to all of them) and a 'spread' / 'copy' predictor left every
+        node equal to it, so the end value a rank would send (generic_implicit.py:105-131 without collocation update: the
+        last node) is bit for bit what its successor already holds as u[0] - the first hand-over of
+        controller_MPI.py:574-583 would replace a value by itself.  Every rank knows that from the stage sequence alone,
+        so none of them sends or receives: identical results, one message (and the transforms around it) per block less."""
+        S = self.S
+        sw = S.levels[0].sweep
+        return (S.status.iter == 0 and len(S.levels) == 1 and self.params.predict_type is None
+                and getattr(sw.params, 'initial_guess', 'spread') in ('spread', 'copy')
+                and not getattr(sw.params, 'do_coll_update', False) and getattr(sw.coll, 'right_is_node', False)
+                and os.environ.get('PYSDC_AMD_SKIP_FIRST', '1') != '0')
+
     # controller_MPI.py:574-664
     def it_check(self, size):
         S = self.S
         L = S.levels[0]
         if self._posted is not None:
             self.handover_complete()      # posted right after the sweep (it_fine)
+        elif self._nothing_new_to_hand_over():
+            pass
         elif self._lockstep(size) or (self._overlap and self._uniform(size)) or (self._abi and self._uniform(size)):
             # lock-step runs: every message is completed here, on both sides - the next sweep overwrites UEND early
             # (sdc_set_early_end_point), so no send may stay in flight behind it
@@ -905,6 +935,7 @@ class controller_dist(_ControllerBase):
                 if req is not None:
                     req.wait()
                     self.req_send[l] = None
+            L.sweep.compute_end_point()   # (the reference's send_full of this stage made it, controller_MPI.py:253; free if it exists)
             self._hook('post_step', S)
             S.status.stage = 'DONE'
 

@@ -406,7 +406,7 @@ struct CommState {
     size_t stage_len = 0;
     bool send_pending = false;      // a send may still be reading UEND
     bool relay = true;              // more than two ranks: two-hop hand-over / mesh broadcast instead of direct messages
-    int posted_recv = -1;           // sdc_comm_handover_post: 1 = a receive is under way, 0 = only a send, -1 = nothing posted
+    int posted_recv = -1;           // sdc_comm_handover_post: 1 / 2 = a field / a spectrum is being received, 0 = only a send, -1 = nothing posted
     unsigned long long two_hop_calls = 0, mesh_bcast_calls = 0;
 };
 
@@ -555,6 +555,16 @@ extern "C" int sdc_comm_set_relay(sdc_ctx* c, int on) {
     return SDC_OK;
 }
 
+// what travels in a lock-step hand-over: 0 = the end value as a field (N doubles), 1 = its half spectrum (2 Nc doubles) -
+// between levels that sweep in Fourier space (sdc_spectral_handover_ok) neither the sender's inverse transform nor the
+// receiver's forward transform is needed then.  Every rank of the communicator has to make the same choice.
+extern "C" int sdc_comm_set_format(sdc_ctx* c, int spectra) {
+    NEED_COMM(c);
+    (void)w;
+    (void)cs;
+    return sdc_set_wire_spectral(c, spectra);
+}
+
 extern "C" int sdc_comm_info(sdc_ctx* c, int* rank, int* size, unsigned long long* two_hop_calls,
                              unsigned long long* mesh_bcast_calls, char* kind16) {
     NEED_COMM(c);
@@ -640,16 +650,32 @@ extern "C" int sdc_comm_handover_post(sdc_ctx* c, int nactive) {
     if (r >= nactive) return SDC_OK;
     const bool sending = r < nactive - 1, receiving = r >= 1;
     const bool two_hop = cs->relay && nactive > 2;
+    const bool spectra = c->wire_spectral;
+    const size_t n = spectra ? 2 * c->Nc : c->N;
+    const double* src = nullptr;
+    double* dst = nullptr;
     int rc;
-    if (sending) {  // (a relay that does not send never reads its own UEND)
-        if ((rc = sdc_stream_wait_uend(c, w->stream)) != SDC_OK) return rc;
+    if (sending) {  // (a relay that does not send never reads its own end value)
+        if (spectra) {
+            src = (const double*)sdc_end_spectrum(c, w->stream);
+            if (!src) return c->err.empty() ? fail(c, SDC_ERR_STATE, "no end value to send") : SDC_ERR_STATE;
+        } else {
+            if ((rc = sdc_stream_wait_uend(c, w->stream)) != SDC_OK) return rc;
+            src = c->UEND;
+        }
     }
     if (receiving) {
-        if ((rc = ensure_inbox(c, cs)) != SDC_OK) return rc;
+        if (spectra) {
+            dst = (double*)sdc_spectrum_inbox(c);
+            if (!dst) return SDC_ERR_NOMEM;
+        } else {
+            if ((rc = ensure_inbox(c, cs)) != SDC_OK) return rc;
+            dst = cs->inbox;
+        }
         if ((rc = inbox_writable(c, cs, w)) != SDC_OK) return rc;
     }
     if (two_hop) {
-        const size_t slot = two_hop_slot(c->N, nactive, r), need = slot * (size_t)(nactive - 1);
+        const size_t slot = two_hop_slot(n, nactive, r), need = slot * (size_t)(nactive - 1);
         if (need > cs->stage_len) {
             if (cs->stage) {
                 HIPCHK(c, hipStreamSynchronize(w->stream));
@@ -662,16 +688,22 @@ extern "C" int sdc_comm_handover_post(sdc_ctx* c, int nactive) {
             c->bytes += cs->stage_len * sizeof(double);
         }
         cs->two_hop_calls++;
-        if ((rc = two_hop_handover(w, c, nactive, c->UEND, cs->inbox, cs->stage, c->N)) != SDC_OK) return rc;
+        if ((rc = two_hop_handover(w, c, nactive, src, dst, cs->stage, n)) != SDC_OK) return rc;
     } else {
         if ((rc = w->group_begin(c)) != SDC_OK) return rc;
-        if (sending) w->send(c, c->UEND, c->N, r + 1);
-        if (receiving) w->recv(c, cs->inbox, c->N, r - 1);
+        if (sending) w->send(c, src, n, r + 1);
+        if (receiving) w->recv(c, dst, n, r - 1);
         if ((rc = w->group_end(c)) != SDC_OK) return rc;
     }
     HIPCHK(c, hipEventRecord(cs->done, w->stream));
-    cs->send_pending = sending;
-    cs->posted_recv = receiving ? 1 : 0;
+    cs->send_pending = sending && !spectra;
+    cs->posted_recv = receiving ? (spectra ? 2 : 1) : 0;
+    if (spectra) {
+        // the end value of this iteration existed for the wire, as a spectrum; its field form was put off (sdc_end_point)
+        // and would otherwise be produced on account of the next sweep, which replaces the iterate it belongs to
+        c->uend_pending = false;
+        c->uend_gen = -1;
+    }
     return SDC_OK;
 }
 
@@ -679,11 +711,19 @@ extern "C" int sdc_comm_handover_complete(sdc_ctx* c) {
     NEED_COMM(c);
     (void)w;
     if (cs->posted_recv < 0) return SDC_OK;
-    const bool receiving = cs->posted_recv == 1;
+    const int kind = cs->posted_recv;
     cs->posted_recv = -1;
+    // (also on a rank that only sent: its next sweep rewrites the spectrum / end value the message reads)
     HIPCHK(c, hipStreamWaitEvent(c->stream, cs->done, 0));
     cs->send_pending = false;
-    return receiving ? deliver_inbox(c, cs) : SDC_OK;
+    if (kind == 1) return deliver_inbox(c, cs);
+    if (kind == 2) {
+        int rc = sdc_replace_u0_spectrum(c);
+        if (rc != SDC_OK) return rc;
+        HIPCHK(c, hipEventRecord(cs->inbox_free, c->stream));  // (the buffer that is the inbox NOW: the old start spectrum)
+        cs->inbox_busy = true;
+    }
+    return SDC_OK;
 }
 
 // a device buffer of rank `root` to every rank, in place, ordered on the engine's stream on both sides

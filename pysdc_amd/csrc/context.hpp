@@ -48,6 +48,16 @@ struct sdc_ctx {
     // value of a step is the start value of the following one, sdc_advance): S0 and SL are, in either order, the last
     // slot of the S block and the separately allocated spectrum Sx.  Fields 0..M-2 are S + m*Nc, field M-1 is SL.
     cd *SL = nullptr, *Sx = nullptr;
+    // Time-parallel runs whose wire carries SPECTRA (sdc_comm_set_format): a third spectrum buffer Sy joins the rotation -
+    // Sin names the one a received start value lands in; when it is taken (replace_u0_spectrum) it becomes S0 and the old
+    // S0 buffer the next inbox.  sl_ev: recorded right after the launch that leaves the last node's spectrum final, so
+    // that a message stream can pick it up while the residual passes still run.  rlines_valid: the work spectra W still
+    // hold the residual of the current iterate after its z / y inverse passes (the x pass only reduced a norm), which lets
+    // a new start value update the node norms by ONE more field through the pipeline instead of M.
+    cd *Sy = nullptr, *Sin = nullptr;
+    bool wire_spectral = false, rlines_valid = false, sl_ev_recorded = false;
+    hipEvent_t sl_ev = nullptr;
+    cd* Wend = nullptr;  // spectrum of an end value that is not the cached last node (forward transform of UEND on demand)
     // Same for the real-space pair: UEND and UEND2 alternate as the end-value buffer; after sdc_advance the start value
     // of the new step is still where the old step left its end value (u0_src) and reaches the U[0] slab only when
     // somebody needs it THERE (ensure_u0); read-only consumers take it where it lies (u0r).

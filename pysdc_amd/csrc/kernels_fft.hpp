@@ -80,19 +80,27 @@ __global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_fwd(FieldPtr
 #endif
 // c2r along axis 0 (inverse of the above, unnormalised).  NORM: max |.| per field goes to norms[field] (the fields
 // are the collocation residuals of the spectral sweep); STORE: the real field is written to out[field].
-template <int N, int T, bool NORM, bool STORE>
+// ADD: a further half spectrum `add` (same layout, one field) is added to every field on the way in - the residual of
+// all nodes changes by the same field when u[0] is replaced (time-parallel runs), and the transform is linear.
+template <int N, int T, bool NORM, bool STORE, bool ADD = false>
 __global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_inv(FieldPtrs p, const cd* __restrict__ W,
                                                                       size_t fstride, int rest,
                                                                       const cd* __restrict__ tw,
-                                                                      unsigned long long* __restrict__ norms) {
+                                                                      unsigned long long* __restrict__ norms,
+                                                                      const cd* __restrict__ add = nullptr, int nfields = 1) {
     constexpr int E = fft_elems(N), P = N / E;
     using LAY = LayStrided<N, T>;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int col = threadIdx.x % T, j = threadIdx.x / T;
     const int ncol = rest >> 1;
-    const int c = blockIdx.x * T + col;
+    // ADD: one-dimensional grid in which the NF workgroups that read the SAME tile of `add` follow each other at a
+    // distance of 8 - workgroups are handed to the 8 XCDs round robin, so those NF land on one XCD and find the tile in
+    // its L2 after the first of them fetched it (id = 8 NF g + 8 f + t: tile 8 g + t, field f)
+    const int bx = ADD ? (int)((blockIdx.x / (8 * nfields)) * 8 + blockIdx.x % 8) : (int)blockIdx.x;
+    const int by = ADD ? (int)((blockIdx.x / 8) % nfields) : (int)blockIdx.y;
+    const int c = bx * T + col;
     const bool ok = c < ncol;
-    const cd* __restrict__ Wf = W + blockIdx.y * fstride;
+    const cd* __restrict__ Wf = W + by * fstride;
     cd r[E];
 #if SDC_XINV_DIRECT
     // C[k] = A[k] + i B[k] (k <= N/2), C[N-k] = conj A[k] + i conj B[k]: every thread fetches the row it needs for each
@@ -123,6 +131,11 @@ __global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_inv(FieldPtr
             const cd* src = Wf + (size_t)k * rest + 2 * (size_t)c;
             A[i] = src[0];
             B[i] = src[1];
+            if constexpr (ADD) {
+                const cd* s2 = add + (size_t)k * rest + 2 * (size_t)c;
+                A[i] = cadd(A[i], s2[0]);
+                B[i] = cadd(B[i], s2[1]);
+            }
         } else {
             A[i] = B[i] = cd{0.0, 0.0};
         }
@@ -172,10 +185,10 @@ __global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_inv(FieldPtr
         // in the pair shows in one output of every thread - looking at one element is an exact test
         if (r[0].x != r[0].x || r[0].y != r[0].y) m = r[0].x + r[0].y;
         m = wave_max(m);
-        if ((threadIdx.x & 63) == 0) atomic_max_abs(norms + blockIdx.y, m);
+        if ((threadIdx.x & 63) == 0) atomic_max_abs(norms + by, m);
     }
     if constexpr (STORE) {
-        double* __restrict__ out = p.out[blockIdx.y];
+        double* __restrict__ out = p.out[by];
         if (ok) {
 #pragma unroll
             for (int i = 0; i < E; ++i)
@@ -418,7 +431,7 @@ template <int N, int DIR, bool SYM = false>
 __global__ __launch_bounds__(z_lines_per_block<N>() * (N / fft_elems(N)) * MAXM, 4) void k_fftz_plain(
     const cd* __restrict__ src, cd* __restrict__ dst, size_t fstride, const cd* __restrict__ tw, unsigned nlines,
     double scale, const cd* __restrict__ src_one = nullptr, int one = -1, const cd* __restrict__ lamI = nullptr,
-    const cd* __restrict__ lamE = nullptr, int ndim = 0) {
+    const cd* __restrict__ lamE = nullptr, int ndim = 0, const cd* sub = nullptr) {
     constexpr int E = fft_elems(N), P = N / E, LPB = z_lines_per_block<N>();
     using LAY = LayContig<N>;
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -432,6 +445,11 @@ __global__ __launch_bounds__(z_lines_per_block<N>() * (N / fft_elems(N)) * MAXM,
     const cd* __restrict__ in = (f == one) ? src_one + line * N : src + base;
 #pragma unroll
     for (int i = 0; i < E; ++i) r[i] = ok ? in[j + i * P] : cd{0.0, 0.0};
+    if (sub) {  // the difference of two spectra is transformed (sub may be the destination: every thread reads its own modes first)
+#pragma unroll
+        for (int i = 0; i < E; ++i)
+            if (ok) r[i] = csub(r[i], sub[base + j + i * P]);
+    }
     if (scale != 1.0) {
 #pragma unroll
         for (int i = 0; i < E; ++i) r[i] = cscale(r[i], scale);

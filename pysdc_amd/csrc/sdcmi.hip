@@ -406,6 +406,22 @@ static int inverse_tail_n(sdc_ctx* c, int nf, cd* work, const FieldPtrs& p, unsi
     return SDC_OK;
 }
 
+// only the last (x) pass, norm-only, of fields that went through the other passes already, plus one more field `add`
+template <int N>
+static int inverse_tail_x_only(sdc_ctx* c, int nf, cd* work, const FieldPtrs& p, unsigned long long* norms, const cd* add) {
+    constexpr int E = fft_elems(N), P = N / E, T = N >= 2048 ? 4 : (N == 1024 ? SDC_T1024 : 8);
+    const size_t lds_str = (size_t)LayStrided<N, T>::doubles(T) * sizeof(double);
+    const int rest = (int)(c->N / c->n);
+    const int tiles = (rest / 2 + T - 1) / T;
+    LaunchTimer lt(c, pname("fft_x_norm_add", nf));
+    // 8 nf ceil(tiles / 8) workgroups in the XCD-aware order the kernel decodes
+    const int groups = (tiles + 7) / 8;
+    hipLaunchKernelGGL((k_fftx_inv<N, T, true, false, true>), dim3(groups * 8 * nf), dim3(P * T), lds_str, c->stream, p, work,
+                       c->Nc, rest, c->tw, norms, add, nf);
+    HIPCHK(c, hipGetLastError());
+    return SDC_OK;
+}
+
 // inverse transform of nf fully transformed spectra src[f] (src + f*Nc) through the work buffer work[f]
 // (work may equal src: in place) into the real fields out[f] - or, with norms != null, into max |.| per field
 template <int N>
@@ -428,6 +444,14 @@ static int inverse_passes_n(sdc_ctx* c, int nf, const cd* src, cd* work, const F
 template <int N>
 static int early_end_point_n(sdc_ctx* c, bool norms_only) {
     if (!c->early_uend || !norms_only) return SDC_OK;
+    if (c->wire_spectral) {
+        // the wire carries the last node's SPECTRUM (final as of now): nothing to transform, only a point in the stream to
+        // wait for; the end value itself stays put off (sdc_end_point: uend_pending)
+        if (!c->sl_ev) HIPCHK(c, hipEventCreateWithFlags(&c->sl_ev, hipEventDisableTiming));
+        HIPCHK(c, hipEventRecord(c->sl_ev, c->stream));
+        c->sl_ev_recorded = true;
+        return SDC_OK;
+    }
     {
         int rcf = uend_write_fence(c);
         if (rcf != SDC_OK) return rcf;
@@ -897,6 +921,33 @@ __global__ void k_init_field(double* __restrict__ out, int ndim, int n, int f0, 
     }
 }
 
+template <int N>
+static int residual_shift_n(sdc_ctx* c, cd* dbuf, const cd* newS0) {
+    constexpr int P = N / fft_elems(N), LPB = z_lines_per_block<N>();
+    const int n = c->n;
+    const size_t lines = (size_t)(n / 2 + 1) * (c->ndim == 3 ? n : 1);
+    {
+        // d = new - old start value, through the contiguous-axis inverse pass, in place over the old spectrum
+        LaunchTimer lt(c, pname("fft_z_diff", 1));
+        const size_t ldsz = (size_t)LayContig<N>::doubles(LPB) * sizeof(double);
+        hipLaunchKernelGGL((k_fftz_plain<N, +1>), dim3((unsigned)((lines + LPB - 1) / LPB)), dim3(P * LPB), ldsz, c->stream,
+                           newS0, dbuf, c->Nc, c->tw, (unsigned)lines, 1.0 / (double)c->N, (const cd*)nullptr, -1,
+                           (const cd*)nullptr, (const cd*)nullptr, 0, (const cd*)dbuf);
+    }
+    HIPCHK(c, hipGetLastError());
+    if (c->ndim == 3) {
+        constexpr int E = fft_elems(N), PS = N / E, T = N >= 2048 ? 4 : (N == 1024 ? SDC_T1024 : 8);
+        const size_t lds_str = (size_t)LayStrided<N, T>::doubles(T) * sizeof(double);
+        LaunchTimer lt(c, pname("fft_y_inv", 1));
+        hipLaunchKernelGGL((k_ffty<N, T, +1>), dim3((n + T - 1) / T, n / 2 + 1, 1), dim3(PS * T), lds_str, c->stream, dbuf,
+                           c->Nc, c->tw);
+        HIPCHK(c, hipGetLastError());
+    }
+    FieldPtrs p;
+    memset(&p, 0, sizeof p);
+    return inverse_tail_x_only<N>(c, c->M, c->W, p, c->res_dev, dbuf);
+}
+
 extern "C" {
 
 int sdc_version(void) { return 100; }
@@ -991,6 +1042,9 @@ int sdc_ctx_destroy(sdc_ctx* c) {
     if (c->uend_ev) (void)hipEventDestroy(c->uend_ev);
     (void)hipFree(c->S);
     (void)hipFree(c->Sx);
+    (void)hipFree(c->Sy);
+    (void)hipFree(c->Wend);
+    if (c->sl_ev) (void)hipEventDestroy(c->sl_ev);
     (void)hipFree(c->UEND2);
     (void)hipFree(c->tw);
     (void)hipFree(c->lamI);
@@ -1160,6 +1214,7 @@ extern "C" int sdc_solve(sdc_ctx* c, const double* rhs, double factor, const dou
 extern "C" int sdc_eval_f(sdc_ctx* c, const double* u, double g_t, double* f_impl, double* f_expl);
 
 static int ensure_work(sdc_ctx* c) {
+    c->rlines_valid = false;  // whoever asks for the work spectra is about to overwrite them (a sweep says so again afterwards)
     if (!c->W) {
         HIPCHK(c, hipMalloc((void**)&c->W, sizeof(cd) * c->Nc * c->M));
         c->bytes += sizeof(cd) * c->Nc * c->M;
@@ -1321,8 +1376,10 @@ int sdc_invalidate_spectra(sdc_ctx* c, int which) {
     if (!c) return SDC_ERR_PARAM;
     if ((which & 2) && c->u_pending)
         return fail(c, SDC_ERR_STATE, "U[1..M] were deferred: sdc_materialize before writing through a kept pointer");
-    c->res_valid = false;
-    c->res_spread = false;
+    if (which & ~8) {  // (the end value does not enter the residual)
+        c->res_valid = false;
+        c->res_spread = false;
+    }
     if (which & 1) {
         c->spec0_valid = false;
         c->spec_spread = false;  // "all nodes equal U[0]" no longer holds for the new U[0]
@@ -1868,6 +1925,7 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
             c->res_valid = true;
             c->res_dt = dt;
             c->rfields_valid = c->keep_rfields;
+            c->rlines_valid = a.virt == 0 && !c->keep_rfields;  // (W: the residual after its z / y inverse passes)
             return SDC_OK;
         }
         c->u_pending = false;  // U[1..M] hold the new iterate; F follows in eval_nodes
@@ -2146,7 +2204,7 @@ int sdc_end_point(sdc_ctx* c, double dt, int do_coll_update) {
         c->uend_gen = -1;
         c->uend_pending = false;
         if (c->u_pending && !c->spread_pending) {  // only the last node is needed
-            if (c->deferred && c->kind == 0 && !c->early_uend && !c->keep_rfields && c->ndim >= 2) {
+            if (c->deferred && c->kind == 0 && (!c->early_uend || c->wire_spectral) && !c->keep_rfields && c->ndim >= 2) {
                 // ... and not even that until somebody reads it: the end value IS the inverse transform of SL
                 // (materialize_uend); a following sdc_advance hands the spectrum over and never needs it in real space
                 c->uend_pending = true;
@@ -2289,6 +2347,110 @@ int sdc_replace_u0(sdc_ctx* c, const double* src) {
     c->res_spread = false;
     c->spec0_valid = false;
     c->spec_spread = false;
+    return SDC_OK;
+}
+
+// ---- start and end values as SPECTRA (time-parallel runs whose levels sweep in Fourier space) ---------------------
+// Between such levels the forward hand-over uend -> u[0] (controller_MPI.py:218-305) needs neither the inverse transform
+// of the sender's last node nor the forward transform of the receiver's new start value: the last node's spectrum IS the
+// message.  sdc_comm_set_format(ctx, 1) turns that on; the three calls below are what the communicator uses.
+static bool spectral_level(const sdc_ctx* c) {
+    return c->kind == 0 && c->reuse && c->deferred && c->ndim >= 2 && fourier_ok(c) && c->have_stencil[0] && !c->spectral_op &&
+           c->expl_kind != SDC_EXPL_REACTION && c->solver_kind == 0 && c->fuse_residual;
+}
+
+int sdc_spectral_handover_ok(sdc_ctx* c) { return c && spectral_level(c) ? 1 : 0; }
+
+// what sdc_comm_set_format does to the engine, without a communicator (a caller that moves the spectra itself)
+int sdc_set_wire_spectral(sdc_ctx* c, int on) {
+    if (!c) return SDC_ERR_PARAM;
+    if (on && !spectral_level(c)) return fail(c, SDC_ERR_STATE, "this level does not sweep in Fourier space");
+    c->wire_spectral = on != 0;
+    return SDC_OK;
+}
+
+// device address of the half spectrum (Nc complex values) a received start value is to be written to
+void* sdc_spectrum_inbox(sdc_ctx* c) {
+    if (!c || ensure_spec_cache(c) != SDC_OK) return nullptr;
+    if (!c->Sy) {
+        if (hipMalloc((void**)&c->Sy, sizeof(cd) * c->Nc) != hipSuccess) {
+            fail(c, SDC_ERR_NOMEM, "spectrum inbox: out of device memory");
+            return nullptr;
+        }
+        c->bytes += sizeof(cd) * c->Nc;
+        c->Sin = c->Sy;
+    }
+    return c->Sin;
+}
+
+// device address of the spectrum of the end value (sdc_end_point has been called), and - stream != null - make that
+// stream wait until it is complete (and for nothing queued on the engine's stream after it)
+void* sdc_end_spectrum(sdc_ctx* c, void* stream) {
+    if (!c || !c->have_coeffs) return nullptr;
+    const cd* src = nullptr;
+    hipEvent_t ev = nullptr;
+    if (c->S && c->spec_valid && c->uend_gen >= 0 && c->uend_gen == c->spec_gen) {
+        if (store_spectra(c, true) != SDC_OK) return nullptr;  // (an iterate that was never stored: now its last node is)
+        src = c->SL;
+        if (c->sl_ev_recorded) ev = c->sl_ev;
+    } else {
+        // any other end value (a predictor's copy of u[0], a collocation update): forward transform of UEND
+        if (materialize_uend(c) != SDC_OK) return nullptr;
+        if (!c->Wend) {
+            if (hipMalloc((void**)&c->Wend, sizeof(cd) * c->Nc) != hipSuccess) {
+                fail(c, SDC_ERR_NOMEM, "end spectrum: out of device memory");
+                return nullptr;
+            }
+            c->bytes += sizeof(cd) * c->Nc;
+        }
+        FieldPtrs p;
+        memset(&p, 0, sizeof p);
+        p.in[0] = c->UEND;
+        if (ensure_work(c) != SDC_OK || fwd_transform(c, 1, p, c->Wend, 0) != SDC_OK) return nullptr;
+        src = c->Wend;
+    }
+    if (stream) {
+        if (!c->sl_ev && hipEventCreateWithFlags(&c->sl_ev, hipEventDisableTiming) != hipSuccess) return nullptr;
+        if (!ev) {
+            if (hipEventRecord(c->sl_ev, c->stream) != hipSuccess) return nullptr;
+            ev = c->sl_ev;
+        }
+        c->sl_ev_recorded = false;
+        if (hipStreamWaitEvent((hipStream_t)stream, ev, 0) != hipSuccess) return nullptr;
+    }
+    return (void*)src;
+}
+
+// u[0] <- the field whose spectrum has been written to sdc_spectrum_inbox().  While the work spectra still hold the
+// residual of the cached iterate after its z / y inverse passes (rlines_valid: the last sweep only reduced norms), the
+// node norms against the new start value follow from ONE more field through those passes - the residual of every node
+// changes by d = new - old (core/sweeper.py:186-199 is linear in u[0]) - and the last pass over W + d.
+int sdc_replace_u0_spectrum(sdc_ctx* c) {
+    if (!c || !c->Sin) return fail(c, SDC_ERR_STATE, "no spectrum inbox (sdc_spectrum_inbox)");
+    if (!spectral_level(c)) return fail(c, SDC_ERR_STATE, "this level does not sweep in Fourier space");
+    STORE_SPECTRA(c, false);  // (an iterate that was not stored is a function of the OLD start value)
+    int rcm = materialize(c, c->spread_pending, false);  // pending copies of the OLD u[0] are stored first
+    if (rcm != SDC_OK) return rcm;
+    const bool fast = c->rlines_valid && c->res_valid && c->u_pending && c->spec0_valid && c->spec_valid && !c->tau_active &&
+                      c->expl_kind != SDC_EXPL_FORCING;
+    if (fast) {
+        HIPCHK(c, hipMemsetAsync(c->res_dev, 0, sizeof(unsigned long long) * 8, c->stream));
+        cd* dbuf = c->S0;
+#define CALL(NN) residual_shift_n<NN>(c, dbuf, c->Sin)
+        int rcd = [&]() -> int { N_DISPATCH(c, CALL) }();
+#undef CALL
+        if (rcd != SDC_OK) return rcd;
+        c->rlines_valid = false;  // W + d is what the norms describe now, W alone is not
+    } else {
+        c->res_valid = false;
+    }
+    std::swap(c->S0, c->Sin);
+    c->spec0_valid = true;
+    c->u0_spec_only = true;  // U[0] is produced from the spectrum when somebody reads it there
+    c->u0_src = nullptr;
+    c->res_spread = false;
+    c->spec_spread = false;
+    c->f0_pending = false;
     return SDC_OK;
 }
 

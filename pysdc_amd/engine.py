@@ -118,6 +118,25 @@ class SweepEngine:
         fields (include/sdcmi.h: sdc_replace_u0)"""
         self._chk(self.lib.sdc_replace_u0(self.ctx, src_ptr))
 
+    def spectral_handover_ok(self):
+        """this level sweeps in Fourier space: its hand-over may carry spectra (include/sdcmi.h: sdc_spectral_handover_ok)"""
+        return bool(self.lib.sdc_spectral_handover_ok(self.ctx))
+
+    def end_spectrum(self, stream_handle=None):
+        p = self.lib.sdc_end_spectrum(self.ctx, C.c_void_p(int(stream_handle)) if stream_handle else None)
+        if not p:
+            self._chk(L.ERR_STATE)
+        return p
+
+    def spectrum_inbox(self):
+        p = self.lib.sdc_spectrum_inbox(self.ctx)
+        if not p:
+            self._chk(L.ERR_NOMEM)
+        return p
+
+    def replace_u0_spectrum(self):
+        self._chk(self.lib.sdc_replace_u0_spectrum(self.ctx))
+
     def advance(self):
         """u[0] <- uend for the next time step on this level (include/sdcmi.h: sdc_advance)"""
         self._chk(self.lib.sdc_advance(self.ctx))

@@ -54,6 +54,11 @@ PROTOTYPES = {
     'sdc_set_early_end_point': (C.c_int, [_vp, C.c_int]),
     'sdc_stream_wait_uend': (C.c_int, [_vp, _vp]),
     'sdc_replace_u0': (C.c_int, [_vp, _vp]),
+    'sdc_spectral_handover_ok': (C.c_int, [_vp]),
+    'sdc_set_wire_spectral': (C.c_int, [_vp, C.c_int]),
+    'sdc_end_spectrum': (_vp, [_vp, _vp]),
+    'sdc_spectrum_inbox': (_vp, [_vp]),
+    'sdc_replace_u0_spectrum': (C.c_int, [_vp]),
     'sdc_comm_unique_id': (C.c_int, [C.c_char_p]),
     'sdc_comm_init': (C.c_int, [_vp, C.c_char_p, C.c_int, C.c_int]),
     'sdc_comm_attach': (C.c_int, [_vp, _vp]),
@@ -67,6 +72,7 @@ PROTOTYPES = {
     'sdc_comm_bcast_buffer': (C.c_int, [_vp, _vp, C.c_size_t, C.c_int]),
     'sdc_comm_set_chunk': (C.c_int, [_vp, C.c_size_t]),
     'sdc_comm_set_relay': (C.c_int, [_vp, C.c_int]),
+    'sdc_comm_set_format': (C.c_int, [_vp, C.c_int]),
     'sdc_comm_info': (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_ulonglong),
                                 C.POINTER(C.c_ulonglong), C.c_char_p]),
     'sdc_comm_selftest': (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int]),

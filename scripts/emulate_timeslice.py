@@ -27,12 +27,18 @@ QI[1:, 1:] = QDELTA_GENERATORS['IE'](qGen=c.generator, tLeft=0).genCoeffs()
 out = {}
 copies = int(sys.argv[3]) if len(sys.argv) > 3 else 8       # the "message": that many 8 N byte device copies
 side = torch.cuda.Stream()
-for keep in ('overlap', True, False):
+variants = tuple(os.environ.get('EMU_VARIANTS', 'spectral,overlap,fields,recompute').split(','))
+for keep in [dict(spectral='spectral', overlap='overlap', fields=True, recompute=False)[v] for v in variants]:
     e = SweepEngine((n, n, n), M)
     e.set_coeffs(c.Qmat, QI, None, c.nodes, c.weights)
     e.set_stencil(0, *fd.periodic_operator_stencil(2, 2, 'center', 1.0 / n, 0.1))
-    e.set_keep_residual_fields(bool(keep))
-    e.set_early_end_point(keep == 'overlap')
+    e.set_keep_residual_fields(bool(keep) and keep != 'spectral')
+    e.set_early_end_point(keep in ('overlap', 'spectral'))
+    if keep == 'spectral':
+        # the wire carries spectra: what a communicator in spectral format does, with device copies standing in for the
+        # message (include/sdcmi.h: sdc_end_spectrum -> sdc_spectrum_inbox -> sdc_replace_u0_spectrum)
+        assert e.spectral_handover_ok()
+        L.check(e.lib.sdc_set_wire_spectral(e.ctx, 1), e.ctx)
     freq = (C.c_int * 3)(2, 2, 2)
     L.check(e.lib.sdc_init_field(e.ctx, e.ptr(L.SLOT_U, 0), freq, 1e-3, 0), e.ctx)
     e.invalidate_spectra(1)
@@ -49,8 +55,22 @@ for keep in ('overlap', True, False):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     uend = torch.as_tensor(_CAI(e.ptr(L.SLOT_UEND), e.N, e), device='cuda')
+    nspec = 2 * (n // 2 + 1) * n * n
     for k in range(iters):
         e.sweep(0.0, dt)
+        if keep == 'spectral':
+            e.end_point(dt, False)          # put off: the end value is the last node's spectrum
+            src = torch.as_tensor(_CAI(e.end_spectrum(side.cuda_stream), nspec, e), device='cuda')
+            dst = torch.as_tensor(_CAI(e.spectrum_inbox(), nspec, e), device='cuda')
+            e.invalidate_spectra(8)         # (what the communicator does: the end value existed for the wire only)
+            with torch.cuda.stream(side):   # the message, posted behind the first launch of the sweep only
+                for _ in range(copies):
+                    dst.copy_(src)
+            e.residual(dt)                  # IT_FINE, while the message travels
+            torch.cuda.current_stream().wait_stream(side)
+            e.replace_u0_spectrum()         # what arrives: node norms from one more field through the inverse passes
+            e.residual(dt)                  # IT_CHECK
+            continue
         if keep == 'overlap':
             e.end_point(dt, False)          # free: the sweep produced UEND right after the spectral update
             e.stream_wait_uend(side.cuda_stream)
@@ -70,8 +90,15 @@ for keep in ('overlap', True, False):
     torch.cuda.synchronize()
     el = (time.perf_counter() - t0) / iters
     prof = e.profile_read()
-    check = float(torch.max(torch.abs(inbox - uend)))       # the last message is the last end value
-    out[{'overlap': 'overlapped_message', True: 'kept_residual_fields', False: 'recomputed_residual'}[keep]] = {
+    if keep == 'spectral':
+        e.end_point(dt, False)
+    e.materialize(L.SLOT_UEND, 0)
+    if keep == 'spectral':   # the new start value, brought back to real space, is the last end value
+        check = float(torch.max(torch.abs(torch.as_tensor(_CAI(e.ptr(L.SLOT_U, 0), e.N, e), device='cuda') - uend)))
+    else:
+        check = float(torch.max(torch.abs(inbox - uend)))       # the last message is the last end value
+    out[{'spectral': 'spectra_on_the_wire', 'overlap': 'overlapped_message', True: 'kept_residual_fields',
+         False: 'recomputed_residual'}[keep]] = {
         'ms_per_iteration': 1e3 * el, 'message_copies': copies, 'inbox_minus_uend': check, 'kernels_ms': {k: round(v[0] / v[1], 2) for k, v in prof.items() if v[1]}}
     e.close()
 print(json.dumps(out))

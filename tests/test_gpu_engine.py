@@ -15,6 +15,8 @@ TOL = 1e-10
 def supported(case):
     meta = case['meta']
     pp = meta['prob_params']
+    if 'k0_u' not in case:
+        return False              # run cases / cases stored as subsamples have their own tests
     if meta['sweeper_params'].get('initial_guess') == 'random':
         return False              # drawn node by node on the host: covered through the plug-in classes
     if meta['prob'] == 'vanderpol':
@@ -25,7 +27,7 @@ def supported(case):
     return n & (n - 1) == 0
 
 
-SWEEP_FILES = ['sweeps_heat.npz', 'sweeps_imex.npz', 'sweeps_adv.npz', 'sweeps_guess.npz']
+SWEEP_FILES = ['sweeps_heat.npz', 'sweeps_imex.npz', 'sweeps_adv.npz', 'sweeps_guess.npz', 'sweeps_pin1024.npz']
 SWEEP_CASES = [(f, n) for f in SWEEP_FILES for n, c in load_cases(f).items() if supported(c)]
 
 
