@@ -387,6 +387,21 @@ def run_workload(args, world, rank, use_dist, with_stream_reference=True):
                     'fft_z_inv', 'fft_y_inv',
                     'fft_x_inv', 'stencil', 'stencil_res', 'res_stencil', 'vdp_sweep', 'vdp_sweep_lazyf', 'vdp_sweep_mfma')
         sweep_ms = sum(v[0] for k, v in prof.items() if k.split('[')[0] in in_sweep) / max(1, sweeps_total // world)
+        # all launches of a sweep together: the bytes they actually move (their algorithmic bytes; PMC traffic agrees to
+        # 1.00x, profiles/) and SURVEY 8(d)'s floor 8 N (3M+1) [IMEX: 8 N (5M+1)], both over the kernel time of a sweep
+        sweep_bytes = sum((kernel_bytes(k, n, M) or 0) * v[1] for k, v in prof.items()
+                          if k.split('[')[0] in in_sweep) / max(1, sweeps_total // world)
+        floor_bytes = 8.0 * n**3 * ((3 if ncomp == 1 else 5) * M + 1) if n else None
+        roof_sweep = None
+        if sweep_ms and n and sweep_bytes:
+            launches = sorted(((k, v[0] / max(1, sweeps_total // world)) for k, v in prof.items()
+                               if k.split('[')[0] in in_sweep), key=lambda kv: -kv[1])
+            roof_sweep = {'bound': 'hbm', 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'ms_per_sweep': sweep_ms,
+                          'bytes_moved_per_sweep': sweep_bytes, 'achieved': sweep_bytes / sweep_ms / 1e6,
+                          'frac': sweep_bytes / sweep_ms / 1e6 / HBM_PEAK_GBS,
+                          'floor_bytes_per_sweep': floor_bytes, 'achieved_on_floor': floor_bytes / sweep_ms / 1e6,
+                          'frac_on_floor': floor_bytes / sweep_ms / 1e6 / HBM_PEAK_GBS,
+                          'launches_ms_per_sweep': {k: round(t, 3) for k, t in launches[:8]}}
         out = {
             'metric': {'heat': 'time-steps/s (HeatND 3-D FD, M=5, implicit SDC sweeps)',
                        'advdiff': 'time-steps/s (advection-diffusion 3-D FD IMEX, M=5)',
@@ -407,7 +422,7 @@ def run_workload(args, world, rank, use_dist, with_stream_reference=True):
             'sweep_kernels_ms': sweep_ms,
             'sweep_floor_gbs': (8.0 * n**3 * ((3 if ncomp == 1 else 5) * M + 1) / sweep_ms / 1e6
                                 if sweep_ms and n else None),
-            'roofline': roof, 'kernels': kern, 'finite': finite,
+            'roofline': roof, 'roofline_sweep': roof_sweep, 'kernels': kern, 'finite': finite,
             'device_bytes_per_gpu': eng.device_bytes,
             'params': {'M': M, 'dt': dt, 'n': n},
         }
@@ -453,7 +468,8 @@ def extras(args):
             recs.append({'title': title, 'metric': r['metric'], 'value': r['value'], 'unit': r['unit'], 'steps': r['steps'],
                          'warmup': r['warmup'], 'ms_per_step': r['ms_per_step'], 'sdc_iters_per_s': r['sdc_iters_per_s'],
                          'niter': r['niter'], 'workload': r['config']['workload'], 'sweep_kernels_ms': r['sweep_kernels_ms'],
-                         'sweep_floor_gbs': r['sweep_floor_gbs'], 'roofline': r['roofline'], 'kernels_top': top,
+                         'sweep_floor_gbs': r['sweep_floor_gbs'], 'roofline': r['roofline'],
+                         'roofline_sweep': r['roofline_sweep'], 'kernels_top': top,
                          'work_counters': r['work_counters'], 'finite': r['finite']})
         except Exception as e:  # noqa: BLE001  a sub-record must never take the headline line down
             recs.append({'title': title, 'error': repr(e)})

@@ -281,12 +281,15 @@ int sdc_set_vdp_block_solver(sdc_ctx* ctx, int kind);
  * over trajectories since context creation (work_counters of Van_der_Pol_implicit.py:71-73). */
 /* out = (dg/du)^{-1} rhs at u for g(u) = u - dt f(u), every trajectory (Van_der_Pol_implicit.py:190-201). */
 int sdc_solve_jacobian(sdc_ctx* ctx, const double* rhs, double dt, const double* u, double* out);
-int sdc_work_counters(sdc_ctx* ctx, unsigned long long* out); /* out[4]; out[3] = CG iterations (sdc_set_solver) */
+int sdc_work_counters(sdc_ctx* ctx, unsigned long long* out); /* out[5]; out[3] = CG, out[4] = GMRES iterations (sdc_set_solver) */
 /* solver_type of GenericNDimFinDiff (generic_ND_FD.py:238-262).  kind 0 ('direct'): the exact solve in Fourier space
  * (default; satisfies any lintol).  kind 1 ('CG'): scipy.sparse.linalg.cg as the reference calls it - x0 = the previous
  * node value, rtol = lintol, atol = 0, maxiter = liniter, every iteration counted (work_counters['CG']); sweeps then run
  * node by node on the device like the reference's loop.  Dot products are reduced in a fixed order, so the counts are
- * reproducible. */
+ * reproducible.  kind 2 ('GMRES'): scipy.sparse.linalg.gmres as the reference calls it (generic_ND_FD.py:241-250) -
+ * restart 20, x0 = the previous node value, rtol = lintol, atol = 0, callback_type 'legacy': every INNER iteration is
+ * counted (work_counters['GMRES']) and maxiter = liniter counts inner iterations; Arnoldi with modified Gram-Schmidt on
+ * the device, the Hessenberg least-squares problem (Givens rotations) on the host. */
 int sdc_set_solver(sdc_ctx* ctx, int kind, double rtol, int maxiter);
 
 /* ---- space transfer between two grids --------------------------------------------------------------------

@@ -888,9 +888,10 @@ class controller_dist(_ControllerBase):
         so none of them sends or receives: identical results, one message (and the transforms around it) per block less."""
         S = self.S
         sw = S.levels[0].sweep
-        return (S.status.iter == 0 and len(S.levels) == 1 and self.params.predict_type is None
-                and getattr(sw.params, 'initial_guess', 'spread') in ('spread', 'copy')
-                and not getattr(sw.params, 'do_coll_update', False) and getattr(sw.coll, 'right_is_node', False)
+        pars = getattr(sw, 'params', None)   # (a sweeper that does not say how it predicts gets its message)
+        return (S.status.iter == 0 and len(S.levels) == 1 and self.params.predict_type is None and pars is not None
+                and getattr(pars, 'initial_guess', None) in ('spread', 'copy')
+                and getattr(pars, 'do_coll_update', True) is False and getattr(sw.coll, 'right_is_node', False)
                 and os.environ.get('PYSDC_AMD_SKIP_FIRST', '1') != '0')
 
     # controller_MPI.py:574-664

@@ -97,6 +97,9 @@ struct sdc_ctx {
     int cg_maxiter = 10000;
     unsigned long long cg_iters = 0;
     double* cgw = nullptr;        // r, p, q, A p + partial sums
+    double* gmw = nullptr;        // GMRES: Krylov basis (restart + 1 fields), w, A v, the update + partial sums
+    size_t gmw_len = 0;
+    unsigned long long gmres_iters = 0;
     bool early_uend = false;      // sweeps produce UEND right after the spectral update (before the residual passes)
     hipEvent_t uend_ev = nullptr;  // recorded when UEND is complete
     bool uend_ev_recorded = false;

@@ -323,9 +323,25 @@ __global__ __launch_bounds__(256) void k_cg(CgArgs a) {
             const double v = a.o1[i] - a.s * a.a1[i];
             a.o1[i] = v;
             acc += v * v;
-        } else {
+        } else if (a.mode == 4) {
             const double v = a.a0[i];
             acc += v * v;
+        } else if (a.mode == 6) {          // GMRES: w = v - s * (A v), |w|^2
+            const double v = a.a0[i] - a.s * a.a1[i];
+            a.o0[i] = v;
+            acc += v * v;
+        } else if (a.mode == 7) {          // <a0, a1>
+            acc += a.a0[i] * a.a1[i];
+        } else if (a.mode == 8) {          // modified Gram-Schmidt: w -= s * v_k, then <next, w>  (next may be w itself)
+            const double v = a.o0[i] - a.s * a.a0[i];
+            a.o0[i] = v;
+            acc += (a.a1 == a.o0 ? v : a.a1[i]) * v;
+        } else if (a.mode == 9) {          // v_new = s * w
+            a.o0[i] = a.s * a.a0[i];
+        } else if (a.mode == 10) {         // t = s * v (a1 null) or t += s * v
+            a.o0[i] = a.a1 ? a.o0[i] + a.s * a.a0[i] : a.s * a.a0[i];
+        } else {                           // 11: x += t
+            a.o0[i] += a.a0[i];
         }
     }
     __shared__ double sh[4];

@@ -47,8 +47,16 @@ __device__ __forceinline__ bool vdp_newton(double& x1, double& x2, double r0, do
 // LAZYF: the right-hand sides of the old iterate are recomputed from its node values (read anyway as Newton
 // guesses; f costs five flops, the same formula gives the same bits) and the new ones are not stored - the F slab
 // is brought up to date on demand (sdc_materialize).  Halves the bytes of the sweep.
+#ifndef SDC_VDP_WAVES
+#define SDC_VDP_WAVES 0  // > 0: waves per SIMD the sweep kernel is compiled for (register budget 512 / waves)
+#endif
+#if SDC_VDP_WAVES > 0
+#define VDP_BOUNDS __launch_bounds__(256, SDC_VDP_WAVES)
+#else
+#define VDP_BOUNDS __launch_bounds__(256)
+#endif
 template <int M, bool LAZYF>
-__global__ __launch_bounds__(256) void k_vdp_sweep(VdpSweepArgs a) {
+__global__ VDP_BOUNDS void k_vdp_sweep(VdpSweepArgs a) {
 #pragma clang fp contract(off)
     unsigned long long newton = 0, rhs = 0, failed = 0;
     const size_t T = a.T, N = 2 * a.T;

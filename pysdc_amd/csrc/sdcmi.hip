@@ -1038,6 +1038,7 @@ int sdc_ctx_destroy(sdc_ctx* c) {
     (void)hipFree(c->W);
     (void)hipFree(c->W2);
     (void)hipFree(c->cgw);
+    (void)hipFree(c->gmw);
     (void)hipFree(c->SP);
     if (c->uend_ev) (void)hipEventDestroy(c->uend_ev);
     (void)hipFree(c->S);
@@ -1127,12 +1128,13 @@ int sdc_work_counters(sdc_ctx* c, unsigned long long* out) {
     for (int k = 0; k < 3; ++k) out[k] = c->red_host[12 + k];
     out[1] += c->rhs_host;
     out[3] = c->cg_iters;
+    out[4] = c->gmres_iters;
     return SDC_OK;
 }
 
 int sdc_set_solver(sdc_ctx* c, int kind, double rtol, int maxiter) {
     if (!c) return SDC_ERR_PARAM;
-    if (kind != 0 && kind != 1) return fail(c, SDC_ERR_PARAM, "solver kind %d (0: direct, 1: CG)", kind);
+    if (kind < 0 || kind > 2) return fail(c, SDC_ERR_PARAM, "solver kind %d (0: direct, 1: CG, 2: GMRES)", kind);
     c->solver_kind = kind;
     c->cg_rtol = rtol;
     c->cg_maxiter = maxiter;
@@ -1140,7 +1142,7 @@ int sdc_set_solver(sdc_ctx* c, int kind, double rtol, int maxiter) {
 }
 
 static int vdp_check_failures(sdc_ctx* c) {
-    unsigned long long v[3];
+    unsigned long long v[5];
     int rc = sdc_work_counters(c, v);
     if (rc != SDC_OK) return rc;
     if (v[2] != 0) {
@@ -1770,7 +1772,7 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
         if (!fourier_only) ENSURE_U0(c);
     }
     if (c->expl_kind == SDC_EXPL_REACTION || c->spectral_op) return sweep_nodewise(c, dt);
-    if (c->solver_kind == 1 || !fourier_ok(c)) return sweep_nodewise(c, dt, true);
+    if (c->solver_kind != 0 || !fourier_ok(c)) return sweep_nodewise(c, dt, true);
     const bool gather_once = c->force_gather;
     c->force_gather = false;
     if (c->reuse && !gather_once && !c->tau_active && c->have_stencil[0] &&
@@ -2062,6 +2064,170 @@ static int cg_solve(sdc_ctx* c, const double* b, double factor, const double* gu
     return SDC_OK;
 }
 
+// scipy.sparse.linalg.gmres as the reference calls it (generic_ND_FD.py:241-250): x0 = guess, rtol = lintol, atol = 0,
+// restart = 20, no preconditioner, callback_type 'legacy' - one count per INNER iteration, and maxiter = liniter counts
+// inner iterations too.  Restated from scipy 1.15 (_isolve/iterative.py: Arnoldi with modified Gram-Schmidt, Givens
+// rotations by LAPACK's lartg, the inner tolerance control of gh-8400), vector work on the device with dot products
+// reduced in a fixed order, the small Hessenberg problem on the host.  rhs must not alias out.
+static void host_lartg(double f, double g, double* c, double* s, double* r) {  // LAPACK 3.10 dlartg, values in safe range
+    if (g == 0.0) {
+        *c = 1.0;
+        *s = 0.0;
+        *r = f;
+    } else if (f == 0.0) {
+        *c = 0.0;
+        *s = g < 0 ? -1.0 : 1.0;
+        *r = fabs(g);
+    } else {
+        const double d = sqrt(f * f + g * g);
+        *c = fabs(f) / d;
+        *r = f < 0 ? -d : d;
+        *s = g / *r;
+    }
+}
+
+static int gmres_solve(sdc_ctx* c, const double* b, double factor, const double* guess, double* x) {
+    if (!c->have_stencil[0]) return fail(c, SDC_ERR_STATE, "implicit operator not set (sdc_set_stencil)");
+    if (b == x) return fail(c, SDC_ERR_PARAM, "GMRES: right-hand side and solution share storage");
+    constexpr int NB = 2048;
+    const size_t N = c->N;
+    int restart = 20;
+    if ((size_t)restart > N) restart = (int)N;
+    const size_t need = ((size_t)restart + 4) * N + NB + 8;
+    if (!c->gmw || c->gmw_len < need) {
+        if (c->gmw) {
+            (void)hipFree(c->gmw);
+            c->bytes -= c->gmw_len * sizeof(double);
+        }
+        HIPCHK(c, hipMalloc((void**)&c->gmw, sizeof(double) * need));
+        c->gmw_len = need;
+        c->bytes += sizeof(double) * need;
+    }
+    double *V = c->gmw, *w = V + (size_t)(restart + 1) * N, *Av = w + N, *tsum = Av + N, *part = tsum + N, *scal = part + NB;
+    const int nb = grid_for(N, 256) < NB ? grid_for(N, 256) : NB;
+    auto launch = [&](int mode, const double* a0, const double* a1, const double* a2, double* o0, double s,
+                      double* result) -> int {
+        CgArgs a{a0, a1, a2, o0, nullptr, s, N, result ? part : nullptr, mode};
+        hipLaunchKernelGGL(k_cg, dim3(nb), dim3(256), 0, c->stream, a);
+        HIPCHK(c, hipGetLastError());
+        if (result) {
+            hipLaunchKernelGGL(k_sum_parts, dim3(1), dim3(256), 0, c->stream, part, nb, scal);
+            HIPCHK(c, hipMemcpyAsync(c->red_host + 15, scal, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            memcpy(result, &c->red_host[15], sizeof(double));
+        }
+        return SDC_OK;
+    };
+    auto apply_A = [&](const double* v) -> int {  // Av = A v
+        const double* in[1] = {v};
+        double* out[1] = {Av};
+        return run_stencil(c, 1, in, out, nullptr, nullptr);
+    };
+    LaunchTimer lt(c, "gmres_solve");
+    int rc;
+    if (!guess) HIPCHK(c, hipMemsetAsync(x, 0, N * sizeof(double), c->stream));
+    else if (guess != x) HIPCHK(c, hipMemcpyAsync(x, guess, N * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    double bb = 0.0;
+    if ((rc = launch(4, b, nullptr, nullptr, nullptr, 0.0, &bb)) != SDC_OK) return rc;
+    const double bnrm2 = sqrt(bb);
+    if (bnrm2 == 0.0) {  // scipy returns b itself
+        HIPCHK(c, hipMemcpyAsync(x, b, N * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        return SDC_OK;
+    }
+    const double atol = c->cg_rtol * bnrm2, eps = 2.220446049250313e-16;
+    const int maxiter = c->cg_maxiter;
+    double ptol_max_factor = 1.0, ptol = bnrm2 * std::min(ptol_max_factor, atol / bnrm2), presid = 0.0;
+    std::vector<double> h((size_t)restart * (restart + 1), 0.0), giv((size_t)restart * 2, 0.0), S(restart + 1), y(restart);
+    int inner_iter = 0;
+    double* r = w;  // the residual is formed where w will live; v[0] takes it over before w is used
+    double rr = 0.0;  // |r|^2 of the current residual
+    for (int iteration = 0; iteration < maxiter; ++iteration) {
+        if (iteration == 0) {
+            // r = b - (x - factor A x); (x0 = 0: scipy copies b - same values)
+            if ((rc = apply_A(x)) != SDC_OK) return rc;
+            if ((rc = launch(0, b, x, Av, r, factor, &rr)) != SDC_OK) return rc;
+            if (sqrt(rr) < atol) return SDC_OK;
+        }
+        // v[0] = r / |r|
+        double tmp = sqrt(rr);
+        if ((rc = launch(9, r, nullptr, nullptr, V, 1.0 / tmp, nullptr)) != SDC_OK) return rc;
+        std::fill(S.begin(), S.end(), 0.0);
+        S[0] = tmp;
+        bool breakdown = false;
+        int col = 0;
+        for (col = 0; col < restart; ++col) {
+            double* vc = V + (size_t)col * N;
+            if ((rc = apply_A(vc)) != SDC_OK) return rc;
+            double ww = 0.0, dot = 0.0;
+            if ((rc = launch(6, vc, Av, nullptr, w, factor, &ww)) != SDC_OK) return rc;  // w = (I - factor A) v_col
+            const double h0 = sqrt(ww);
+            // modified Gram-Schmidt; the axpy of step k and the dot product of step k + 1 share a pass
+            if ((rc = launch(7, V, w, nullptr, nullptr, 0.0, &dot)) != SDC_OK) return rc;
+            for (int k = 0; k <= col; ++k) {
+                h[(size_t)col * (restart + 1) + k] = dot;
+                const double* next = k < col ? V + (size_t)(k + 1) * N : w;
+                double nd = 0.0;
+                if ((rc = launch(8, V + (size_t)k * N, next, nullptr, w, dot, &nd)) != SDC_OK) return rc;
+                dot = nd;  // <v_{k+1}, w> or, after the last step, |w|^2
+            }
+            const double h1 = sqrt(dot);
+            double* hc = &h[(size_t)col * (restart + 1)];
+            hc[col + 1] = h1;
+            if (h1 <= eps * h0) {  // exact solution indicator
+                hc[col + 1] = 0.0;
+                breakdown = true;
+                HIPCHK(c, hipMemcpyAsync(V + (size_t)(col + 1) * N, w, N * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+            } else {
+                if ((rc = launch(9, w, nullptr, nullptr, V + (size_t)(col + 1) * N, 1.0 / h1, nullptr)) != SDC_OK) return rc;
+            }
+            for (int k = 0; k < col; ++k) {  // past rotations on the new column
+                const double cc = giv[2 * k], ss = giv[2 * k + 1], n0 = hc[k], n1 = hc[k + 1];
+                hc[k] = cc * n0 + ss * n1;
+                hc[k + 1] = -ss * n0 + cc * n1;
+            }
+            double cc, ss, mag;
+            host_lartg(hc[col], hc[col + 1], &cc, &ss, &mag);
+            giv[2 * col] = cc;
+            giv[2 * col + 1] = ss;
+            hc[col] = mag;
+            hc[col + 1] = 0.0;
+            const double t2 = -ss * S[col];
+            S[col] = cc * S[col];
+            S[col + 1] = t2;
+            presid = fabs(t2);
+            ++inner_iter;
+            c->gmres_iters++;  // the reference's legacy callback
+            if (inner_iter == maxiter) break;
+            if (presid <= ptol || breakdown) break;
+        }
+        if (col == restart) col = restart - 1;  // (the loop ran out: Python leaves col at its last value)
+        // back substitution on the rotated Hessenberg matrix (rows of h are ITS columns), singular case as in scipy
+        if (h[(size_t)col * (restart + 1) + col] == 0.0) S[col] = 0.0;
+        for (int k = 0; k <= col; ++k) y[k] = S[k];
+        for (int k = col; k > 0; --k) {
+            if (y[k] != 0.0) {
+                y[k] /= h[(size_t)k * (restart + 1) + k];
+                const double tk = y[k];
+                for (int q = 0; q < k; ++q) y[q] -= tk * h[(size_t)k * (restart + 1) + q];
+            }
+        }
+        if (y[0] != 0.0) y[0] /= h[0];
+        // x += y @ v[:col+1]: the combination first, then ONE addition to x
+        for (int k = 0; k <= col; ++k)
+            if ((rc = launch(10, V + (size_t)k * N, k ? tsum : nullptr, nullptr, tsum, y[k], nullptr)) != SDC_OK) return rc;
+        if ((rc = launch(11, tsum, nullptr, nullptr, x, 0.0, nullptr)) != SDC_OK) return rc;
+        if ((rc = apply_A(x)) != SDC_OK) return rc;
+        if ((rc = launch(0, b, x, Av, r, factor, &rr)) != SDC_OK) return rc;
+        const double rnorm = sqrt(rr);
+        if (inner_iter == maxiter) return SDC_OK;  // legacy exit
+        if (rnorm <= atol || breakdown) break;
+        if (presid <= ptol) ptol_max_factor = std::max(eps, 0.25 * ptol_max_factor);
+        else ptol_max_factor = std::min(1.0, 1.5 * ptol_max_factor);
+        ptol = presid * std::min(ptol_max_factor, atol / rnorm);
+    }
+    return SDC_OK;
+}
+
 int sdc_solve(sdc_ctx* c, const double* rhs, double factor, const double* guess, double* out) {
     if (!c || !rhs || !out) return fail(c, SDC_ERR_PARAM, "null pointer");
     if (c->kind == 1) {
@@ -2075,6 +2241,7 @@ int sdc_solve(sdc_ctx* c, const double* rhs, double factor, const double* guess,
         return vdp_check_failures(c);
     }
     if (c->solver_kind == 1 && !c->spectral_op) return cg_solve(c, rhs, factor, guess, out);
+    if (c->solver_kind == 2 && !c->spectral_op) return gmres_solve(c, rhs, factor, guess, out);
     if (!fourier_ok(c) && !c->spectral_op) {
         // a grid the FFT kernels do not transform (n not a power of two, or too long): conjugate gradients to
         // round-off instead of the exact solve - for symmetric operators only
@@ -2086,11 +2253,19 @@ int sdc_solve(sdc_ctx* c, const double* rhs, double factor, const double* guess,
                 if (s.off[b] == -s.off[a] && s.w[b] == s.w[a]) found = true;
             symmetric = found;
         }
-        if (!symmetric)
-            return fail(c, SDC_ERR_UNSUPPORTED,
-                        "n = %d is not a power of two (<= 1024; 2048 in 1-D / 2-D) and the operator is not symmetric: no solver", c->n);
         const double keep_rtol = c->cg_rtol;
         const int keep_maxiter = c->cg_maxiter;
+        if (!symmetric) {
+            // ... and GMRES to round-off for the others (advection: non-symmetric)
+            const unsigned long long keep_gm = c->gmres_iters;
+            c->cg_rtol = 1e-14;
+            c->cg_maxiter = 100000;
+            int rcg = gmres_solve(c, rhs, factor, guess, out);
+            c->cg_rtol = keep_rtol;
+            c->cg_maxiter = keep_maxiter;
+            c->gmres_iters = keep_gm;  // not the user's solver: nothing to count
+            return rcg;
+        }
         const unsigned long long keep_iters = c->cg_iters;
         c->cg_rtol = 1e-14;
         c->cg_maxiter = 100000;

@@ -228,13 +228,13 @@ class SweepEngine:
         self._chk(self.lib.sdc_set_vdp_block_solver(self.ctx, {'closed_form': 0, 'mfma': 1}[kind]))
 
     def work_counters(self):
-        out = (C.c_ulonglong * 4)()
+        out = (C.c_ulonglong * 5)()
         self._chk(self.lib.sdc_work_counters(self.ctx, out))
-        return dict(newton=int(out[0]), rhs=int(out[1]), failed=int(out[2]), CG=int(out[3]))
+        return dict(newton=int(out[0]), rhs=int(out[1]), failed=int(out[2]), CG=int(out[3]), GMRES=int(out[4]))
 
     def set_solver(self, kind, rtol=1e-12, maxiter=10000):
-        """'direct' (exact Fourier solve) or 'CG' (include/sdcmi.h: sdc_set_solver)"""
-        self._chk(self.lib.sdc_set_solver(self.ctx, {'direct': 0, 'CG': 1}[kind], float(rtol), int(maxiter)))
+        """'direct' (exact Fourier solve), 'CG' or 'GMRES' (include/sdcmi.h: sdc_set_solver)"""
+        self._chk(self.lib.sdc_set_solver(self.ctx, {'direct': 0, 'CG': 1, 'GMRES': 2}[kind], float(rtol), int(maxiter)))
 
     # ---- vectors ----
     def vec_copy(self, n, x, y):

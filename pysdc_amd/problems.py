@@ -89,6 +89,35 @@ class Problem:
     def u_exact(self, t):
         raise NotImplementedError('ERROR: problem has to implement u_exact(self, t)')
 
+    # ---- output through the stock file hook (core/problem.py:84-97; hooks/log_solution.py:207-282 LogToFile) ---------
+    # The hook asks the problem for an output file and for the host form of a solution.  The file format is pySDC's own
+    # (helpers/fieldsIO.py), so it comes from the pySDC installation the hook itself comes from; the solution is mirrored
+    # to host memory here - one device-to-host copy per logged time, nothing on the sweep path.
+    def setUpFieldsIO(self):
+        pass
+
+    def getOutputFile(self, fileName):
+        from pySDC.helpers.fieldsIO import Rectilinear, Scalar  # (wherever the stock hook is importable, this is too)
+
+        shape = self.init[0]
+        shape = (int(shape),) if np.isscalar(shape) else tuple(shape)
+        grid = getattr(self, 'xvalues', None)
+        if grid is not None and all(len(grid) == n for n in shape):
+            out = Rectilinear(np.float64, fileName=fileName)
+            out.setHeader(nVar=1, coords=[np.asarray(grid, dtype=float)] * len(shape))
+        else:  # no grid to describe (ensembles of scalar equations): a flat record per time
+            out = Scalar(np.float64, fileName=fileName)
+            out.setHeader(nVar=int(np.prod(shape)))
+        out.initialize()
+        return out
+
+    def processSolutionForOutput(self, u):
+        host = u.get() if hasattr(u, 'get') else np.asarray(u)
+        grid = getattr(self, 'xvalues', None)
+        if grid is not None and all(len(grid) == n for n in host.shape):
+            return np.ascontiguousarray(host, dtype=np.float64)[None, ...]   # (nVar, *grid)
+        return np.ascontiguousarray(host, dtype=np.float64).reshape(-1)
+
     # ---- engine binding: the level's SweepEngine also serves eval_f / solve_system ------------------------
     ncomp = 1
 
@@ -168,13 +197,6 @@ class GenericNDimFinDiff(Problem):
             )
         if solver_type not in ('direct', 'CG', 'GMRES'):
             raise ProblemError(f'solver type "{solver_type}" not known in generic advection-diffusion implementation!')
-        if solver_type == 'GMRES':
-            # the reference's GMRES (generic_ND_FD.py:241-250: scipy gmres, restart 20, legacy callback) is an iterative
-            # solve whose iteration counts are observable (work_counters['GMRES']); answering it with the exact solve
-            # would report counts the reference never produces, so it is refused rather than imitated
-            raise NotImplementedError("solver_type='GMRES' is not built on the device: use 'direct' (exact solve in "
-                                      "Fourier space, any operator) or 'CG' (the reference's conjugate gradients, "
-                                      'symmetric operators)')
         super().__init__(init=(nvars[0] if ndim == 1 else nvars, None, np.dtype('float64')))
         dx, xvalues = fd.grid_1d(size=nvars[0], bc=bc, left_boundary=0.0, right_boundary=1.0)
         self._stencil = fd.periodic_operator_stencil(derivative, order, stencil_type, dx, coeff)
@@ -196,8 +218,8 @@ class GenericNDimFinDiff(Problem):
         # (I - factor*A) u = rhs.  'direct' is the exact solve in Fourier space; 'CG' runs the reference's conjugate
         # gradients on the device (x0 = previous node value, rtol = lintol, iterations counted like the reference's
         # callback, generic_ND_FD.py:158-159,252-260).
-        if solver_type == 'CG':
-            self.work_counters['CG'] = _DeviceCounter(self, 'CG')
+        if solver_type in ('CG', 'GMRES'):
+            self.work_counters[solver_type] = _DeviceCounter(self, solver_type)
 
     @property
     def ndim(self):
@@ -224,8 +246,8 @@ class GenericNDimFinDiff(Problem):
 
     def configure_engine(self, engine):
         engine.set_stencil(0, *self._stencil)
-        if self.solver_type == 'CG':
-            engine.set_solver('CG', self.lintol, self.liniter)
+        if self.solver_type in ('CG', 'GMRES'):
+            engine.set_solver(self.solver_type, self.lintol, self.liniter)
 
     # ---- odd-extension staging for fields that are not slab views (dirichlet-zero) ----------------------------
     def _ext(self, k):
@@ -266,7 +288,7 @@ class GenericNDimFinDiff(Problem):
 
     def solve_system(self, rhs, factor, u0, t):
         sol = self._out_u()
-        guess = self._stage_in(u0, 2) if self.solver_type == 'CG' and u0 is not None else None
+        guess = self._stage_in(u0, 2) if self.solver_type in ('CG', 'GMRES') and u0 is not None else None
         self.engine.solve(self._stage_in(rhs, 0), float(factor), self._out_ptr(1, sol), guess)
         self._stage_out(1, sol)
         return sol

@@ -11,7 +11,7 @@ own entry points, switched on by environment variables (or call the function aft
 GOLDEN_FFT=1 fft_transfer_main (transfer_fft.npz, runs_ac_fft.npz), GOLDEN_RELAY=1 relay_main (runs_relay.npz),
 GOLDEN_CG=1 cg_main (sweeps_cg.npz), GOLDEN_VDPJ=1 vdp_jacobian_main (vdp_jacobian.npz), GOLDEN_DML=1
 dirichlet_ml_main (transfer_dirichlet.npz, runs_ml_dirichlet.npz), GOLDEN_GUESS=1 guess_main (sweeps_guess.npz), GOLDEN_SKIP=1 skip_main (runs_skip.npz), GOLDEN_RELAY8=1 relay8_main (runs_relay8.npz),
-GOLDEN_BIG3D=1 big3d_main (sweeps_big3d.npz), GOLDEN_CFG5=1 cfg5_main (runs_cfg5.npz), GOLDEN_ML8=1 ml8_main (runs_ml8.npz), GOLDEN_DND=1 dirichlet_nd_main (sweeps_dirichlet_nd.npz, runs_dirichlet_nd.npz), GOLDEN_NSW2=1 nsweeps2_main (runs_nsweeps2.npz), GOLDEN_PIN1024=1 pin1024_main (sweeps_pin1024.npz, 20 minutes);
+GOLDEN_BIG3D=1 big3d_main (sweeps_big3d.npz), GOLDEN_CFG5=1 cfg5_main (runs_cfg5.npz), GOLDEN_ML8=1 ml8_main (runs_ml8.npz), GOLDEN_DND=1 dirichlet_nd_main (sweeps_dirichlet_nd.npz, runs_dirichlet_nd.npz), GOLDEN_NSW2=1 nsweeps2_main (runs_nsweeps2.npz), GOLDEN_PIN1024=1 pin1024_main (sweeps_pin1024.npz, 20 minutes), GOLDEN_GMRES=1 gmres_main (sweeps_gmres.npz);
 GOLDEN_ML=0 skips the multi-level block.
 
 ``qmat`` (third-party, absent here) is replaced by oracle/qmat_shim, which forwards to
@@ -951,3 +951,28 @@ def pin1024_main():
 
 if __name__ == '__main__' and os.environ.get('GOLDEN_PIN1024', '0') == '1':
     pin1024_main()
+
+
+def gmres_main():
+    """solver_type='GMRES' (generic_ND_FD.py:241-250: scipy gmres, restart 20, rtol=lintol, atol=0, x0 = previous node
+    value, callback_type='legacy'): sweeps with the accumulated work_counters['GMRES'] (one count per inner iteration)
+    after every sweep - the non-symmetric advection operators, for which CG is not an option, and a heat case."""
+    RR = dict(quad_type='RADAU-RIGHT')
+    cases = []
+    cases.append(sweep_case('gmres_adv1d_64', 'advection', dict(nvars=64, c=1.0, freq=2, order=2, stencil_type='center',
+                                                                solver_type='GMRES', lintol=1e-12, liniter=1000),
+                            'generic_implicit', dict(num_nodes=3, QI='LU', **RR), 0.01, u0_kind='exact'))
+    cases.append(sweep_case('gmres_adv2d_32_upwind', 'advection', dict(nvars=(32, 32), c=1.0, freq=2, order=1, stencil_type='upwind',
+                                                                       solver_type='GMRES', lintol=1e-10, liniter=1000),
+                            'generic_implicit', dict(num_nodes=3, QI='IE', **RR), 0.02, u0_kind='randn'))
+    cases.append(sweep_case('gmres_heat3d_16', 'heat_unforced', dict(nvars=(16, 16, 16), nu=0.1, freq=2, solver_type='GMRES',
+                                                                    lintol=1e-12, liniter=1000),
+                            'generic_implicit', dict(num_nodes=3, QI='LU', **RR), 0.01, u0_kind='exact'))
+    cases.append(sweep_case('gmres_heat2d_32_stiff', 'heat_unforced', dict(nvars=(32, 32), nu=0.1, freq=2, solver_type='GMRES',
+                                                                          lintol=1e-10, liniter=1000),
+                            'generic_implicit', dict(num_nodes=5, QI='IE', **RR), 0.05, u0_kind='randn'))
+    save('sweeps_gmres.npz', cases)
+
+
+if __name__ == '__main__' and os.environ.get('GOLDEN_GMRES', '0') == '1':
+    gmres_main()

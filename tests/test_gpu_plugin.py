@@ -470,16 +470,21 @@ def test_plugin_random_walk_deferred_vs_eager(seed):
     same(np.stack([levels[0][1].f[k].get() for k in range(M + 1)]), np.stack([levels[1][1].f[k].get() for k in range(M + 1)]))
 
 
-@pytest.mark.parametrize('name', list(load_cases('sweeps_cg.npz')))
+KRYLOV = [('sweeps_cg.npz', n) for n in load_cases('sweeps_cg.npz')] + [('sweeps_gmres.npz', n) for n in load_cases('sweeps_gmres.npz')]
+
+
+@pytest.mark.parametrize('fname,name', KRYLOV)
 @pytest.mark.parametrize('fused', [True, False])
-def test_cg_sweeps_vs_golden(name, fused):
-    """solver_type='CG' (generic_ND_FD.py:252-260) on the device: sweeps against the reference's CG sweeps, node
-    values to 1e-10 and the accumulated work_counters['CG'] after every sweep (fused: the engine's node loop;
-    not fused: solve_system called from the host node loop)."""
+def test_cg_sweeps_vs_golden(fname, name, fused):
+    """solver_type='CG' (generic_ND_FD.py:252-260) and 'GMRES' (:241-250, the non-symmetric advection operators among the
+    cases) on the device: sweeps against the reference's sweeps with scipy's solvers, node values to 1e-10 and the
+    accumulated work_counters['CG'] / ['GMRES'] after every sweep (fused: the engine's node loop; not fused:
+    solve_system called from the host node loop)."""
     from pysdc_amd.level import Step
 
-    case = load_cases('sweeps_cg.npz')[name]
+    case = load_cases(fname)[name]
     meta = case['meta']
+    key = meta['prob_params']['solver_type']
     probs, sweeps = _classes()
     pc = probs[meta['prob']]
     if not fused:
@@ -504,8 +509,8 @@ def test_cg_sweeps_vs_golden(name, fused):
         L.sweep.compute_residual()
         ref = float(case[f'k{k}_res_full_abs'])
         assert abs(L.status.residual - ref) <= 1e-7 * abs(ref) + 1e-11, k
-        counts.append(L.prob.work_counters['CG'].niter)
-    assert counts == list(case['work_CG']), (counts, list(case['work_CG']))
+        counts.append(L.prob.work_counters[key].niter)
+    assert counts == list(case[f'work_{key}']), (counts, list(case[f'work_{key}']))
 
 
 def test_vdp_solve_jacobian_vs_reference():
@@ -558,6 +563,40 @@ def test_grids_without_fft_fall_back_to_cg(nvars):
         L.sweep.compute_residual()
         O.compute_residual(OL)
         assert abs(L.status.residual - OL.status_residual) <= 1e-7 * OL.status_residual + 1e-12
+
+
+@pytest.mark.parametrize('nvars,stencil', [((100,), 'center'), ((36, 36), 'upwind')])
+def test_grids_without_fft_fall_back_to_gmres_for_advection(nvars, stencil):
+    """... and with GMRES for operators that are not symmetric (advectionNd): sweeps against the oracle's direct solve"""
+    from oracle import sdc_oracle as O
+    from pysdc_amd.level import Step
+    from pysdc_amd.problems import advectionNd
+    from pysdc_amd.sweepers import generic_implicit
+
+    M, dt = 3, 0.01
+    order = 2 if stencil == 'center' else 1
+    pp = dict(nvars=nvars if len(nvars) > 1 else nvars[0], c=1.0, freq=2, order=order, stencil_type=stencil)
+    S = Step(dict(problem_class=advectionNd, problem_params=dict(pp, nvars=nvars), sweeper_class=generic_implicit,
+                  sweeper_params=dict(num_nodes=M, quad_type='RADAU-RIGHT', QI='LU'), level_params=dict(dt=dt),
+                  step_params=dict(maxiter=10)))
+    L = S.levels[0]
+    L.status.time = 0.0
+    OP = O.Advection(**pp)
+    u0h = np.asarray(OP.u_exact(0.0)) + 1e-2 * np.random.default_rng(5).standard_normal(nvars)
+    u0 = L.prob.u_init
+    u0[:] = u0h
+    L.u[0] = u0
+    L.sweep.predict()
+    sw = L.sweep
+    OL = O.Level(OP, O.Coll(sw.coll.nodes, sw.coll.weights, sw.coll.Qmat, sw.QI), dt)
+    OL.time = 0.0
+    OL.u[0] = u0h.copy()
+    O.predict(OL, 'spread')
+    for k in range(3):
+        L.sweep.update_nodes()
+        O.sweep(OL)
+        assert rel_err(np.stack([np.asarray(x) for x in L.u]), np.stack(OL.u)) < TOL, k
+    assert 'GMRES' not in L.prob.work_counters          # the fallback is not the user's solver: nothing is counted
 
 
 def test_log_solution_hook_keeps_owning_copies():
@@ -862,3 +901,40 @@ def test_consecutive_runs_continue_without_reloading_the_start_value():
     assert u._lineage is None
     u, _ = C.run(u, 2 * dt, 4 * dt)
     assert rel_err(u.get(), ref.get()) < 1e-13
+
+
+def test_gpu_timings_hook_and_host_mirror_on_device():
+    """hooks/log_timings.py:328-342 GPUTimings on device levels: HIP events recorded on the engine's stream around every
+    hook pair - device seconds per run / step / iteration / sweep under the reference's keys with the GPU_ prefix, beside
+    the always-on wall-clock timings; and the host mirror the stock file hook asks the problem for
+    (processSolutionForOutput, hooks/log_solution.py:207-282) is the end value, bit for bit."""
+    from pysdc_amd.controller import controller_nonMPI
+    from pysdc_amd.hooks import GPUTimings
+    from pysdc_amd.problems import heatNd_unforced
+    from pysdc_amd.stats import get_sorted
+    from pysdc_amd.sweepers import generic_implicit
+    from pysdc_amd.synth import init_field
+
+    n, dt, steps = 128, 2e-3, 3
+    desc = dict(problem_class=heatNd_unforced, problem_params=dict(nvars=(n, n, n), nu=0.1, freq=2),
+                sweeper_class=generic_implicit, sweeper_params=dict(num_nodes=5, quad_type='RADAU-RIGHT', QI='IE'),
+                level_params=dict(dt=dt, restol=-1.0, nsweeps=1), step_params=dict(maxiter=4))
+    C = controller_nonMPI(1, dict(logger_level=40, hook_class=[GPUTimings]), desc)
+    P = C.MS[0].levels[0].prob
+    u0 = P.u_init
+    u0[:] = init_field((n, n, n), 2, 1e-3, 0)
+    uend, stats = C.run(u0, 0.0, steps * dt)
+
+    def series(kind):
+        return [v for _, v in get_sorted(stats, type=kind, sortby='time')]
+
+    g_run, g_step, g_it, g_sw = (series(f'GPU_timing_{k}') for k in ('run', 'step', 'iteration', 'sweep'))
+    w_run, w_step = series('timing_run'), series('timing_step')
+    assert len(g_run) == 1 and len(g_step) == steps and len(g_it) == 4 * steps and len(g_sw) == 4 * steps
+    assert all(v > 0 for v in g_run + g_step + g_it + g_sw)
+    assert sum(g_sw) <= sum(g_it) * 1.001 <= sum(g_step) * 1.002 <= g_run[0] * 1.003      # nested intervals on one stream
+    # device time of a step cannot exceed the wall time around it by more than the event resolution
+    assert all(g <= w * 1.05 + 2e-4 for g, w in zip(g_step, w_step)) and g_run[0] <= w_run[0] * 1.05 + 2e-4
+    assert sum(g_sw) > 0.3 * g_run[0]                                                       # the sweeps are most of a run
+    mirror = P.processSolutionForOutput(uend)
+    assert mirror.shape == (1, n, n, n) and mirror.dtype == np.float64 and np.array_equal(mirror[0], uend.get())

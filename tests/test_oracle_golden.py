@@ -10,7 +10,7 @@ from tests._cases import load_cases, make_oracle_problem, make_oracle_coll, rel_
 # agreement is at rounding level (Newton / CG paths included)
 TOL = 1e-13
 
-SWEEP_FILES = ['sweeps_heat.npz', 'sweeps_imex.npz', 'sweeps_adv.npz', 'sweeps_vdp.npz', 'sweeps_ac.npz', 'sweeps_cg.npz', 'sweeps_guess.npz',
+SWEEP_FILES = ['sweeps_heat.npz', 'sweeps_imex.npz', 'sweeps_adv.npz', 'sweeps_vdp.npz', 'sweeps_ac.npz', 'sweeps_cg.npz', 'sweeps_gmres.npz', 'sweeps_guess.npz',
                'sweeps_dirichlet_nd.npz']
 SWEEP_CASES = ([(f, n) for f in SWEEP_FILES for n in load_cases(f)]
                + [('sweeps_pin1024.npz', 'pin_heat1d_1024_M5_IE')])   # (its 2-D companion is stored as subsamples: GPU tests)

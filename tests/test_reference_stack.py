@@ -123,3 +123,33 @@ def test_reference_multilevel_stack_drives_product_classes(ref, name):
         assert rel_err(uend.get(), case['uend']) < 1e-10
         res = [v for _, v in ref['get_sorted'](stats, type='residual_post_iteration', sortby='time')]
         np.testing.assert_allclose(res, case['res'], rtol=1e-6, atol=1e-11)
+
+
+def test_reference_file_hook_mirrors_device_solutions_to_disk(ref, tmp_path):
+    """the stock LogToFile hook (hooks/log_solution.py:207-282) around the product classes: it asks the problem for the
+    output file (pySDC's own FieldsIO format) and for the host form of L.u[0] / L.uend (processSolutionForOutput: the
+    device-to-host mirror) - the file then holds the initial value and every step's end value of the golden run"""
+    from pySDC.helpers.fieldsIO import FieldsIO
+    from pySDC.implementations.hooks.log_solution import LogSolution, LogToFile
+
+    case = load_cases('runs.npz')['mssdc_P2_jac']
+    meta = case['meta']
+
+    class ToFile(LogToFile):
+        filename = str(tmp_path / 'run.pySDC')
+        time_increment = 0
+
+    with host_device():
+        C = ref['controller'](1, dict(logger_level=40, hook_class=[ToFile, LogSolution]), _description(meta))
+        u0 = C.MS[0].levels[0].prob.u_init
+        u0[:] = case['u0']
+        uend, stats = C.run(u0, meta['t0'], meta['Tend'])
+        logged = ref['get_sorted'](stats, type='u', sortby='time')
+        f = FieldsIO.fromFile(ToFile.filename)
+        assert len(f.times) == len(logged) + 1                      # initial value + one record per step
+        t0, first = f.readField(0)
+        assert t0 == meta['t0'] and np.array_equal(first[0], case['u0'])
+        for idx, (t, sol) in enumerate(logged, start=1):
+            tf, field = f.readField(idx)
+            assert abs(tf - t) < 1e-12 and np.array_equal(field[0], sol.get())
+        assert np.array_equal(f.readField(len(f.times) - 1)[1][0], uend.get())

@@ -25,7 +25,8 @@ def _bare_controller(rank, size):
 
     C = object.__new__(controller_dist)
     C.dist, C.comm, C.rank, C.size, C.relay = QD, None, rank, size, True
-    C.two_hop_calls = C.bcast_two_hop_calls = 0
+    C._two_hop_calls = C._bcast_two_hop_calls = 0
+    C._comms, C._abi = None, False
     C._relay_stage = None
     C.S = types.SimpleNamespace(status=types.SimpleNamespace(iter=3))
     return C
