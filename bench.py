@@ -33,9 +33,10 @@ def _kernel_bytes(name, n, M, ncomp=1):
     N = n**3
     field = 8.0 * N
     spec = 16.0 * (n // 2 + 1) * n * n
-    base, nf = name, M
-    if '[' in name:
-        base, nf = name[:name.index('[')], int(name[name.index('[') + 1:-1])
+    base, nf, groups = name, M, 1
+    if '[' in name:   # "fft_y_inv[5]": five fields; "fft_y_inv[5/32]": five fields, one of 32 groups of kx planes per launch
+        base, inner = name[:name.index('[')], name[name.index('[') + 1:-1]
+        nf, groups = (int(v) for v in inner.split('/')) if '/' in inner else (int(inner), 1)
     table = {
         'gather': (1 + M * ncomp + M) * field,          # u0 + F[1..M] -> R[1..M]
         'fft_x_fwd': nf * (field + spec),               # real tiles in, half spectra out
@@ -71,7 +72,8 @@ def _kernel_bytes(name, n, M, ncomp=1):
         'spread': (2 + 2 * M) * field,
         'copy': 2 * field,
     }
-    return table.get(base)
+    b = table.get(base)
+    return b / groups if b is not None else None
 
 
 def _cpu_sample(sample_n, M, dt_ref_n, target_n, nsweeps):
@@ -284,6 +286,8 @@ def run_workload(args, world, rank, use_dist, with_stream_reference=True):
     eng.set_deferred(not args.eager_fields)
     if args.virtual_sweeps is not None and hasattr(eng, 'set_virtual_sweeps'):
         eng.set_virtual_sweeps(args.virtual_sweeps)
+    if getattr(args, 'pipeline_groups', 0) > 1:
+        eng.set_pipeline_groups(args.pipeline_groups)
     if args.workload in ('vdp', 'allencahn'):
         u0 = L.prob.u_exact(0.0)
     else:
@@ -375,6 +379,8 @@ def run_workload(args, world, rank, use_dist, with_stream_reference=True):
             if os.path.exists(tfile):
                 tr = json.load(open(tfile)).get(f'{dom[0].split("[")[0]}@{n}')
                 traffic = tr['hbm_bytes_per_launch'] if tr else None  # PMC passes of the same build (profiles/)
+                if traffic is not None and '/' in dom[0]:   # one of G groups per launch (PMC passes run ungrouped)
+                    traffic /= int(dom[0][dom[0].index('/') + 1:-1])
             roof = {'kernel': dom[0], 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                     'frac': ach / HBM_PEAK_GBS, 'traffic': traffic,
                     'algorithmic_bytes_per_launch': kernel_bytes(dom[0], n, M),
@@ -452,6 +458,8 @@ def extras(args):
              dict(eager_fields=True, steps=3, warmup=1)),
             ('heat 1024^3, iterate to restol 1e-10 (maxiter 50)', dict(restol=1e-10, steps=2, warmup=1)),
             ('heat 1024^3, diagonal QDelta MIN-SR-S (node-parallel preconditioner; SURVEY 8d)', dict(qi='MIN-SR-S', steps=3, warmup=1)),
+            ('heat 1024^3, z / y passes of every sweep pipelined over 32 groups of kx planes on two streams (wall clock only: '
+             'launches that overlap have no durations of their own)', dict(pipeline_groups=32, steps=4, warmup=1)),
             ("heat 256^3 with the reference's CG (rtol 1e-12) on the device instead of the exact Fourier solve",
              dict(n=256, solver_type='CG', steps=2, warmup=1)),
             ('BASELINE config 2: heat 512^3', dict(n=512, steps=10, warmup=2)),
@@ -610,6 +618,10 @@ def main():
     ap.add_argument('--virtual-sweeps', type=int, default=None,
                     help='sdc_set_virtual_sweeps: sweeps per step whose iterate is recomputed from the transform of u0 instead '
                          'of stored (0: every sweep stores its iterate, the round-1 data flow; default: the library\'s)')
+    ap.add_argument('--pipeline-groups', type=int, default=0,
+                    help='sdc_set_pipeline_groups: issue the z / y passes of a sweep in this many groups of kx planes, the y '
+                         'pass of a group on a second stream (launches that share the GPU have no durations of their own: the '
+                         'per-kernel figures of such a run double-count; default off)')
     ap.add_argument('--skip-residual', action='store_true',
                     help="sweeper parameter skip_residual_computation for every stage (the reference's switch for runs with a "
                          'fixed number of sweeps): no residual is computed; NOT the headline configuration')

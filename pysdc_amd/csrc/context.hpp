@@ -57,6 +57,11 @@ struct sdc_ctx {
     cd *Sy = nullptr, *Sin = nullptr;
     bool wire_spectral = false, rlines_valid = false, sl_ev_recorded = false;
     hipEvent_t sl_ev = nullptr;
+    // z / y passes of a Fourier-space sweep issued in groups of kx planes, the y pass of a group on a second stream while
+    // the z pass of the next group runs (one is bound by its arithmetic, the other by memory): pipe_groups > 1
+    int pipe_groups = -1;  // -1: the default for the grid (sdc_set_pipeline_groups)
+    hipStream_t aux = nullptr;
+    hipEvent_t pipe_ev[257] = {};
     cd* Wend = nullptr;  // spectrum of an end value that is not the cached last node (forward transform of UEND on demand)
     // Same for the real-space pair: UEND and UEND2 alternate as the end-value buffer; after sdc_advance the start value
     // of the new step is still where the old step left its end value (u0_src) and reaches the U[0] slab only when
@@ -165,9 +170,9 @@ static int fail(sdc_ctx* c, int code, const char* fmt, ...) {
 // is not perturbed.
 static void prof_flush(sdc_ctx* c) {
     if (c->pool_used == 0) return;
-    (void)hipEventSynchronize(c->pool[2 * c->pool_used - 1]);
     for (size_t i = 0; i < c->pool_used; ++i) {
         float ms = 0;
+        (void)hipEventSynchronize(c->pool[2 * i + 1]);  // (pairs of the second stream end in their own order)
         if (hipEventElapsedTime(&ms, c->pool[2 * i], c->pool[2 * i + 1]) == hipSuccess) {
             ProfEntry& e = c->prof[c->pool_names[i]];
             e.ms += ms;
@@ -181,7 +186,9 @@ struct LaunchTimer {
     sdc_ctx* c;
     size_t slot = 0;
     bool on;
-    LaunchTimer(sdc_ctx* c_, const char* n) : c(c_), on(c_->profiling) {
+    hipStream_t s;
+    LaunchTimer(sdc_ctx* c_, const char* n, hipStream_t other = nullptr, bool use_other = false)
+        : c(c_), on(c_->profiling), s(use_other ? other : c_->stream) {
         if (!on) return;
         constexpr size_t kPairs = 2048;
         if (c->pool.empty()) {
@@ -192,21 +199,22 @@ struct LaunchTimer {
         if (c->pool_used == kPairs) prof_flush(c);
         slot = c->pool_used++;
         c->pool_names[slot] = n;
-        (void)hipEventRecord(c->pool[2 * slot], c->stream);
+        (void)hipEventRecord(c->pool[2 * slot], s);
     }
     ~LaunchTimer() {
-        if (on) (void)hipEventRecord(c->pool[2 * slot + 1], c->stream);
+        if (on) (void)hipEventRecord(c->pool[2 * slot + 1], s);
     }
 };
 
 static inline int is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
 
-// profile names that carry the number of fields of the launch, e.g. "fft_x_fwd[5]" (interned, static lifetime)
-static const char* pname(const char* base, int nf) {
+// profile names that carry the number of fields of the launch, e.g. "fft_x_fwd[5]" - and, for a launch that covers one of
+// G groups of kx planes, "[5/G]" (interned, static lifetime)
+static const char* pname(const char* base, int nf, int groups = 1) {
     static std::map<std::string, std::string> table;
     static std::mutex guard;  // contexts of several host threads (in-process ranks of the tests) intern concurrently
     std::lock_guard<std::mutex> lock(guard);
-    std::string key = std::string(base) + "[" + std::to_string(nf) + "]";
+    std::string key = std::string(base) + "[" + std::to_string(nf) + (groups > 1 ? "/" + std::to_string(groups) : "") + "]";
     auto it = table.find(key);
     if (it == table.end()) it = table.emplace(key, key).first;
     return it->second.c_str();

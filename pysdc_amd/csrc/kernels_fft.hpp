@@ -304,14 +304,14 @@ __global__ __launch_bounds__((N / 2 / fft_elems(N / 2)) * T, SDC_XHALF_WAVES) vo
 // c2c in place along the middle axis of W[f][kx][y][z] (3-D only): tile = all y x T z-columns
 template <int N, int T, int DIR>
 __global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_ffty(cd* __restrict__ W, size_t fstride,
-                                                                  const cd* __restrict__ tw) {
+                                                                  const cd* __restrict__ tw, int kx0 = 0) {
     constexpr int E = fft_elems(N), P = N / E;
     using LAY = LayStrided<N, T>;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int col = threadIdx.x % T, j = threadIdx.x / T;
     const int c = blockIdx.x * T + col;
     const bool ok = c < N;
-    cd* __restrict__ base = W + blockIdx.z * fstride + (size_t)blockIdx.y * N * N + c;
+    cd* __restrict__ base = W + blockIdx.z * fstride + (size_t)(blockIdx.y + kx0) * N * N + c;  // kx0: a launch per group of kx planes
     cd r[E];
 #pragma unroll
     for (int i = 0; i < E; ++i) r[i] = ok ? ld_stream(base + (size_t)(j + i * P) * N) : cd{0.0, 0.0};
@@ -513,6 +513,7 @@ struct SpecArgs {
     // either (2: ... and the line transform gets the iterate itself instead of its residual); last_only: only the last
     // node's spectrum is stored.
     int replay, virt, last_only;
+    unsigned block0;  // first workgroup of a launch that covers a range of lines
 };
 
 // one thread per Fourier mode: gather on the cached transforms + node-coupled solve, S updated in place.
@@ -849,18 +850,19 @@ void k_spec_z(SpecArgs a, unsigned nlines) {
     using LAY = LayContig<N>;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     cd* rbuf = reinterpret_cast<cd*>(lds);  // [NF][CH]
+    const unsigned bid = blockIdx.x + a.block0;  // (block0: a launch that covers only a range of lines, e.g. a group of kx planes)
     const int c = threadIdx.x / P, j = threadIdx.x % P;
     const int f = c / LPB, l = c % LPB;
-    const size_t line = (size_t)blockIdx.x * LPB + l;
+    const size_t line = (size_t)bid * LPB + l;
     const bool ok = line < nlines;
-    const size_t span0 = (size_t)blockIdx.x * SPAN, nmodes = (size_t)nlines * N;
+    const size_t span0 = (size_t)bid * SPAN, nmodes = (size_t)nlines * N;
     cd r[E];
     if constexpr (PAIR) {
         // Real symmetric symbol: the modes kz and N - kz of a line share lam, hence the node multipliers.  One item
         // p in [0, N/2] per thread and round: multipliers once, both modes scaled by them.  (LPB == 1: the workgroup's
         // span is ONE line, kx and ky are the same for all of it.)
         constexpr int NI = N / 2 + 1, IT2 = (NI + NT - 1) / NT;
-        const size_t base = (size_t)blockIdx.x * N;
+        const size_t base = (size_t)bid * N;
         cd lo[IT2], hi[IT2];
         double lz[IT2];
 #pragma unroll
@@ -875,8 +877,8 @@ void k_spec_z(SpecArgs a, unsigned nlines) {
             }
         }
         double lxy = 0.0;
-        if (a.ndim == 3) lxy = a.lamI[blockIdx.x / N].x + a.lamI[blockIdx.x % N].x;
-        else if (a.ndim == 2) lxy = a.lamI[blockIdx.x].x;
+        if (a.ndim == 3) lxy = a.lamI[bid / N].x + a.lamI[bid % N].x;
+        else if (a.ndim == 2) lxy = a.lamI[bid].x;
         double hm[IT2][NF];
 #pragma unroll
         for (int it = 0; it < IT2; ++it) {

@@ -363,7 +363,7 @@ static int fwd_transform_n(sdc_ctx* c, int nf, const FieldPtrs& p, cd* dst, size
 
 // the inverse passes after the contiguous-axis one: work[f] -> real fields out[f] or (norms != null) max |.|
 template <int N>
-static int inverse_tail_n(sdc_ctx* c, int nf, cd* work, const FieldPtrs& p, unsigned long long* norms) {
+static int inverse_tail_n(sdc_ctx* c, int nf, cd* work, const FieldPtrs& p, unsigned long long* norms, bool y_done = false) {
     constexpr int E = fft_elems(N), P = N / E, T = N >= 2048 ? 4 : (N == 1024 ? SDC_T1024 : 8);
     const size_t lds_str = (size_t)LayStrided<N, T>::doubles(T) * sizeof(double);
     const int n = c->n;
@@ -374,7 +374,7 @@ static int inverse_tail_n(sdc_ctx* c, int nf, cd* work, const FieldPtrs& p, unsi
     } else {
         const int rest = (int)(c->N / n);
         const int tiles = (rest / 2 + T - 1) / T;
-        if (c->ndim == 3) {
+        if (c->ndim == 3 && !y_done) {
             LaunchTimer lt(c, pname("fft_y_inv", nf));
             hipLaunchKernelGGL((k_ffty<N, T, +1>), dim3((n + T - 1) / T, n / 2 + 1, nf), dim3(P * T), lds_str, c->stream,
                                work, c->Nc, c->tw);
@@ -473,12 +473,12 @@ static int early_end_point_n(sdc_ctx* c, bool norms_only) {
 }
 
 template <int N, int NF, bool V>
-static void launch_spec_z_cfg(sdc_ctx* c, SpecArgs& a, size_t lines, int mode) {
+static void launch_spec_z_cfg(sdc_ctx* c, SpecArgs& a, size_t lines, int mode, size_t launch_lines) {
     constexpr int P = N / specz_elems<N, V>(), LPB = specz_lines<N, V>();
     constexpr int SPAN = LPB * N, CH = SPAN > SDC_SPECZ_CH ? SDC_SPECZ_CH : SPAN;
     size_t ldsz = (size_t)LayContig<N>::doubles(NF * LPB) * sizeof(double);
     if ((size_t)NF * CH * sizeof(cd) > ldsz) ldsz = (size_t)NF * CH * sizeof(cd);
-    const dim3 grid((unsigned)((lines + LPB - 1) / LPB)), block(P * LPB * NF);
+    const dim3 grid((unsigned)((launch_lines + LPB - 1) / LPB)), block(P * LPB * NF);  // (lines: the bound the kernel checks)
     const int expl = a.lamE ? 1 : (a.SP ? 2 : 0);
 #define ZL(M_, E_) hipLaunchKernelGGL((k_spec_z<N, NF, M_, E_>), grid, block, ldsz, c->stream, a, (unsigned)lines)
     if constexpr (V) {  // (iterate recomputed from S0: real symbol, no explicit part - sdc_sweep sees to that)
@@ -499,9 +499,9 @@ static void launch_spec_z_cfg(sdc_ctx* c, SpecArgs& a, size_t lines, int mode) {
 #undef ZL
 }
 template <int N, int NF>
-static void launch_spec_z(sdc_ctx* c, SpecArgs& a, size_t lines, int mode) {
-    if (mode == 3) launch_spec_z_cfg<N, NF, true>(c, a, lines, mode);
-    else launch_spec_z_cfg<N, NF, false>(c, a, lines, mode);
+static void launch_spec_z(sdc_ctx* c, SpecArgs& a, size_t lines, int mode, size_t launch_lines = 0) {
+    if (mode == 3) launch_spec_z_cfg<N, NF, true>(c, a, lines, mode, launch_lines ? launch_lines : lines);
+    else launch_spec_z_cfg<N, NF, false>(c, a, lines, mode, launch_lines ? launch_lines : lines);
 }
 
 // spectral sweep; then either the inverse passes into out[f], or (norms != null) only the node norms of the
@@ -521,12 +521,55 @@ static int spec_sweep_n(sdc_ctx* c, int nf, SpecArgs& a, const FieldPtrs& p, uns
                                                      "spec_z_res_v4", "spec_z_res_v5", "spec_z_res_v6", "spec_z_res_v7+"};
                 static const char* const inames[] = {"spec_z_v0", "spec_z_v1", "spec_z_v2", "spec_z_v3",
                                                      "spec_z_v4", "spec_z_v5", "spec_z_v6", "spec_z_v7+"};
-                LaunchTimer lt(c, pname(a.virt == 2 ? inames[a.replay < 7 ? a.replay : 7]
-                                        : a.virt ? vnames[a.replay < 7 ? a.replay : 7]
-                                               : norms ? (a.spread ? "spec_z_res_spread" : "spec_z_res")
-                                                       : (a.spread ? "spec_z_spread" : "spec_z"), nf));
+                const char* zbase = a.virt == 2 ? inames[a.replay < 7 ? a.replay : 7]
+                                    : a.virt ? vnames[a.replay < 7 ? a.replay : 7]
+                                             : norms ? (a.spread ? "spec_z_res_spread" : "spec_z_res")
+                                                     : (a.spread ? "spec_z_spread" : "spec_z");
 #define ZCASE(MM) \
-    case MM: launch_spec_z<N, MM>(c, a, lines, a.virt ? 3 : (norms ? 1 : 0)); break;
+    case MM: launch_spec_z<N, MM>(c, a, lines, a.virt ? 3 : (norms ? 1 : 0), glines); break;
+                size_t glines = 0;
+                // Pipelined z / y passes (sdc_set_pipeline_groups): the kx planes are cut into G groups; the y pass of a
+                // group runs on a second stream while the engine's stream already works on the z pass of the next group -
+                // one launch is bound by its arithmetic, the other by memory (1024^3: about 1 ms per sweep)
+                int G = c->pipe_groups < 0 ? 1 : c->pipe_groups;  // (off unless asked for: see sdc_set_pipeline_groups)
+                if (!(G > 1 && norms && !p.out[0] && c->ndim == 3 && N >= 256 && !c->early_uend)) G = 1;
+                const unsigned lpb = a.virt ? specz_lines<N, true>() : specz_lines<N, false>();  // lines per workgroup
+                if (G > n / 2 + 1) G = n / 2 + 1;
+                if (G > 1) {
+                    constexpr int E = fft_elems(N), PS = N / E, T = N >= 2048 ? 4 : (N == 1024 ? SDC_T1024 : 8);
+                    const size_t lds_str = (size_t)LayStrided<N, T>::doubles(T) * sizeof(double);
+                    const int nkx = n / 2 + 1;
+                    if (!c->aux) {
+                        HIPCHK(c, hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+                        for (auto& e : c->pipe_ev) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                    }
+                    HIPCHK(c, hipEventRecord(c->pipe_ev[256], c->stream));  // W is free (earlier work of the engine's stream)
+                    HIPCHK(c, hipStreamWaitEvent(c->aux, c->pipe_ev[256], 0));
+                    const char* zname = pname(zbase, nf, G);
+                    const char* yname = pname("fft_y_inv", nf, G);
+                    for (int g = 0; g < G; ++g) {
+                        const int k0 = (int)((long long)nkx * g / G), k1 = (int)((long long)nkx * (g + 1) / G);
+                        if (k1 <= k0) continue;
+                        a.block0 = (unsigned)k0 * (unsigned)n / lpb;  // (n is a multiple of the lines per workgroup)
+                        glines = (size_t)(k1 - k0) * n;
+                        {
+                            LaunchTimer lt(c, zname);
+                            switch (nf) { ZCASE(1) ZCASE(2) ZCASE(3) ZCASE(4) ZCASE(5) }
+                        }
+                        HIPCHK(c, hipEventRecord(c->pipe_ev[g], c->stream));
+                        HIPCHK(c, hipStreamWaitEvent(c->aux, c->pipe_ev[g], 0));
+                        LaunchTimer lt(c, yname, c->aux, true);
+                        hipLaunchKernelGGL((k_ffty<N, T, +1>), dim3((n + T - 1) / T, k1 - k0, nf), dim3(PS * T), lds_str, c->aux,
+                                           c->W, c->Nc, c->tw, k0);
+                    }
+                    a.block0 = 0;
+                    glines = 0;
+                    HIPCHK(c, hipEventRecord(c->pipe_ev[256], c->aux));
+                    HIPCHK(c, hipStreamWaitEvent(c->stream, c->pipe_ev[256], 0));
+                    HIPCHK(c, hipGetLastError());
+                    return inverse_tail_n<N>(c, nf, c->W, p, norms, true);
+                }
+                LaunchTimer lt(c, pname(zbase, nf));
                 switch (nf) { ZCASE(1) ZCASE(2) ZCASE(3) ZCASE(4) ZCASE(5) }
 #undef ZCASE
             }
@@ -979,6 +1022,7 @@ int sdc_ctx_create(sdc_ctx** out, int device, int ndim, int n, int num_nodes, in
     c->M = num_nodes;
     c->ncomp = ncomp;
     c->stream = (hipStream_t)stream;
+    if (const char* pg = getenv("SDC_PIPE_GROUPS")) c->pipe_groups = atoi(pg) > 256 ? 256 : (atoi(pg) < 0 ? -1 : atoi(pg));
     c->N = 1;
     for (int d = 0; d < ndim; ++d) c->N *= (size_t)n;
     c->Nc = ndim == 1 ? c->N : (size_t)(n / 2 + 1) * (c->N / n);
@@ -1044,6 +1088,11 @@ int sdc_ctx_destroy(sdc_ctx* c) {
     (void)hipFree(c->S);
     (void)hipFree(c->Sx);
     (void)hipFree(c->Sy);
+    if (c->aux) {
+        (void)hipStreamSynchronize(c->aux);
+        (void)hipStreamDestroy(c->aux);
+        for (auto& e : c->pipe_ev) (void)hipEventDestroy(e);
+    }
     (void)hipFree(c->Wend);
     if (c->sl_ev) (void)hipEventDestroy(c->sl_ev);
     (void)hipFree(c->UEND2);
@@ -1412,6 +1461,12 @@ int sdc_set_virtual_sweeps(sdc_ctx* c, int max_sweeps) {
     if (!c || max_sweeps < 0) return fail(c, SDC_ERR_PARAM, "bad number of sweeps");
     if (max_sweeps == 0) STORE_SPECTRA(c, false);
     c->virt_max = max_sweeps;
+    return SDC_OK;
+}
+
+int sdc_set_pipeline_groups(sdc_ctx* c, int groups) {
+    if (!c || groups > 256) return fail(c, SDC_ERR_PARAM, "pipeline groups: -1 (default), 0 / 1 (off) .. 256");
+    c->pipe_groups = groups < 0 ? -1 : groups;
     return SDC_OK;
 }
 
