@@ -298,6 +298,14 @@ int sdc_work_counters(sdc_ctx* ctx, unsigned long long* out); /* out[5]; out[3] 
  * counted (work_counters['GMRES']) and maxiter = liniter counts inner iterations; Arnoldi with modified Gram-Schmidt on
  * the device, the Hessenberg least-squares problem (Givens rotations) on the host. */
 int sdc_set_solver(sdc_ctx* ctx, int kind, double rtol, int maxiter);
+/* Bounded grids whose stencil depends on the row: dirichlet-zero with stencils of order >= 4, where the reference shifts
+ * one-sided stencils into the rows next to the boundary (helpers/problem_helper.py:143-224) - a non-symmetric banded matrix
+ * per axis, Kronecker-summed over the axes (:226-237).  cols[n_interior][width] (-1 = unused) and weights[n_interior][width]
+ * give the 1-D rows.  From then on sdc_eval_f / sdc_solve of this context work on COMPACT fields of n_interior^ndim values
+ * (the start of a slab field is such a field): eval_f applies the operator, sdc_solve runs the configured Krylov solver
+ * (sdc_set_solver: CG / GMRES with the user's tolerance, counted) or, for 'direct', GMRES to round-off in place of the
+ * reference's sparse LU.  Sweeps on such levels run node by node from the host (no fused sweep). */
+int sdc_set_banded_operator(sdc_ctx* ctx, int n_interior, int width, const int* cols, const double* weights);
 
 /* ---- space transfer between two grids --------------------------------------------------------------------
  * mesh_to_mesh (transfer_classes/TransferMesh.py:9-218): Pspace / Rspace are Kronecker products of ONE 1-D

@@ -97,7 +97,13 @@ struct sdc_ctx {
     bool f_pending = false;       // F[1..M] = f(U[1..M]) not stored yet
     cd* SP = nullptr;             // transform of the forcing profile (heatNd_forced), valid while specP_valid
     bool specP_valid = false;
-    int solver_kind = 0;          // 0: exact solve in Fourier space, 1: conjugate gradients (solver_type='CG')
+    // bounded grids with row-dependent stencils (sdc_set_banded_operator): fields are compact nb^ndim arrays at the start of
+    // the slab fields; the operator is applied axis by axis from a row table, the solve is iterative
+    int nb = 0, bw = 0;
+    size_t Nb = 0;
+    int* bcols = nullptr;
+    double* bwts = nullptr;
+    int solver_kind = 0;          // 0: exact solve in Fourier space, 1: conjugate gradients (solver_type='CG'), 2: GMRES
     double cg_rtol = 1e-12;
     int cg_maxiter = 10000;
     unsigned long long cg_iters = 0;

@@ -408,3 +408,33 @@ __global__ void k_reaction(const double* __restrict__ u, double* __restrict__ ou
     }
 }
 
+
+
+// ------------------------------------------------------------------------------------------------------
+// banded operator on a bounded grid (dirichlet-zero with the reference's shifted boundary stencils of order >= 4,
+// helpers/problem_helper.py:143-224): out = sum over the axes of the 1-D operator given as a row table
+// (cols[n][W], -1 = unused; w[n][W]) applied along that axis - the Kronecker sum the reference assembles
+// (problem_helper.py:226-237).  One thread per point of the compact n^ndim field; not a hot path.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_banded_apply(const double* __restrict__ in, double* __restrict__ out, int ndim, int n,
+                                                       int W, const int* __restrict__ cols, const double* __restrict__ w) {
+    const size_t N = ndim == 1 ? (size_t)n : (ndim == 2 ? (size_t)n * n : (size_t)n * n * n);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < N; i += (size_t)gridDim.x * blockDim.x) {
+        size_t rest = i, stride = 1;
+        double acc = 0.0;
+        for (int ax = ndim - 1; ax >= 0; --ax) {  // the last axis is the contiguous one
+            const int r = (int)(rest % n);
+            rest /= n;
+            const int* cr = cols + (size_t)r * W;
+            const double* wr = w + (size_t)r * W;
+            double s = 0.0;
+            for (int k = 0; k < W; ++k) {
+                const int j = cr[k];
+                if (j >= 0) s += wr[k] * in[i + ((long long)j - r) * (long long)stride];
+            }
+            acc += s;
+            stride *= (size_t)n;
+        }
+        out[i] = acc;
+    }
+}

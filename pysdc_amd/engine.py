@@ -67,6 +67,15 @@ class SweepEngine:
         w = np.ascontiguousarray(weights, dtype=np.float64)
         self._chk(self.lib.sdc_set_stencil(self.ctx, which, len(offsets), off, _dptr(w)))
 
+    def set_banded_operator(self, cols, weights):
+        """row table of a 1-D operator on a bounded grid (include/sdcmi.h: sdc_set_banded_operator)"""
+        cols = np.ascontiguousarray(cols, dtype=np.int32)
+        w = np.ascontiguousarray(weights, dtype=np.float64)
+        if cols.shape != w.shape or cols.ndim != 2:
+            raise ParameterError('cols and weights must be (n_interior, width) tables')
+        self._chk(self.lib.sdc_set_banded_operator(self.ctx, cols.shape[0], cols.shape[1],
+                                                   cols.ctypes.data_as(C.POINTER(C.c_int)), _dptr(w)))
+
     def set_symbol(self, which, table):
         t = np.ascontiguousarray(np.asarray(table, dtype=np.complex128)).view(np.float64)
         assert t.size == 2 * self.n

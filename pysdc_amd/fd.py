@@ -96,3 +96,40 @@ def periodic_operator_stencil(derivative, order, kind, dx, coeff):
     w = w / dx**derivative
     w = w * coeff
     return [int(s) for s in offsets], [float(x) for x in w]
+
+
+def dirichlet_operator_rows(derivative, order, kind, dx, coeff, size):
+    """coeff * d^derivative/dx^derivative on `size` interior points between two boundary points that hold zero, as a table of
+    rows: (columns[size][W] int32, -1 = unused; weights[size][W]).  Interior rows carry the stencil of the given kind; in
+    the rows whose stencil would reach beyond the boundary point the reference SHIFTS a one-sided stencil of width
+    order + derivative so that it starts at the boundary point (helpers/problem_helper.py:143-224, `reduce = False`): row i
+    (i < half width) uses the grid offsets -(i+1) .. order + derivative - (i+2), whose first weight multiplies the boundary
+    value (zero here) and is dropped; mirrored at the other end.  Weights: Fornberg's recursion in exact rationals, then the
+    reference's two scalings (/ dx**derivative, * coeff)."""
+    w_in, off_in = finite_difference_stencil(derivative, order, kind)
+    half_left, half_right = -int(min(off_in)), int(max(off_in))
+    shifted = order + derivative
+    if size < max(shifted - 1, len(off_in)):
+        raise ValueError(f'{size} interior points are too few for boundary stencils of width {shifted}')
+    rows = []
+    for i in range(size):
+        if i < half_left:                      # next to the left boundary: offsets -(i+1) .. , first one is the boundary
+            offs = list(range(-(i + 1), shifted - (i + 1)))
+            w, offs = finite_difference_stencil(derivative, offsets=offs)
+            entries = [(i + int(o), float(x)) for o, x in zip(offs[1:], w[1:])]
+        elif size - 1 - i < half_right:        # next to the right boundary: mirrored
+            k = size - 1 - i
+            offs = list(range(-(shifted - (k + 2)), k + 2))
+            w, offs = finite_difference_stencil(derivative, offsets=offs)
+            entries = [(i + int(o), float(x)) for o, x in zip(offs[:-1], w[:-1])]
+        else:
+            entries = [(i + int(o), float(x)) for o, x in zip(off_in, w_in) if 0 <= i + int(o) < size]
+        rows.append(entries)
+    width = max(len(r) for r in rows)
+    cols = -np.ones((size, width), dtype=np.int32)
+    wts = np.zeros((size, width))
+    for i, entries in enumerate(rows):
+        for k, (j, x) in enumerate(entries):
+            cols[i, k] = j
+            wts[i, k] = x / dx**derivative * coeff
+    return cols, wts

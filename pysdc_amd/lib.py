@@ -48,6 +48,7 @@ PROTOTYPES = {
     'sdc_set_pipeline_groups': (C.c_int, [_vp, C.c_int]),
     'sdc_set_deferred': (C.c_int, [_vp, C.c_int]),
     'sdc_set_solver': (C.c_int, [_vp, C.c_int, C.c_double, C.c_int]),
+    'sdc_set_banded_operator': (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_int), _dp]),
     'sdc_solve_jacobian': (C.c_int, [_vp, _vp, C.c_double, _vp, _vp]),
     'sdc_advance': (C.c_int, [_vp]),
     'sdc_defer_f0': (C.c_int, [_vp]),

@@ -190,10 +190,11 @@ class GenericNDimFinDiff(Problem):
         ndim = len(nvars)
         if bc not in ('periodic', 'dirichlet-zero'):
             raise ProblemError(f'the MI355X engine implements periodic and dirichlet-zero boundaries, got bc={bc!r}')
-        if bc == 'dirichlet-zero' and (order != 2 or derivative != 2 or stencil_type != 'center'):
+        if bc == 'dirichlet-zero' and (derivative != 2 or stencil_type != 'center' or order % 2):
             raise ProblemError(
-                'dirichlet-zero is available for the second-order centred second derivative (odd extension; the shifted '
-                f'boundary stencils of higher orders are not built); got order={order}, derivative={derivative}'
+                'dirichlet-zero is available for the centred second derivative of even order (order 2: odd extension and the '
+                f'sine-transform solve; higher orders: banded rows and an iterative solve); got order={order}, '
+                f'derivative={derivative}, stencil_type={stencil_type!r}'
             )
         if solver_type not in ('direct', 'CG', 'GMRES'):
             raise ProblemError(f'solver type "{solver_type}" not known in generic advection-diffusion implementation!')
@@ -206,10 +207,18 @@ class GenericNDimFinDiff(Problem):
         # 2-D / 3-D: the interior is strided inside the extension, so fields stay compact and are packed into / extracted
         # from extension-sized scratch around eval_f and solve_system (sdc_odd_extend / sdc_odd_extract); the sweep then
         # runs node by node on datatype operations (fused = False).
-        self.view_offset = 1 if (bc == 'dirichlet-zero' and ndim == 1) else 0
-        self.odd_nd = bc == 'dirichlet-zero' and ndim > 1
+        # dirichlet-zero with stencils of order >= 4: the reference shifts one-sided stencils into the rows next to the
+        # boundary (helpers/problem_helper.py:143-224) - a non-symmetric banded matrix per axis.  Fields stay compact (the
+        # first n^ndim values of slab fields sized (n+1)^ndim), eval_f applies the row table axis by axis, the solve is
+        # GMRES (to round-off for 'direct', the user's tolerance and counts for 'GMRES' / 'CG'), sweeps run node by node.
+        self.banded = bc == 'dirichlet-zero' and order > 2
+        self.view_offset = 1 if (bc == 'dirichlet-zero' and ndim == 1 and not self.banded) else 0
+        self.odd_nd = bc == 'dirichlet-zero' and ndim > 1 and not self.banded
         self.engine_nvars = (2 * (nvars[0] + 1),) * ndim if bc == 'dirichlet-zero' else nvars
-        if self.odd_nd:
+        if self.banded:
+            self.engine_nvars = (nvars[0] + 1,) * ndim
+            self._rows = fd.dirichlet_operator_rows(derivative, order, stencil_type, dx, coeff, nvars[0])
+        if self.odd_nd or self.banded:
             self.fused = False
         self._scratch = None
         self._makeAttributeAndRegister('nvars', 'stencil_type', 'order', 'bc', localVars=locals(), readOnly=True)
@@ -245,7 +254,10 @@ class GenericNDimFinDiff(Problem):
         return generic_implicit
 
     def configure_engine(self, engine):
-        engine.set_stencil(0, *self._stencil)
+        if self.banded:
+            engine.set_banded_operator(*self._rows)
+        else:
+            engine.set_stencil(0, *self._stencil)
         if self.solver_type in ('CG', 'GMRES'):
             engine.set_solver(self.solver_type, self.lintol, self.liniter)
 
@@ -257,7 +269,9 @@ class GenericNDimFinDiff(Problem):
         return self._scratch[k]
 
     def _stage_in(self, u, k):
-        """pointer the engine can read: the field itself (periodic) or its odd extension in scratch k"""
+        """pointer the engine can read: the field itself (periodic, banded) or its odd extension in scratch k"""
+        if self.banded:
+            return u.ptr
         if self.odd_nd:
             e = self._ext(k)
             L.check(self.engine.lib.sdc_odd_extend(self.engine.ctx, u.ptr, e.ptr, self.nvars[0], self.ndim), self.engine.ctx)
@@ -278,7 +292,7 @@ class GenericNDimFinDiff(Problem):
             self.engine.vec_copy(self.nvars[0], self._ext(k).ptr + 8, dst.ptr)
 
     def _out_ptr(self, k, dst):
-        return self._ext(k).ptr if (self.view_offset or self.odd_nd) else dst.ptr
+        return self._ext(k).ptr if (self.view_offset or self.odd_nd) else dst.ptr   # (banded: in place, nothing to stage)
 
     def eval_f(self, u, t):
         f = self._out_f()
@@ -367,7 +381,7 @@ class heatNd_forced(heatNd_unforced):
             for i in range(1, self.ndim):
                 p = p * np.sin(np.pi * self.freq[i] * g[i])
             engine.set_forcing_profile(np.broadcast_to(p, self.engine_nvars))
-        else:
+        elif not self.banded:   # (banded rows: eval_f adds profile * g(t) itself, on the compact fields)
             engine.set_forcing_profile(self._profile())
 
     @classmethod
@@ -378,6 +392,12 @@ class heatNd_forced(heatNd_unforced):
 
     def eval_f(self, u, t):
         f = self._out_f()
+        if self.banded:   # the operator by its row table; the forcing is profile(x) * g(t) (HeatEquation_ND_FD.py:162-204)
+            self.engine.eval_f(u.ptr, 0.0, f.impl.ptr)
+            if getattr(self, '_profile_dev', None) is None:
+                self._profile_dev = self._from_host(self._profile())
+            f.expl._axpby(float(self.forcing_g(t)), self._profile_dev, 0.0, self._profile_dev, f.expl)
+            return f
         if self.odd_nd:
             e = self.engine
             e.eval_f(self._stage_in(u, 0), float(self.forcing_g(t)), self._ext(1).ptr, self._ext(2).ptr)

@@ -11,7 +11,7 @@ own entry points, switched on by environment variables (or call the function aft
 GOLDEN_FFT=1 fft_transfer_main (transfer_fft.npz, runs_ac_fft.npz), GOLDEN_RELAY=1 relay_main (runs_relay.npz),
 GOLDEN_CG=1 cg_main (sweeps_cg.npz), GOLDEN_VDPJ=1 vdp_jacobian_main (vdp_jacobian.npz), GOLDEN_DML=1
 dirichlet_ml_main (transfer_dirichlet.npz, runs_ml_dirichlet.npz), GOLDEN_GUESS=1 guess_main (sweeps_guess.npz), GOLDEN_SKIP=1 skip_main (runs_skip.npz), GOLDEN_RELAY8=1 relay8_main (runs_relay8.npz),
-GOLDEN_BIG3D=1 big3d_main (sweeps_big3d.npz), GOLDEN_CFG5=1 cfg5_main (runs_cfg5.npz), GOLDEN_ML8=1 ml8_main (runs_ml8.npz), GOLDEN_DND=1 dirichlet_nd_main (sweeps_dirichlet_nd.npz, runs_dirichlet_nd.npz), GOLDEN_NSW2=1 nsweeps2_main (runs_nsweeps2.npz), GOLDEN_PIN1024=1 pin1024_main (sweeps_pin1024.npz, 20 minutes), GOLDEN_GMRES=1 gmres_main (sweeps_gmres.npz);
+GOLDEN_BIG3D=1 big3d_main (sweeps_big3d.npz), GOLDEN_CFG5=1 cfg5_main (runs_cfg5.npz), GOLDEN_ML8=1 ml8_main (runs_ml8.npz), GOLDEN_DND=1 dirichlet_nd_main (sweeps_dirichlet_nd.npz, runs_dirichlet_nd.npz), GOLDEN_NSW2=1 nsweeps2_main (runs_nsweeps2.npz), GOLDEN_PIN1024=1 pin1024_main (sweeps_pin1024.npz, 20 minutes), GOLDEN_GMRES=1 gmres_main (sweeps_gmres.npz), GOLDEN_DHO=1 dirichlet_ho_main (sweeps_dirichlet_ho.npz, runs_dirichlet_ho.npz, dirichlet_ho_matrices.npz);
 GOLDEN_ML=0 skips the multi-level block.
 
 ``qmat`` (third-party, absent here) is replaced by oracle/qmat_shim, which forwards to
@@ -976,3 +976,42 @@ def gmres_main():
 
 if __name__ == '__main__' and os.environ.get('GOLDEN_GMRES', '0') == '1':
     gmres_main()
+
+
+def dirichlet_ho_main():
+    """dirichlet-zero with stencils of order 4 / 6 / 8: the reference shifts the stencil in the rows next to the boundary
+    (helpers/problem_helper.py:143-224), which makes the operator non-symmetric; its solves are SuperLU ('direct') or GMRES.
+    Sweeps in 1-D / 2-D / 3-D, a run to restol, and the 1-D operator matrices themselves (dense) for the construction test."""
+    from pySDC.helpers import problem_helper
+
+    RR = dict(quad_type='RADAU-RIGHT')
+    cases = []
+    cases.append(sweep_case('heat1d_dirichlet_o4', 'heat_unforced', dict(nvars=63, nu=0.1, freq=3, order=4, bc='dirichlet-zero'),
+                            'generic_implicit', dict(num_nodes=3, QI='LU', **RR), 5e-3))
+    cases.append(sweep_case('heat1d_dirichlet_o6', 'heat_unforced', dict(nvars=31, nu=0.1, freq=2, order=6, bc='dirichlet-zero'),
+                            'generic_implicit', dict(num_nodes=5, QI='IE', **RR), 1e-2))
+    cases.append(sweep_case('heat2d_dirichlet_o4', 'heat_unforced', dict(nvars=(15, 15), nu=0.1, freq=(1, 2), order=4, bc='dirichlet-zero'),
+                            'generic_implicit', dict(num_nodes=3, QI='LU', **RR), 2e-2))
+    cases.append(sweep_case('heat3d_dirichlet_o4_gmres', 'heat_unforced',
+                            dict(nvars=(7, 7, 7), nu=0.1, freq=(1, 1, 2), order=4, bc='dirichlet-zero', solver_type='GMRES',
+                                 lintol=1e-12, liniter=1000),
+                            'generic_implicit', dict(num_nodes=3, QI='IE', **RR), 1e-2))
+    cases.append(sweep_case('forced2d_dirichlet_o8', 'heat_forced', dict(nvars=(15, 15), nu=0.1, freq=(1, 3), order=8, bc='dirichlet-zero'),
+                            'imex_1st_order', dict(num_nodes=3, QI='LU', QE='EE', **RR), 2e-2, u0_kind='exact'))
+    save('sweeps_dirichlet_ho.npz', cases)
+    cases = [run_case('heat2d_dirichlet_o4_run', prob='heat_unforced',
+                      prob_params=dict(nvars=(31, 31), nu=0.1, freq=(1, 1), order=4, bc='dirichlet-zero'), sweeper='generic_implicit',
+                      sweeper_params=dict(num_nodes=3, QI='LU', **RR), level_params=dict(dt=0.05, restol=1e-9), maxiter=50, t0=0.0,
+                      Tend=0.15)]
+    save('runs_dirichlet_ho.npz', cases)
+    mats = {}
+    for order in (4, 6, 8):
+        for size in (15, 31):
+            A, _ = problem_helper.get_finite_difference_matrix(derivative=2, order=order, stencil_type='center', dx=1.0 / (size + 1),
+                                                              size=size, dim=1, bc='dirichlet-zero')
+            mats[f'A_o{order}_n{size}'] = A.toarray()
+    np.savez_compressed(os.path.join(OUT, 'dirichlet_ho_matrices.npz'), **mats)
+
+
+if __name__ == '__main__' and os.environ.get('GOLDEN_DHO', '0') == '1':
+    dirichlet_ho_main()

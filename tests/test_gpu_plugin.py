@@ -29,6 +29,7 @@ def description_from(meta, problem_class=None):
 
 RUNS = ([('runs.npz', n) for n in load_cases('runs.npz')] + [('runs_dirichlet.npz', n) for n in load_cases('runs_dirichlet.npz')]
         + [('runs_dirichlet_nd.npz', n) for n in load_cases('runs_dirichlet_nd.npz')]
+        + [('runs_dirichlet_ho.npz', n) for n in load_cases('runs_dirichlet_ho.npz')]
         + [('runs_skip.npz', n) for n in load_cases('runs_skip.npz')])
 
 
@@ -277,14 +278,17 @@ def test_bench_single_rank_distributed_path():
 
 
 DIRICHLET_SWEEPS = ([('sweeps_heat.npz', 'heat1d_dirichlet'), ('sweeps_imex.npz', 'forced1d_dirichlet')]
-                    + [('sweeps_dirichlet_nd.npz', n) for n in load_cases('sweeps_dirichlet_nd.npz')])
+                    + [('sweeps_dirichlet_nd.npz', n) for n in load_cases('sweeps_dirichlet_nd.npz')]
+                    + [('sweeps_dirichlet_ho.npz', n) for n in load_cases('sweeps_dirichlet_ho.npz')])
 
 
 @pytest.mark.parametrize('fname,name', DIRICHLET_SWEEPS)
 @pytest.mark.parametrize('fused', [True, False])
 def test_dirichlet_sweeps_vs_golden(fname, name, fused):
-    """dirichlet-zero against golden sweeps of the reference: 1-D (odd extension inside the engine, fused sweeps) and 2-D /
-    3-D (fields packed into their odd extension around eval_f / solve_system, node-by-node sweeps)."""
+    """dirichlet-zero against golden sweeps of the reference: 1-D (odd extension inside the engine, fused sweeps), 2-D /
+    3-D (fields packed into their odd extension around eval_f / solve_system, node-by-node sweeps), and stencils of order
+    4 / 6 / 8 whose rows next to the boundary carry the reference's shifted one-sided stencils (banded row table, GMRES to
+    round-off in place of the sparse LU - or the reference's own GMRES with its iteration counts)."""
     from pysdc_amd.level import Step
 
     case = load_cases(fname)[name]
@@ -292,9 +296,9 @@ def test_dirichlet_sweeps_vs_golden(fname, name, fused):
     probs, sweeps = _classes()
     pc = probs[meta['prob']]
     pp = {k: tuple(v) if isinstance(v, list) else v for k, v in meta['prob_params'].items()}
-    if len(pp['nvars']) > 1 if isinstance(pp['nvars'], tuple) else False:
+    if (len(pp['nvars']) > 1 if isinstance(pp['nvars'], tuple) else False) or pp.get('order', 2) > 2:
         if fused:
-            pytest.skip('2-D / 3-D dirichlet levels sweep node by node')
+            pytest.skip('2-D / 3-D dirichlet levels and boundary-shifted stencils sweep node by node')
     elif not fused:
         pc = type(pc.__name__ + '_nodewise', (pc,), {'fused': False})
     S = Step(dict(problem_class=pc, problem_params=pp, sweeper_class=sweeps[meta['sweeper']],
@@ -323,6 +327,8 @@ def test_dirichlet_sweeps_vs_golden(fname, name, fused):
     for k in range(1, meta['nsweeps'] + 1):
         L.sweep.update_nodes()
         check(f'k{k}')
+        for key in L.prob.work_counters:          # the reference's solver, its counts (GMRES on the banded operator)
+            assert L.prob.work_counters[key].niter == int(case[f'work_{key}'][k - 1]), (key, k)
 
 
 @pytest.mark.parametrize('virtual', [0, 8])
