@@ -173,6 +173,9 @@ int sdc_set_wire_spectral(sdc_ctx* ctx, int on); /* the engine side of sdc_comm_
 void* sdc_end_spectrum(sdc_ctx* ctx, void* stream);
 void* sdc_spectrum_inbox(sdc_ctx* ctx);
 int sdc_replace_u0_spectrum(sdc_ctx* ctx);
+/* a new block starts from the field whose spectrum lies in the inbox (nothing of the finished step is kept): what sdc_advance
+ * is for the rank that owns the end value, for the ranks that received it (sdc_comm_bcast_end_spectrum) */
+int sdc_start_from_spectrum(sdc_ctx* ctx);
 
 /* ---- time-rank communication (RCCL over xGMI; host mailboxes as the rehearsal wire) --------------------------
  * The forward transfer uend -> u[0] of the next time rank (controller_MPI.py:218-305 send_full / recv_full; mesh.py:85-125
@@ -200,6 +203,8 @@ int sdc_replace_u0_spectrum(sdc_ctx* ctx);
  *   sdc_bcast(ctx, slot, m, root)    one slab field of rank `root` to all, in place (more than two ranks and relay on:
  *                                    scatter + all-gather over the mesh, same bits)
  *   sdc_comm_bcast_buffer(ctx, p, n, root)  the same for any device buffer of n doubles
+ *   sdc_comm_bcast_end_spectrum(ctx, root)  the end value of a block as its half spectrum: from the root's cache into the other
+ *                                    ranks' spectrum inboxes (sdc_advance on the root, sdc_start_from_spectrum elsewhere)
  *   sdc_comm_set_chunk(ctx, n)       cut every message into pieces of n doubles inside its group (0 = one piece)
  *   sdc_comm_set_format(ctx, 1)      lock-step hand-overs carry half spectra instead of fields (sdc_end_spectrum ->
  *                                    sdc_spectrum_inbox -> sdc_replace_u0_spectrum); same choice on every rank
@@ -220,6 +225,7 @@ int sdc_comm_handover_post(sdc_ctx* ctx, int nactive);
 int sdc_comm_handover_complete(sdc_ctx* ctx);
 int sdc_bcast(sdc_ctx* ctx, int slot, int m, int root);
 int sdc_comm_bcast_buffer(sdc_ctx* ctx, double* buf, size_t n, int root);
+int sdc_comm_bcast_end_spectrum(sdc_ctx* ctx, int root);
 int sdc_comm_set_chunk(sdc_ctx* ctx, size_t doubles_per_piece);
 int sdc_comm_set_relay(sdc_ctx* ctx, int on);
 int sdc_comm_set_format(sdc_ctx* ctx, int spectra);

@@ -104,6 +104,10 @@ class DeviceComm:
         """any device buffer of n doubles, in place"""
         self._e(self.engine.lib.sdc_comm_bcast_buffer(self.engine.ctx, ptr, int(n), int(root)))
 
+    def bcast_end_spectrum(self, root):
+        """the end value of a block as its half spectrum, into the other ranks' spectrum inboxes"""
+        self._e(self.engine.lib.sdc_comm_bcast_end_spectrum(self.engine.ctx, int(root)))
+
     def set_chunk(self, doubles_per_piece):
         self._e(self.engine.lib.sdc_comm_set_chunk(self.engine.ctx, int(doubles_per_piece)))
 

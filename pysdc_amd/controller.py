@@ -362,6 +362,9 @@ class controller_nonMPI(_ControllerBase):
             S.levels[0].sweep.update_nodes()
 
 
+_FROM_WIRE = object()   # restart_block: u[0] is the spectrum this rank's communicator received
+
+
 class _WorkList:
     def __init__(self, works):
         self.works = works
@@ -560,11 +563,20 @@ class controller_dist(_ControllerBase):
                 # a single time rank: the next block starts on the same level from its own end value
                 self.restart_block(1, time, None, True)
                 continue
+            active = time < Tend - eps10
+            num_next = self._all_sum(active)
+            if self.spectral_wire and num_next > 0:
+                # another block follows, and the levels sweep in Fourier space: the end value travels as its half spectrum
+                # from the root's cache into everybody's spectrum inbox and becomes u[0] there - no inverse transform on
+                # the root, no forward transform anywhere (only the last block's end value is needed as a field)
+                self._comms[0].bcast_end_spectrum(root)
+                num_active = num_next
+                self.restart_block(num_active, time, _FROM_WIRE if self.rank != root else None, active)
+                continue
             if self.rank == root:
                 uend[:] = S.levels[0].uend
             self.broadcast(uend, root)
-            active = time < Tend - eps10
-            num_active = self._all_sum(active)
+            num_active = num_next
             if num_active > 0:
                 self.restart_block(num_active, time, uend, active)
         self._hook('post_run', S)
@@ -583,6 +595,8 @@ class controller_dist(_ControllerBase):
         S.status.last = self.rank == size - 1
         if u0 is None:
             S.levels[0].advance()
+        elif u0 is _FROM_WIRE:
+            S.levels[0].start_from_wire()
         else:
             S.init_step(u0)
         S.status.done = False

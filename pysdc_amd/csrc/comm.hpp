@@ -766,6 +766,40 @@ extern "C" int sdc_comm_bcast_buffer(sdc_ctx* c, double* buf, size_t n, int root
     return bcast_buffer(c, cs, w, buf, n, root);
 }
 
+// The end value of a block from rank `root` to every rank AS ITS HALF SPECTRUM (levels that sweep in Fourier space): the
+// root sends the last node's spectrum as it lies in its cache, the others receive into their spectrum inbox
+// (sdc_start_from_spectrum makes it the start value of the next block; the root itself continues with sdc_advance) - no
+// inverse transform on the root, no forward transform anywhere (controller_MPI.py:125-130 without leaving Fourier space).
+extern "C" int sdc_comm_bcast_end_spectrum(sdc_ctx* c, int root) {
+    NEED_COMM(c);
+    if (root < 0 || root >= w->size) return fail(c, SDC_ERR_PARAM, "root out of range");
+    if (!sdc_spectral_handover_ok(c)) return fail(c, SDC_ERR_STATE, "this level does not sweep in Fourier space");
+    if (cs->posted_recv >= 0) return fail(c, SDC_ERR_STATE, "a posted hand-over is still open (sdc_comm_handover_complete)");
+    const size_t n = 2 * c->Nc;
+    double* buf;
+    int rc;
+    if (w->rank == root) {
+        buf = (double*)sdc_end_spectrum(c, w->stream);
+        if (!buf) return c->err.empty() ? fail(c, SDC_ERR_STATE, "no end value to broadcast") : SDC_ERR_STATE;
+    } else {
+        buf = (double*)sdc_spectrum_inbox(c);
+        if (!buf) return SDC_ERR_NOMEM;
+        if ((rc = inbox_writable(c, cs, w)) != SDC_OK) return rc;
+        HIPCHK(c, hipEventRecord(cs->ready, c->stream));  // (whatever still reads the buffer that is the inbox now)
+        HIPCHK(c, hipStreamWaitEvent(w->stream, cs->ready, 0));
+    }
+    if (cs->relay && w->size > 2) {
+        cs->mesh_bcast_calls++;
+        rc = mesh_bcast(w, c, buf, n, root);
+    } else {
+        rc = w->bcast(c, buf, n, root);
+    }
+    if (rc != SDC_OK) return rc;
+    HIPCHK(c, hipEventRecord(cs->done, w->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, cs->done, 0));
+    return SDC_OK;
+}
+
 // host waits until every message posted so far has completed
 extern "C" int sdc_comm_sync(sdc_ctx* c) {
     NEED_COMM(c);

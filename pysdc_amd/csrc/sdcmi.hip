@@ -2734,6 +2734,25 @@ int sdc_replace_u0_spectrum(sdc_ctx* c) {
     return SDC_OK;
 }
 
+// A new block starts from the value whose spectrum lies in the inbox (the end value of the previous block, broadcast as a
+// spectrum: sdc_comm_bcast_end_spectrum): what sdc_advance does on the rank that owns that end value, for everybody else.
+// Nothing of the finished step survives (reset_level, core/level.py:110-131).
+int sdc_start_from_spectrum(sdc_ctx* c) {
+    if (!c || !c->Sin) return fail(c, SDC_ERR_STATE, "no spectrum inbox (sdc_spectrum_inbox)");
+    if (!spectral_level(c)) return fail(c, SDC_ERR_STATE, "this level does not sweep in Fourier space");
+    std::swap(c->S0, c->Sin);
+    c->spec0_valid = true;
+    c->u0_spec_only = true;
+    c->u0_src = nullptr;
+    c->spec_valid = c->spec_spread = false;
+    c->spec_virtual = 0;
+    c->u_pending = c->f_pending = c->spread_pending = c->f0_pending = false;
+    c->rfields_valid = c->rlines_valid = c->res_valid = c->res_spread = false;
+    c->uend_pending = false;
+    c->uend_gen = -1;
+    return SDC_OK;
+}
+
 int sdc_integrate(sdc_ctx* c, double dt, double* const* dst) {
     if (!c || !dst) return fail(c, SDC_ERR_PARAM, "null pointer");
     if (!c->have_coeffs) return fail(c, SDC_ERR_STATE, "coefficients not set (sdc_set_coeffs)");

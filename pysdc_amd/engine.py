@@ -147,6 +147,9 @@ class SweepEngine:
             self._chk(L.ERR_NOMEM)
         return p
 
+    def start_from_spectrum(self):
+        self._chk(self.lib.sdc_start_from_spectrum(self.ctx))
+
     def replace_u0_spectrum(self):
         self._chk(self.lib.sdc_replace_u0_spectrum(self.ctx))
 

@@ -366,6 +366,14 @@ class Level(DeviceBacked):
         self._res_cache = None
         self._uend_valid = False  # (the end-value buffer of the finished step now holds this step's start value)
 
+    def start_from_wire(self):
+        """next block on a rank that RECEIVED the end value of the previous one as a spectrum (sdc_comm_bcast_end_spectrum): it
+        becomes u[0] inside the engine, like advance() on the rank that owns it; include/sdcmi.h: sdc_start_from_spectrum"""
+        self.engine.start_from_spectrum()
+        self._u.mark([0])
+        self._res_cache = None
+        self._uend_valid = False
+
     def reset_level(self, reset_status=True):
         """pySDC/core/level.py:110-131."""
         self._lists()

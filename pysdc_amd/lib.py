@@ -61,6 +61,7 @@ PROTOTYPES = {
     'sdc_end_spectrum': (_vp, [_vp, _vp]),
     'sdc_spectrum_inbox': (_vp, [_vp]),
     'sdc_replace_u0_spectrum': (C.c_int, [_vp]),
+    'sdc_start_from_spectrum': (C.c_int, [_vp]),
     'sdc_comm_unique_id': (C.c_int, [C.c_char_p]),
     'sdc_comm_init': (C.c_int, [_vp, C.c_char_p, C.c_int, C.c_int]),
     'sdc_comm_attach': (C.c_int, [_vp, _vp]),
@@ -72,6 +73,7 @@ PROTOTYPES = {
     'sdc_comm_handover_post': (C.c_int, [_vp, C.c_int]),
     'sdc_comm_handover_complete': (C.c_int, [_vp]),
     'sdc_comm_bcast_buffer': (C.c_int, [_vp, _vp, C.c_size_t, C.c_int]),
+    'sdc_comm_bcast_end_spectrum': (C.c_int, [_vp, C.c_int]),
     'sdc_comm_set_chunk': (C.c_int, [_vp, C.c_size_t]),
     'sdc_comm_set_relay': (C.c_int, [_vp, C.c_int]),
     'sdc_comm_set_format': (C.c_int, [_vp, C.c_int]),

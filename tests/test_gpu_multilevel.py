@@ -384,7 +384,7 @@ def test_time_parallel_controller_64cubed_matches_serial_emulation(nranks, M, si
             v = Pd.u_init
             v[:] = u0h
             uend, stats = Cd.run(v, meta['t0'], meta['Tend'])
-            out[rank] = (uend.get(), Cd.two_hop_calls, Cd._overlap)
+            out[rank] = (uend.get(), Cd.two_hop_calls, Cd._overlap and Cd.spectral_wire)   # (spectra on the wire, also between blocks)
         except Exception:  # noqa: BLE001
             errors.append(traceback.format_exc())
             try:
