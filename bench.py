@@ -208,9 +208,8 @@ def run_workload(args, world, rank, use_dist, with_stream_reference=True):
         if args.n is None:
             # 1024^3 with M = 5 needs ~30 fields of 8.6 GB (slabs U 6, F 6, end values 2, work + cached spectra 11,
             # start / end value objects of the runs 5); fall back to the largest configuration that fits if this GPU
-            # cannot hold it (time-parallel runs: no second end-value buffer, but an inbox, the relay staging and a
-            # spare work spectrum)
-            need = (30.5 if world == 1 else 32.5) * 8.0 * n**3
+            # cannot hold it (time-parallel runs: no second end-value buffer, but the spectrum inbox and the relay staging)
+            need = (30.5 if world == 1 else 31.5) * 8.0 * n**3
             free = torch.cuda.mem_get_info()[0]
             if free < need:
                 n = 512

@@ -1332,8 +1332,9 @@ static int ensure_spec_cache(sdc_ctx* c) {
         c->spec_valid = c->spec0_valid = false;
     }
     // the second end-value buffer of sdc_advance, allocated with the cache (not inside a time loop) - unless this is a
-    // time-parallel level (keep_rfields is switched on before its first sweep): those never advance in place
-    if (!c->UEND2 && !c->keep_rfields) {
+    // time-parallel level (keep_rfields / early_uend are switched on before its first sweep): those advance in place only as
+    // spectra (sdc_advance allocates the buffer itself should it ever need it)
+    if (!c->UEND2 && !c->keep_rfields && !c->early_uend) {
         HIPCHK(c, hipMalloc((void**)&c->UEND2, c->N * sizeof(double)));
         c->bytes += c->N * sizeof(double);
     }
