@@ -162,6 +162,12 @@ struct LayContig {  // lines are separate: [col][pos]
     DEVI static int idx(int col, int pos) { return col * kLine + pos + (pos >> 4); }
     static constexpr int doubles(int cols) { return cols * kLine; }
 };
+template <int N>
+struct LayCols {  // like LayContig, with the columns 16 dwords apart modulo the 64 banks (8 columns written by one wave)
+    static constexpr int kLine = N + (N >> 4) + 8;
+    DEVI static int idx(int col, int pos) { return col * kLine + pos + (pos >> 4); }
+    static constexpr int doubles(int cols) { return cols * kLine; }
+};
 template <int N, int T>
 struct LayStrided {  // T columns interleaved: [pos][col]
     DEVI static int idx(int col, int pos) { return (pos + (pos >> 4)) * T + col; }

@@ -78,6 +78,9 @@ __global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_fwd(FieldPtr
 #ifndef SDC_XINV_DIRECT
 #define SDC_XINV_DIRECT 0
 #endif
+#ifndef SDC_XWAVE
+#define SDC_XWAVE 0  // 1: the norm-only pass transforms every column inside one wavefront (4 workgroup barriers per tile, not 12)
+#endif
 // c2r along axis 0 (inverse of the above, unnormalised).  NORM: max |.| per field goes to norms[field] (the fields
 // are the collocation residuals of the spectral sweep); STORE: the real field is written to out[field].
 // ADD: a further half spectrum `add` (same layout, one field) is added to every field on the way in - the residual of
@@ -89,6 +92,7 @@ __global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_inv(FieldPtr
                                                                       unsigned long long* __restrict__ norms,
                                                                       const cd* __restrict__ add = nullptr, int nfields = 1) {
     constexpr int E = fft_elems(N), P = N / E;
+    constexpr bool XWAVE = SDC_XWAVE && NORM && !STORE && P == 64 && !SDC_XINV_DIRECT;  // (norm-only pass, one wave per column)
     using LAY = LayStrided<N, T>;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int col = threadIdx.x % T, j = threadIdx.x / T;
@@ -122,6 +126,7 @@ __global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_inv(FieldPtr
         else if (!up) r[i] = cd{a.x - b.y, a.y + b.x};
         else r[i] = cd{a.x + b.y, -a.y + b.x};
     }
+    fft_line<N, +1, LAY>(r, j, col, lds, tw);
 #else
     cd A[E], B[E];
 #pragma unroll
@@ -141,6 +146,43 @@ __global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_inv(FieldPtr
         }
     }
     // C[k] = A[k] + i B[k] (k <= N/2), C[N-k] = conj A[k] + i conj B[k]
+    if constexpr (XWAVE) {
+        // One wavefront per column for the transform: the loads above are coalesced over (rows, columns) - 8 rows x 8
+        // columns per wave - but a column whose 64 threads sit in ONE wave exchanges through LDS without workgroup
+        // barriers.  So the unpacked line goes to LDS column by column (both halves: the thread that holds row k makes
+        // C[k] and C[N-k]) and every wave picks up its column: 4 workgroup barriers per tile instead of 12.
+        using LC = LayCols<N>;
+        const int cw = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+#pragma unroll
+            for (int i = 0; i < E; ++i) {
+                const int k = j + i * P;
+                if (k <= N / 2) {
+                    const bool edge = (k == 0) || (k == N / 2);
+                    double own, mir;
+                    if (part == 0) {
+                        own = edge ? A[i].x : A[i].x - B[i].y;
+                        mir = A[i].x + B[i].y;
+                    } else {
+                        own = edge ? B[i].x : A[i].y + B[i].x;
+                        mir = -A[i].y + B[i].x;
+                    }
+                    lds[LC::idx(col, k)] = own;
+                    if (!edge) lds[LC::idx(col, N - k)] = mir;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < E; ++i) {
+                const double v = lds[LC::idx(cw, lane + i * P)];
+                if (part == 0) r[i].x = v;
+                else r[i].y = v;
+            }
+            __syncthreads();
+        }
+        fft_line<N, +1, LC, true>(r, lane, cw, lds, tw);
+    } else {
 #pragma unroll
     for (int part = 0; part < 2; ++part) {
 #pragma unroll
@@ -174,8 +216,9 @@ __global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_inv(FieldPtr
         }
         __syncthreads();
     }
-#endif
     fft_line<N, +1, LAY>(r, j, col, lds, tw);
+    }
+#endif
     if constexpr (NORM) {
         double m = 0.0;  // columns beyond the edge were transformed from zeros
 #pragma unroll

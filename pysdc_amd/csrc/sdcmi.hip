@@ -381,6 +381,8 @@ template <int N>
 static int inverse_tail_n(sdc_ctx* c, int nf, cd* work, const FieldPtrs& p, unsigned long long* norms, bool y_done = false) {
     constexpr int E = fft_elems(N), P = N / E, T = N >= 2048 ? 4 : (N == 1024 ? SDC_T1024 : 8);
     const size_t lds_str = (size_t)LayStrided<N, T>::doubles(T) * sizeof(double);
+    // (the norm-only pass with one wave per column keeps the columns apart in LDS: a few more bytes)
+    const size_t lds_x = (SDC_XWAVE && P == 64) ? (size_t)LayCols<N>::doubles(T) * sizeof(double) : lds_str;
     const int n = c->n;
     if (c->ndim == 1) {
         if (norms) return fail(c, SDC_ERR_UNSUPPORTED, "norm-only inverse transform in 1-D");
@@ -407,7 +409,7 @@ static int inverse_tail_n(sdc_ctx* c, int nf, cd* work, const FieldPtrs& p, unsi
                     hipLaunchKernelGGL((k_fftx_norm_half<N, TH>), dim3((rest + TH - 1) / TH, nf), dim3(PH * TH), lds_half,
                                        c->stream, work, c->Nc, rest, c->tw, c->tw + N, norms);
                 } else {
-                    hipLaunchKernelGGL((k_fftx_inv<N, T, true, false>), dim3(tiles, nf), dim3(P * T), lds_str, c->stream,
+                    hipLaunchKernelGGL((k_fftx_inv<N, T, true, false>), dim3(tiles, nf), dim3(P * T), lds_x, c->stream,
                                        p, work, c->Nc, rest, c->tw, norms);
                 }
             }
@@ -425,7 +427,8 @@ static int inverse_tail_n(sdc_ctx* c, int nf, cd* work, const FieldPtrs& p, unsi
 template <int N>
 static int inverse_tail_x_only(sdc_ctx* c, int nf, cd* work, const FieldPtrs& p, unsigned long long* norms, const cd* add) {
     constexpr int E = fft_elems(N), P = N / E, T = N >= 2048 ? 4 : (N == 1024 ? SDC_T1024 : 8);
-    const size_t lds_str = (size_t)LayStrided<N, T>::doubles(T) * sizeof(double);
+    const size_t lds_str = (SDC_XWAVE && P == 64) ? (size_t)LayCols<N>::doubles(T) * sizeof(double)
+                                                  : (size_t)LayStrided<N, T>::doubles(T) * sizeof(double);
     const int rest = (int)(c->N / c->n);
     const int tiles = (rest / 2 + T - 1) / T;
     LaunchTimer lt(c, pname("fft_x_norm_add", nf));
