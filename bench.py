@@ -661,7 +661,11 @@ def main():
     if world != args.gpus:
         print(json.dumps({'error': f'--gpus {args.gpus} but WORLD_SIZE={world} in the environment'}), flush=True)
         raise SystemExit(2)
-    torch.cuda.set_device(0 if args.same_device else local_rank)
+    try:
+        torch.cuda.set_device(0 if args.same_device else local_rank)
+    except Exception as e:  # noqa: BLE001  (fewer GPUs than ranks: say so in the one line the caller parses)
+        print(json.dumps({'error': f'rank {rank}: no GPU {local_rank} ({e!r}); {torch.cuda.device_count()} visible'}), flush=True)
+        raise SystemExit(3)
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
