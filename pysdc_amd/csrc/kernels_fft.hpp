@@ -10,6 +10,24 @@ struct FieldPtrs {
     double* out[MAXM];
 };
 
+// A pointwise reaction term evaluated where the values pass through registers anyway (Allen-Cahn: the explicit part of
+// imex right-hand sides, AllenCahn_MPIFFT.py:83-85 / AllenCahn_2D_FFT.py): of the field the first pass READS (eval_f of a
+// given u) or of the field the last pass WRITES (the node value a sweep just solved for).  out == null: nothing.
+struct ReactEpi {
+    double* out;
+    int field, kind, nu;
+    double p0, p1;
+};
+__device__ __forceinline__ double react_value(double v, int kind, double p0, double p1, int nu) {
+#pragma clang fp contract(off)
+    if (kind == 1) {
+        double pw = 1.0;
+        for (int q = 0; q < nu; ++q) pw *= v;
+        return p0 * v * (1.0 - pw);
+    }
+    return p0 * v * (1.0 - v) * (1.0 - 2.0 * v) - p1 * v * (1.0 - v);
+}
+
 // 1-D problems: promote the real line to complex / take the real part back
 __global__ void k_promote(FieldPtrs p, cd* W, size_t N) {
     const int f = blockIdx.y;
@@ -26,7 +44,8 @@ __global__ void k_realpart(FieldPtrs p, const cd* W, size_t N) {
 // column ("two for one"), unpacked to the half spectra W[k][rest], k = 0..N/2.
 template <int N, int T>
 __global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_fwd(FieldPtrs p, cd* __restrict__ W, size_t fstride,
-                                                                      int rest, const cd* __restrict__ tw) {
+                                                                      int rest, const cd* __restrict__ tw,
+                                                                      ReactEpi epi = ReactEpi{nullptr, 0, 0, 0, 0.0, 0.0}) {
     constexpr int E = fft_elems(N), P = N / E;
     using LAY = LayStrided<N, T>;
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -39,6 +58,12 @@ __global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_fwd(FieldPtr
 #pragma unroll
     for (int i = 0; i < E; ++i)
         r[i] = ok ? *reinterpret_cast<const cd*>(in + (size_t)(j + i * P) * rest + 2 * (size_t)c) : cd{0.0, 0.0};
+    if (epi.out && (int)blockIdx.y == epi.field && ok) {  // reaction term of the field that is being read
+#pragma unroll
+        for (int i = 0; i < E; ++i)
+            *reinterpret_cast<cd*>(epi.out + (size_t)(j + i * P) * rest + 2 * (size_t)c) =
+                cd{react_value(r[i].x, epi.kind, epi.p0, epi.p1, epi.nu), react_value(r[i].y, epi.kind, epi.p0, epi.p1, epi.nu)};
+    }
     fft_line<N, -1, LAY>(r, j, col, lds, tw);
     // unpack: A[k] = (C[k] + conj C[N-k]) / 2, B[k] = (C[k] - conj C[N-k]) / (2i)
     cd A[E], B[E];
@@ -90,7 +115,8 @@ __global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_inv(FieldPtr
                                                                       size_t fstride, int rest,
                                                                       const cd* __restrict__ tw,
                                                                       unsigned long long* __restrict__ norms,
-                                                                      const cd* __restrict__ add = nullptr, int nfields = 1) {
+                                                                      const cd* __restrict__ add = nullptr, int nfields = 1,
+                                                                      ReactEpi epi = ReactEpi{nullptr, 0, 0, 0, 0.0, 0.0}) {
     constexpr int E = fft_elems(N), P = N / E;
     constexpr bool XWAVE = SDC_XWAVE && NORM && !STORE && P == 64 && !SDC_XINV_DIRECT;  // (norm-only pass, one wave per column)
     using LAY = LayStrided<N, T>;
@@ -236,6 +262,13 @@ __global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_inv(FieldPtr
 #pragma unroll
             for (int i = 0; i < E; ++i)
                 *reinterpret_cast<cd*>(out + (size_t)(j + i * P) * rest + 2 * (size_t)c) = r[i];
+            if (epi.out && by == epi.field) {  // reaction term of the field that is being written
+#pragma unroll
+                for (int i = 0; i < E; ++i)
+                    *reinterpret_cast<cd*>(epi.out + (size_t)(j + i * P) * rest + 2 * (size_t)c) =
+                        cd{react_value(r[i].x, epi.kind, epi.p0, epi.p1, epi.nu),
+                           react_value(r[i].y, epi.kind, epi.p0, epi.p1, epi.nu)};
+            }
         }
     }
 }

@@ -391,21 +391,11 @@ __global__ __launch_bounds__(256, EXPL ? 2 : 3) void k_stencil3d_res(StencilResA
 // pointwise explicit (reaction) terms of the Allen-Cahn problems
 //   kind 1: c * u * (1 - u^nu),  c = 1/eps^2          (AllenCahn_2D_FFT.py:140-141)
 //   kind 2: -2/eps^2 u (1-u)(1-2u) - 6 dw u (1-u)     (AllenCahn_MPIFFT.py:83-85)
+__device__ __forceinline__ double react_value(double v, int kind, double p0, double p1, int nu);  // kernels_fft.hpp
 __global__ void k_reaction(const double* __restrict__ u, double* __restrict__ out, size_t n, int kind, double p0,
                            double p1, int nu) {
-#pragma clang fp contract(off)
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const double v = u[i];
-        double r;
-        if (kind == 1) {
-            double pw = 1.0;
-            for (int q = 0; q < nu; ++q) pw *= v;
-            r = p0 * v * (1.0 - pw);
-        } else {
-            r = p0 * v * (1.0 - v) * (1.0 - 2.0 * v) - p1 * v * (1.0 - v);
-        }
-        out[i] = r;
-    }
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = react_value(u[i], kind, p0, p1, nu);
 }
 
 

@@ -279,8 +279,17 @@ static int eval_nodes_plain(sdc_ctx* c) {
     return run_stencil(c, M, in, oi, (c->expl_kind == SDC_EXPL_STENCIL || c->expl_kind == SDC_EXPL_FORCING) ? oe : nullptr, g);
 }
 
+// reaction term riding on a pass of the pipeline (see ReactEpi): where 0 = none, 1 = of the input field `field` (first pass),
+// 2 = of the output field `field` (last pass)
+struct ReactReq {
+    int where = 0, field = 0;
+    double* out = nullptr;
+};
 template <int N>
-static int fft_pipeline_n(sdc_ctx* c, int nf, const FieldPtrs& p, ZArgs& z) {
+static int fft_pipeline_n(sdc_ctx* c, int nf, const FieldPtrs& p, ZArgs& z, const ReactReq& rq = ReactReq()) {
+    const ReactEpi none{nullptr, 0, 0, 0, 0.0, 0.0};
+    const ReactEpi epi{rq.out, rq.field, c->react_kind, c->react_nu, c->react_p0, c->react_p1};
+    const bool can = c->ndim >= 2 && rq.out != nullptr;  // (1-D lines go through k_promote / k_realpart: the caller launches k_reaction)
     constexpr int E = fft_elems(N), P = N / E;
     constexpr int T = N >= 2048 ? 4 : (N == 1024 ? SDC_T1024 : 8);  // complex columns per strided tile (128-byte row segments up to N = 1024)
     const size_t lds_str = (size_t)LayStrided<N, T>::doubles(T) * sizeof(double);
@@ -304,7 +313,7 @@ static int fft_pipeline_n(sdc_ctx* c, int nf, const FieldPtrs& p, ZArgs& z) {
         {
             LaunchTimer lt(c, pname("fft_x_fwd", nfi));
             hipLaunchKernelGGL((k_fftx_fwd<N, T>), dim3(tiles, nfi), dim3(P * T), lds_str, c->stream, p, c->W, c->Nc,
-                               rest, c->tw);
+                               rest, c->tw, (can && rq.where == 1) ? epi : none);
         }
         if (c->ndim == 3) {
             LaunchTimer lt(c, pname("fft_y_fwd", nfi));
@@ -336,7 +345,7 @@ static int fft_pipeline_n(sdc_ctx* c, int nf, const FieldPtrs& p, ZArgs& z) {
         }
         LaunchTimer lt(c, pname("fft_x_inv", nf));
         hipLaunchKernelGGL((k_fftx_inv<N, T, false, true>), dim3(tiles, nf), dim3(P * T), lds_str, c->stream, p, c->W, c->Nc,
-                           rest, c->tw, nullptr);
+                           rest, c->tw, nullptr, nullptr, 1, (can && rq.where == 2) ? epi : none);
     }
     HIPCHK(c, hipGetLastError());
     return SDC_OK;
@@ -865,7 +874,7 @@ static int symbol_norm(sdc_ctx* c, const cd* src, unsigned long long* slot) {
 }
 
 // (I - alpha_f A) out_f = in_f + sum_{j<f} (cI[f][j] A + cE[f][j] B) out_j for f = 0..nf-1
-static int fft_pipeline(sdc_ctx* c, int nf, const FieldPtrs& p, ZArgs& z) {
+static int fft_pipeline(sdc_ctx* c, int nf, const FieldPtrs& p, ZArgs& z, const ReactReq& rq = ReactReq()) {
     if (!c->have_stencil[0]) return fail(c, SDC_ERR_STATE, "implicit operator not set (sdc_set_stencil)");
     if (!fourier_ok(c))
         return fail(c, SDC_ERR_UNSUPPORTED,
@@ -875,17 +884,17 @@ static int fft_pipeline(sdc_ctx* c, int nf, const FieldPtrs& p, ZArgs& z) {
         if (rw != SDC_OK) return rw;
     }
     switch (c->n) {
-        case 2: return fft_pipeline_n<2>(c, nf, p, z);
-        case 4: return fft_pipeline_n<4>(c, nf, p, z);
-        case 8: return fft_pipeline_n<8>(c, nf, p, z);
-        case 16: return fft_pipeline_n<16>(c, nf, p, z);
-        case 32: return fft_pipeline_n<32>(c, nf, p, z);
-        case 64: return fft_pipeline_n<64>(c, nf, p, z);
-        case 128: return fft_pipeline_n<128>(c, nf, p, z);
-        case 256: return fft_pipeline_n<256>(c, nf, p, z);
-        case 512: return fft_pipeline_n<512>(c, nf, p, z);
-        case 1024: return fft_pipeline_n<1024>(c, nf, p, z);
-        case 2048: return fft_pipeline_n<2048>(c, nf, p, z);
+        case 2: return fft_pipeline_n<2>(c, nf, p, z, rq);
+        case 4: return fft_pipeline_n<4>(c, nf, p, z, rq);
+        case 8: return fft_pipeline_n<8>(c, nf, p, z, rq);
+        case 16: return fft_pipeline_n<16>(c, nf, p, z, rq);
+        case 32: return fft_pipeline_n<32>(c, nf, p, z, rq);
+        case 64: return fft_pipeline_n<64>(c, nf, p, z, rq);
+        case 128: return fft_pipeline_n<128>(c, nf, p, z, rq);
+        case 256: return fft_pipeline_n<256>(c, nf, p, z, rq);
+        case 512: return fft_pipeline_n<512>(c, nf, p, z, rq);
+        case 1024: return fft_pipeline_n<1024>(c, nf, p, z, rq);
+        case 2048: return fft_pipeline_n<2048>(c, nf, p, z, rq);
     }
     return fail(c, SDC_ERR_UNSUPPORTED, "n = %d", c->n);
 }
@@ -1585,6 +1594,7 @@ int sdc_eval_f(sdc_ctx* c, const double* u, double g_t, double* f_impl, double* 
     if (!c->have_stencil[0]) return fail(c, SDC_ERR_STATE, "implicit operator not set (sdc_set_stencil)");
     if (c->expl_kind == SDC_EXPL_FORCING && !c->profile) return fail(c, SDC_ERR_STATE, "forcing profile not set");
     if (c->spectral_op || c->expl_kind == SDC_EXPL_REACTION) {
+        bool react_done = false;
         if (c->spectral_op) {
             FieldPtrs p;
             memset(&p, 0, sizeof p);
@@ -1593,7 +1603,13 @@ int sdc_eval_f(sdc_ctx* c, const double* u, double g_t, double* f_impl, double* 
             p.in[0] = u;
             p.out[0] = f_impl;
             z.apply = 1;
-            int rc0 = fft_pipeline(c, 1, p, z);
+            ReactReq rq;
+            if (f_expl && c->expl_kind == SDC_EXPL_REACTION && c->ndim >= 2 && f_expl != u) {
+                rq.where = 1;  // the explicit part is a function of the very values the first pass reads
+                rq.out = f_expl;
+                react_done = true;
+            }
+            int rc0 = fft_pipeline(c, 1, p, z, rq);
             if (rc0 != SDC_OK) return rc0;
         } else {
             const double* in1[1] = {u};
@@ -1601,7 +1617,7 @@ int sdc_eval_f(sdc_ctx* c, const double* u, double g_t, double* f_impl, double* 
             int rc0 = run_stencil(c, 1, in1, oi1, nullptr, nullptr);
             if (rc0 != SDC_OK) return rc0;
         }
-        if (f_expl && c->expl_kind == SDC_EXPL_REACTION) {
+        if (f_expl && c->expl_kind == SDC_EXPL_REACTION && !react_done) {
             LaunchTimer lt(c, "reaction");
             hipLaunchKernelGGL(k_reaction, dim3(grid_for(c->N, 256)), dim3(256), 0, c->stream, u, f_expl, c->N,
                                c->react_kind, c->react_p0, c->react_p1, c->react_nu);
@@ -1770,11 +1786,16 @@ static int sweep_nodewise(sdc_ctx* c, double dt, bool keep_guess = false) {
             p2.out[1] = c->F + ((size_t)(m + 1) * c->ncomp) * c->N;
             z2.alpha[0] = alpha;
             z2.dup = 1;
-            rc = fft_pipeline(c, 2, p2, z2);
+            if (imex && c->expl_kind != SDC_EXPL_REACTION)
+                return fail(c, SDC_ERR_UNSUPPORTED, "explicit part of a symbol-only operator must be a reaction term");
+            ReactReq rq2;
+            if (imex && c->ndim >= 2) {  // f_expl(u_m) leaves the last inverse pass together with u_m
+                rq2.where = 2;
+                rq2.out = c->F + ((size_t)(m + 1) * c->ncomp + 1) * c->N;
+            }
+            rc = fft_pipeline(c, 2, p2, z2, rq2);
             if (rc != SDC_OK) return rc;
-            if (imex) {
-                if (c->expl_kind != SDC_EXPL_REACTION)
-                    return fail(c, SDC_ERR_UNSUPPORTED, "explicit part of a symbol-only operator must be a reaction term");
+            if (imex && rq2.where == 0) {
                 LaunchTimer lt(c, "reaction");
                 hipLaunchKernelGGL(k_reaction, dim3(grid_for(c->N, 256)), dim3(256), 0, c->stream, um,
                                    c->F + ((size_t)(m + 1) * c->ncomp + 1) * c->N, c->N, c->react_kind, c->react_p0,

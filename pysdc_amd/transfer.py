@@ -63,9 +63,17 @@ class BaseTransfer:
 
     @classmethod
     def _mix(cls, matrix_row, fields):
-        """sum_m matrix_row[m] * fields[m], accumulated left to right like the reference's loops."""
-        acc = matrix_row[0] * fields[0]
-        for coeff, field in zip(matrix_row[1:], fields[1:]):
+        """sum_m matrix_row[m] * fields[m], accumulated left to right like the reference's loops.  Terms with a zero
+        coefficient are left out (x + 0*y = x for finite y); a row that is a unit vector - both levels share their
+        nodes - IS one of the fields (the callers only read the result)."""
+        terms = [(c, f) for c, f in zip(matrix_row, fields) if c != 0.0]
+        if not terms:
+            return 0.0 * fields[0]
+        (c0, f0), rest = terms[0], terms[1:]
+        if not rest and c0 == 1.0:
+            return f0
+        acc = c0 * f0
+        for coeff, field in rest:
             acc = cls._add_scaled(acc, coeff, field)
         return acc
 
@@ -84,6 +92,91 @@ class BaseTransfer:
         in_space = many(list(fine_fields)) if many else [self.space_transfer.restrict(x) for x in fine_fields]
         return [self._mix(self.Rcoll[n], in_space) for n in range(self.coarse.sweep.coll.num_nodes)]
 
+    # ---- batched device paths ------------------------------------------------------------------------------------------
+    # With the same nodes on both levels (Pcoll = Rcoll = identity), plain meshes in slabs and the table-driven space
+    # transfer, the node loops of restrict / prolong collapse into a few launches over fields that lie one behind the other:
+    # u[0..M] restricted straight into the coarse U slab, tau = R(Q_F f_F) - Q_G f_G as one difference into the TAU slab,
+    # the coarse-grid correction as one difference, one batched prolongation and one in-place addition over U[1..M].  Same
+    # arithmetic as the node-by-node code below (which remains for every other case), ~30 launches and the copies of the
+    # temporaries fewer per iteration.
+    def _batched(self):
+        sp = self.space_transfer
+        fine, coarse = self.fine, self.coarse
+        return (getattr(self, '_nodes_shared', None) is not False
+                and self.Pcoll.shape[0] == self.Pcoll.shape[1] and np.array_equal(self.Pcoll, np.eye(self.Pcoll.shape[0]))
+                and np.array_equal(self.Rcoll, np.eye(self.Rcoll.shape[0]))
+                and type(sp) is mesh_to_mesh and not sp.identity
+                and all(hasattr(L, 'engine') and hasattr(L, '_u') and not L._view_offset()
+                        and getattr(L.prob, 'dtype_u', None) is hip_mesh and getattr(L.prob, 'fused', False)
+                        for L in (fine, coarse))
+                and type(fine).__module__ == type(coarse).__module__ == 'pysdc_amd.level')
+
+    def _space_batch(self, key, nfields, src_ptr, dst_ptr):
+        sp = self.space_transfer
+        idx, w, width, (n_out, n_in) = sp._tab[key]
+        Lb.check(Lb.load().sdc_transfer_apply_batch(None, nfields, sp.ndim, n_out, n_in, width, idx.ptr, w.ptr, src_ptr,
+                                                    dst_ptr), None)
+
+    def _restrict_batched(self):
+        fine, coarse = self.fine, self.coarse
+        M = fine.sweep.coll.num_nodes
+        ef, ec = fine.engine, coarse.engine
+        nc = ec.N
+        ef.ptr(Lb.SLOT_U, 1)                      # (node fields that were put off are stored now)
+        ec.ptr(Lb.SLOT_U, 1)
+        coarse._lists()
+        self._space_batch('R', M + 1, ef.ptr(Lb.SLOT_U, 0), ec.ptr(Lb.SLOT_U, 0))
+        coarse._u.mark(range(M + 1))
+        coarse._touched(Lb.SLOT_U, 0)
+        coarse._touched(Lb.SLOT_U, 1)
+        self._refresh_f(coarse, 0, coarse.time)
+        for n in range(1, M + 1):
+            self._refresh_f(coarse, n, coarse.time + coarse.dt * coarse.sweep.coll.nodes[n - 1])
+        quad_coarse = coarse.sweep.integrate()    # M fields, one behind the other
+        quad_fine = fine.sweep.integrate()
+        on_coarse = hip_mesh(((M * nc,), None, np.dtype('float64')), val=None)
+        self._space_batch('R', M, quad_fine[0].ptr, on_coarse.ptr)
+        if coarse.tau[0] is None:                 # (sets the slab up and tells the engine)
+            coarse._activate_tau()
+        tau = hip_mesh.view(ec.ptr(Lb.SLOT_TAU, 0), (M * nc,), keep=ec)
+        qc = hip_mesh.view(quad_coarse[0].ptr, (M * nc,), keep=quad_coarse[0])
+        tau._axpby(1.0, on_coarse, -1.0, qc, tau)
+        if fine.tau[0] is not None:               # a correction the fine level itself received from above travels down too
+            carried = hip_mesh(((M * nc,), None, np.dtype('float64')), val=None)
+            self._space_batch('R', M, ef.ptr(Lb.SLOT_TAU, 0), carried.ptr)
+            tau._axpby(1.0, tau, 1.0, carried, tau)
+        coarse._tau.mark(range(M))
+        coarse._touched(Lb.SLOT_TAU, 0)
+        # the snapshot the coarse-grid correction is measured against: one buffer each for u and f
+        imex = getattr(coarse.prob, 'ncomp', 1) == 2
+        uold = hip_mesh(((M * nc,), None, np.dtype('float64')), val=None)
+        uold._axpby(1.0, hip_mesh.view(ec.ptr(Lb.SLOT_U, 1), (M * nc,), keep=ec), 0.0, None, uold)
+        shape = coarse._field_shape()
+        for n in range(1, M + 1):
+            coarse.uold[n] = hip_mesh.view(uold.ptr + 8 * (n - 1) * nc, shape, keep=uold)
+            coarse.fold[n] = coarse.prob.dtype_f(coarse.f[n])
+        self._uold_batch = uold
+        coarse.status.unlocked = True
+
+    def _prolong_batched(self):
+        fine, coarse = self.fine, self.coarse
+        M = fine.sweep.coll.num_nodes
+        ef, ec = fine.engine, coarse.engine
+        nc, nf = ec.N, ef.N
+        uold = getattr(self, '_uold_batch', None)
+        if uold is None or any(coarse.uold[n] is None or coarse.uold[n].ptr != uold.ptr + 8 * (n - 1) * nc for n in range(1, M + 1)):
+            return False
+        diff = hip_mesh(((M * nc,), None, np.dtype('float64')), val=None)
+        diff._axpby(1.0, hip_mesh.view(ec.ptr(Lb.SLOT_U, 1), (M * nc,), keep=ec), -1.0, uold, diff)
+        delta = hip_mesh(((M * nf,), None, np.dtype('float64')), val=None)
+        self._space_batch('P', M, diff.ptr, delta.ptr)
+        nodes = hip_mesh.view(ef.ptr(Lb.SLOT_U, 1), (M * nf,), keep=ef)
+        nodes._axpby(1.0, nodes, 1.0, delta, nodes)
+        fine._touched(Lb.SLOT_U, 1)
+        for n in range(1, M + 1):
+            self._refresh_f(fine, n, fine.time + fine.dt * fine.sweep.coll.nodes[n - 1])
+        return True
+
     def restrict(self):
         """FAS restriction (base_transfer.py:93-168): coarse node values R u_F, coarse right-hand sides
         re-evaluated there, tau = R(Q_F f_F) - Q_G f_G (+ R tau_F), and the snapshot uold / fold that the
@@ -93,6 +186,9 @@ class BaseTransfer:
             raise UnlockError('fine level is still locked, cannot use data from there')
         Mf, Mc = fine.sweep.coll.num_nodes, coarse.sweep.coll.num_nodes
         cprob = coarse.prob
+        self._uold_batch = None
+        if self._batched() and all(fine.u[m] is not None for m in range(Mf + 1)):
+            return self._restrict_batched()
 
         coarse.u[0] = self.space_transfer.restrict(fine.u[0])
         for n, value in enumerate(self._to_coarse_nodes([fine.u[m] for m in range(1, Mf + 1)]), start=1):
@@ -135,6 +231,8 @@ class BaseTransfer:
         if not coarse.status.unlocked:
             raise UnlockError('coarse level is still locked, cannot use data from there')
         Mf, Mc = fine.sweep.coll.num_nodes, coarse.sweep.coll.num_nodes
+        if self._batched() and self._prolong_batched():
+            return
         delta = self._coarse_correction(coarse.u, coarse.uold)
         for n in range(1, Mf + 1):
             for m in range(Mc):
