@@ -47,6 +47,12 @@ __device__ __forceinline__ bool vdp_newton(double& x1, double& x2, double r0, do
 // LAZYF: the right-hand sides of the old iterate are recomputed from its node values (read anyway as Newton
 // guesses; f costs five flops, the same formula gives the same bits) and the new ones are not stored - the F slab
 // is brought up to date on demand (sdc_materialize).  Halves the bytes of the sweep.
+#ifndef SDC_VDP_LDS_COEFFS
+#define SDC_VDP_LDS_COEFFS 0  // 1: quadrature coefficients from LDS - the compiler then holds all 50 in VGPRs (249): worse
+#endif
+#ifndef SDC_VDP_KEEP_NODES
+#define SDC_VDP_KEEP_NODES 1  // 0: node values re-read instead of held (150 instead of 160 VGPRs; measured 0.757 vs 0.736 ms)
+#endif
 #ifndef SDC_VDP_WAVES
 #define SDC_VDP_WAVES 0  // > 0: waves per SIMD the sweep kernel is compiled for (register budget 512 / waves)
 #endif
@@ -60,20 +66,48 @@ __global__ VDP_BOUNDS void k_vdp_sweep(VdpSweepArgs a) {
 #pragma clang fp contract(off)
     unsigned long long newton = 0, rhs = 0, failed = 0;
     const size_t T = a.T, N = 2 * a.T;
+#if SDC_VDP_LDS_COEFFS
+    // the 2 M^2 quadrature coefficients from LDS (same-address reads: broadcasts) instead of ~100 scalar registers that
+    // would be spilled into vector registers
+    __shared__ double sQ[M][M], sQI[M][M];
+    if (threadIdx.x < M * M) {
+        sQ[threadIdx.x / M][threadIdx.x % M] = a.Q[threadIdx.x / M][threadIdx.x % M];
+        sQI[threadIdx.x / M][threadIdx.x % M] = a.QI[threadIdx.x / M][threadIdx.x % M];
+    }
+    __syncthreads();
+#define VQ(m, j) sQ[m][j]
+#define VQI(m, j) sQI[m][j]
+#else
+#define VQ(m, j) a.Q[m][j]
+#define VQI(m, j) a.QI[m][j]
+#endif
     double nmax[M];
 #pragma unroll
     for (int m = 0; m < M; ++m) nmax[m] = 0.0;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < T; i += (size_t)gridDim.x * blockDim.x) {
         const double mu = a.mu;
         const double u00 = a.U[i], u01 = a.U[T + i];
-        double f0[M], f1[M], g0[M], g1[M], un0[M], un1[M];
+        // Live state per trajectory: the right-hand sides of all nodes (old ones, replaced node by node by the new ones)
+        // and the gathered sums - 4 M doubles.  Node values are NOT kept: the old one of node m is read again when its
+        // Newton iteration starts (as the guess), the new ones are read back for the residual (this thread wrote them:
+        // L2 hits) - 2 M doubles fewer in registers than holding them.  Measured round 3: no faster (0.757 against 0.736 ms
+        // per sweep of 1e7 trajectories), and compiled for 4 waves per SIMD it still spills (0.95 ms): occupancy is not
+        // what this kernel waits for.  SDC_VDP_KEEP_NODES=1 (default) holds them.
+        double f0[M], f1[M], g0[M], g1[M];
+#if SDC_VDP_KEEP_NODES
+        double un0[M], un1[M];
+#endif
 #pragma unroll
         for (int m = 0; m < M; ++m) {
             if (LAZYF) {
-                un0[m] = a.U[(size_t)(m + 1) * N + i];  // old node value: guess below, f here
-                un1[m] = a.U[(size_t)(m + 1) * N + T + i];
-                f0[m] = un1[m];
-                f1[m] = mu * (1 - un0[m] * un0[m]) * un1[m] - un0[m];
+                const double o0 = a.U[(size_t)(m + 1) * N + i];  // old node value: f here, guess below
+                const double o1 = a.U[(size_t)(m + 1) * N + T + i];
+#if SDC_VDP_KEEP_NODES
+                un0[m] = o0;
+                un1[m] = o1;
+#endif
+                f0[m] = o1;
+                f1[m] = mu * (1 - o0 * o0) * o1 - o0;
             } else {
                 f0[m] = a.F[(size_t)(m + 1) * N + i];
                 f1[m] = a.F[(size_t)(m + 1) * N + T + i];
@@ -84,13 +118,13 @@ __global__ VDP_BOUNDS void k_vdp_sweep(VdpSweepArgs a) {
             double s0 = 0.0, s1 = 0.0;
 #pragma unroll
             for (int j = 0; j < M; ++j) {
-                s0 += a.Q[m][j] * f0[j];
-                s1 += a.Q[m][j] * f1[j];
+                s0 += VQ(m, j) * f0[j];
+                s1 += VQ(m, j) * f1[j];
             }
 #pragma unroll
             for (int j = 0; j < M; ++j) {
-                s0 -= a.QI[m][j] * f0[j];
-                s1 -= a.QI[m][j] * f1[j];
+                s0 -= VQI(m, j) * f0[j];
+                s1 -= VQI(m, j) * f1[j];
             }
             g0[m] = s0 + u00;
             g1[m] = s1 + u01;
@@ -105,13 +139,18 @@ __global__ VDP_BOUNDS void k_vdp_sweep(VdpSweepArgs a) {
 #pragma unroll
             for (int j = 0; j < M; ++j) {
                 if (j < m) {
-                    r0 += a.QI[m][j] * f0[j];
-                    r1 += a.QI[m][j] * f1[j];
+                    r0 += VQI(m, j) * f0[j];
+                    r1 += VQI(m, j) * f1[j];
                 }
             }
-            const double h = a.QI[m][m];
+            const double h = VQI(m, m);
+#if SDC_VDP_KEEP_NODES
             double x1 = LAZYF ? un0[m] : a.U[(size_t)(m + 1) * N + i];
             double x2 = LAZYF ? un1[m] : a.U[(size_t)(m + 1) * N + T + i];
+#else
+            double x1 = a.U[(size_t)(m + 1) * N + i];
+            double x2 = a.U[(size_t)(m + 1) * N + T + i];
+#endif
             if (h == 0.0) {
                 x1 = r0;
                 x2 = r1;
@@ -120,8 +159,10 @@ __global__ VDP_BOUNDS void k_vdp_sweep(VdpSweepArgs a) {
             }
             a.U[(size_t)(m + 1) * N + i] = x1;
             a.U[(size_t)(m + 1) * N + T + i] = x2;
+#if SDC_VDP_KEEP_NODES
             un0[m] = x1;
             un1[m] = x2;
+#endif
             f0[m] = x2;
             f1[m] = mu * (1 - x1 * x1) * x2 - x1;
             if (!LAZYF) {
@@ -131,17 +172,23 @@ __global__ VDP_BOUNDS void k_vdp_sweep(VdpSweepArgs a) {
             rhs += 1;
         }
         if (a.norms) {
-            // collocation residual of the new iterate (core/sweeper.py:186-199), all values still in registers
+            // collocation residual of the new iterate (core/sweeper.py:186-199): the right-hand sides are in registers,
+            // the node values are read back
 #pragma unroll
             for (int m = 0; m < M; ++m) {
                 double s0 = 0.0, s1 = 0.0;
 #pragma unroll
                 for (int j = 0; j < M; ++j) {
-                    s0 += a.Q[m][j] * f0[j];
-                    s1 += a.Q[m][j] * f1[j];
+                    s0 += VQ(m, j) * f0[j];
+                    s1 += VQ(m, j) * f1[j];
                 }
+#if SDC_VDP_KEEP_NODES
                 s0 += u00 - un0[m];
                 s1 += u01 - un1[m];
+#else
+                s0 += u00 - a.U[(size_t)(m + 1) * N + i];
+                s1 += u01 - a.U[(size_t)(m + 1) * N + T + i];
+#endif
                 if (a.tau) {
                     s0 += a.tau[(size_t)m * N + i];
                     s1 += a.tau[(size_t)m * N + T + i];
@@ -169,6 +216,8 @@ __global__ VDP_BOUNDS void k_vdp_sweep(VdpSweepArgs a) {
             if ((threadIdx.x & 63) == 0) atomic_max_abs(a.norms + m, v);
         }
     }
+#undef VQ
+#undef VQI
 }
 
 // ------------------------------------------------------------------------------------------------------
