@@ -567,6 +567,12 @@ def launch_ranks(args, argv):
                     os.killpg(p.pid, 9)
                 except OSError:
                     pass
+        import glob
+        for f in glob.glob(f'/dev/shm/sdcmi.{procs[0].pid}-*'):   # mailboxes of the shared-memory wire a killed rank left behind
+            try:
+                os.unlink(f)
+            except OSError:
+                pass
     line = None
     for ln in (out0 or '').splitlines():
         if ln.startswith('{'):

@@ -279,6 +279,14 @@ struct ShmWire : Wire {
     }
     int group_end(sdc_ctx* c) override {
         int rc = SDC_OK;
+        // single-slot boxes: one message per ordered pair and group (what every pattern above it sends); a second one would
+        // wait for a receiver that only takes messages after its own sends
+        for (size_t i = 0; i < ops.size(); ++i)
+            for (size_t k = i + 1; k < ops.size(); ++k)
+                if (ops[i].is_send == ops[k].is_send && ops[i].peer == ops[k].peer) {
+                    ops.clear();
+                    return fail(c, SDC_ERR_COMM, "shm wire: two messages for one peer in one group");
+                }
         for (const Op& o : ops)
             if (o.is_send && (rc = put(c, o.buf, o.n, o.peer)) != SDC_OK) return rc;
         if ((rc = drain(c)) != SDC_OK) return rc;  // the data is in the boxes: tell the receivers
