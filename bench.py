@@ -683,6 +683,18 @@ def main():
         import datetime
 
         os.environ.setdefault('SDC_COMM_TIMEOUT', '300')
+        # a watchdog of the rank's own (under a launcher that has none): a job stuck in a collective ends with a JSON error
+        # line from rank 0 and a non-zero exit code instead of hanging until somebody else's limit
+        import threading
+
+        def give_up():
+            if rank == 0:
+                print(json.dumps({'error': f'rank 0: job exceeded --job-timeout {args.job_timeout:.0f} s', 'n_gpus': world}), flush=True)
+            os._exit(4)
+
+        watchdog = threading.Timer(args.job_timeout, give_up)
+        watchdog.daemon = True
+        watchdog.start()
         try:
             # the process group only carries host data (rendezvous, unique id, 1-byte flags, counts): gloo; the state
             # vectors travel through the C-ABI communicator (RCCL or the shared-memory wire)
@@ -706,6 +718,7 @@ def main():
                 out['cpu_baseline'] = {'error': repr(e)}
         print(json.dumps(out), flush=True)
     if use_dist:
+        watchdog.cancel()
         dist.destroy_process_group()
 
 
