@@ -339,8 +339,9 @@ def test_time_parallel_skip_residual_computation(name, fname, size):
         assert out[r]['overlap']
 
 
-@pytest.mark.parametrize('nranks,M,size', [(3, 3, 64), (8, 5, 64), (4, 5, 256)])
-def test_time_parallel_controller_64cubed_matches_serial_emulation(nranks, M, size):
+@pytest.mark.parametrize('nranks,M,size,prob', [(3, 3, 64, 'heat_unforced'), (8, 5, 64, 'heat_unforced'), (4, 5, 256, 'heat_unforced'),
+                                                 (3, 5, 64, 'advdiff'), (4, 3, 128, 'advection')])
+def test_time_parallel_controller_64cubed_matches_serial_emulation(nranks, M, size, prob):
     """three / eight ranks on 64^3 and four on 256^3 (the fused spectral sweep kernel, norm passes, kept residual
     fields; at 256^3 the kernels run long enough for ordering mistakes between the streams to show) through
     controller_dist with the in-process stand-in, against controller_nonMPI emulating the processes; two blocks, the
@@ -355,8 +356,15 @@ def test_time_parallel_controller_64cubed_matches_serial_emulation(nranks, M, si
     from pysdc_amd.stats import get_sorted
     from tests import _fake_dist as FD
 
-    meta = dict(prob='heat_unforced', prob_params=dict(nvars=[n, n, n], nu=0.1, freq=2), sweeper='generic_implicit',
-                sweeper_params=dict(num_nodes=M, quad_type='RADAU-RIGHT', QI='IE'), level_params=dict(dt=2e-3, restol=-1),
+    # (also the IMEX sweeper on advection-diffusion - complex explicit symbol, iterates stored - and implicit advection:
+    # the same spectra-on-the-wire hand-over and residual update by one more field through the inverse passes)
+    pp = {'heat_unforced': dict(nvars=[n, n, n], nu=0.1, freq=2), 'advdiff': dict(nvars=[n, n, n], nu=0.02, c=1.0, freq=2),
+          'advection': dict(nvars=[n, n, n], c=1.0, freq=2)}[prob]
+    sw = dict(num_nodes=M, quad_type='RADAU-RIGHT', QI='IE')
+    if prob == 'advdiff':
+        sw['QE'] = 'EE'
+    meta = dict(prob=prob, prob_params=pp, sweeper='imex_1st_order' if prob == 'advdiff' else 'generic_implicit',
+                sweeper_params=sw, level_params=dict(dt=2e-3, restol=-1),
                 maxiter=3, controller_params={}, t0=0.0, Tend=2e-3 * (2 * nranks - nranks // 2))
     from pysdc_amd.synth import init_field
     from tests.test_gpu_plugin import description_from
