@@ -207,3 +207,92 @@ def test_integrate_vs_golden_node_values(fname, name):
                 ref += dt * case['coll_Qmat'][m + 1, j] * fsum[j]
             assert rel_err(got[m], ref) < TOL, (k, m)
     e.close()
+
+
+@pytest.mark.parametrize('virtual', [8, 0])
+def test_put_off_end_value_survives_a_predictor(virtual):
+    """sweep, compute_end_point (put off while sweeps stay in Fourier space), predict, THEN read the end value: the
+    reference's predict leaves L.uend alone (core/sweeper.py:125-162), so the value of the sweep must come out - the
+    engine has to transform it back before the predictor drops the iterate it belongs to"""
+    n, M, dt = 64, 3, 1e-2
+    u0 = np.random.default_rng(4).standard_normal((n, n, n))
+    ends = []
+    for deferred in (True, False):
+        e = G.engine_for('heat_unforced', dict(nvars=(n, n, n), nu=0.1), M)
+        from pysdc_amd.coeffs import CollBase, QDELTA_GENERATORS
+
+        c = CollBase(M, 0, 1, 'LEGENDRE', 'RADAU-RIGHT')
+        qi = np.zeros_like(c.Qmat)
+        qi[1:, 1:] = QDELTA_GENERATORS['LU'](qGen=c.generator, tLeft=0).genCoeffs()
+        e.set_coeffs(c.Qmat, qi, None, c.nodes, c.weights)
+        e.set_deferred(deferred)
+        e.set_virtual_sweeps(virtual)
+        e.upload(L.SLOT_U, 0, u0)
+        e.predict(0.0, dt)
+        e.sweep(0.0, dt)
+        e.sweep(0.0, dt)
+        e.end_point(dt, False)
+        e.predict(0.0, dt)                     # drops the iterate; UEND has not been read yet
+        ends.append(e.download(L.SLOT_UEND))
+        e.close()
+    assert rel_err(ends[0], ends[1]) < 1e-12 and np.max(np.abs(ends[1] - u0)) > 1e-3
+
+
+@pytest.mark.parametrize('nvars', [(64, 64, 64), (128, 128)])
+def test_start_value_replaced_as_a_spectrum_equals_replaced_as_a_field(nvars):
+    """sdc_replace_u0_spectrum (time-parallel hand-over that carries spectra): node norms of the residual against the new
+    start value - from one more field through the inverse passes - and the sweeps that follow equal those of an engine
+    that was handed the same value as a field (sdc_replace_u0 after kept residual fields)"""
+    import torch
+
+    M, dt = 5, 2e-3
+    rng = np.random.default_rng(9)
+    u0, v = rng.standard_normal(nvars), rng.standard_normal(nvars)
+
+    def engine(spectral):
+        from pysdc_amd.coeffs import CollBase, QDELTA_GENERATORS
+
+        e = G.engine_for('heat_unforced', dict(nvars=nvars, nu=0.1), M)
+        c = CollBase(M, 0, 1, 'LEGENDRE', 'RADAU-RIGHT')
+        qi = np.zeros_like(c.Qmat)
+        qi[1:, 1:] = QDELTA_GENERATORS['IE'](qGen=c.generator, tLeft=0).genCoeffs()
+        e.set_coeffs(c.Qmat, qi, None, c.nodes, c.weights)
+        e.set_virtual_sweeps(0)
+        e.set_early_end_point(True)
+        if spectral:
+            L.check(e.lib.sdc_set_wire_spectral(e.ctx, 1), e.ctx)
+        else:
+            e.set_keep_residual_fields(True)
+        e.upload(L.SLOT_U, 0, u0)
+        e.predict(0.0, dt)
+        e.sweep(0.0, dt)
+        e.residual(dt)
+        return e
+
+    a, b = engine(True), engine(False)
+    # the new start value: as a field for b; its spectrum for a (made by a third engine's forward transform = end spectrum)
+    b.upload(L.SLOT_UEND, 0, v)
+    b.replace_u0(b.ptr(L.SLOT_UEND))
+    src = G.engine_for('heat_unforced', dict(nvars=nvars, nu=0.1), M)
+    src.set_coeffs(*[np.zeros((M + 1, M + 1))] * 2, None, np.ones(M), np.ones(M))
+    src.upload(L.SLOT_UEND, 0, v)
+    nspec = 2 * (nvars[0] // 2 + 1) * int(np.prod(nvars[1:]))
+    from pysdc_amd.hip_mesh import _CAI
+
+    spec = torch.as_tensor(_CAI(src.end_spectrum(), nspec, src), device='cuda')
+    torch.as_tensor(_CAI(a.spectrum_inbox(), nspec, a), device='cuda').copy_(spec)
+    torch.cuda.synchronize()
+    a.replace_u0_spectrum()
+    ra, na = a.residual(dt)
+    rb, nb = b.residual(dt)
+    np.testing.assert_allclose(na, nb, rtol=1e-9)
+    for k in range(2):
+        a.sweep(0.0, dt)
+        b.sweep(0.0, dt)
+        np.testing.assert_allclose(a.residual(dt)[1], b.residual(dt)[1], rtol=1e-8)
+    a.end_point(dt, False)
+    b.end_point(dt, False)
+    assert rel_err(a.download(L.SLOT_UEND), b.download(L.SLOT_UEND)) < 1e-11
+    assert rel_err(a.download(L.SLOT_U, 0), v) < 1e-12          # U[0] itself, produced from the spectrum on demand
+    for e in (a, b, src):
+        e.close()
