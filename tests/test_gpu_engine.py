@@ -296,3 +296,46 @@ def test_start_value_replaced_as_a_spectrum_equals_replaced_as_a_field(nvars):
     assert rel_err(a.download(L.SLOT_U, 0), v) < 1e-12          # U[0] itself, produced from the spectrum on demand
     for e in (a, b, src):
         e.close()
+
+
+def test_error_paths_of_the_round_3_entry_points():
+    """new C-ABI calls fail loudly with the reference's exception types: no communicator, a level that does not sweep in
+    Fourier space asked for the spectral hand-over, a banded operator that does not fit, an unknown solver"""
+    from pysdc_amd.comm import DeviceComm, shm_unique_id
+    from pysdc_amd.engine import SweepEngine
+    from pysdc_amd.errors import CommunicationError, ParameterError, UnlockError
+
+    e = SweepEngine((16, 16), 3)
+    for call in (lambda: L.check(e.lib.sdc_comm_handover_post(e.ctx, 2), e.ctx),
+                 lambda: L.check(e.lib.sdc_comm_exchange(e.ctx, 1, -1), e.ctx),
+                 lambda: L.check(e.lib.sdc_comm_bcast_end_spectrum(e.ctx, 0), e.ctx)):
+        with pytest.raises(UnlockError):           # SDC_ERR_STATE: no communicator (sdc_comm_init)
+            call()
+    with pytest.raises(UnlockError):               # no stencil set: not a level that sweeps in Fourier space
+        L.check(e.lib.sdc_set_wire_spectral(e.ctx, 1), e.ctx)
+    with pytest.raises(UnlockError):
+        e.replace_u0_spectrum()                    # no spectrum inbox
+    with pytest.raises(ParameterError):
+        e.set_banded_operator(np.zeros((17, 3), dtype=np.int32), np.zeros((17, 3)))   # 17 interior points > 16 per axis
+    with pytest.raises(ParameterError):
+        e.set_banded_operator(np.full((15, 3), 15, dtype=np.int32), np.zeros((15, 3)))  # column index out of range
+    with pytest.raises(KeyError):
+        e.set_solver('BiCGStab')
+    comm = DeviceComm(e, 1, 0, uid=shm_unique_id())
+    with pytest.raises(ParameterError):
+        comm.handover_post(2)                      # more active ranks than the communicator has
+    with pytest.raises(ParameterError):
+        comm.exchange(send_to=3)
+    assert comm.info() == dict(rank=0, size=1, two_hop_handovers=0, mesh_broadcasts=0, wire='shm')
+    comm.close()
+    with pytest.raises(CommunicationError):        # a peer that never shows up: the mailbox wire times out instead of hanging
+        import os
+
+        os.environ['SDC_COMM_TIMEOUT'] = '0.3'
+        try:
+            lonely = DeviceComm(e, 2, 1, uid=shm_unique_id())
+            lonely.exchange(recv_from=0)
+        finally:
+            del os.environ['SDC_COMM_TIMEOUT']
+    lonely.close()
+    e.close()
