@@ -678,6 +678,7 @@ def main():
         # one node by contract: rendezvous and the gloo side group (1-byte flags) on the loopback interface - the container's
         # host name may not resolve, which gloo would otherwise try
         os.environ.setdefault('GLOO_SOCKET_IFNAME', 'lo')
+        os.environ.setdefault('NCCL_SOCKET_IFNAME', 'lo')   # (RCCL's bootstrap: the unique id carries an address of this interface)
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29531')
         import datetime
