@@ -17,6 +17,7 @@ on the device and are resident in HBM before the timed region.  Prints ONE JSON 
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -144,8 +145,16 @@ def cpu_baseline(M, dt_ref_n, target_n=1024, nsweeps=4, max_workers=32):
     raw_one = 1.0 / r64['seconds']
     per_sweep_dof_64 = r64['seconds'] / (nsweeps * 64**3)
     per_sweep_dof_128 = r128['seconds'] / (1 * 128**3)
+    # the two one-core samples say how the cost per DOF grows with the grid (CG iterations per solve grow with n): continued
+    # as a power law to the target size it gives a second, less flattering figure beside the linear-in-DOF `value`
+    growth = per_sweep_dof_128 / per_sweep_dof_64
+    alpha = math.log(max(growth, 1.0)) / math.log(2.0)
+    trend = (target_n / 64.0) ** alpha
     return {
         'value': raw_all * scale, 'unit': 'time-steps/s', 'cores': workers, 'kind': 'port',
+        'value_with_measured_growth': raw_all * scale / trend,
+        'growth_note': f'cost per DOF x {growth:.2f} from 64^3 to 128^3 (one sweep each, one core) = n^{alpha:.2f}; continued to '
+                       f'{target_n}^3: x {trend:.1f} on top of the linear-in-DOF scaling of `value`',
         'sample': f'{workers} concurrent copies (host has {ncpu} cores) of: heat 3-D 64^3 f64, M={M}, 1 time step = '
                   f'{nsweeps} sweeps, CG rtol 1e-12 ({r64["cg_iterations"]} CG iterations); slowest copy {slowest:.1f} s '
                   f'(+{r64["setup_seconds"]:.1f} s matrix setup each, not counted; {wall:.0f} s wall incl. start-up); value = '
