@@ -54,6 +54,10 @@ def _kernel_bytes(name, n, M, ncomp=1):
         # iterate recomputed from the transform of u0 (virtual sweeps): S0 in, the residual's transformed lines out
         **{f'spec_z_res_v{r}': (1 + nf) * spec for r in ('0', '1', '2', '3', '4', '5', '6', '7+')},
         **{f'spec_z_v{r}': (1 + nf) * spec for r in ('0', '1', '2', '3', '4', '5', '6', '7+')},   # (the iterate itself out)
+        # long runs of sweeps: the real node multipliers of a mode pair (nf doubles per two modes) are read from a table,
+        # advanced by one sweep and written back instead of being recomputed by replaying every earlier sweep
+        'spec_z_res_tab': (1 + nf) * spec + nf * spec / 2,
+        'spec_z_tab': (1 + nf) * spec + nf * spec / 2,
         'spec_store': (1 + nf) * spec,                      # ... and its transforms written out when somebody needs them
         'spec_store_last': 2 * spec,                        # (only the last node's: the end value / next start value)
         'fft_x_norm': nf * spec,
@@ -294,6 +298,8 @@ def run_workload(args, world, rank, use_dist, with_stream_reference=True):
     eng.set_deferred(not args.eager_fields)
     if args.virtual_sweeps is not None and hasattr(eng, 'set_virtual_sweeps'):
         eng.set_virtual_sweeps(args.virtual_sweeps)
+    if args.multiplier_table is not None and hasattr(eng, 'set_multiplier_table'):
+        eng.set_multiplier_table(args.multiplier_table)
     if getattr(args, 'pipeline_groups', 0) > 1:
         eng.set_pipeline_groups(args.pipeline_groups)
     if args.workload in ('vdp', 'allencahn'):
@@ -395,7 +401,7 @@ def run_workload(args, world, rank, use_dist, with_stream_reference=True):
                     'ms_per_launch': dom[1][0] / dom[1][1],
                     'stream_reference_gbs': stream_reference(torch, eng) if with_stream_reference else None}
         in_sweep = ('gather', 'fft_x_fwd', 'fft_y_fwd', 'fft_z_fwd', 'fft_z_solve', 'spec_point', 'spec_point_res', 'spec_point_only', 'spec_z', 'spec_z_res', 'spec_z_spread', 'spec_z_res_spread',
-                    'spec_z_res_v0', 'spec_z_res_v1', 'spec_z_res_v2', 'spec_z_res_v3', 'spec_z_res_v4', 'spec_z_res_v5', 'spec_z_res_v6', 'spec_z_res_v7+', 'spec_store',
+                    'spec_z_res_v0', 'spec_z_res_v1', 'spec_z_res_v2', 'spec_z_res_v3', 'spec_z_res_v4', 'spec_z_res_v5', 'spec_z_res_v6', 'spec_z_res_v7+', 'spec_store', 'spec_z_res_tab', 'spec_z_tab',
                     'spec_z_v0', 'spec_z_v1', 'spec_z_v2', 'spec_z_v3', 'spec_z_v4', 'spec_z_v5', 'spec_z_v6', 'spec_z_v7+',
                     'fft_x_norm', 'fft_x_inv_norm',
                     'fft_z_inv', 'fft_y_inv',
@@ -632,6 +638,9 @@ def main():
     ap.add_argument('--virtual-sweeps', type=int, default=None,
                     help='sdc_set_virtual_sweeps: sweeps per step whose iterate is recomputed from the transform of u0 instead '
                          'of stored (0: every sweep stores its iterate, the round-1 data flow; default: the library\'s)')
+    ap.add_argument('--multiplier-table', type=int, default=None,
+                    help='sdc_set_multiplier_table: first sweep of a step that takes the node multipliers of a mode pair from '
+                         'the table instead of replaying the earlier sweeps (0: never; default: the engine\'s, 8)')
     ap.add_argument('--pipeline-groups', type=int, default=0,
                     help='sdc_set_pipeline_groups: issue the z / y passes of a sweep in this many groups of kx planes, the y '
                          'pass of a group on a second stream (launches that share the GPU have no durations of their own: the '

@@ -121,6 +121,14 @@ int sdc_set_skip_residual(sdc_ctx* ctx, int on);
  * u[0], other coefficients) has it written out first.  max_sweeps: sweeps per step that may be repeated that way before
  * the iterate is stored after all (arithmetic grows with each; default 16), 0: every sweep stores its iterate. */
 int sdc_set_virtual_sweeps(sdc_ctx* ctx, int max_sweeps);
+/* Long runs of such sweeps (a step iterated to a residual tolerance: restol of the level, core/level.py:16-21, tens of
+ * sweeps).  For a real symbol the iterate of a mode is the start value times M real node multipliers that the modes kz and
+ * N - kz of a line share; from the from_sweep-th sweep of a step on they are kept in a table (M doubles per mode pair, about
+ * a quarter of one node's spectrum per node), read, advanced by one sweep and written back by every launch instead of being
+ * recomputed from 1 - constant cost per sweep where replaying grows with every sweep, and no switch to stored iterates
+ * at max_sweeps.  Same arithmetic in the same order as the replay.  Used when the replayed sweeps get that far
+ * (max_sweeps > from_sweep) and the table can be allocated; from_sweep 0: never (default 8: where one more replayed sweep costs what the table traffic does at 1024^3). */
+int sdc_set_multiplier_table(sdc_ctx* ctx, int from_sweep);
 /* A Fourier-space sweep that only delivers residual norms is three launches: the pointwise sweep fused with the inverse pass
  * along the contiguous axis (bound by its f64 arithmetic), the in-place pass along the middle axis (bound by memory), the
  * norm-only pass along the first axis.  With groups > 1 the first two are issued per group of kx planes, the middle-axis pass

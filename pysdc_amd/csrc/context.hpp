@@ -80,6 +80,11 @@ struct sdc_ctx {
     // needs it (store_spectra).  sl_stored: the last node's spectrum has been written to SL all the same.
     int spec_virtual = 0, virt_max = 16;
     bool sl_stored = false;
+    // Long runs of sweeps (mode pairs): from the g_from-th sweep of a step on the node multipliers are kept in a table
+    // (Gm, M doubles per mode pair) and advanced by one sweep per launch instead of being recomputed from 1 every time;
+    // g_sweeps = the sweeps its content stands for (with the coefficients vcoef), 0 = nothing in it.  g_from 0: no table.
+    double* Gm = nullptr;
+    int g_from = 8, g_sweeps = 0;
     SpecCoef vcoef;
     cd *tw = nullptr, *lamI = nullptr, *lamE = nullptr;
     bool sym_real[2] = {false, false};  // the stencil is symmetric: its Fourier symbol is real (imaginary parts stored as 0)

@@ -591,6 +591,11 @@ struct SpecArgs {
     // node's spectrum is stored.
     int replay, virt, last_only;
     unsigned block0;  // first workgroup of a launch that covers a range of lines
+    // Table of the real node multipliers (mode pairs, long runs of sweeps): G[(line * NF + m) * (N/2 + 1) + p], p = 0 .. N/2.
+    // gmode 1: the launch replays as usual and leaves the multipliers of ITS iterate in the table; 2: it takes the
+    // multipliers of the previous iterate from the table, does one sweep on them and writes them back (no replay).
+    double* G;
+    int gmode;
 };
 
 // one thread per Fourier mode: gather on the cached transforms + node-coupled solve, S updated in place.
@@ -616,6 +621,24 @@ DEVI cd node_divide(cd acc, cd lam, double al, int real_sym) {
 // real arithmetic for a real symbol without explicit part (heat): 9 fused multiply-adds per node and sweep on average
 // instead of ~40 on the transformed values themselves.  The residual of the result is h_m * u0 with
 //   h_m = 1 - g_m + (lam + mu) sum_j rQ[m][j] g_j.
+// one sweep on the multipliers (inv[m] = 1 / (1 - alpha_m lam))
+template <int NF>
+DEVI void virt_step_real(const SpecArgs& a, double lam, const double (&inv)[NF], double (&g)[NF]) {
+    double o[NF];
+#pragma unroll
+    for (int q = 0; q < NF; ++q) o[q] = g[q];
+#pragma unroll
+    for (int m = 0; m < NF; ++m) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < NF; ++q) t = fma(a.gI[m][q], o[q], t);
+        if (a.coupled) {
+#pragma unroll
+            for (int q = 0; q < m; ++q) t = fma(a.cI[m][q], g[q], t);
+        }
+        g[m] = fma(lam, t, 1.0) * inv[m];
+    }
+}
 template <int NF>
 DEVI void virt_multipliers_real(const SpecArgs& a, double lam, int nsweeps, double (&g)[NF]) {
     double inv[NF];
@@ -624,22 +647,15 @@ DEVI void virt_multipliers_real(const SpecArgs& a, double lam, int nsweeps, doub
         inv[m] = fast_rcp(1.0 - a.alpha[m] * lam);
         g[m] = 1.0;
     }
-    for (int s = 0; s < nsweeps; ++s) {
-        double o[NF];
+    for (int s = 0; s < nsweeps; ++s) virt_step_real<NF>(a, lam, inv, g);
+}
+// ... of the iterate whose multipliers the table holds: one more sweep on them
+template <int NF>
+DEVI void virt_multipliers_from_table(const SpecArgs& a, double lam, double (&g)[NF]) {
+    double inv[NF];
 #pragma unroll
-        for (int q = 0; q < NF; ++q) o[q] = g[q];
-#pragma unroll
-        for (int m = 0; m < NF; ++m) {
-            double t = 0.0;
-#pragma unroll
-            for (int q = 0; q < NF; ++q) t = fma(a.gI[m][q], o[q], t);
-            if (a.coupled) {
-#pragma unroll
-                for (int q = 0; q < m; ++q) t = fma(a.cI[m][q], g[q], t);
-            }
-            g[m] = fma(lam, t, 1.0) * inv[m];
-        }
-    }
+    for (int m = 0; m < NF; ++m) inv[m] = fast_rcp(1.0 - a.alpha[m] * lam);
+    virt_step_real<NF>(a, lam, inv, g);
 }
 template <int NF, bool HASE>
 DEVI void virt_multipliers(const SpecArgs& a, cd lam, cd mu, int nsweeps, cd (&g)[NF]) {
@@ -812,11 +828,25 @@ __global__ __launch_bounds__(256) void k_spec_store_pairs(SpecArgs a, int n, siz
         const size_t ilo = base + p_, ihi = base + (p_ ? n - p_ : n / 2);
         const cd lo = a.S0[ilo], hi = a.S0[ihi];
         double g[NF];
-        virt_multipliers_real<NF>(a, a.lamI[p_].x + lxy, nsweeps, g);
+        // (gmode 2: the table holds the multipliers of exactly this iterate)
+        const double* gt = a.gmode == 2 ? a.G + ln * (size_t)NF * (size_t)(n / 2 + 1) : nullptr;
+        if (gt) {
+#pragma unroll
+            for (int m = 0; m < NF; ++m) g[m] = (!a.last_only || m == NF - 1) ? gt[(size_t)m * (n / 2 + 1) + p_] : 0.0;
+        } else {
+            virt_multipliers_real<NF>(a, a.lamI[p_].x + lxy, nsweeps, g);
+        }
 #pragma unroll
         for (int m = 0; m < NF; ++m)
             if (!a.last_only || m == NF - 1) SPEC_FIELD(a, m, NF)[ilo] = cd{g[m] * lo.x, g[m] * lo.y};
-        if (p_ == 0) virt_multipliers_real<NF>(a, a.lamI[n / 2].x + lxy, nsweeps, g);
+        if (p_ == 0) {
+            if (gt) {
+#pragma unroll
+                for (int m = 0; m < NF; ++m) g[m] = (!a.last_only || m == NF - 1) ? gt[(size_t)m * (n / 2 + 1) + n / 2] : 0.0;
+            } else {
+                virt_multipliers_real<NF>(a, a.lamI[n / 2].x + lxy, nsweeps, g);
+            }
+        }
 #pragma unroll
         for (int m = 0; m < NF; ++m)
             if (!a.last_only || m == NF - 1) SPEC_FIELD(a, m, NF)[ihi] = cd{g[m] * hi.x, g[m] * hi.y};
@@ -917,8 +947,8 @@ template <int N, int NF, int MODE, int EXPL>
 // the second one - 2 waves / SIMD worth of registers instead of spilling; measured 5.7 -> 4.2 ms at 512^3)
 __global__ __launch_bounds__((specz_threads<N, NF, (MODE >= 3)>()), (specz_min_waves<N, (MODE >= 3)>()))
 void k_spec_z(SpecArgs a, unsigned nlines) {
-    constexpr bool RES = MODE >= 1, UPD = MODE <= 1 || MODE >= 3, VIRT = MODE >= 3, PAIR = MODE == 4, HASE = EXPL == 1,
-                   HASP = EXPL == 2;
+    constexpr bool RES = MODE >= 1, UPD = MODE <= 1 || MODE >= 3, VIRT = MODE >= 3, PAIR = MODE >= 4, GTAB = MODE == 5,
+                   HASE = EXPL == 1, HASP = EXPL == 2;
     static_assert(!(VIRT && HASP), "a forced iterate is not a function of the start value alone");
     constexpr int E = specz_elems<N, (MODE >= 3)>(), P = N / E, LPB = specz_lines<N, (MODE >= 3)>();
     static_assert(!PAIR || (LPB == 1 && !HASE), "mode pairs: one line per field and workgroup, real symbol only");
@@ -961,7 +991,26 @@ void k_spec_z(SpecArgs a, unsigned nlines) {
         for (int it = 0; it < IT2; ++it) {
             const double lam = lz[it] + lxy;
             double g[NF];
-            virt_multipliers_real<NF>(a, lam, a.replay + 1, g);
+            if constexpr (GTAB) {
+                // long runs of sweeps: the multipliers of the previous iterate come from the table (gmode 2) instead of
+                // being recomputed from 1 by a.replay sweeps, and those of this one go back into it
+                const int p_ = threadIdx.x + it * NT;
+                double* gp = a.G + (size_t)bid * NF * NI + p_;
+                const bool mine = p_ < NI && ok;
+                if (a.gmode == 2) {
+#pragma unroll
+                    for (int m = 0; m < NF; ++m) g[m] = mine ? gp[(size_t)m * NI] : 1.0;
+                    virt_multipliers_from_table<NF>(a, lam, g);
+                } else {
+                    virt_multipliers_real<NF>(a, lam, a.replay + 1, g);
+                }
+                if (mine) {
+#pragma unroll
+                    for (int m = 0; m < NF; ++m) gp[(size_t)m * NI] = g[m];
+                }
+            } else {
+                virt_multipliers_real<NF>(a, lam, a.replay + 1, g);
+            }
             if (a.virt == 2) {  // the iterate itself is wanted in real space (node values stored by every sweep)
 #pragma unroll
                 for (int m = 0; m < NF; ++m) hm[it][m] = g[m] * a.invN;

@@ -512,7 +512,8 @@ static void launch_spec_z_cfg(sdc_ctx* c, SpecArgs& a, size_t lines, int mode, s
         (void)expl;
         if constexpr (LPB == 1 && SDC_SPECZ_PAIRS) {
             // real symmetric symbol: the modes kz and N - kz of a line share their node multipliers
-            if (a.real_sym) ZL(4, 0);
+            if (a.real_sym && a.gmode) ZL(5, 0);
+            else if (a.real_sym) ZL(4, 0);
             else ZL(3, 0);
         } else ZL(3, 0);
     } else {
@@ -548,7 +549,8 @@ static int spec_sweep_n(sdc_ctx* c, int nf, SpecArgs& a, const FieldPtrs& p, uns
                                                      "spec_z_res_v4", "spec_z_res_v5", "spec_z_res_v6", "spec_z_res_v7+"};
                 static const char* const inames[] = {"spec_z_v0", "spec_z_v1", "spec_z_v2", "spec_z_v3",
                                                      "spec_z_v4", "spec_z_v5", "spec_z_v6", "spec_z_v7+"};
-                const char* zbase = a.virt == 2 ? inames[a.replay < 7 ? a.replay : 7]
+                const char* zbase = a.virt && a.gmode == 2 ? (a.virt == 2 ? "spec_z_tab" : "spec_z_res_tab")
+                                    : a.virt == 2 ? inames[a.replay < 7 ? a.replay : 7]
                                     : a.virt ? vnames[a.replay < 7 ? a.replay : 7]
                                              : norms ? (a.spread ? "spec_z_res_spread" : "spec_z_res")
                                                      : (a.spread ? "spec_z_spread" : "spec_z");
@@ -792,6 +794,10 @@ static int store_spectra(sdc_ctx* c, bool last_only) {
     a.nf = c->M;
     a.ndim = c->ndim;
     a.last_only = last_only ? 1 : 0;
+    if (c->Gm && c->g_sweeps > 0 && c->g_sweeps == c->spec_virtual) {  // the multipliers of this very iterate are on record
+        a.G = c->Gm;
+        a.gmode = 2;
+    }
     const int n = c->n;
     const size_t lines = c->ndim == 1 ? 1 : (size_t)(n / 2 + 1) * (c->ndim == 3 ? n : 1);
     const size_t nmodes = lines * n;
@@ -1123,6 +1129,7 @@ int sdc_ctx_destroy(sdc_ctx* c) {
         for (auto& e : c->pipe_ev) (void)hipEventDestroy(e);
     }
     (void)hipFree(c->Wend);
+    (void)hipFree(c->Gm);
     if (c->sl_ev) (void)hipEventDestroy(c->sl_ev);
     (void)hipFree(c->UEND2);
     (void)hipFree(c->tw);
@@ -1268,6 +1275,7 @@ int sdc_set_symbol(sdc_ctx* c, int which, const double* table) {
     c->have_stencil[which] = true;
     if (which == 0) c->spectral_op = true;
     c->spec_valid = c->spec0_valid = false;
+    c->g_sweeps = 0;  // (multipliers of another symbol)
     return SDC_OK;
 }
 
@@ -1514,6 +1522,13 @@ int sdc_set_virtual_sweeps(sdc_ctx* c, int max_sweeps) {
     if (!c || max_sweeps < 0) return fail(c, SDC_ERR_PARAM, "bad number of sweeps");
     if (max_sweeps == 0) STORE_SPECTRA(c, false);
     c->virt_max = max_sweeps;
+    return SDC_OK;
+}
+
+int sdc_set_multiplier_table(sdc_ctx* c, int from_sweep) {
+    if (!c || from_sweep < 0) return fail(c, SDC_ERR_PARAM, "multiplier table: first sweep that uses it (0: never)");
+    c->g_from = from_sweep;
+    c->g_sweeps = 0;
     return SDC_OK;
 }
 
@@ -2000,13 +2015,34 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
             now.coupled = a.coupled;
             now.real_sym = a.real_sym;
             now.has_e = a.lamE ? 1 : 0;
+            // the multiplier table takes over where replaying gets dearer than 2 M doubles of traffic per mode pair - if the
+            // replayed sweeps get that far (virt_max) and the table can be had
+            bool table = go && pairs_z && !spec_only && c->g_from > 0 && c->virt_max > c->g_from && c->spec_virtual >= c->g_from;
+            if (table && !c->Gm) {
+                const size_t glines = (size_t)(c->n / 2 + 1) * (c->ndim == 3 ? c->n : 1);
+                const size_t gbytes = sizeof(double) * glines * (size_t)M * (size_t)(c->n / 2 + 1);
+                if (hipMalloc((void**)&c->Gm, gbytes) == hipSuccess) {
+                    c->bytes += gbytes;
+                    c->g_sweeps = 0;
+                } else {  // no room: sweeps are replayed up to virt_max and stored from there on, as without the table
+                    (void)hipGetLastError();
+                    c->Gm = nullptr;
+                    c->g_from = 0;
+                    table = false;
+                }
+            }
             if (go && a.spread) {
+                if (memcmp(&now, &c->vcoef, sizeof now) != 0) c->g_sweeps = 0;
                 memcpy(&c->vcoef, &now, sizeof now);
                 a.replay = 0;
-            } else if (go && c->spec_valid && c->spec_virtual > 0 && c->spec_virtual < c->virt_max &&
+            } else if (go && c->spec_valid && c->spec_virtual > 0 && (c->spec_virtual < c->virt_max || table) &&
                        memcmp(&now, &c->vcoef, sizeof now) == 0) {
                 a.replay = c->spec_virtual;
                 a.spread = 1;
+                if (table) {
+                    a.G = c->Gm;
+                    a.gmode = c->g_sweeps == c->spec_virtual ? 2 : 1;
+                }
             } else {
                 go = false;
                 STORE_SPECTRA(c, false);
@@ -2014,6 +2050,7 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
             if (go) {
                 a.virt = iter_out ? 2 : 1;
                 c->spec_virtual = a.replay + 1;
+                if (a.gmode && !spec_only) c->g_sweeps = c->spec_virtual;
                 c->sl_stored = false;
                 if (spec_only) {  // no residual wanted: nothing to launch at all - the sweep is remembered
                     c->spec_gen++;

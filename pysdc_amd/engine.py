@@ -108,6 +108,10 @@ class SweepEngine:
         """sweeps per step whose iterate is not stored but recomputed from the transform of u[0] (0: off)"""
         self._chk(self.lib.sdc_set_virtual_sweeps(self.ctx, int(max_sweeps)))
 
+    def set_multiplier_table(self, from_sweep):
+        """first sweep of a step that takes the node multipliers from a table instead of replaying earlier sweeps (0: never)"""
+        self._chk(self.lib.sdc_set_multiplier_table(self.ctx, int(from_sweep)))
+
     def set_pipeline_groups(self, groups):
         """z / y passes of a norm-only sweep issued in this many groups of kx planes on two streams (-1 default, 0 off)"""
         self._chk(self.lib.sdc_set_pipeline_groups(self.ctx, int(groups)))
