@@ -250,11 +250,34 @@ struct StencilResArgs {
 };
 
 // WF = false: F is not stored (deferred, sdc_materialize) - the launch then only reads u0 and U[1..M].
+// SDC_STENCIL_HALO_AHEAD 1: the halo of a plane is requested in the SAME iteration as its interior (two planes ahead of the
+// one being computed) - it is the interior of the neighbouring tiles, whose workgroups run next to this one on the same
+// XCD (xcd_swizzle) and request it at that very time, so the line is fetched from HBM once.  (Requested one iteration
+// later, as in round 2, the neighbour's copy had already left the 4 MB L2, through which ~4 MB pass per plane and XCD:
+// PMC traffic 138.5 GB per launch at 1024^3, M = 5, against 94.5 GB algorithmic.)  The halo waits in a per-thread LDS slot
+// for one iteration (no registers to spare: 168 VGPRs at M = 5), and the tile is single-buffered (a second barrier per
+// plane) so that three workgroups still fit a CU.  0: round 2's arrangement.
+#ifndef SDC_STENCIL_HALO_AHEAD
+#define SDC_STENCIL_HALO_AHEAD 1
+#endif
+#ifndef SDC_STENCIL_U0_NT
+#define SDC_STENCIL_U0_NT 0  // u0 has no halo: nontemporal loads would leave the L2 to the planes that are shared
+#endif
+__device__ __forceinline__ double2 ld_u0_pair(const double* q) {
+#if SDC_STENCIL_U0_NT
+    return double2{__builtin_nontemporal_load(q), __builtin_nontemporal_load(q + 1)};
+#else
+    return *reinterpret_cast<const double2*>(q);
+#endif
+}
 template <int M, bool EXPL, bool WF>
-__global__ __launch_bounds__(256, EXPL ? 2 : 3) void k_stencil3d_res(StencilResArgs a) {
-    // LDS: 2 buffers x M fields x (8+2) rows x 66 doubles = 52.8 KB at M = 5 -> three workgroups per CU
+__global__ __launch_bounds__(256, (EXPL || M >= 6) ? 2 : 3) void k_stencil3d_res(StencilResArgs a) {
+    // LDS, round 2: 2 buffers x M fields x (8+2) rows x 66 doubles = 52.8 KB at M = 5 -> three workgroups per CU;
+    // halo ahead: 1 buffer (26.4 KB) + M x 80 halo slots of 16 bytes (6.4 KB)
     constexpr int TZ = 64, TY = 8, LW = TZ + 2;
-    __shared__ double tile[2][M][TY + 2][LW];
+    constexpr bool AHEAD = SDC_STENCIL_HALO_AHEAD != 0;
+    __shared__ double tile[AHEAD ? 1 : 2][M][TY + 2][LW];
+    __shared__ double2 stage[AHEAD ? M : 1][AHEAD ? 64 + 2 * TY : 1];
     const int n = a.n;
     const int tz = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int ntz = n / TZ, nty = n / TY;
@@ -310,27 +333,31 @@ __global__ __launch_bounds__(256, EXPL ? 2 : 3) void k_stencil3d_res(StencilResA
         cur[j] = *reinterpret_cast<const double2*>(uj + wrapx(x0) + off);
         nxt[j] = *reinterpret_cast<const double2*>(uj + wrapx(x0 + 1) + off);
         put(0, j, cur[j], halo_load(uj + wrapx(x0)));
+        if constexpr (AHEAD) {
+            if (hy || hz) stage[j][t] = halo_load(uj + wrapx(x0 + 1));
+        }
         nmax[j] = 0.0;
     }
-    u0c = *reinterpret_cast<const double2*>(a.U + wrapx(x0) + off);
+    u0c = ld_u0_pair(a.U + wrapx(x0) + off);
     const double cI = 3.0 * a.wI[1], cE = EXPL ? 3.0 * a.wE[1] : 0.0;
     const size_t fstep = (size_t)(EXPL ? 2 : 1) * a.N;  // distance between F[j] and F[j+1]
     for (int p = 0; p < a.xchunk; ++p) {
-        const int b = p & 1;
+        const int b = AHEAD ? 0 : (p & 1);
         const int x = x0 + p;
         __syncthreads();
         const bool more = p + 1 < a.xchunk;
-        // in flight while this plane is computed: the interior of plane x+2 and the halo of plane x+1
+        // in flight while this plane is computed: the interior of plane x+2 and the halo of plane x+1 (AHEAD: of x+2 too)
         double2 nn[M], hn[M];
         if (more) {
             const size_t px1 = wrapx(x + 1), px2 = wrapx(x + 2);
+            const bool halo_wanted = !AHEAD || p + 2 < a.xchunk;  // (AHEAD: plane x+2 is computed by this workgroup)
 #pragma unroll
             for (int j = 0; j < M; ++j) {
                 const double* uj = a.U + (size_t)(j + 1) * a.N;
                 nn[j] = *reinterpret_cast<const double2*>(uj + px2 + off);
-                hn[j] = halo_load(uj + px1);
+                hn[j] = halo_wanted ? halo_load(uj + (AHEAD ? px2 : px1)) : double2{0.0, 0.0};
             }
-            u0n = *reinterpret_cast<const double2*>(a.U + px1 + off);
+            u0n = ld_u0_pair(a.U + px1 + off);
         }
         const size_t po = (size_t)x * sx + off;
         double2 fv[M];
@@ -345,14 +372,30 @@ __global__ __launch_bounds__(256, EXPL ? 2 : 3) void k_stencil3d_res(StencilResA
                       (a.wI[0] * zm + a.wI[2] * c1) + cI * c0;
             fv[j].y = (a.wI[0] * prev[j].y + a.wI[2] * nxt[j].y) + (a.wI[0] * ym1 + a.wI[2] * yp1) +
                       (a.wI[0] * c0 + a.wI[2] * zp) + cI * c1;
-            if (WF) *reinterpret_cast<double2*>(a.F + (size_t)(j + 1) * fstep + po) = fv[j];
+            if (WF) {
+                double* fo = a.F + (size_t)(j + 1) * fstep + po;
+                if constexpr (AHEAD) {  // (written once, read by nobody here: keep the L2 for the planes being shared)
+                    __builtin_nontemporal_store(fv[j].x, fo);
+                    __builtin_nontemporal_store(fv[j].y, fo + 1);
+                } else {
+                    *reinterpret_cast<double2*>(fo) = fv[j];
+                }
+            }
             if (EXPL) {
                 double2 fe;
                 fe.x = (a.wE[0] * prev[j].x + a.wE[2] * nxt[j].x) + (a.wE[0] * ym0 + a.wE[2] * yp0) +
                        (a.wE[0] * zm + a.wE[2] * c1) + cE * c0;
                 fe.y = (a.wE[0] * prev[j].y + a.wE[2] * nxt[j].y) + (a.wE[0] * ym1 + a.wE[2] * yp1) +
                        (a.wE[0] * c0 + a.wE[2] * zp) + cE * c1;
-                if (WF) *reinterpret_cast<double2*>(a.F + (size_t)(j + 1) * fstep + a.N + po) = fe;
+                if (WF) {
+                    double* fo = a.F + (size_t)(j + 1) * fstep + a.N + po;
+                    if constexpr (AHEAD) {
+                        __builtin_nontemporal_store(fe.x, fo);
+                        __builtin_nontemporal_store(fe.y, fo + 1);
+                    } else {
+                        *reinterpret_cast<double2*>(fo) = fe;
+                    }
+                }
                 fv[j].x += fe.x;  // the residual integrates impl + expl (imex_1st_order.py:52)
                 fv[j].y += fe.y;
             }
@@ -371,9 +414,19 @@ __global__ __launch_bounds__(256, EXPL ? 2 : 3) void k_stencil3d_res(StencilResA
             nmax[m] = (nmax[m] > r || nmax[m] != nmax[m]) ? nmax[m] : r;
         }
         if (more) {
+            if constexpr (AHEAD) __syncthreads();  // everybody has read plane x from the (single) tile
 #pragma unroll
             for (int j = 0; j < M; ++j) {
-                put(b ^ 1, j, nxt[j], hn[j]);
+                if constexpr (AHEAD) {
+                    double2 h1 = double2{0.0, 0.0};
+                    if (hy || hz) {
+                        h1 = stage[j][t];      // halo of plane x+1, requested an iteration ago
+                        stage[j][t] = hn[j];   // ... of plane x+2
+                    }
+                    put(0, j, nxt[j], h1);
+                } else {
+                    put(b ^ 1, j, nxt[j], hn[j]);
+                }
                 prev[j] = cur[j];
                 cur[j] = nxt[j];
                 nxt[j] = nn[j];

@@ -134,6 +134,13 @@ static void quad_base(sdc_ctx* c, QuadArgs& a) {
     a.nout = c->M;
 }
 
+// planes a workgroup of the marching 3-D stencil kernels takes: 64, fewer on small grids so that the launch still has a
+// few workgroups per CU (256^3, one field: 128 workgroups with 64 planes each - half the CUs idle; 1024 with 8)
+static inline int stencil_xchunk(int n, size_t tiles) {
+    int x = n >= 64 ? 64 : n;
+    while (x > 8 && tiles * (size_t)(n / x) < 1024) x >>= 1;
+    return x;
+}
 static int run_stencil(sdc_ctx* c, int nf, const double* const* in, double* const* outI, double* const* outE,
                        const double* g) {
     StencilArgs a;
@@ -171,9 +178,9 @@ static int run_stencil(sdc_ctx* c, int nf, const double* const* in, double* cons
         }
         s3.useE = needE ? 1 : 0;
         s3.n = c->n;
-        s3.xchunk = c->n >= 64 ? 64 : c->n;
-        s3.nchunks = c->n / s3.xchunk;
         s3.ntiles = (c->n / 64) * (c->n / (8 * RPT));
+        s3.xchunk = stencil_xchunk(c->n, (size_t)s3.ntiles * nf);
+        s3.nchunks = c->n / s3.xchunk;
         hipLaunchKernelGGL((k_stencil3d<RPT>), dim3(s3.ntiles * s3.nchunks * nf), dim3(256), 0, c->stream, s3);
         HIPCHK(c, hipGetLastError());
         return SDC_OK;
@@ -221,7 +228,7 @@ static int eval_nodes(sdc_ctx* c, double dt) {
         a.norms = c->res_dev;
         a.n = c->n;
         a.N = c->N;
-        a.xchunk = c->n >= 64 ? 64 : c->n;
+        a.xchunk = stencil_xchunk(c->n, (size_t)(c->n / 64) * (c->n / 8));
         a.nchunks = c->n / a.xchunk;
         HIPCHK(c, hipMemsetAsync(c->res_dev, 0, sizeof(unsigned long long) * 8, c->stream));
         const unsigned grid = (unsigned)((c->n / 64) * (c->n / 8) * a.nchunks);
@@ -1690,9 +1697,9 @@ int sdc_predict(sdc_ctx* c, double t, double dt, int guess, double fill_u, doubl
         s3.useE = explS ? 1 : 0;
         s3.fmax = c->res_dev + 7;
         s3.n = c->n;
-        s3.xchunk = 64;
-        s3.nchunks = c->n / s3.xchunk;
         s3.ntiles = (c->n / 64) * (c->n / (8 * RPT));
+        s3.xchunk = stencil_xchunk(c->n, (size_t)s3.ntiles);
+        s3.nchunks = c->n / s3.xchunk;
         {
             LaunchTimer lt(c, "stencil_max");
             hipLaunchKernelGGL((k_stencil3d<RPT>), dim3(s3.ntiles * s3.nchunks), dim3(256), 0, c->stream, s3);

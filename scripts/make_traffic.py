@@ -28,7 +28,7 @@ summary = {kind: {k: {'sum': sum(v.values()), 'dispatches': len(v), 'per_dispatc
                   for k, v in rows.items()} for kind, rows in (('fetch', fetch), ('write', write))}
 json.dump(summary, open(f'{out}/pmc_summary.json', 'w'), indent=1)
 
-NAMES = [(r'k_spec_z<\d+, \d+, [34], \d+>', 'spec_z_res_v0'), (r'k_spec_store', 'spec_store'),
+NAMES = [(r'k_spec_z<\d+, \d+, 5, \d+>', 'spec_z_res_tab'), (r'k_spec_z<\d+, \d+, [34], \d+>', 'spec_z_res_v0'), (r'k_spec_store', 'spec_store'),
          (r'k_spec_z<\d+, \d+, 1, \d+>', 'spec_z_res'), (r'k_spec_z<\d+, \d+, 0, \d+>', 'spec_z'),
          (r'k_ffty<\d+, \d+, 1>', 'fft_y_inv'), (r'k_ffty<\d+, \d+, -1>', 'fft_y_fwd'),
          (r'k_fftx_inv<\d+, \d+, true, false(, false)?>', 'fft_x_norm'), (r'k_fftx_norm_half', 'fft_x_norm'),
