@@ -254,6 +254,8 @@ __global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_inv(FieldPtr
         // real parts of output 0 over the real parts only, its imaginary part over the imaginary ones), so a NaN anywhere
         // in the pair shows in one output of every thread - looking at one element is an exact test
         if (r[0].x != r[0].x || r[0].y != r[0].y) m = r[0].x + r[0].y;
+        // (one guarded atomic per wave: reducing over the workgroup first was measured - 9.82 -> 10.17 ms at 1024^3, the
+        // barrier keeps finished waves from retiring; the relaxed read in atomic_max_abs is not a hot spot)
         m = wave_max(m);
         if ((threadIdx.x & 63) == 0) atomic_max_abs(norms + by, m);
     }

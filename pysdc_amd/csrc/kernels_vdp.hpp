@@ -16,6 +16,7 @@ struct VdpSweepArgs {
                                            // first and multiplies by f afterwards, so the product is made once on the host
     unsigned long long* counters;
     unsigned long long* norms;  // node-wise max of the collocation residual after the sweep, or null
+    int spread;  // the old iterate is the spread start value (U[1..M] = U[0] was never written out): only U[0] is read
 };
 
 // Newton for u - h f(u) = r with the closed-form 2x2 inverse (Van_der_Pol_implicit.py:131-201)
@@ -41,6 +42,31 @@ __device__ __forceinline__ bool vdp_newton(double& x1, double& x2, double r0, do
         ++newton;
     }
     return !(res != res || it == maxiter);
+}
+
+// Work counters of a launch: summed over the workgroup first, then ONE atomic per counter and workgroup (and none for a
+// zero) - 16 384 waves adding to the same three words one after the other were a measurable part of a 0.2 ms launch.
+// Every thread of the workgroup must call this (it contains a barrier).
+__device__ __forceinline__ void vdp_add_counters(unsigned long long* counters, unsigned long long newton, unsigned long long rhs,
+                                                 unsigned long long failed) {
+    __shared__ unsigned long long part[3][16];
+    for (int o = 32; o > 0; o >>= 1) {
+        newton += __shfl_xor(newton, o, 64);
+        rhs += __shfl_xor(rhs, o, 64);
+        failed += __shfl_xor(failed, o, 64);
+    }
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        part[0][w] = newton;
+        part[1][w] = rhs;
+        part[2][w] = failed;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3 && counters) {
+        unsigned long long t = 0;
+        for (int k = 0; k < nw; ++k) t += part[threadIdx.x][k];
+        if (t) atomicAdd(counters + threadIdx.x, t);
+    }
 }
 
 // one generic_implicit sweep (generic_implicit.py:51-103) for every trajectory, node values on the slabs
@@ -100,8 +126,8 @@ __global__ VDP_BOUNDS void k_vdp_sweep(VdpSweepArgs a) {
 #pragma unroll
         for (int m = 0; m < M; ++m) {
             if (LAZYF) {
-                const double o0 = a.U[(size_t)(m + 1) * N + i];  // old node value: f here, guess below
-                const double o1 = a.U[(size_t)(m + 1) * N + T + i];
+                const double o0 = a.spread ? u00 : a.U[(size_t)(m + 1) * N + i];  // old node value: f here, guess below
+                const double o1 = a.spread ? u01 : a.U[(size_t)(m + 1) * N + T + i];
 #if SDC_VDP_KEEP_NODES
                 un0[m] = o0;
                 un1[m] = o1;
@@ -199,23 +225,8 @@ __global__ VDP_BOUNDS void k_vdp_sweep(VdpSweepArgs a) {
             }
         }
     }
-    for (int o = 32; o > 0; o >>= 1) {
-        newton += __shfl_xor(newton, o, 64);
-        rhs += __shfl_xor(rhs, o, 64);
-        failed += __shfl_xor(failed, o, 64);
-    }
-    if ((threadIdx.x & 63) == 0) {
-        atomicAdd(a.counters + 0, newton);
-        atomicAdd(a.counters + 1, rhs);
-        atomicAdd(a.counters + 2, failed);
-    }
-    if (a.norms) {
-#pragma unroll
-        for (int m = 0; m < M; ++m) {
-            const double v = wave_max(nmax[m]);
-            if ((threadIdx.x & 63) == 0) atomic_max_abs(a.norms + m, v);
-        }
-    }
+    vdp_add_counters(a.counters, newton, rhs, failed);
+    if (a.norms) block_max_to_slots<M>(a.norms, nmax);
 #undef VQ
 #undef VQI
 }
@@ -394,38 +405,62 @@ __global__ __launch_bounds__(256) void k_vdp_sweep_mfma(VdpSweepArgs a) {
             }
         }
     }
-    for (int o = 32; o > 0; o >>= 1) {
-        newton += __shfl_xor(newton, o, 64);
-        rhs += __shfl_xor(rhs, o, 64);
-        failed += __shfl_xor(failed, o, 64);
-    }
-    if ((threadIdx.x & 63) == 0) {
-        atomicAdd(a.counters + 0, newton);
-        atomicAdd(a.counters + 1, rhs);
-        atomicAdd(a.counters + 2, failed);
-    }
-    if (a.norms) {
-#pragma unroll
-        for (int m = 0; m < M; ++m) {
-            const double v = wave_max(nmax[m]);
-            if ((threadIdx.x & 63) == 0) atomic_max_abs(a.norms + m, v);
-        }
-    }
+    vdp_add_counters(a.counters, newton, rhs, failed);
+    if (a.norms) block_max_to_slots<M>(a.norms, nmax);
 }
 
-__global__ void k_vdp_eval(const double* __restrict__ u, double* __restrict__ f, size_t T, double mu,
-                           unsigned long long* counters) {
+// f(u) of the ensemble (Van_der_Pol_implicit.py:76-98); fmax (or null): max |f| over both components on the way (the
+// residual of a spread predictor).  Two trajectories per thread and iteration when T is even (16-byte accesses: this
+// launch moves little per thread and waits for memory latency).
+__global__ __launch_bounds__(256) void k_vdp_eval(const double* __restrict__ u, double* __restrict__ f, size_t T, double mu,
+                                                  unsigned long long* counters, unsigned long long* fmax = nullptr) {
 #pragma clang fp contract(off)
     unsigned long long rhs = 0;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < T; i += (size_t)gridDim.x * blockDim.x) {
-        const double x1 = u[i], x2 = u[T + i];
-        f[i] = x2;
-        f[T + i] = mu * (1 - x1 * x1) * x2 - x1;
-        rhs += 1;
+    double mx = 0.0;
+    auto upd = [&](double v) {
+        v = fabs(v);
+        mx = (mx > v || mx != mx) ? mx : v;
+    };
+    if ((T & 1) == 0 && ((reinterpret_cast<size_t>(u) | reinterpret_cast<size_t>(f)) & 15) == 0) {
+        const size_t H = T / 2;
+        const double2* __restrict__ u1 = reinterpret_cast<const double2*>(u);
+        const double2* __restrict__ u2 = reinterpret_cast<const double2*>(u + T);
+        double2* __restrict__ f1 = reinterpret_cast<double2*>(f);
+        double2* __restrict__ f2 = reinterpret_cast<double2*>(f + T);
+        for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < H; i += (size_t)gridDim.x * blockDim.x) {
+            const double2 x1 = u1[i], x2 = u2[i];
+            double2 g;
+            g.x = mu * (1 - x1.x * x1.x) * x2.x - x1.x;
+            g.y = mu * (1 - x1.y * x1.y) * x2.y - x1.y;
+            f1[i] = x2;
+            f2[i] = g;
+            if (fmax) {
+                upd(x2.x);
+                upd(x2.y);
+                upd(g.x);
+                upd(g.y);
+            }
+            rhs += 2;
+        }
+    } else {
+        for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < T; i += (size_t)gridDim.x * blockDim.x) {
+            const double x1 = u[i], x2 = u[T + i];
+            const double g = mu * (1 - x1 * x1) * x2 - x1;
+            f[i] = x2;
+            f[T + i] = g;
+            if (fmax) {
+                upd(x2);
+                upd(g);
+            }
+            rhs += 1;
+        }
     }
-    if (!counters) return;  // storing deferred values: those evaluations were counted by the sweep
-    for (int o = 32; o > 0; o >>= 1) rhs += __shfl_xor(rhs, o, 64);
-    if ((threadIdx.x & 63) == 0 && rhs) atomicAdd(counters + 1, rhs);
+    if (fmax) {
+        mx = wave_max(mx);
+        if ((threadIdx.x & 63) == 0) atomic_max_abs(fmax, mx);
+    }
+    // (counters == null: storing deferred values - those evaluations were counted by the sweep)
+    vdp_add_counters(counters, 0, rhs, 0);
 }
 
 __global__ void k_vdp_solve(const double* __restrict__ rhsv, const double* __restrict__ guess, double* __restrict__ out,
@@ -437,14 +472,7 @@ __global__ void k_vdp_solve(const double* __restrict__ rhsv, const double* __res
         out[i] = x1;
         out[T + i] = x2;
     }
-    for (int o = 32; o > 0; o >>= 1) {
-        newton += __shfl_xor(newton, o, 64);
-        failed += __shfl_xor(failed, o, 64);
-    }
-    if ((threadIdx.x & 63) == 0) {
-        atomicAdd(counters + 0, newton);
-        atomicAdd(counters + 2, failed);
-    }
+    vdp_add_counters(counters, newton, 0, failed);
 }
 
 // (dg/du)^{-1} rhs for g(u) = u - dt f(u): the closed-form 2x2 inverse of Van_der_Pol_implicit.py:190-201, one

@@ -1670,8 +1670,10 @@ int sdc_predict(sdc_ctx* c, double t, double dt, int guess, double fill_u, doubl
     const bool spread_res = guess == SDC_GUESS_SPREAD && c->expl_kind != SDC_EXPL_FORCING && !c->tau_active;
     if (spread_res) HIPCHK(c, hipMemsetAsync(c->res_dev, 0, sizeof(unsigned long long) * 8, c->stream));
     c->spread_pending = c->f_pending = c->u_pending = c->f0_pending = c->rfields_valid = false;
-    const bool lazy_spread = c->deferred && c->kind == 0 && guess == SDC_GUESS_SPREAD && c->expl_kind != SDC_EXPL_FORCING;
-    if (!lazy_spread) ENSURE_U0(c);  // (the deferred spread only READS the start value: wherever it lies)
+    // (van der Pol ensemble: the first sweep reads U[0] alone, sdc_sweep)
+    const bool lazy_spread = c->deferred && (c->kind == 0 || (c->kind == 1 && !c->tau_active)) && guess == SDC_GUESS_SPREAD &&
+                             c->expl_kind != SDC_EXPL_FORCING;
+    if (!lazy_spread || c->kind == 1) ENSURE_U0(c);  // (the deferred spread only READS the start value: wherever it lies)
     // with the 3-D three-point kernel even f(u0) itself is not stored: one pass over u0 that only reduces max|f(u0)|
     auto three = [](const Stencil& s) { return s.npts == 3 && s.off[0] == -1 && s.off[1] == 0 && s.off[2] == 1; };
     const bool explS = c->expl_kind == SDC_EXPL_STENCIL;
@@ -1679,6 +1681,7 @@ int sdc_predict(sdc_ctx* c, double t, double dt, int guess, double fill_u, doubl
                             c->have_stencil[0] && three(c->st[0]) &&
                             (c->expl_kind == SDC_EXPL_NONE || (explS && c->have_stencil[1] && three(c->st[1])));
     int rc = SDC_OK;
+    bool f0_max_done = false;
     if (f0_by_norm && c->u0_spec_only && c->spec0_valid && c->S0 && c->expl_kind != SDC_EXPL_FORCING) {
         // the start value exists as its transform only: max |f(u0)| from the norm-only inverse transform of symbol * S0
         rc = symbol_norm(c, c->S0, c->res_dev + 7);
@@ -1708,12 +1711,20 @@ int sdc_predict(sdc_ctx* c, double t, double dt, int guess, double fill_u, doubl
         c->f0_pending = true;
     } else {
         U0R(c, u0p);
-        rc = sdc_eval_f(c, u0p, c->gvals[0], c->F, c->ncomp == 2 ? c->F + c->N : nullptr);
-        if (rc != SDC_OK) return rc;
+        if (c->kind == 1 && lazy_spread && spread_res) {  // max |f(u0)| on the way (no second pass over F[0])
+            LaunchTimer lt(c, "vdp_eval");
+            hipLaunchKernelGGL(k_vdp_eval, dim3(grid_for(c->N / 4, 256)), dim3(256), 0, c->stream, u0p, c->F, c->N / 2,
+                               c->vdp_mu, c->counters, c->res_dev + 7);
+            HIPCHK(c, hipGetLastError());
+            f0_max_done = true;
+        } else {
+            rc = sdc_eval_f(c, u0p, c->gvals[0], c->F, c->ncomp == 2 ? c->F + c->N : nullptr);
+            if (rc != SDC_OK) return rc;
+        }
     }
     if (lazy_spread) {
         // the node copies are not stored until somebody reads them (materialize); only max|f(u0)| is needed now
-        if (spread_res && !f0_by_norm) {
+        if (spread_res && !f0_by_norm && !f0_max_done) {
             LaunchTimer lt(c, "amax");
             hipLaunchKernelGGL(k_amax_sum, dim3(grid_for(c->N, 256)), dim3(256), 0, c->stream, c->F,
                                c->ncomp == 2 ? c->F + c->N : nullptr, c->N, c->res_dev + 7);
@@ -1877,6 +1888,16 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
         }
         const bool lazyf = c->deferred && !c->force_gather;
         c->force_gather = false;
+        if (c->spread_pending) {
+            // node copies of a spread predictor that were never written: the closed-form kernel takes U[0] for all of them
+            if (lazyf && c->vdp_block_solver != 1) {
+                a.spread = 1;
+                c->spread_pending = false;
+            } else {
+                int rcm = materialize(c, true, true);
+                if (rcm != SDC_OK) return rcm;
+            }
+        }
         if (c->vdp_block_solver == 1 && lazyf) {
             LaunchTimer lt(c, "vdp_sweep_mfma");
             const size_t ldsv = (size_t)4 * 64 * 10 * sizeof(double);
