@@ -112,6 +112,7 @@ struct sdc_ctx {
     double cg_rtol = 1e-12;
     int cg_maxiter = 10000;
     unsigned long long cg_iters = 0;
+    std::map<double, int> cg_hist;  // iterations of the previous solve per factor (size of the first batch of the next one)
     double* cgw = nullptr;        // r, p, q, A p + partial sums
     double* gmw = nullptr;        // GMRES: Krylov basis (restart + 1 fields), w, A v, the update + partial sums
     size_t gmw_len = 0;
@@ -147,6 +148,7 @@ struct sdc_ctx {
     std::vector<hipEvent_t> pool;            // event pairs recorded around launches while profiling
     std::vector<const char*> pool_names;
     size_t pool_used = 0;                    // pairs in flight
+    int prof_open = 0;                       // LaunchTimer brackets that are open right now (nested: a solver around its launches)
     std::map<std::string, ProfEntry> prof;
     std::vector<std::string> prof_names;
     std::string err;
@@ -188,6 +190,8 @@ static void prof_flush(sdc_ctx* c) {
             ProfEntry& e = c->prof[c->pool_names[i]];
             e.ms += ms;
             e.calls += 1;
+        } else {
+            (void)hipGetLastError();  // (a pair that cannot be read is dropped; the error must not surface in a later check)
         }
     }
     c->pool_used = 0;
@@ -207,13 +211,27 @@ struct LaunchTimer {
             c->pool_names.resize(kPairs);
             for (auto& e : c->pool) (void)hipEventCreate(&e);
         }
-        if (c->pool_used == kPairs) prof_flush(c);
+        if (c->pool_used == c->pool_names.size()) {
+            // full: read the pairs out - unless an enclosing timer is still open (a solver's launches inside its own
+            // bracket), whose end is not recorded yet: then the pool grows instead
+            if (c->prof_open == 0) {
+                prof_flush(c);
+            } else {
+                const size_t old = c->pool_names.size();
+                c->pool.resize(2 * (old + kPairs));
+                c->pool_names.resize(old + kPairs);
+                for (size_t i = 2 * old; i < c->pool.size(); ++i) (void)hipEventCreate(&c->pool[i]);
+            }
+        }
         slot = c->pool_used++;
         c->pool_names[slot] = n;
+        ++c->prof_open;
         (void)hipEventRecord(c->pool[2 * slot], s);
     }
     ~LaunchTimer() {
-        if (on) (void)hipEventRecord(c->pool[2 * slot + 1], s);
+        if (!on) return;
+        (void)hipEventRecord(c->pool[2 * slot + 1], s);
+        --c->prof_open;
     }
 };
 

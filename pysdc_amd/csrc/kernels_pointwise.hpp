@@ -337,10 +337,19 @@ struct CgArgs {
     size_t n;
     double* part;
     int mode;
+    // iterations enqueued without a host round trip (cg_solve): the scalar comes from device memory (sdev[0], written by
+    // k_cg_scalars) and the launch does nothing once the iteration has stopped (*done != 0)
+    const double* sdev;
+    const double* done;
 };
+
+// scalars of the conjugate-gradient iteration kept on the device (cg_solve): slots of `scal`
+enum { CGS_RHO = 1, CGS_ALPHA = 3, CGS_BETA = 4, CGS_ATOL = 5, CGS_DONE = 6, CGS_ITERS = 7, CGS_MAXITER = 8 };
 
 __global__ __launch_bounds__(256) void k_cg(CgArgs a) {
 #pragma clang fp contract(off)
+    if (a.done && *a.done != 0.0) return;
+    if (a.sdev) a.s = *a.sdev;
     double acc = 0.0;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < a.n; i += (size_t)gridDim.x * blockDim.x) {
         if (a.mode == 0) {
@@ -386,6 +395,35 @@ __global__ __launch_bounds__(256) void k_cg(CgArgs a) {
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0 && a.part) a.part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// sum of the partial sums of the launch before (same order as k_sum_parts), then the scalar step of the iteration
+// (scipy.sparse.linalg.cg as the reference calls it, generic_ND_FD.py:252-260; the arithmetic the host loop of round 2 did):
+//   step 0 (after p.Ap):  alpha = rho / pq
+//   step 1 (after r.r):   iterations += 1;  stop if sqrt(rr) < atol or the iteration limit is reached, else
+//                         beta = rr / rho,  rho = rr
+__global__ __launch_bounds__(256) void k_cg_scalars(const double* __restrict__ part, int nb, double* __restrict__ scal, int step) {
+#pragma clang fp contract(off)
+    if (scal[CGS_DONE] != 0.0) return;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nb; i += 256) acc += part[i];
+    __shared__ double sh[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const double v = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    if (step == 0) {
+        scal[CGS_ALPHA] = scal[CGS_RHO] / v;
+    } else {
+        const double its = scal[CGS_ITERS] + 1.0;
+        scal[CGS_ITERS] = its;
+        if (sqrt(v) < scal[CGS_ATOL]) scal[CGS_DONE] = 1.0;
+        else if (its >= scal[CGS_MAXITER]) scal[CGS_DONE] = 2.0;
+        else scal[CGS_BETA] = v / scal[CGS_RHO];
+        scal[CGS_RHO] = v;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_sum_parts(const double* __restrict__ part, int nb, double* __restrict__ out) {

@@ -177,6 +177,46 @@ def test_vdp_ensemble_vs_golden():
         assert L.prob.work_counters['rhs'].niter == sum(int(cases[n]['work_rhs'][-1]) for n in names)
 
 
+def test_vdp_spread_predictor_is_put_off_until_somebody_reads_it():
+    """the node copies of a spread predictor (core/sweeper.py:129-143) are not written for the ensemble either: the first
+    sweep reads u[0] alone.  Reading them before the sweep delivers u[0] and f(u[0]) at every node; sweeping afterwards
+    gives the same iterate and counts as sweeping at once."""
+    from pysdc_amd.level import Step
+    from pysdc_amd.problems import vanderpol_ensemble
+    from pysdc_amd.sweepers import generic_implicit
+
+    rng = np.random.default_rng(2)
+    u0 = rng.uniform(-2, 2, size=(2, 777))
+    desc = dict(problem_class=vanderpol_ensemble, problem_params=dict(ntraj=777, u0=u0, mu=5.0, newton_tol=1e-9),
+                sweeper_class=generic_implicit, sweeper_params=dict(num_nodes=5, quad_type='RADAU-RIGHT', QI='LU'),
+                level_params=dict(dt=0.05), step_params=dict(maxiter=4))
+    out = []
+    for peek in (False, True):
+        L = Step(desc).levels[0]
+        L.status.time = 0.0
+        L.u[0] = L.prob.u_exact(0.0)
+        L.sweep.predict()
+        L.sweep.update_nodes()            # (the first sweep of a level creates the views of the node fields: addresses are
+        L.engine.profile_enable(True)     # handed out, so everything deferred is written once - not part of what is counted)
+        newton0, rhs0 = L.prob.work_counters['newton'].niter, L.prob.work_counters['rhs'].niter
+        L.sweep.predict()
+        if peek:
+            f0 = np.stack([u0[1], 5.0 * (1 - u0[0] ** 2) * u0[1] - u0[0]])
+            for m in range(1, 6):
+                assert np.array_equal(np.asarray(L.u[m]), u0)
+                np.testing.assert_allclose(np.asarray(L.f[m]), f0, rtol=1e-15, atol=0)
+        L.sweep.compute_residual()
+        res0 = L.status.residual
+        L.sweep.update_nodes()
+        L.sweep.compute_residual()
+        prof = L.engine.profile_read()
+        assert ('spread' in prof) == peek, prof.keys()
+        out.append((res0, L.status.residual, np.stack([np.asarray(L.u[m]) for m in range(6)]),
+                    L.prob.work_counters['newton'].niter - newton0, L.prob.work_counters['rhs'].niter - rhs0))
+    assert out[0][0] == out[1][0] and out[0][1] == out[1][1]
+    assert np.array_equal(out[0][2], out[1][2]) and out[0][3:] == out[1][3:]
+
+
 @pytest.mark.parametrize('ntraj', [9, 200])
 def test_vdp_mfma_block_solver_vs_golden(ntraj):
     """the Newton block solves on the matrix cores (v_mfma_f64_4x4x4, two trajectories per block): the nine golden
