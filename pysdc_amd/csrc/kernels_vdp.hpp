@@ -80,13 +80,12 @@ __device__ __forceinline__ void vdp_add_counters(unsigned long long* counters, u
 #define SDC_VDP_KEEP_NODES 1  // 0: node values re-read instead of held (150 instead of 160 VGPRs; measured 0.757 vs 0.736 ms)
 #endif
 #ifndef SDC_VDP_WAVES
-#define SDC_VDP_WAVES 0  // > 0: waves per SIMD the sweep kernel is compiled for (register budget 512 / waves)
+#define SDC_VDP_WAVES 0  // > 0: waves per SIMD the sweep kernel is compiled for (register budget 512 / waves) whatever M
 #endif
-#if SDC_VDP_WAVES > 0
-#define VDP_BOUNDS __launch_bounds__(256, SDC_VDP_WAVES)
-#else
-#define VDP_BOUNDS __launch_bounds__(256)
-#endif
+// Default: 4 waves per SIMD up to M = 5 (128 registers, a few spilled: 0.480 -> 0.468 ms per sweep of 1e7 trajectories once the
+// counter atomics were out of the way - with them in it, round 3 had measured this setting as a loss), the compiler's choice
+// above (160+ registers at M = 5 already).
+#define VDP_BOUNDS __launch_bounds__(256, SDC_VDP_WAVES > 0 ? SDC_VDP_WAVES : (M <= 5 ? 4 : 1))
 template <int M, bool LAZYF>
 __global__ VDP_BOUNDS void k_vdp_sweep(VdpSweepArgs a) {
 #pragma clang fp contract(off)

@@ -1879,7 +1879,14 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
                 a.Q[m][j] = dt * c->Q[m + 1][j + 1];
                 a.QI[m][j] = dt * c->QI[m + 1][j + 1];
             }
-        const int grid = grid_for(a.T, 256);
+#ifndef SDC_VDP_FULL_GRID
+#define SDC_VDP_FULL_GRID 0  // 1: one trajectory per thread (no grid-stride loop)
+#endif
+#ifndef SDC_VDP_GRID_CAP
+#define SDC_VDP_GRID_CAP 4096  // workgroups of the sweep launch at most (grid-stride loop over the trajectories)
+#endif
+        int grid = SDC_VDP_FULL_GRID ? (int)((a.T + 255) / 256) : grid_for(a.T, 256);
+        if (!SDC_VDP_FULL_GRID && grid > SDC_VDP_GRID_CAP) grid = SDC_VDP_GRID_CAP;
         // F[1..M] = f(U[1..M]) unless somebody overwrote an F field (force_gather): recompute instead of reading,
         // and leave the new values to sdc_materialize
         if (c->force_gather) {
