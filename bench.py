@@ -56,6 +56,9 @@ def _kernel_bytes(name, n, M, ncomp=1):
         **{f'spec_z_v{r}': (1 + nf) * spec for r in ('0', '1', '2', '3', '4', '5', '6', '7+')},   # (the iterate itself out)
         # long runs of sweeps: the real node multipliers of a mode pair (nf doubles per two modes) are read from a table,
         # advanced by one sweep and written back instead of being recomputed by replaying every earlier sweep
+        # the sweep expected to be the last of its step also writes the last node's spectrum (end value / next start value)
+        'spec_z_res_last': (2 + nf) * spec,
+        'spec_z_last': (2 + nf) * spec,
         'spec_z_res_tab': (1 + nf) * spec + nf * spec / 2,
         'spec_z_tab': (1 + nf) * spec + nf * spec / 2,
         'spec_store': (1 + nf) * spec,                      # ... and its transforms written out when somebody needs them
@@ -401,7 +404,7 @@ def run_workload(args, world, rank, use_dist, with_stream_reference=True):
                     'ms_per_launch': dom[1][0] / dom[1][1],
                     'stream_reference_gbs': stream_reference(torch, eng) if with_stream_reference else None}
         in_sweep = ('gather', 'fft_x_fwd', 'fft_y_fwd', 'fft_z_fwd', 'fft_z_solve', 'spec_point', 'spec_point_res', 'spec_point_only', 'spec_z', 'spec_z_res', 'spec_z_spread', 'spec_z_res_spread',
-                    'spec_z_res_v0', 'spec_z_res_v1', 'spec_z_res_v2', 'spec_z_res_v3', 'spec_z_res_v4', 'spec_z_res_v5', 'spec_z_res_v6', 'spec_z_res_v7+', 'spec_store', 'spec_z_res_tab', 'spec_z_tab',
+                    'spec_z_res_v0', 'spec_z_res_v1', 'spec_z_res_v2', 'spec_z_res_v3', 'spec_z_res_v4', 'spec_z_res_v5', 'spec_z_res_v6', 'spec_z_res_v7+', 'spec_store', 'spec_z_res_tab', 'spec_z_tab', 'spec_z_res_last', 'spec_z_last',
                     'spec_z_v0', 'spec_z_v1', 'spec_z_v2', 'spec_z_v3', 'spec_z_v4', 'spec_z_v5', 'spec_z_v6', 'spec_z_v7+',
                     'fft_x_norm', 'fft_x_inv_norm',
                     'fft_z_inv', 'fft_y_inv',

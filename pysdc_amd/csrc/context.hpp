@@ -80,6 +80,7 @@ struct sdc_ctx {
     // needs it (store_spectra).  sl_stored: the last node's spectrum has been written to SL all the same.
     int spec_virtual = 0, virt_max = 16;
     bool sl_stored = false;
+    int prev_sweeps = 0;  // sweeps the step before this one took (its last sweep wrote SL itself: sdc_sweep, store_last)
     // Long runs of sweeps (mode pairs): from the g_from-th sweep of a step on the node multipliers are kept in a table
     // (Gm, M doubles per mode pair) and advanced by one sweep per launch instead of being recomputed from 1 every time;
     // g_sweeps = the sweeps its content stands for (with the coefficients vcoef), 0 = nothing in it.  g_from 0: no table.

@@ -598,6 +598,9 @@ struct SpecArgs {
     // multipliers of the previous iterate from the table, does one sweep on them and writes them back (no replay).
     double* G;
     int gmode;
+    // mode-pair launches: the last node's spectrum of the NEW iterate goes to SL on the way (what k_spec_store_pairs would
+    // write with last_only: the end value / next start value) - the launch has its multipliers in registers
+    int store_last;
 };
 
 // one thread per Fourier mode: gather on the cached transforms + node-coupled solve, S updated in place.
@@ -1012,6 +1015,13 @@ void k_spec_z(SpecArgs a, unsigned nlines) {
                 }
             } else {
                 virt_multipliers_real<NF>(a, lam, a.replay + 1, g);
+            }
+            if (a.store_last) {
+                const int p_ = threadIdx.x + it * NT;
+                if (p_ < NI && ok) {
+                    a.SL[base + p_] = cd{g[NF - 1] * lo[it].x, g[NF - 1] * lo[it].y};
+                    if (p_ >= 1 && p_ < N / 2) a.SL[base + N - p_] = cd{g[NF - 1] * hi[it].x, g[NF - 1] * hi[it].y};
+                }
             }
             if (a.virt == 2) {  // the iterate itself is wanted in real space (node values stored by every sweep)
 #pragma unroll

@@ -556,7 +556,8 @@ static int spec_sweep_n(sdc_ctx* c, int nf, SpecArgs& a, const FieldPtrs& p, uns
                                                      "spec_z_res_v4", "spec_z_res_v5", "spec_z_res_v6", "spec_z_res_v7+"};
                 static const char* const inames[] = {"spec_z_v0", "spec_z_v1", "spec_z_v2", "spec_z_v3",
                                                      "spec_z_v4", "spec_z_v5", "spec_z_v6", "spec_z_v7+"};
-                const char* zbase = a.virt && a.gmode == 2 ? (a.virt == 2 ? "spec_z_tab" : "spec_z_res_tab")
+                const char* zbase = a.virt && a.store_last ? (a.virt == 2 ? "spec_z_last" : "spec_z_res_last")
+                                    : a.virt && a.gmode == 2 ? (a.virt == 2 ? "spec_z_tab" : "spec_z_res_tab")
                                     : a.virt == 2 ? inames[a.replay < 7 ? a.replay : 7]
                                     : a.virt ? vnames[a.replay < 7 ? a.replay : 7]
                                              : norms ? (a.spread ? "spec_z_res_spread" : "spec_z_res")
@@ -1851,6 +1852,9 @@ static int sweep_nodewise(sdc_ctx* c, double dt, bool keep_guess = false) {
     return SDC_OK;
 }
 
+#ifndef SDC_STORE_LAST_IN_SWEEP
+#define SDC_STORE_LAST_IN_SWEEP 1
+#endif
 int sdc_sweep(sdc_ctx* c, double t, double dt) {
     (void)t;
     if (!c) return SDC_ERR_PARAM;
@@ -2086,7 +2090,12 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
                 a.virt = iter_out ? 2 : 1;
                 c->spec_virtual = a.replay + 1;
                 if (a.gmode && !spec_only) c->g_sweeps = c->spec_virtual;
-                c->sl_stored = false;
+                // the step before took as many sweeps as this one is about to have had: probably the last of the step - its
+                // launch writes the last node's spectrum on the way (one store per mode of a launch bound by arithmetic)
+                // instead of leaving it to spec_store_last (S0 read and the multipliers recomputed: 4.2 ms at 1024^3)
+                a.store_last = (pairs_z && !spec_only && a.gmode == 0 && c->prev_sweeps > 0 &&
+                                c->spec_virtual == c->prev_sweeps && SDC_STORE_LAST_IN_SWEEP) ? 1 : 0;
+                c->sl_stored = a.store_last != 0;
                 if (spec_only) {  // no residual wanted: nothing to launch at all - the sweep is remembered
                     c->spec_gen++;
                     c->spec_valid = true;
@@ -2659,6 +2668,7 @@ int sdc_advance(sdc_ctx* c) {
     c->spec_spread = false;
     // UEND is the inverse transform of the last node's spectrum: that spectrum is the transform of the new u[0]
     const bool handover = c->S && c->spec_valid && c->uend_gen >= 0 && c->uend_gen == c->spec_gen;
+    c->prev_sweeps = (c->spec_valid && c->spec_virtual > 0) ? c->spec_virtual : 0;
     if (handover) STORE_SPECTRA(c, true);  // (SL has to BE there; S0 changes below)
     if (handover && c->uend_pending && c->kind == 0 && c->deferred) {
         // the end value was never transformed back: the start value of the new step exists as its transform only

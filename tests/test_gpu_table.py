@@ -105,3 +105,41 @@ def test_table_is_dropped_when_the_step_size_changes():
         t += dt
     e.close()
     f.close()
+
+
+def test_last_sweep_of_a_step_writes_the_end_spectrum_itself():
+    """steps of equal length: from the second step on the launch of the sweep that the step before ended with also writes
+    the last node's spectrum (end value / next start value) - no spec_store_last launch any more, same values as the engine
+    that stores every iterate"""
+    nvars, M, K, steps = (512, 512), 3, 4, 4
+    dt = 315.0 / (0.1 * 8 * 512 * 512)
+    e = _engine(nvars, M)
+    f = _engine(nvars, M)
+    f.set_virtual_sweeps(0)
+    u0 = G.profile_for(nvars, 2) + 1e-3 * np.random.default_rng(3).standard_normal(nvars)
+    for eng in (e, f):
+        eng.upload(L.SLOT_U, 0, u0)
+    e.profile_enable(True)
+    t = 0.0
+    for step in range(steps):
+        for eng in (e, f):
+            eng.predict(t, dt, 'spread')
+            for _ in range(K if step != 2 else K + 1):    # (one step takes a sweep more: the guess is wrong there)
+                eng.sweep(t, dt)
+        ra, rb = e.residual(dt, 'full_abs')[0], f.residual(dt, 'full_abs')[0]
+        assert abs(ra - rb) <= 1e-9 * abs(rb) + 1e-15
+        for eng in (e, f):
+            eng.end_point(dt, False)
+        if step % 2:                                           # (the end value is looked at, or only handed over)
+            ua, ub = e.download(L.SLOT_UEND), f.download(L.SLOT_UEND)
+            np.testing.assert_allclose(ua, ub, rtol=0, atol=1e-13 * np.max(np.abs(ub)))
+        for eng in (e, f):
+            eng.advance()
+        t += dt
+    np.testing.assert_allclose(e.download(L.SLOT_U, 0), f.download(L.SLOT_U, 0), rtol=0, atol=1e-13 * np.max(np.abs(u0)))
+    prof = {k.split('[')[0]: v for k, v in e.profile_read().items()}
+    # step 0: no guess (spec_store_last); step 1: guessed 4, right; step 2: guessed 4, took 5 (the fourth launch wrote a
+    # spectrum that the fifth made stale: spec_store_last again); step 3: guessed 5, took 4 (spec_store_last)
+    assert prof['spec_z_res_last'][1] == 2 and prof['spec_store_last'][1] == 3, prof
+    e.close()
+    f.close()
