@@ -214,6 +214,10 @@ def run_workload(args, world, rank, use_dist, with_stream_reference=True):
     from pysdc_amd.problems import heatNd_unforced, advectiondiffusionNd_imex, vanderpol_ensemble, allencahn_imex
     from pysdc_amd.transfer import mesh_to_mesh
     from pysdc_amd.sweepers import generic_implicit, imex_1st_order
+    import pysdc_amd.level as _level
+    if not hasattr(_level, '_LAZY_DEFAULT'):
+        _level._LAZY_DEFAULT = _level.LAZY_PREDICTOR_RESIDUAL   # (the environment's choice; sub-records switch back and forth)
+    _level.LAZY_PREDICTOR_RESIDUAL = _level._LAZY_DEFAULT and not args.eager_predictor_residual
     from pysdc_amd.stats import get_sorted
 
     M, K = args.nodes, (args.sweeps if args.restol < 0 else 50)
@@ -438,7 +442,9 @@ def run_workload(args, world, rank, use_dist, with_stream_reference=True):
             'config': {'workload': f'{wl}{fallback_note}, ' + (f'{K} sweeps/step (restol=-1, maxiter={K})' if args.restol < 0 else f'restol={args.restol:g} (maxiter={K})') + f', dt={dt:g}, '
                                    f'solver={"direct (Fourier)" if args.solver_type == "direct" else "CG rtol 1e-12 on the device"}, spectral_reuse={not args.no_spectral_reuse}, '
                                    f'deferred_node_fields={not args.eager_fields}'
-                                   + (', skip_residual_computation=all stages' if args.skip_residual else ''),
+                                   + (', skip_residual_computation=all stages' if args.skip_residual else '')
+                                   + (', residual of the predictor\'s state evaluated when read (restol < 0: nobody reads it)'
+                                      if (_level.LAZY_PREDICTOR_RESIDUAL and args.restol < 0) else ''),
                        'time_parallel': f'{world} time-slice(s), one per GPU, multi-step SDC '
                                         f'({"Jacobi" if args.mssdc == "jacobi" else "Gauss-Seidel"})'},
             'sdc_iters_per_s': units * sweeps_total / el,
@@ -473,6 +479,8 @@ def extras(args):
 
     plan = [('heat 1024^3, every sweep stores U and F like the reference\'s update_nodes (--eager-fields)',
              dict(eager_fields=True, steps=3, warmup=1)),
+            ("heat 1024^3, the residual of the predictor's state computed when compute_residual is called, as the reference "
+             "does (--eager-predictor-residual), not when somebody reads it", dict(eager_predictor_residual=True, steps=3, warmup=1)),
             ('heat 1024^3, iterate to restol 1e-10 (maxiter 50)', dict(restol=1e-10, steps=2, warmup=1)),
             ('heat 1024^3, diagonal QDelta MIN-SR-S (node-parallel preconditioner; SURVEY 8d)', dict(qi='MIN-SR-S', steps=3, warmup=1)),
             ('heat 1024^3, z / y passes of every sweep pipelined over 32 groups of kx planes on two streams (wall clock only: '
@@ -644,6 +652,9 @@ def main():
     ap.add_argument('--multiplier-table', type=int, default=None,
                     help='sdc_set_multiplier_table: first sweep of a step that takes the node multipliers of a mode pair from '
                          'the table instead of replaying the earlier sweeps (0: never; default: the engine\'s, 8)')
+    ap.add_argument('--eager-predictor-residual', action='store_true',
+                    help='compute the residual of the state the spread predictor leaves when compute_residual is called (like the '
+                         'reference) instead of when somebody reads L.status.residual - with restol < 0 nobody does')
     ap.add_argument('--pipeline-groups', type=int, default=0,
                     help='sdc_set_pipeline_groups: issue the z / y passes of a sweep in this many groups of kx planes, the y '
                          'pass of a group on a second stream (launches that share the GPU have no durations of their own: the '

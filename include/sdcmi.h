@@ -129,6 +129,14 @@ int sdc_set_virtual_sweeps(sdc_ctx* ctx, int max_sweeps);
  * at max_sweeps.  Same arithmetic in the same order as the replay.  Used when the replayed sweeps get that far
  * (max_sweeps > from_sweep) and the table can be allocated; from_sweep 0: never (default 8: where one more replayed sweep costs what the table traffic does at 1024^3). */
 int sdc_set_multiplier_table(sdc_ctx* ctx, int from_sweep);
+/* The residual of the state a 'spread' predictor leaves (core/sweeper.py:164-215 with every node equal to u[0]) is
+ * dt |sum_j Q[m][j]| max|f(u[0])|.  When u[0] exists as its transform only (the step before handed it over in Fourier space),
+ * max|f(u[0])| costs a norm-only inverse transform of one field.  on = 1: sdc_predict puts that transform off until
+ * sdc_residual is called for this state; sdc_residual_deferred returns 1 while a call of sdc_residual would have to do it, so
+ * that a caller whose convergence test cannot depend on the value (controller_nonMPI.py:493 with restol < 0,
+ * check_convergence.py:60-92) may postpone the call until somebody reads L.status.residual.  Default 0: computed by sdc_predict. */
+int sdc_set_lazy_predictor_residual(sdc_ctx* ctx, int on);
+int sdc_residual_deferred(sdc_ctx* ctx);
 /* A Fourier-space sweep that only delivers residual norms is three launches: the pointwise sweep fused with the inverse pass
  * along the contiguous axis (bound by its f64 arithmetic), the in-place pass along the middle axis (bound by memory), the
  * norm-only pass along the first axis.  With groups > 1 the first two are issued per group of kx planes, the middle-axis pass

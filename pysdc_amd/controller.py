@@ -41,7 +41,10 @@ def check_convergence(S):
     """check_convergence.py:60-92 (residual / maxiter rule; e_tol belongs to an optional plug-in)."""
     L = S.levels[0]
     iter_converged = S.status.iter >= S.params.maxiter
-    res_converged = L.status.residual <= L.params.restol and (S.status.iter > 0 or L.status.sweep > 0)
+    # (restol < 0: no residual - a max norm, or nan - can be below it; the attribute is not even read then, and a residual
+    # that was put off until somebody reads it stays put off: level.LevelStatus)
+    res_converged = (L.params.restol >= 0 and L.status.residual <= L.params.restol
+                     and (S.status.iter > 0 or L.status.sweep > 0))
     converged = (iter_converged or res_converged or bool(S.status.force_done)) and not S.status.force_continue
     return bool(converged)
 

@@ -73,6 +73,8 @@ struct sdc_ctx {
     // value of the new step may exist as its spectrum S0 only (u0_spec_only) - the predictor's residual then takes
     // max |f(u0)| from the norm-only inverse transform of symbol * S0 instead of a stencil pass over u0.
     bool uend_pending = false, u0_spec_only = false;
+    // ... and that norm itself waits until the residual of the predictor's state is asked for (sdc_set_lazy_predictor_residual)
+    bool lazy_f0norm = false, f0norm_pending = false;
     int u0_rc = SDC_OK;  // why u0r() could not deliver the start value
     bool spec_valid = false, spec0_valid = false, spec_spread = false, reuse = true, force_gather = false;
     // Iterates that are not stored: spec_virtual > 0 (while spec_valid) = the cached iterate is the result of that many

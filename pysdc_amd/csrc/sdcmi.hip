@@ -1533,6 +1533,17 @@ int sdc_set_virtual_sweeps(sdc_ctx* c, int max_sweeps) {
     return SDC_OK;
 }
 
+int sdc_set_lazy_predictor_residual(sdc_ctx* c, int on) {
+    if (!c) return SDC_ERR_PARAM;
+    c->lazy_f0norm = on != 0;
+    return SDC_OK;
+}
+
+int sdc_residual_deferred(sdc_ctx* c) {
+    if (!c) return SDC_ERR_PARAM;
+    return (c->res_spread && c->f0norm_pending && !c->res_valid) ? 1 : 0;
+}
+
 int sdc_set_multiplier_table(sdc_ctx* c, int from_sweep) {
     if (!c || from_sweep < 0) return fail(c, SDC_ERR_PARAM, "multiplier table: first sweep that uses it (0: never)");
     c->g_from = from_sweep;
@@ -1671,6 +1682,7 @@ int sdc_predict(sdc_ctx* c, double t, double dt, int guess, double fill_u, doubl
     const bool spread_res = guess == SDC_GUESS_SPREAD && c->expl_kind != SDC_EXPL_FORCING && !c->tau_active;
     if (spread_res) HIPCHK(c, hipMemsetAsync(c->res_dev, 0, sizeof(unsigned long long) * 8, c->stream));
     c->spread_pending = c->f_pending = c->u_pending = c->f0_pending = c->rfields_valid = false;
+    c->f0norm_pending = false;
     // (van der Pol ensemble: the first sweep reads U[0] alone, sdc_sweep)
     const bool lazy_spread = c->deferred && (c->kind == 0 || (c->kind == 1 && !c->tau_active)) && guess == SDC_GUESS_SPREAD &&
                              c->expl_kind != SDC_EXPL_FORCING;
@@ -1684,9 +1696,15 @@ int sdc_predict(sdc_ctx* c, double t, double dt, int guess, double fill_u, doubl
     int rc = SDC_OK;
     bool f0_max_done = false;
     if (f0_by_norm && c->u0_spec_only && c->spec0_valid && c->S0 && c->expl_kind != SDC_EXPL_FORCING) {
-        // the start value exists as its transform only: max |f(u0)| from the norm-only inverse transform of symbol * S0
-        rc = symbol_norm(c, c->S0, c->res_dev + 7);
-        if (rc != SDC_OK) return rc;
+        // the start value exists as its transform only: max |f(u0)| from the norm-only inverse transform of symbol * S0 -
+        // when somebody asks for the residual of the predictor's state (sdc_residual; sdc_residual_deferred tells whether
+        // asking costs that transform): three passes over one field that a run with fixed sweep counts never needs
+        if (c->lazy_f0norm) {
+            c->f0norm_pending = true;
+        } else {
+            rc = symbol_norm(c, c->S0, c->res_dev + 7);
+            if (rc != SDC_OK) return rc;
+        }
         c->f0_pending = true;
     } else if (f0_by_norm) {
         constexpr int RPT = 4;
@@ -2555,6 +2573,13 @@ int sdc_residual(sdc_ctx* c, double dt, int type, double* node_norms, double* re
         // the sweep's fused eval_f kernel already reduced the node norms of this very state
         HIPCHK(c, hipMemcpyAsync(c->red, c->res_dev, sizeof(unsigned long long) * 8, hipMemcpyDeviceToDevice, c->stream));
     } else if (c->res_spread) {
+        if (c->f0norm_pending) {  // (put off by sdc_predict; res_spread: no sweep since - S0 and the work buffer are as it left them)
+            c->f0norm_pending = false;
+            if (!(c->spec0_valid && c->S0)) return fail(c, SDC_ERR_STATE, "the transform of u[0] is gone: predict again");
+            HIPCHK(c, hipMemsetAsync(c->res_dev + 7, 0, sizeof(unsigned long long), c->stream));
+            int rcn = symbol_norm(c, c->S0, c->res_dev + 7);
+            if (rcn != SDC_OK) return rcn;
+        }
         HIPCHK(c, hipMemcpyAsync(c->red + 7, c->res_dev + 7, sizeof(unsigned long long), hipMemcpyDeviceToDevice, c->stream));
         from_spread = true;
     } else if (c->u_pending && !c->spread_pending && c->spec_valid && !c->tau_active && c->ndim >= 2) {

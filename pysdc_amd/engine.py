@@ -112,6 +112,17 @@ class SweepEngine:
         """first sweep of a step that takes the node multipliers from a table instead of replaying earlier sweeps (0: never)"""
         self._chk(self.lib.sdc_set_multiplier_table(self.ctx, int(from_sweep)))
 
+    def set_lazy_predictor_residual(self, on):
+        """sdc_predict puts the norm-only transform behind the residual of a spread state off until sdc_residual asks for it"""
+        self._chk(self.lib.sdc_set_lazy_predictor_residual(self.ctx, int(bool(on))))
+
+    def residual_deferred(self):
+        """True while residual() would have to do that transform first (include/sdcmi.h: sdc_residual_deferred)"""
+        rc = self.lib.sdc_residual_deferred(self.ctx)
+        if rc < 0:
+            self._chk(rc)
+        return rc == 1
+
     def set_pipeline_groups(self, groups):
         """z / y passes of a norm-only sweep issued in this many groups of kx planes on two streams (-1 default, 0 off)"""
         self._chk(self.lib.sdc_set_pipeline_groups(self.ctx, int(groups)))

@@ -2,6 +2,7 @@
 on top of device slabs: ``L.u[m]``, ``L.f[m]``, ``L.tau[m]``, ``L.uend`` are views into the SweepEngine's
 U / F / TAU / UEND slabs; assigning to them copies into the slab (SURVEY.md 8b "Level/data surface")."""
 import logging
+import os
 
 import numpy as np
 
@@ -9,6 +10,11 @@ from pysdc_amd import lib as Lb
 from pysdc_amd.engine import SweepEngine
 from pysdc_amd.errors import ParameterError
 from pysdc_amd.hip_mesh import hip_mesh, hip_imex_mesh
+
+
+# The residual of the state a spread predictor leaves is evaluated when somebody reads L.status.residual (0 in the environment
+# variable: when compute_residual is called, like every other residual)
+LAZY_PREDICTOR_RESIDUAL = os.environ.get('PYSDC_AMD_LAZY_RESIDUAL', '1') != '0'
 
 
 class _Frozen:
@@ -31,15 +37,45 @@ class LevelParams(_Frozen):
 
 
 class LevelStatus(_Frozen):
-    """pySDC/core/level.py:24-39."""
+    """pySDC/core/level.py:24-39.  ``residual`` may be handed a callable instead of a number: it is then evaluated when
+    somebody reads the attribute (the residual of a predictor's state that no convergence test can depend on,
+    sweepers.compute_residual) - readers never see anything but the number."""
 
     def __init__(self):
-        self.residual = None
+        self._residual = None
         self.unlocked = False
         self.updated = False
         self.time = None
         self.dt_new = None
         self.sweep = None
+
+    @property
+    def residual(self):
+        r = self._residual
+        if callable(r):
+            self._residual = None     # (a thunk that fails is not called again)
+            r = self._residual = r()
+        return r
+
+    @residual.setter
+    def residual(self, value):
+        self._residual = value
+
+    def residual_is_deferred(self):
+        return callable(self._residual)
+
+    def drop_deferred_residual(self):
+        """the state the put-off residual belongs to is about to change (a sweep, a new predictor): nobody has asked"""
+        if callable(self._residual):
+            self._residual = None
+
+    def get(self, key, default=None):
+        return self.residual if key == 'residual' else self.__dict__.get(key, default)
+
+    def __getstate__(self):          # (copies / pickles carry the number, not a closure over the engine)
+        d = dict(self.__dict__)
+        d['_residual'] = self.residual
+        return d
 
 
 class SlabList:
@@ -145,6 +181,11 @@ class DeviceBacked:
             if nvars is None:
                 raise ParameterError('problem does not define nvars: cannot create device slabs')
             self._engine_obj = SweepEngine(getattr(P, 'engine_nvars', nvars), M, getattr(P, 'ncomp', 1))
+            # a status object that can hold a put-off residual (the product's own Level): the engine may put the norm behind
+            # the predictor's residual off until it is asked for
+            st = getattr(self, 'status', None)
+            if isinstance(st, LevelStatus) and LAZY_PREDICTOR_RESIDUAL:
+                self._engine_obj.set_lazy_predictor_residual(True)
             P.bind_engine(self._engine_obj)
             self._db_sweep().push_coeffs(self._engine_obj)
         return self._engine_obj

@@ -46,6 +46,8 @@ PROTOTYPES = {
     'sdc_set_skip_residual': (C.c_int, [_vp, C.c_int]),
     'sdc_set_virtual_sweeps': (C.c_int, [_vp, C.c_int]),
     'sdc_set_multiplier_table': (C.c_int, [_vp, C.c_int]),
+    'sdc_set_lazy_predictor_residual': (C.c_int, [_vp, C.c_int]),
+    'sdc_residual_deferred': (C.c_int, [_vp]),
     'sdc_set_pipeline_groups': (C.c_int, [_vp, C.c_int]),
     'sdc_set_deferred': (C.c_int, [_vp, C.c_int]),
     'sdc_set_solver': (C.c_int, [_vp, C.c_int, C.c_double, C.c_int]),

@@ -162,6 +162,8 @@ class Sweeper:
                 # the reference draws one scalar per node and field (sweeper.py:155-156); the engine fills all
                 # nodes with one pair, so draw node by node on the generic path instead
                 return self._predict_generic()
+            if hasattr(L.status, 'drop_deferred_residual'):
+                L.status.drop_deferred_residual()
             e.predict(L.time, L.dt, guess, fu, ff)
             D.u.mark(range(M + 1))
             D.f.mark(range(M + 1))
@@ -207,13 +209,22 @@ class Sweeper:
             # the device state is unchanged since the last evaluation -> same value, no second pass
             # (the controller calls this twice per iteration)
             D = self._dev()
+
+            def evaluate(D=D, rt=rt, dt=L.dt):
+                res, norms = D.engine.residual(dt, rt)
+                D._res_cache = ((rt, dt), res)
+                D.publish_residual_norms(norms)  # node-wise max norms; the M residual vectors are not materialised
+                return res
+
             if D._res_cache is not None and D._res_cache[0] == (rt, L.dt):
                 L.status.residual = D._res_cache[1]
+            elif (L.params.restol < 0 and hasattr(L.status, 'residual_is_deferred')
+                  and getattr(D.engine, 'residual_deferred', lambda: False)()):
+                # the state a spread predictor left, its norm not computed yet (include/sdcmi.h: sdc_residual_deferred), and a
+                # convergence test that cannot depend on the value (restol < 0): evaluated when somebody reads the attribute
+                L.status.residual = evaluate
             else:
-                res, norms = D.engine.residual(L.dt, rt)
-                L.status.residual = res
-                D._res_cache = ((rt, L.dt), res)
-                D.publish_residual_norms(norms)  # node-wise max norms; the M residual vectors are not materialised
+                L.status.residual = evaluate()
         else:
             res_norm = []
             L.residual = self.integrate()
@@ -263,6 +274,8 @@ class Sweeper:
             raise ParameterError('update_nodes needs values at all nodes (predict first)')
         self._push_forcing()
         D.engine.set_unlocked(True)
+        if hasattr(L.status, 'drop_deferred_residual'):
+            L.status.drop_deferred_residual()   # (belongs to the state this sweep replaces)
         # skip_residual_computation covering every stage that follows a sweep: the engine then only moves the iterate
         skip = _STAGES_AFTER_SWEEP <= set(self.params.skip_residual_computation)
         if skip != self._skip_sent:

@@ -228,6 +228,12 @@ class HostEngine:
         self._store(L)
         self._t, self._dt = t, dt
 
+    def set_lazy_predictor_residual(self, on):
+        pass      # (nothing is put off on the host)
+
+    def residual_deferred(self):
+        return False
+
     def residual(self, dt, residual_type='full_abs'):
         self.calls.append('residual')
         L = self._level(getattr(self, '_t', 0.0), dt)

@@ -143,3 +143,52 @@ def test_last_sweep_of_a_step_writes_the_end_spectrum_itself():
     assert prof['spec_z_res_last'][1] == 2 and prof['spec_store_last'][1] == 3, prof
     e.close()
     f.close()
+
+
+def test_residual_of_the_predictors_state_is_evaluated_when_it_is_read():
+    """steps that hand their end value over in Fourier space: max|f(u0)| behind the residual of the spread state would cost a
+    norm-only transform of one field per step.  With restol < 0 no convergence test can depend on it: compute_residual
+    leaves a thunk in L.status.residual (pysdc_amd.level.LevelStatus), the transform runs if somebody reads the attribute
+    - and then delivers the value the engine computes at once without the switch."""
+    from pysdc_amd.controller import controller_nonMPI
+    from pysdc_amd.problems import heatNd_unforced
+    from pysdc_amd.sweepers import generic_implicit
+    import pysdc_amd.level as LV
+
+    n, dt = 64, 1e-3
+    desc = dict(problem_class=heatNd_unforced, problem_params=dict(nvars=(n, n, n), nu=0.1, freq=2, order=2),
+                sweeper_class=generic_implicit, sweeper_params=dict(num_nodes=3, quad_type='RADAU-RIGHT', QI='IE'),
+                level_params=dict(dt=dt, restol=-1.0, nsweeps=1), step_params=dict(maxiter=3))
+    seen = {}
+    saved = LV.LAZY_PREDICTOR_RESIDUAL
+    try:
+        for lazy in (True, False):
+            LV.LAZY_PREDICTOR_RESIDUAL = lazy
+            C = controller_nonMPI(1, dict(logger_level=40), desc)
+            Lv = C.MS[0].levels[0]
+            u0 = Lv.prob.u_exact(0.0)
+            C.run(u0, 0.0, 2 * dt)                      # two steps: the third starts from a spectrum
+            eng = Lv.engine
+            Lv.status.time = 2 * dt
+            eng.profile_enable(True)
+            Lv.sweep.predict()                          # (without the switch the engine computes the norm here)
+            Lv.sweep.compute_residual(stage='IT_CHECK')
+            assert Lv.status.residual_is_deferred() == lazy
+            names = {k.split('[')[0] for k in eng.profile_read()}
+            assert ('fft_z_sym' in names) == (not lazy), names
+            first = Lv.status.residual                   # somebody reads it
+            assert isinstance(first, float) and first > 0 and not Lv.status.residual_is_deferred()
+            assert Lv.status.residual == first
+            names = {k.split('[')[0] for k in eng.profile_read()}
+            assert 'fft_z_sym' in names, names
+            Lv.sweep.update_nodes()
+            Lv.sweep.compute_residual(stage='IT_FINE')
+            seen[lazy] = (first, Lv.status.residual)
+            # a put-off residual nobody asked for is dropped by the sweep that replaces its state
+            Lv.sweep.predict()
+            Lv.sweep.compute_residual(stage='IT_CHECK')
+            Lv.sweep.update_nodes()
+            assert not Lv.status.residual_is_deferred()
+    finally:
+        LV.LAZY_PREDICTOR_RESIDUAL = saved
+    assert seen[True] == seen[False], seen
