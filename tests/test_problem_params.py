@@ -31,3 +31,33 @@ def test_accepted_and_normalised():
     assert _grid_spec((16, 16, 16), 4, 'periodic') == ((16, 16, 16), (4, 4, 4), 'periodic')
     assert _grid_spec(63, 3, 'dirichlet-zero') == ((63,), (3,), 'dirichlet-zero')     # odd frequencies are fine there
     assert _grid_spec(64, -1, 'dirichlet-zero') == ((64,), (-1,), 'periodic')          # 1-D Gaussian start value
+
+
+def test_level_status_holds_a_put_off_residual():
+    """pysdc_amd.level.LevelStatus.residual: a callable handed to it is evaluated once, when the attribute is read;
+    readers (comparisons, get, copies) only ever see the number"""
+    import copy
+    import pickle
+
+    from pysdc_amd.level import LevelStatus
+
+    calls = []
+
+    def thunk():
+        calls.append(1)
+        return 0.25
+
+    st = LevelStatus()
+    assert st.residual is None and not st.residual_is_deferred()
+    st.residual = thunk
+    assert st.residual_is_deferred() and not calls
+    assert st.residual <= 0.3 and st.residual == 0.25 and st.get('residual') == 0.25
+    assert calls == [1] and not st.residual_is_deferred()
+    st.residual = thunk
+    st.drop_deferred_residual()               # the state it belonged to is gone: nobody asked
+    assert st.residual is None and calls == [1]
+    st.residual = thunk
+    clone = pickle.loads(pickle.dumps(st))    # copies carry the number
+    assert clone.residual == 0.25 and calls == [1, 1]
+    st.residual = 1.5
+    assert copy.deepcopy(st).residual == 1.5 and st.get('unlocked') is False
