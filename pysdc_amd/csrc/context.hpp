@@ -75,6 +75,9 @@ struct sdc_ctx {
     bool uend_pending = false, u0_spec_only = false;
     // ... and that norm itself waits until the residual of the predictor's state is asked for (sdc_set_lazy_predictor_residual)
     bool lazy_f0norm = false, f0norm_pending = false;
+    // node norms of the residual that a sweep brought to the host together with its counters (valid with res_valid)
+    bool res_host_valid = false;
+    unsigned long long res_host[8] = {};
     int u0_rc = SDC_OK;  // why u0r() could not deliver the start value
     bool spec_valid = false, spec0_valid = false, spec_spread = false, reuse = true, force_gather = false;
     // Iterates that are not stored: spec_virtual > 0 (while spec_valid) = the cached iterate is the result of that many
