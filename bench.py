@@ -131,7 +131,9 @@ def _collect(proc, timeout=600):
 def cpu_baseline(M, dt_ref_n, target_n=1024, nsweeps=4, max_workers=32):
     """kind = "port": the oracle timed on the GPU box's host cores, on bounded samples of the same workload.
       * one core, 64^3, one time step (4 sweeps), and - beside it - one core, 128^3, ONE sweep: shows what the
-        linear-in-DOF extrapolation to the target size leaves out (CG iteration counts grow with the grid);
+        linear-in-DOF extrapolation to the target size leaves out (the cost per DOF grows with the grid - at constant
+        stiffness the CG iteration counts hardly do: 405 per sweep at 128^3, 406 at 256^3, where one sweep takes 78.5 s =
+        4.7e-6 s per DOF against 3.3e-6 at 128^3, profiles/r03/cpu_sample_256.json via scripts/cpu_sample.py);
       * many host cores: `cores` independent copies of the 64^3 sample at once (the reference's NumPy / SciPy path is
         single-threaded, so throughput over cores = independent time steps), value = cores / slowest copy.  At most 32:
         the sparse mat-vecs are bound by host memory bandwidth - on the 256-core GPU box 32 copies run 3 x slower each
@@ -152,7 +154,7 @@ def cpu_baseline(M, dt_ref_n, target_n=1024, nsweeps=4, max_workers=32):
     raw_one = 1.0 / r64['seconds']
     per_sweep_dof_64 = r64['seconds'] / (nsweeps * 64**3)
     per_sweep_dof_128 = r128['seconds'] / (1 * 128**3)
-    # the two one-core samples say how the cost per DOF grows with the grid (CG iterations per solve grow with n): continued
+    # the two one-core samples say how the cost per DOF grows with the grid (memory hierarchy; the iteration counts stay): continued
     # as a power law to the target size it gives a second, less flattering figure beside the linear-in-DOF `value`
     growth = per_sweep_dof_128 / per_sweep_dof_64
     alpha = math.log(max(growth, 1.0)) / math.log(2.0)
