@@ -1,0 +1,100 @@
+"""Edge sizes of the sweep path on the device against the oracle (oracle/sdc_oracle.py restating generic_implicit.py:51-103,
+core/sweeper.py:125-215): the smallest grids the reference accepts (an even number of points per periodic axis: 2, 4, ...),
+one node up to eight, the shortest and the longest lines of the transform kernels, and the default data flow (spectral
+reuse, deferred node fields) as well as the one that stores every field.  Tolerance 1e-10 relative (BASELINE.json), residual
+norms 1e-9."""
+import numpy as np
+import pytest
+
+from oracle import sdc_oracle as O
+from pysdc_amd import lib as L
+from pysdc_amd.coeffs import CollBase, QDELTA_GENERATORS
+from tests._cases import rel_err
+from tests import _gpu as G
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def _coll(M, qi, quad='RADAU-RIGHT'):
+    c = CollBase(M, 0, 1, 'LEGENDRE', quad)
+    QI = np.zeros_like(c.Qmat)
+    QI[1:, 1:] = QDELTA_GENERATORS[qi](qGen=c.generator, tLeft=0).genCoeffs()
+    return c, QI
+
+
+@pytest.mark.parametrize('deferred', [True, False])
+@pytest.mark.parametrize('nvars,M,qi', [((2,), 1, 'IE'), ((2,), 3, 'LU'), ((4,), 2, 'IE'), ((2, 2), 3, 'IE'), ((4, 4), 1, 'LU'),
+                                        ((2, 2, 2), 2, 'IE'), ((4, 4, 4), 3, 'LU'), ((8, 8, 8), 8, 'IE'), ((16,), 8, 'LU'),
+                                        ((4, 4), 7, 'IE'), ((2048,), 6, 'IE'), ((16, 16, 16), 1, 'IE')])
+def test_small_grids_and_node_counts_vs_oracle(nvars, M, qi, deferred):
+    rng = np.random.default_rng(7)
+    n, nd = nvars[0], len(nvars)
+    c, QI = _coll(M, qi)
+    dt = 20.0 / (0.1 * 4 * nd * n * n)        # moderately stiff at every size
+    P = O.HeatUnforced(nvars if nd > 1 else n, 0.1, 2, order=2)
+    coll = O.Coll(c.nodes, c.weights, c.Qmat, QI)
+    Lv = O.Level(P, coll, dt)
+    u0 = rng.standard_normal(nvars)
+    Lv.time = 0.0
+    Lv.u[0] = np.array(u0)
+    O.predict(Lv, 'spread')
+
+    e = G.engine_for('heat_unforced', dict(nvars=nvars, nu=0.1, order=2), M)
+    e.set_coeffs(c.Qmat, QI, None, c.nodes, c.weights)
+    e.set_deferred(deferred)
+    e.upload(L.SLOT_U, 0, u0)
+    e.predict(0.0, dt, 'spread')
+    O.compute_residual(Lv)
+    res, _ = e.residual(dt, 'full_abs')
+    assert abs(res - Lv.status_residual) <= 1e-9 * abs(Lv.status_residual) + 1e-14
+    for k in range(3):
+        O.sweep(Lv)
+        O.compute_residual(Lv)
+        e.sweep(0.0, dt)
+        res, norms = e.residual(dt, 'full_abs')
+        scale = max(abs(Lv.status_residual), 1e-12 * float(np.max(np.abs(u0))))
+        assert abs(res - Lv.status_residual) <= 1e-8 * scale + 1e-14, (k, res, Lv.status_residual)
+        u = e.download_u()
+        f = e.download_f()
+        for m in range(M + 1):
+            assert rel_err(u[m], Lv.u[m]) < TOL, (k, m)
+            assert rel_err(f[m], Lv.f[m]) < 1e-9, (k, m)
+        for dcu in (False, True):
+            O.compute_end_point(Lv, dcu)
+            e.end_point(dt, dcu)
+            assert rel_err(e.download(L.SLOT_UEND), Lv.uend) < TOL, (k, dcu)
+    e.close()
+
+
+@pytest.mark.parametrize('quad', ['GAUSS', 'LOBATTO', 'RADAU-LEFT'])
+def test_node_sets_whose_end_point_is_not_the_last_node(quad):
+    """quadrature rules without / with the left end point (core/collocation.py:88-97): the end value needs the collocation
+    update (core/sweeper.py: compute_end_point) or, for LOBATTO, is the last node again"""
+    nvars, M = (32, 32), 3
+    c, QI = _coll(M, 'IE', quad)
+    dt = 5e-3
+    P = O.HeatUnforced(nvars, 0.1, 2, order=2)
+    coll = O.Coll(c.nodes, c.weights, c.Qmat, QI, right_is_node=quad == 'LOBATTO', left_is_node=quad in ('LOBATTO', 'RADAU-LEFT'))
+    Lv = O.Level(P, coll, dt)
+    u0 = np.random.default_rng(9).standard_normal(nvars)
+    Lv.time = 0.0
+    Lv.u[0] = np.array(u0)
+    O.predict(Lv, 'spread')
+    e = G.engine_for('heat_unforced', dict(nvars=nvars, nu=0.1, order=2), M)
+    e.set_coeffs(c.Qmat, QI, None, c.nodes, c.weights)
+    e.upload(L.SLOT_U, 0, u0)
+    e.predict(0.0, dt, 'spread')
+    for k in range(2):
+        O.sweep(Lv)
+        e.sweep(0.0, dt)
+        O.compute_residual(Lv)
+        res, _ = e.residual(dt, 'full_abs')
+        assert abs(res - Lv.status_residual) <= 1e-8 * abs(Lv.status_residual) + 1e-14
+        O.compute_end_point(Lv, True)
+        e.end_point(dt, True)
+        assert rel_err(e.download(L.SLOT_UEND), Lv.uend) < TOL
+    u = e.download_u()
+    for m in range(M + 1):
+        assert rel_err(u[m], Lv.u[m]) < TOL
+    e.close()
