@@ -98,3 +98,81 @@ def test_node_sets_whose_end_point_is_not_the_last_node(quad):
     for m in range(M + 1):
         assert rel_err(u[m], Lv.u[m]) < TOL
     e.close()
+
+
+@pytest.mark.parametrize('nvars,M', [((4,), 1), ((4,), 3), ((4, 4), 2), ((8, 8), 5), ((4, 4, 4), 3), ((8, 8, 8), 2)])
+def test_imex_small_grids_vs_oracle(nvars, M):
+    """imex_1st_order.py:57-137 on the smallest grids: implicit diffusion, explicit advection (complex symbol)"""
+    nd, n = len(nvars), nvars[0]
+    c = CollBase(M, 0, 1, 'LEGENDRE', 'RADAU-RIGHT')
+    QI = np.zeros_like(c.Qmat)
+    QI[1:, 1:] = QDELTA_GENERATORS['IE'](qGen=c.generator, tLeft=0).genCoeffs()
+    QE = np.zeros_like(c.Qmat)
+    QE[1:, 1:] = QDELTA_GENERATORS['EE'](qGen=c.generator, tLeft=0).genCoeffs()
+    dt = 0.5 / (n * n)
+    P = O.AdvectionDiffusionIMEX(nvars if nd > 1 else n, 0.02, 1.0, 2, order=2)
+    Lv = O.Level(P, O.Coll(c.nodes, c.weights, c.Qmat, QI, QE), dt)
+    u0 = np.random.default_rng(13).standard_normal(nvars)
+    Lv.time = 0.0
+    Lv.u[0] = np.array(u0)
+    O.predict(Lv, 'spread')
+    e = G.engine_for('advdiff', dict(nvars=nvars, nu=0.02, c=1.0, order=2), M)
+    e.set_coeffs(c.Qmat, QI, QE, c.nodes, c.weights)
+    e.upload(L.SLOT_U, 0, u0)
+    e.predict(0.0, dt, 'spread')
+    for k in range(3):
+        O.sweep(Lv)
+        O.compute_residual(Lv)
+        e.sweep(0.0, dt)
+        res, _ = e.residual(dt, 'full_abs')
+        assert abs(res - Lv.status_residual) <= 1e-8 * abs(Lv.status_residual) + 1e-14, (k, res, Lv.status_residual)
+        u, f = e.download_u(), e.download_f()
+        for m in range(M + 1):
+            assert rel_err(u[m], Lv.u[m]) < TOL, (k, m)
+            assert rel_err(f[m], Lv.f[m]) < 1e-9, (k, m)
+        O.compute_end_point(Lv, False)
+        e.end_point(dt, False)
+        assert rel_err(e.download(L.SLOT_UEND), Lv.uend) < TOL
+    e.close()
+
+
+@pytest.mark.parametrize('ntraj', [1, 2, 63, 64, 65, 257])
+def test_vdp_ensembles_of_ragged_size(ntraj):
+    """ensembles that do not fill a wavefront / a workgroup, odd and even trajectory counts (the vectorised and the scalar
+    branch of the right-hand-side launch): every trajectory against the oracle's scalar van der Pol sweeps
+    (Van_der_Pol_implicit.py:76-201), Newton counts summed"""
+    from pysdc_amd.level import Step
+    from pysdc_amd.problems import vanderpol_ensemble
+    from pysdc_amd.sweepers import generic_implicit
+
+    rng = np.random.default_rng(21)
+    u0 = rng.uniform(-2, 2, size=(2, ntraj))
+    M, dt = 3, 0.05
+    c, QI = _coll(M, 'LU')
+    desc = dict(problem_class=vanderpol_ensemble, problem_params=dict(ntraj=ntraj, u0=u0, mu=5.0, newton_tol=1e-9),
+                sweeper_class=generic_implicit, sweeper_params=dict(num_nodes=M, quad_type='RADAU-RIGHT', QI='LU'),
+                level_params=dict(dt=dt), step_params=dict(maxiter=3))
+    Lv = Step(desc).levels[0]
+    Lv.status.time = 0.0
+    Lv.u[0] = Lv.prob.u_exact(0.0)
+    Lv.sweep.predict()
+    refs = []
+    for i in range(ntraj):
+        P = O.VanDerPol(mu=5.0, newton_tol=1e-9, u0=tuple(u0[:, i]))
+        Lo = O.Level(P, O.Coll(c.nodes, c.weights, c.Qmat, QI), dt)
+        Lo.time = 0.0
+        Lo.u[0] = np.array(u0[:, i])
+        O.predict(Lo, 'spread')
+        refs.append((P, Lo))
+    for k in range(3):
+        Lv.sweep.update_nodes()
+        Lv.sweep.compute_residual()
+        U = np.stack([np.asarray(Lv.u[m]) for m in range(M + 1)])      # (M+1, 2, ntraj)
+        worst = 0.0
+        for i, (P, Lo) in enumerate(refs):
+            O.sweep(Lo)
+            O.compute_residual(Lo)
+            worst = max(worst, Lo.status_residual)
+            assert rel_err(U[:, :, i], np.stack(Lo.u)) < TOL, (k, i)
+        assert abs(Lv.status.residual - worst) <= 1e-9 * max(worst, 1e-6)
+    assert Lv.prob.work_counters['newton'].niter == sum(P.work_counters['newton'].niter for P, _ in refs)
