@@ -127,7 +127,12 @@ __global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_inv(FieldPtr
     // ADD: one-dimensional grid in which the NF workgroups that read the SAME tile of `add` follow each other at a
     // distance of 8 - workgroups are handed to the 8 XCDs round robin, so those NF land on one XCD and find the tile in
     // its L2 after the first of them fetched it (id = 8 NF g + 8 f + t: tile 8 g + t, field f)
-    const int bx = ADD ? (int)((blockIdx.x / (8 * nfields)) * 8 + blockIdx.x % 8) : (int)blockIdx.x;
+#ifndef SDC_X_SWZ
+#define SDC_X_SWZ 0  // 1: every XCD a contiguous eighth of the tiles (the 8 XCDs then work 2 MB apart instead of on adjacent 256 bytes)
+#endif
+    const int bx = ADD ? (int)((blockIdx.x / (8 * nfields)) * 8 + blockIdx.x % 8)
+                       : ((SDC_X_SWZ && (gridDim.x & 7u) == 0) ? (int)((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3))
+                                                               : (int)blockIdx.x);
     const int by = ADD ? (int)((blockIdx.x / 8) % nfields) : (int)blockIdx.y;
     const int c = bx * T + col;
     const bool ok = c < ncol;
@@ -388,9 +393,42 @@ __global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_ffty(cd* __restri
     using LAY = LayStrided<N, T>;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int col = threadIdx.x % T, j = threadIdx.x / T;
-    const int c = blockIdx.x * T + col;
+    // SDC_Y_SWZ: which tile a workgroup takes.  Workgroups are handed to the 8 XCDs round robin in the order x fastest, then y.
+    // 0 (rounds 1 - 2): tile = blockIdx.x, plane = blockIdx.y - the 8 XCDs work on 8 adjacent 128-byte segments of the same
+    // rows at the same time, i.e. all of them on the same few DRAM pages / channels.  3 (default since round 3): every XCD
+    // streams through its own contiguous range of kx planes (the planes left over when their number is not a multiple of 8
+    // keep the plain order) - `fft_y_inv[5]` at 1024^3 16.2 -> 15.1 ms on one box, 13.8 - 14.6 on another; 2: whole planes,
+    // handed out in groups of 8 (15.3); 1: a contiguous eighth of the tiles of each plane (17.3 - 18.0: worse than plain).
+    // The same idea was measured for the x pass (every XCD a contiguous eighth of the tiles: 9.5 -> 9.6 - 9.8 ms, SDC_X_SWZ)
+    // and for the contiguous-axis launch (SDC_Z_SWZ: no difference) and left off there.
+#ifndef SDC_Y_SWZ
+#define SDC_Y_SWZ 3
+#endif
+    unsigned bx = blockIdx.x, by = blockIdx.y;
+#if SDC_Y_SWZ == 1
+    if ((gridDim.x & 7u) == 0) bx = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+#elif SDC_Y_SWZ == 2
+    {
+        const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y, full = (gridDim.y >> 3) * 8u * gridDim.x;
+        if (lin < full) {
+            const unsigned xcd = lin & 7u, slot = lin >> 3;
+            by = (slot / gridDim.x) * 8u + xcd;
+            bx = slot % gridDim.x;
+        }
+    }
+#elif SDC_Y_SWZ == 3
+    {   // every XCD a contiguous range of planes
+        const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y, per = gridDim.y >> 3, full = per * 8u * gridDim.x;
+        if (lin < full) {
+            const unsigned xcd = lin & 7u, slot = lin >> 3;
+            by = xcd * per + slot / gridDim.x;
+            bx = slot % gridDim.x;
+        }
+    }
+#endif
+    const int c = bx * T + col;
     const bool ok = c < N;
-    cd* __restrict__ base = W + blockIdx.z * fstride + (size_t)(blockIdx.y + kx0) * N * N + c;  // kx0: a launch per group of kx planes
+    cd* __restrict__ base = W + blockIdx.z * fstride + (size_t)(by + kx0) * N * N + c;  // kx0: a launch per group of kx planes
     cd r[E];
 #pragma unroll
     for (int i = 0; i < E; ++i) r[i] = ok ? ld_stream(base + (size_t)(j + i * P) * N) : cd{0.0, 0.0};
@@ -962,7 +1000,11 @@ void k_spec_z(SpecArgs a, unsigned nlines) {
     using LAY = LayContig<N>;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     cd* rbuf = reinterpret_cast<cd*>(lds);  // [NF][CH]
-    const unsigned bid = blockIdx.x + a.block0;  // (block0: a launch that covers only a range of lines, e.g. a group of kx planes)
+#ifndef SDC_Z_SWZ
+#define SDC_Z_SWZ 0  // 1: every XCD a contiguous eighth of the lines of the launch
+#endif
+    const unsigned bsw = (SDC_Z_SWZ && (gridDim.x & 7u) == 0) ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const unsigned bid = bsw + a.block0;  // (block0: a launch that covers only a range of lines, e.g. a group of kx planes)
     const int c = threadIdx.x / P, j = threadIdx.x % P;
     const int f = c / LPB, l = c % LPB;
     const size_t line = (size_t)bid * LPB + l;
