@@ -128,11 +128,19 @@ __global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_inv(FieldPtr
     // distance of 8 - workgroups are handed to the 8 XCDs round robin, so those NF land on one XCD and find the tile in
     // its L2 after the first of them fetched it (id = 8 NF g + 8 f + t: tile 8 g + t, field f)
 #ifndef SDC_X_SWZ
-#define SDC_X_SWZ 0  // 1: every XCD a contiguous eighth of the tiles (the 8 XCDs then work 2 MB apart instead of on adjacent 256 bytes)
+#define SDC_X_SWZ 0  // 1: every XCD a contiguous eighth of the tiles (9.5 -> 9.6 - 9.8 ms); 3: every XCD whole rows of the (y, z)
+                     // plane (9.56 - 9.60 -> 9.65 - 9.86 ms): measured in round 3, the plain order stays
 #endif
-    const int bx = ADD ? (int)((blockIdx.x / (8 * nfields)) * 8 + blockIdx.x % 8)
-                       : ((SDC_X_SWZ && (gridDim.x & 7u) == 0) ? (int)((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3))
-                                                               : (int)blockIdx.x);
+    int bx_ = (int)blockIdx.x;
+    if (SDC_X_SWZ == 1 && (gridDim.x & 7u) == 0) bx_ = (int)((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3));
+    if (SDC_X_SWZ == 3 && !ADD) {  // every XCD whole rows of the (y, z) plane: XCD x takes the rows y = 8 g + x and walks along z
+        constexpr unsigned ZT = (N / 2 + T - 1) / T;
+        if (gridDim.x == (unsigned)N * ZT && (N & 7) == 0) {
+            const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+            bx_ = (int)(((slot / ZT) * 8u + xcd) * ZT + slot % ZT);
+        }
+    }
+    const int bx = ADD ? (int)((blockIdx.x / (8 * nfields)) * 8 + blockIdx.x % 8) : bx_;
     const int by = ADD ? (int)((blockIdx.x / 8) % nfields) : (int)blockIdx.y;
     const int c = bx * T + col;
     const bool ok = c < ncol;
