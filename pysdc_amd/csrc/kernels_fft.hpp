@@ -131,9 +131,14 @@ __global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_inv(FieldPtr
 #define SDC_X_SWZ 0  // 1: every XCD a contiguous eighth of the tiles (9.5 -> 9.6 - 9.8 ms); 3: every XCD whole rows of the (y, z)
                      // plane (9.56 - 9.60 -> 9.65 - 9.86 ms): measured in round 3, the plain order stays
 #endif
+#ifndef SDC_X_SWZ_STORE
+#define SDC_X_SWZ_STORE 3  // ... of the launches that WRITE the real fields (eager node fields, end values, multi-level paths): a pass
+                           // that reads and writes gains from XCDs that work apart (17.2 - 17.5 -> 16.8 ms for five 1024^3 fields)
+#endif
+    constexpr int XS = STORE ? SDC_X_SWZ_STORE : SDC_X_SWZ;
     int bx_ = (int)blockIdx.x;
-    if (SDC_X_SWZ == 1 && (gridDim.x & 7u) == 0) bx_ = (int)((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3));
-    if (SDC_X_SWZ == 3 && !ADD) {  // every XCD whole rows of the (y, z) plane: XCD x takes the rows y = 8 g + x and walks along z
+    if (XS == 1 && (gridDim.x & 7u) == 0) bx_ = (int)((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3));
+    if (XS == 3 && !ADD) {  // every XCD whole rows of the (y, z) plane: XCD x takes the rows y = 8 g + x and walks along z
         constexpr unsigned ZT = (N / 2 + T - 1) / T;
         if (gridDim.x == (unsigned)N * ZT && (N & 7) == 0) {
             const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
