@@ -629,6 +629,8 @@ class controller_dist(_ControllerBase):
             if send:
                 L.sweep.compute_end_point()
             do_recv = recv and not S.status.first and not S.status.prev_done
+            if do_recv and hasattr(L, 'settle_residual'):
+                L.settle_residual()
             self._comms[level].exchange(send_to=self.rank + 1 if send and not S.status.last else None,
                                         recv_from=self.rank - 1 if do_recv else None)
             if do_recv:
@@ -807,6 +809,8 @@ class controller_dist(_ControllerBase):
         self._hook('pre_comm', S, 0)
         if self._abi:
             L.sweep.compute_end_point()  # free when the sweep produced UEND early
+            if self.rank >= 1 and hasattr(L, 'settle_residual'):
+                L.settle_residual()              # (a put-off residual is a function of the u[0] this message replaces)
             self._comms[0].handover_post(size)   # (its own stream, behind UEND only; two hops for more than two ranks)
             if self.spectral_wire:
                 # the end value left as its spectrum; as a field it was never produced, and nobody asks for it before the
@@ -906,7 +910,10 @@ class controller_dist(_ControllerBase):
         S = self.S
         sw = S.levels[0].sweep
         pars = getattr(sw, 'params', None)   # (a sweeper that does not say how it predicts gets its message)
-        return (S.status.iter == 0 and len(S.levels) == 1 and self.params.predict_type is None and pars is not None
+        from pysdc_amd import sweepers as _sw
+
+        own = type(sw) in (_sw.generic_implicit, _sw.imex_1st_order)   # (a subclass may override predict(): it gets its message)
+        return (S.status.iter == 0 and len(S.levels) == 1 and self.params.predict_type is None and pars is not None and own
                 and getattr(pars, 'initial_guess', None) in ('spread', 'copy')
                 and getattr(pars, 'do_coll_update', True) is False and getattr(sw.coll, 'right_is_node', False)
                 and os.environ.get('PYSDC_AMD_SKIP_FIRST', '1') != '0')
@@ -918,7 +925,9 @@ class controller_dist(_ControllerBase):
         if self._posted is not None:
             self.handover_complete()      # posted right after the sweep (it_fine)
         elif self._nothing_new_to_hand_over():
-            pass
+            # no message; the hooks around the hand-over still fire (communication statistics keep the reference's shape)
+            self._hook('pre_comm', S, 0)
+            self._hook('post_comm', S, 0)
         elif self._lockstep(size) or (self._overlap and self._uniform(size)) or (self._abi and self._uniform(size)):
             # lock-step runs: every message is completed here, on both sides - the next sweep overwrites UEND early
             # (sdc_set_early_end_point), so no send may stay in flight behind it

@@ -1034,7 +1034,7 @@ static int residual_shift_n(sdc_ctx* c, cd* dbuf, const cd* newS0) {
 
 extern "C" {
 
-int sdc_version(void) { return 100; }
+int sdc_version(void) { return 101; }  // 101: sdc_work_counters writes out[5]
 
 int sdc_init_field(sdc_ctx* c, double* dst, const int* freq, double amp, unsigned long long seed) {
     if (!c || !dst || !freq) return fail(c, SDC_ERR_PARAM, "null pointer");
@@ -1184,6 +1184,7 @@ int sdc_set_stencil(sdc_ctx* c, int which, int npts, const int* offsets, const d
     if (!c || which < 0 || which > 1 || npts < 1 || npts > MAXSTEN || !offsets || !weights)
         return fail(c, SDC_ERR_PARAM, "bad stencil (npts must be 1..%d)", MAXSTEN);
     STORE_SPECTRA(c, false);  // (an iterate that was not stored is a function of the OLD symbol)
+    c->g_sweeps = 0;          // (and so are the node multipliers on record)
     Stencil& s = c->st[which];
     s.npts = npts;
     for (int k = 0; k < npts; ++k) {

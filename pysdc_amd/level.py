@@ -126,6 +126,8 @@ class SlabList:
         else:
             if self._slot == Lb.SLOT_TAU and not any(self._valid):
                 self._L._activate_tau()
+            if self._slot == Lb.SLOT_U and m == 0:
+                self._L.settle_residual()   # (a put-off residual belongs to the start value that is about to go)
             v = self._view(m)
             if value is not v:
                 v[:] = value
@@ -165,6 +167,13 @@ class DeviceBacked:
         self._uend_valid = False
         self._uend_view = None
         self._res_cache = None
+
+    def settle_residual(self):
+        """a residual that was put off (LevelStatus: evaluated when read) is evaluated NOW: the state it belongs to - u[0] in
+        particular - is about to be replaced, and whoever reads it later must get the number the eager path stored"""
+        st = getattr(self, 'status', None)
+        if st is not None and hasattr(st, 'residual_is_deferred') and st.residual_is_deferred():
+            st.residual  # noqa: B018  (the property evaluates and keeps the number)
 
     # what the two flavours provide
     def _db_prob(self):
@@ -380,6 +389,7 @@ class Level(DeviceBacked):
         if self._view_offset():
             self.u[0] = src
             return
+        self.settle_residual()
         self.engine.replace_u0(src.ptr)
         self._u.mark([0])
         self._res_cache = None

@@ -102,14 +102,27 @@ class BaseTransfer:
     def _batched(self):
         sp = self.space_transfer
         fine, coarse = self.fine, self.coarse
-        return (getattr(self, '_nodes_shared', None) is not False
-                and self.Pcoll.shape[0] == self.Pcoll.shape[1] and np.array_equal(self.Pcoll, np.eye(self.Pcoll.shape[0]))
+        def fused_sweeper(L):   # the sweeper's own integrate() hands out ONE buffer only on its fused path
+            probe = getattr(L.sweep, '_fused', None)
+            return callable(probe) and bool(probe())
+
+        return (self.Pcoll.shape[0] == self.Pcoll.shape[1] and np.array_equal(self.Pcoll, np.eye(self.Pcoll.shape[0]))
                 and np.array_equal(self.Rcoll, np.eye(self.Rcoll.shape[0]))
                 and type(sp) is mesh_to_mesh and not sp.identity
                 and all(hasattr(L, 'engine') and hasattr(L, '_u') and not L._view_offset()
                         and getattr(L.prob, 'dtype_u', None) is hip_mesh and getattr(L.prob, 'fused', False)
-                        for L in (fine, coarse))
+                        and fused_sweeper(L) for L in (fine, coarse))
                 and type(fine).__module__ == type(coarse).__module__ == 'pysdc_amd.level')
+
+    @staticmethod
+    def _one_buffer(fields, nbytes):
+        """are these M fields one behind the other in ONE allocation (what Sweeper._integrate_fused returns)?  A sweeper
+        class that overrides integrate() may hand out separately allocated meshes: those take the node-by-node path"""
+        try:
+            base = fields[0].ptr
+            return all(f.ptr == base + nbytes * k for k, f in enumerate(fields))
+        except (AttributeError, IndexError, TypeError):
+            return False
 
     def _space_batch(self, key, nfields, src_ptr, dst_ptr):
         sp = self.space_transfer
@@ -132,10 +145,20 @@ class BaseTransfer:
         self._refresh_f(coarse, 0, coarse.time)
         for n in range(1, M + 1):
             self._refresh_f(coarse, n, coarse.time + coarse.dt * coarse.sweep.coll.nodes[n - 1])
-        quad_coarse = coarse.sweep.integrate()    # M fields, one behind the other
+        quad_coarse = coarse.sweep.integrate()    # M fields, one behind the other (checked: a user's integrate() need not)
         quad_fine = fine.sweep.integrate()
         on_coarse = hip_mesh(((M * nc,), None, np.dtype('float64')), val=None)
-        self._space_batch('R', M, quad_fine[0].ptr, on_coarse.ptr)
+        if self._one_buffer(quad_fine, 8 * ef.N):
+            self._space_batch('R', M, quad_fine[0].ptr, on_coarse.ptr)
+        else:
+            for k in range(M):
+                self._space_batch('R', 1, quad_fine[k].ptr, on_coarse.ptr + 8 * k * nc)
+        if not self._one_buffer(quad_coarse, 8 * nc):
+            packed = hip_mesh(((M * nc,), None, np.dtype('float64')), val=None)
+            for k in range(M):
+                dst = hip_mesh.view(packed.ptr + 8 * k * nc, (nc,), keep=packed)
+                dst._axpby(1.0, hip_mesh.view(quad_coarse[k].ptr, (nc,), keep=quad_coarse[k]), 0.0, None, dst)
+            quad_coarse = [packed]
         if coarse.tau[0] is None:                 # (sets the slab up and tells the engine)
             coarse._activate_tau()
         tau = hip_mesh.view(ec.ptr(Lb.SLOT_TAU, 0), (M * nc,), keep=ec)
