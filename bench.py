@@ -572,6 +572,7 @@ def compact_line(out, subs=None, cpu=None, details_path=None):
                             'ms_per_iteration': [p['ms_per_iteration'] for p in pr],
                             'comm_ms_per_iteration': [p['comm_ms_per_iteration'] for p in pr],
                             'kernel_ms_per_iteration': [p['kernel_ms_per_iteration'] for p in pr],
+                            'sweeps': [sum(p['niter']) for p in pr],
                             'wire': pr[0].get('wire'), 'message_bytes': pr[0].get('message_bytes')}
     if details_path:
         line['details'] = details_path

@@ -137,6 +137,20 @@ int sdc_set_multiplier_table(sdc_ctx* ctx, int from_sweep);
  * check_convergence.py:60-92) may postpone the call until somebody reads L.status.residual.  Default 0: computed by sdc_predict. */
 int sdc_set_lazy_predictor_residual(sdc_ctx* ctx, int on);
 int sdc_residual_deferred(sdc_ctx* ctx);
+/* Residuals the host does not wait for (compute_residual + CheckConvergence on the device).
+ * sdc_residual_post queues everything sdc_residual does on the context's stream and ends with a one-workgroup launch that
+ * finishes the number on the device - node norms -> L.status.residual by residual_type (core/sweeper.py:200-215) and the
+ * test `residual <= restol` of check_convergence.py:72-75 against the tolerance given by sdc_set_restol (< 0: never
+ * converged, the reference's default) - and writes the record into pinned host memory, its ticket last.  It returns the
+ * ticket without synchronising.  sdc_residual_wait(ticket, block, ...) looks at that memory: ready = 1 and the values once
+ * the record is there; with block = 1 it waits for it (polling the host memory, no stream synchronisation on the fast
+ * path).  A caller whose control flow cannot depend on the value (restol < 0, a fixed number of sweeps) never waits: it
+ * collects the values when somebody reads them (pysdc_amd.engine.ResidualFuture).  The last 256 tickets can be asked for.
+ * sdc_residual = post + wait(block). */
+int sdc_set_restol(sdc_ctx* ctx, double restol);
+int sdc_residual_post(sdc_ctx* ctx, double dt, int residual_type, unsigned long long* ticket);
+int sdc_residual_wait(sdc_ctx* ctx, unsigned long long ticket, int block, double* node_norms, double* residual, int* converged,
+                      int* ready);
 /* A Fourier-space sweep that only delivers residual norms is three launches: the pointwise sweep fused with the inverse pass
  * along the contiguous axis (bound by its f64 arithmetic), the in-place pass along the middle axis (bound by memory), the
  * norm-only pass along the first axis.  With groups > 1 the first two are issued per group of kx planes, the middle-axis pass

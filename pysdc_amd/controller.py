@@ -43,8 +43,13 @@ def check_convergence(S):
     iter_converged = S.status.iter >= S.params.maxiter
     # (restol < 0: no residual - a max norm, or nan - can be below it; the attribute is not even read then, and a residual
     # that was put off until somebody reads it stays put off: level.LevelStatus)
-    res_converged = (L.params.restol >= 0 and L.status.residual <= L.params.restol
-                     and (S.status.iter > 0 or L.status.sweep > 0))
+    res_converged = False
+    if L.params.restol >= 0 and (S.status.iter > 0 or L.status.sweep > 0):
+        # a residual that is on its way brings the answer with it: `residual <= restol` as the device found it, read from
+        # pinned host memory (engine.ResidualFuture.converged; include/sdcmi.h: sdc_residual_post) - same comparison, same bits
+        peek = getattr(L.status, 'peek_residual', None)
+        r = peek() if peek is not None else L.status.residual
+        res_converged = bool(r.converged) if getattr(r, 'queued', False) else bool(r <= L.params.restol)
     converged = (iter_converged or res_converged or bool(S.status.force_done)) and not S.status.force_continue
     return bool(converged)
 

@@ -1,6 +1,7 @@
 // libsdcmi: context of one level (device slabs, coefficients, operator tables) and launch timing.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -34,6 +35,16 @@ struct ProfEntry {
 };
 
 struct CommState;  // comm.hpp: RCCL communicator, message stream, inbox
+
+// one finished residual as the device leaves it in pinned host memory (sdc_residual_post)
+#define RES_RING 256
+struct ResRecord {
+    unsigned long long seq;    // ticket this record answers; written LAST
+    double residual;           // the number compute_residual stores in L.status.residual (core/sweeper.py:200-215)
+    double norms[MAXM];        // node-wise max norms of the collocation residual
+    int converged;             // residual <= restol (check_convergence.py:72-75), taken on the device
+    int pad;
+};
 
 struct sdc_ctx {
     CommState* comm = nullptr;
@@ -96,6 +107,15 @@ struct sdc_ctx {
     bool sym_real[2] = {false, false};  // the stencil is symmetric: its Fourier symbol is real (imaginary parts stored as 0)
     unsigned long long* red = nullptr;  // reduction slots (device)
     unsigned long long* red_host = nullptr;
+    // Residuals that the host does not wait for (sdc_residual_post / sdc_residual_wait): a one-workgroup launch at the end of
+    // the residual's device work finishes the number (node norms -> residual, residual <= restol) and writes the record into
+    // pinned host memory; its sequence number goes last, behind a system-scope fence.  The host compares that number with
+    // its ticket - no stream synchronisation, no copy.  RES_RING records in flight; the host side of a ticket (what the
+    // record must be read as) lives in ring_meta.
+    ResRecord* ring = nullptr;          // host address of the pinned records
+    ResRecord* ring_dev = nullptr;      // the same memory as the device sees it
+    unsigned long long ring_seq = 0;    // last ticket handed out
+    double restol = -1.0;               // tolerance the device-side flag is taken against (sdc_set_restol)
     bool tau_active = false, have_coeffs = false, have_stencil[2] = {false, false}, unlocked = false;
     int expl_kind = SDC_EXPL_NONE;
     bool res_spread = false;  // state = spread predictor of an autonomous f: residual_m = dt |sum_j Q[m][j]| max|f(u0)|

@@ -1079,6 +1079,9 @@ int sdc_ctx_create(sdc_ctx** out, int device, int ndim, int n, int num_nodes, in
         HIPCHK(nullptr, hipMalloc((void**)&c->UEND, fb));
         HIPCHK(nullptr, hipMalloc((void**)&c->red, sizeof(unsigned long long) * 16));
         HIPCHK(nullptr, hipHostMalloc((void**)&c->red_host, sizeof(unsigned long long) * 16));
+        HIPCHK(nullptr, hipHostMalloc((void**)&c->ring, sizeof(ResRecord) * RES_RING, hipHostMallocMapped | hipHostMallocCoherent));
+        memset(c->ring, 0, sizeof(ResRecord) * RES_RING);
+        HIPCHK(nullptr, hipHostGetDevicePointer((void**)&c->ring_dev, c->ring, 0));
         c->bytes = fb * (c->M + 1) * (1 + ncomp) + fb;
         HIPCHK(nullptr, hipMalloc((void**)&c->counters, sizeof(unsigned long long) * 4));
         HIPCHK(nullptr, hipMalloc((void**)&c->res_dev, sizeof(unsigned long long) * 8));
@@ -1137,6 +1140,7 @@ int sdc_ctx_destroy(sdc_ctx* c) {
         for (auto& e : c->pipe_ev) (void)hipEventDestroy(e);
     }
     (void)hipFree(c->Wend);
+    if (c->ring) (void)hipHostFree(c->ring);
     (void)hipFree(c->Gm);
     if (c->sl_ev) (void)hipEventDestroy(c->sl_ev);
     (void)hipFree(c->UEND2);
@@ -2569,24 +2573,86 @@ int sdc_solve_jacobian(sdc_ctx* c, const double* rhs, double dt, const double* u
     return SDC_OK;
 }
 
-int sdc_residual(sdc_ctx* c, double dt, int type, double* node_norms, double* residual) {
-    if (!c || !residual) return fail(c, SDC_ERR_PARAM, "null pointer");
+// the last launch of a residual: finishes the number on the device and leaves the record in pinned host memory
+struct PublishArgs {
+    const unsigned long long* norms;   // M node norms (bit patterns of non-negative doubles; NaN sorts above everything)
+    const unsigned long long* f0max;   // spread predictor: max |f(u0)|, the node norms are scale[m] * it (or null)
+    const unsigned long long* u0norm;  // relative residual types: max |u0| (or null)
+    double scale[MAXM];
+    double restol;
+    int M, type;
+};
+
+__global__ void k_publish_residual(PublishArgs a, ResRecord* dst, unsigned long long seq) {
+    if (threadIdx.x != 0) return;
+    double mx = 0.0, last = 0.0;
+    for (int m = 0; m < a.M; ++m) {
+        double v;
+        if (a.f0max) {
+            v = fabs(a.scale[m]) * __longlong_as_double((long long)*a.f0max);
+        } else {
+            v = __longlong_as_double((long long)a.norms[m]);
+        }
+        dst->norms[m] = v;
+        mx = (v > mx || v != v) ? v : mx;   // (a NaN stays, like np.max / max() over the reference's list)
+        last = v;
+    }
+    const double u0n = a.u0norm ? __longlong_as_double((long long)*a.u0norm) : 1.0;
+    double r;
+    switch (a.type) {
+        case SDC_RES_FULL_ABS: r = mx; break;
+        case SDC_RES_LAST_ABS: r = last; break;
+        case SDC_RES_FULL_REL: r = mx / u0n; break;
+        default: r = last / u0n; break;
+    }
+    dst->residual = r;
+    dst->converged = (a.restol >= 0.0 && r <= a.restol) ? 1 : 0;
+    __threadfence_system();
+    *(volatile unsigned long long*)&dst->seq = seq;
+}
+
+int sdc_set_restol(sdc_ctx* c, double restol) {
+    if (!c) return SDC_ERR_PARAM;
+    c->restol = restol;
+    return SDC_OK;
+}
+
+int sdc_residual_post(sdc_ctx* c, double dt, int type, unsigned long long* ticket) {
+    if (!c || !ticket) return fail(c, SDC_ERR_PARAM, "null pointer");
     if (!c->have_coeffs) return fail(c, SDC_ERR_STATE, "coefficients not set (sdc_set_coeffs)");
     if (type < 0 || type > 3)
         return fail(c, SDC_ERR_PARAM,
                     "residual_type = %d not implemented, choose full_abs, last_abs, full_rel or last_rel instead", type);
     const int M = c->M;
-    bool from_spread = false;
+    PublishArgs pa;
+    memset(&pa, 0, sizeof pa);
+    pa.M = M;
+    pa.type = type;
+    pa.restol = c->restol;
+    const unsigned long long seq = c->ring_seq + 1;
+    ResRecord* slot = c->ring + seq % RES_RING;
     // the sweep that reduced these norms ended with a look at its counters anyway (van der Pol: Newton failures are reported
-    // by the sweep) and brought the norms along: nothing to launch, copy or wait for
+    // by the sweep) and brought the norms along: nothing to launch, copy or wait for - the host writes the record itself
     const bool on_host = c->kind == 1 && c->res_valid && c->res_dt == dt && c->res_host_valid && type < SDC_RES_FULL_REL;
     if (on_host) {
-        memcpy(c->red_host, c->res_host, sizeof(unsigned long long) * 8);
-    } else {
-    HIPCHK(c, hipMemsetAsync(c->red, 0, sizeof(unsigned long long) * 16, c->stream));
+        double mx = 0.0, last = 0.0;
+        for (int m = 0; m < M; ++m) {
+            double v;
+            memcpy(&v, &c->res_host[m], sizeof(double));
+            slot->norms[m] = v;
+            mx = (v > mx || v != v) ? v : mx;
+            last = v;
+        }
+        slot->residual = type == SDC_RES_FULL_ABS ? mx : last;
+        slot->converged = (c->restol >= 0.0 && slot->residual <= c->restol) ? 1 : 0;
+        slot->seq = seq;
+        c->ring_seq = seq;
+        *ticket = seq;
+        return SDC_OK;
+    }
     if (c->res_valid && c->res_dt == dt) {
-        // the sweep's fused eval_f kernel already reduced the node norms of this very state
-        HIPCHK(c, hipMemcpyAsync(c->red, c->res_dev, sizeof(unsigned long long) * 8, hipMemcpyDeviceToDevice, c->stream));
+        // the sweep's fused kernels already reduced the node norms of this very state
+        pa.norms = c->res_dev;
     } else if (c->res_spread) {
         if (c->f0norm_pending) {  // (put off by sdc_predict; res_spread: no sweep since - S0 and the work buffer are as it left them)
             c->f0norm_pending = false;
@@ -2595,58 +2661,84 @@ int sdc_residual(sdc_ctx* c, double dt, int type, double* node_norms, double* re
             int rcn = symbol_norm(c, c->S0, c->res_dev + 7);
             if (rcn != SDC_OK) return rcn;
         }
-        HIPCHK(c, hipMemcpyAsync(c->red + 7, c->res_dev + 7, sizeof(unsigned long long), hipMemcpyDeviceToDevice, c->stream));
-        from_spread = true;
-    } else if (c->u_pending && !c->spread_pending && c->spec_valid && !c->tau_active && c->ndim >= 2) {
-        // the iterate lives in the spectral cache (u[0] was replaced after the sweep, or dt differs): reduce the
-        // residual from its transform instead of bringing U and F back to real space
-        int rcs = spec_residual(c, dt, c->red);
-        if (rcs != SDC_OK) return rcs;
+        pa.f0max = c->res_dev + 7;
+        for (int m = 0; m < M; ++m) {
+            double sq = 0.0;
+            for (int j = 1; j <= M; ++j) sq += dt * c->Q[m + 1][j];
+            pa.scale[m] = sq;
+        }
     } else {
-        ENSURE_U0(c);
-        int rcm = materialize(c, true, true);
-        if (rcm != SDC_OK) return rcm;
-        QuadArgs q;
-        quad_base(c, q);
-        q.u0 = c->U;
-        q.tau = c->tau_active ? c->TAU : nullptr;
-        q.Usub = c->U;
-        q.norms = c->red;
-        for (int m = 0; m < M; ++m)
-            for (int j = 0; j < M; ++j) q.cI[m][j] = q.cE[m][j] = dt * c->Q[m + 1][j + 1];
-        int rc = launch_quad<1>(c, q, "residual");
-        if (rc != SDC_OK) return rc;
+        HIPCHK(c, hipMemsetAsync(c->red, 0, sizeof(unsigned long long) * 16, c->stream));
+        pa.norms = c->red;
+        if (c->u_pending && !c->spread_pending && c->spec_valid && !c->tau_active && c->ndim >= 2) {
+            // the iterate lives in the spectral cache (u[0] was replaced after the sweep, or dt differs): reduce the
+            // residual from its transform instead of bringing U and F back to real space
+            int rcs = spec_residual(c, dt, c->red);
+            if (rcs != SDC_OK) return rcs;
+        } else {
+            ENSURE_U0(c);
+            int rcm = materialize(c, true, true);
+            if (rcm != SDC_OK) return rcm;
+            QuadArgs q;
+            quad_base(c, q);
+            q.u0 = c->U;
+            q.tau = c->tau_active ? c->TAU : nullptr;
+            q.Usub = c->U;
+            q.norms = c->red;
+            for (int m = 0; m < M; ++m)
+                for (int j = 0; j < M; ++j) q.cI[m][j] = q.cE[m][j] = dt * c->Q[m + 1][j + 1];
+            int rc = launch_quad<1>(c, q, "residual");
+            if (rc != SDC_OK) return rc;
+        }
     }
     if (type >= SDC_RES_FULL_REL) {
         U0R(c, u0p);
+        HIPCHK(c, hipMemsetAsync(c->red + 8, 0, sizeof(unsigned long long), c->stream));
         LaunchTimer lt(c, "amax");
         hipLaunchKernelGGL(k_amax, dim3(grid_for(c->N, 256)), dim3(256), 0, c->stream, u0p, c->N, c->red + 8);
+        pa.u0norm = c->red + 8;
     }
-    HIPCHK(c, hipMemcpyAsync(c->red_host, c->red, sizeof(unsigned long long) * 16, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    slot->seq = 0;   // (a record of RES_RING tickets ago: sdc_residual_wait no longer answers for it)
+    hipLaunchKernelGGL(k_publish_residual, dim3(1), dim3(64), 0, c->stream, pa, c->ring_dev + seq % RES_RING, seq);
+    HIPCHK(c, hipGetLastError());
+    c->ring_seq = seq;
+    *ticket = seq;
+    return SDC_OK;
+}
+
+int sdc_residual_wait(sdc_ctx* c, unsigned long long ticket, int block, double* node_norms, double* residual, int* converged,
+                      int* ready) {
+    if (!c || !ready) return fail(c, SDC_ERR_PARAM, "null pointer");
+    if (ticket == 0 || ticket > c->ring_seq || ticket + RES_RING <= c->ring_seq)
+        return fail(c, SDC_ERR_STATE, "residual ticket %llu is not in flight (last %llu, %d records kept)", ticket, c->ring_seq,
+                    RES_RING);
+    volatile ResRecord* r = c->ring + ticket % RES_RING;
+    *ready = r->seq == ticket;
+    if (!*ready && block) {
+        // the record arrives by itself when the stream gets there; look at it for a while, then wait on the stream (which
+        // also surfaces a launch that failed)
+        for (int spin = 0; spin < 2000000 && r->seq != ticket; ++spin) __builtin_ia32_pause();
+        if (r->seq != ticket) HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (r->seq != ticket) return fail(c, SDC_ERR_HIP, "the residual record of ticket %llu never arrived", ticket);
+        *ready = 1;
     }
-    double norms[MAXM], mx = 0.0;
-    double f0max = 0.0;
-    memcpy(&f0max, &c->red_host[7], sizeof(double));
-    for (int m = 0; m < M; ++m) {
-        memcpy(&norms[m], &c->red_host[m], sizeof(double));
-        if (from_spread) {
-            double sq = 0.0;
-            for (int j = 1; j <= M; ++j) sq += dt * c->Q[m + 1][j];
-            norms[m] = fabs(sq) * f0max;
-        }
-        if (node_norms) node_norms[m] = norms[m];
-        mx = (norms[m] > mx || norms[m] != norms[m]) ? norms[m] : mx;
-    }
-    double u0n;
-    memcpy(&u0n, &c->red_host[8], sizeof(double));
-    switch (type) {
-        case SDC_RES_FULL_ABS: *residual = mx; break;
-        case SDC_RES_LAST_ABS: *residual = norms[M - 1]; break;
-        case SDC_RES_FULL_REL: *residual = mx / u0n; break;
-        default: *residual = norms[M - 1] / u0n; break;
+    if (*ready) {
+        std::atomic_thread_fence(std::memory_order_acquire);
+        if (node_norms)
+            for (int m = 0; m < c->M; ++m) node_norms[m] = r->norms[m];
+        if (residual) *residual = r->residual;
+        if (converged) *converged = r->converged;
     }
     return SDC_OK;
+}
+
+int sdc_residual(sdc_ctx* c, double dt, int type, double* node_norms, double* residual) {
+    if (!c || !residual) return fail(c, SDC_ERR_PARAM, "null pointer");
+    unsigned long long ticket = 0;
+    int rc = sdc_residual_post(c, dt, type, &ticket);
+    if (rc != SDC_OK) return rc;
+    int ready = 0;
+    return sdc_residual_wait(c, ticket, 1, node_norms, residual, nullptr, &ready);
 }
 
 int sdc_end_point(sdc_ctx* c, double dt, int do_coll_update) {

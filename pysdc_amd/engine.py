@@ -1,5 +1,7 @@
 """Thin object wrapper around one libsdcmi context = the device state of one pySDC Level."""
+import collections
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -9,6 +11,63 @@ from pysdc_amd.errors import ParameterError
 
 def _dptr(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class ResidualFuture:
+    """A residual that is on its way (include/sdcmi.h: sdc_residual_post): the device work is queued, the number - and the
+    node norms, and `residual <= restol` as the device found it - are read from pinned host memory when somebody asks.
+    Stands for its number wherever one is needed (float(); calling it returns the number, which is how LevelStatus
+    evaluates what it holds).  ``fetch(block)`` returns (residual, norms, converged) or None while the record is not there."""
+
+    queued = True    # (the work is on the stream already: nothing about it has to happen before the state changes)
+    __slots__ = ('_fetch_fn', '_value', '_norms', '_converged', '__weakref__')
+
+    def __init__(self, fetch):
+        self._fetch_fn, self._value, self._norms, self._converged = fetch, None, None, None
+
+    @classmethod
+    def ready(cls, value, norms, restol=-1.0):
+        """a residual that is known already (engines without a queue: tests/_host_engine.py)"""
+        f = cls(None)
+        f._value, f._norms, f._converged = float(value), np.array(norms, dtype=float), bool(restol >= 0 and value <= restol)
+        return f
+
+    def _fetch(self, block):
+        got = self._fetch_fn(block)
+        if got is None:
+            return False
+        self._value, self._norms, self._converged = got
+        self._fetch_fn = None
+        return True
+
+    def done(self):
+        """has the record arrived?  Never waits."""
+        return self._value is not None or self._fetch(False)
+
+    def result(self):
+        if self._value is None:
+            self._fetch(True)
+        return self._value
+
+    @property
+    def norms(self):
+        self.result()
+        return self._norms
+
+    @property
+    def converged(self):
+        """residual <= restol, taken on the device against the tolerance of sdc_set_restol"""
+        self.result()
+        return self._converged
+
+    def __float__(self):
+        return float(self.result())
+
+    def __call__(self):
+        return self.result()
+
+    def __repr__(self):
+        return f'ResidualFuture({self._value if self._value is not None else "pending"})'
 
 
 class SweepEngine:
@@ -35,9 +94,18 @@ class SweepEngine:
         L.check(self.lib.sdc_ctx_create(C.byref(self.ctx), device, self.ndim, self.n, self.M, self.ncomp,
                                         C.c_void_p(stream)))
         self.tau_active = False
+        self._futures = collections.deque()   # weak references to residuals on their way (residual_post)
+        self._restol_sent = None
 
     def close(self):
         if getattr(self, 'ctx', None):
+            for ref in list(getattr(self, '_futures', ())):   # residuals still on their way are collected while the records exist
+                fut = ref()
+                if fut is not None:
+                    try:
+                        fut.result()
+                    except Exception:  # noqa: BLE001
+                        pass
             self.lib.sdc_ctx_destroy(self.ctx)
             self.ctx = None
 
@@ -236,6 +304,39 @@ class SweepEngine:
         res = C.c_double()
         self._chk(self.lib.sdc_residual(self.ctx, dt, L.RES_TYPES[residual_type], _dptr(norms), C.byref(res)))
         return res.value, norms
+
+    def residual_post(self, dt, residual_type='full_abs', restol=-1.0):
+        """queue the residual of the current state and return a ResidualFuture at once (no synchronisation); restol is the
+        tolerance the device takes its `converged` flag against"""
+        if residual_type not in L.RES_TYPES:
+            raise ParameterError(
+                f'residual_type = {residual_type} not implemented, choose '
+                f'full_abs, last_abs, full_rel or last_rel instead'
+            )
+        if restol != self._restol_sent:
+            self._chk(self.lib.sdc_set_restol(self.ctx, float(restol)))
+            self._restol_sent = restol
+        # the library keeps the last 256 records: whoever still holds an older ticket gets its values now (long done)
+        while len(self._futures) >= 200:
+            old = self._futures.popleft()()
+            if old is not None:
+                old.result()
+        t = C.c_ulonglong()
+        self._chk(self.lib.sdc_residual_post(self.ctx, dt, L.RES_TYPES[residual_type], C.byref(t)))
+        ticket = t.value
+
+        def fetch(block, self=self, ticket=ticket):
+            if not self.ctx:
+                raise RuntimeError('the engine of this residual is closed')
+            norms = np.zeros(self.M)
+            res, conv, ready = C.c_double(), C.c_int(), C.c_int()
+            self._chk(self.lib.sdc_residual_wait(self.ctx, ticket, int(block), _dptr(norms), C.byref(res), C.byref(conv),
+                                                 C.byref(ready)))
+            return (res.value, norms, bool(conv.value)) if ready.value else None
+
+        fut = ResidualFuture(fetch)
+        self._futures.append(weakref.ref(fut))
+        return fut
 
     def end_point(self, dt, do_coll_update):
         self._chk(self.lib.sdc_end_point(self.ctx, dt, int(bool(do_coll_update))))

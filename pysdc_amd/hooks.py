@@ -27,6 +27,9 @@ class Hooks:
             self.__stats[key] = value if initialize is None else initialize
 
     def return_stats(self):
+        for k, v in self.__stats.items():   # residuals that were on their way when they were logged are numbers by now
+            if getattr(v, 'queued', False):
+                self.__stats[k] = v.result()
         return self.__stats
 
     def reset_stats(self):
@@ -55,21 +58,28 @@ def _meta(step, L, **kw):
     return d
 
 
+def _residual_now_or_later(L):
+    """the residual for the statistics: the number - or, when the device is still working on it, the ResidualFuture that
+    return_stats() turns into the number (logging must not make the host wait for the device)"""
+    peek = getattr(L.status, 'peek_residual', None)
+    return peek() if peek is not None else L.status.residual
+
+
 class DefaultHooks(Hooks):
     """default_hook.py:10-98."""
 
     def post_sweep(self, step, level_number):
         L = step.levels[level_number]
-        self.add_to_stats(L.status.residual, **_meta(step, L, type='residual_post_sweep'))
+        self.add_to_stats(_residual_now_or_later(L), **_meta(step, L, type='residual_post_sweep'))
 
     def post_iteration(self, step, level_number):
         L = step.levels[level_number]
-        self.add_to_stats(L.status.residual, **_meta(step, L, type='residual_post_iteration'))
+        self.add_to_stats(_residual_now_or_later(L), **_meta(step, L, type='residual_post_iteration'))
 
     def post_step(self, step, level_number):
         L = step.levels[level_number]
         self.add_to_stats(step.status.iter, **_meta(step, L, type='niter'))
-        self.add_to_stats(L.status.residual, **_meta(step, L, type='residual_post_step'))
+        self.add_to_stats(_residual_now_or_later(L), **_meta(step, L, type='residual_post_step'))
 
 
 class Timings(Hooks):

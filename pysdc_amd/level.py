@@ -62,11 +62,19 @@ class LevelStatus(_Frozen):
         self._residual = value
 
     def residual_is_deferred(self):
-        return callable(self._residual)
+        """a residual whose device work has NOT been queued yet (a thunk); one that is merely on its way
+        (engine.ResidualFuture) is not deferred: nothing has to happen before the state it belongs to changes"""
+        return callable(self._residual) and not getattr(self._residual, 'queued', False)
+
+    def peek_residual(self):
+        """what `residual` would return, without waiting for a residual that is on its way: the ResidualFuture itself in that
+        case (hooks keep it and read the number when the statistics are collected)"""
+        r = self._residual
+        return r if getattr(r, 'queued', False) else self.residual
 
     def drop_deferred_residual(self):
         """the state the put-off residual belongs to is about to change (a sweep, a new predictor): nobody has asked"""
-        if callable(self._residual):
+        if self.residual_is_deferred():
             self._residual = None
 
     def get(self, key, default=None):
@@ -267,6 +275,10 @@ class DeviceBacked:
     def publish_residual_norms(self, norms):
         self.residual = list(norms)
 
+    def publish_residual_future(self, fut):
+        """node norms that are on their way: `residual` (a property of Level) collects them when it is read"""
+        self._residual_norms = fut
+
 
 class ForeignLevelState(DeviceBacked):
     """Device state kept by a pysdc_amd sweeper for a level object that is NOT a pysdc_amd.level.Level - in
@@ -326,6 +338,9 @@ class ForeignLevelState(DeviceBacked):
     def publish_residual_norms(self, norms):
         self.host.residual = list(norms)
 
+    def publish_residual_future(self, fut):
+        self.host.residual = list(fut.norms)
+
 
 class Level(DeviceBacked):
     """pySDC/core/level.py:42-191."""
@@ -350,6 +365,22 @@ class Level(DeviceBacked):
 
     def _db_sweep(self):
         return self.__sweep
+
+    @property
+    def residual(self):
+        """node-wise max norms of the collocation residual (the reference keeps the M residual vectors here,
+        core/sweeper.py:186-199; the engine reduces them on the way).  Norms that are still on their way
+        (publish_residual_future) are collected now."""
+        fut = self.__dict__.get('_residual_norms')
+        if fut is not None:
+            self.__dict__['_residual_norms'] = None
+            self.__dict__['_residual_list'] = list(fut.norms)
+        return self.__dict__.get('_residual_list')
+
+    @residual.setter
+    def residual(self, value):
+        self.__dict__['_residual_norms'] = None
+        self.__dict__['_residual_list'] = value
 
     # ---- device state ----------------------------------------------------------------------------------
     @property

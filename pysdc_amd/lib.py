@@ -47,6 +47,10 @@ PROTOTYPES = {
     'sdc_set_virtual_sweeps': (C.c_int, [_vp, C.c_int]),
     'sdc_set_multiplier_table': (C.c_int, [_vp, C.c_int]),
     'sdc_set_lazy_predictor_residual': (C.c_int, [_vp, C.c_int]),
+    'sdc_set_restol': (C.c_int, [_vp, C.c_double]),
+    'sdc_residual_post': (C.c_int, [_vp, C.c_double, C.c_int, C.POINTER(C.c_ulonglong)]),
+    'sdc_residual_wait': (C.c_int, [_vp, C.c_ulonglong, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                    C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     'sdc_residual_deferred': (C.c_int, [_vp]),
     'sdc_set_pipeline_groups': (C.c_int, [_vp, C.c_int]),
     'sdc_set_deferred': (C.c_int, [_vp, C.c_int]),

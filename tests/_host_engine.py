@@ -241,6 +241,13 @@ class HostEngine:
         norms = O.compute_residual(L)
         return L.status_residual, np.array(norms)
 
+    def residual_post(self, dt, residual_type='full_abs', restol=-1.0):
+        """the queued form of the device engine (SweepEngine.residual_post): on the host the number is there at once"""
+        from pysdc_amd.engine import ResidualFuture
+
+        res, norms = self.residual(dt, residual_type)
+        return ResidualFuture.ready(res, norms, restol)
+
     def end_point(self, dt, do_coll_update):
         self.calls.append('end_point')
         L = self._level(getattr(self, '_t', 0.0), dt)

@@ -229,10 +229,11 @@ def test_bench_two_ranks_on_one_gpu_end_to_end(tmp_path):
     rec = json.loads(lines[-1])
     assert 'error' not in rec, rec
     assert rec['n_gpus'] == 2 and rec['steps'] == steps and rec['scaling'] == 'weak'
-    assert rec['value'] == pytest.approx(2 * steps / (rec['ms_per_step'] * 1e-3 * steps), rel=1e-6)
-    assert len(rec['per_rank']) == 2 and [p['rank'] for p in rec['per_rank']] == [0, 1]
-    assert all(p['niter'] == [4] * steps and p['wire'] == 'shm' for p in rec['per_rank'])
-    assert rec['niter'] == [4] * steps and rec['finite']
+    assert rec['value'] == pytest.approx(2 * steps / (rec['ms_per_step'] * 1e-3 * steps), rel=1e-3)   # (the line rounds)
+    assert len(lines[-1]) < 6000
+    pr = rec['per_rank']     # (compact: one list per quantity, one entry per rank; the full per-rank records are in the side file)
+    assert len(pr['seconds']) == 2 and pr['sweeps'] == [4 * steps] * 2 and pr['wire'] == 'shm'
+    assert rec['niter'] == 4 and rec['finite']
     # the same six time steps by the serial controller emulating two ranks
     dt = 1e-3 * (512.0 / n) ** 2
     desc = dict(problem_class=heatNd_unforced, problem_params=dict(nvars=(n, n, n), nu=0.1, freq=2, order=2),
