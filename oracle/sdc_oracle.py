@@ -76,11 +76,21 @@ def fd_grid(size, bc):
     raise NotImplementedError(bc)
 
 
-def fd_matrix(derivative, order, stencil_type, dx, size, dim, bc):
-    """Sparse FD operator; helpers/problem_helper.py:83-242 (periodic and dirichlet-zero with
-    shifted boundary stencils; the Neumann / 'reduce' branches are outside the hot path)."""
+def fd_matrix_and_vector(derivative, order, stencil_type, dx, size, dim, bc, bc_params=None):
+    """Sparse FD operator and the boundary vector b; helpers/problem_helper.py:83-242 in full: periodic wrap-around,
+    Dirichlet and Neumann rows on either side (bc a string or a pair), shifted one-sided stencils or reduced order next to
+    the boundary (`reduce`), boundary values / derivatives `val`, `neumann_bc_order`.  b is set at the FLAT indices of the
+    1-D boundary rows whatever `dim` is (:204,224 - the reference's own TODO at :226), and that is restated as it stands."""
     coeff, steps = fd_stencil(derivative, order, stencil_type)
-    if bc == 'periodic':
+    if type(bc) is not tuple:
+        assert type(bc) == str, 'Please pass BCs as string or tuple of strings'
+        bc = (bc, bc)
+    bc_params = bc_params if bc_params is not None else {}
+    if type(bc_params) is not list:
+        bc_params = [bc_params, bc_params]
+    b = np.zeros(size**dim)
+    if bc[0] == 'periodic':
+        assert bc[1] == 'periodic'
         A1 = 0 * sp.eye(size, format='csc')
         for i in steps:
             A1 += coeff[i] * sp.eye(size, k=steps[i])
@@ -88,24 +98,39 @@ def fd_matrix(derivative, order, stencil_type, dx, size, dim, bc):
                 A1 += coeff[i] * sp.eye(size, k=-size + steps[i])
             if steps[i] < 0:
                 A1 += coeff[i] * sp.eye(size, k=size + steps[i])
-    elif 'dirichlet' in bc:
+    else:
         A1 = sp.diags(coeff, steps, shape=(size, size), format='lil')
+        defaults = {'val': 0.0, 'neumann_bc_order': order, 'reduce': False}
         for side in (0, 1):
+            assert 'neumann' in bc[side] or 'dirichlet' in bc[side], f'unknown BC type : {bc[side]}'
+            bc_params[side] = {**defaults, **bc_params[side]}
+            par = bc_params[side].copy()
+            val, reduce, n_order = par.pop('val'), par.pop('reduce'), par.pop('neumann_bc_order')
+            assert len(par) == 0, f'unused BCs parameters : {par}'
             width = -min(steps) if side == 0 else max(steps)
             for i in range(width):
                 line = i if side == 0 else -i - 1
                 keep = slice(1, None) if side == 0 else slice(None, -1)
-                b_steps = (
-                    np.arange(-(i + 1), order + derivative - (i + 1))
-                    if side == 0
-                    else np.arange(-(order + derivative) + (i + 2), (i + 2))
-                )
-                b_coeff, b_steps = fd_stencil(derivative, steps=b_steps)
+                edge = 0 if side == 0 else -1
+                if reduce:
+                    b_coeff, b_steps = fd_stencil(derivative, order=2 * (i + 1), stencil_type='center')
+                else:
+                    b_steps = (
+                        np.arange(-(i + 1), order + derivative - (i + 1))
+                        if side == 0
+                        else np.arange(-(order + derivative) + (i + 2), (i + 2))
+                    )
+                    b_coeff, b_steps = fd_stencil(derivative, steps=b_steps)
                 cols = slice(None, len(b_coeff) - 1) if side == 0 else slice(-len(b_coeff) + 1, None)
                 A1[line, :] = 0
                 A1[line, cols] = b_coeff[keep]
-    else:
-        raise NotImplementedError(bc)
+                if 'dirichlet' in bc[side]:
+                    b[line] = val * b_coeff[edge]
+                elif 'neumann' in bc[side]:
+                    n_coeff, n_steps = fd_stencil(1, order=n_order, stencil_type='forward' if side == 0 else 'backward')
+                    cols = slice(None, len(n_coeff) - 1) if side == 0 else slice(-len(n_coeff) + 1, None)
+                    A1[line, cols] -= b_coeff[edge] / n_coeff[edge] * n_coeff[keep]
+                    b[line] = val * b_coeff[edge] / n_coeff[edge] * dx
     A1 = A1.tocsc()
     if dim == 1:
         A = A1
@@ -120,7 +145,13 @@ def fd_matrix(derivative, order, stencil_type, dx, size, dim, bc):
     else:
         raise NotImplementedError(dim)
     A /= dx**derivative
-    return A
+    b /= dx**derivative
+    return A, b
+
+
+def fd_matrix(derivative, order, stencil_type, dx, size, dim, bc):
+    """the operator alone, the way generic_ND_FD.py:140-148 asks for it: no bc_params are passed on, b is dropped"""
+    return fd_matrix_and_vector(derivative, order, stencil_type, dx, size, dim, bc)[0]
 
 
 class _Counter:
@@ -137,7 +168,7 @@ class _Counter:
 # problems
 # ----------------------------------------------------------------------------------------------
 class FDProblem:
-    """du/dt = A u on a periodic / dirichlet-zero grid;
+    """du/dt = A u on a periodic grid or between Dirichlet / Neumann boundaries (bc a string or a pair of strings);
     implementations/problem_classes/generic_ND_FD.py:84-159 (setup), :188-206 (eval_f),
     :208-264 (solve_system)."""
 

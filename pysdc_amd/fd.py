@@ -98,38 +98,108 @@ def periodic_operator_stencil(derivative, order, kind, dx, coeff):
     return [int(s) for s in offsets], [float(x) for x in w]
 
 
-def dirichlet_operator_rows(derivative, order, kind, dx, coeff, size):
-    """coeff * d^derivative/dx^derivative on `size` interior points between two boundary points that hold zero, as a table of
-    rows: (columns[size][W] int32, -1 = unused; weights[size][W]).  Interior rows carry the stencil of the given kind; in
-    the rows whose stencil would reach beyond the boundary point the reference SHIFTS a one-sided stencil of width
-    order + derivative so that it starts at the boundary point (helpers/problem_helper.py:143-224, `reduce = False`): row i
-    (i < half width) uses the grid offsets -(i+1) .. order + derivative - (i+2), whose first weight multiplies the boundary
-    value (zero here) and is dropped; mirrored at the other end.  Weights: Fornberg's recursion in exact rationals, then the
-    reference's two scalings (/ dx**derivative, * coeff)."""
+# ---- bounded grids with any mix of Dirichlet / Neumann ends (helpers/problem_helper.py:143-224) -------------------------------
+_BC_DEFAULTS = ('val', 'neumann_bc_order', 'reduce')
+
+
+def _side_params(bc_params, side, order):
+    """parameters of one end: val (boundary value / boundary derivative), neumann_bc_order (accuracy of the one-sided first
+    derivative that closes a Neumann end; default: the operator's order), reduce (centred stencils of growing order next to
+    the boundary instead of shifted one-sided ones); unknown keys are refused like the reference does (:166)"""
+    given = bc_params[side] if isinstance(bc_params, (list, tuple)) else (bc_params or {})
+    extra = set(given) - set(_BC_DEFAULTS)
+    if extra:
+        raise AssertionError(f'unused BCs parameters : { {k: given[k] for k in sorted(extra)} }')
+    return (given.get('val', 0.0), given.get('neumann_bc_order', order), bool(given.get('reduce', False)))
+
+
+def bounded_operator_rows(derivative, order, kind, dx, size, bc, bc_params=None):
+    """d^derivative/dx^derivative on `size` interior points of a bounded 1-D grid whose two ends carry a Dirichlet or a Neumann
+    condition each - the matrix AND the boundary vector of the reference's `get_finite_difference_matrix(dim=1)`, as
+    (rows, b): rows[i] = {column: weight} (already divided by dx**derivative), b[i] the constant the boundary data add to
+    row i (f = A u + b).  bc: one string for both ends or a pair; an end is Neumann if its string contains 'neumann',
+    Dirichlet if it contains 'dirichlet' (so 'dirichlet-zero', 'neumann-zero' are accepted like there).
+
+    Row i within the half width of the interior stencil from an end gets a stencil that starts AT the boundary point: a
+    one-sided one of order + derivative points shifted there (default), or - `reduce` - the centred stencil of order
+    2 (i+1).  Its weight w_b on the boundary point multiplies data, not unknowns:
+      Dirichlet, u(boundary) = val:            b[i] = w_b val
+      Neumann,  u'(boundary) = val:            the boundary value is eliminated through the one-sided first-derivative stencil
+                                               n of accuracy neumann_bc_order over the boundary point and its neighbours,
+                                               u_b = (val dx - sum_{k>0} n_k u_k) / n_0:   row -= w_b / n_0 * n_{k>0},
+                                               b[i] = w_b val dx / n_0.
+    All weights are Fornberg's, exact rationals rounded once (module docstring)."""
+    ends = bc if isinstance(bc, tuple) else (bc, bc)
+    if len(ends) != 2 or not all(isinstance(e, str) for e in ends):
+        raise AssertionError('Please pass BCs as string or tuple of strings')
+    for e in ends:
+        if 'neumann' not in e and 'dirichlet' not in e:
+            raise AssertionError(f'unknown BC type : {e}')
     w_in, off_in = finite_difference_stencil(derivative, order, kind)
-    half_left, half_right = -int(min(off_in)), int(max(off_in))
-    shifted = order + derivative
-    if size < max(shifted - 1, len(off_in)):
-        raise ValueError(f'{size} interior points are too few for boundary stencils of width {shifted}')
-    rows = []
-    for i in range(size):
-        if i < half_left:                      # next to the left boundary: offsets -(i+1) .. , first one is the boundary
-            offs = list(range(-(i + 1), shifted - (i + 1)))
-            w, offs = finite_difference_stencil(derivative, offsets=offs)
-            entries = [(i + int(o), float(x)) for o, x in zip(offs[1:], w[1:])]
-        elif size - 1 - i < half_right:        # next to the right boundary: mirrored
-            k = size - 1 - i
-            offs = list(range(-(shifted - (k + 2)), k + 2))
-            w, offs = finite_difference_stencil(derivative, offsets=offs)
-            entries = [(i + int(o), float(x)) for o, x in zip(offs[:-1], w[:-1])]
-        else:
-            entries = [(i + int(o), float(x)) for o, x in zip(off_in, w_in) if 0 <= i + int(o) < size]
-        rows.append(entries)
+    reach = (-int(min(off_in)), int(max(off_in)))           # rows this close to the left / right end are rewritten
+    rows = [{i + int(o): float(x) for o, x in zip(off_in, w_in) if 0 <= i + int(o) < size} for i in range(size)]
+    b = np.zeros(size)
+    for side, end in enumerate(ends):
+        val, n_order, reduce = _side_params(bc_params, side, order)
+        for i in range(reach[side]):
+            row = i if side == 0 else size - 1 - i
+            if reduce:
+                w, offs = finite_difference_stencil(derivative, 2 * (i + 1), 'center')
+            else:
+                first = -(i + 1) if side == 0 else -(order + derivative) + (i + 2)
+                w, offs = finite_difference_stencil(derivative, offsets=range(first, first + order + derivative))
+            # the stencil as the reference places it: its first (left end) / last (right end) weight sits on the boundary
+            # point, the others on the len(w) - 1 grid points next to that end, in order
+            inner = list(w[1:]) if side == 0 else list(w[:-1])
+            w_b = float(w[0] if side == 0 else w[-1])
+            cols = range(len(inner)) if side == 0 else range(size - len(inner), size)
+            if len(inner) > size:
+                raise ValueError(f'{size} interior points are too few for a boundary stencil of {len(w)} points')
+            entries = {int(c): float(x) for c, x in zip(cols, inner)}
+            if 'dirichlet' in end:
+                b[row] = val * w_b
+            else:
+                n, _ = finite_difference_stencil(1, n_order, 'forward' if side == 0 else 'backward')
+                n_in = list(n[1:]) if side == 0 else list(n[:-1])
+                n_b = float(n[0] if side == 0 else n[-1])
+                if len(n_in) > size:
+                    raise ValueError(f'{size} interior points are too few for a Neumann closure of order {n_order}')
+                ncols = range(len(n_in)) if side == 0 else range(size - len(n_in), size)
+                for c, x in zip(ncols, n_in):
+                    entries[int(c)] = entries.get(int(c), 0.0) - w_b / n_b * float(x)
+                b[row] = val * w_b / n_b * dx
+            rows[row] = entries
+    scale = dx**derivative
+    return [{c: x / scale for c, x in r.items()} for r in rows], b / scale
+
+
+def rows_to_table(rows, coeff=1.0):
+    """row dictionaries -> the fixed-width table sdc_set_banded_operator takes: (columns[size][W] int32, -1 = unused;
+    weights[size][W], multiplied by coeff - the factor generic_ND_FD.py:149 applies to the finished matrix)"""
+    size = len(rows)
     width = max(len(r) for r in rows)
     cols = -np.ones((size, width), dtype=np.int32)
     wts = np.zeros((size, width))
-    for i, entries in enumerate(rows):
-        for k, (j, x) in enumerate(entries):
-            cols[i, k] = j
-            wts[i, k] = x / dx**derivative * coeff
+    for i, r in enumerate(rows):
+        for k, c in enumerate(sorted(r)):
+            cols[i, k] = c
+            wts[i, k] = r[c] * coeff
     return cols, wts
+
+
+def rows_to_dense(rows):
+    A = np.zeros((len(rows), len(rows)))
+    for i, r in enumerate(rows):
+        for c, x in r.items():
+            A[i, c] = x
+    return A
+
+
+def boundary_vector_nd(b_1d, size, dim):
+    """the vector get_finite_difference_matrix returns for `dim` dimensions: the 1-D boundary constants at the SAME flat
+    indices of a zero vector of length size**dim (helpers/problem_helper.py:137,204,224: `b[iLine] = ...` with iLine a row of
+    the 1-D matrix; its extension to the other faces is the reference's own TODO at :226)"""
+    b = np.zeros(size**dim)
+    for i in np.nonzero(b_1d)[0]:
+        b[i if i < size - 1 - i else i - size] = b_1d[i]      # (rows of the left end count from the front, the others from the back)
+    return b

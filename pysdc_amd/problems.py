@@ -185,17 +185,16 @@ class GenericNDimFinDiff(Problem):
     fused = True
 
     def __init__(self, nvars=512, coeff=1.0, derivative=1, freq=2, stencil_type='center', order=2, lintol=1e-12,
-                 liniter=10000, solver_type='direct', bc='periodic', bcParams=None):
+                 liniter=10000, solver_type='direct', bc='periodic', bcParams=None, use_bcParams=False):
         nvars, freq, bc = _grid_spec(nvars, freq, bc)
         ndim = len(nvars)
-        if bc not in ('periodic', 'dirichlet-zero'):
-            raise ProblemError(f'the MI355X engine implements periodic and dirichlet-zero boundaries, got bc={bc!r}')
-        if bc == 'dirichlet-zero' and (derivative != 2 or stencil_type != 'center' or order % 2):
-            raise ProblemError(
-                'dirichlet-zero is available for the centred second derivative of even order (order 2: odd extension and the '
-                f'sine-transform solve; higher orders: banded rows and an iterative solve); got order={order}, '
-                f'derivative={derivative}, stencil_type={stencil_type!r}'
-            )
+        # Boundaries: 'periodic'; or Dirichlet / Neumann ends in any mix - one string for both ends ('dirichlet-zero',
+        # 'dirichlet', 'neumann', 'neumann-zero', ...: an end is what its string contains, helpers/problem_helper.py:157) or a
+        # pair such as ('dirichlet', 'neumann') (generic_ND_FD.py:50-54).  bcParams is accepted and - exactly like the
+        # reference, whose constructor neither passes it on nor keeps the boundary vector (generic_ND_FD.py:140-148:
+        # `self.A, _ = get_finite_difference_matrix(..., bc=bc)`) - has no effect on the operator: boundary values and
+        # derivatives are zero.  The helper underneath (pysdc_amd.fd.bounded_operator_rows) implements all of them.
+        # An unknown boundary type ends in get_1d_grid's NotImplementedError, as there (helpers/problem_helper.py:267).
         if solver_type not in ('direct', 'CG', 'GMRES'):
             raise ProblemError(f'solver type "{solver_type}" not known in generic advection-diffusion implementation!')
         super().__init__(init=(nvars[0] if ndim == 1 else nvars, None, np.dtype('float64')))
@@ -207,17 +206,28 @@ class GenericNDimFinDiff(Problem):
         # 2-D / 3-D: the interior is strided inside the extension, so fields stay compact and are packed into / extracted
         # from extension-sized scratch around eval_f and solve_system (sdc_odd_extend / sdc_odd_extract); the sweep then
         # runs node by node on datatype operations (fused = False).
-        # dirichlet-zero with stencils of order >= 4: the reference shifts one-sided stencils into the rows next to the
-        # boundary (helpers/problem_helper.py:143-224) - a non-symmetric banded matrix per axis.  Fields stay compact (the
+        # every other bounded grid - dirichlet-zero with stencils of order >= 4, Neumann ends, mixed ends, one-sided
+        # stencils: the reference rewrites the rows next to the boundary (helpers/problem_helper.py:143-224: shifted
+        # one-sided stencils, a Neumann end eliminated through a one-sided first derivative) - a non-symmetric banded matrix per axis.  Fields stay compact (the
         # first n^ndim values of slab fields sized (n+1)^ndim), eval_f applies the row table axis by axis, the solve is
         # GMRES (to round-off for 'direct', the user's tolerance and counts for 'GMRES' / 'CG'), sweeps run node by node.
-        self.banded = bc == 'dirichlet-zero' and order > 2
-        self.view_offset = 1 if (bc == 'dirichlet-zero' and ndim == 1 and not self.banded) else 0
-        self.odd_nd = bc == 'dirichlet-zero' and ndim > 1 and not self.banded
-        self.engine_nvars = (2 * (nvars[0] + 1),) * ndim if bc == 'dirichlet-zero' else nvars
+        bounded = bc != 'periodic'
+        odd_extension = bc == 'dirichlet-zero' and derivative == 2 and stencil_type == 'center' and order == 2
+        self.banded = bounded and not odd_extension
+        self.view_offset = 1 if (odd_extension and ndim == 1) else 0
+        self.odd_nd = odd_extension and ndim > 1
+        self.engine_nvars = (2 * (nvars[0] + 1),) * ndim if odd_extension else nvars
         if self.banded:
-            self.engine_nvars = (nvars[0] + 1,) * ndim
-            self._rows = fd.dirichlet_operator_rows(derivative, order, stencil_type, dx, coeff, nvars[0])
+            self.engine_nvars = (nvars[0] + nvars[0] % 2,) * ndim    # (slab fields: an even number of points per axis, >= n)
+            # use_bcParams (an extension, default off = the reference's behaviour described above): the rows are built WITH
+            # bcParams and the boundary vector is kept: f(u) = coeff (D u + b), (I - factor coeff D) u = rhs + factor coeff b.
+            # 1-D only - in more dimensions the reference's b covers two corners of the grid (its own TODO, :226)
+            if use_bcParams and ndim > 1:
+                raise NotImplementedError('boundary data (bcParams) are defined for one dimension (helpers/problem_helper.py:226)')
+            rows, bvec = fd.bounded_operator_rows(derivative, order, stencil_type, dx, nvars[0], bc,
+                                                  bcParams if use_bcParams else None)
+            self._rows = fd.rows_to_table(rows, coeff)
+            self._bvec_host = coeff * bvec if (use_bcParams and np.any(bvec)) else None
         if self.odd_nd or self.banded:
             self.fused = False
         self._scratch = None
@@ -294,15 +304,31 @@ class GenericNDimFinDiff(Problem):
     def _out_ptr(self, k, dst):
         return self._ext(k).ptr if (self.view_offset or self.odd_nd) else dst.ptr   # (banded: in place, nothing to stage)
 
+    def _boundary_data(self):
+        """coeff * b on the device (use_bcParams), or None"""
+        if getattr(self, '_bvec_host', None) is None:
+            return None
+        if getattr(self, '_bvec_dev', None) is None:
+            self._bvec_dev = self._from_host(self._bvec_host.reshape(self.nvars))
+        return self._bvec_dev
+
     def eval_f(self, u, t):
         f = self._out_f()
         self.engine.eval_f(self._stage_in(u, 0), 0.0, self._out_ptr(1, f))
         self._stage_out(1, f)
+        b = self._boundary_data()
+        if b is not None:
+            f._axpby(1.0, f, 1.0, b, f)
         return f
 
     def solve_system(self, rhs, factor, u0, t):
         sol = self._out_u()
         guess = self._stage_in(u0, 2) if self.solver_type in ('CG', 'GMRES') and u0 is not None else None
+        b = self._boundary_data()
+        if b is not None:
+            shifted = self._out_u()
+            shifted._axpby(1.0, rhs, float(factor), b, shifted)
+            rhs = shifted
         self.engine.solve(self._stage_in(rhs, 0), float(factor), self._out_ptr(1, sol), guess)
         self._stage_out(1, sol)
         return sol

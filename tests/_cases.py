@@ -22,8 +22,9 @@ def load_cases(fname):
 
 def make_oracle_problem(prob, pp):
     pp = dict(pp)
-    if 'nvars' in pp and isinstance(pp['nvars'], list):
-        pp['nvars'] = tuple(pp['nvars'])
+    for key in ('nvars', 'bc', 'freq'):      # (JSON has no tuples)
+        if isinstance(pp.get(key), list):
+            pp[key] = tuple(pp[key])
     if prob == 'heat_unforced':
         return O.HeatUnforced(**pp)
     if prob == 'heat_forced':

@@ -11,7 +11,7 @@ own entry points, switched on by environment variables (or call the function aft
 GOLDEN_FFT=1 fft_transfer_main (transfer_fft.npz, runs_ac_fft.npz), GOLDEN_RELAY=1 relay_main (runs_relay.npz),
 GOLDEN_CG=1 cg_main (sweeps_cg.npz), GOLDEN_VDPJ=1 vdp_jacobian_main (vdp_jacobian.npz), GOLDEN_DML=1
 dirichlet_ml_main (transfer_dirichlet.npz, runs_ml_dirichlet.npz), GOLDEN_GUESS=1 guess_main (sweeps_guess.npz), GOLDEN_SKIP=1 skip_main (runs_skip.npz), GOLDEN_RELAY8=1 relay8_main (runs_relay8.npz),
-GOLDEN_BIG3D=1 big3d_main (sweeps_big3d.npz), GOLDEN_CFG5=1 cfg5_main (runs_cfg5.npz), GOLDEN_ML8=1 ml8_main (runs_ml8.npz), GOLDEN_DND=1 dirichlet_nd_main (sweeps_dirichlet_nd.npz, runs_dirichlet_nd.npz), GOLDEN_NSW2=1 nsweeps2_main (runs_nsweeps2.npz), GOLDEN_PIN1024=1 pin1024_main (sweeps_pin1024.npz, 20 minutes), GOLDEN_GMRES=1 gmres_main (sweeps_gmres.npz), GOLDEN_DHO=1 dirichlet_ho_main (sweeps_dirichlet_ho.npz, runs_dirichlet_ho.npz, dirichlet_ho_matrices.npz);
+GOLDEN_BIG3D=1 big3d_main (sweeps_big3d.npz), GOLDEN_CFG5=1 cfg5_main (runs_cfg5.npz), GOLDEN_ML8=1 ml8_main (runs_ml8.npz), GOLDEN_DND=1 dirichlet_nd_main (sweeps_dirichlet_nd.npz, runs_dirichlet_nd.npz), GOLDEN_NSW2=1 nsweeps2_main (runs_nsweeps2.npz), GOLDEN_PIN1024=1 pin1024_main (sweeps_pin1024.npz, 20 minutes), GOLDEN_GMRES=1 gmres_main (sweeps_gmres.npz), GOLDEN_DHO=1 dirichlet_ho_main (sweeps_dirichlet_ho.npz, runs_dirichlet_ho.npz, dirichlet_ho_matrices.npz), GOLDEN_BC=1 boundary_main (boundary_matrices.npz, sweeps_neumann.npz, runs_neumann.npz);
 GOLDEN_ML=0 skips the multi-level block.
 
 ``qmat`` (third-party, absent here) is replaced by oracle/qmat_shim, which forwards to
@@ -1015,3 +1015,77 @@ def dirichlet_ho_main():
 
 if __name__ == '__main__' and os.environ.get('GOLDEN_DHO', '0') == '1':
     dirichlet_ho_main()
+
+
+def boundary_main():
+    """Neumann / mixed / inhomogeneous boundaries (helpers/problem_helper.py:143-224; generic_ND_FD.py:50-70).
+    boundary_matrices.npz: A (dense) and b of get_finite_difference_matrix for every branch - both kinds of ends and their
+    mixes, val != 0, reduce, neumann_bc_order, centred and one-sided interior stencils, dim 1 and (for b's indexing) dim 2 / 3.
+    sweeps_neumann.npz / runs_neumann.npz: the problem classes with such boundaries (the constructor of GenericNDimFinDiff
+    passes neither bcParams nor b on, generic_ND_FD.py:140-148: what the classes compute is the homogeneous operator)."""
+    from pySDC.helpers import problem_helper
+
+    combos = [(2, 2, 'center'), (2, 4, 'center'), (2, 6, 'center'), (1, 2, 'center'), (1, 4, 'center'), (1, 1, 'upwind'),
+              (1, 3, 'upwind'), (1, 5, 'upwind'), (1, 2, 'forward'), (1, 3, 'backward')]
+    bcs = ['dirichlet', 'neumann', ('dirichlet', 'neumann'), ('neumann', 'dirichlet'), 'neumann-zero']
+    pars = [None, {'val': 1.5}, {'reduce': True}, {'neumann_bc_order': 2},
+            [{'val': -0.5, 'reduce': True}, {'val': 2.0, 'neumann_bc_order': 3}]]
+    cases, arrays = [], {}
+
+    def add(der, order, kind, bc, par, size, dim):
+        dx = 1.0 / (size + 1)
+        given = None if par is None else ([dict(p) for p in par] if isinstance(par, list) else dict(par))
+        A, b = problem_helper.get_finite_difference_matrix(derivative=der, order=order, stencil_type=kind, dx=dx, size=size,
+                                                           dim=dim, bc=bc, bc_params=given)
+        k = len(cases)
+        cases.append(dict(derivative=der, order=order, stencil_type=kind, bc=bc, bc_params=par, size=size, dim=dim, dx=dx))
+        arrays[f'A{k}'] = A.toarray() if dim == 1 else np.zeros((1, 1))
+        arrays[f'b{k}'] = b
+
+    for der, order, kind in combos:
+        for bc in bcs:
+            for par in pars:
+                add(der, order, kind, bc, par, 17, 1)
+    for dim in (2, 3):
+        add(2, 4, 'center', ('neumann', 'dirichlet'), [{'val': 1.0}, {'val': 2.0}], 9, dim)
+        add(1, 3, 'upwind', 'dirichlet', {'val': -3.0}, 9, dim)
+    np.savez_compressed(os.path.join(OUT, 'boundary_matrices.npz'), cases=np.array(json.dumps(cases)), **arrays)
+
+    RR = dict(quad_type='RADAU-RIGHT')
+    cases = []
+    cases.append(sweep_case('heat1d_neumann_o2', 'heat_unforced', dict(nvars=63, nu=0.1, freq=3, order=2, bc='neumann'),
+                            'generic_implicit', dict(num_nodes=3, QI='LU', **RR), 5e-3))
+    cases.append(sweep_case('heat1d_neumann_zero_o4', 'heat_unforced', dict(nvars=32, nu=0.1, freq=2, order=4, bc='neumann-zero'),
+                            'generic_implicit', dict(num_nodes=5, QI='IE', **RR), 1e-2))
+    cases.append(sweep_case('heat1d_mixed_o2', 'heat_unforced', dict(nvars=40, nu=0.1, freq=1, order=2, bc=('dirichlet', 'neumann')),
+                            'generic_implicit', dict(num_nodes=3, QI='LU', **RR), 1e-2))
+    cases.append(sweep_case('heat1d_dirichlet_even_grid', 'heat_unforced', dict(nvars=48, nu=0.1, freq=2, order=2, bc='dirichlet'),
+                            'generic_implicit', dict(num_nodes=3, QI='IE', **RR), 1e-2))
+    cases.append(sweep_case('heat2d_neumann_o2', 'heat_unforced', dict(nvars=(16, 16), nu=0.1, freq=(1, 2), order=2, bc='neumann'),
+                            'generic_implicit', dict(num_nodes=3, QI='LU', **RR), 2e-2))
+    cases.append(sweep_case('heat2d_mixed_o4', 'heat_unforced', dict(nvars=(15, 15), nu=0.1, freq=(1, 1), order=4, bc=('neumann', 'dirichlet')),
+                            'generic_implicit', dict(num_nodes=3, QI='IE', **RR), 2e-2))
+    cases.append(sweep_case('heat3d_neumann_o2_gmres', 'heat_unforced',
+                            dict(nvars=(8, 8, 8), nu=0.1, freq=(1, 1, 2), order=2, bc='neumann', solver_type='GMRES', lintol=1e-12,
+                                 liniter=1000),
+                            'generic_implicit', dict(num_nodes=3, QI='IE', **RR), 1e-2))
+    cases.append(sweep_case('forced1d_neumann_o2', 'heat_forced', dict(nvars=31, nu=0.1, freq=2, order=2, bc='neumann'),
+                            'imex_1st_order', dict(num_nodes=3, QI='LU', QE='EE', **RR), 1e-2, u0_kind='exact'))
+    cases.append(sweep_case('forced2d_mixed_o4', 'heat_forced', dict(nvars=(15, 15), nu=0.1, freq=(1, 3), order=4, bc=('dirichlet', 'neumann')),
+                            'imex_1st_order', dict(num_nodes=3, QI='LU', QE='EE', **RR), 2e-2, u0_kind='exact'))
+    cases.append(sweep_case('advection1d_dirichlet_upwind3', 'advection', dict(nvars=40, c=1.0, freq=2, order=3, stencil_type='upwind', bc='dirichlet'),
+                            'generic_implicit', dict(num_nodes=3, QI='LU', **RR), 1e-2))
+    save('sweeps_neumann.npz', cases)
+    cases = [run_case('heat2d_neumann_run', prob='heat_unforced',
+                      prob_params=dict(nvars=(24, 24), nu=0.1, freq=(1, 1), order=2, bc='neumann'), sweeper='generic_implicit',
+                      sweeper_params=dict(num_nodes=3, QI='LU', **RR), level_params=dict(dt=0.05, restol=1e-9), maxiter=50, t0=0.0,
+                      Tend=0.15),
+             run_case('forced1d_mixed_run', prob='heat_forced',
+                      prob_params=dict(nvars=63, nu=0.1, freq=1, order=2, bc=('neumann', 'dirichlet')), sweeper='imex_1st_order',
+                      sweeper_params=dict(num_nodes=3, QI='LU', QE='EE', **RR), level_params=dict(dt=0.02, restol=1e-9), maxiter=50,
+                      t0=0.0, Tend=0.06)]
+    save('runs_neumann.npz', cases)
+
+
+if __name__ == '__main__' and os.environ.get('GOLDEN_BC', '0') == '1':
+    boundary_main()

@@ -30,6 +30,7 @@ def description_from(meta, problem_class=None):
 RUNS = ([('runs.npz', n) for n in load_cases('runs.npz')] + [('runs_dirichlet.npz', n) for n in load_cases('runs_dirichlet.npz')]
         + [('runs_dirichlet_nd.npz', n) for n in load_cases('runs_dirichlet_nd.npz')]
         + [('runs_dirichlet_ho.npz', n) for n in load_cases('runs_dirichlet_ho.npz')]
+        + [('runs_neumann.npz', n) for n in load_cases('runs_neumann.npz')]
         + [('runs_skip.npz', n) for n in load_cases('runs_skip.npz')])
 
 
@@ -319,7 +320,8 @@ def test_bench_single_rank_distributed_path():
 
 DIRICHLET_SWEEPS = ([('sweeps_heat.npz', 'heat1d_dirichlet'), ('sweeps_imex.npz', 'forced1d_dirichlet')]
                     + [('sweeps_dirichlet_nd.npz', n) for n in load_cases('sweeps_dirichlet_nd.npz')]
-                    + [('sweeps_dirichlet_ho.npz', n) for n in load_cases('sweeps_dirichlet_ho.npz')])
+                    + [('sweeps_dirichlet_ho.npz', n) for n in load_cases('sweeps_dirichlet_ho.npz')]
+                    + [('sweeps_neumann.npz', n) for n in load_cases('sweeps_neumann.npz')])   # Neumann / mixed ends, one-sided stencils
 
 
 @pytest.mark.parametrize('fname,name', DIRICHLET_SWEEPS)

@@ -61,3 +61,26 @@ def test_level_status_holds_a_put_off_residual():
     assert clone.residual == 0.25 and calls == [1, 1]
     st.residual = 1.5
     assert copy.deepcopy(st).residual == 1.5 and st.get('unlocked') is False
+
+
+def test_bounded_grids_of_any_mix_are_accepted_like_the_reference():
+    """bc as one string for both ends or a pair (generic_ND_FD.py:50-54); an end is Dirichlet / Neumann if its string
+    contains the word (helpers/problem_helper.py:157); point counts are only checked for the exact string 'dirichlet-zero'
+    (generic_ND_FD.py:130); bcParams changes nothing, as in the reference (generic_ND_FD.py:140-148)."""
+    import numpy as np
+
+    from pysdc_amd.problems import heatNd_unforced, GenericNDimFinDiff
+
+    P = heatNd_unforced(nvars=40, nu=0.1, freq=1, order=2, bc=('dirichlet', 'neumann'))
+    assert P.bc == ('dirichlet', 'neumann') and P.banded and not P.fused and P.engine_nvars == (40,)
+    assert abs(P.dx - 1 / 41) < 1e-15
+    assert heatNd_unforced(nvars=48, bc='dirichlet').banded                       # (an even grid: no rule for this string)
+    assert heatNd_unforced(nvars=63, bc='dirichlet-zero').view_offset == 1        # order 2: the odd extension stays
+    assert heatNd_unforced(nvars=(16, 16), bc='neumann', freq=(1, 2)).banded
+    a = GenericNDimFinDiff(nvars=17, coeff=0.5, derivative=2, order=4, bc='neumann')
+    b = GenericNDimFinDiff(nvars=17, coeff=0.5, derivative=2, order=4, bc='neumann', bcParams={'val': 3.0, 'reduce': True})
+    assert np.array_equal(a._rows[0], b._rows[0]) and np.array_equal(a._rows[1], b._rows[1])
+    with pytest.raises(NotImplementedError):
+        heatNd_unforced(nvars=40, bc='robin')
+    with pytest.raises(NotImplementedError):       # get_1d_grid looks for the exact words in a pair (problem_helper.py:263)
+        heatNd_unforced(nvars=40, bc=('dirichlet-zero', 'neumann-zero'))
