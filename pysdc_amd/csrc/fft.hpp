@@ -156,23 +156,32 @@ DEVI void dft(cd (&x)[R]) {
 constexpr int fft_elems(int N) { return N < SDC_FFT_E ? N : SDC_FFT_E; }
 
 // LDS index maps (in doubles).  The skew (pos >> 4) breaks the power-of-two strides of the stage-1 scatter.
+// kUnit: doubles between neighbouring (skewed) positions of one column.  A run of positions pos0 + m * d with d a multiple of
+// 16 - or d = 1 inside one group of 16 - is affine in m: idx(col, pos0) + m * kUnit * (d + d / 16) resp. + m * kUnit, which lets
+// the exchange address all its elements from ONE computed index plus compile-time offsets (SDC_FFT_AFFINE).
 template <int N>
 struct LayContig {  // lines are separate: [col][pos]
     static constexpr int kLine = N + (N >> 4);
+    static constexpr int kUnit = 1;
     DEVI static int idx(int col, int pos) { return col * kLine + pos + (pos >> 4); }
     static constexpr int doubles(int cols) { return cols * kLine; }
 };
 template <int N>
 struct LayCols {  // like LayContig, with the columns 16 dwords apart modulo the 64 banks (8 columns written by one wave)
     static constexpr int kLine = N + (N >> 4) + 8;
+    static constexpr int kUnit = 1;
     DEVI static int idx(int col, int pos) { return col * kLine + pos + (pos >> 4); }
     static constexpr int doubles(int cols) { return cols * kLine; }
 };
 template <int N, int T>
 struct LayStrided {  // T columns interleaved: [pos][col]
+    static constexpr int kUnit = T;
     DEVI static int idx(int col, int pos) { return (pos + (pos >> 4)) * T + col; }
     static constexpr int doubles(int) { return (N + (N >> 4)) * T; }
 };
+#ifndef SDC_FFT_AFFINE
+#define SDC_FFT_AFFINE 1
+#endif
 
 // one Stockham stage on the registers of one thread: radix R, NS = product of the previous radices
 template <int N, int R, int NS, int DIR, int EE = fft_elems(N)>
@@ -229,21 +238,34 @@ DEVI void fft_sync() {
 template <int N, int R, int NS, class LAY, bool WAVE = false, int EE = fft_elems(N)>
 DEVI void fft_exchange(cd (&r)[EE], int j, int col, double* lds) {
     constexpr int E = EE, P = N / E, NB = E / R;
+    // positions written: base + t * NS; read: j + i * P.  Affine in t / i when the steps are multiples of 16 (no carry into the
+    // skew) or, for NS = 1, when base is a multiple of 16 and t < 16
+    constexpr bool WAFF = SDC_FFT_AFFINE && (NS % 16 == 0 || (NS == 1 && R == 16));
+    constexpr bool RAFF = SDC_FFT_AFFINE && P % 16 == 0;
+    constexpr int WSTEP = LAY::kUnit * (NS % 16 == 0 ? NS + NS / 16 : 1), RSTEP = LAY::kUnit * (P + P / 16);
+    int wbase[NB];
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+        const int b = j + q * P;
+        const int k = b & (NS - 1);
+        wbase[q] = WAFF ? LAY::idx(col, (b - k) * R + k) : (b - k) * R + k;
+    }
+    const int rbase = LAY::idx(col, j);
 #pragma unroll
     for (int part = 0; part < 2; ++part) {
 #pragma unroll
         for (int q = 0; q < NB; ++q) {
-            const int b = j + q * P;
-            const int k = b & (NS - 1);
-            const int base = (b - k) * R + k;
 #pragma unroll
-            for (int t = 0; t < R; ++t)
-                lds[LAY::idx(col, base + t * NS)] = part == 0 ? r[q + t * NB].x : r[q + t * NB].y;
+            for (int t = 0; t < R; ++t) {
+                const double v = part == 0 ? r[q + t * NB].x : r[q + t * NB].y;
+                if constexpr (WAFF) lds[wbase[q] + t * WSTEP] = v;
+                else lds[LAY::idx(col, wbase[q] + t * NS)] = v;
+            }
         }
         fft_sync<WAVE>();
 #pragma unroll
         for (int i = 0; i < E; ++i) {
-            const double v = lds[LAY::idx(col, j + i * P)];
+            const double v = RAFF ? lds[rbase + i * RSTEP] : lds[LAY::idx(col, j + i * P)];
             if (part == 0) r[i].x = v;
             else r[i].y = v;
         }

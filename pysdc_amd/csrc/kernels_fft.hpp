@@ -198,6 +198,11 @@ __global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_inv(FieldPtr
         // C[k] and C[N-k]) and every wave picks up its column: 4 workgroup barriers per tile instead of 12.
         using LC = LayCols<N>;
         const int cw = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        // rows k = j + i P and N - k, P a multiple of 16: the skewed positions are affine in i (fft.hpp) - one index each,
+        // compile-time offsets for the rest
+        static_assert(P % 16 == 0, "XWAVE: 64 threads per column");
+        constexpr int STEP = P + P / 16;
+        const int i_own = LC::idx(col, j), i_mir = LC::idx(col, N - j), i_rd = LC::idx(cw, lane);
 #pragma unroll
         for (int part = 0; part < 2; ++part) {
 #pragma unroll
@@ -213,14 +218,14 @@ __global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_inv(FieldPtr
                         own = edge ? B[i].x : A[i].y + B[i].x;
                         mir = -A[i].y + B[i].x;
                     }
-                    lds[LC::idx(col, k)] = own;
-                    if (!edge) lds[LC::idx(col, N - k)] = mir;
+                    lds[i_own + i * STEP] = own;
+                    if (!edge) lds[i_mir - i * STEP] = mir;
                 }
             }
             __syncthreads();
 #pragma unroll
             for (int i = 0; i < E; ++i) {
-                const double v = lds[LC::idx(cw, lane + i * P)];
+                const double v = lds[i_rd + i * STEP];
                 if (part == 0) r[i].x = v;
                 else r[i].y = v;
             }
