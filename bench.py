@@ -324,12 +324,19 @@ def run_workload(args, world, rank, use_dist, with_stream_reference=True):
     del u0
     sync()
     eng.profile_enable(True)
+    coarser = [Lc.engine for Lc in step.levels[1:] if hasattr(Lc, 'engine')]
+    for ec in coarser:
+        ec.profile_enable(True)
     t0 = time.perf_counter()
     uend, stats = ctrl.run(uend, block * args.warmup, block * (args.warmup + args.steps))
     sync()
     el = time.perf_counter() - t0
     prof = eng.profile_read()
     eng.profile_enable(False)
+    prof_coarse = []
+    for ec in coarser:
+        prof_coarse.append((ec.n, ec.profile_read()))
+        ec.profile_enable(False)
 
     el_own = el
     elt = torch.tensor([el], dtype=torch.float64)   # (host tensor: the process group is gloo)
@@ -408,6 +415,32 @@ def run_workload(args, world, rank, use_dist, with_stream_reference=True):
                              'frac': tf / F64_VALU_PEAK_TFLOPS, 'hbm_gbs': ach,
                              'note': f'{VDP_VALU_PER_WAVE} VALU wave-instructions per 64 trajectories and sweep (SQ_INSTS_VALU, '
                                      'profiles/r03/vdp_block_solver_counters.json) priced as 64-lane FMAs'})
+        if args.workload == 'allencahn' and sweeps_total:
+            # a multi-level iteration is many short launches: the figure that says something is the iteration as a whole -
+            # algorithmic bytes of every launch the engines of both levels timed (quadratures, transforms, node right-hand
+            # sides; the space-transfer launches run outside the engines and are left out of the bytes, not of the time),
+            # over the WALL time of an iteration
+            tab_extra = {'node_rhs': 4.0, 'axpby': 3.0, 'copy': 2.0, 'fill': 1.0, 'reaction': 2.0, 'integrate': 1 + 2 * M + M,
+                         'end_point': 2 + 2 * M}
+            def it_bytes(pr, n_):
+                tot = 0.0
+                for k_, v_ in pr.items():
+                    b_ = _kernel_bytes(k_, n_, M, ncomp)
+                    if b_ is None and k_.split('[')[0] in tab_extra:
+                        b_ = tab_extra[k_.split('[')[0]] * 8.0 * n_**3
+                    tot += (b_ or 0.0) * v_[1]
+                return tot
+            moved = it_bytes(prof, n) + sum(it_bytes(pc, nc_) for nc_, pc in prof_coarse)
+            kernel_ms = sum(v_[0] for v_ in prof.values()) + sum(v_[0] for _, pc in prof_coarse for v_ in pc.values())
+            iters = max(1, sweeps_total // world)
+            wall_ms = 1e3 * el / iters
+            roof = {'kernel': 'iteration (fine sweep, FAS down / coarse sweep / up, re-evaluation)', 'bound': 'hbm',
+                    'achieved': moved / iters / wall_ms / 1e6, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': moved / iters / wall_ms / 1e6 / HBM_PEAK_GBS, 'traffic': None,
+                    'algorithmic_bytes_per_launch': moved / iters, 'ms_per_launch': wall_ms,
+                    'engine_kernel_ms_per_iteration': kernel_ms / iters,
+                    'launches_per_iteration': (sum(v_[1] for v_ in prof.values())
+                                               + sum(v_[1] for _, pc in prof_coarse for v_ in pc.values())) / iters}
         in_sweep = ('gather', 'fft_x_fwd', 'fft_y_fwd', 'fft_z_fwd', 'fft_z_solve', 'spec_point', 'spec_point_res', 'spec_point_only', 'spec_z', 'spec_z_res', 'spec_z_spread', 'spec_z_res_spread',
                     'spec_z_res_v0', 'spec_z_res_v1', 'spec_z_res_v2', 'spec_z_res_v3', 'spec_z_res_v4', 'spec_z_res_v5', 'spec_z_res_v6', 'spec_z_res_v7+', 'spec_store', 'spec_z_res_tab', 'spec_z_tab', 'spec_z_res_last', 'spec_z_last',
                     'spec_z_v0', 'spec_z_v1', 'spec_z_v2', 'spec_z_v3', 'spec_z_v4', 'spec_z_v5', 'spec_z_v6', 'spec_z_v7+',

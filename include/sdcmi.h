@@ -296,6 +296,13 @@ int sdc_integrate(sdc_ctx* ctx, double dt, double* const* dst);
 /* eval_f (generic_ND_FD.py:188-206; HeatEquation_ND_FD.py:162-204 for the IMEX variant).  g_t is the value
  * of the forcing's time factor g(t) (only read for SDC_EXPL_FORCING); f_expl may be NULL. */
 int sdc_eval_f(sdc_ctx* ctx, const double* u, double g_t, double* f_impl, double* f_expl);
+/* eval_f of nf <= num_nodes fields in ONE pass of the launches sdc_eval_f takes per field (spectral operators: one transform
+ * round trip for all of them, the pointwise reaction term of each riding on the pass that reads it; stencil operators: one
+ * marching launch).  This is the loop of core/base_transfer.py:207-213 (`F.f[m] = P.eval_f(F.u[m], ...)` for every node after
+ * a prolongation) and of the predictors' node evaluations.  g_t: one forcing factor per field, or null; f_expl: null or one
+ * pointer per field.  Same values as nf calls of sdc_eval_f. */
+int sdc_eval_f_batch(sdc_ctx* ctx, int nf, const double* const* u, const double* g_t, double* const* f_impl,
+                     double* const* f_expl);
 /* solve_system(rhs, factor, u0, t) (generic_ND_FD.py:208-264, 'direct'): (I - factor*A) out = rhs; `guess` is
  * the reference's u0 argument (unused by the direct solver, may be NULL; the Newton solver requires it). */
 int sdc_solve(sdc_ctx* ctx, const double* rhs, double factor, const double* guess, double* out);
@@ -356,6 +363,11 @@ int sdc_transfer_apply(void* stream, int ndim, int n_out, int n_in, int width, c
  * values U[1..M] of a slab, a set of quadrature integrals - one launch per axis for all of them. */
 int sdc_transfer_apply_batch(void* stream, int nfields, int ndim, int n_out, int n_in, int width, const int* idx,
                              const double* w, const double* in, double* out);
+/* ... with accumulate = 1 the last pass ADDS the result to `out` instead of storing it: the coarse-grid correction
+ * u_F[m] += P (u_G[m] - uold_G[m]) of core/base_transfer.py:196-205 without a field for the prolonged difference and
+ * without the pass that adds it (same bits: x + P d either way). */
+int sdc_transfer_apply_batch_acc(void* stream, int nfields, int ndim, int n_out, int n_in, int width, const int* idx,
+                                 const double* w, const double* in, double* out, int accumulate);
 
 /* Fourier prolongation between two periodic grids held by two contexts (the levels' engines):
  * mesh_to_mesh_fft (1-D, transfer_classes/TransferMesh_FFT.py:36-57: rfft, low modes + Nyquist copied, irfft,

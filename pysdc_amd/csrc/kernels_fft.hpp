@@ -15,8 +15,10 @@ struct FieldPtrs {
 // given u) or of the field the last pass WRITES (the node value a sweep just solved for).  out == null: nothing.
 struct ReactEpi {
     double* out;
-    int field, kind, nu;
+    int field, kind, nu;   // field < 0: every field f of the launch, into outs[f]
     double p0, p1;
+    double* outs[MAXM];
+    __host__ __device__ double* target(int f) const { return field < 0 ? outs[f] : (f == field ? out : nullptr); }
 };
 __device__ __forceinline__ double react_value(double v, int kind, double p0, double p1, int nu) {
 #pragma clang fp contract(off)
@@ -45,7 +47,7 @@ __global__ void k_realpart(FieldPtrs p, const cd* W, size_t N) {
 template <int N, int T>
 __global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_fwd(FieldPtrs p, cd* __restrict__ W, size_t fstride,
                                                                       int rest, const cd* __restrict__ tw,
-                                                                      ReactEpi epi = ReactEpi{nullptr, 0, 0, 0, 0.0, 0.0}) {
+                                                                      ReactEpi epi = ReactEpi{nullptr, 0, 0, 0, 0.0, 0.0, {}}) {
     constexpr int E = fft_elems(N), P = N / E;
     using LAY = LayStrided<N, T>;
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -58,10 +60,10 @@ __global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_fwd(FieldPtr
 #pragma unroll
     for (int i = 0; i < E; ++i)
         r[i] = ok ? *reinterpret_cast<const cd*>(in + (size_t)(j + i * P) * rest + 2 * (size_t)c) : cd{0.0, 0.0};
-    if (epi.out && (int)blockIdx.y == epi.field && ok) {  // reaction term of the field that is being read
+    if (double* const eo = epi.target((int)blockIdx.y); eo && ok) {  // reaction term of the field that is being read
 #pragma unroll
         for (int i = 0; i < E; ++i)
-            *reinterpret_cast<cd*>(epi.out + (size_t)(j + i * P) * rest + 2 * (size_t)c) =
+            *reinterpret_cast<cd*>(eo + (size_t)(j + i * P) * rest + 2 * (size_t)c) =
                 cd{react_value(r[i].x, epi.kind, epi.p0, epi.p1, epi.nu), react_value(r[i].y, epi.kind, epi.p0, epi.p1, epi.nu)};
     }
     fft_line<N, -1, LAY>(r, j, col, lds, tw);
@@ -117,7 +119,7 @@ __global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_inv(FieldPtr
                                                                       const cd* __restrict__ tw,
                                                                       unsigned long long* __restrict__ norms,
                                                                       const cd* __restrict__ add = nullptr, int nfields = 1,
-                                                                      ReactEpi epi = ReactEpi{nullptr, 0, 0, 0, 0.0, 0.0}) {
+                                                                      ReactEpi epi = ReactEpi{nullptr, 0, 0, 0, 0.0, 0.0, {}}) {
     constexpr int E = fft_elems(N), P = N / E;
     constexpr bool XWAVE = SDC_XWAVE && NORM && !STORE && P == 64 && !SDC_XINV_DIRECT;  // (norm-only pass, one wave per column)
     using LAY = LayStrided<N, T>;
@@ -288,10 +290,10 @@ __global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_inv(FieldPtr
 #pragma unroll
             for (int i = 0; i < E; ++i)
                 *reinterpret_cast<cd*>(out + (size_t)(j + i * P) * rest + 2 * (size_t)c) = r[i];
-            if (epi.out && by == epi.field) {  // reaction term of the field that is being written
+            if (double* const eo = epi.target(by)) {  // reaction term of the field that is being written
 #pragma unroll
                 for (int i = 0; i < E; ++i)
-                    *reinterpret_cast<cd*>(epi.out + (size_t)(j + i * P) * rest + 2 * (size_t)c) =
+                    *reinterpret_cast<cd*>(eo + (size_t)(j + i * P) * rest + 2 * (size_t)c) =
                         cd{react_value(r[i].x, epi.kind, epi.p0, epi.p1, epi.nu),
                            react_value(r[i].y, epi.kind, epi.p0, epi.p1, epi.nu)};
             }

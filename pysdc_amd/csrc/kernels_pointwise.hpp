@@ -121,11 +121,10 @@ __global__ __launch_bounds__(256) void k_quad(QuadArgs a) {
         }
     }
     if (MODE == 1) {
-#pragma unroll
-        for (int mo = 0; mo < M; ++mo) {
-            double v = wave_max(nmax[mo]);
-            if ((threadIdx.x & 63) == 0 && mo < a.nout) atomic_max_abs(a.norms + mo, v);
-        }
+        // one guarded atomic per value and WORKGROUP: on a small field all waves of the launch are resident at once, every one
+        // of them finds the slot at zero and queues its atomic on the same address (128^3, M = 3: 16 384 waves x 3 atomics made a
+        // 35 us pass take 200 us - config 5's coarse level)
+        block_max_to_slots<M>(a.norms, nmax, a.nout);
     }
 }
 
@@ -210,8 +209,8 @@ __global__ void k_amax(const double* __restrict__ x, size_t n, unsigned long lon
         double v = fabs(x[i]);
         m = (m > v || m != m) ? m : v;
     }
-    m = wave_max(m);
-    if ((threadIdx.x & 63) == 0) atomic_max_abs(slot, m);
+    const double mm[1] = {m};
+    block_max_to_slots<1>(slot, mm);   // (one guarded atomic per workgroup: small fields have all their waves in flight at once)
 }
 
 // max |x + y| (y may be null): max |f_impl(u0) + f_expl(u0)| for the residual of a deferred spread predictor
@@ -222,8 +221,8 @@ __global__ void k_amax_sum(const double* __restrict__ x, const double* __restric
         double v = fabs(y ? x[i] + y[i] : x[i]);
         m = (m > v || m != m) ? m : v;
     }
-    m = wave_max(m);
-    if ((threadIdx.x & 63) == 0) atomic_max_abs(slot, m);
+    const double mm[1] = {m};
+    block_max_to_slots<1>(slot, mm);
 }
 
 __global__ void k_axpby(size_t n, double a, const double* __restrict__ x, double b, const double* __restrict__ y,

@@ -14,6 +14,7 @@ struct XferArgs {
     const double* w;    // [W][n_out] weights (zero-padded)
     size_t outer, inner;
     int n_out, n_in, W;
+    int accumulate;     // 1: out += result (the coarse-grid correction added to the node values by the pass that makes it)
 };
 
 // one axis of the tensor product: out[o][i][q] = sum_j w[j][i] * in[o][idx[j][i]][q].  IDX = unsigned when the
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(256) void k_xfer_line(XferArgs a) {
                 acc = wj != 0.0 ? acc + wj * vj : acc;
             }
         }
-        a.out[p] = acc;
+        a.out[p] = a.accumulate ? a.out[p] + acc : acc;
     }
 }
 
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(256) void k_xfer_axis(XferArgs a) {
                 const double wj = a.w[(size_t)j * a.n_out + i];
                 if (wj != 0.0) acc += wj * src[(size_t)a.idx[(size_t)j * a.n_out + i] * a.inner];
             }
-            dst[(size_t)i * a.inner] = acc;
+            dst[(size_t)i * a.inner] = a.accumulate ? dst[(size_t)i * a.inner] + acc : acc;
         }
     }
 }
@@ -106,6 +107,11 @@ __global__ __launch_bounds__(256) void k_xfer_axis_rows(XferArgs a, unsigned nq)
                     acc.x += wj * v.x;
                     acc.y += wj * v.y;
                 }
+            }
+            if (a.accumulate) {
+                const double2 old = dst[(size_t)i * row];
+                acc.x = old.x + acc.x;
+                acc.y = old.y + acc.y;
             }
             dst[(size_t)i * row] = acc;
         }

@@ -112,7 +112,8 @@ static double* slot_ptr(sdc_ctx* c, int slot, int m, int comp) {
 template <int MODE>
 static int launch_quad(sdc_ctx* c, const QuadArgs& a, const char* name) {
     LaunchTimer lt(c, name);
-    const int grid = grid_for(c->N / 2, 256);
+    int grid = grid_for(c->N / 2, 256);
+    if (MODE == 1 && grid > 2048) grid = 2048;   // (norms: fewer, longer workgroups - fewer atomics on the M slots)
 #define QCASE(MM)                                                                                   \
     case MM:                                                                                        \
         if (c->ncomp == 2) hipLaunchKernelGGL((k_quad<MM, 2, MODE>), dim3(grid), dim3(256), 0, c->stream, a); \
@@ -289,14 +290,16 @@ static int eval_nodes_plain(sdc_ctx* c) {
 // reaction term riding on a pass of the pipeline (see ReactEpi): where 0 = none, 1 = of the input field `field` (first pass),
 // 2 = of the output field `field` (last pass)
 struct ReactReq {
-    int where = 0, field = 0;
+    int where = 0, field = 0;   // field < 0: of every field of the pipeline, into outs[f]
     double* out = nullptr;
+    double* outs[MAXM] = {};
 };
 template <int N>
 static int fft_pipeline_n(sdc_ctx* c, int nf, const FieldPtrs& p, ZArgs& z, const ReactReq& rq = ReactReq()) {
-    const ReactEpi none{nullptr, 0, 0, 0, 0.0, 0.0};
-    const ReactEpi epi{rq.out, rq.field, c->react_kind, c->react_nu, c->react_p0, c->react_p1};
-    const bool can = c->ndim >= 2 && rq.out != nullptr;  // (1-D lines go through k_promote / k_realpart: the caller launches k_reaction)
+    const ReactEpi none{nullptr, 0, 0, 0, 0.0, 0.0, {}};
+    ReactEpi epi{rq.out, rq.field, c->react_kind, c->react_nu, c->react_p0, c->react_p1, {}};
+    for (int f = 0; f < MAXM; ++f) epi.outs[f] = rq.outs[f];
+    const bool can = c->ndim >= 2 && (rq.out != nullptr || rq.field < 0);  // (1-D lines go through k_promote / k_realpart: the caller launches k_reaction)
     constexpr int E = fft_elems(N), P = N / E;
     constexpr int T = N >= 2048 ? 4 : (N == 1024 ? SDC_T1024 : 8);  // complex columns per strided tile (128-byte row segments up to N = 1024)
     const size_t lds_str = (size_t)LayStrided<N, T>::doubles(T) * sizeof(double);
@@ -1671,6 +1674,68 @@ int sdc_eval_f(sdc_ctx* c, const double* u, double g_t, double* f_impl, double* 
     double* oe[1] = {f_expl};
     double g[1] = {g_t};
     return run_stencil(c, 1, in, oi, f_expl ? oe : nullptr, g);
+}
+
+int sdc_eval_f_batch(sdc_ctx* c, int nf, const double* const* u, const double* g_t, double* const* f_impl,
+                     double* const* f_expl) {
+    if (!c || !u || !f_impl || nf < 1) return fail(c, SDC_ERR_PARAM, "null pointer");
+    if (nf > c->M) return fail(c, SDC_ERR_PARAM, "at most num_nodes = %d fields per call (the work spectra), got %d", c->M, nf);
+    for (int f = 0; f < nf; ++f)
+        if (!u[f] || !f_impl[f]) return fail(c, SDC_ERR_PARAM, "null field pointer");
+    const bool batched_spectral = c->kind == 0 && !c->nb && c->spectral_op && c->ndim >= 2 &&
+                                  (c->expl_kind == SDC_EXPL_NONE || c->expl_kind == SDC_EXPL_REACTION);
+    const bool batched_stencil = c->kind == 0 && !c->nb && !c->spectral_op && c->have_stencil[0] &&
+                                 c->expl_kind != SDC_EXPL_REACTION && !(c->expl_kind == SDC_EXPL_FORCING && !c->profile);
+    if (batched_spectral) {
+        // ONE transform round trip for all fields: forward passes, the symbol on the contiguous axis, inverse passes; the
+        // pointwise reaction term of every field rides on the pass that reads it
+        FieldPtrs p;
+        memset(&p, 0, sizeof p);
+        ZArgs z;
+        memset(&z, 0, sizeof z);
+        ReactReq rq;
+        bool react = c->expl_kind == SDC_EXPL_REACTION && f_expl != nullptr;
+        for (int f = 0; f < nf; ++f) {
+            p.in[f] = u[f];
+            p.out[f] = f_impl[f];
+            if (react && (!f_expl[f] || f_expl[f] == u[f])) react = false;
+        }
+        z.apply = 1;
+        if (react) {
+            rq.where = 1;
+            rq.field = -1;
+            for (int f = 0; f < nf; ++f) rq.outs[f] = f_expl[f];
+        }
+        int rc0 = fft_pipeline(c, nf, p, z, rq);
+        if (rc0 != SDC_OK) return rc0;
+        if (!react && f_expl && c->expl_kind == SDC_EXPL_REACTION)
+            for (int f = 0; f < nf; ++f)
+                if (f_expl[f]) {
+                    LaunchTimer lt(c, "reaction");
+                    hipLaunchKernelGGL(k_reaction, dim3(grid_for(c->N, 256)), dim3(256), 0, c->stream, u[f], f_expl[f], c->N,
+                                       c->react_kind, c->react_p0, c->react_p1, c->react_nu);
+                    HIPCHK(c, hipGetLastError());
+                }
+        return SDC_OK;
+    }
+    if (batched_stencil) {
+        const double* in[MAXM];
+        double *oi[MAXM], *oe[MAXM], g[MAXM];
+        bool expl = f_expl != nullptr;
+        for (int f = 0; f < nf; ++f) {
+            in[f] = u[f];
+            oi[f] = f_impl[f];
+            oe[f] = f_expl ? f_expl[f] : nullptr;
+            g[f] = g_t ? g_t[f] : 0.0;
+            if (expl && !oe[f]) expl = false;
+        }
+        if (expl || !f_expl) return run_stencil(c, nf, in, oi, expl ? oe : nullptr, g);
+    }
+    for (int f = 0; f < nf; ++f) {   // every other kind of level: field by field
+        int rc = sdc_eval_f(c, u[f], g_t ? g_t[f] : 0.0, f_impl[f], f_expl ? f_expl[f] : nullptr);
+        if (rc != SDC_OK) return rc;
+    }
+    return SDC_OK;
 }
 
 int sdc_predict(sdc_ctx* c, double t, double dt, int guess, double fill_u, double fill_f) {
@@ -3089,6 +3154,11 @@ int sdc_transfer_apply(void* stream, int ndim, int n_out, int n_in, int width, c
 
 int sdc_transfer_apply_batch(void* stream, int nfields, int ndim, int n_out, int n_in, int width, const int* idx,
                              const double* w, const double* in, double* out) {
+    return sdc_transfer_apply_batch_acc(stream, nfields, ndim, n_out, n_in, width, idx, w, in, out, 0);
+}
+
+int sdc_transfer_apply_batch_acc(void* stream, int nfields, int ndim, int n_out, int n_in, int width, const int* idx,
+                                 const double* w, const double* in, double* out, int accumulate) {
     if (nfields < 1 || ndim < 1 || ndim > 3 || n_out < 1 || n_in < 1 || width < 1 || !idx || !w || !in || !out)
         return fail(nullptr, SDC_ERR_PARAM, "bad transfer arguments");
     // separable: one pass per axis (cost ~ ndim * width per point instead of width^ndim), last axis first so that
@@ -3134,6 +3204,7 @@ int sdc_transfer_apply_batch(void* stream, int nfields, int ndim, int n_out, int
         for (int d = axis + 1; d < ndim; ++d) a.inner *= (size_t)dims[d];
         a.in = src;
         a.out = pass == ndim - 1 ? out : scratch[pass & 1];
+        a.accumulate = (accumulate && pass == ndim - 1) ? 1 : 0;
         const size_t total = a.outer * (size_t)n_out * a.inner;
         const size_t in_total = a.outer * (size_t)n_in * a.inner;
         const bool small = total < 0xffffffffull && in_total < 0xffffffffull;

@@ -349,6 +349,13 @@ class SweepEngine:
     def eval_f(self, u_ptr, g_t, fi_ptr, fe_ptr=None):
         self._chk(self.lib.sdc_eval_f(self.ctx, u_ptr, g_t, fi_ptr, fe_ptr))
 
+    def eval_f_many(self, u_ptrs, fi_ptrs, fe_ptrs=None, g_ts=None):
+        """eval_f of several fields in one pass of the launches (include/sdcmi.h: sdc_eval_f_batch)"""
+        nf = len(u_ptrs)
+        arr = lambda ps: (C.c_void_p * nf)(*[C.c_void_p(int(p)) for p in ps])   # noqa: E731
+        g = None if g_ts is None else _dptr(np.ascontiguousarray(g_ts, dtype=np.float64))
+        self._chk(self.lib.sdc_eval_f_batch(self.ctx, nf, arr(u_ptrs), g, arr(fi_ptrs), None if fe_ptrs is None else arr(fe_ptrs)))
+
     def solve(self, rhs_ptr, factor, out_ptr, guess_ptr=None):
         self._chk(self.lib.sdc_solve(self.ctx, rhs_ptr, factor, guess_ptr, out_ptr))
 

@@ -97,6 +97,7 @@ PROTOTYPES = {
     'sdc_end_point': (C.c_int, [_vp, C.c_double, C.c_int]),
     'sdc_integrate': (C.c_int, [_vp, C.c_double, C.POINTER(_vp)]),
     'sdc_eval_f': (C.c_int, [_vp, _vp, C.c_double, _vp, _vp]),
+    'sdc_eval_f_batch': (C.c_int, [_vp, C.c_int, C.POINTER(_vp), _dp, C.POINTER(_vp), C.POINTER(_vp)]),
     'sdc_solve': (C.c_int, [_vp, _vp, C.c_double, _vp, _vp]),
     'sdc_vec_copy': (C.c_int, [_vp, C.c_size_t, _vp, _vp]),
     'sdc_vec_fill': (C.c_int, [_vp, C.c_size_t, C.c_double, _vp]),
@@ -106,6 +107,7 @@ PROTOTYPES = {
     'sdc_set_vdp_block_solver': (C.c_int, [_vp, C.c_int]),
     'sdc_work_counters': (C.c_int, [_vp, C.POINTER(C.c_ulonglong)]),
     'sdc_transfer_apply_batch': (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
+    'sdc_transfer_apply_batch_acc': (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int]),
     'sdc_transfer_apply': (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     'sdc_odd_mirror': (C.c_int, [_vp, _vp, C.c_int]),
     'sdc_odd_extend': (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int]),

@@ -650,6 +650,14 @@ class _SpectralLaplacianIMEX(Problem):
         if 'rhs' in self.work_counters:
             self.work_counters['rhs']()
 
+    def eval_f_into_many(self, us, ts, outs):
+        """eval_f_into for several fields at once: ONE transform round trip for all of them (the node loop after a
+        prolongation, core/base_transfer.py:207-213); the right-hand side does not depend on t"""
+        self.engine.eval_f_many([u.ptr for u in us], [o.impl.ptr for o in outs], [o.expl.ptr for o in outs])
+        if 'rhs' in self.work_counters:
+            for _ in us:
+                self.work_counters['rhs']()
+
     def solve_system(self, rhs, factor, u0, t):
         me = self._out_u()
         self.engine.solve(rhs.ptr, float(factor), me.ptr)

@@ -86,6 +86,21 @@ class BaseTransfer:
         else:
             L.f[n] = L.prob.eval_f(L.u[n], t)
 
+    @classmethod
+    def _refresh_f_nodes(cls, L, nodes):
+        """L.f[n] = f(L.u[n], t_n) for every n in nodes (core/base_transfer.py:207-213, :141-147): one batched evaluation when
+        the problem offers it and the right-hand sides live in slabs, node by node otherwise"""
+        times = {n: (L.time if n == 0 else L.time + L.dt * L.sweep.coll.nodes[n - 1]) for n in nodes}
+        many = getattr(L.prob, 'eval_f_into_many', None)
+        if many is not None and hasattr(L.f, 'write') and len(nodes) > 1:
+            views = {}
+            for n in nodes:      # (write() hands out the slab view and marks the entry valid)
+                L.f.write(n, lambda view, n=n: views.__setitem__(n, view))
+            many([L.u[n] for n in nodes], [times[n] for n in nodes], [views[n] for n in nodes])
+            return
+        for n in nodes:
+            cls._refresh_f(L, n, times[n])
+
     def _to_coarse_nodes(self, fine_fields):
         """space restriction of every fine-node field followed by the node restriction Rcoll."""
         many = getattr(self.space_transfer, 'restrict_many', None)
@@ -124,11 +139,11 @@ class BaseTransfer:
         except (AttributeError, IndexError, TypeError):
             return False
 
-    def _space_batch(self, key, nfields, src_ptr, dst_ptr):
+    def _space_batch(self, key, nfields, src_ptr, dst_ptr, accumulate=False):
         sp = self.space_transfer
         idx, w, width, (n_out, n_in) = sp._tab[key]
-        Lb.check(Lb.load().sdc_transfer_apply_batch(None, nfields, sp.ndim, n_out, n_in, width, idx.ptr, w.ptr, src_ptr,
-                                                    dst_ptr), None)
+        Lb.check(Lb.load().sdc_transfer_apply_batch_acc(None, nfields, sp.ndim, n_out, n_in, width, idx.ptr, w.ptr, src_ptr,
+                                                        dst_ptr, int(accumulate)), None)
 
     def _restrict_batched(self):
         fine, coarse = self.fine, self.coarse
@@ -143,8 +158,7 @@ class BaseTransfer:
         coarse._touched(Lb.SLOT_U, 0)
         coarse._touched(Lb.SLOT_U, 1)
         self._refresh_f(coarse, 0, coarse.time)
-        for n in range(1, M + 1):
-            self._refresh_f(coarse, n, coarse.time + coarse.dt * coarse.sweep.coll.nodes[n - 1])
+        self._refresh_f_nodes(coarse, list(range(1, M + 1)))
         quad_coarse = coarse.sweep.integrate()    # M fields, one behind the other (checked: a user's integrate() need not)
         quad_fine = fine.sweep.integrate()
         on_coarse = hip_mesh(((M * nc,), None, np.dtype('float64')), val=None)
@@ -191,13 +205,10 @@ class BaseTransfer:
             return False
         diff = hip_mesh(((M * nc,), None, np.dtype('float64')), val=None)
         diff._axpby(1.0, hip_mesh.view(ec.ptr(Lb.SLOT_U, 1), (M * nc,), keep=ec), -1.0, uold, diff)
-        delta = hip_mesh(((M * nf,), None, np.dtype('float64')), val=None)
-        self._space_batch('P', M, diff.ptr, delta.ptr)
-        nodes = hip_mesh.view(ef.ptr(Lb.SLOT_U, 1), (M * nf,), keep=ef)
-        nodes._axpby(1.0, nodes, 1.0, delta, nodes)
+        # u_F[m] += P diff[m]: the last pass of the prolongation adds its result to the node values where they lie
+        self._space_batch('P', M, diff.ptr, ef.ptr(Lb.SLOT_U, 1), accumulate=True)
         fine._touched(Lb.SLOT_U, 1)
-        for n in range(1, M + 1):
-            self._refresh_f(fine, n, fine.time + fine.dt * fine.sweep.coll.nodes[n - 1])
+        self._refresh_f_nodes(fine, list(range(1, M + 1)))
         return True
 
     def restrict(self):
