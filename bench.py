@@ -480,7 +480,10 @@ def run_workload(args, world, rank, use_dist, with_stream_reference=True):
                                    + (', residual of the predictor\'s state put off until somebody reads it (--lazy-predictor-residual)'
                                       if (_level.LAZY_PREDICTOR_RESIDUAL and args.restol < 0) else ''),
                        'time_parallel': f'{world} time-slice(s), one per GPU, multi-step SDC '
-                                        f'({"Jacobi" if args.mssdc == "jacobi" else "Gauss-Seidel"})'},
+                                        f'({"Jacobi" if args.mssdc == "jacobi" else "Gauss-Seidel"})'
+                                        + (f'; wire {args.wire}, mode: {getattr(args, "wire_mode", "default")}'
+                                           + (f' (64^3 check vs serial emulation: {args.wire_check:.1e})'
+                                              if getattr(args, 'wire_check', None) is not None else '') if world > 1 else '')},
             'sdc_iters_per_s': units * sweeps_total / el,
             'niter': niter,
             'work_counters': {k: v.niter for k, v in L.prob.work_counters.items()},
@@ -578,7 +581,7 @@ def compact_line(out, subs=None, cpu=None, details_path=None):
     niter = out.get('niter') or []
     line = {k: out[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better',
                                 'scaling', 'vs_baseline', 'dtype', 'data')}
-    line['config'] = {'workload': out['config']['workload'][:400], 'time_parallel': out['config']['time_parallel'][:120]}
+    line['config'] = {'workload': out['config']['workload'][:400], 'time_parallel': out['config']['time_parallel'][:260]}
     line['sdc_iters_per_s'] = out['sdc_iters_per_s']
     line['niter'] = niter[0] if len(set(niter)) == 1 else {'min': min(niter), 'max': max(niter), 'sum': sum(niter)}
     line['finite'] = out['finite']
@@ -658,6 +661,64 @@ def preflight(torch, dist, rank, world, wire):
         e.close()
         return info
     return None
+
+
+WIRE_MODES = [   # tried in this order until one reproduces the serial emulation on a small grid (validate_wire)
+    ('default', {}),
+    ('fields on the wire, every hand-over sent', {'PYSDC_AMD_SPECTRAL_WIRE': '0', 'PYSDC_AMD_SKIP_FIRST': '0'}),
+    ('direct messages only (no two-hop relay), fields, every hand-over sent',
+     {'PYSDC_AMD_SPECTRAL_WIRE': '0', 'PYSDC_AMD_SKIP_FIRST': '0', 'PYSDC_AMD_RELAY': '0'}),
+]
+
+
+def validate_wire(args, torch, dist, rank, world):
+    """Before the 8.6 GB fields exist: the multi-rank run itself on a 64^3 grid - same controller, same wire, same options
+    (spectra on the wire, two-hop relay, skipped first hand-over) - against controller_nonMPI emulating the ranks in this
+    process.  The RCCL wire has carried one rank before this job (no multi-GPU box was reachable during development), so a
+    mode that does not reproduce the emulation is dropped for the next, more conservative one; the line says which ran.
+    A hang ends with the watchdog's JSON error.  Returns (mode name, max relative difference)."""
+    import numpy as np
+
+    from pysdc_amd.controller import controller_nonMPI, controller_dist
+    from pysdc_amd.problems import heatNd_unforced
+    from pysdc_amd.sweepers import generic_implicit
+
+    n, M, K, blocks = 64, 5, 3, 2
+    dt = 1e-3 * (512.0 / n) ** 2
+    desc = dict(problem_class=heatNd_unforced, problem_params=dict(nvars=(n, n, n), nu=0.1, freq=2, order=2),
+                sweeper_class=generic_implicit, sweeper_params=dict(num_nodes=M, quad_type='RADAU-RIGHT', QI='IE'),
+                level_params=dict(dt=dt, restol=-1.0, nsweeps=1), step_params=dict(maxiter=K))
+    cpar = dict(logger_level=40, mssdc_jac=args.mssdc == 'jacobi')
+    serial = controller_nonMPI(world, cpar, desc)
+    L0 = serial.MS[0].levels[0]
+    u0 = L0.prob.u_exact(0.0)
+    ref, _ = serial.run(u0, 0.0, blocks * world * dt)
+    ref = ref.get()
+    del serial
+    last = None
+    for name, env in WIRE_MODES:
+        saved = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        ok = 0
+        try:
+            ctrl = controller_dist(dict(cpar, comm_wire=args.wire), desc)
+            got, _ = ctrl.run(ctrl.S.levels[0].prob.u_exact(0.0), 0.0, blocks * world * dt)
+            err = float(np.max(np.abs(got.get() - ref)) / np.max(np.abs(ref)))
+            ctrl.close() if hasattr(ctrl, 'close') else None
+            ok = 1 if err <= 1e-10 else 0
+            last = f'{name}: differs from the serial emulation by {err:.2e}'
+        except Exception as e:  # noqa: BLE001
+            err, last = float('nan'), f'{name}: {e!r}'
+        t = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)     # every rank must agree, and every rank takes the same branch
+        if int(t.item()) == 1:
+            return name, err
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    raise RuntimeError(f'no wire mode reproduces the serial emulation on rank {rank} ({last})')
 
 
 def launch_ranks(args, argv):
@@ -802,6 +863,8 @@ def main():
                          'torch.distributed process group itself (rendezvous, flags, counts) is gloo in both cases')
     ap.add_argument('--same-device', action='store_true',
                     help='all ranks on GPU 0 (rehearsal of the multi-rank path on a one-GPU box; needs --backend gloo)')
+    ap.add_argument('--no-wire-check', action='store_true',
+                    help='--gpus > 1: skip the small-grid run over the wire that is compared with the serial emulation')
     ap.add_argument('--job-timeout', type=float, default=1500.0,
                     help='--gpus > 1 started without a launcher: seconds after which the parent ends the job with an error')
     ap.add_argument('--dump-end-value', default=None,
@@ -859,8 +922,10 @@ def main():
             # vectors travel through the C-ABI communicator (RCCL or the shared-memory wire)
             dist.init_process_group('gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
             preflight(torch, dist, rank, world, args.wire)
+            args.wire_mode, args.wire_check = (validate_wire(args, torch, dist, rank, world)
+                                               if world > 1 and not args.no_wire_check else ('default (not checked)', None))
         except Exception as e:  # noqa: BLE001  fail fast and loudly: no hang, no partial line
-            print(json.dumps({'error': f'rank {rank}: preflight of the {args.wire} wire failed: {e!r}'}), flush=True)
+            print(json.dumps({'error': f'rank {rank}: preflight of the {args.wire} wire failed: {e!r}'[:1500]}), flush=True)
             raise SystemExit(3)
         if args.p2p_chunk_mb > 0:
             os.environ['PYSDC_AMD_P2P_CHUNK'] = str(int(args.p2p_chunk_mb * (1 << 20) // 8))

@@ -201,7 +201,8 @@ def test_levels_of_one_rank_share_a_communicator():
     assert _thread_ranks(2, body) == [(0.0, 0.0), (1.0, 10.0)]
 
 
-def test_bench_two_ranks_on_one_gpu_end_to_end(tmp_path):
+@pytest.mark.parametrize('ranks,n,steps,warmup', [(2, 256, 2, 1), (8, 256, 1, 1)])
+def test_bench_ranks_on_one_gpu_end_to_end(tmp_path, ranks, n, steps, warmup):
     """`python bench.py --gpus 2` as the driver starts it (no launcher, no environment): the parent starts the rank
     processes, they rendezvous over gloo, the state vectors travel through the C-ABI communicator (shared-memory wire,
     both ranks on GPU 0), rank 0's JSON line comes back.  The end value equals controller_nonMPI emulating the two
@@ -218,9 +219,8 @@ def test_bench_two_ranks_on_one_gpu_end_to_end(tmp_path):
     import ctypes as C
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    n, steps, warmup = 256, 2, 1
     dump = str(tmp_path / 'uend.npy')
-    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--n', str(n), '--backend', 'gloo', '--same-device',
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(ranks), '--n', str(n), '--backend', 'gloo', '--same-device',
            '--steps', str(steps), '--warmup', str(warmup), '--dump-end-value', dump, '--job-timeout', '600']
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=env, cwd=root)
@@ -228,23 +228,25 @@ def test_bench_two_ranks_on_one_gpu_end_to_end(tmp_path):
     assert res.returncode == 0 and lines, (res.returncode, res.stdout[-2000:], res.stderr[-2000:])
     rec = json.loads(lines[-1])
     assert 'error' not in rec, rec
-    assert rec['n_gpus'] == 2 and rec['steps'] == steps and rec['scaling'] == 'weak'
-    assert rec['value'] == pytest.approx(2 * steps / (rec['ms_per_step'] * 1e-3 * steps), rel=1e-3)   # (the line rounds)
+    assert rec['n_gpus'] == ranks and rec['steps'] == steps and rec['scaling'] == 'weak'
+    assert rec['value'] == pytest.approx(ranks * steps / (rec['ms_per_step'] * 1e-3 * steps), rel=1e-3)   # (the line rounds)
     assert len(lines[-1]) < 6000
     pr = rec['per_rank']     # (compact: one list per quantity, one entry per rank; the full per-rank records are in the side file)
-    assert len(pr['seconds']) == 2 and pr['sweeps'] == [4 * steps] * 2 and pr['wire'] == 'shm'
+    assert len(pr['seconds']) == ranks and pr['sweeps'] == [4 * steps] * ranks and pr['wire'] == 'shm'
     assert rec['niter'] == 4 and rec['finite']
-    # the same six time steps by the serial controller emulating two ranks
+    # the multi-rank path was checked against the serial emulation on a small grid before the run, in its default mode
+    assert 'mode: default (64^3 check vs serial emulation' in rec['config']['time_parallel'], rec['config']
+    # the same time steps by the serial controller emulating the ranks
     dt = 1e-3 * (512.0 / n) ** 2
     desc = dict(problem_class=heatNd_unforced, problem_params=dict(nvars=(n, n, n), nu=0.1, freq=2, order=2),
                 sweeper_class=generic_implicit, sweeper_params=dict(num_nodes=5, quad_type='RADAU-RIGHT', QI='IE'),
                 level_params=dict(dt=dt, restol=-1.0, nsweeps=1), step_params=dict(maxiter=4))
-    ctrl = controller_nonMPI(2, dict(logger_level=40), desc)
+    ctrl = controller_nonMPI(ranks, dict(logger_level=40), desc)
     lvl = ctrl.MS[0].levels[0]
     u0 = lvl.prob.u_init
     L.check(lvl.engine.lib.sdc_init_field(lvl.engine.ctx, u0.ptr, (C.c_int * 3)(2, 2, 2), 1e-3, 0), lvl.engine.ctx)
-    ref, stats = ctrl.run(u0, 0.0, 2 * dt * (warmup + steps))
-    assert [v for _, v in get_sorted(stats, type='niter')] == [4] * (2 * (warmup + steps))
+    ref, stats = ctrl.run(u0, 0.0, ranks * dt * (warmup + steps))
+    assert [v for _, v in get_sorted(stats, type='niter')] == [4] * (ranks * (warmup + steps))
     ref, got = ref.get(), np.load(dump)
     assert np.max(np.abs(got - ref)) <= 1e-12 * np.max(np.abs(ref))
 
