@@ -11,7 +11,7 @@ own entry points, switched on by environment variables (or call the function aft
 GOLDEN_FFT=1 fft_transfer_main (transfer_fft.npz, runs_ac_fft.npz), GOLDEN_RELAY=1 relay_main (runs_relay.npz),
 GOLDEN_CG=1 cg_main (sweeps_cg.npz), GOLDEN_VDPJ=1 vdp_jacobian_main (vdp_jacobian.npz), GOLDEN_DML=1
 dirichlet_ml_main (transfer_dirichlet.npz, runs_ml_dirichlet.npz), GOLDEN_GUESS=1 guess_main (sweeps_guess.npz), GOLDEN_SKIP=1 skip_main (runs_skip.npz), GOLDEN_RELAY8=1 relay8_main (runs_relay8.npz),
-GOLDEN_BIG3D=1 big3d_main (sweeps_big3d.npz), GOLDEN_CFG5=1 cfg5_main (runs_cfg5.npz), GOLDEN_ML8=1 ml8_main (runs_ml8.npz), GOLDEN_DND=1 dirichlet_nd_main (sweeps_dirichlet_nd.npz, runs_dirichlet_nd.npz), GOLDEN_NSW2=1 nsweeps2_main (runs_nsweeps2.npz), GOLDEN_PIN1024=1 pin1024_main (sweeps_pin1024.npz, 20 minutes), GOLDEN_GMRES=1 gmres_main (sweeps_gmres.npz), GOLDEN_DHO=1 dirichlet_ho_main (sweeps_dirichlet_ho.npz, runs_dirichlet_ho.npz, dirichlet_ho_matrices.npz), GOLDEN_BC=1 boundary_main (boundary_matrices.npz, sweeps_neumann.npz, runs_neumann.npz);
+GOLDEN_BIG3D=1 big3d_main (sweeps_big3d.npz), GOLDEN_CFG5=1 cfg5_main (runs_cfg5.npz), GOLDEN_ML8=1 ml8_main (runs_ml8.npz), GOLDEN_DND=1 dirichlet_nd_main (sweeps_dirichlet_nd.npz, runs_dirichlet_nd.npz), GOLDEN_NSW2=1 nsweeps2_main (runs_nsweeps2.npz), GOLDEN_PIN1024=1 pin1024_main (sweeps_pin1024.npz, 20 minutes), GOLDEN_GMRES=1 gmres_main (sweeps_gmres.npz), GOLDEN_DHO=1 dirichlet_ho_main (sweeps_dirichlet_ho.npz, runs_dirichlet_ho.npz, dirichlet_ho_matrices.npz), GOLDEN_BC=1 boundary_main (boundary_matrices.npz, sweeps_neumann.npz, runs_neumann.npz), GOLDEN_PIN512=1 pin512_main (sweeps_pin512.npz);
 GOLDEN_ML=0 skips the multi-level block.
 
 ``qmat`` (third-party, absent here) is replaced by oracle/qmat_shim, which forwards to
@@ -1089,3 +1089,24 @@ def boundary_main():
 
 if __name__ == '__main__' and os.environ.get('GOLDEN_BC', '0') == '1':
     boundary_main()
+
+
+def pin512_main():
+    """config 3's kernel instances (line length 512, M = 5, complex symbol: k_spec_z<512,5,1,1>, the strided passes <512,8>)
+    pinned to the reference on a FULL spectrum: advection-diffusion IMEX 2-D 512^2 (implicit diffusion nu = 0.02, explicit
+    centred advection c = 1, order 2), imex_1st_order M=5 RADAU-RIGHT, QI=IE, QE=EE, dt = 1e-3 - the bench's config-3
+    parameters - input = sine mode + 1e-3 seeded noise, three sweeps with the reference's SuperLU solve.  A 512^3 field
+    that does not depend on one axis reduces to this 2-D problem exactly (both stencils sum to zero along that axis), so
+    the case also pins the 3-D launches of config 3 at their own size (tests/test_gpu_pin512.py)."""
+    RR = dict(quad_type='RADAU-RIGHT')
+    sw = dict(num_nodes=5, QI='IE', QE='EE', **RR)
+    pp = dict(nvars=(512, 512), nu=0.02, c=1.0, freq=2, order=2, bc='periodic')
+    full = sweep_case('pin_advdiff2d_512_M5_IE', 'advdiff', pp, 'imex_1st_order', sw, 1e-3, t0=0.0, nsweeps=3, seed=0,
+                      u0_kind='exact')
+    c = _reduce_fields(full, 8)
+    c['k3_uend_0_q'] = np.asarray(full['k3_uend_0'])[1::4, 3::4].copy()
+    save('sweeps_pin512.npz', [c])
+
+
+if __name__ == '__main__' and os.environ.get('GOLDEN_PIN512', '0') == '1':
+    pin512_main()

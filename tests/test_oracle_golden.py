@@ -204,3 +204,66 @@ def test_big3d_run_vs_reference_with_exact_solve():
     assert rel_err(uend, rc['uend']) < 1e-11
     res = [r for _, hist in stats['residuals'] for r in hist]
     np.testing.assert_allclose(res, rc['res'], rtol=1e-5, atol=5e-12)
+
+
+def test_pin512_imex_case_replayed_by_the_oracle():
+    """the 2-D 512^2 advection-diffusion IMEX case that pins config 3's kernel instances (sweeps_pin512.npz, generated by the
+    reference with SuperLU) replayed by the oracle with its Fourier solve (equal to the sparse LU to 2e-15,
+    test_solver_equivalence_budget): subsampled node values, right-hand sides, end values and residuals"""
+    case = load_cases('sweeps_pin512.npz')['pin_advdiff2d_512_M5_IE']
+    meta = case['meta']
+    pp = {k: tuple(v) if isinstance(v, list) else v for k, v in meta['prob_params'].items()}
+    prob = make_oracle_problem('advdiff', pp)
+    prob.solve_system = lambda rhs, factor, u0, t: O.spectral_solve(prob.diff, rhs, factor)
+    coll = make_oracle_coll(case)
+    L = O.Level(prob, coll, meta['dt'])
+    L.time = meta['t0']
+    n = 512
+    x = np.arange(n) / n
+    u0 = np.sin(np.pi * 2 * x[None, :]) * np.sin(np.pi * 2 * x[:, None]) + 1e-3 * np.random.default_rng(0).standard_normal((n, n))
+    thin = lambda v: np.asarray(v)[..., 1::8] if np.asarray(v).ndim <= 2 else np.asarray(v)[..., 1::8, 5::8]   # noqa: E731
+    assert np.array_equal(thin(u0), case['u0_sub'])
+    L.u[0] = u0
+    O.predict(L, 'spread')
+    for k in range(0, meta['nsweeps'] + 1):
+        if k > 0:
+            O.sweep(L)
+        assert rel_err(thin(np.stack(L.u)), case[f'k{k}_u_sub']) < 1e-12, k
+        assert rel_err(thin(np.stack(L.f)), case[f'k{k}_f_sub']) < 1e-11, k
+        for rt in ('full_abs', 'last_rel'):
+            L.residual_type = rt
+            O.compute_residual(L)
+            ref = float(case[f'k{k}_res_{rt}'])
+            assert abs(L.status_residual - ref) <= 1e-9 * abs(ref) + 1e-14, (k, rt)
+        O.compute_end_point(L, False)
+        assert rel_err(thin(L.uend), case[f'k{k}_uend_0_sub']) < 1e-12, k
+
+
+def test_pin1024_2d_case_replayed_by_the_oracle():
+    """the 2-D 1024^2 heat case behind the bench's own kernel instances (sweeps_pin1024.npz: the reference with SuperLU,
+    20 minutes) replayed by the oracle with its Fourier solve: subsampled node values, end values and residuals"""
+    case = load_cases('sweeps_pin1024.npz')['pin_heat2d_1024_M5_IE']
+    meta = case['meta']
+    pp = {k: tuple(v) if isinstance(v, list) else v for k, v in meta['prob_params'].items()}
+    prob = make_oracle_problem('heat_unforced', pp)
+    prob.solve_system = lambda rhs, factor, u0, t: O.spectral_solve(prob, rhs, factor)
+    coll = make_oracle_coll(case)
+    L = O.Level(prob, coll, meta['dt'])
+    L.time = meta['t0']
+    n = 1024
+    x = np.arange(n) / n
+    u0 = np.sin(np.pi * 2 * x[None, :]) * np.sin(np.pi * 2 * x[:, None]) + 1e-3 * np.random.default_rng(0).standard_normal((n, n))
+    thin = lambda v: np.asarray(v)[..., 1::16] if np.asarray(v).ndim <= 2 else np.asarray(v)[..., 1::16, 9::16]   # noqa: E731
+    assert np.array_equal(thin(u0), case['u0_sub'])
+    L.u[0] = u0
+    O.predict(L, 'spread')
+    for k in range(0, meta['nsweeps'] + 1):
+        if k > 0:
+            O.sweep(L)
+        assert rel_err(thin(np.stack(L.u)), case[f'k{k}_u_sub']) < 1e-12, k
+        L.residual_type = 'full_abs'
+        O.compute_residual(L)
+        ref = float(case[f'k{k}_res_full_abs'])
+        assert abs(L.status_residual - ref) <= 1e-9 * abs(ref) + 1e-14, k
+        O.compute_end_point(L, False)
+        assert rel_err(thin(L.uend), case[f'k{k}_uend_0_sub']) < 1e-12, k
