@@ -19,6 +19,14 @@ from pysdc_amd.errors import ParameterError
 # object can hold a number that is on its way; PYSDC_AMD_QUEUED_RESIDUAL=0: the blocking call, as for foreign level objects
 QUEUED_RESIDUALS = __import__('os').environ.get('PYSDC_AMD_QUEUED_RESIDUAL', '1') != '0'
 
+# L.status.residual from the node-wise max norms, per residual_type (core/sweeper.py:200-215)
+_RESIDUAL_REDUCERS = {
+    'full_abs': lambda norms, L: max(norms),
+    'last_abs': lambda norms, L: norms[-1],
+    'full_rel': lambda norms, L: max(norms) / abs(L.u[0]),
+    'last_rel': lambda norms, L: norms[-1] / abs(L.u[0]),
+}
+
 # every controller stage that asks for the residual after a sweep or a transfer (controller_nonMPI.py / controller_MPI.py)
 _STAGES_AFTER_SWEEP = {'IT_CHECK', 'IT_FINE', 'IT_DOWN', 'IT_UP', 'IT_COARSE'}
 
@@ -56,11 +64,10 @@ class Sweeper:
             self.rng = np.random.RandomState(params['random_seed'])
         self.params = _Pars(params)
         self.coll = params['collocation_class'](**params)
-        if not self.coll.right_is_node and not self.params.do_coll_update:
-            self.logger.warning(
-                'we need to do a collocation update here, since the right end point is not a node. Changing this!'
-            )
+        if not (self.coll.right_is_node or self.params.do_coll_update):
+            # (the end point is not a node: only the quadrature over all nodes reaches it, core/sweeper.py:82-87)
             self.params.do_coll_update = True
+            self.logger.warning('we need to do a collocation update here, since the right end point is not a node. Changing this!')
         self.__level = level
         self.parallelizable = False
         for name in ['genQI', 'genQE']:
@@ -73,27 +80,32 @@ class Sweeper:
             raise ParameterError(f'unknown Q-Delta type {qdType!r}')
         return QDELTA_GENERATORS[qdType](qGen=self.coll.generator, tLeft=self.coll.tleft)
 
-    def get_Qdelta_implicit(self, qd_type, k=None):
-        QDmat = np.zeros_like(self.coll.Qmat)
-        if not hasattr(self, 'genQI') or qd_type not in _aliases(type(self.genQI)) | {type(self.genQI).__name__}:
-            self.genQI = self.buildGenerator(qd_type)
-        QDmat[1:, 1:] = self.genQI.genCoeffs(k=k)
-        err_msg = 'Lower triangular matrix expected!'
-        np.testing.assert_array_equal(np.triu(QDmat, k=1), np.zeros(QDmat.shape), err_msg=err_msg)
-        if np.allclose(np.diag(np.diag(QDmat)), QDmat):
+    def _qdelta(self, slot, qd_type, k, explicit):
+        """(M+1) x (M+1) Q-Delta matrix with a zero first row, from the generator kept in `slot` ('genQI' / 'genQE'; rebuilt
+        when another type is asked for).  Implicit: lower triangular, zero first column; explicit: strictly lower
+        triangular with the node distances in the first column.  A diagonal result makes the sweeper parallelizable
+        (pySDC/core/sweeper.py:97-123)."""
+        gen = getattr(self, slot, None)
+        if gen is None or qd_type not in _aliases(type(gen)) | {type(gen).__name__}:
+            gen = self.buildGenerator(qd_type)
+            setattr(self, slot, gen)
+        full = np.zeros(self.coll.Qmat.shape, dtype=float)
+        if explicit:
+            full[1:, 1:], full[1:, 0] = gen.genCoeffs(k=k, dTau=True)
+        else:
+            full[1:, 1:] = gen.genCoeffs(k=k)
+        above = np.triu(full, k=0 if explicit else 1)
+        np.testing.assert_array_equal(above, np.zeros(full.shape),
+                                      err_msg=('Strictly lower' if explicit else 'Lower') + ' triangular matrix expected!')
+        if np.allclose(np.diag(np.diag(full)), full):
             self.parallelizable = True
-        return QDmat
+        return full
+
+    def get_Qdelta_implicit(self, qd_type, k=None):
+        return self._qdelta('genQI', qd_type, k, explicit=False)
 
     def get_Qdelta_explicit(self, qd_type, k=None):
-        QDmat = np.zeros(self.coll.Qmat.shape, dtype=float)
-        if not hasattr(self, 'genQE') or qd_type not in _aliases(type(self.genQE)) | {type(self.genQE).__name__}:
-            self.genQE = self.buildGenerator(qd_type)
-        QDmat[1:, 1:], QDmat[1:, 0] = self.genQE.genCoeffs(k=k, dTau=True)
-        err_msg = 'Strictly lower triangular matrix expected!'
-        np.testing.assert_array_equal(np.triu(QDmat, k=0), np.zeros(QDmat.shape), err_msg=err_msg)
-        if np.allclose(np.diag(np.diag(QDmat)), QDmat):
-            self.parallelizable = True
-        return QDmat
+        return self._qdelta('genQE', qd_type, k, explicit=True)
 
     def updateVariableCoeffs(self, k):
         """pySDC/core/sweeper.py:262-276."""
@@ -239,21 +251,15 @@ class Sweeper:
             else:
                 L.status.residual = evaluate()
         else:
-            res_norm = []
-            L.residual = self.integrate()
-            for m in range(self.coll.num_nodes):
-                L.residual[m] += L.u[0] - L.u[m + 1]
+            # node by node on datatype operations (core/sweeper.py:186-215): residual_m = u0 + (Q F)_m - u_m (+ tau_m)
+            vectors = self.integrate()
+            for m, r in enumerate(vectors):
+                r += L.u[0] - L.u[m + 1]
                 if L.tau[m] is not None:
-                    L.residual[m] += L.tau[m]
-                res_norm.append(abs(L.residual[m]))
-            if rt == 'full_abs':
-                L.status.residual = max(res_norm)
-            elif rt == 'last_abs':
-                L.status.residual = res_norm[-1]
-            elif rt == 'full_rel':
-                L.status.residual = max(res_norm) / abs(L.u[0])
-            else:
-                L.status.residual = res_norm[-1] / abs(L.u[0])
+                    r += L.tau[m]
+            L.residual = vectors
+            norms = [abs(r) for r in vectors]
+            L.status.residual = _RESIDUAL_REDUCERS[rt](norms, L)
         L.status.updated = False
         return None
 

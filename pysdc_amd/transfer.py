@@ -271,8 +271,7 @@ class BaseTransfer:
         for n in range(1, Mf + 1):
             for m in range(Mc):
                 fine.u[n] = self._add_scaled(fine.u[n], self.Pcoll[n - 1, m], delta[m])
-        for n in range(1, Mf + 1):
-            self._refresh_f(fine, n, fine.time + fine.dt * fine.sweep.coll.nodes[n - 1])
+        self._refresh_f_nodes(fine, list(range(1, Mf + 1)))
 
     def prolong_f(self):
         """variant that also interpolates the change of f instead of re-evaluating it (base_transfer.py:209-251)."""
@@ -300,49 +299,39 @@ class _SpacePars:
             setattr(self, k, v)
 
 
-def _continue_periodic_array(arr, nn):
-    """helpers/transfer_helper.py:72-92."""
-    nn = np.asarray(nn)
-    d_nn = nn[1:] - nn[:-1]
-    if np.all(d_nn == np.ones(nn.shape[0] - 1)):
-        return arr[nn]
-    cont_arr = [arr[nn[0]]]
-    shift = 0.0
-    for n, d in zip(nn[1:], d_nn):
-        if d != 1:
-            shift = -1
-        cont_arr.append(arr[n] + shift)
-    return np.asarray(cont_arr)
+def _unwrapped_abscissae(grid, cols):
+    """the coarse abscissae of the (ascending) column set `cols`, continued over the periodic seam: columns are
+    neighbours on the circle, so wherever two consecutive entries are not adjacent indices the set has wrapped and every
+    abscissa from there on belongs one period (1.0) to the left (what helpers/transfer_helper.py:72-92 computes)"""
+    cols = np.asarray(cols)
+    wrapped = np.concatenate(([False], np.cumsum(np.diff(cols) != 1) > 0))
+    return grid[cols] - wrapped.astype(float)
 
 
 def interpolation_matrix_1d(fine_grid, coarse_grid, k=2):
-    """Dense (n_fine x n_coarse) interpolation matrix for periodic, equidistant, nested grids: the same
-    construction, row by row, as helpers/transfer_helper.py:153-186 (including its behaviour when the k nearest
-    neighbours wrap around a very small coarse grid), so the device operator equals the reference's matrix."""
+    """Dense (n_fine x n_coarse) interpolation matrix for periodic, equidistant, nested grids - the reference's matrix
+    (helpers/transfer_helper.py:153-186), including its behaviour when the k nearest neighbours wrap around a very small
+    coarse grid: even fine points coincide with a coarse point; an odd one, between the coarse points c and c + 1, gets the
+    Lagrange weights of the k columns c - k/2 + 1 .. c + k/2 taken modulo the grid and SORTED, evaluated on abscissae made
+    monotone across the seam."""
     from scipy.interpolate import BarycentricInterpolator
 
-    M = np.zeros((fine_grid.size, coarse_grid.size))
-    for i, p in enumerate(fine_grid):
-        if i % 2 == 0:
-            M[i, int(i / 2)] = 1.0
-            continue
-        if k == 0:
-            continue
-        nn = []
-        cpos, offset = int(i / 2), int(k / 2)
-        for j in range(k):
-            nn.append(cpos - offset + 1 + j)
-            if nn[-1] < 0:
-                nn[-1] += coarse_grid.size
-            elif nn[-1] > coarse_grid.size - 1:
-                nn[-1] -= coarse_grid.size
-        nn = sorted(nn)
-        cont_arr = np.array(_continue_periodic_array(coarse_grid, nn), dtype=float)
-        if p > np.mean(fine_grid) and not (cont_arr[0] <= p <= cont_arr[-1]):
-            cont_arr += 1
-        one = np.asarray([1.0] + [0.0] * (k - 1))
+    nc = coarse_grid.size
+    M = np.zeros((fine_grid.size, nc))
+    M[np.arange(0, fine_grid.size, 2), np.arange(0, fine_grid.size, 2) // 2] = 1.0
+    if k == 0:
+        return M
+    centre = np.mean(fine_grid)
+    basis = np.eye(k)
+    for i in range(1, fine_grid.size, 2):
+        p = fine_grid[i]
+        first = i // 2 - k // 2 + 1
+        cols = sorted(q + nc if q < 0 else (q - nc if q > nc - 1 else q) for q in range(first, first + k))
+        xs = _unwrapped_abscissae(coarse_grid, cols)
+        if p > centre and not (xs[0] <= p <= xs[-1]):     # the point lies in the period the abscissae were moved out of
+            xs = xs + 1
         with np.errstate(divide='ignore'):
-            M[i, nn] = np.asarray([BarycentricInterpolator(cont_arr, np.roll(one, l))(p) for l in range(k)])
+            M[i, cols] = [BarycentricInterpolator(xs, basis[l])(p) for l in range(k)]
     return M
 
 
