@@ -1629,8 +1629,13 @@ int sdc_eval_f(sdc_ctx* c, const double* u, double g_t, double* f_impl, double* 
         HIPCHK(c, hipGetLastError());
         return SDC_OK;
     }
-    if (c->nb) {  // bounded grid, row-dependent stencils: the implicit part only (explicit parts are the caller's)
-        if (f_expl) return fail(c, SDC_ERR_UNSUPPORTED, "the banded operator evaluates the implicit part only");
+    if (c->nb) {  // bounded grid, row-dependent stencils; the only explicit part there is: a u-independent forcing profile(x) g(t)
+        if (f_expl) {
+            if (c->expl_kind != SDC_EXPL_FORCING || !c->profile)
+                return fail(c, SDC_ERR_UNSUPPORTED, "the banded operator evaluates the implicit part (and a forcing profile) only");
+            int rcp = sdc_vec_axpby(c, c->N, g_t, c->profile, 0.0, nullptr, f_expl);
+            if (rcp != SDC_OK) return rcp;
+        }
         return apply_operator(c, u, f_impl);
     }
     if (!c->have_stencil[0]) return fail(c, SDC_ERR_STATE, "implicit operator not set (sdc_set_stencil)");
@@ -2046,6 +2051,7 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
         if (!fourier_only) ENSURE_U0(c);
     }
     if (c->expl_kind == SDC_EXPL_REACTION || c->spectral_op) return sweep_nodewise(c, dt);
+    if (c->nb) return sweep_nodewise(c, dt, true);   // bounded grid, row table: iterative node solves (guess = old node value)
     if (c->solver_kind != 0 || !fourier_ok(c)) return sweep_nodewise(c, dt, true);
     const bool gather_once = c->force_gather;
     c->force_gather = false;

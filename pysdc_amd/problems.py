@@ -228,7 +228,11 @@ class GenericNDimFinDiff(Problem):
                                                   bcParams if use_bcParams else None)
             self._rows = fd.rows_to_table(rows, coeff)
             self._bvec_host = coeff * bvec if (use_bcParams and np.any(bvec)) else None
-        if self.odd_nd or self.banded:
+        # banded levels sweep inside the engine (sdc_sweep: one gather for all nodes, then per node right-hand side, GMRES /
+        # CG solve with the old node value as the guess, operator application [+ forcing profile] - the reference's node loop
+        # as device launches without a host round trip per datatype operation); on odd extensions in 2-D / 3-D the sweep
+        # runs node by node on datatype operations
+        if self.odd_nd:
             self.fused = False
         self._scratch = None
         self._makeAttributeAndRegister('nvars', 'stencil_type', 'order', 'bc', localVars=locals(), readOnly=True)
@@ -407,7 +411,11 @@ class heatNd_forced(heatNd_unforced):
             for i in range(1, self.ndim):
                 p = p * np.sin(np.pi * self.freq[i] * g[i])
             engine.set_forcing_profile(np.broadcast_to(p, self.engine_nvars))
-        elif not self.banded:   # (banded rows: eval_f adds profile * g(t) itself, on the compact fields)
+        elif self.banded:       # compact fields: the profile's n^ndim values lead the engine's (slab-sized) field
+            flat = np.zeros(int(np.prod(self.engine_nvars)))
+            flat[: int(np.prod(self.nvars))] = np.asarray(self._profile(), dtype=float).reshape(-1)
+            engine.set_forcing_profile(flat.reshape(self.engine_nvars))
+        else:
             engine.set_forcing_profile(self._profile())
 
     @classmethod

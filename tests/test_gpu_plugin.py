@@ -338,10 +338,10 @@ def test_dirichlet_sweeps_vs_golden(fname, name, fused):
     probs, sweeps = _classes()
     pc = probs[meta['prob']]
     pp = {k: tuple(v) if isinstance(v, list) else v for k, v in meta['prob_params'].items()}
-    if (len(pp['nvars']) > 1 if isinstance(pp['nvars'], tuple) else False) or pp.get('order', 2) > 2:
-        if fused:
-            pytest.skip('2-D / 3-D dirichlet levels and boundary-shifted stencils sweep node by node')
-    elif not fused:
+    probe = pc(**pp)
+    if fused and not probe.fused:
+        pytest.skip('2-D / 3-D odd extensions and banded IMEX levels sweep node by node')
+    if not fused:
         pc = type(pc.__name__ + '_nodewise', (pc,), {'fused': False})
     S = Step(dict(problem_class=pc, problem_params=pp, sweeper_class=sweeps[meta['sweeper']],
                   sweeper_params=dict(meta['sweeper_params']), level_params=dict(dt=meta['dt']),

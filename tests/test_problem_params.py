@@ -72,7 +72,7 @@ def test_bounded_grids_of_any_mix_are_accepted_like_the_reference():
     from pysdc_amd.problems import heatNd_unforced, GenericNDimFinDiff
 
     P = heatNd_unforced(nvars=40, nu=0.1, freq=1, order=2, bc=('dirichlet', 'neumann'))
-    assert P.bc == ('dirichlet', 'neumann') and P.banded and not P.fused and P.engine_nvars == (40,)
+    assert P.bc == ('dirichlet', 'neumann') and P.banded and P.fused and P.engine_nvars == (40,)
     assert abs(P.dx - 1 / 41) < 1e-15
     assert heatNd_unforced(nvars=48, bc='dirichlet').banded                       # (an even grid: no rule for this string)
     assert heatNd_unforced(nvars=63, bc='dirichlet-zero').view_offset == 1        # order 2: the odd extension stays
