@@ -151,13 +151,6 @@ int sdc_set_restol(sdc_ctx* ctx, double restol);
 int sdc_residual_post(sdc_ctx* ctx, double dt, int residual_type, unsigned long long* ticket);
 int sdc_residual_wait(sdc_ctx* ctx, unsigned long long ticket, int block, double* node_norms, double* residual, int* converged,
                       int* ready);
-/* A Fourier-space sweep that only delivers residual norms is three launches: the pointwise sweep fused with the inverse pass
- * along the contiguous axis (bound by its f64 arithmetic), the in-place pass along the middle axis (bound by memory), the
- * norm-only pass along the first axis.  With groups > 1 the first two are issued per group of kx planes, the middle-axis pass
- * of a group on a second stream while the engine's stream runs the first launch of the next group (1024^3, 32 groups: 168 ->
- * 164 ms per time step).  Off by default (-1, 0, 1): launches that share the GPU no longer have durations of their own, and
- * the per-kernel accounting of the bench is made on launches that run alone.  Same arithmetic, same results. */
-int sdc_set_pipeline_groups(sdc_ctx* ctx, int groups);
 /* Deferred node fields (default on).  The spectral-reuse sweep reads neither F[1..M] nor the M copies a 'spread'
  * predictor makes (core/sweeper.py:140-146): the engine therefore leaves them unwritten until somebody needs
  * them.  sdc_slot_ptr / sdc_upload / sdc_download / sdc_integrate / sdc_end_point / sdc_residual and the

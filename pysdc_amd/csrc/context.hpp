@@ -68,11 +68,6 @@ struct sdc_ctx {
     cd *Sy = nullptr, *Sin = nullptr;
     bool wire_spectral = false, rlines_valid = false, sl_ev_recorded = false;
     hipEvent_t sl_ev = nullptr;
-    // z / y passes of a Fourier-space sweep issued in groups of kx planes, the y pass of a group on a second stream while
-    // the z pass of the next group runs (one is bound by its arithmetic, the other by memory): pipe_groups > 1
-    int pipe_groups = -1;  // -1: the default for the grid (sdc_set_pipeline_groups)
-    hipStream_t aux = nullptr;
-    hipEvent_t pipe_ev[257] = {};
     cd* Wend = nullptr;  // spectrum of an end value that is not the cached last node (forward transform of UEND on demand)
     // Same for the real-space pair: UEND and UEND2 alternate as the end-value buffer; after sdc_advance the start value
     // of the new step is still where the old step left its end value (u0_src) and reaches the U[0] slab only when

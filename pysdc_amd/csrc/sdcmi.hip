@@ -567,48 +567,7 @@ static int spec_sweep_n(sdc_ctx* c, int nf, SpecArgs& a, const FieldPtrs& p, uns
                                                      : (a.spread ? "spec_z_spread" : "spec_z");
 #define ZCASE(MM) \
     case MM: launch_spec_z<N, MM>(c, a, lines, a.virt ? 3 : (norms ? 1 : 0), glines); break;
-                size_t glines = 0;
-                // Pipelined z / y passes (sdc_set_pipeline_groups): the kx planes are cut into G groups; the y pass of a
-                // group runs on a second stream while the engine's stream already works on the z pass of the next group -
-                // one launch is bound by its arithmetic, the other by memory (1024^3: about 1 ms per sweep)
-                int G = c->pipe_groups < 0 ? 1 : c->pipe_groups;  // (off unless asked for: see sdc_set_pipeline_groups)
-                if (!(G > 1 && norms && !p.out[0] && c->ndim == 3 && N >= 256 && !c->early_uend)) G = 1;
-                const unsigned lpb = a.virt ? specz_lines<N, true>() : specz_lines<N, false>();  // lines per workgroup
-                if (G > n / 2 + 1) G = n / 2 + 1;
-                if (G > 1) {
-                    constexpr int E = fft_elems(N), PS = N / E, T = N >= 2048 ? 4 : (N == 1024 ? SDC_T1024 : 8);
-                    const size_t lds_str = (size_t)LayStrided<N, T>::doubles(T) * sizeof(double);
-                    const int nkx = n / 2 + 1;
-                    if (!c->aux) {
-                        HIPCHK(c, hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
-                        for (auto& e : c->pipe_ev) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-                    }
-                    HIPCHK(c, hipEventRecord(c->pipe_ev[256], c->stream));  // W is free (earlier work of the engine's stream)
-                    HIPCHK(c, hipStreamWaitEvent(c->aux, c->pipe_ev[256], 0));
-                    const char* zname = pname(zbase, nf, G);
-                    const char* yname = pname("fft_y_inv", nf, G);
-                    for (int g = 0; g < G; ++g) {
-                        const int k0 = (int)((long long)nkx * g / G), k1 = (int)((long long)nkx * (g + 1) / G);
-                        if (k1 <= k0) continue;
-                        a.block0 = (unsigned)k0 * (unsigned)n / lpb;  // (n is a multiple of the lines per workgroup)
-                        glines = (size_t)(k1 - k0) * n;
-                        {
-                            LaunchTimer lt(c, zname);
-                            switch (nf) { ZCASE(1) ZCASE(2) ZCASE(3) ZCASE(4) ZCASE(5) }
-                        }
-                        HIPCHK(c, hipEventRecord(c->pipe_ev[g], c->stream));
-                        HIPCHK(c, hipStreamWaitEvent(c->aux, c->pipe_ev[g], 0));
-                        LaunchTimer lt(c, yname, c->aux, true);
-                        hipLaunchKernelGGL((k_ffty<N, T, +1>), dim3((n + T - 1) / T, k1 - k0, nf), dim3(PS * T), lds_str, c->aux,
-                                           c->W, c->Nc, c->tw, k0);
-                    }
-                    a.block0 = 0;
-                    glines = 0;
-                    HIPCHK(c, hipEventRecord(c->pipe_ev[256], c->aux));
-                    HIPCHK(c, hipStreamWaitEvent(c->stream, c->pipe_ev[256], 0));
-                    HIPCHK(c, hipGetLastError());
-                    return inverse_tail_n<N>(c, nf, c->W, p, norms, true);
-                }
+                const size_t glines = 0;
                 LaunchTimer lt(c, pname(zbase, nf));
                 switch (nf) { ZCASE(1) ZCASE(2) ZCASE(3) ZCASE(4) ZCASE(5) }
 #undef ZCASE
@@ -1037,7 +996,7 @@ static int residual_shift_n(sdc_ctx* c, cd* dbuf, const cd* newS0) {
 
 extern "C" {
 
-int sdc_version(void) { return 101; }  // 101: sdc_work_counters writes out[5]
+int sdc_version(void) { return 102; }  // 101: sdc_work_counters writes out[5]; 102: residual post / wait, batched eval_f, accumulating transfer; sdc_set_pipeline_groups gone
 
 int sdc_init_field(sdc_ctx* c, double* dst, const int* freq, double amp, unsigned long long seed) {
     if (!c || !dst || !freq) return fail(c, SDC_ERR_PARAM, "null pointer");
@@ -1066,7 +1025,6 @@ int sdc_ctx_create(sdc_ctx** out, int device, int ndim, int n, int num_nodes, in
     c->M = num_nodes;
     c->ncomp = ncomp;
     c->stream = (hipStream_t)stream;
-    if (const char* pg = getenv("SDC_PIPE_GROUPS")) c->pipe_groups = atoi(pg) > 256 ? 256 : (atoi(pg) < 0 ? -1 : atoi(pg));
     c->N = 1;
     for (int d = 0; d < ndim; ++d) c->N *= (size_t)n;
     c->Nc = ndim == 1 ? c->N : (size_t)(n / 2 + 1) * (c->N / n);
@@ -1137,11 +1095,6 @@ int sdc_ctx_destroy(sdc_ctx* c) {
     (void)hipFree(c->S);
     (void)hipFree(c->Sx);
     (void)hipFree(c->Sy);
-    if (c->aux) {
-        (void)hipStreamSynchronize(c->aux);
-        (void)hipStreamDestroy(c->aux);
-        for (auto& e : c->pipe_ev) (void)hipEventDestroy(e);
-    }
     (void)hipFree(c->Wend);
     if (c->ring) (void)hipHostFree(c->ring);
     (void)hipFree(c->Gm);
@@ -1556,12 +1509,6 @@ int sdc_set_multiplier_table(sdc_ctx* c, int from_sweep) {
     if (!c || from_sweep < 0) return fail(c, SDC_ERR_PARAM, "multiplier table: first sweep that uses it (0: never)");
     c->g_from = from_sweep;
     c->g_sweeps = 0;
-    return SDC_OK;
-}
-
-int sdc_set_pipeline_groups(sdc_ctx* c, int groups) {
-    if (!c || groups > 256) return fail(c, SDC_ERR_PARAM, "pipeline groups: -1 (default), 0 / 1 (off) .. 256");
-    c->pipe_groups = groups < 0 ? -1 : groups;
     return SDC_OK;
 }
 

@@ -191,10 +191,6 @@ class SweepEngine:
             self._chk(rc)
         return rc == 1
 
-    def set_pipeline_groups(self, groups):
-        """z / y passes of a norm-only sweep issued in this many groups of kx planes on two streams (-1 default, 0 off)"""
-        self._chk(self.lib.sdc_set_pipeline_groups(self.ctx, int(groups)))
-
     def set_deferred(self, on):
         """leave F[1..M] / the spread copies unwritten until they are read (include/sdcmi.h: sdc_set_deferred)"""
         self._chk(self.lib.sdc_set_deferred(self.ctx, int(bool(on))))

@@ -11,11 +11,9 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_n$N$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 ARGS="$GRAFT_REPO_ROOT/bench.py --n $N --steps 3 --warmup 1 --no-cpu-baseline --no-extras --details-file $OUT/bench_details.json $EXTRA"
-# the counter passes run with the z / y passes of a sweep as ONE launch each (SDC_PIPE_GROUPS=1): per-launch traffic of the
-# kernels as such; the stats pass runs the default (pipelined) configuration the bench line comes from
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o run -- python3 $ARGS > $OUT/bench_stats.log 2>&1
-SDC_PIPE_GROUPS=1 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o run -- python3 $ARGS > $OUT/bench_fetch.log 2>&1
-SDC_PIPE_GROUPS=1 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o run -- python3 $ARGS > $OUT/bench_write.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o run -- python3 $ARGS > $OUT/bench_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o run -- python3 $ARGS > $OUT/bench_write.log 2>&1
 python3 $GRAFT_REPO_ROOT/scripts/make_traffic.py $OUT $N
 find $OUT -name "*kernel_trace.csv" -size +2M -delete
 find $OUT -name "*counter_collection.csv" -size +2M -delete

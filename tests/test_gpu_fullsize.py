@@ -745,47 +745,3 @@ def test_eager_sweeps_recompute_the_iterate_too(n, ndim):
         e.close()
 
 
-@pytest.mark.parametrize('n,groups', [(256, 4), (256, 129), (512, 7), (1024, 32)])
-def test_pipelined_z_and_y_passes_give_the_same_residuals_and_iterates(n, groups):
-    """sdc_set_pipeline_groups: the z / y passes of a norm-only sweep issued per group of kx planes, the y pass of a group on
-    a second stream - same kernels on the same data in another launch order: node residuals and node values bit for bit
-    those of the unpipelined sweep (uneven groups, one plane per group, the default of the headline grid)"""
-    import torch
-
-    if n == 1024 and torch.cuda.mem_get_info()[0] < 2 * 24 * 8.0 * n**3:
-        groups_list = [(0,), (groups,)]      # one engine at a time
-    else:
-        groups_list = [(0, groups)]
-    M, dt = 5, 1e-3 * (512.0 / n) ** 2
-    results = {}
-    for gs in groups_list:
-        engines = []
-        for g in gs:
-            e = G.engine_for('heat_unforced', dict(nvars=(n, n, n), nu=0.1), M)
-            from pysdc_amd.coeffs import CollBase, QDELTA_GENERATORS
-
-            c = CollBase(M, 0, 1, 'LEGENDRE', 'RADAU-RIGHT')
-            qi = np.zeros_like(c.Qmat)
-            qi[1:, 1:] = QDELTA_GENERATORS['IE'](qGen=c.generator, tLeft=0).genCoeffs()
-            e.set_coeffs(c.Qmat, qi, None, c.nodes, c.weights)
-            e.set_pipeline_groups(g)
-            import ctypes as C
-
-            L.check(e.lib.sdc_init_field(e.ctx, e.ptr(L.SLOT_U, 0), (C.c_int * 3)(2, 2, 2), 1e-3, 0), e.ctx)
-            e.invalidate_spectra(1)
-            e.profile_enable(True)
-            e.predict(0.0, dt)
-            norms = []
-            for k in range(3):
-                e.sweep(0.0, dt)
-                norms.append(e.residual(dt)[1].copy())
-            e.end_point(dt, False)
-            uend = torch.empty(e.N, dtype=torch.float64, device='cuda')
-            e.vec_copy(e.N, e.ptr(L.SLOT_UEND), uend.data_ptr())
-            names = set(e.profile_read())
-            results[g] = (np.array(norms), uend, names)
-            e.close()
-    (n0, u0_, names0), (n1, u1_, names1) = results[0], results[groups]
-    assert np.array_equal(n0, n1)
-    assert bool(torch.equal(u0_, u1_))
-    assert 'fft_y_inv[5]' in names0 and f'fft_y_inv[5/{groups}]' in names1 and f'spec_z_res_v0[5/{groups}]' in names1
