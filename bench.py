@@ -933,7 +933,10 @@ def main():
     try:
         out = run_workload(args, world, rank, use_dist)
     except MemoryError as e:
-        print(json.dumps({'error': str(e), 'n_gpus': world}), flush=True)
+        if rank == 0:
+            print(json.dumps({'error': str(e), 'n_gpus': world}), flush=True)
+        else:
+            print(f'rank {rank}: {e}', file=sys.stderr, flush=True)
         os._exit(5)   # (other ranks reach the same verdict on their own GPU; nobody waits in a collective)
     if rank == 0:
         subs = cpu = cpu_detail = cb = None
