@@ -7,6 +7,7 @@ imex_1st_order.py:6-137.  When the problem is one the engine can sweep in one ca
 finite-difference operators) each method is ONE C-ABI call on the level's device slabs; otherwise the same
 algorithm runs node by node on ``hip_mesh`` operations with ``prob.eval_f`` / ``prob.solve_system``."""
 import logging
+import os
 
 import numpy as np
 
@@ -17,7 +18,7 @@ from pysdc_amd.errors import ParameterError
 
 # compute_residual queues the residual and does not wait for it (include/sdcmi.h: sdc_residual_post) where the level's status
 # object can hold a number that is on its way; PYSDC_AMD_QUEUED_RESIDUAL=0: the blocking call, as for foreign level objects
-QUEUED_RESIDUALS = __import__('os').environ.get('PYSDC_AMD_QUEUED_RESIDUAL', '1') != '0'
+QUEUED_RESIDUALS = os.environ.get('PYSDC_AMD_QUEUED_RESIDUAL', '1') != '0'
 
 # L.status.residual from the node-wise max norms, per residual_type (core/sweeper.py:200-215)
 _RESIDUAL_REDUCERS = {
