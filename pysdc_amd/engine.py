@@ -94,12 +94,13 @@ class SweepEngine:
         L.check(self.lib.sdc_ctx_create(C.byref(self.ctx), device, self.ndim, self.n, self.M, self.ncomp,
                                         C.c_void_p(stream)))
         self.tau_active = False
-        self._futures = collections.deque()   # weak references to residuals on their way (residual_post)
+        self._futures = collections.deque()   # (ticket, weak reference) of residuals on their way (residual_post)
+        self._issued = 0                      # last ticket of the residual ring handed out (posted or blocking)
         self._restol_sent = None
 
     def close(self):
         if getattr(self, 'ctx', None):
-            for ref in list(getattr(self, '_futures', ())):   # residuals still on their way are collected while the records exist
+            for _, ref in list(getattr(self, '_futures', ())):   # residuals still on their way are collected while the records exist
                 fut = ref()
                 if fut is not None:
                     try:
@@ -298,7 +299,9 @@ class SweepEngine:
             )
         norms = np.zeros(self.M)
         res = C.c_double()
+        self._retire_old_tickets()
         self._chk(self.lib.sdc_residual(self.ctx, dt, L.RES_TYPES[residual_type], _dptr(norms), C.byref(res)))
+        self._issued += 1        # (a ticket of the same ring)
         return res.value, norms
 
     def residual_post(self, dt, residual_type='full_abs', restol=-1.0):
@@ -312,14 +315,10 @@ class SweepEngine:
         if restol != self._restol_sent:
             self._chk(self.lib.sdc_set_restol(self.ctx, float(restol)))
             self._restol_sent = restol
-        # the library keeps the last 256 records: whoever still holds an older ticket gets its values now (long done)
-        while len(self._futures) >= 200:
-            old = self._futures.popleft()()
-            if old is not None:
-                old.result()
+        self._retire_old_tickets()
         t = C.c_ulonglong()
         self._chk(self.lib.sdc_residual_post(self.ctx, dt, L.RES_TYPES[residual_type], C.byref(t)))
-        ticket = t.value
+        ticket = self._issued = t.value
 
         def fetch(block, self=self, ticket=ticket):
             if not self.ctx:
@@ -331,8 +330,18 @@ class SweepEngine:
             return (res.value, norms, bool(conv.value)) if ready.value else None
 
         fut = ResidualFuture(fetch)
-        self._futures.append(weakref.ref(fut))
+        self._futures.append((ticket, weakref.ref(fut)))
         return fut
+
+    def _retire_old_tickets(self, keep=200):
+        """the library keeps the last 256 residual records: whoever still holds a ticket that the NEXT post would bring
+        within 56 records of being overwritten gets its values now (its launch is long done).  Blocking residual() calls use
+        tickets too (sdc_residual = post + wait), so the distance is counted in tickets, not in pending futures."""
+        while self._futures and self._futures[0][0] <= self._issued + 1 - keep:
+            _, ref = self._futures.popleft()
+            old = ref()
+            if old is not None:
+                old.result()
 
     def end_point(self, dt, do_coll_update):
         self._chk(self.lib.sdc_end_point(self.ctx, dt, int(bool(do_coll_update))))

@@ -157,3 +157,27 @@ def test_runs_to_a_tolerance_stop_where_the_blocking_path_stops():
     assert seen[-1][0] is True and any(a is False for a, _ in seen)
     assert out[True][0] == out[False][0] and all(1 < k < 30 for k in out[True][0]), out[True][0]
     assert out[True][2] == out[False][2] and np.array_equal(out[True][1], out[False][1])
+
+
+def test_blocking_calls_between_posts_do_not_lose_pending_tickets():
+    """sdc_residual (blocking) draws tickets from the same 256-record ring as sdc_residual_post: a future that stays pending
+    while hundreds of blocking calls go by is collected before its record is overwritten"""
+    from pysdc_amd import lib as Lb
+    from pysdc_amd.coeffs import CollBase, QDELTA_GENERATORS
+    from tests._gpu import engine_for
+
+    e = engine_for('heat_unforced', dict(nvars=(16, 16, 16), nu=0.1), 3)
+    c = CollBase(3, 0, 1, 'LEGENDRE', 'RADAU-RIGHT')
+    QI = np.zeros_like(c.Qmat)
+    QI[1:, 1:] = QDELTA_GENERATORS['IE'](qGen=c.generator, tLeft=0).genCoeffs()
+    e.set_coeffs(c.Qmat, QI, None, c.nodes, c.weights)
+    e.upload(Lb.SLOT_U, 0, np.random.default_rng(1).standard_normal(e.nvars))
+    e.predict(0.0, 1e-3, 'spread', 0.0, 0.0)
+    e.set_unlocked(True)
+    e.sweep(0.0, 1e-3)
+    first = e.residual_post(1e-3, 'full_abs')
+    want, _ = e.residual(1e-3, 'full_abs')
+    for _ in range(400):
+        e.residual(1e-3, 'last_abs')
+    assert first.result() == want
+    e.close()
