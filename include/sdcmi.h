@@ -376,6 +376,13 @@ int sdc_fft_prolong(sdc_ctx* coarse, sdc_ctx* fine, const double* src, double* d
  * (the Fourier solve becomes the sine-transform solve).  This rebuilds the end points and the mirrored half of
  * one field after its interior was written.  ctx may be NULL. */
 int sdc_odd_mirror(sdc_ctx* ctx, double* field, int n_interior);
+/* dirichlet-zero in 2-D / 3-D with the centred order-2 operator (generic_ND_FD.py:130, helpers/problem_helper.py:143-160 with
+ * zero boundary values): the level's fields are the n_interior^ndim interior points, stored compactly at the start of the
+ * context's slab fields; the context's grid is the odd extension, 2 (n_interior + 1) points per axis, on which the operator
+ * is the periodic one and the Fourier solve is the sine-transform solve.  After this call sdc_eval_f / sdc_solve take and
+ * return COMPACT fields (they pack into extension-sized scratch, run, extract), and sdc_sweep runs the node loop on the
+ * device.  n_interior = 0 switches the mode off. */
+int sdc_set_odd_interior(sdc_ctx* ctx, int n_interior);
 /* The same idea in 2-D / 3-D (generic_ND_FD.py:99-133 'dirichlet-zero', order 2; helpers/problem_helper.py:143-224): the
  * interior n^ndim values are not contiguous inside their odd extension of (2(n+1))^ndim points, so fields stay compact and
  * are packed into / extracted from an extension-sized scratch field around eval_f and solve (problem level: the sweep then

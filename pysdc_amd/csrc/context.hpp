@@ -129,6 +129,13 @@ struct sdc_ctx {
     size_t Nb = 0;
     int* bcols = nullptr;
     double* bwts = nullptr;
+    // dirichlet-zero in 2-D / 3-D by the odd extension (sdc_set_odd_interior): level fields are compact odd_n^ndim arrays at the
+    // start of the slab fields (the interior is strided inside its extension of 2 (odd_n + 1) points per axis, which is the
+    // engine's grid); sdc_eval_f / sdc_solve pack them into extension-sized scratch, run the periodic kernels, extract
+    int odd_n = 0;
+    bool odd_busy = false;        // inside such a call: the pointers ARE extensions
+    double* odd_buf[3] = {nullptr, nullptr, nullptr};
+    double* profile_compact = nullptr;   // the forcing profile in the layout of the compact fields (predictor fill)
     int solver_kind = 0;          // 0: exact solve in Fourier space, 1: conjugate gradients (solver_type='CG'), 2: GMRES
     double cg_rtol = 1e-12;
     int cg_maxiter = 10000;

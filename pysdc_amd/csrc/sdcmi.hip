@@ -1097,6 +1097,8 @@ int sdc_ctx_destroy(sdc_ctx* c) {
     (void)hipFree(c->Sy);
     (void)hipFree(c->Wend);
     if (c->ring) (void)hipHostFree(c->ring);
+    for (double* b : c->odd_buf) (void)hipFree(b);
+    (void)hipFree(c->profile_compact);
     (void)hipFree(c->Gm);
     if (c->sl_ev) (void)hipEventDestroy(c->sl_ev);
     (void)hipFree(c->UEND2);
@@ -1277,6 +1279,11 @@ int sdc_set_forcing_profile(sdc_ctx* c, const double* host_profile) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->expl_kind = SDC_EXPL_FORCING;
     c->specP_valid = false;
+    if (c->profile_compact) {   // (made from the old profile)
+        (void)hipFree(c->profile_compact);
+        c->profile_compact = nullptr;
+        c->bytes -= c->N * sizeof(double);
+    }
     return SDC_OK;
 }
 
@@ -1337,6 +1344,18 @@ static int launch_spread(sdc_ctx* c, int guess, double fill_u, double fill_f, bo
     a.u0 = u0p;
     a.f0 = c->F;
     a.profile = c->profile;
+    if (c->odd_n && c->profile && c->expl_kind == SDC_EXPL_FORCING) {
+        // compact interior fields (sdc_set_odd_interior): the fill needs the profile in THEIR layout - the interior of the
+        // extension-shaped one, extracted once
+        if (!c->profile_compact) {
+            HIPCHK(c, hipMalloc((void**)&c->profile_compact, c->N * sizeof(double)));
+            HIPCHK(c, hipMemsetAsync(c->profile_compact, 0, c->N * sizeof(double), c->stream));
+            c->bytes += c->N * sizeof(double);
+            int rcx = sdc_odd_extract(c, c->profile, c->profile_compact, c->odd_n, c->ndim);
+            if (rcx != SDC_OK) return rcx;
+        }
+        a.profile = c->profile_compact;
+    }
     a.U = c->U;
     a.F = c->F;
     a.N = c->N;
@@ -1567,8 +1586,45 @@ int sdc_download(sdc_ctx* c, int slot, int m, int comp, double* host) {
     return SDC_OK;
 }
 
+int sdc_set_odd_interior(sdc_ctx* c, int n_interior) {
+    if (!c) return SDC_ERR_PARAM;
+    if (n_interior != 0 && (c->ndim < 2 || c->n != 2 * (n_interior + 1)))
+        return fail(c, SDC_ERR_PARAM, "odd extension of %d interior points needs an engine grid of %d per axis in 2-D / 3-D, got %d (%d-D)",
+                    n_interior, 2 * (n_interior + 1), c->n, c->ndim);
+    c->odd_n = n_interior;
+    return SDC_OK;
+}
+static int odd_scratch(sdc_ctx* c, int k) {
+    if (!c->odd_buf[k]) {
+        HIPCHK(c, hipMalloc((void**)&c->odd_buf[k], c->N * sizeof(double)));
+        c->bytes += c->N * sizeof(double);
+    }
+    return SDC_OK;
+}
+struct OddScope {   // the calls between construction and destruction see extension-sized fields
+    sdc_ctx* c;
+    explicit OddScope(sdc_ctx* c_) : c(c_) { c->odd_busy = true; }
+    ~OddScope() { c->odd_busy = false; }
+};
+
 int sdc_eval_f(sdc_ctx* c, const double* u, double g_t, double* f_impl, double* f_expl) {
     if (!c || !u || !f_impl) return fail(c, SDC_ERR_PARAM, "null pointer");
+    if (c->odd_n && !c->odd_busy) {   // compact interior fields: through the odd extension and back
+        for (int k = 0; k < (f_expl ? 3 : 2); ++k) {
+            int rs = odd_scratch(c, k);
+            if (rs != SDC_OK) return rs;
+        }
+        int rc = sdc_odd_extend(c, u, c->odd_buf[0], c->odd_n, c->ndim);
+        if (rc != SDC_OK) return rc;
+        {
+            OddScope scope(c);
+            rc = sdc_eval_f(c, c->odd_buf[0], g_t, c->odd_buf[1], f_expl ? c->odd_buf[2] : nullptr);
+        }
+        if (rc != SDC_OK) return rc;
+        rc = sdc_odd_extract(c, c->odd_buf[1], f_impl, c->odd_n, c->ndim);
+        if (rc == SDC_OK && f_expl) rc = sdc_odd_extract(c, c->odd_buf[2], f_expl, c->odd_n, c->ndim);
+        return rc;
+    }
     if (c->kind == 1) {
         LaunchTimer lt(c, "vdp_eval");
         hipLaunchKernelGGL(k_vdp_eval, dim3(grid_for(c->N / 2, 256)), dim3(256), 0, c->stream, u, f_impl, c->N / 2,
@@ -1634,9 +1690,9 @@ int sdc_eval_f_batch(sdc_ctx* c, int nf, const double* const* u, const double* g
     if (nf > c->M) return fail(c, SDC_ERR_PARAM, "at most num_nodes = %d fields per call (the work spectra), got %d", c->M, nf);
     for (int f = 0; f < nf; ++f)
         if (!u[f] || !f_impl[f]) return fail(c, SDC_ERR_PARAM, "null field pointer");
-    const bool batched_spectral = c->kind == 0 && !c->nb && c->spectral_op && c->ndim >= 2 &&
+    const bool batched_spectral = c->kind == 0 && !c->nb && !c->odd_n && c->spectral_op && c->ndim >= 2 &&
                                   (c->expl_kind == SDC_EXPL_NONE || c->expl_kind == SDC_EXPL_REACTION);
-    const bool batched_stencil = c->kind == 0 && !c->nb && !c->spectral_op && c->have_stencil[0] &&
+    const bool batched_stencil = c->kind == 0 && !c->nb && !c->odd_n && !c->spectral_op && c->have_stencil[0] &&
                                  c->expl_kind != SDC_EXPL_REACTION && !(c->expl_kind == SDC_EXPL_FORCING && !c->profile);
     if (batched_spectral) {
         // ONE transform round trip for all fields: forward passes, the symbol on the contiguous axis, inverse passes; the
@@ -1712,7 +1768,7 @@ int sdc_predict(sdc_ctx* c, double t, double dt, int guess, double fill_u, doubl
     // with the 3-D three-point kernel even f(u0) itself is not stored: one pass over u0 that only reduces max|f(u0)|
     auto three = [](const Stencil& s) { return s.npts == 3 && s.off[0] == -1 && s.off[1] == 0 && s.off[2] == 1; };
     const bool explS = c->expl_kind == SDC_EXPL_STENCIL;
-    const bool f0_by_norm = lazy_spread && spread_res && !c->spectral_op && c->ndim == 3 && c->n % 64 == 0 &&
+    const bool f0_by_norm = lazy_spread && spread_res && !c->spectral_op && !c->odd_n && c->ndim == 3 && c->n % 64 == 0 &&
                             c->have_stencil[0] && three(c->st[0]) &&
                             (c->expl_kind == SDC_EXPL_NONE || (explS && c->have_stencil[1] && three(c->st[1])));
     int rc = SDC_OK;
@@ -1993,12 +2049,13 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
         // only a sweep that stays in Fourier space and stores nothing in real space leaves the start value where it
         // lies (u0_src); every other data flow reads the U[0] slab
         const bool fourier_only = c->reuse && !c->force_gather && !c->tau_active && c->have_stencil[0] && fourier_ok(c) &&
-                                  c->expl_kind != SDC_EXPL_REACTION && !c->spectral_op && c->solver_kind == 0 &&
+                                  c->expl_kind != SDC_EXPL_REACTION && !c->spectral_op && c->solver_kind == 0 && !c->odd_n &&
                                   c->deferred && c->ndim >= 2 && (c->skip_residual || c->fuse_residual);
         if (!fourier_only) ENSURE_U0(c);
     }
     if (c->expl_kind == SDC_EXPL_REACTION || c->spectral_op) return sweep_nodewise(c, dt);
     if (c->nb) return sweep_nodewise(c, dt, true);   // bounded grid, row table: iterative node solves (guess = old node value)
+    if (c->odd_n) return sweep_nodewise(c, dt, c->solver_kind != 0);   // compact fields, solves / evaluations through the odd extension
     if (c->solver_kind != 0 || !fourier_ok(c)) return sweep_nodewise(c, dt, true);
     const bool gather_once = c->force_gather;
     c->force_gather = false;
@@ -2510,6 +2567,22 @@ static int gmres_solve(sdc_ctx* c, const double* b, double factor, const double*
 
 int sdc_solve(sdc_ctx* c, const double* rhs, double factor, const double* guess, double* out) {
     if (!c || !rhs || !out) return fail(c, SDC_ERR_PARAM, "null pointer");
+    if (c->odd_n && !c->odd_busy) {   // compact interior fields: the solve on the odd extension is the sine-transform solve
+        const bool with_guess = guess != nullptr && c->solver_kind != 0;
+        for (int k = 0; k < (with_guess ? 3 : 2); ++k) {
+            int rs = odd_scratch(c, k);
+            if (rs != SDC_OK) return rs;
+        }
+        int rc = sdc_odd_extend(c, rhs, c->odd_buf[0], c->odd_n, c->ndim);
+        if (rc == SDC_OK && with_guess) rc = sdc_odd_extend(c, guess, c->odd_buf[2], c->odd_n, c->ndim);
+        if (rc != SDC_OK) return rc;
+        {
+            OddScope scope(c);
+            rc = sdc_solve(c, c->odd_buf[0], factor, with_guess ? c->odd_buf[2] : nullptr, c->odd_buf[1]);
+        }
+        if (rc != SDC_OK) return rc;
+        return sdc_odd_extract(c, c->odd_buf[1], out, c->odd_n, c->ndim);
+    }
     if (c->kind == 1) {
         if (!guess) return fail(c, SDC_ERR_PARAM, "the Newton solver needs an initial guess");
         {

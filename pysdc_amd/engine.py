@@ -136,6 +136,11 @@ class SweepEngine:
         w = np.ascontiguousarray(weights, dtype=np.float64)
         self._chk(self.lib.sdc_set_stencil(self.ctx, which, len(offsets), off, _dptr(w)))
 
+    def set_odd_interior(self, n_interior):
+        """compact interior fields of a dirichlet-zero level inside slab fields of the odd extension's size
+        (include/sdcmi.h: sdc_set_odd_interior)"""
+        self._chk(self.lib.sdc_set_odd_interior(self.ctx, int(n_interior)))
+
     def set_banded_operator(self, cols, weights):
         """row table of a 1-D operator on a bounded grid (include/sdcmi.h: sdc_set_banded_operator)"""
         cols = np.ascontiguousarray(cols, dtype=np.int32)

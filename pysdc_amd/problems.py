@@ -230,10 +230,9 @@ class GenericNDimFinDiff(Problem):
             self._bvec_host = coeff * bvec if (use_bcParams and np.any(bvec)) else None
         # banded levels sweep inside the engine (sdc_sweep: one gather for all nodes, then per node right-hand side, GMRES /
         # CG solve with the old node value as the guess, operator application [+ forcing profile] - the reference's node loop
-        # as device launches without a host round trip per datatype operation); on odd extensions in 2-D / 3-D the sweep
-        # runs node by node on datatype operations
-        if self.odd_nd:
-            self.fused = False
+        # as device launches without a host round trip per datatype operation)
+        # (odd extensions in 2-D / 3-D sweep inside the engine too since round 4: sdc_set_odd_interior makes sdc_eval_f /
+        # sdc_solve take the compact interior fields and go through the extension themselves)
         self._scratch = None
         self._makeAttributeAndRegister('nvars', 'stencil_type', 'order', 'bc', localVars=locals(), readOnly=True)
         self._makeAttributeAndRegister('freq', 'lintol', 'liniter', 'solver_type', localVars=locals())
@@ -272,6 +271,8 @@ class GenericNDimFinDiff(Problem):
             engine.set_banded_operator(*self._rows)
         else:
             engine.set_stencil(0, *self._stencil)
+        if self.odd_nd:
+            engine.set_odd_interior(self.nvars[0])
         if self.solver_type in ('CG', 'GMRES'):
             engine.set_solver(self.solver_type, self.lintol, self.liniter)
 
@@ -283,13 +284,10 @@ class GenericNDimFinDiff(Problem):
         return self._scratch[k]
 
     def _stage_in(self, u, k):
-        """pointer the engine can read: the field itself (periodic, banded) or its odd extension in scratch k"""
-        if self.banded:
+        """pointer the engine can read: the field itself (periodic, banded, compact interior of an odd extension in 2-D / 3-D
+        - the engine packs and extracts those itself) or, in 1-D, its odd extension in scratch k"""
+        if self.banded or self.odd_nd:
             return u.ptr
-        if self.odd_nd:
-            e = self._ext(k)
-            L.check(self.engine.lib.sdc_odd_extend(self.engine.ctx, u.ptr, e.ptr, self.nvars[0], self.ndim), self.engine.ctx)
-            return e.ptr
         if not self.view_offset:
             return u.ptr
         e = self._ext(k)
@@ -299,14 +297,11 @@ class GenericNDimFinDiff(Problem):
         return e.ptr
 
     def _stage_out(self, k, dst):
-        if self.odd_nd:
-            L.check(self.engine.lib.sdc_odd_extract(self.engine.ctx, self._ext(k).ptr, dst.ptr, self.nvars[0], self.ndim),
-                    self.engine.ctx)
-        elif self.view_offset:
+        if self.view_offset:
             self.engine.vec_copy(self.nvars[0], self._ext(k).ptr + 8, dst.ptr)
 
     def _out_ptr(self, k, dst):
-        return self._ext(k).ptr if (self.view_offset or self.odd_nd) else dst.ptr   # (banded: in place, nothing to stage)
+        return self._ext(k).ptr if self.view_offset else dst.ptr   # (banded, odd extension in 2-D / 3-D: in place, nothing to stage)
 
     def _boundary_data(self):
         """coeff * b on the device (use_bcParams), or None"""
@@ -432,11 +427,8 @@ class heatNd_forced(heatNd_unforced):
                 self._profile_dev = self._from_host(self._profile())
             f.expl._axpby(float(self.forcing_g(t)), self._profile_dev, 0.0, self._profile_dev, f.expl)
             return f
-        if self.odd_nd:
-            e = self.engine
-            e.eval_f(self._stage_in(u, 0), float(self.forcing_g(t)), self._ext(1).ptr, self._ext(2).ptr)
-            for k, part in ((1, f.impl), (2, f.expl)):
-                L.check(e.lib.sdc_odd_extract(e.ctx, self._ext(k).ptr, part.ptr, self.nvars[0], self.ndim), e.ctx)
+        if self.odd_nd:   # (compact fields in and out: the engine goes through the extension itself)
+            self.engine.eval_f(u.ptr, float(self.forcing_g(t)), f.impl.ptr, f.expl.ptr)
         elif self.view_offset:
             self.engine.eval_f(self._stage_in(u, 0), float(self.forcing_g(t)), self._ext(1).ptr, self._ext(2).ptr)
             n = self.nvars[0]
