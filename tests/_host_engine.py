@@ -57,6 +57,15 @@ class HostLib:
     def sdc_last_error(self, ctx):
         return b'host stand-in'
 
+    engine = None   # the HostEngine this handle belongs to (entry points that take a context)
+
+    def sdc_defer_f0(self, ctx):
+        """F[0] = f(U[0]) after U[0] was replaced (include/sdcmi.h: put off on the device, evaluated at once here)"""
+        e = self.engine
+        g0 = e.gvals[0] if e.gvals is not None else 0.0
+        e.eval_f(e.U[0].ctypes.data, g0, e.F[0, 0].ctypes.data, e.F[0, 1].ctypes.data if e.ncomp == 2 else None)
+        return 0
+
     # space transfer (include/sdcmi.h: sdc_transfer_apply[_batch]): the 1-D operator given as fixed-width rows, stored
     # entry-major ([width][n_out]), applied along every axis
     def sdc_transfer_apply_batch(self, stream, nfields, ndim, n_out, n_in, width, idx, w, src, dst):
@@ -140,6 +149,7 @@ class HostEngine:
         self.stencil, self.profile, self.gvals, self.times = {}, None, None, None
         self.tau_active = False
         self.lib = HostLib()
+        self.lib.engine = self
         self.ctx = None
         self.calls = []
 
@@ -230,6 +240,13 @@ class HostEngine:
 
     def set_lazy_predictor_residual(self, on):
         pass      # (nothing is put off on the host)
+
+    # what the product's own controllers use on their Level objects (Level.advance, run-to-run tokens)
+    def advance(self):
+        self.U[0][:] = self.UEND
+
+    def end_value_generation(self):
+        return 0      # (no token: every run loads its start value)
 
     def residual_deferred(self):
         return False
