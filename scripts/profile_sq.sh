@@ -4,7 +4,7 @@ set -u
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_sq
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="$GRAFT_REPO_ROOT/bench.py --n ${1:-1024} --steps 2 --warmup 1 --no-cpu-baseline --no-extras"
+ARGS="$GRAFT_REPO_ROOT/bench.py --n ${1:-1024} --steps 2 --warmup 1 --no-cpu-baseline --no-extras --details-file $OUT/bench_details.json"
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS --output-format csv -d $OUT/p1 -o run -- python3 $ARGS > $OUT/log1.txt 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM SQ_WAVES --output-format csv -d $OUT/p2 -o run -- python3 $ARGS > $OUT/log2.txt 2>&1
 python3 - <<PY
@@ -14,7 +14,7 @@ cnt = collections.defaultdict(int)
 for f in glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"]
-        if not any(s in k for s in ("k_spec_z", "k_ffty<1024, 8, 1>", "k_fftx_inv<1024, 8, true, false>")):
+        if not any(s in k for s in ("k_spec_z", "k_ffty<1024, 8, 1>", "k_fftx_inv<1024, 8, true, false")):
             continue
         res[k[:40]][row["Counter_Name"]] += float(row["Counter_Value"] or 0)
         if row["Counter_Name"] == "SQ_WAVE_CYCLES":
