@@ -1119,7 +1119,9 @@ void k_spec_z(SpecArgs a, unsigned nlines) {
 #pragma unroll
             for (int i = 0; i < E; ++i) {
                 const int o = j + i * P;
-                if (o / CH == ch) r[i] = ok ? rbuf[f * CH + (o % CH)] : cd{0.0, 0.0};
+                // (unconditional: a workgroup beyond the last line - there is none with one line per workgroup - would transform
+                // what the buffer holds and store nothing; a test per element costs two register moves and a branch each)
+                if (o / CH == ch) r[i] = rbuf[f * CH + (o % CH)];
             }
             __syncthreads();
         }
