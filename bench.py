@@ -487,8 +487,9 @@ def run_workload(args, world, rank, use_dist, with_stream_reference=True):
                                    + (', skip_residual_computation=all stages' if args.skip_residual else '')
                                    + (', residual of the predictor\'s state put off until somebody reads it (--lazy-predictor-residual)'
                                       if (_level.LAZY_PREDICTOR_RESIDUAL and args.restol < 0) else ''),
-                       'time_parallel': f'{world} time-slice(s), one per GPU, multi-step SDC '
-                                        f'({"Jacobi" if args.mssdc == "jacobi" else "Gauss-Seidel"})'
+                       'time_parallel': f'{world} time-slice(s), one per GPU, '
+                                        + ('two-level PFASST' if (args.workload == 'allencahn' and world > 1) else
+                                           f'multi-step SDC ({"Jacobi" if args.mssdc == "jacobi" else "Gauss-Seidel"})')
                                         + (f'; wire {args.wire}, mode: {getattr(args, "wire_mode", "default")}'
                                            + (f' (64^3 check vs serial emulation: {args.wire_check:.1e})'
                                               if getattr(args, 'wire_check', None) is not None else '') if world > 1 else '')},
