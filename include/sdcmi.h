@@ -149,6 +149,12 @@ int sdc_residual_deferred(sdc_ctx* ctx);
  * sdc_residual = post + wait(block). */
 int sdc_set_restol(sdc_ctx* ctx, double restol);
 int sdc_residual_post(sdc_ctx* ctx, double dt, int residual_type, unsigned long long* ticket);
+/* ... and, when the residual is reduced from F in real space anyway (node-by-node levels), the quadrature sums themselves -
+ * dt sum_j Q[m][j] f_j, what sdc_integrate returns - into integrals[0..M-1] in the SAME pass over F: a fine level's
+ * compute_residual is followed by the restriction's integrate() (core/base_transfer.py:120-127).  *wrote = 1 if they were
+ * written (0: the residual came from a cache or from Fourier space; call sdc_integrate). */
+int sdc_residual_post_integrals(sdc_ctx* ctx, double dt, int residual_type, double* const* integrals, int* wrote,
+                                unsigned long long* ticket);
 int sdc_residual_wait(sdc_ctx* ctx, unsigned long long ticket, int block, double* node_norms, double* residual, int* converged,
                       int* ready);
 /* Deferred node fields (default on).  The spectral-reuse sweep reads neither F[1..M] nor the M copies a 'spread'

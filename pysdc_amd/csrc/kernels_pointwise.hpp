@@ -73,6 +73,8 @@ __device__ inline void block_max_to_slots(unsigned long long* slots, const doubl
 }
 
 // out[mo] = u0 + sum_j cI[mo][j] F_impl[j] (+ cE[mo][j] F_expl[j]) (+ tau[mo]) (- U[mo+1], max-norm)
+// MODE 0: the sums are stored; 1: node norms of the residual only; 2: the norms AND the bare quadrature sums (out[mo]): the
+// residual of a fine level and the integrals its restriction asks for next (core/base_transfer.py:120-127) in one pass over F
 template <int M, int NCOMP, int MODE>
 __global__ __launch_bounds__(256) void k_quad(QuadArgs a) {
     const size_t n2 = a.N >> 1;
@@ -102,6 +104,7 @@ __global__ __launch_bounds__(256) void k_quad(QuadArgs a) {
                         acc.y += a.cI[mo][j] * fi[j].y;
                     }
                 }
+                if (MODE == 2) reinterpret_cast<double2*>(a.out[mo])[i] = acc;   // the quadrature alone: what integrate() returns
                 acc.x += u0.x;
                 acc.y += u0.y;
                 if (a.tau) {
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(256) void k_quad(QuadArgs a) {
             }
         }
     }
-    if (MODE == 1) {
+    if (MODE >= 1) {
         // one guarded atomic per value and WORKGROUP: on a small field all waves of the launch are resident at once, every one
         // of them finds the slot at zero and queues its atomic on the same address (128^3, M = 3: 16 384 waves x 3 atomics made a
         // 35 us pass take 200 us - config 5's coarse level)

@@ -113,7 +113,7 @@ template <int MODE>
 static int launch_quad(sdc_ctx* c, const QuadArgs& a, const char* name) {
     LaunchTimer lt(c, name);
     int grid = grid_for(c->N / 2, 256);
-    if (MODE == 1 && grid > 2048) grid = 2048;   // (norms: fewer, longer workgroups - fewer atomics on the M slots)
+    if (MODE >= 1 && grid > 2048) grid = 2048;   // (norms: fewer, longer workgroups - fewer atomics on the M slots)
 #define QCASE(MM)                                                                                   \
     case MM:                                                                                        \
         if (c->ncomp == 2) hipLaunchKernelGGL((k_quad<MM, 2, MODE>), dim3(grid), dim3(256), 0, c->stream, a); \
@@ -2709,7 +2709,12 @@ int sdc_set_restol(sdc_ctx* c, double restol) {
 }
 
 int sdc_residual_post(sdc_ctx* c, double dt, int type, unsigned long long* ticket) {
+    return sdc_residual_post_integrals(c, dt, type, nullptr, nullptr, ticket);
+}
+
+int sdc_residual_post_integrals(sdc_ctx* c, double dt, int type, double* const* integrals, int* wrote, unsigned long long* ticket) {
     if (!c || !ticket) return fail(c, SDC_ERR_PARAM, "null pointer");
+    if (wrote) *wrote = 0;
     if (!c->have_coeffs) return fail(c, SDC_ERR_STATE, "coefficients not set (sdc_set_coeffs)");
     if (type < 0 || type > 3)
         return fail(c, SDC_ERR_PARAM,
@@ -2778,8 +2783,17 @@ int sdc_residual_post(sdc_ctx* c, double dt, int type, unsigned long long* ticke
             q.norms = c->red;
             for (int m = 0; m < M; ++m)
                 for (int j = 0; j < M; ++j) q.cI[m][j] = q.cE[m][j] = dt * c->Q[m + 1][j + 1];
-            int rc = launch_quad<1>(c, q, "residual");
-            if (rc != SDC_OK) return rc;
+            bool with_integrals = integrals != nullptr;
+            for (int m = 0; m < M && with_integrals; ++m) with_integrals = integrals[m] != nullptr;
+            if (with_integrals) {   // the quadrature sums are wanted as fields too (sdc_integrate's result): same pass
+                for (int m = 0; m < M; ++m) q.out[m] = integrals[m];
+                int rc = launch_quad<2>(c, q, "residual_integrate");
+                if (rc != SDC_OK) return rc;
+                if (wrote) *wrote = 1;
+            } else {
+                int rc = launch_quad<1>(c, q, "residual");
+                if (rc != SDC_OK) return rc;
+            }
         }
     }
     if (type >= SDC_RES_FULL_REL) {

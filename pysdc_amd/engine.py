@@ -309,9 +309,11 @@ class SweepEngine:
         self._issued += 1        # (a ticket of the same ring)
         return res.value, norms
 
-    def residual_post(self, dt, residual_type='full_abs', restol=-1.0):
+    def residual_post(self, dt, residual_type='full_abs', restol=-1.0, integrals=None):
         """queue the residual of the current state and return a ResidualFuture at once (no synchronisation); restol is the
-        tolerance the device takes its `converged` flag against"""
+        tolerance the device takes its `converged` flag against.  integrals: M device addresses that receive the quadrature
+        sums dt Q F (integrate()'s result) in the same pass when the residual is reduced from F in real space;
+        `self.integrals_written` says whether they were"""
         if residual_type not in L.RES_TYPES:
             raise ParameterError(
                 f'residual_type = {residual_type} not implemented, choose '
@@ -322,7 +324,15 @@ class SweepEngine:
             self._restol_sent = restol
         self._retire_old_tickets()
         t = C.c_ulonglong()
-        self._chk(self.lib.sdc_residual_post(self.ctx, dt, L.RES_TYPES[residual_type], C.byref(t)))
+        self.integrals_written = False
+        if integrals is not None:
+            wrote = C.c_int()
+            dst = (C.c_void_p * self.M)(*[C.c_void_p(int(p)) for p in integrals])
+            self._chk(self.lib.sdc_residual_post_integrals(self.ctx, dt, L.RES_TYPES[residual_type], dst, C.byref(wrote),
+                                                           C.byref(t)))
+            self.integrals_written = bool(wrote.value)
+        else:
+            self._chk(self.lib.sdc_residual_post(self.ctx, dt, L.RES_TYPES[residual_type], C.byref(t)))
         ticket = self._issued = t.value
 
         def fetch(block, self=self, ticket=ticket):

@@ -175,6 +175,7 @@ class DeviceBacked:
         self._uend_valid = False
         self._uend_view = None
         self._res_cache = None
+        self.integrals_wanted = False   # set by a BaseTransfer whose fine level this is: compute_residual brings integrate() along
 
     def settle_residual(self):
         """a residual that was put off (LevelStatus: evaluated when read) is evaluated NOW: the state it belongs to - u[0] in

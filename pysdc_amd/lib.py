@@ -49,6 +49,8 @@ PROTOTYPES = {
     'sdc_set_lazy_predictor_residual': (C.c_int, [_vp, C.c_int]),
     'sdc_set_restol': (C.c_int, [_vp, C.c_double]),
     'sdc_residual_post': (C.c_int, [_vp, C.c_double, C.c_int, C.POINTER(C.c_ulonglong)]),
+    'sdc_residual_post_integrals': (C.c_int, [_vp, C.c_double, C.c_int, C.POINTER(_vp), C.POINTER(C.c_int),
+                                              C.POINTER(C.c_ulonglong)]),
     'sdc_residual_wait': (C.c_int, [_vp, C.c_ulonglong, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                     C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     'sdc_residual_deferred': (C.c_int, [_vp]),

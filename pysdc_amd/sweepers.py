@@ -245,8 +245,13 @@ class Sweeper:
                 # queued, not waited for (include/sdcmi.h: sdc_residual_post): the device finishes the number and the test
                 # against restol and leaves both in pinned host memory; whoever reads L.status.residual, L.residual or the
                 # convergence flag collects them there - a run with a fixed number of sweeps never waits
-                fut = D.engine.residual_post(L.dt, rt, restol=L.params.restol)
-                D._res_cache = ((rt, L.dt), fut)
+                me = None
+                if getattr(D, 'integrals_wanted', False) and not D._view_offset() and stage in ('IT_FINE', 'IT_DOWN', 'IT_UP'):
+                    # a coarser level follows: its FAS correction starts from integrate() of THIS state (BaseTransfer.restrict)
+                    me = self._integral_fields()
+                fut = D.engine.residual_post(L.dt, rt, restol=L.params.restol,
+                                             integrals=None if me is None else [x.ptr for x in me])
+                D._res_cache = ((rt, L.dt), fut, me if (me is not None and D.engine.integrals_written) else None)
                 D.publish_residual_future(fut)
                 L.status.residual = fut
             else:
@@ -273,15 +278,25 @@ class Sweeper:
     def update_nodes(self):
         raise NotImplementedError('ERROR: sweeper has to implement update_nodes(self)')
 
-    def _integrate_fused(self):
-        L = self.level
+    def _integral_fields(self):
+        """one buffer, the M integrals one behind the other (a transfer class can then restrict them together)"""
         from pysdc_amd.hip_mesh import hip_mesh
 
-        # one buffer, the M integrals one behind the other (a transfer class can then restrict them together)
         D = self._dev()
         M, size = self.coll.num_nodes, D.engine.N
         buf = hip_mesh(((M * size,), None, np.dtype('float64')), val=None)
-        me = [hip_mesh.view(buf.ptr + 8 * k * size, D._field_shape(), keep=buf) for k in range(M)]
+        return [hip_mesh.view(buf.ptr + 8 * k * size, D._field_shape(), keep=buf) for k in range(M)]
+
+    def _integrate_fused(self):
+        L = self.level
+        D = self._dev()
+        # the residual of this very state brought the quadrature sums along (compute_residual on a level whose restriction
+        # asks for them next: same pass over F) - handed out once, the caller owns them like any result of integrate()
+        cache = D._res_cache
+        if cache is not None and len(cache) > 2 and cache[2] is not None and cache[0][1] == L.dt:
+            D._res_cache = (cache[0], cache[1], None)
+            return cache[2]
+        me = self._integral_fields()
         D.engine.integrate(L.dt, [x.ptr for x in me])
         return me
 

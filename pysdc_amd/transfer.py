@@ -41,6 +41,10 @@ class BaseTransfer:
         self.space_transfer = space_transfer_class(
             fine_prob=self.fine.prob, coarse_prob=self.coarse.prob, params=space_transfer_params
         )
+        if hasattr(self.fine, 'integrals_wanted'):
+            # restrict() starts from integrate() of the fine level's state (core/base_transfer.py:120-127): its residual, which
+            # the controller asks for just before, can bring those sums along in the same pass over F
+            self.fine.integrals_wanted = True
 
     @staticmethod
     def get_transfer_matrix_Q(f_nodes, c_nodes):

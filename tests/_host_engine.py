@@ -258,11 +258,17 @@ class HostEngine:
         norms = O.compute_residual(L)
         return L.status_residual, np.array(norms)
 
-    def residual_post(self, dt, residual_type='full_abs', restol=-1.0):
-        """the queued form of the device engine (SweepEngine.residual_post): on the host the number is there at once"""
+    integrals_written = False
+
+    def residual_post(self, dt, residual_type='full_abs', restol=-1.0, integrals=None):
+        """the queued form of the device engine (SweepEngine.residual_post): on the host the number is there at once; the
+        quadrature sums are written too when asked for"""
         from pysdc_amd.engine import ResidualFuture
 
         res, norms = self.residual(dt, residual_type)
+        self.integrals_written = integrals is not None
+        if integrals is not None:
+            self.integrate(dt, integrals)
         return ResidualFuture.ready(res, norms, restol)
 
     def end_point(self, dt, do_coll_update):
