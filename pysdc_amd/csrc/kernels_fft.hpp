@@ -30,6 +30,15 @@ __device__ __forceinline__ double react_value(double v, int kind, double p0, dou
     return p0 * v * (1.0 - v) * (1.0 - 2.0 * v) - p1 * v * (1.0 - v);
 }
 
+// Terms added to the field a forward transform reads, on the way in: in[0] + sum_k c[k] x[k] - the right-hand side of one node
+// of the reference's loop (generic_implicit.py:87-89 / imex_1st_order.py:92-94: gathered part + dt QI[m][j] f_j (+ dt QE[m][j]
+// f_j.expl) of the nodes before it) without a pass of its own.  n = 0: nothing.
+struct LinTerms {
+    const double* x[2 * MAXM];
+    double c[2 * MAXM];
+    int n;
+};
+
 // 1-D problems: promote the real line to complex / take the real part back
 __global__ void k_promote(FieldPtrs p, cd* W, size_t N) {
     const int f = blockIdx.y;
@@ -47,7 +56,8 @@ __global__ void k_realpart(FieldPtrs p, const cd* W, size_t N) {
 template <int N, int T>
 __global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_fwd(FieldPtrs p, cd* __restrict__ W, size_t fstride,
                                                                       int rest, const cd* __restrict__ tw,
-                                                                      ReactEpi epi = ReactEpi{nullptr, 0, 0, 0, 0.0, 0.0, {}}) {
+                                                                      ReactEpi epi = ReactEpi{nullptr, 0, 0, 0, 0.0, 0.0, {}},
+                                                                      LinTerms lin = LinTerms{{}, {}, 0}) {
     constexpr int E = fft_elems(N), P = N / E;
     using LAY = LayStrided<N, T>;
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -60,6 +70,18 @@ __global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_fwd(FieldPtr
 #pragma unroll
     for (int i = 0; i < E; ++i)
         r[i] = ok ? *reinterpret_cast<const cd*>(in + (size_t)(j + i * P) * rest + 2 * (size_t)c) : cd{0.0, 0.0};
+    if (lin.n > 0 && blockIdx.y == 0 && ok) {   // (same accumulation order as k_lincomb: base, then term by term)
+        for (int k = 0; k < lin.n; ++k) {
+            const double* __restrict__ xk = lin.x[k];
+            const double ck = lin.c[k];
+#pragma unroll
+            for (int i = 0; i < E; ++i) {
+                const cd v = *reinterpret_cast<const cd*>(xk + (size_t)(j + i * P) * rest + 2 * (size_t)c);
+                r[i].x += ck * v.x;
+                r[i].y += ck * v.y;
+            }
+        }
+    }
     if (double* const eo = epi.target((int)blockIdx.y); eo && ok) {  // reaction term of the field that is being read
 #pragma unroll
         for (int i = 0; i < E; ++i)

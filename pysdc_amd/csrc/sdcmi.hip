@@ -21,6 +21,9 @@
 #ifndef SDC_SPECZ_PAIRS
 #define SDC_SPECZ_PAIRS 1
 #endif
+#ifndef SDC_FUSE_NODE_RHS
+#define SDC_FUSE_NODE_RHS 1   // node-by-node sweeps on symbol operators: the terms of earlier nodes ride on the forward pass
+#endif
 #ifndef SDC_SPEC_GRID
 #define SDC_SPEC_GRID 4096
 #endif
@@ -295,7 +298,8 @@ struct ReactReq {
     double* outs[MAXM] = {};
 };
 template <int N>
-static int fft_pipeline_n(sdc_ctx* c, int nf, const FieldPtrs& p, ZArgs& z, const ReactReq& rq = ReactReq()) {
+static int fft_pipeline_n(sdc_ctx* c, int nf, const FieldPtrs& p, ZArgs& z, const ReactReq& rq = ReactReq(),
+                          const LinTerms* lin = nullptr) {
     const ReactEpi none{nullptr, 0, 0, 0, 0.0, 0.0, {}};
     ReactEpi epi{rq.out, rq.field, c->react_kind, c->react_nu, c->react_p0, c->react_p1, {}};
     for (int f = 0; f < MAXM; ++f) epi.outs[f] = rq.outs[f];
@@ -323,7 +327,7 @@ static int fft_pipeline_n(sdc_ctx* c, int nf, const FieldPtrs& p, ZArgs& z, cons
         {
             LaunchTimer lt(c, pname("fft_x_fwd", nfi));
             hipLaunchKernelGGL((k_fftx_fwd<N, T>), dim3(tiles, nfi), dim3(P * T), lds_str, c->stream, p, c->W, c->Nc,
-                               rest, c->tw, (can && rq.where == 1) ? epi : none);
+                               rest, c->tw, (can && rq.where == 1) ? epi : none, lin ? *lin : LinTerms{{}, {}, 0});
         }
         if (c->ndim == 3) {
             LaunchTimer lt(c, pname("fft_y_fwd", nfi));
@@ -850,7 +854,8 @@ static int symbol_norm(sdc_ctx* c, const cd* src, unsigned long long* slot) {
 }
 
 // (I - alpha_f A) out_f = in_f + sum_{j<f} (cI[f][j] A + cE[f][j] B) out_j for f = 0..nf-1
-static int fft_pipeline(sdc_ctx* c, int nf, const FieldPtrs& p, ZArgs& z, const ReactReq& rq = ReactReq()) {
+static int fft_pipeline(sdc_ctx* c, int nf, const FieldPtrs& p, ZArgs& z, const ReactReq& rq = ReactReq(),
+                        const LinTerms* lin = nullptr) {
     if (!c->have_stencil[0]) return fail(c, SDC_ERR_STATE, "implicit operator not set (sdc_set_stencil)");
     if (!fourier_ok(c))
         return fail(c, SDC_ERR_UNSUPPORTED,
@@ -860,17 +865,17 @@ static int fft_pipeline(sdc_ctx* c, int nf, const FieldPtrs& p, ZArgs& z, const 
         if (rw != SDC_OK) return rw;
     }
     switch (c->n) {
-        case 2: return fft_pipeline_n<2>(c, nf, p, z, rq);
-        case 4: return fft_pipeline_n<4>(c, nf, p, z, rq);
-        case 8: return fft_pipeline_n<8>(c, nf, p, z, rq);
-        case 16: return fft_pipeline_n<16>(c, nf, p, z, rq);
-        case 32: return fft_pipeline_n<32>(c, nf, p, z, rq);
-        case 64: return fft_pipeline_n<64>(c, nf, p, z, rq);
-        case 128: return fft_pipeline_n<128>(c, nf, p, z, rq);
-        case 256: return fft_pipeline_n<256>(c, nf, p, z, rq);
-        case 512: return fft_pipeline_n<512>(c, nf, p, z, rq);
-        case 1024: return fft_pipeline_n<1024>(c, nf, p, z, rq);
-        case 2048: return fft_pipeline_n<2048>(c, nf, p, z, rq);
+        case 2: return fft_pipeline_n<2>(c, nf, p, z, rq, lin);
+        case 4: return fft_pipeline_n<4>(c, nf, p, z, rq, lin);
+        case 8: return fft_pipeline_n<8>(c, nf, p, z, rq, lin);
+        case 16: return fft_pipeline_n<16>(c, nf, p, z, rq, lin);
+        case 32: return fft_pipeline_n<32>(c, nf, p, z, rq, lin);
+        case 64: return fft_pipeline_n<64>(c, nf, p, z, rq, lin);
+        case 128: return fft_pipeline_n<128>(c, nf, p, z, rq, lin);
+        case 256: return fft_pipeline_n<256>(c, nf, p, z, rq, lin);
+        case 512: return fft_pipeline_n<512>(c, nf, p, z, rq, lin);
+        case 1024: return fft_pipeline_n<1024>(c, nf, p, z, rq, lin);
+        case 2048: return fft_pipeline_n<2048>(c, nf, p, z, rq, lin);
     }
     return fail(c, SDC_ERR_UNSUPPORTED, "n = %d", c->n);
 }
@@ -1880,6 +1885,13 @@ static int sweep_nodewise(sdc_ctx* c, double dt, bool keep_guess = false) {
     for (int m = 0; m < M; ++m) {
         double* um = c->U + (size_t)(m + 1) * c->N;
         double* rhs = keep_guess ? G + (size_t)m * c->N : um;
+        const double alpha = dt * c->QI[m + 1][m + 1];
+        // operator given by its symbol, direct solve: solve and implicit evaluation share one forward transform - and the
+        // terms of the nodes before this one are added by that transform's first pass as it reads the gathered field
+        const bool shared_fwd = c->spectral_op && !keep_guess && c->solver_kind == 0 && c->M >= 2;  // (two work spectra needed)
+        const bool rhs_on_the_way = shared_fwd && c->ndim >= 2 && SDC_FUSE_NODE_RHS;
+        LinTerms lin;
+        memset(&lin, 0, sizeof lin);
         if (m > 0) {
             LinArgs la;
             memset(&la, 0, sizeof la);
@@ -1897,14 +1909,19 @@ static int sweep_nodewise(sdc_ctx* c, double dt, bool keep_guess = false) {
                     la.c[la.nterms++] = ce;
                 }
             }
-            if (la.nterms > 0) {
+            if (la.nterms > 0 && rhs_on_the_way) {
+                for (int k = 0; k < la.nterms; ++k) {
+                    lin.x[k] = la.x[k];
+                    lin.c[k] = la.c[k];
+                }
+                lin.n = la.nterms;
+            } else if (la.nterms > 0) {
                 LaunchTimer lt(c, "node_rhs");
                 hipLaunchKernelGGL(k_lincomb, dim3(grid_for(c->N / 2, 256)), dim3(256), 0, c->stream, la);
                 HIPCHK(c, hipGetLastError());
             }
         }
-        const double alpha = dt * c->QI[m + 1][m + 1];
-        if (c->spectral_op && !keep_guess && c->solver_kind == 0 && c->M >= 2) {  // (two work spectra needed)
+        if (shared_fwd) {
             // operator given by its symbol: the solve and the evaluation of the implicit part at the new value share
             // one forward transform (u_hat and symbol * u_hat leave the spectral pass together)
             FieldPtrs p2;
@@ -1923,7 +1940,7 @@ static int sweep_nodewise(sdc_ctx* c, double dt, bool keep_guess = false) {
                 rq2.where = 2;
                 rq2.out = c->F + ((size_t)(m + 1) * c->ncomp + 1) * c->N;
             }
-            rc = fft_pipeline(c, 2, p2, z2, rq2);
+            rc = fft_pipeline(c, 2, p2, z2, rq2, lin.n ? &lin : nullptr);
             if (rc != SDC_OK) return rc;
             if (imex && rq2.where == 0) {
                 LaunchTimer lt(c, "reaction");
