@@ -931,8 +931,21 @@ def main():
             # vectors travel through the C-ABI communicator (RCCL or the shared-memory wire)
             dist.init_process_group('gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
             preflight(torch, dist, rank, world, args.wire)
-            args.wire_mode, args.wire_check = (validate_wire(args, torch, dist, rank, world)
-                                               if world > 1 and not args.no_wire_check else ('default (not checked)', None))
+            args.wire_mode, args.wire_check = 'default (not checked)', None
+            if world > 1 and not args.no_wire_check:
+                def stuck():   # a hand-over that never completes on the small grid: say so in seconds, not after the job's limit
+                    if rank == 0:
+                        print(json.dumps({'error': f'the {args.wire} wire did not complete a 64^3 multi-rank run within 300 s '
+                                                   '(validate_wire)', 'n_gpus': world}), flush=True)
+                    os._exit(4)
+
+                guard = threading.Timer(300.0, stuck)
+                guard.daemon = True
+                guard.start()
+                try:
+                    args.wire_mode, args.wire_check = validate_wire(args, torch, dist, rank, world)
+                finally:
+                    guard.cancel()
         except Exception as e:  # noqa: BLE001  fail fast and loudly: no hang, no partial line
             print(json.dumps({'error': f'rank {rank}: preflight of the {args.wire} wire failed: {e!r}'[:1500]}), flush=True)
             raise SystemExit(3)
