@@ -3245,6 +3245,31 @@ int sdc_transfer_apply_batch_acc(void* stream, int nfields, int ndim, int n_out,
         }
         scratch_len = need;
     }
+#ifndef SDC_XFER_FUSED3
+#define SDC_XFER_FUSED3 1
+#endif
+    if (SDC_XFER_FUSED3 && ndim == 3 && n_out < n_in && width <= 3 && !accumulate &&
+        (size_t)nfields * n_out * n_out * n_out < 0xffffffffull) {
+        // coarsening with a narrow table (rorder 2: three entries per row): all three axes in one launch, same bits
+        XferArgs a;
+        memset(&a, 0, sizeof a);
+        a.idx = idx;
+        a.w = w;
+        a.W = width;
+        a.n_in = n_in;
+        a.n_out = n_out;
+        a.in = in;
+        a.out = out;
+        const size_t total = (size_t)nfields * n_out * n_out * n_out;
+        const dim3 g(grid_for(total, 256));
+        switch (width) {
+        case 1: hipLaunchKernelGGL((k_xfer_fused3<1>), g, dim3(256), 0, (hipStream_t)stream, a, (unsigned)nfields); break;
+        case 2: hipLaunchKernelGGL((k_xfer_fused3<2>), g, dim3(256), 0, (hipStream_t)stream, a, (unsigned)nfields); break;
+        default: hipLaunchKernelGGL((k_xfer_fused3<3>), g, dim3(256), 0, (hipStream_t)stream, a, (unsigned)nfields); break;
+        }
+        HIPCHK(nullptr, hipGetLastError());
+        return SDC_OK;
+    }
     int dims[3] = {n_in, n_in, n_in};
     const double* src = in;
     for (int pass = 0; pass < ndim; ++pass) {
