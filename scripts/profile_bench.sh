@@ -10,7 +10,7 @@ TAG=${3:-}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_n$N$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="$GRAFT_REPO_ROOT/bench.py --n $N --steps 3 --warmup 1 --no-cpu-baseline --no-extras --details-file $OUT/bench_details.json $EXTRA"
+ARGS="$GRAFT_REPO_ROOT/bench.py --n $N --steps 3 --warmup 1 --no-cpu-baseline --no-extras --details-file $OUT/bench_details_$$.json $EXTRA"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o run -- python3 $ARGS > $OUT/bench_stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o run -- python3 $ARGS > $OUT/bench_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o run -- python3 $ARGS > $OUT/bench_write.log 2>&1
