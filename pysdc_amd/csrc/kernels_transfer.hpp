@@ -124,50 +124,46 @@ __global__ __launch_bounds__(256) void k_xfer_axis_rows(XferArgs a, unsigned nq)
 // instead of two intermediate fields being written and read: 256^3 -> 128^3, four fields: 343 -> ~120 us.
 template <int W>
 __global__ __launch_bounds__(256) void k_xfer_fused3(XferArgs a, unsigned nfields) {
+    // grid: x = segments of the contiguous output axis, y = j, z = i + n_out * field: no integer divisions, and the table
+    // entries of i and j are uniform over the workgroup (scalar loads)
     const unsigned n_out = (unsigned)a.n_out, n_in = (unsigned)a.n_in;
-    const size_t per_field = (size_t)n_out * n_out * n_out, total = per_field * nfields;
-    const size_t in_field = (size_t)n_in * n_in * n_in;
-    for (size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x; p < total; p += (size_t)gridDim.x * blockDim.x) {
-        const unsigned o = (unsigned)(p / per_field);
-        unsigned rem = (unsigned)(p - (size_t)o * per_field);
-        const unsigned k = rem % n_out;
-        rem /= n_out;
-        const unsigned j = rem % n_out, i = rem / n_out;
-        const double* __restrict__ src = a.in + (size_t)o * in_field;
-        double wk[W], wj[W];
-        unsigned ik[W], ij[W];
+    const unsigned k = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+    const unsigned o = blockIdx.z / n_out, i = blockIdx.z - o * n_out;
+    (void)nfields;
+    if (k >= n_out) return;
+    const double* __restrict__ src = a.in + (size_t)o * n_in * n_in * n_in;
+    double wk[W];
+    unsigned ik[W];
 #pragma unroll
-        for (int c = 0; c < W; ++c) {
-            wk[c] = a.w[(size_t)c * n_out + k];
-            ik[c] = (unsigned)a.idx[(size_t)c * n_out + k];
-            wj[c] = a.w[(size_t)c * n_out + j];
-            ij[c] = (unsigned)a.idx[(size_t)c * n_out + j];
-        }
-        double acc0 = 0.0;
-#pragma unroll
-        for (int aa = 0; aa < W; ++aa) {
-            const double wi = a.w[(size_t)aa * n_out + i];
-            if (wi != 0.0) {
-                const double* __restrict__ plane = src + (size_t)a.idx[(size_t)aa * n_out + i] * n_in * n_in;
-                double acc1 = 0.0;
-#pragma unroll
-                for (int b = 0; b < W; ++b) {
-                    if (wj[b] != 0.0) {
-                        const double* __restrict__ row = plane + (size_t)ij[b] * n_in;
-                        double acc2 = 0.0;
-#pragma unroll
-                        for (int c = 0; c < W; ++c) {
-                            const double v = row[ik[c]];
-                            acc2 = wk[c] != 0.0 ? acc2 + wk[c] * v : acc2;
-                        }
-                        acc1 += wj[b] * acc2;
-                    }
-                }
-                acc0 += wi * acc1;
-            }
-        }
-        a.out[p] = acc0;
+    for (int c = 0; c < W; ++c) {
+        wk[c] = a.w[(size_t)c * n_out + k];
+        ik[c] = (unsigned)a.idx[(size_t)c * n_out + k];
     }
+    double acc0 = 0.0;
+#pragma unroll
+    for (int aa = 0; aa < W; ++aa) {
+        const double wi = a.w[(size_t)aa * n_out + i];
+        if (wi != 0.0) {
+            const double* __restrict__ plane = src + (size_t)a.idx[(size_t)aa * n_out + i] * n_in * n_in;
+            double acc1 = 0.0;
+#pragma unroll
+            for (int b = 0; b < W; ++b) {
+                const double wj = a.w[(size_t)b * n_out + j];
+                if (wj != 0.0) {
+                    const double* __restrict__ row = plane + (size_t)a.idx[(size_t)b * n_out + j] * n_in;
+                    double acc2 = 0.0;
+#pragma unroll
+                    for (int c = 0; c < W; ++c) {
+                        const double v = row[ik[c]];
+                        acc2 = wk[c] != 0.0 ? acc2 + wk[c] * v : acc2;
+                    }
+                    acc1 += wj * acc2;
+                }
+            }
+            acc0 += wi * acc1;
+        }
+    }
+    a.out[(((size_t)o * n_out + i) * n_out + j) * n_out + k] = acc0;
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -3248,8 +3248,8 @@ int sdc_transfer_apply_batch_acc(void* stream, int nfields, int ndim, int n_out,
 #ifndef SDC_XFER_FUSED3
 #define SDC_XFER_FUSED3 1
 #endif
-    if (SDC_XFER_FUSED3 && ndim == 3 && n_out < n_in && width <= 3 && !accumulate &&
-        (size_t)nfields * n_out * n_out * n_out < 0xffffffffull) {
+    if (SDC_XFER_FUSED3 && ndim == 3 && n_out < n_in && width <= 3 && !accumulate && n_out <= 65535 &&
+        (size_t)n_out * nfields <= 65535) {
         // coarsening with a narrow table (rorder 2: three entries per row): all three axes in one launch, same bits
         XferArgs a;
         memset(&a, 0, sizeof a);
@@ -3260,12 +3260,12 @@ int sdc_transfer_apply_batch_acc(void* stream, int nfields, int ndim, int n_out,
         a.n_out = n_out;
         a.in = in;
         a.out = out;
-        const size_t total = (size_t)nfields * n_out * n_out * n_out;
-        const dim3 g(grid_for(total, 256));
+        const unsigned bx = n_out >= 256 ? 256u : (unsigned)((n_out + 63) / 64 * 64);
+        const dim3 g((unsigned)((n_out + bx - 1) / bx), (unsigned)n_out, (unsigned)n_out * (unsigned)nfields), blk(bx);
         switch (width) {
-        case 1: hipLaunchKernelGGL((k_xfer_fused3<1>), g, dim3(256), 0, (hipStream_t)stream, a, (unsigned)nfields); break;
-        case 2: hipLaunchKernelGGL((k_xfer_fused3<2>), g, dim3(256), 0, (hipStream_t)stream, a, (unsigned)nfields); break;
-        default: hipLaunchKernelGGL((k_xfer_fused3<3>), g, dim3(256), 0, (hipStream_t)stream, a, (unsigned)nfields); break;
+        case 1: hipLaunchKernelGGL((k_xfer_fused3<1>), g, blk, 0, (hipStream_t)stream, a, (unsigned)nfields); break;
+        case 2: hipLaunchKernelGGL((k_xfer_fused3<2>), g, blk, 0, (hipStream_t)stream, a, (unsigned)nfields); break;
+        default: hipLaunchKernelGGL((k_xfer_fused3<3>), g, blk, 0, (hipStream_t)stream, a, (unsigned)nfields); break;
         }
         HIPCHK(nullptr, hipGetLastError());
         return SDC_OK;
