@@ -581,7 +581,7 @@ def compact_sub(r):
     return _r(c, 4)
 
 
-def compact_line(out, subs=None, cpu=None, details_path=None):
+def compact_line(out, subs=None, cpu=None, details_path=None, sustained=None):
     """THE line the driver parses: the contract's keys, `roofline` and `cpu_baseline`, the sweep's fraction, one short list
     of sub-values.  Everything else - per-kernel tables, per-step iteration lists, long descriptions, the sub-records'
     own rooflines - goes to the side file.  Kept far below the 8 KB of standard output the driver retains
@@ -611,6 +611,18 @@ def compact_line(out, subs=None, cpu=None, details_path=None):
                 line['value_eager_fields'] = r['value']
             if 'error' not in r and r['title'].startswith('heat 1024^3 lazy'):
                 line['value_lazy_predictor_residual'] = r['value']
+    if sustained is not None:
+        # the same configuration re-timed at the end of the process (after the sub-records): what the part sustains
+        if 'error' in sustained:
+            line['value_sustained'] = None
+            line['sustained'] = {'error': sustained['error'][:120]}
+        else:
+            rf, rsw = sustained.get('roofline') or {}, sustained.get('roofline_sweep') or {}
+            line['value_sustained'] = sustained['value']
+            line['sustained'] = {'steps': sustained['steps'], 'ms_per_step': sustained['ms_per_step'],
+                                 'roofline': {'kernel': rf.get('kernel'), 'frac': rf.get('frac'),
+                                              'ms_per_launch': rf.get('ms_per_launch')},
+                                 'sweep_frac': rsw.get('frac'), 'ms_per_sweep': rsw.get('ms_per_sweep')}
     if out.get('per_rank'):
         pr = out['per_rank']
         line['per_rank'] = {'seconds': [p['seconds'] for p in pr],
@@ -970,16 +982,28 @@ def main():
                                  big_n=args.cpu_big_n, mid_n=args.cpu_mid_n)
             except Exception as e:  # pragma: no cover
                 cpu = {'error': repr(e)[:200]}
+        sustained = None
         if headline and not args.no_extras and args.n is None:
             subs = extras(args)
+            # the headline configuration once more at the END of the process, >= 20 timed steps: clocks under sustained load
+            # (the first seconds of a process run ~7 % faster than everything after them) - `value_sustained`
+            import gc
+
+            gc.collect()
+            torch.cuda.empty_cache()
+            try:
+                a2 = argparse.Namespace(**{**vars(args), 'steps': max(20, args.steps), 'warmup': 2})
+                sustained = run_workload(a2, 1, 0, False, with_stream_reference=False)
+            except Exception as e:  # noqa: BLE001  (never takes the line down)
+                sustained = {'error': repr(e)[:200]}
         if cb is not None:
             try:
                 cpu, cpu_detail = cb.finish()
             except Exception as e:  # pragma: no cover
                 cpu = {'error': repr(e)[:200]}
         details = write_details(args.details_file, {'headline': out, 'sub_records': subs, 'cpu_baseline': cpu,
-                                                    'cpu_samples': cpu_detail, 'argv': sys.argv[1:]})
-        line = json.dumps(compact_line(out, subs, cpu, details), allow_nan=False)
+                                                    'cpu_samples': cpu_detail, 'sustained': sustained, 'argv': sys.argv[1:]})
+        line = json.dumps(compact_line(out, subs, cpu, details, sustained), allow_nan=False)
         assert len(line) < 6000, len(line)
         sys.stderr.flush()
         print(line, flush=True)

@@ -157,6 +157,13 @@ int sdc_residual_post_integrals(sdc_ctx* ctx, double dt, int residual_type, doub
                                 unsigned long long* ticket);
 int sdc_residual_wait(sdc_ctx* ctx, unsigned long long ticket, int block, double* node_norms, double* residual, int* converged,
                       int* ready);
+/* Where the residual of the current state would come from if it were asked for now (with this dt): 0 = node norms a sweep
+ * already reduced, 1 = the closed form of a spread predictor's state, 2 = reduced from the spectrum of the cached iterate,
+ * 3 = one pass over u[0], U[1..M], F[1..M] in real space - the only route on which sdc_residual_post_integrals writes the
+ * quadrature sums (a caller allocates their M fields only then).  Negative: error code. */
+int sdc_residual_route(sdc_ctx* ctx, double dt);
+/* the last ticket handed out by sdc_residual_post / sdc_residual (0: none yet) */
+unsigned long long sdc_residual_last_ticket(sdc_ctx* ctx);
 /* Deferred node fields (default on).  The spectral-reuse sweep reads neither F[1..M] nor the M copies a 'spread'
  * predictor makes (core/sweeper.py:140-146): the engine therefore leaves them unwritten until somebody needs
  * them.  sdc_slot_ptr / sdc_upload / sdc_download / sdc_integrate / sdc_end_point / sdc_residual and the
@@ -183,6 +190,19 @@ int sdc_set_keep_residual_fields(sdc_ctx* ctx, int on);
  * sdc_end_point without collocation update is then free); sdc_stream_wait_uend(ctx, stream) makes another HIP
  * stream (the one the message is posted on) wait until UEND is complete - and for nothing queued after it. */
 int sdc_set_early_end_point(sdc_ctx* ctx, int on);
+/* Time-parallel levels that sweep in Fourier space with spectra on the wire (sdc_comm_set_format): how the engine deals
+ * with a u[0] that is replaced between sweeps (controller_MPI.py:218-233, :574-583).
+ *  trail_sources (default 5, 0 = off): iterates are not stored; a sweep recomputes its iterate from the start values the slice
+ *    has had since its spread predictor (the sweep is linear: u^k = sum_i C_i(lambda) u0_i per Fourier mode with real node
+ *    multipliers), reads those <= trail_sources spectra and writes only the residual lines and the last node's spectrum.
+ *    One more start value than that, or sdc_set_virtual_sweeps' limit, and the iterate is stored after all.
+ *  defer_last_pass (default 1): the last inverse pass of a sweep's residual waits until the new start value has arrived;
+ *    ONE pass over the residual lines then reduces the node norms before AND after the receive (they differ by one field, the
+ *    difference of the two start values).  Residuals posted meanwhile (sdc_residual_post) are published by that pass;
+ *    a blocking wait, the next sweep or anything else that needs the work spectra runs it at once.
+ *  split_send (default 0): a sweep first writes the last node's spectrum by a small launch of its own, so that the message
+ *    leaves before the passes put off for the previous iterate and the sweep's own residual passes run. */
+int sdc_set_timeslice_options(sdc_ctx* ctx, int trail_sources, int defer_last_pass, int split_send);
 int sdc_stream_wait_uend(sdc_ctx* ctx, void* other_stream);
 int sdc_replace_u0(sdc_ctx* ctx, const double* src);
 /* Start and end values as SPECTRA.  Between levels that sweep in Fourier space (periodic finite differences, exact solve,
@@ -346,7 +366,9 @@ int sdc_set_solver(sdc_ctx* ctx, int kind, double rtol, int maxiter);
  * give the 1-D rows.  From then on sdc_eval_f / sdc_solve of this context work on COMPACT fields of n_interior^ndim values
  * (the start of a slab field is such a field): eval_f applies the operator, sdc_solve runs the configured Krylov solver
  * (sdc_set_solver: CG / GMRES with the user's tolerance, counted) or, for 'direct', GMRES to round-off in place of the
- * reference's sparse LU.  Sweeps on such levels run node by node from the host (no fused sweep). */
+ * reference's sparse LU.  sdc_sweep on such levels runs the reference's node loop inside the engine (gather for all nodes,
+ * then per node right-hand side, Krylov solve from the old node value, operator application).  Buffers handed to
+ * sdc_eval_f / sdc_solve on such a context need n_interior^ndim doubles (f_expl of a forced level included). */
 int sdc_set_banded_operator(sdc_ctx* ctx, int n_interior, int width, const int* cols, const double* weights);
 
 /* ---- space transfer between two grids --------------------------------------------------------------------

@@ -49,7 +49,9 @@ def check_convergence(S):
         # pinned host memory (engine.ResidualFuture.converged; include/sdcmi.h: sdc_residual_post) - same comparison, same bits
         peek = getattr(L.status, 'peek_residual', None)
         r = peek() if peek is not None else L.status.residual
-        res_converged = bool(r.converged) if getattr(r, 'queued', False) else bool(r <= L.params.restol)
+        # (the flag was taken against the tolerance the residual was posted with: a tolerance changed since is compared here)
+        on_device = getattr(r, 'queued', False) and getattr(r, 'restol', None) == L.params.restol
+        res_converged = bool(r.converged) if on_device else bool(float(r) <= L.params.restol)
     converged = (iter_converged or res_converged or bool(S.status.force_done)) and not S.status.force_continue
     return bool(converged)
 
@@ -546,6 +548,13 @@ class controller_dist(_ControllerBase):
             # update the node norms from the residual lines the sweep left in its work spectra; everybody else keeps the
             # residual FIELDS and updates them in real space (sdc_replace_u0)
             eng.set_keep_residual_fields(not spectra)
+            if spectra and hasattr(eng, 'set_timeslice_options'):
+                # iterates recomputed from the start values received so far instead of stored, the last inverse pass of a
+                # residual put off until the new start value is there (one pass then yields the norms before and after the
+                # receive), optionally the last node's spectrum first (include/sdcmi.h: sdc_set_timeslice_options)
+                eng.set_timeslice_options(int(os.environ.get('PYSDC_AMD_TRAIL', '5')),
+                                          os.environ.get('PYSDC_AMD_DEFER_X', '1') != '0',
+                                          os.environ.get('PYSDC_AMD_SPLIT_SEND', '0') != '0')
             # the end value (its spectrum) is produced early so that it can be sent while the residual is reduced -
             # only in lock-step runs, where every posted message is completed before the next sweep (the sweep
             # overwrites what the message reads), and only with ONE sweep per iteration: with nsweeps > 1 it_fine posts a

@@ -1,6 +1,7 @@
 // libsdcmi: context of one level (device slabs, coefficients, operator tables) and launch timing.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstdarg>
@@ -9,6 +10,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <type_traits>
 #include <vector>
 #include "../../include/sdcmi.h"
 #include "fft.hpp"
@@ -36,6 +38,38 @@ struct ProfEntry {
 
 struct CommState;  // comm.hpp: RCCL communicator, message stream, inbox
 
+// A slab of equal fields whose device memory is mapped field by field when somebody first touches it (virtual-memory API:
+// one reserved address range, so the addresses views and kernels hold never move).  The sweeps that stay in Fourier space
+// never touch U[1..M] / F / the node spectra S[0..M-2]: at 1024^3 that is 137 GB that is simply never mapped.  Small fields (or
+// a runtime without the API) get one plain allocation, everything present from the start.
+struct LazySlab {
+    char* base = nullptr;
+    size_t field_bytes = 0;
+    int nfields = 0;
+    bool vmm = false;
+    std::vector<hipMemGenericAllocationHandle_t> handles;
+    std::vector<char> mapped;
+    bool all_mapped = true;
+};
+#define MAXTRAIL 8     // start values a trail of unstored sweeps may depend on (time-parallel runs)
+#define MAXVSWEEPS 32  // sweeps whose start-value indices are on record
+
+// Residual norms whose last inverse pass (x) has not run yet: the residual lines sit in W after their z / y passes and wait -
+// for the start value the time-rank is about to receive (then ONE x pass reduces the norms before and after the receive,
+// the difference field added on the way), or for somebody who wants the numbers.
+struct PendingTicket {
+    unsigned long long seq;
+    int type, after;       // after = 1: the residual against the start value received since the sweep
+    double restol;
+};
+struct PendingX {
+    bool pending = false;      // W holds nf residual fields after their z / y inverse passes, norms not reduced yet
+    bool has_delta = false;    // ... and u[0] has been replaced since: d_new - d_old is added for the second set of norms
+    int nf = 0;
+    const cd *d_old = nullptr, *d_new = nullptr;
+    std::vector<PendingTicket> tickets;
+};
+
 // one finished residual as the device leaves it in pinned host memory (sdc_residual_post)
 #define RES_RING 256
 struct ResRecord {
@@ -53,6 +87,8 @@ struct sdc_ctx {
     size_t Nc = 0;      // complex entries of one spectrum field
     hipStream_t stream = nullptr;
     double *U = nullptr, *F = nullptr, *TAU = nullptr, *UEND = nullptr, *profile = nullptr;
+    LazySlab slabU, slabF, slabS;   // U[0..M], F[0..M][ncomp], S[0..M-1]: mapped on first touch (need_nodes, need_node_spectra)
+    size_t lazy_min_bytes = (size_t)256 << 20;   // fields at least this large are mapped lazily (SDC_LAZY_MIN_BYTES)
     cd* W = nullptr;
     cd *S = nullptr, *S0 = nullptr;  // spectral cache: transforms of U[1..M] and of U[0] (lazy)
     // The transform of the LAST node and the transform of u[0] trade places from one time step to the next (the end
@@ -65,7 +101,21 @@ struct sdc_ctx {
     // that a message stream can pick it up while the residual passes still run.  rlines_valid: the work spectra W still
     // hold the residual of the current iterate after its z / y inverse passes (the x pass only reduced a norm), which lets
     // a new start value update the node norms by ONE more field through the pipeline instead of M.
-    cd *Sy = nullptr, *Sin = nullptr;
+    cd* Sin = nullptr;
+    // spectrum-sized buffers nobody uses right now (sources of a finished trail, difference spectra, ...) and the ones this
+    // context allocated one by one (freed with it)
+    std::vector<cd*> spool, spool_owned;
+    // Trail (time-parallel levels, spectra on the wire): the iterate after spec_virtual unstored sweeps as a function of the
+    // start values the slice has had since its spread predictor - trail_src[0] the block's, trail_src[i] the i-th one received -
+    // and of which sweep started from which (vsrc).  trail_ns = 0: no trail (the iterate depends on S0 alone, as in serial runs).
+    int trail_max = 5, trail_ns = 0;
+    const cd* trail_src[MAXTRAIL] = {};
+    unsigned char vsrc[MAXVSWEEPS] = {};
+    PendingX xp;
+    unsigned long long* res_devA = nullptr;   // norms BEFORE the receive when one x pass delivers both sets
+    bool defer_x = true;                      // spectra on the wire: the x pass of a sweep's residual waits for the receive
+    bool split_send = false;                  // ... and the last node's spectrum is produced by a launch of its own, first
+    bool sl_ev_by_split = false;
     bool wire_spectral = false, rlines_valid = false, sl_ev_recorded = false;
     hipEvent_t sl_ev = nullptr;
     cd* Wend = nullptr;  // spectrum of an end value that is not the cached last node (forward transform of UEND on demand)
@@ -205,6 +255,131 @@ static int fail(sdc_ctx* c, int code, const char* fmt, ...) {
             return fail(c, e_ == hipErrorOutOfMemory ? SDC_ERR_NOMEM : SDC_ERR_HIP, "%s: %s", #call, \
                         hipGetErrorString(e_));                                                      \
     } while (0)
+
+// ---- lazily mapped slabs ---------------------------------------------------------------------------------------------
+// reserve the address range of nfields fields; `eager` fields from the start are mapped right away
+static int slab_map(sdc_ctx* c, LazySlab& sl, int first, int count);
+static int slab_reserve(sdc_ctx* c, LazySlab& sl, size_t field_bytes, int nfields, int eager) {
+    sl.field_bytes = field_bytes;
+    sl.nfields = nfields;
+    sl.handles.assign(nfields, hipMemGenericAllocationHandle_t{});
+    sl.mapped.assign(nfields, 0);
+    int vmm = 0;
+    size_t gran = 0;
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = c->device;
+    if (field_bytes >= c->lazy_min_bytes && eager < nfields &&
+        hipDeviceGetAttribute(&vmm, hipDeviceAttributeVirtualMemoryManagementSupported, c->device) == hipSuccess && vmm &&
+        hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) == hipSuccess && gran > 0 &&
+        field_bytes % gran == 0) {
+        void* base = nullptr;
+        if (hipMemAddressReserve(&base, field_bytes * nfields, gran, nullptr, 0) == hipSuccess) {
+            sl.base = static_cast<char*>(base);
+            sl.vmm = true;
+            sl.all_mapped = false;
+            if (getenv("SDC_LAZY_DEBUG"))
+                fprintf(stderr, "[sdcmi] ctx %p: reserved %d fields of %zu bytes at %p .. %p\n", (void*)c, nfields, field_bytes, base,
+                        (void*)(sl.base + field_bytes * nfields));
+            return slab_map(c, sl, 0, eager);
+        }
+    }
+    (void)hipGetLastError();
+    sl.vmm = false;
+    HIPCHK(c, hipMalloc((void**)&sl.base, field_bytes * nfields));
+    HIPCHK(c, hipMemsetAsync(sl.base, 0, field_bytes * nfields, c->stream));
+    std::fill(sl.mapped.begin(), sl.mapped.end(), 1);
+    sl.all_mapped = true;
+    c->bytes += field_bytes * nfields;
+    return SDC_OK;
+}
+// fields [first, first + count) become real (zero-filled) memory; no-op for the ones that are
+static int slab_map(sdc_ctx* c, LazySlab& sl, int first, int count) {
+    if (sl.all_mapped) return SDC_OK;
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = c->device;
+    hipMemAccessDesc acc = {};
+    acc.location.type = hipMemLocationTypeDevice;
+    acc.location.id = c->device;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    for (int f = first; f < first + count && f < sl.nfields; ++f) {
+        if (sl.mapped[f]) continue;
+        char* at = sl.base + (size_t)f * sl.field_bytes;
+        hipError_t e = hipMemCreate(&sl.handles[f], sl.field_bytes, &prop, 0);
+        if (e != hipSuccess)
+            return fail(c, e == hipErrorOutOfMemory ? SDC_ERR_NOMEM : SDC_ERR_HIP, "mapping field %d of a slab (%zu bytes): %s", f,
+                        sl.field_bytes, hipGetErrorString(e));
+        e = hipMemMap(at, sl.field_bytes, 0, sl.handles[f], 0);
+        if (e == hipSuccess) e = hipMemSetAccess(at, sl.field_bytes, &acc, 1);
+        if (e != hipSuccess) {
+            (void)hipMemRelease(sl.handles[f]);
+            return fail(c, SDC_ERR_HIP, "mapping field %d of a slab: %s", f, hipGetErrorString(e));
+        }
+        sl.mapped[f] = 1;
+        c->bytes += sl.field_bytes;
+        if (getenv("SDC_LAZY_DEBUG")) fprintf(stderr, "[sdcmi] ctx %p: mapped field %d at %p\n", (void*)c, f, (void*)at);
+        HIPCHK(c, hipMemsetAsync(at, 0, sl.field_bytes, c->stream));
+    }
+    bool all = true;
+    for (char m : sl.mapped) all = all && m;
+    sl.all_mapped = all;
+    return SDC_OK;
+}
+static void slab_free(LazySlab& sl) {
+    if (!sl.base) return;
+    if (sl.vmm) {
+        for (int f = 0; f < sl.nfields; ++f)
+            if (sl.mapped[f]) {
+                (void)hipMemUnmap(sl.base + (size_t)f * sl.field_bytes, sl.field_bytes);
+                (void)hipMemRelease(sl.handles[f]);
+            }
+        (void)hipMemAddressFree(sl.base, sl.field_bytes * sl.nfields);
+    } else {
+        (void)hipFree(sl.base);
+    }
+    sl.base = nullptr;
+}
+// U[1..M] and F are about to be read or written in real space
+static inline int need_nodes(sdc_ctx* c) {
+    if (c->slabU.all_mapped && c->slabF.all_mapped) return SDC_OK;
+    int rc = slab_map(c, c->slabU, 0, c->slabU.nfields);
+    return rc == SDC_OK ? slab_map(c, c->slabF, 0, c->slabF.nfields) : rc;
+}
+// F[0] alone (f(u[0]) is evaluated) / the node spectra S[0..M-2] (an iterate is stored in Fourier space)
+static inline int need_f0(sdc_ctx* c) { return slab_map(c, c->slabF, 0, c->ncomp); }
+static inline int need_node_spectra(sdc_ctx* c) { return slab_map(c, c->slabS, 0, c->slabS.nfields); }
+#define NEED_NODES(c)                      \
+    do {                                   \
+        int rcn_ = need_nodes(c);          \
+        if (rcn_ != SDC_OK) return rcn_;   \
+    } while (0)
+
+// ---- spare spectra ---------------------------------------------------------------------------------------------------
+static cd* spool_get(sdc_ctx* c) {
+    if (!c->spool.empty()) {
+        cd* b = c->spool.back();
+        c->spool.pop_back();
+        return b;
+    }
+    cd* b = nullptr;
+    if (hipMalloc((void**)&b, sizeof(cd) * c->Nc) != hipSuccess) {
+        (void)hipGetLastError();
+        fail(c, SDC_ERR_NOMEM, "out of device memory for one more spectrum (%zu bytes)", sizeof(cd) * c->Nc);
+        return nullptr;
+    }
+    c->spool_owned.push_back(b);
+    c->bytes += sizeof(cd) * c->Nc;
+    return b;
+}
+static void spool_put(sdc_ctx* c, const cd* b) {
+    if (!b) return;
+    for (cd* x : c->spool)
+        if (x == b) return;
+    c->spool.push_back(const_cast<cd*>(b));
+}
 
 // Per-kernel device time: a pair of events from a pool is recorded around every launch on the context's
 // stream; nothing synchronises until the pool is full or the profile is read, so the timed region of bench.py

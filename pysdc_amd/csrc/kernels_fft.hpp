@@ -135,15 +135,25 @@ __global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_fwd(FieldPtr
 // are the collocation residuals of the spectral sweep); STORE: the real field is written to out[field].
 // ADD: a further half spectrum `add` (same layout, one field) is added to every field on the way in - the residual of
 // all nodes changes by the same field when u[0] is replaced (time-parallel runs), and the transform is linear.
-template <int N, int T, bool NORM, bool STORE, bool ADD = false>
+// SCR: the transformed tile of ONE field parked in / taken from a scratch field in the arrangement the threads hold it
+// (scr[(tile * E + i) * threads + thread]: every access a contiguous 16 bytes per lane).  1: the tile is stored there and
+// nothing else happens (the difference of two start values, time-parallel runs: the residual of EVERY node changes by that
+// field when u[0] is replaced, core/sweeper.py:186-199 is linear in u[0]).  2: max |r| goes to norms2[field] and max |r + d|
+// with d from the scratch to norms[field] - the residual before and after the receive out of one pass over the residual
+// lines (same XCD-aware order as ADD: the nfields workgroups that read one scratch tile follow each other on one XCD).
+template <int N, int T, bool NORM, bool STORE, bool ADD = false, int SCR = 0>
 __global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_inv(FieldPtrs p, const cd* __restrict__ W,
                                                                       size_t fstride, int rest,
                                                                       const cd* __restrict__ tw,
                                                                       unsigned long long* __restrict__ norms,
                                                                       const cd* __restrict__ add = nullptr, int nfields = 1,
-                                                                      ReactEpi epi = ReactEpi{nullptr, 0, 0, 0, 0.0, 0.0, {}}) {
+                                                                      ReactEpi epi = ReactEpi{nullptr, 0, 0, 0, 0.0, 0.0, {}},
+                                                                      cd* __restrict__ scr = nullptr,
+                                                                      unsigned long long* __restrict__ norms2 = nullptr) {
     constexpr int E = fft_elems(N), P = N / E;
-    constexpr bool XWAVE = SDC_XWAVE && NORM && !STORE && P == 64 && !SDC_XINV_DIRECT;  // (norm-only pass, one wave per column)
+    static_assert(SCR == 0 || (!STORE && !ADD && (SCR == 1) == !NORM), "scratch variants: 1 = store only, 2 = both norm sets");
+    constexpr bool GRID1D = ADD || SCR == 2;
+    constexpr bool XWAVE = SDC_XWAVE && ((NORM && !STORE) || SCR != 0) && P == 64 && !SDC_XINV_DIRECT;  // (nothing stored in real space: one wave per column)
     using LAY = LayStrided<N, T>;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int col = threadIdx.x % T, j = threadIdx.x / T;
@@ -162,17 +172,18 @@ __global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_inv(FieldPtr
     constexpr int XS = STORE ? SDC_X_SWZ_STORE : SDC_X_SWZ;
     int bx_ = (int)blockIdx.x;
     if (XS == 1 && (gridDim.x & 7u) == 0) bx_ = (int)((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3));
-    if (XS == 3 && !ADD) {  // every XCD whole rows of the (y, z) plane: XCD x takes the rows y = 8 g + x and walks along z
+    if (XS == 3 && !GRID1D) {  // every XCD whole rows of the (y, z) plane: XCD x takes the rows y = 8 g + x and walks along z
         constexpr unsigned ZT = (N / 2 + T - 1) / T;
         if (gridDim.x == (unsigned)N * ZT && (N & 7) == 0) {
             const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
             bx_ = (int)(((slot / ZT) * 8u + xcd) * ZT + slot % ZT);
         }
     }
-    const int bx = ADD ? (int)((blockIdx.x / (8 * nfields)) * 8 + blockIdx.x % 8) : bx_;
-    const int by = ADD ? (int)((blockIdx.x / 8) % nfields) : (int)blockIdx.y;
+    const int bx = GRID1D ? (int)((blockIdx.x / (8 * nfields)) * 8 + blockIdx.x % 8) : bx_;
+    const int by = GRID1D ? (int)((blockIdx.x / 8) % nfields) : (int)blockIdx.y;
     const int c = bx * T + col;
     const bool ok = c < ncol;
+    if (SCR == 2 && bx * T >= ncol) return;   // (a padding workgroup of the last group of 8: no scratch tile behind it)
     const cd* __restrict__ Wf = W + by * fstride;
     cd r[E];
 #if SDC_XINV_DIRECT
@@ -293,7 +304,33 @@ __global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_inv(FieldPtr
     fft_line<N, +1, LAY>(r, j, col, lds, tw);
     }
 #endif
-    if constexpr (NORM) {
+    if constexpr (SCR == 1) {
+        cd* __restrict__ dst = scr + (size_t)bx * E * blockDim.x + threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < E; ++i) dst[(size_t)i * blockDim.x] = r[i];
+    }
+    if constexpr (SCR == 2) {
+        // the norms before the receive from r, the norms after it from r + d (d: the transformed difference of the two start
+        // values, parked by the SCR == 1 launch in this very arrangement)
+        const cd* __restrict__ src = scr + (size_t)bx * E * blockDim.x + threadIdx.x;
+        double m0 = 0.0, m1 = 0.0;
+        cd d0 = src[0];
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            const cd d = i == 0 ? d0 : src[(size_t)i * blockDim.x];
+            m0 = fmax(m0, fmax(fabs(r[i].x), fabs(r[i].y)));
+            m1 = fmax(m1, fmax(fabs(r[i].x + d.x), fabs(r[i].y + d.y)));
+        }
+        // (NaN: see below - one element of every thread tells; the difference field gets the same test)
+        if (r[0].x != r[0].x || r[0].y != r[0].y) m0 = m1 = r[0].x + r[0].y;
+        if (d0.x != d0.x || d0.y != d0.y) m1 = d0.x + d0.y;
+        m0 = wave_max(m0);
+        m1 = wave_max(m1);
+        if ((threadIdx.x & 63) == 0) {
+            atomic_max_abs(norms2 + by, m0);
+            atomic_max_abs(norms + by, m1);
+        }
+    } else if constexpr (NORM) {
         double m = 0.0;  // columns beyond the edge were transformed from zeros
 #pragma unroll
         for (int i = 0; i < E; ++i) m = fmax(m, fmax(fabs(r[i].x), fabs(r[i].y)));
@@ -681,6 +718,11 @@ struct SpecArgs {
     // mode-pair launches: the last node's spectrum of the NEW iterate goes to SL on the way (what k_spec_store_pairs would
     // write with last_only: the end value / next start value) - the launch has its multipliers in registers
     int store_last;
+    // Trail (time-parallel levels): the iterate after nsw unstored sweeps depends on ns start values - src[0] the one the spread
+    // predictor copied to every node, src[i] the i-th one received since; sweep s (0-based) started from src[vsrc[s]].
+    const cd* src[MAXTRAIL];
+    int ns, nsw;
+    unsigned char vsrc[MAXVSWEEPS];
 };
 
 // one thread per Fourier mode: gather on the cached transforms + node-coupled solve, S updated in place.
@@ -775,6 +817,177 @@ DEVI void virt_multipliers(const SpecArgs& a, cd lam, cd mu, int nsweeps, cd (&g
         }
     }
 }
+// Trail of unstored sweeps whose start values differ (time-parallel levels: u[0] is replaced between sweeps,
+// controller_MPI.py:218-233).  One sweep with start value s maps the node vector as  u <- T u + b s  per mode, with
+//   (T x)_m = lam (sum_q gI[m][q] x_q + sum_{q<m} cI[m][q] (T x)_q) / (1 - alpha_m lam),   b = the same with "1 +" for "gI x".
+// From "all nodes equal src[0]" the iterate after J sweeps is  T^J 1 * src[0] + sum_s T^(J-1-s) b * src[vsrc[s]]:  two chains
+// of real node multipliers (2J - 1 applications of T) whatever the number of start values.  Real symmetric symbol only.
+template <int NF>
+DEVI void trail_apply(const SpecArgs& a, double lam, const double (&inv)[NF], double (&x)[NF]) {
+    double o[NF];
+#pragma unroll
+    for (int q = 0; q < NF; ++q) o[q] = x[q];
+#pragma unroll
+    for (int m = 0; m < NF; ++m) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < NF; ++q) t = fma(a.gI[m][q], o[q], t);
+        if (a.coupled) {
+#pragma unroll
+            for (int q = 0; q < m; ++q) t = fma(a.cI[m][q], x[q], t);
+        }
+        x[m] = lam * t * inv[m];
+    }
+}
+// node values of the modes p (lo) and n - p (hi; paired) of the line that starts at `base` after a.nsw sweeps
+template <int NF>
+DEVI void trail_iterate(const SpecArgs& a, double lam, size_t base, int p_, int n, bool paired, cd (&ulo)[NF], cd (&uhi)[NF]) {
+    double inv[NF], x[NF], y[NF];
+    const int J = a.nsw;
+    // (the first start value's modes are on their way while the multipliers are set up)
+    const cd* sp = a.src[a.vsrc[J - 1]];
+    cd slo = sp[base + p_], shi = paired ? sp[base + n - p_] : cd{0.0, 0.0};
+#pragma unroll
+    for (int m = 0; m < NF; ++m) {
+        inv[m] = fast_rcp(1.0 - a.alpha[m] * lam);
+        y[m] = 1.0;
+        ulo[m] = uhi[m] = cd{0.0, 0.0};
+    }
+#pragma unroll
+    for (int m = 0; m < NF; ++m) {   // b
+        double t = 0.0;
+        if (a.coupled) {
+#pragma unroll
+            for (int q = 0; q < m; ++q) t = fma(a.cI[m][q], x[q], t);
+        }
+        x[m] = fma(lam, t, 1.0) * inv[m];
+    }
+    for (int s = 0; s < J; ++s) {
+        // x = T^s b belongs to sweep J - 1 - s; the start value of the sweep before it is fetched one step ahead
+        const cd clo = slo, chi = shi;
+        const cd* sn = s + 1 < J ? a.src[a.vsrc[J - 2 - s]] : a.src[0];
+        slo = sn[base + p_];
+        if (paired) shi = sn[base + n - p_];
+#pragma unroll
+        for (int m = 0; m < NF; ++m) {
+            ulo[m] = cd{fma(x[m], clo.x, ulo[m].x), fma(x[m], clo.y, ulo[m].y)};
+            uhi[m] = cd{fma(x[m], chi.x, uhi[m].x), fma(x[m], chi.y, uhi[m].y)};
+        }
+        trail_apply<NF>(a, lam, inv, y);
+        if (s + 1 < J) trail_apply<NF>(a, lam, inv, x);
+    }
+    // y = T^J 1: what is left of the spread predictor's copies of src[0]
+#pragma unroll
+    for (int m = 0; m < NF; ++m) {
+        ulo[m] = cd{fma(y[m], slo.x, ulo[m].x), fma(y[m], slo.y, ulo[m].y)};
+        uhi[m] = cd{fma(y[m], shi.x, uhi[m].x), fma(y[m], shi.y, uhi[m].y)};
+    }
+}
+// The residual of that iterate against the current start value (the last sweep's), and the last node's value, for K mode
+// pairs of one thread side by side (independent chains: the f64 pipe always has a second one to issue from).  Works on the
+// real node multipliers alone: sweeps come in runs that share a start value (it changes only when one is received), the
+// multipliers of a run are the sum of its chain vectors, and a start value's modes are touched once - when its run is over:
+//   R_m += (delta - G_m + lam sum_q rQ[m][q] G_q) * s,   u_M += G_M * s.
+template <int NF, int K>
+DEVI void trail_residual(const SpecArgs& a, const double (&lam)[K], size_t base, const int (&p_)[K], const bool (&paired)[K], int n,
+                         cd (&rlo)[K][NF], cd (&rhi)[K][NF], cd (&ulo)[K], cd (&uhi)[K]) {
+    double inv[K][NF], x[K][NF], y[K][NF], G[K][NF];
+    const int J = a.nsw, now = a.vsrc[J - 1];
+    int cur = now;
+    cd slo[K], shi[K];
+    const cd* sp = a.src[cur];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        slo[k] = sp[base + p_[k]];
+        shi[k] = paired[k] ? sp[base + n - p_[k]] : cd{0.0, 0.0};
+        ulo[k] = uhi[k] = cd{0.0, 0.0};
+#pragma unroll
+        for (int m = 0; m < NF; ++m) {
+            inv[k][m] = fast_rcp(1.0 - a.alpha[m] * lam[k]);
+            y[k][m] = 1.0;
+            G[k][m] = 0.0;
+            rlo[k][m] = rhi[k][m] = cd{0.0, 0.0};
+        }
+#pragma unroll
+        for (int m = 0; m < NF; ++m) {   // b
+            double t = 0.0;
+            if (a.coupled) {
+#pragma unroll
+                for (int q = 0; q < m; ++q) t = fma(a.cI[m][q], x[k][q], t);
+            }
+            x[k][m] = fma(lam[k], t, 1.0) * inv[k][m];
+        }
+    }
+    auto close_run = [&](int next) {   // the run of `cur` is complete: its start value enters, the next one's modes are fetched
+        const double one = cur == now ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+#pragma unroll
+            for (int m = 0; m < NF; ++m) {
+                double t = 0.0;
+#pragma unroll
+                for (int q = 0; q < NF; ++q) t = fma(a.rQ[m][q], G[k][q], t);
+                const double h = fma(lam[k], t, one - G[k][m]);
+                rlo[k][m] = cd{fma(h, slo[k].x, rlo[k][m].x), fma(h, slo[k].y, rlo[k][m].y)};
+                rhi[k][m] = cd{fma(h, shi[k].x, rhi[k][m].x), fma(h, shi[k].y, rhi[k][m].y)};
+            }
+            ulo[k] = cd{fma(G[k][NF - 1], slo[k].x, ulo[k].x), fma(G[k][NF - 1], slo[k].y, ulo[k].y)};
+            uhi[k] = cd{fma(G[k][NF - 1], shi[k].x, uhi[k].x), fma(G[k][NF - 1], shi[k].y, uhi[k].y)};
+        }
+        if (next >= 0) {
+            const cd* sn = a.src[next];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                slo[k] = sn[base + p_[k]];
+                if (paired[k]) shi[k] = sn[base + n - p_[k]];
+#pragma unroll
+                for (int m = 0; m < NF; ++m) G[k][m] = 0.0;
+            }
+            cur = next;
+        }
+    };
+    for (int s = 0; s < J; ++s) {
+        const int of = a.vsrc[J - 1 - s];   // x = T^s b belongs to sweep J - 1 - s
+        if (of != cur) close_run(of);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+#pragma unroll
+            for (int m = 0; m < NF; ++m) G[k][m] += x[k][m];
+            trail_apply<NF>(a, lam[k], inv[k], y[k]);
+            if (s + 1 < J) trail_apply<NF>(a, lam[k], inv[k], x[k]);
+        }
+    }
+    if (cur != 0) close_run(0);
+#pragma unroll
+    for (int k = 0; k < K; ++k)   // y = T^J 1: what is left of the spread predictor's copies of src[0]
+#pragma unroll
+        for (int m = 0; m < NF; ++m) G[k][m] += y[k][m];
+    close_run(-1);
+}
+
+// ... written out: all node spectra or (last_only) only the last one - what store_spectra does for a trail
+template <int NF>
+__global__ __launch_bounds__(256) void k_trail_store(SpecArgs a, int n, size_t nitems) {
+    const int H = n / 2;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < nitems; idx += (size_t)gridDim.x * blockDim.x) {
+        const int p_ = (int)(idx % (size_t)(H + 1));
+        const size_t ln = idx / (size_t)(H + 1);
+        double lxy = 0.0;
+        if (a.ndim == 3) lxy = a.lamI[ln / n].x + a.lamI[ln % n].x;
+        else if (a.ndim == 2) lxy = a.lamI[ln].x;
+        const size_t base = ln * (size_t)n;
+        const bool paired = p_ >= 1 && p_ < H;
+        cd ulo[NF], uhi[NF];
+        trail_iterate<NF>(a, a.lamI[p_].x + lxy, base, p_, n, paired, ulo, uhi);
+#pragma unroll
+        for (int m = 0; m < NF; ++m)
+            if (!a.last_only || m == NF - 1) {
+                SPEC_FIELD(a, m, NF)[base + p_] = ulo[m];
+                if (paired) SPEC_FIELD(a, m, NF)[base + n - p_] = uhi[m];
+            }
+    }
+}
+
 // u[m] = g_m u0 (and, RES, r[m] = h_m u0) for the iterate after nsweeps sweeps
 template <int NF, bool HASE, bool RES>
 DEVI void virt_iterate(const SpecArgs& a, cd lam, cd mu, cd u0h, int nsweeps, cd (&u)[NF], cd (&r)[NF]) {
@@ -1012,6 +1225,9 @@ __global__ __launch_bounds__(256) void k_spec_residual(SpecArgs a, int n, size_t
 #ifndef SDC_SPECZ_VHOIST
 #define SDC_SPECZ_VHOIST 1  // MODE 3: the S0 loads of all chunks are issued before the first chunk is worked on
 #endif
+#ifndef SDC_TRAIL_K2
+#define SDC_TRAIL_K2 0   // 1: two pairs per thread side by side (256 VGPRs and 200 bytes of scratch at five nodes: one at a time it is)
+#endif
 template <int N, bool V = false>
 constexpr int specz_elems() {
     return N == 512 ? 8 : (N == 256 ? SDC_SPECZ_E256 : (N == 1024 ? (V ? SDC_SPECZ_VE1024 : SDC_SPECZ_E1024) : fft_elems(N)));
@@ -1030,13 +1246,13 @@ constexpr int specz_min_waves() { return specz_lines<N, V>() > 1 ? 2 : (V ? SDC_
 template <int N, int NF, int MODE, int EXPL>
 // (several lines per workgroup, N < 1024: the elements a thread takes from the first chunk stay live while it works on
 // the second one - 2 waves / SIMD worth of registers instead of spilling; measured 5.7 -> 4.2 ms at 512^3)
-__global__ __launch_bounds__((specz_threads<N, NF, (MODE >= 3)>()), (specz_min_waves<N, (MODE >= 3)>()))
+__global__ __launch_bounds__((specz_threads<N, NF, (MODE >= 3)>()), ((MODE == 6 && N >= 1024) ? 2 : specz_min_waves<N, (MODE >= 3)>()))
 void k_spec_z(SpecArgs a, unsigned nlines) {
-    constexpr bool RES = MODE >= 1, UPD = MODE <= 1 || MODE >= 3, VIRT = MODE >= 3, PAIR = MODE >= 4, GTAB = MODE == 5,
-                   HASE = EXPL == 1, HASP = EXPL == 2;
+    constexpr bool RES = MODE >= 1, UPD = MODE <= 1 || MODE >= 3, VIRT = MODE >= 3, TRAIL = MODE == 6, PAIR = MODE >= 4 && !TRAIL,
+                   GTAB = MODE == 5, HASE = EXPL == 1, HASP = EXPL == 2;
     static_assert(!(VIRT && HASP), "a forced iterate is not a function of the start value alone");
     constexpr int E = specz_elems<N, (MODE >= 3)>(), P = N / E, LPB = specz_lines<N, (MODE >= 3)>();
-    static_assert(!PAIR || (LPB == 1 && !HASE), "mode pairs: one line per field and workgroup, real symbol only");
+    static_assert(!(PAIR || TRAIL) || (LPB == 1 && !HASE), "mode pairs: one line per field and workgroup, real symbol only");
     constexpr int SPAN = LPB * N, CH = SPAN > SDC_SPECZ_CH ? SDC_SPECZ_CH : SPAN, NCH = SPAN / CH, NT = LPB * P * NF;
     constexpr int ITS = (CH + NT - 1) / NT;  // modes per thread and chunk
     using LAY = LayContig<N>;
@@ -1148,7 +1364,57 @@ void k_spec_z(SpecArgs a, unsigned nlines) {
             __syncthreads();
         }
     }
-    constexpr bool HOIST = VIRT && !PAIR && SDC_SPECZ_VHOIST;
+    if constexpr (TRAIL) {
+        // MODE 6: the iterate is a function of SEVERAL start values (trail_residual).  All mode pairs of the line are worked on
+        // before anything is handed over - two pairs per thread side by side where the wave has two - through a buffer that
+        // holds the whole line of every field (the transform's exchange planes take its place afterwards).
+        constexpr int H = N / 2, NI = H + 1, ITT = (NI + NT - 1) / NT;
+        const size_t base = (size_t)bid * N;
+        double lxy = 0.0;
+        if (a.ndim == 3) lxy = a.lamI[bid / N].x + a.lamI[bid % N].x;
+        else if (a.ndim == 2) lxy = a.lamI[bid].x;
+        auto work = [&](auto kc, int g) {
+            constexpr int K = decltype(kc)::value;
+            int p_[K];
+            bool mine[K], paired[K];
+            double lam[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const int p0 = (int)threadIdx.x + (g + k) * NT;
+                mine[k] = ok && p0 < NI;
+                p_[k] = mine[k] ? p0 : H;   // (a lane without a pair of its own follows along on a valid one, stores nothing)
+                paired[k] = p_[k] >= 1 && p_[k] < H;
+                lam[k] = a.lamI[p_[k]].x + lxy;
+            }
+            cd rlo[K][NF], rhi[K][NF], ulo[K], uhi[K];
+            trail_residual<NF, K>(a, lam, base, p_, paired, N, rlo, rhi, ulo, uhi);
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                if (!mine[k]) continue;
+                if (a.store_last) {   // the last node's spectrum: what the wire carries, and the next step's start value
+                    a.SL[base + p_[k]] = ulo[k];
+                    if (paired[k]) a.SL[base + N - p_[k]] = uhi[k];
+                }
+#pragma unroll
+                for (int m = 0; m < NF; ++m) {
+                    rbuf[m * N + p_[k]] = cscale(rlo[k][m], a.invN);
+                    if (paired[k]) rbuf[m * N + N - p_[k]] = cscale(rhi[k][m], a.invN);
+                }
+            }
+        };
+#pragma unroll
+        for (int g = 0; g < ITT; g += (SDC_TRAIL_K2 ? 2 : 1)) {
+            // (wave-uniform: does any lane of this wave have a second pair in this round?)
+            const bool two = SDC_TRAIL_K2 && g + 1 < ITT && (int)(threadIdx.x & ~63u) + (g + 1) * NT < NI;
+            if (two) work(std::integral_constant<int, 2>{}, g);
+            else if ((int)(threadIdx.x & ~63u) + g * NT < NI) work(std::integral_constant<int, 1>{}, g);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < E; ++i) r[i] = rbuf[f * N + j + i * P];
+        __syncthreads();
+    }
+    constexpr bool HOIST = VIRT && !PAIR && !TRAIL && SDC_SPECZ_VHOIST;
     cd in0all[HOIST ? NCH : 1][ITS];
     if constexpr (HOIST) {
 #pragma unroll
@@ -1161,7 +1427,7 @@ void k_spec_z(SpecArgs a, unsigned nlines) {
             }
     }
 #pragma unroll
-    for (int ch = 0; ch < (PAIR ? 0 : NCH); ++ch) {
+    for (int ch = 0; ch < ((PAIR || TRAIL) ? 0 : NCH); ++ch) {
         // all loads of this chunk first: (NF + 1) * ITS independent 16-byte loads per thread in flight
         cd in0[ITS], inq[ITS][VIRT ? 1 : NF], inp[ITS];
 #pragma unroll

@@ -52,6 +52,13 @@ static inline int grid_for(size_t work, int block) {
 // the start value where it lies (read-only consumers) / brought home to the U[0] slab (everybody else)
 static int spectrum_to_field(sdc_ctx* c, const cd* src, double* out);  // inverse transform of ONE cached spectrum
 static int store_spectra(sdc_ctx* c, bool last_only);               // spectra of an iterate that was never stored
+static int flush_x(sdc_ctx* c);                                     // residual norms whose last inverse pass was put off
+static int trail_reset(sdc_ctx* c);
+#define FLUSH_X(c)                              \
+    do {                                        \
+        int rcx_ = flush_x(c);                  \
+        if (rcx_ != SDC_OK) return rcx_;        \
+    } while (0)
 #define STORE_SPECTRA(c, last)                  \
     do {                                        \
         int rcs_ = store_spectra(c, last);      \
@@ -114,6 +121,7 @@ static double* slot_ptr(sdc_ctx* c, int slot, int m, int comp) {
 
 template <int MODE>
 static int launch_quad(sdc_ctx* c, const QuadArgs& a, const char* name) {
+    NEED_NODES(c);
     LaunchTimer lt(c, name);
     int grid = grid_for(c->N / 2, 256);
     if (MODE >= 1 && grid > 2048) grid = 2048;   // (norms: fewer, longer workgroups - fewer atomics on the M slots)
@@ -214,6 +222,7 @@ static int apply_operator(sdc_ctx* c, const double* v, double* Av) {
 // F[1..M] = A U[1..M] for the new iterate; fused with the residual when the fast 3-D kernel applies
 static int eval_nodes(sdc_ctx* c, double dt) {
     const int M = c->M;
+    NEED_NODES(c);
     auto three = [](const Stencil& s) { return s.npts == 3 && s.off[0] == -1 && s.off[1] == 0 && s.off[2] == 1; };
     const bool expl = c->ncomp == 2 && c->expl_kind == SDC_EXPL_STENCIL;
     if (c->fuse_residual && c->ndim == 3 && (c->ncomp == 1 || expl) && !c->tau_active && c->n % 64 == 0 &&
@@ -264,6 +273,7 @@ static int eval_nodes(sdc_ctx* c, double dt) {
 // F[1..M] = f(U[1..M]) by the plain stencil launch
 static int eval_nodes_plain(sdc_ctx* c) {
     const int M = c->M;
+    NEED_NODES(c);
     c->f_pending = false;
     if (c->kind == 1) {  // van der Pol ensemble: node by node, not counted again
         for (int m = 1; m <= M; ++m) {
@@ -401,7 +411,8 @@ static int fwd_transform_n(sdc_ctx* c, int nf, const FieldPtrs& p, cd* dst, size
 
 // the inverse passes after the contiguous-axis one: work[f] -> real fields out[f] or (norms != null) max |.|
 template <int N>
-static int inverse_tail_n(sdc_ctx* c, int nf, cd* work, const FieldPtrs& p, unsigned long long* norms, bool y_done = false) {
+static int inverse_tail_n(sdc_ctx* c, int nf, cd* work, const FieldPtrs& p, unsigned long long* norms, bool y_done = false,
+                          bool defer_x = false) {
     constexpr int E = fft_elems(N), P = N / E, T = N >= 2048 ? 4 : (N == 1024 ? SDC_T1024 : 8);
     const size_t lds_str = (size_t)LayStrided<N, T>::doubles(T) * sizeof(double);
     // (the norm-only pass with one wave per column keeps the columns apart in LDS: a few more bytes)
@@ -418,6 +429,16 @@ static int inverse_tail_n(sdc_ctx* c, int nf, cd* work, const FieldPtrs& p, unsi
             LaunchTimer lt(c, pname("fft_y_inv", nf));
             hipLaunchKernelGGL((k_ffty<N, T, +1>), dim3((n + T - 1) / T, n / 2 + 1, nf), dim3(P * T), lds_str, c->stream,
                                work, c->Nc, c->tw);
+        }
+        if (norms && defer_x && !p.out[0] && !y_done) {
+            // the last pass waits: for the start value this time-rank is about to receive (one pass then reduces the norms
+            // before and after the receive, flush_x) or for somebody who wants the numbers
+            HIPCHK(c, hipGetLastError());
+            c->xp.pending = true;
+            c->xp.has_delta = false;
+            c->xp.nf = nf;
+            c->xp.tickets.clear();
+            return SDC_OK;
         }
         if (norms) {
             if (p.out[0]) {  // the residual fields are kept as well
@@ -463,6 +484,49 @@ static int inverse_tail_x_only(sdc_ctx* c, int nf, cd* work, const FieldPtrs& p,
     return SDC_OK;
 }
 
+// The difference of two start values through the inverse passes, parked in the arrangement the x pass holds its tiles in
+// (dscr), then ONE x pass over the nf residual fields in `work` that reduces max |r| into normsA and max |r + d| into norms.
+template <int N>
+static int joint_norms_n(sdc_ctx* c, int nf, cd* work, const cd* d_new, const cd* d_old, cd* dbuf, cd* dscr,
+                         unsigned long long* norms, unsigned long long* normsA) {
+    constexpr int E = fft_elems(N), P = N / E, T = N >= 2048 ? 4 : (N == 1024 ? SDC_T1024 : 8), LPB = z_lines_per_block<N>();
+    const size_t lds_str = (size_t)LayStrided<N, T>::doubles(T) * sizeof(double);
+    const size_t lds_x = (SDC_XWAVE && P == 64) ? (size_t)LayCols<N>::doubles(T) * sizeof(double) : lds_str;
+    const int n = c->n;
+    const size_t lines = (size_t)(n / 2 + 1) * (c->ndim == 3 ? n : 1);
+    const int rest = (int)(c->N / n);
+    const int tiles = (rest / 2 + T - 1) / T;
+    const ReactEpi none{nullptr, 0, 0, 0, 0.0, 0.0, {}};
+    FieldPtrs p;
+    memset(&p, 0, sizeof p);
+    {
+        LaunchTimer lt(c, pname("fft_z_diff", 1));
+        const size_t ldsz = (size_t)LayContig<N>::doubles(LPB) * sizeof(double);
+        hipLaunchKernelGGL((k_fftz_plain<N, +1>), dim3((unsigned)((lines + LPB - 1) / LPB)), dim3(P * LPB), ldsz, c->stream,
+                           d_new, dbuf, c->Nc, c->tw, (unsigned)lines, 1.0 / (double)c->N, (const cd*)nullptr, -1,
+                           (const cd*)nullptr, (const cd*)nullptr, 0, d_old);
+    }
+    if (c->ndim == 3) {
+        LaunchTimer lt(c, pname("fft_y_inv", 1));
+        hipLaunchKernelGGL((k_ffty<N, T, +1>), dim3((n + T - 1) / T, n / 2 + 1, 1), dim3(P * T), lds_str, c->stream, dbuf,
+                           c->Nc, c->tw);
+    }
+    {
+        LaunchTimer lt(c, pname("fft_x_scr", 1));
+        hipLaunchKernelGGL((k_fftx_inv<N, T, false, false, false, 1>), dim3(tiles, 1), dim3(P * T), lds_x, c->stream, p, dbuf,
+                           c->Nc, rest, c->tw, (unsigned long long*)nullptr, (const cd*)nullptr, 1, none, dscr,
+                           (unsigned long long*)nullptr);
+    }
+    {
+        LaunchTimer lt(c, pname("fft_x_norm2", nf));
+        const int groups = (tiles + 7) / 8;   // (8 nf ceil(tiles / 8) workgroups in the XCD-aware order the kernel decodes)
+        hipLaunchKernelGGL((k_fftx_inv<N, T, true, false, false, 2>), dim3(groups * 8 * nf), dim3(P * T), lds_x, c->stream, p,
+                           work, c->Nc, rest, c->tw, norms, (const cd*)nullptr, nf, none, dscr, normsA);
+    }
+    HIPCHK(c, hipGetLastError());
+    return SDC_OK;
+}
+
 // inverse transform of nf fully transformed spectra src[f] (src + f*Nc) through the work buffer work[f]
 // (work may equal src: in place) into the real fields out[f] - or, with norms != null, into max |.| per field
 template <int N>
@@ -485,6 +549,10 @@ static int inverse_passes_n(sdc_ctx* c, int nf, const cd* src, cd* work, const F
 template <int N>
 static int early_end_point_n(sdc_ctx* c, bool norms_only) {
     if (!c->early_uend || !norms_only) return SDC_OK;
+    if (c->wire_spectral && c->sl_ev_by_split) {   // (recorded behind the launch that wrote the spectrum by itself: sdc_sweep)
+        c->sl_ev_by_split = false;
+        return SDC_OK;
+    }
     if (c->wire_spectral) {
         // the wire carries the last node's SPECTRUM (final as of now): nothing to transform, only a point in the stream to
         // wait for; the end value itself stays put off (sdc_end_point: uend_pending)
@@ -519,6 +587,7 @@ static void launch_spec_z_cfg(sdc_ctx* c, SpecArgs& a, size_t lines, int mode, s
     constexpr int SPAN = LPB * N, CH = SPAN > SDC_SPECZ_CH ? SDC_SPECZ_CH : SPAN;
     size_t ldsz = (size_t)LayContig<N>::doubles(NF * LPB) * sizeof(double);
     if ((size_t)NF * CH * sizeof(cd) > ldsz) ldsz = (size_t)NF * CH * sizeof(cd);
+    if (V && a.ns > 0 && (size_t)NF * N * sizeof(cd) > ldsz) ldsz = (size_t)NF * N * sizeof(cd);  // (trail: the whole line of every field)
     const dim3 grid((unsigned)((launch_lines + LPB - 1) / LPB)), block(P * LPB * NF);  // (lines: the bound the kernel checks)
     const int expl = a.lamE ? 1 : (a.SP ? 2 : 0);
 #define ZL(M_, E_) hipLaunchKernelGGL((k_spec_z<N, NF, M_, E_>), grid, block, ldsz, c->stream, a, (unsigned)lines)
@@ -526,7 +595,8 @@ static void launch_spec_z_cfg(sdc_ctx* c, SpecArgs& a, size_t lines, int mode, s
         (void)expl;
         if constexpr (LPB == 1 && SDC_SPECZ_PAIRS) {
             // real symmetric symbol: the modes kz and N - kz of a line share their node multipliers
-            if (a.real_sym && a.gmode) ZL(5, 0);
+            if (a.real_sym && a.ns > 0) ZL(6, 0);
+            else if (a.real_sym && a.gmode) ZL(5, 0);
             else if (a.real_sym) ZL(4, 0);
             else ZL(3, 0);
         } else ZL(3, 0);
@@ -579,7 +649,9 @@ static int spec_sweep_n(sdc_ctx* c, int nf, SpecArgs& a, const FieldPtrs& p, uns
             HIPCHK(c, hipGetLastError());
             int rce = early_end_point_n<N>(c, norms != nullptr);
             if (rce != SDC_OK) return rce;
-            return inverse_tail_n<N>(c, nf, c->W, p, norms);
+            // time-parallel levels with spectra on the wire: the last pass waits for the start value that is on its way
+            const bool dx = c->defer_x && c->wire_spectral && c->early_uend && c->ndim >= 2;
+            return inverse_tail_n<N>(c, nf, c->W, p, norms, false, dx);
         }
     }
     {
@@ -712,6 +784,10 @@ static int spec_residual(sdc_ctx* c, double dt, unsigned long long* norms) {
     int rw = ensure_work(c);
     if (rw != SDC_OK) return rw;
     STORE_SPECTRA(c, false);  // (before S0 is replaced: an iterate that was not stored is a function of the OLD one)
+    {
+        int rcn = need_node_spectra(c);
+        if (rcn != SDC_OK) return rcn;
+    }
     if (!c->spec0_valid) {
         FieldPtrs p0;
         memset(&p0, 0, sizeof p0);
@@ -768,12 +844,40 @@ static int store_spectra(sdc_ctx* c, bool last_only) {
     a.nf = c->M;
     a.ndim = c->ndim;
     a.last_only = last_only ? 1 : 0;
+    if (!last_only) {
+        int rcn = need_node_spectra(c);
+        if (rcn != SDC_OK) return rcn;
+    }
+    const int n = c->n;
+    const size_t lines = c->ndim == 1 ? 1 : (size_t)(n / 2 + 1) * (c->ndim == 3 ? n : 1);
+    if (c->trail_ns > 0) {
+        // the iterate depends on several start values (time-parallel levels): trail_iterate per mode pair
+        a.ns = c->trail_ns;
+        a.nsw = c->spec_virtual;
+        for (int i = 0; i < c->trail_ns; ++i) a.src[i] = c->trail_src[i];
+        memcpy(a.vsrc, c->vsrc, sizeof a.vsrc);
+        const size_t nitems = lines * (size_t)(n / 2 + 1);
+        size_t tb = (nitems + 255) / 256;
+        if (tb > SDC_SPEC_GRID) tb = SDC_SPEC_GRID;
+        {
+            LaunchTimer lt(c, pname(last_only ? "trail_store_last" : "trail_store", c->M));
+#define SCASE(MM) \
+    case MM: hipLaunchKernelGGL((k_trail_store<MM>), dim3((unsigned)tb), dim3(256), 0, c->stream, a, n, nitems); break;
+            switch (c->M) { SCASE(1) SCASE(2) SCASE(3) SCASE(4) SCASE(5) SCASE(6) SCASE(7) SCASE(8) }
+#undef SCASE
+        }
+        HIPCHK(c, hipGetLastError());
+        c->sl_stored = true;
+        if (!last_only) {
+            c->spec_virtual = 0;
+            return trail_reset(c);
+        }
+        return SDC_OK;
+    }
     if (c->Gm && c->g_sweeps > 0 && c->g_sweeps == c->spec_virtual) {  // the multipliers of this very iterate are on record
         a.G = c->Gm;
         a.gmode = 2;
     }
-    const int n = c->n;
-    const size_t lines = c->ndim == 1 ? 1 : (size_t)(n / 2 + 1) * (c->ndim == 3 ? n : 1);
     const size_t nmodes = lines * n;
     size_t gblocks = (nmodes + 255) / 256;
     if (gblocks > SDC_SPEC_GRID) gblocks = SDC_SPEC_GRID;
@@ -805,6 +909,10 @@ static int inverse_from_cache(sdc_ctx* c, int first, int nf, const FieldPtrs& p)
     int rw = ensure_work(c);
     if (rw != SDC_OK) return rw;
     STORE_SPECTRA(c, first == c->M - 1 && nf == 1);
+    if (!(first == c->M - 1 && nf == 1)) {
+        int rcn = need_node_spectra(c);
+        if (rcn != SDC_OK) return rcn;
+    }
     const double invN = 1.0 / (double)c->N;
     // (the last node's spectrum lives behind its own pointer)
     const bool has_last = first + nf == c->M;
@@ -973,17 +1081,17 @@ __global__ void k_init_field(double* __restrict__ out, int ndim, int n, int f0, 
 }
 
 template <int N>
-static int residual_shift_n(sdc_ctx* c, cd* dbuf, const cd* newS0) {
+static int residual_shift_n(sdc_ctx* c, cd* dbuf, const cd* newS0, const cd* oldS0) {
     constexpr int P = N / fft_elems(N), LPB = z_lines_per_block<N>();
     const int n = c->n;
     const size_t lines = (size_t)(n / 2 + 1) * (c->ndim == 3 ? n : 1);
     {
-        // d = new - old start value, through the contiguous-axis inverse pass, in place over the old spectrum
+        // d = new - old start value, through the contiguous-axis inverse pass (dbuf may be the old spectrum itself: in place)
         LaunchTimer lt(c, pname("fft_z_diff", 1));
         const size_t ldsz = (size_t)LayContig<N>::doubles(LPB) * sizeof(double);
         hipLaunchKernelGGL((k_fftz_plain<N, +1>), dim3((unsigned)((lines + LPB - 1) / LPB)), dim3(P * LPB), ldsz, c->stream,
                            newS0, dbuf, c->Nc, c->tw, (unsigned)lines, 1.0 / (double)c->N, (const cd*)nullptr, -1,
-                           (const cd*)nullptr, (const cd*)nullptr, 0, (const cd*)dbuf);
+                           (const cd*)nullptr, (const cd*)nullptr, 0, oldS0);
     }
     HIPCHK(c, hipGetLastError());
     if (c->ndim == 3) {
@@ -997,6 +1105,66 @@ static int residual_shift_n(sdc_ctx* c, cd* dbuf, const cd* newS0) {
     FieldPtrs p;
     memset(&p, 0, sizeof p);
     return inverse_tail_x_only<N>(c, c->M, c->W, p, c->res_dev, dbuf);
+}
+
+// publishing launch of one residual ticket (see k_publish_residual below)
+static int publish_ticket(sdc_ctx* c, const PendingTicket& t, const unsigned long long* norms);
+
+// Residual norms whose last inverse pass was put off (inverse_tail_n, defer_x): run it now - alone, or, when the start value
+// has been replaced since (sdc_replace_u0_spectrum), as the pass that reduces the norms before AND after the receive - and
+// publish the tickets that wait for it.  Everything that is about to overwrite W, the norm slots or the spectra involved
+// comes through here first.
+static int flush_x(sdc_ctx* c) {
+    PendingX& xp = c->xp;
+    if (!xp.pending) return SDC_OK;
+    xp.pending = false;
+    const unsigned long long* before = c->res_dev;
+    FieldPtrs p0;
+    memset(&p0, 0, sizeof p0);
+    int rc = SDC_OK;
+    if (xp.has_delta) {
+        cd* dbuf = spool_get(c);
+        cd* dscr = dbuf ? spool_get(c) : nullptr;
+        if (!dbuf || !dscr) {
+            spool_put(c, dbuf);
+            return SDC_ERR_NOMEM;
+        }
+        HIPCHK(c, hipMemsetAsync(c->res_devA, 0, sizeof(unsigned long long) * 8, c->stream));
+#define CALL(NN) joint_norms_n<NN>(c, xp.nf, c->W, xp.d_new, xp.d_old, dbuf, dscr, c->res_dev, c->res_devA)
+        rc = [&]() -> int { N_DISPATCH(c, CALL) }();
+#undef CALL
+        spool_put(c, dbuf);   // (stream-ordered: whoever takes them next works behind these launches)
+        spool_put(c, dscr);
+        before = c->res_devA;
+        c->rlines_valid = false;   // W + d is what the current norms describe
+    } else {
+#define CALL(NN) inverse_tail_n<NN>(c, xp.nf, c->W, p0, c->res_dev, true)
+        rc = [&]() -> int { N_DISPATCH(c, CALL) }();
+#undef CALL
+    }
+    if (rc != SDC_OK) return rc;
+    for (const PendingTicket& t : xp.tickets) {
+        rc = publish_ticket(c, t, (xp.has_delta && !t.after) ? before : c->res_dev);
+        if (rc != SDC_OK) return rc;
+    }
+    xp.tickets.clear();
+    xp.has_delta = false;
+    xp.d_old = xp.d_new = nullptr;
+    return SDC_OK;
+}
+
+// the trail of unstored sweeps is over (its iterate was stored, or its state is gone): the start values it depended on -
+// all but the current one - are spare buffers again
+static int trail_reset(sdc_ctx* c) {
+    if (c->trail_ns == 0) return SDC_OK;
+    if (c->xp.pending && c->xp.has_delta) FLUSH_X(c);   // (reads two of them)
+    for (int i = 0; i < c->trail_ns; ++i) {
+        const cd* b = c->trail_src[i];
+        if (b != c->S0 && b != c->SL && b != c->Sin) spool_put(c, b);
+        c->trail_src[i] = nullptr;
+    }
+    c->trail_ns = 0;
+    return SDC_OK;
 }
 
 extern "C" {
@@ -1040,20 +1208,30 @@ int sdc_ctx_create(sdc_ctx** out, int device, int ndim, int n, int num_nodes, in
     int rc = [&]() -> int {
         HIPCHK(nullptr, hipSetDevice(device));
         const size_t fb = c->N * sizeof(double);
-        HIPCHK(nullptr, hipMalloc((void**)&c->U, fb * (c->M + 1)));
-        HIPCHK(nullptr, hipMalloc((void**)&c->F, fb * (c->M + 1) * ncomp));
+        if (const char* lm = getenv("SDC_LAZY_MIN_BYTES")) c->lazy_min_bytes = (size_t)strtoull(lm, nullptr, 10);
+        // U[0] is there from the start; U[1..M] and F are mapped when something first touches them in real space (the sweeps
+        // that stay in Fourier space never do)
+        c->bytes = 0;
+        int rcs = slab_reserve(c, c->slabU, fb, c->M + 1, 1);
+        if (rcs == SDC_OK) rcs = slab_reserve(c, c->slabF, fb, (c->M + 1) * ncomp, 0);
+        if (rcs != SDC_OK) {
+            g_create_err = c->err;
+            return rcs;
+        }
+        c->U = reinterpret_cast<double*>(c->slabU.base);
+        c->F = reinterpret_cast<double*>(c->slabF.base);
         HIPCHK(nullptr, hipMalloc((void**)&c->UEND, fb));
         HIPCHK(nullptr, hipMalloc((void**)&c->red, sizeof(unsigned long long) * 16));
         HIPCHK(nullptr, hipHostMalloc((void**)&c->red_host, sizeof(unsigned long long) * 16));
         HIPCHK(nullptr, hipHostMalloc((void**)&c->ring, sizeof(ResRecord) * RES_RING, hipHostMallocMapped | hipHostMallocCoherent));
         memset(c->ring, 0, sizeof(ResRecord) * RES_RING);
         HIPCHK(nullptr, hipHostGetDevicePointer((void**)&c->ring_dev, c->ring, 0));
-        c->bytes = fb * (c->M + 1) * (1 + ncomp) + fb;
+        c->bytes += fb;
         HIPCHK(nullptr, hipMalloc((void**)&c->counters, sizeof(unsigned long long) * 4));
-        HIPCHK(nullptr, hipMalloc((void**)&c->res_dev, sizeof(unsigned long long) * 8));
+        HIPCHK(nullptr, hipMalloc((void**)&c->res_dev, sizeof(unsigned long long) * 16));
+        c->res_devA = c->res_dev + 8;
         HIPCHK(nullptr, hipMemsetAsync(c->counters, 0, sizeof(unsigned long long) * 4, c->stream));
-        HIPCHK(nullptr, hipMemsetAsync(c->U, 0, fb * (c->M + 1), c->stream));
-        HIPCHK(nullptr, hipMemsetAsync(c->F, 0, fb * (c->M + 1) * ncomp, c->stream));
+        HIPCHK(nullptr, hipMemsetAsync(c->res_dev, 0, sizeof(unsigned long long) * 16, c->stream));
         HIPCHK(nullptr, hipMemsetAsync(c->UEND, 0, fb, c->stream));
         HIPCHK(nullptr, hipEventCreate(&c->ev0));
         HIPCHK(nullptr, hipEventCreate(&c->ev1));
@@ -1083,10 +1261,13 @@ int sdc_ctx_create(sdc_ctx** out, int device, int ndim, int n, int num_nodes, in
 
 int sdc_ctx_destroy(sdc_ctx* c) {
     if (!c) return SDC_OK;
+    (void)flush_x(c);
     comm_free(c);
     (void)hipStreamSynchronize(c->stream);
-    (void)hipFree(c->U);
-    (void)hipFree(c->F);
+    slab_free(c->slabU);
+    slab_free(c->slabF);
+    slab_free(c->slabS);
+    for (cd* b : c->spool_owned) (void)hipFree(b);
     (void)hipFree(c->TAU);
     (void)hipFree(c->UEND);
     (void)hipFree(c->W);
@@ -1097,9 +1278,7 @@ int sdc_ctx_destroy(sdc_ctx* c) {
     (void)hipFree(c->gmw);
     (void)hipFree(c->SP);
     if (c->uend_ev) (void)hipEventDestroy(c->uend_ev);
-    (void)hipFree(c->S);
     (void)hipFree(c->Sx);
-    (void)hipFree(c->Sy);
     (void)hipFree(c->Wend);
     if (c->ring) (void)hipHostFree(c->ring);
     for (double* b : c->odd_buf) (void)hipFree(b);
@@ -1306,6 +1485,7 @@ extern "C" int sdc_solve(sdc_ctx* c, const double* rhs, double factor, const dou
 extern "C" int sdc_eval_f(sdc_ctx* c, const double* u, double g_t, double* f_impl, double* f_expl);
 
 static int ensure_work(sdc_ctx* c) {
+    FLUSH_X(c);               // (residual lines that still wait for their last pass)
     c->rlines_valid = false;  // whoever asks for the work spectra is about to overwrite them (a sweep says so again afterwards)
     if (!c->W) {
         HIPCHK(c, hipMalloc((void**)&c->W, sizeof(cd) * c->Nc * c->M));
@@ -1325,11 +1505,16 @@ static int ensure_tau(sdc_ctx* c) {
 
 static int ensure_spec_cache(sdc_ctx* c) {
     if (!c->S) {
-        HIPCHK(c, hipMalloc((void**)&c->S, sizeof(cd) * c->Nc * c->M));
+        // the last node's slot is there from the start (it takes turns with the start value's spectrum); the other node
+        // spectra are mapped when an iterate is first STORED (need_node_spectra) - sweeps that recompute their iterate never do
+        int rcs = slab_reserve(c, c->slabS, sizeof(cd) * c->Nc, c->M, 0);
+        if (rcs == SDC_OK) rcs = slab_map(c, c->slabS, c->M - 1, 1);
+        if (rcs != SDC_OK) return rcs;
+        c->S = reinterpret_cast<cd*>(c->slabS.base);
         HIPCHK(c, hipMalloc((void**)&c->Sx, sizeof(cd) * c->Nc));
         c->S0 = c->Sx;
         c->SL = c->S + (size_t)(c->M - 1) * c->Nc;
-        c->bytes += sizeof(cd) * c->Nc * (c->M + 1);
+        c->bytes += sizeof(cd) * c->Nc;
         c->spec_valid = c->spec0_valid = false;
     }
     // the second end-value buffer of sdc_advance, allocated with the cache (not inside a time loop) - unless this is a
@@ -1345,6 +1530,7 @@ static int ensure_spec_cache(sdc_ctx* c) {
 static int launch_spread(sdc_ctx* c, int guess, double fill_u, double fill_f, bool reduce_f0) {
     SpreadArgs a;
     memset(&a, 0, sizeof a);
+    NEED_NODES(c);
     U0R(c, u0p);
     a.u0 = u0p;
     a.f0 = c->F;
@@ -1382,6 +1568,7 @@ static int launch_spread(sdc_ctx* c, int guess, double fill_u, double fill_f, bo
 
 // bring deferred real-space state up to date before it is read (or partially overwritten)
 static int materialize(sdc_ctx* c, bool need_u, bool need_f) {
+    if (need_u || need_f) NEED_NODES(c);
     if (c->spread_pending && (need_u || need_f)) {
         if (c->f0_pending) {  // the copies are copies of F[0]
             U0R(c, u0p);
@@ -1419,17 +1606,24 @@ int sdc_materialize(sdc_ctx* c, int slot, int m) {
             if (rc0 != SDC_OK) return rc0;
         }
         if (c->f0_pending) {
+            int rcf = need_f0(c);
+            if (rcf != SDC_OK) return rcf;
             c->f0_pending = false;
             return sdc_eval_f(c, c->U, c->gvals[0], c->F, c->ncomp == 2 ? c->F + c->N : nullptr);
         }
         return SDC_OK;
     }
     if (slot == SDC_SLOT_F && m == 0) {
+        {
+            int rcf = need_f0(c);
+            if (rcf != SDC_OK) return rcf;
+        }
         if (!c->f0_pending) return SDC_OK;
         U0R(c, u0p);
         c->f0_pending = false;
         return sdc_eval_f(c, u0p, c->gvals[0], c->F, c->ncomp == 2 ? c->F + c->N : nullptr);
     }
+    NEED_NODES(c);
     if (slot < 0) ENSURE_U0(c);  // "everything": all of the real-space state is about to be used as it is stored
     if (slot < 0 && c->f0_pending) {
         c->f0_pending = false;
@@ -1467,6 +1661,7 @@ void* sdc_slot_ptr(sdc_ctx* c, int slot, int m, int comp) {
     if (!c) return nullptr;
     // whoever asks for the address of a node field is about to read or write it
     if ((slot == SDC_SLOT_U || slot == SDC_SLOT_F) && sdc_materialize(c, slot, m) != SDC_OK) return nullptr;
+    if (((slot == SDC_SLOT_U && m != 0) || (slot == SDC_SLOT_F && m != 0)) && need_nodes(c) != SDC_OK) return nullptr;
     if (slot == SDC_SLOT_TAU && ensure_tau(c) != SDC_OK) return nullptr;
     if (slot == SDC_SLOT_UEND) {
         if (materialize_uend(c) != SDC_OK) return nullptr;
@@ -1641,7 +1836,8 @@ int sdc_eval_f(sdc_ctx* c, const double* u, double g_t, double* f_impl, double* 
         if (f_expl) {
             if (c->expl_kind != SDC_EXPL_FORCING || !c->profile)
                 return fail(c, SDC_ERR_UNSUPPORTED, "the banded operator evaluates the implicit part (and a forcing profile) only");
-            int rcp = sdc_vec_axpby(c, c->N, g_t, c->profile, 0.0, nullptr, f_expl);
+            // (compact fields: Nb values - the caller's f_expl need not be longer than that)
+            int rcp = sdc_vec_axpby(c, problem_size(c), g_t, c->profile, 0.0, nullptr, f_expl);
             if (rcp != SDC_OK) return rcp;
         }
         return apply_operator(c, u, f_impl);
@@ -1757,6 +1953,7 @@ int sdc_predict(sdc_ctx* c, double t, double dt, int guess, double fill_u, doubl
     if (!c) return SDC_ERR_PARAM;
     if (!c->have_coeffs) return fail(c, SDC_ERR_STATE, "coefficients not set (sdc_set_coeffs)");
     if (guess < 0 || guess > 3) return fail(c, SDC_ERR_PARAM, "initial_guess option %d not implemented", guess);
+    FLUSH_X(c);
     // a put-off end value is the inverse transform of the iterate this predictor is about to drop (the reference's
     // predict leaves L.uend alone, core/sweeper.py:125-162)
     MATERIALIZE_UEND(c);
@@ -1814,13 +2011,16 @@ int sdc_predict(sdc_ctx* c, double t, double dt, int guess, double fill_u, doubl
     } else {
         U0R(c, u0p);
         if (c->kind == 1 && lazy_spread && spread_res) {  // max |f(u0)| on the way (no second pass over F[0])
+            rc = need_f0(c);
+            if (rc != SDC_OK) return rc;
             LaunchTimer lt(c, "vdp_eval");
             hipLaunchKernelGGL(k_vdp_eval, dim3(grid_for(c->N / 4, 256)), dim3(256), 0, c->stream, u0p, c->F, c->N / 2,
                                c->vdp_mu, c->counters, c->res_dev + 7);
             HIPCHK(c, hipGetLastError());
             f0_max_done = true;
         } else {
-            rc = sdc_eval_f(c, u0p, c->gvals[0], c->F, c->ncomp == 2 ? c->F + c->N : nullptr);
+            rc = need_f0(c);
+            if (rc == SDC_OK) rc = sdc_eval_f(c, u0p, c->gvals[0], c->F, c->ncomp == 2 ? c->F + c->N : nullptr);
             if (rc != SDC_OK) return rc;
         }
     }
@@ -1979,6 +2179,7 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
     c->res_spread = false;
     c->rfields_valid = false;
     if (c->kind == 1) {
+        NEED_NODES(c);
         VdpSweepArgs a;
         memset(&a, 0, sizeof a);
         a.U = c->U;
@@ -2100,6 +2301,8 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
             // the first M-1 nodes into the strided block, the last one to wherever its spectrum lives right now
             for (int m = 0; m < M - 1; ++m) p.in[m] = c->U + (size_t)(m + 1) * c->N;
             if (M > 1) {
+                int rcn = need_node_spectra(c);   // (the iterate is stored in the node spectra from here on)
+                if (rcn != SDC_OK) return rcn;
                 int rc0 = fwd_transform(c, M - 1, p, c->S, c->Nc);
                 if (rc0 != SDC_OK) return rc0;
             }
@@ -2140,6 +2343,7 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
             // norms only: nothing is stored in real space - unless the residual FIELDS are wanted (keep_rfields),
             // which then occupy the U[1..M] slab while the iterate itself lives in the cache
             p.out[m] = (spec_only || (norms_only && !c->keep_rfields)) ? nullptr : c->U + (size_t)(m + 1) * c->N;
+            if (p.out[m]) NEED_NODES(c);
             a.alpha[m] = dt * c->QI[m + 1][m + 1];
             for (int j = 0; j < M; ++j) {
                 a.gI[m][j] = dt * (c->Q[m + 1][j + 1] - c->QI[m + 1][j + 1]);
@@ -2156,6 +2360,7 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
         // transform of u0 alone, and so is every later one while u0 and the coefficients stay what they are: a sweep
         // then reads S0 only, repeats the earlier sweeps in registers (a.replay), and stores nothing but the residual
         // lines - 6 instead of 16 spectrum passes.  store_spectra writes the iterate out when somebody needs it.
+        bool go = false;
         {
             const bool fused_z = SDC_FUSE_SPECZ && c->n >= 64 && c->n <= 1024 && M <= 5;
             // (with a residual to deliver this pays for a REAL symbol without explicit part - heat: real multipliers, and
@@ -2164,7 +2369,11 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
             // (a sweep that stores the node values - eager fields - hands the iterate itself to the transform: mode pairs only)
             const bool pairs_z = SDC_SPECZ_PAIRS && fused_z && c->n >= 512 && a.real_sym && !a.lamE;
             const bool iter_out = !spec_only && !norms_only && pairs_z;
-            bool go = c->virt_max > 0 && (c->deferred || iter_out) && !c->keep_rfields && !c->early_uend && c->ndim >= 2 &&
+            // Time-parallel levels (spectra on the wire, the end value wanted early): u[0] is replaced between the sweeps, so the
+            // unstored iterate becomes a function of ALL the start values the slice has had since its predictor - a trail
+            // (trail_iterate), kept while their number stays below trail_max; the launch always writes the last node's spectrum
+            const bool trail = c->wire_spectral && c->early_uend && c->trail_max > 0 && norms_only && pairs_z && !c->keep_rfields;
+            go = c->virt_max > 0 && (c->deferred || iter_out) && !c->keep_rfields && (!c->early_uend || trail) && c->ndim >= 2 &&
                       c->expl_kind != SDC_EXPL_FORCING &&
                       (spec_only || iter_out || (norms_only && fused_z && a.real_sym && !a.lamE));
             SpecCoef now;
@@ -2179,7 +2388,7 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
             now.has_e = a.lamE ? 1 : 0;
             // the multiplier table takes over where replaying gets dearer than 2 M doubles of traffic per mode pair - if the
             // replayed sweeps get that far (virt_max) and the table can be had
-            bool table = go && pairs_z && !spec_only && c->g_from > 0 && c->virt_max > c->g_from && c->spec_virtual >= c->g_from;
+            bool table = go && !trail && pairs_z && !spec_only && c->g_from > 0 && c->virt_max > c->g_from && c->spec_virtual >= c->g_from;
             if (table && !c->Gm) {
                 const size_t glines = (size_t)(c->n / 2 + 1) * (c->ndim == 3 ? c->n : 1);
                 const size_t gbytes = sizeof(double) * glines * (size_t)M * (size_t)(c->n / 2 + 1);
@@ -2197,7 +2406,14 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
                 if (memcmp(&now, &c->vcoef, sizeof now) != 0) c->g_sweeps = 0;
                 memcpy(&c->vcoef, &now, sizeof now);
                 a.replay = 0;
+                int rct = trail_reset(c);   // (start values of a trail that is over)
+                if (rct != SDC_OK) return rct;
+                if (trail) {
+                    c->trail_ns = 1;
+                    c->trail_src[0] = c->S0;
+                }
             } else if (go && c->spec_valid && c->spec_virtual > 0 && (c->spec_virtual < c->virt_max || table) &&
+                       (c->trail_ns > 0) == trail && (!trail || c->spec_virtual < MAXVSWEEPS) &&
                        memcmp(&now, &c->vcoef, sizeof now) == 0) {
                 a.replay = c->spec_virtual;
                 a.spread = 1;
@@ -2218,7 +2434,41 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
                 // instead of leaving it to spec_store_last (S0 read and the multipliers recomputed: 4.2 ms at 1024^3)
                 a.store_last = (pairs_z && !spec_only && a.gmode == 0 && c->prev_sweeps > 0 &&
                                 c->spec_virtual == c->prev_sweeps && SDC_STORE_LAST_IN_SWEEP) ? 1 : 0;
-                c->sl_stored = a.store_last != 0;
+                if (c->trail_ns > 0) {
+                    // this sweep starts from the current start value: the last one on the trail
+                    c->vsrc[c->spec_virtual - 1] = (unsigned char)(c->trail_ns - 1);
+                    a.ns = c->trail_ns;
+                    a.nsw = c->spec_virtual;
+                    for (int i = 0; i < c->trail_ns; ++i) a.src[i] = c->trail_src[i];
+                    memcpy(a.vsrc, c->vsrc, sizeof a.vsrc);
+                    a.store_last = 1;
+                    for (int m = 0; m < M; ++m)
+                        for (int j = 0; j < M; ++j) a.rQ[m][j] = dt * c->Q[m + 1][j + 1];
+                    if (c->split_send) {
+                        // the last node's spectrum by a launch of its own, FIRST: the message leaves while the passes that were
+                        // put off for the previous iterate (flush_x) and this sweep's own residual passes run
+                        SpecArgs al = a;
+                        al.last_only = 1;
+                        const size_t tl = c->ndim == 1 ? 1 : (size_t)(c->n / 2 + 1) * (c->ndim == 3 ? c->n : 1);
+                        const size_t nitems = tl * (size_t)(c->n / 2 + 1);
+                        size_t tb = (nitems + 255) / 256;
+                        if (tb > SDC_SPEC_GRID) tb = SDC_SPEC_GRID;
+                        {
+                            LaunchTimer lt(c, pname("trail_send", M));
+#define SCASE(MM) \
+    case MM: hipLaunchKernelGGL((k_trail_store<MM>), dim3((unsigned)tb), dim3(256), 0, c->stream, al, c->n, nitems); break;
+                            switch (M) { SCASE(1) SCASE(2) SCASE(3) SCASE(4) SCASE(5) }
+#undef SCASE
+                        }
+                        HIPCHK(c, hipGetLastError());
+                        if (!c->sl_ev) HIPCHK(c, hipEventCreateWithFlags(&c->sl_ev, hipEventDisableTiming));
+                        HIPCHK(c, hipEventRecord(c->sl_ev, c->stream));
+                        c->sl_ev_recorded = true;
+                        a.store_last = 0;
+                        c->sl_ev_by_split = true;   // (early_end_point_n: the event stands)
+                    }
+                }
+                c->sl_stored = a.store_last != 0 || (c->trail_ns > 0);
                 if (spec_only) {  // no residual wanted: nothing to launch at all - the sweep is remembered
                     c->spec_gen++;
                     c->spec_valid = true;
@@ -2233,6 +2483,11 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
         }
         // nothing downstream needs the node values in real space to keep sweeping: only the node norms of the
         // residual are produced (from its transform), U and F stay deferred
+        if (!go) {   // the iterate is (about to be) stored in the node spectra
+            int rcn = need_node_spectra(c);
+            if (rcn != SDC_OK) return rcn;
+        }
+        FLUSH_X(c);   // (norms of the previous iterate that still wait for their last pass: before the slots are cleared)
         if (norms_only) {
             for (int m = 0; m < M; ++m)
                 for (int j = 0; j < M; ++j) a.rQ[m][j] = dt * c->Q[m + 1][j + 1];
@@ -2719,6 +2974,20 @@ __global__ void k_publish_residual(PublishArgs a, ResRecord* dst, unsigned long 
     *(volatile unsigned long long*)&dst->seq = seq;
 }
 
+}  // extern "C"
+static int publish_ticket(sdc_ctx* c, const PendingTicket& t, const unsigned long long* norms) {
+    PublishArgs pa;
+    memset(&pa, 0, sizeof pa);
+    pa.M = c->M;
+    pa.type = t.type;
+    pa.restol = t.restol;
+    pa.norms = norms;
+    hipLaunchKernelGGL(k_publish_residual, dim3(1), dim3(64), 0, c->stream, pa, c->ring_dev + t.seq % RES_RING, t.seq);
+    HIPCHK(c, hipGetLastError());
+    return SDC_OK;
+}
+extern "C" {
+
 int sdc_set_restol(sdc_ctx* c, double restol) {
     if (!c) return SDC_ERR_PARAM;
     c->restol = restol;
@@ -2744,6 +3013,10 @@ int sdc_residual_post_integrals(sdc_ctx* c, double dt, int type, double* const* 
     pa.restol = c->restol;
     const unsigned long long seq = c->ring_seq + 1;
     ResRecord* slot = c->ring + seq % RES_RING;
+    // the record this ticket replaces (RES_RING tickets ago) may still be on its way - its publishing launch queued behind a
+    // long run of posts nobody waited for: let it land before the slot is written again (host or device), or it would
+    // overwrite the newer record
+    if (seq > RES_RING && slot->seq != seq - RES_RING) HIPCHK(c, hipStreamSynchronize(c->stream));
     // the sweep that reduced these norms ended with a look at its counters anyway (van der Pol: Newton failures are reported
     // by the sweep) and brought the norms along: nothing to launch, copy or wait for - the host writes the record itself
     const bool on_host = c->kind == 1 && c->res_valid && c->res_dt == dt && c->res_host_valid && type < SDC_RES_FULL_REL;
@@ -2762,6 +3035,18 @@ int sdc_residual_post_integrals(sdc_ctx* c, double dt, int type, double* const* 
         c->ring_seq = seq;
         *ticket = seq;
         return SDC_OK;
+    }
+    if (c->xp.pending) {
+        if (c->res_valid && c->res_dt == dt && type < SDC_RES_FULL_REL) {
+            // the norms of this very state wait for their last inverse pass (flush_x): the ticket waits with them - for the
+            // start value the rank is about to receive, the next sweep, or somebody who asks (sdc_residual_wait)
+            slot->seq = 0;
+            c->xp.tickets.push_back(PendingTicket{seq, type, c->xp.has_delta ? 1 : 0, c->restol});
+            c->ring_seq = seq;
+            *ticket = seq;
+            return SDC_OK;
+        }
+        FLUSH_X(c);
     }
     if (c->res_valid && c->res_dt == dt) {
         // the sweep's fused kernels already reduced the node norms of this very state
@@ -2828,6 +3113,16 @@ int sdc_residual_post_integrals(sdc_ctx* c, double dt, int type, double* const* 
     return SDC_OK;
 }
 
+int sdc_residual_route(sdc_ctx* c, double dt) {
+    if (!c) return SDC_ERR_PARAM;
+    if (c->res_valid && c->res_dt == dt) return 0;
+    if (c->res_spread) return 1;
+    if (c->u_pending && !c->spread_pending && c->spec_valid && !c->tau_active && c->ndim >= 2) return 2;
+    return 3;
+}
+
+unsigned long long sdc_residual_last_ticket(sdc_ctx* c) { return c ? c->ring_seq : 0; }
+
 int sdc_residual_wait(sdc_ctx* c, unsigned long long ticket, int block, double* node_norms, double* residual, int* converged,
                       int* ready) {
     if (!c || !ready) return fail(c, SDC_ERR_PARAM, "null pointer");
@@ -2836,6 +3131,7 @@ int sdc_residual_wait(sdc_ctx* c, unsigned long long ticket, int block, double* 
                     RES_RING);
     volatile ResRecord* r = c->ring + ticket % RES_RING;
     *ready = r->seq == ticket;
+    if (!*ready && block && c->xp.pending) FLUSH_X(c);   // (the record may be waiting for a pass that was put off)
     if (!*ready && block) {
         // the record arrives by itself when the stream gets there; look at it for a while, then wait on the stream (which
         // also surfaces a launch that failed)
@@ -2894,7 +3190,10 @@ int sdc_end_point(sdc_ctx* c, double dt, int do_coll_update) {
             return rci;
         }
         // a pending spread means U[M] equals U[0]
-        if (!c->spread_pending) return sdc_vec_copy(c, c->N, c->U + (size_t)c->M * c->N, c->UEND);
+        if (!c->spread_pending) {
+            NEED_NODES(c);
+            return sdc_vec_copy(c, c->N, c->U + (size_t)c->M * c->N, c->UEND);
+        }
         U0R(c, u0p);
         return sdc_vec_copy(c, c->N, u0p, c->UEND);
     }
@@ -2916,6 +3215,7 @@ int sdc_end_point(sdc_ctx* c, double dt, int do_coll_update) {
 
 int sdc_advance(sdc_ctx* c) {
     if (!c) return SDC_ERR_PARAM;
+    FLUSH_X(c);
     int rcm = materialize(c, c->spread_pending, false);  // pending copies of the OLD u[0] are stored first
     if (rcm != SDC_OK) return rcm;
     c->res_valid = false;
@@ -2925,6 +3225,12 @@ int sdc_advance(sdc_ctx* c) {
     const bool handover = c->S && c->spec_valid && c->uend_gen >= 0 && c->uend_gen == c->spec_gen;
     c->prev_sweeps = (c->spec_valid && c->spec_virtual > 0) ? c->spec_virtual : 0;
     if (handover) STORE_SPECTRA(c, true);  // (SL has to BE there; S0 changes below)
+    if (handover) {
+        // the step is over (every handover branch below drops its iterate): the start values its trail depended on are spare
+        // buffers again - all but the current one and the last node's spectrum, which trade places
+        int rct = trail_reset(c);
+        if (rct != SDC_OK) return rct;
+    }
     if (handover && c->uend_pending && c->kind == 0 && c->deferred) {
         // the end value was never transformed back: the start value of the new step exists as its transform only
         std::swap(c->S0, c->SL);
@@ -2973,6 +3279,17 @@ int sdc_advance(sdc_ctx* c) {
     return SDC_OK;
 }
 
+int sdc_set_timeslice_options(sdc_ctx* c, int trail_sources, int defer_last_pass, int split_send) {
+    if (!c || trail_sources < 0 || trail_sources > MAXTRAIL)
+        return fail(c, SDC_ERR_PARAM, "trail: 0 .. %d start values", MAXTRAIL);
+    FLUSH_X(c);
+    if (trail_sources < c->trail_max) STORE_SPECTRA(c, false);
+    c->trail_max = trail_sources;
+    c->defer_x = defer_last_pass != 0;
+    c->split_send = split_send != 0;
+    return SDC_OK;
+}
+
 int sdc_set_early_end_point(sdc_ctx* c, int on) {
     if (!c) return SDC_ERR_PARAM;
     c->early_uend = on != 0;
@@ -3002,6 +3319,7 @@ int sdc_set_keep_residual_fields(sdc_ctx* c, int on) {
 
 int sdc_replace_u0(sdc_ctx* c, const double* src) {
     if (!c || !src) return fail(c, SDC_ERR_PARAM, "null pointer");
+    FLUSH_X(c);
     ENSURE_U0(c);  // (the update of the kept residual fields reads the old start value)
     int rcm = materialize(c, c->spread_pending, false);  // pending copies of the OLD u[0] are stored first
     if (rcm != SDC_OK) return rcm;
@@ -3048,14 +3366,12 @@ int sdc_set_wire_spectral(sdc_ctx* c, int on) {
 // device address of the half spectrum (Nc complex values) a received start value is to be written to
 void* sdc_spectrum_inbox(sdc_ctx* c) {
     if (!c || ensure_spec_cache(c) != SDC_OK) return nullptr;
-    if (!c->Sy) {
-        if (hipMalloc((void**)&c->Sy, sizeof(cd) * c->Nc) != hipSuccess) {
-            fail(c, SDC_ERR_NOMEM, "spectrum inbox: out of device memory");
-            return nullptr;
-        }
-        c->bytes += sizeof(cd) * c->Nc;
-        c->Sin = c->Sy;
+    if (!c->Sin) {
+        c->Sin = spool_get(c);
+        if (!c->Sin) return nullptr;
     }
+    // (a pass that was put off reads the old start value, which - off a trail - is the buffer the next message lands in)
+    if (c->xp.pending && c->xp.has_delta && (c->xp.d_old == c->Sin || c->xp.d_new == c->Sin) && flush_x(c) != SDC_OK) return nullptr;
     return c->Sin;
 }
 
@@ -3104,23 +3420,50 @@ void* sdc_end_spectrum(sdc_ctx* c, void* stream) {
 int sdc_replace_u0_spectrum(sdc_ctx* c) {
     if (!c || !c->Sin) return fail(c, SDC_ERR_STATE, "no spectrum inbox (sdc_spectrum_inbox)");
     if (!spectral_level(c)) return fail(c, SDC_ERR_STATE, "this level does not sweep in Fourier space");
-    STORE_SPECTRA(c, false);  // (an iterate that was not stored is a function of the OLD start value)
+    // An iterate that was not stored is a function of the start values so far: on a trail the old one simply stays on record
+    // (the received one joins it); otherwise the iterate is written out before its only source goes
+    const bool on_trail = c->spec_valid && c->spec_virtual > 0 && c->trail_ns > 0 && c->trail_ns < c->trail_max &&
+                          c->trail_ns < MAXTRAIL && c->trail_src[c->trail_ns - 1] == c->S0 && !c->tau_active;
+    if (!on_trail) STORE_SPECTRA(c, false);
     int rcm = materialize(c, c->spread_pending, false);  // pending copies of the OLD u[0] are stored first
     if (rcm != SDC_OK) return rcm;
-    const bool fast = c->rlines_valid && c->res_valid && c->u_pending && c->spec0_valid && c->spec_valid && !c->tau_active &&
-                      c->expl_kind != SDC_EXPL_FORCING;
-    if (fast) {
-        HIPCHK(c, hipMemsetAsync(c->res_dev, 0, sizeof(unsigned long long) * 8, c->stream));
-        cd* dbuf = c->S0;
-#define CALL(NN) residual_shift_n<NN>(c, dbuf, c->Sin)
-        int rcd = [&]() -> int { N_DISPATCH(c, CALL) }();
-#undef CALL
-        if (rcd != SDC_OK) return rcd;
-        c->rlines_valid = false;  // W + d is what the norms describe now, W alone is not
+    const bool linear_shift = c->res_valid && c->u_pending && c->spec0_valid && c->spec_valid && !c->tau_active &&
+                              c->expl_kind != SDC_EXPL_FORCING;
+    if (c->xp.pending && !c->xp.has_delta && linear_shift && c->n >= 64) {
+        // the residual lines of the sweep still wait for their last pass: it will reduce the norms before and after this
+        // receive in one go (flush_x) - the residual of every node changes by d = new - old (core/sweeper.py:186-199 is linear
+        // in u[0]).  Nothing is launched here.
+        c->xp.has_delta = true;
+        c->xp.d_old = c->S0;
+        c->xp.d_new = c->Sin;
     } else {
-        c->res_valid = false;
+        FLUSH_X(c);
+        const bool fast = c->rlines_valid && linear_shift;
+        if (fast) {
+            HIPCHK(c, hipMemsetAsync(c->res_dev, 0, sizeof(unsigned long long) * 8, c->stream));
+            // the difference goes through the passes in place over the old spectrum - or, when that one stays on the trail,
+            // through a spare buffer
+            cd* dbuf = on_trail ? spool_get(c) : c->S0;
+            if (!dbuf) return SDC_ERR_NOMEM;
+#define CALL(NN) residual_shift_n<NN>(c, dbuf, c->Sin, c->S0)
+            int rcd = [&]() -> int { N_DISPATCH(c, CALL) }();
+#undef CALL
+            if (on_trail) spool_put(c, dbuf);
+            if (rcd != SDC_OK) return rcd;
+            c->rlines_valid = false;  // W + d is what the norms describe now, W alone is not
+        } else {
+            c->res_valid = false;
+        }
     }
-    std::swap(c->S0, c->Sin);
+    if (on_trail) {
+        cd* next_inbox = spool_get(c);
+        if (!next_inbox) return SDC_ERR_NOMEM;
+        c->trail_src[c->trail_ns++] = c->Sin;
+        c->S0 = c->Sin;
+        c->Sin = next_inbox;
+    } else {
+        std::swap(c->S0, c->Sin);
+    }
     c->spec0_valid = true;
     c->u0_spec_only = true;  // U[0] is produced from the spectrum when somebody reads it there
     c->u0_src = nullptr;
@@ -3136,6 +3479,11 @@ int sdc_replace_u0_spectrum(sdc_ctx* c) {
 int sdc_start_from_spectrum(sdc_ctx* c) {
     if (!c || !c->Sin) return fail(c, SDC_ERR_STATE, "no spectrum inbox (sdc_spectrum_inbox)");
     if (!spectral_level(c)) return fail(c, SDC_ERR_STATE, "this level does not sweep in Fourier space");
+    FLUSH_X(c);   // (norms of the finished block that still wait for their last pass read the spectra that move below)
+    {
+        int rct = trail_reset(c);
+        if (rct != SDC_OK) return rct;
+    }
     std::swap(c->S0, c->Sin);
     c->spec0_valid = true;
     c->u0_spec_only = true;
@@ -3405,6 +3753,7 @@ int sdc_odd_extract(sdc_ctx* c, const double* ext, double* interior, int n_inter
 
 int sdc_sync(sdc_ctx* c) {
     if (!c) return SDC_ERR_PARAM;
+    FLUSH_X(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return SDC_OK;
 }

@@ -20,15 +20,16 @@ class ResidualFuture:
     evaluates what it holds).  ``fetch(block)`` returns (residual, norms, converged) or None while the record is not there."""
 
     queued = True    # (the work is on the stream already: nothing about it has to happen before the state changes)
-    __slots__ = ('_fetch_fn', '_value', '_norms', '_converged', '__weakref__')
+    __slots__ = ('_fetch_fn', '_value', '_norms', '_converged', 'restol', '__weakref__')
 
-    def __init__(self, fetch):
+    def __init__(self, fetch, restol=-1.0):
         self._fetch_fn, self._value, self._norms, self._converged = fetch, None, None, None
+        self.restol = restol    # the tolerance the device's flag is taken against (a reader with another one compares itself)
 
     @classmethod
     def ready(cls, value, norms, restol=-1.0):
         """a residual that is known already (engines without a queue: tests/_host_engine.py)"""
-        f = cls(None)
+        f = cls(None, restol)
         f._value, f._norms, f._converged = float(value), np.array(norms, dtype=float), bool(restol >= 0 and value <= restol)
         return f
 
@@ -201,6 +202,10 @@ class SweepEngine:
         """leave F[1..M] / the spread copies unwritten until they are read (include/sdcmi.h: sdc_set_deferred)"""
         self._chk(self.lib.sdc_set_deferred(self.ctx, int(bool(on))))
 
+    def set_timeslice_options(self, trail_sources=5, defer_last_pass=True, split_send=False):
+        """how a time-parallel level deals with a u[0] that is replaced between sweeps (include/sdcmi.h)"""
+        self._chk(self.lib.sdc_set_timeslice_options(self.ctx, int(trail_sources), int(bool(defer_last_pass)), int(bool(split_send))))
+
     def set_early_end_point(self, on):
         self._chk(self.lib.sdc_set_early_end_point(self.ctx, int(bool(on))))
 
@@ -305,9 +310,19 @@ class SweepEngine:
         norms = np.zeros(self.M)
         res = C.c_double()
         self._retire_old_tickets()
-        self._chk(self.lib.sdc_residual(self.ctx, dt, L.RES_TYPES[residual_type], _dptr(norms), C.byref(res)))
-        self._issued += 1        # (a ticket of the same ring)
+        try:
+            self._chk(self.lib.sdc_residual(self.ctx, dt, L.RES_TYPES[residual_type], _dptr(norms), C.byref(res)))
+        finally:
+            self._issued = int(self.lib.sdc_residual_last_ticket(self.ctx))   # (a ticket of the same ring, taken even by a call that failed)
         return res.value, norms
+
+    def residual_route(self, dt):
+        """where a residual asked for now would come from (include/sdcmi.h: sdc_residual_route); 3 = a pass over F in real
+        space, the only route that can bring the quadrature sums along"""
+        rc = self.lib.sdc_residual_route(self.ctx, dt)
+        if rc < 0:
+            self._chk(rc)
+        return rc
 
     def residual_post(self, dt, residual_type='full_abs', restol=-1.0, integrals=None):
         """queue the residual of the current state and return a ResidualFuture at once (no synchronisation); restol is the
@@ -344,7 +359,7 @@ class SweepEngine:
                                                  C.byref(ready)))
             return (res.value, norms, bool(conv.value)) if ready.value else None
 
-        fut = ResidualFuture(fetch)
+        fut = ResidualFuture(fetch, restol)
         self._futures.append((ticket, weakref.ref(fut)))
         return fut
 

@@ -53,7 +53,10 @@ class LevelStatus(_Frozen):
     def residual(self):
         r = self._residual
         if callable(r):
-            self._residual = None     # (a thunk that fails is not called again)
+            if not getattr(r, 'queued', False):
+                self._residual = None     # (a thunk that fails is not called again)
+            # (a residual that is on its way stays where it is should collecting it fail: the engine's error surfaces again
+            # for the next reader instead of a None that no comparison understands)
             r = self._residual = r()
         return r
 

@@ -54,6 +54,9 @@ PROTOTYPES = {
     'sdc_residual_wait': (C.c_int, [_vp, C.c_ulonglong, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                     C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     'sdc_residual_deferred': (C.c_int, [_vp]),
+    'sdc_residual_route': (C.c_int, [_vp, C.c_double]),
+    'sdc_set_timeslice_options': (C.c_int, [_vp, C.c_int, C.c_int, C.c_int]),
+    'sdc_residual_last_ticket': (C.c_ulonglong, [_vp]),
     'sdc_set_deferred': (C.c_int, [_vp, C.c_int]),
     'sdc_set_solver': (C.c_int, [_vp, C.c_int, C.c_double, C.c_int]),
     'sdc_set_banded_operator': (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_int), _dp]),

@@ -246,8 +246,10 @@ class Sweeper:
                 # against restol and leaves both in pinned host memory; whoever reads L.status.residual, L.residual or the
                 # convergence flag collects them there - a run with a fixed number of sweeps never waits
                 me = None
-                if getattr(D, 'integrals_wanted', False) and not D._view_offset() and stage in ('IT_FINE', 'IT_DOWN', 'IT_UP'):
-                    # a coarser level follows: its FAS correction starts from integrate() of THIS state (BaseTransfer.restrict)
+                if (getattr(D, 'integrals_wanted', False) and not D._view_offset() and stage in ('IT_FINE', 'IT_DOWN', 'IT_UP')
+                        and getattr(D.engine, 'residual_route', lambda dt: 3)(L.dt) == 3):
+                    # a coarser level follows: its FAS correction starts from integrate() of THIS state (BaseTransfer.restrict) -
+                    # and this residual is one pass over F in real space (the only route that can write the sums on its way)
                     me = self._integral_fields()
                 fut = D.engine.residual_post(L.dt, rt, restol=L.params.restol,
                                              integrals=None if me is None else [x.ptr for x in me])

@@ -53,27 +53,46 @@ for keep in [dict(spectral='spectral', overlap='overlap', fields=True, recompute
     e.residual(dt)
     uend = torch.as_tensor(_CAI(e.ptr(L.SLOT_UEND), e.N, e), device='cuda')
     nspec = 2 * (n // 2 + 1) * n * n
+    futures, inbox_free = [], None
+    if keep == 'spectral':
+        opts = [int(v) for v in os.environ.get('EMU_OPTS', '5,1,0').split(',')]   # trail sources, deferred last pass, split send
+        e.set_timeslice_options(*opts)
     # (one untimed iteration first: buffers that only this data flow needs - the spectrum inbox, the difference spectrum - are
     # allocated by its first use, and an 8.6 GB hipMalloc can take 100 ms on a fresh box)
-    for k in range(iters + 1):
-        if k == 1:
+    K = int(os.environ.get('EMU_SWEEPS', '4'))    # sweeps per block (the bench's 4): every block starts from a spread predictor
+    for k in range(iters + (K if keep == 'spectral' else 1)):
+        if k == (K if keep == 'spectral' else 1):
+            for f in futures:
+                f.result()
+            futures = []
             e.profile_read()
             e.profile_enable(True)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
+        if keep == 'spectral' and k % K == 0:
+            # a new block: the slice starts from the end value of the block before as a spectrum (here: its own), predicts,
+            # and - like every rank of a block - skips the first hand-over (all of them hold the same start value)
+            e.end_point(dt, False)
+            e.advance()
+            e.predict(0.0, dt)
+            futures.append(e.residual_post(dt))
         e.sweep(0.0, dt)
         if keep == 'spectral':
             e.end_point(dt, False)          # put off: the end value is the last node's spectrum
             src = torch.as_tensor(_CAI(e.end_spectrum(side.cuda_stream), nspec, e), device='cuda')
             dst = torch.as_tensor(_CAI(e.spectrum_inbox(), nspec, e), device='cuda')
             e.invalidate_spectra(8)         # (what the communicator does: the end value existed for the wire only)
-            with torch.cuda.stream(side):   # the message, posted behind the first launch of the sweep only
+            with torch.cuda.stream(side):   # the message, posted behind the launch that wrote the last node's spectrum only
+                if inbox_free is not None:  # (... and behind the engine's last use of the buffer it lands in: sdc_comm's inbox_free)
+                    side.wait_event(inbox_free)
                 for _ in range(copies):
                     dst.copy_(src)
-            e.residual(dt)                  # IT_FINE, while the message travels
+            futures.append(e.residual_post(dt))   # IT_FINE: queued; its last pass waits for the receive (defer_last_pass)
             torch.cuda.current_stream().wait_stream(side)
-            e.replace_u0_spectrum()         # what arrives: node norms from one more field through the inverse passes
-            e.residual(dt)                  # IT_CHECK
+            e.replace_u0_spectrum()         # what arrives
+            inbox_free = torch.cuda.Event()
+            inbox_free.record()
+            futures.append(e.residual_post(dt))   # IT_CHECK
             continue
         if keep == 'overlap':
             e.end_point(dt, False)          # free: the sweep produced UEND right after the spectral update
@@ -91,9 +110,12 @@ for keep in [dict(spectral='spectral', overlap='overlap', fields=True, recompute
                 inbox.copy_(uend)
         e.replace_u0(inbox.data_ptr())      # what arrives
         e.residual(dt)                      # IT_CHECK
+    for f in futures:                       # (whoever logged them collects them at the end of the run)
+        f.result()
     torch.cuda.synchronize()
     el = (time.perf_counter() - t0) / iters
     prof = e.profile_read()
+    dev_bytes = e.device_bytes
     if keep == 'spectral':
         e.end_point(dt, False)
     e.materialize(L.SLOT_UEND, 0)
@@ -103,7 +125,8 @@ for keep in [dict(spectral='spectral', overlap='overlap', fields=True, recompute
         check = float(torch.max(torch.abs(inbox - uend)))       # the last message is the last end value
     out[{'spectral': 'spectra_on_the_wire', 'overlap': 'overlapped_message', True: 'kept_residual_fields',
          False: 'recomputed_residual'}[keep]] = {
-        'ms_per_iteration': 1e3 * el, 'message_copies': copies, 'inbox_minus_uend': check, 'kernels_ms': {k: round(v[0] / v[1], 2) for k, v in prof.items() if v[1]},
+        'ms_per_iteration': 1e3 * el, 'message_copies': copies, 'options': os.environ.get('EMU_OPTS', '5,1,0') if keep == 'spectral' else None,
+        'device_bytes': dev_bytes, 'inbox_minus_uend': check, 'kernels_ms': {k: round(v[0] / v[1], 2) for k, v in prof.items() if v[1]},
         'kernels_ms_per_iteration': {k: round(v[0] / iters, 2) for k, v in prof.items() if v[1]}}
     e.close()
 print(json.dumps(out))

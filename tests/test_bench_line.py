@@ -54,9 +54,13 @@ def test_headline_line_with_every_sub_record_fits_and_parses():
     subs = [_record(title=t) for t, _ in bench.SUB_PLAN] + [{'title': 'x' * 100, 'error': 'e' * 1000}]
     subs[2]['niter'] = [43, 32]
     subs[2]['restol'] = 1e-10
-    line = json.dumps(bench.compact_line(_record(), subs, _cpu(), 'gpurun_out/bench_details.json'), allow_nan=False)
+    line = json.dumps(bench.compact_line(_record(), subs, _cpu(), 'gpurun_out/bench_details.json', _record(steps=20)),
+                      allow_nan=False)
     assert len(line) < 6000, len(line)
     rec = _strict(line)
+    # the headline configuration re-timed at the end of the process
+    assert rec['value_sustained'] and rec['sustained']['steps'] == 20 and 0 < rec['sustained']['roofline']['frac'] < 1
+    assert rec['sustained']['sweep_frac'] and rec['sustained']['ms_per_step']
     for k in CONTRACT:
         assert k in rec, k
     assert set(rec['config']) == {'workload', 'time_parallel'} and 'model' not in rec['config']
@@ -68,6 +72,11 @@ def test_headline_line_with_every_sub_record_fits_and_parses():
     assert rec['niter'] == 4 and rec['sub'][2]['niter'] == [43, 32]
     assert rec['value_eager_fields'] and rec['value_lazy_predictor_residual']
     assert all(len(t) <= 40 for t, _ in bench.SUB_PLAN)
+
+
+def test_a_failed_sustained_run_does_not_take_the_line_down():
+    rec = _strict(json.dumps(bench.compact_line(_record(), None, _cpu(), None, {'error': 'MemoryError()' * 40}), allow_nan=False))
+    assert rec['value_sustained'] is None and len(rec['sustained']['error']) <= 120 and rec['value']
 
 
 def test_eight_rank_line_fits_and_parses():
