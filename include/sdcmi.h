@@ -277,6 +277,11 @@ int sdc_comm_bcast_buffer(sdc_ctx* ctx, double* buf, size_t n, int root);
 int sdc_comm_bcast_end_spectrum(sdc_ctx* ctx, int root);
 int sdc_comm_set_chunk(sdc_ctx* ctx, size_t doubles_per_piece);
 int sdc_comm_set_relay(sdc_ctx* ctx, int on);
+/* Two ranks: the direct message r -> r + 1 uses ONE xGMI link (8.6 GB at 1024^3: ~134 ms) while the host link idles.  With
+ * share > 0 that fraction of every lock-step hand-over (its tail) travels through pinned host memory instead - a ring of slots
+ * in POSIX shared memory registered with the HIP runtime, filled by the sender and drained by the receiver on helper threads
+ * and streams of their own, beside the direct transfer of the head.  0 (default): off.  Same choice on both ranks. */
+int sdc_comm_set_host_share(sdc_ctx* ctx, double share);
 int sdc_comm_set_format(sdc_ctx* ctx, int spectra);
 int sdc_comm_info(sdc_ctx* ctx, int* rank, int* size, unsigned long long* two_hop_calls, unsigned long long* mesh_bcast_calls,
                   char* kind16);
@@ -331,7 +336,13 @@ int sdc_solve(sdc_ctx* ctx, const double* rhs, double factor, const double* gues
 int sdc_vec_copy(sdc_ctx* ctx, size_t n, const double* x, double* y);
 int sdc_vec_fill(sdc_ctx* ctx, size_t n, double a, double* y);
 int sdc_vec_axpby(sdc_ctx* ctx, size_t n, double a, const double* x, double b, const double* y, double* z);
-int sdc_vec_amax(sdc_ctx* ctx, size_t n, const double* x, double* out); /* abs(): max-norm, synchronises */
+int sdc_vec_amax(sdc_ctx* ctx, size_t n, const double* x, double* out);
+/* A box of a C-ordered field of `shape` (ndim <= 4) - per axis start, step (may be negative), count: what basic indexing of
+ * the reference's ndarray datatype selects (datatype_classes/mesh.py:12-60: `u[i]`, `u[..., j]`, `u[1:-1]`).  direction 0:
+ * compact <- box (a gather into count[0] * ... * count[ndim-1] doubles), 1: box <- compact (scatter), 2: box <- value.
+ * Runs on the context's stream (NULL: the default context of the calling thread, like the other sdc_vec_* calls). */
+int sdc_vec_box(sdc_ctx* ctx, int ndim, const long long* shape, const long long* start, const long long* step,
+                const long long* count, double* field, double* compact, int direction, double value); /* abs(): max-norm, synchronises */
 
 /* ---- van der Pol ensemble (BASELINE config 4; Van_der_Pol_implicit.py:106-201) -------------------------
  * ntraj independent trajectories are ONE level with N = 2 * ntraj unknowns, SoA fields [x1[ntraj], x2[ntraj]]

@@ -118,6 +118,11 @@ class DeviceComm:
     def set_relay(self, on):
         self._e(self.engine.lib.sdc_comm_set_relay(self.engine.ctx, int(bool(on))))
 
+    def set_host_share(self, share):
+        """two ranks: this fraction of every lock-step hand-over goes through pinned host memory beside the direct message
+        (include/sdcmi.h: sdc_comm_set_host_share)"""
+        self._e(self.engine.lib.sdc_comm_set_host_share(self.engine.ctx, float(share)))
+
     def info(self):
         rank, size = C.c_int(), C.c_int()
         hops, mesh = C.c_ulonglong(), C.c_ulonglong()

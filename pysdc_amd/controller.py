@@ -453,6 +453,10 @@ class controller_dist(_ControllerBase):
             owner = DeviceComm(self.S.levels[0].engine, self.size, self.rank, wire=self.wire,
                                host_bcast=lambda uid: torch_host_bcast(uid, 0, self.host_comm, self.dist))
             owner.set_relay(self.relay)
+            if self.size == 2:
+                # two ranks: one xGMI link would carry the whole message - a share of it goes through pinned host memory
+                # beside it (include/sdcmi.h: sdc_comm_set_host_share)
+                owner.set_host_share(float(os.environ.get('PYSDC_AMD_HOST_SHARE', '0.45')))
             if self.p2p_chunk > 0:
                 owner.set_chunk(self.p2p_chunk)
             self._comms = [owner] + [DeviceComm.attach(L.engine, owner) for L in self.S.levels[1:]]

@@ -25,6 +25,7 @@
 #include <atomic>
 #include <chrono>
 #include <memory>
+#include <thread>
 
 struct RcclApi {
     void* handle = nullptr;
@@ -313,6 +314,116 @@ struct ShmWire : Wire {
     int sync(sdc_ctx* c) override { return drain(c); }
 };
 
+// A second path for TWO ranks.  The direct message of a two-rank run travels over ONE of a GPU's seven xGMI links (8.6 GB at
+// 1024^3: ~134 ms at the ~64 GB/s a link sustains) while the host link idles; a share of it - the tail of the message - goes
+// through pinned host memory instead: the sender copies chunks into a ring of `depth` slots in POSIX shared memory (registered
+// with the HIP runtime: DMA at the host link's rate), the receiver copies them out as they arrive; both sides run their loop on
+// a helper thread and a stream of their own, beside the RCCL transfer of the head of the message.  With 45 % of the message on
+// this path both finish in ~75 - 80 ms (PCIe Gen5 x16: ~50 GB/s either way).  One-directional: file /dev/shm/<job>.pipe.<src>.<dst>.
+struct HostPipe {
+    struct Head {
+        std::atomic<unsigned long long> posted, consumed;
+        char pad[48];
+    };
+    static_assert(sizeof(Head) == 64, "pipe header");
+    std::string path;
+    int fd = -1;
+    unsigned char* base = nullptr;
+    size_t map_bytes = 0, chunk = 0;   // chunk: doubles per slot
+    int depth = 2;
+    bool device = true, registered = false, creator = false;
+    hipStream_t stream = nullptr;
+    double timeout_s = 120.0;
+    Head* head() const { return reinterpret_cast<Head*>(base); }
+    double* slot(unsigned long long k) const { return reinterpret_cast<double*>(base + sizeof(Head)) + (size_t)(k % (unsigned)depth) * chunk; }
+    ~HostPipe() {
+        if (stream) {
+            (void)hipStreamSynchronize(stream);
+            (void)hipStreamDestroy(stream);
+        }
+        if (base) {
+            if (registered) (void)hipHostUnregister(base);
+            munmap(base, map_bytes);
+        }
+        if (fd >= 0) close(fd);
+        if (!path.empty()) shm_unlink(path.c_str());
+    }
+    int open(sdc_ctx* c, const std::string& job, int src, int dst, size_t chunk_doubles, bool on_device) {
+        path = "/" + job + ".pipe." + std::to_string(src) + "." + std::to_string(dst);
+        chunk = chunk_doubles;
+        device = on_device;
+        fd = shm_open(path.c_str(), O_CREAT | O_RDWR, 0600);
+        if (fd < 0) return fail(c, SDC_ERR_COMM, "shm_open(%s): %s", path.c_str(), strerror(errno));
+        map_bytes = sizeof(Head) + (size_t)depth * chunk * sizeof(double);
+        if (ftruncate(fd, (off_t)map_bytes) != 0) return fail(c, SDC_ERR_COMM, "ftruncate(%s): %s", path.c_str(), strerror(errno));
+        void* m = mmap(nullptr, map_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        if (m == MAP_FAILED) return fail(c, SDC_ERR_COMM, "mmap(%s): %s", path.c_str(), strerror(errno));
+        base = static_cast<unsigned char*>(m);
+        if (device) {
+            registered = hipHostRegister(base, map_bytes, hipHostRegisterDefault) == hipSuccess;   // (pageable copies still work)
+            if (!registered) (void)hipGetLastError();
+            if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return fail(c, SDC_ERR_HIP, "cannot create the pipe's stream");
+        }
+        return SDC_OK;
+    }
+    template <class Pred>
+    int wait_for(Pred ready, std::string* err, const char* what) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spin = 0; !ready(); ++spin) {
+            if (spin < 4000) sched_yield();
+            else usleep(20);
+            if ((spin & 1023) == 1023 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) {
+                *err = std::string("host pipe ") + path + ": " + what + " timed out";
+                return SDC_ERR_COMM;
+            }
+        }
+        return SDC_OK;
+    }
+    // host loops (helper threads): n doubles from / to a buffer of the pipe's kind, chunk by chunk
+    int send(const double* buf, size_t n, std::string* err) {
+        Head* h = head();
+        for (size_t o = 0; o < n; o += chunk) {
+            const size_t len = std::min(chunk, n - o);
+            int rc = wait_for([&] { return h->posted.load(std::memory_order_relaxed) - h->consumed.load(std::memory_order_acquire) < (unsigned)depth; },
+                              err, "waiting for a free slot");
+            if (rc != SDC_OK) return rc;
+            double* at = slot(h->posted.load(std::memory_order_relaxed));
+            if (device) {
+                if (hipMemcpyAsync(at, buf + o, len * sizeof(double), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+                    hipStreamSynchronize(stream) != hipSuccess) {
+                    *err = "host pipe " + path + ": device-to-host copy failed";
+                    return SDC_ERR_HIP;
+                }
+            } else {
+                memcpy(at, buf + o, len * sizeof(double));
+            }
+            h->posted.fetch_add(1, std::memory_order_release);
+        }
+        return SDC_OK;
+    }
+    int recv(double* buf, size_t n, std::string* err) {
+        Head* h = head();
+        for (size_t o = 0; o < n; o += chunk) {
+            const size_t len = std::min(chunk, n - o);
+            int rc = wait_for([&] { return h->posted.load(std::memory_order_acquire) > h->consumed.load(std::memory_order_relaxed); }, err,
+                              "waiting for a chunk");
+            if (rc != SDC_OK) return rc;
+            const double* at = slot(h->consumed.load(std::memory_order_relaxed));
+            if (device) {
+                if (hipMemcpyAsync(buf + o, at, len * sizeof(double), hipMemcpyHostToDevice, stream) != hipSuccess ||
+                    hipStreamSynchronize(stream) != hipSuccess) {
+                    *err = "host pipe " + path + ": host-to-device copy failed";
+                    return SDC_ERR_HIP;
+                }
+            } else {
+                memcpy(buf + o, at, len * sizeof(double));
+            }
+            h->consumed.fetch_add(1, std::memory_order_release);
+        }
+        return SDC_OK;
+    }
+};
+
 // ------------------------------------------------------------------------------------------------------------------
 // the exchange patterns (any wire, any buffers of that wire's kind)
 // ------------------------------------------------------------------------------------------------------------------
@@ -416,7 +527,28 @@ struct CommState {
     bool relay = true;              // more than two ranks: two-hop hand-over / mesh broadcast instead of direct messages
     int posted_recv = -1;           // sdc_comm_handover_post: 1 / 2 = a field / a spectrum is being received, 0 = only a send, -1 = nothing posted
     unsigned long long two_hop_calls = 0, mesh_bcast_calls = 0;
+    // two ranks: a share of the direct message through pinned host memory (HostPipe), on helper threads
+    double host_share = 0.0;        // 0: off
+    std::string job;                // names the pipes' files (the same on both ranks)
+    std::unique_ptr<HostPipe> pipe_out, pipe_in;
+    std::thread helper_out, helper_in;
+    int helper_rc_out = SDC_OK, helper_rc_in = SDC_OK;
+    std::string helper_err_out, helper_err_in;
+    hipEvent_t pipe_ready = nullptr;   // engine / message side -> pipe streams: source complete, destination free
+    unsigned long long host_path_calls = 0;
 };
+// the helper threads of a posted hand-over have finished (their data is in place: they synchronise their own streams)
+static int join_helpers(sdc_ctx* c, CommState* cs) {
+    if (cs->helper_out.joinable()) cs->helper_out.join();
+    if (cs->helper_in.joinable()) cs->helper_in.join();
+    int rc = cs->helper_rc_out != SDC_OK ? cs->helper_rc_out : cs->helper_rc_in;
+    if (rc != SDC_OK) {
+        const std::string& e = cs->helper_rc_out != SDC_OK ? cs->helper_err_out : cs->helper_err_in;
+        cs->helper_rc_out = cs->helper_rc_in = SDC_OK;
+        return fail(c, rc, "%s", e.c_str());
+    }
+    return SDC_OK;
+}
 
 // UEND is about to be overwritten: a send that reads it has to be through first (device-side wait, no host block)
 static int uend_write_fence(sdc_ctx* c) {
@@ -431,6 +563,10 @@ static int uend_write_fence(sdc_ctx* c) {
 static void comm_free(sdc_ctx* c) {
     CommState* cs = c->comm;
     if (!cs) return;
+    (void)join_helpers(nullptr, cs);
+    cs->pipe_out.reset();
+    cs->pipe_in.reset();
+    if (cs->pipe_ready) (void)hipEventDestroy(cs->pipe_ready);
     if (cs->wire) (void)cs->wire->sync(nullptr);
     cs->wire.reset();
     if (cs->ready) (void)hipEventDestroy(cs->ready);
@@ -490,6 +626,7 @@ extern "C" int sdc_comm_init(sdc_ctx* c, const char* uid128, int nranks, int ran
         auto w = make_shm_wire(uid128, nranks, rank, std::max(c->N, 2 * c->Nc) + 8, true);
         if (hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) != hipSuccess)
             return fail(c, SDC_ERR_HIP, "cannot create the message stream");
+        cs->job = static_cast<ShmWire*>(w.get())->job;
         cs->wire = w;
     } else {
         std::string why;
@@ -508,6 +645,13 @@ extern "C" int sdc_comm_init(sdc_ctx* c, const char* uid128, int nranks, int ran
         }
         if (hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) != hipSuccess)
             return fail(c, SDC_ERR_HIP, "cannot create the message stream");
+        {   // (a name both ranks derive from the unique id: files of the host pipes)
+            unsigned long long hsh = 1469598103934665603ull;
+            for (int i = 0; i < 128; ++i) hsh = (hsh ^ (unsigned char)uid128[i]) * 1099511628211ull;
+            char nm[64];
+            snprintf(nm, sizeof nm, "sdcmi.r%016llx", hsh);
+            cs->job = nm;
+        }
         cs->wire = w;
     }
     int rc = comm_events(c, cs.get());
@@ -560,6 +704,18 @@ extern "C" int sdc_comm_set_relay(sdc_ctx* c, int on) {
     NEED_COMM(c);
     (void)w;
     cs->relay = on != 0;
+    return SDC_OK;
+}
+
+// two ranks: `share` of every lock-step hand-over (0 <= share < 1; 0 = off) travels through pinned host memory beside the
+// direct message (HostPipe above).  Both ranks must make the same choice.
+extern "C" int sdc_comm_set_host_share(sdc_ctx* c, double share) {
+    NEED_COMM(c);
+    (void)w;
+    if (!(share >= 0.0 && share < 1.0)) return fail(c, SDC_ERR_PARAM, "share of the message on the host path: 0 <= share < 1");
+    int rc = join_helpers(c, cs);
+    if (rc != SDC_OK) return rc;
+    cs->host_share = share;
     return SDC_OK;
 }
 
@@ -698,9 +854,50 @@ extern "C" int sdc_comm_handover_post(sdc_ctx* c, int nactive) {
         cs->two_hop_calls++;
         if ((rc = two_hop_handover(w, c, nactive, src, dst, cs->stage, n)) != SDC_OK) return rc;
     } else {
+        // two ranks: the tail of the message through pinned host memory, on helper threads, beside the direct transfer
+        size_t n_host = 0;
+        if (nactive == 2 && cs->host_share > 0.0 && n >= 4096) {
+            n_host = ((size_t)((double)n * cs->host_share) / 512) * 512;
+            size_t slot_doubles = (size_t)16 << 20;   // 128 MB slots (SDC_PIPE_CHUNK: doubles per slot, for tests)
+            if (const char* pc = getenv("SDC_PIPE_CHUNK")) slot_doubles = std::max<size_t>(512, strtoull(pc, nullptr, 10));
+            const size_t chunk = std::min<size_t>(n_host, slot_doubles);
+            if ((rc = join_helpers(c, cs)) != SDC_OK) return rc;
+            if (!cs->pipe_ready) HIPCHK(c, hipEventCreateWithFlags(&cs->pipe_ready, hipEventDisableTiming));
+            // (whatever the message stream waits for - the end value complete, the inbox free - the pipes wait for too)
+            HIPCHK(c, hipEventRecord(cs->pipe_ready, w->stream));
+            if (sending) {
+                if (!cs->pipe_out || cs->pipe_out->chunk != chunk) {
+                    cs->pipe_out.reset(new HostPipe);
+                    if ((rc = cs->pipe_out->open(c, cs->job, r, r + 1, chunk, true)) != SDC_OK) return rc;
+                }
+                HIPCHK(c, hipStreamWaitEvent(cs->pipe_out->stream, cs->pipe_ready, 0));
+                HostPipe* pp = cs->pipe_out.get();
+                const double* from = src + (n - n_host);
+                const int dev = c->device;
+                cs->helper_out = std::thread([cs, pp, from, n_host, dev] {
+                    (void)hipSetDevice(dev);
+                    cs->helper_rc_out = pp->send(from, n_host, &cs->helper_err_out);
+                });
+            }
+            if (receiving) {
+                if (!cs->pipe_in || cs->pipe_in->chunk != chunk) {
+                    cs->pipe_in.reset(new HostPipe);
+                    if ((rc = cs->pipe_in->open(c, cs->job, r - 1, r, chunk, true)) != SDC_OK) return rc;
+                }
+                HIPCHK(c, hipStreamWaitEvent(cs->pipe_in->stream, cs->pipe_ready, 0));
+                HostPipe* pp = cs->pipe_in.get();
+                double* to = dst + (n - n_host);
+                const int dev = c->device;
+                cs->helper_in = std::thread([cs, pp, to, n_host, dev] {
+                    (void)hipSetDevice(dev);
+                    cs->helper_rc_in = pp->recv(to, n_host, &cs->helper_err_in);
+                });
+            }
+            cs->host_path_calls++;
+        }
         if ((rc = w->group_begin(c)) != SDC_OK) return rc;
-        if (sending) w->send(c, src, n, r + 1);
-        if (receiving) w->recv(c, dst, n, r - 1);
+        if (sending) w->send(c, src, n - n_host, r + 1);
+        if (receiving) w->recv(c, dst, n - n_host, r - 1);
         if ((rc = w->group_end(c)) != SDC_OK) return rc;
     }
     HIPCHK(c, hipEventRecord(cs->done, w->stream));
@@ -721,6 +918,10 @@ extern "C" int sdc_comm_handover_complete(sdc_ctx* c) {
     if (cs->posted_recv < 0) return SDC_OK;
     const int kind = cs->posted_recv;
     cs->posted_recv = -1;
+    {   // (the share that went through host memory: its helper threads end with the data in place)
+        int rch = join_helpers(c, cs);
+        if (rch != SDC_OK) return rch;
+    }
     // (also on a rank that only sent: its next sweep rewrites the spectrum / end value the message reads)
     HIPCHK(c, hipStreamWaitEvent(c->stream, cs->done, 0));
     cs->send_pending = false;

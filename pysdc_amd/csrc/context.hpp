@@ -38,19 +38,6 @@ struct ProfEntry {
 
 struct CommState;  // comm.hpp: RCCL communicator, message stream, inbox
 
-// A slab of equal fields whose device memory is mapped field by field when somebody first touches it (virtual-memory API:
-// one reserved address range, so the addresses views and kernels hold never move).  The sweeps that stay in Fourier space
-// never touch U[1..M] / F / the node spectra S[0..M-2]: at 1024^3 that is 137 GB that is simply never mapped.  Small fields (or
-// a runtime without the API) get one plain allocation, everything present from the start.
-struct LazySlab {
-    char* base = nullptr;
-    size_t field_bytes = 0;
-    int nfields = 0;
-    bool vmm = false;
-    std::vector<hipMemGenericAllocationHandle_t> handles;
-    std::vector<char> mapped;
-    bool all_mapped = true;
-};
 #define MAXTRAIL 8     // start values a trail of unstored sweeps may depend on (time-parallel runs)
 #define MAXVSWEEPS 32  // sweeps whose start-value indices are on record
 
@@ -87,8 +74,13 @@ struct sdc_ctx {
     size_t Nc = 0;      // complex entries of one spectrum field
     hipStream_t stream = nullptr;
     double *U = nullptr, *F = nullptr, *TAU = nullptr, *UEND = nullptr, *profile = nullptr;
-    LazySlab slabU, slabF, slabS;   // U[0..M], F[0..M][ncomp], S[0..M-1]: mapped on first touch (need_nodes, need_node_spectra)
-    size_t lazy_min_bytes = (size_t)256 << 20;   // fields at least this large are mapped lazily (SDC_LAZY_MIN_BYTES)
+    // The node fields live in blocks of their own that are allocated when something first touches them in real space: U0 = u[0]
+    // (always there), Un = U[1..M], F = F[0..M][ncomp], Sn = the node spectra S[0..M-2] (the last node's has its own buffer).
+    // The sweeps that stay in Fourier space never touch Un, F, Sn - 128 GB at 1024^3 that are simply never allocated.  `U` is
+    // the base the node index counts from: U + m N = U[m] for m >= 1 (Un - N); u[0] is reached through U0 ONLY.
+    double *U0 = nullptr, *Un = nullptr;
+    cd* Sn = nullptr;
+    size_t lazy_min_bytes = (size_t)64 << 20;   // contexts with smaller fields allocate everything at once (SDC_LAZY_MIN_BYTES)
     cd* W = nullptr;
     cd *S = nullptr, *S0 = nullptr;  // spectral cache: transforms of U[1..M] and of U[0] (lazy)
     // The transform of the LAST node and the transform of u[0] trade places from one time step to the next (the end
@@ -256,101 +248,33 @@ static int fail(sdc_ctx* c, int code, const char* fmt, ...) {
                         hipGetErrorString(e_));                                                      \
     } while (0)
 
-// ---- lazily mapped slabs ---------------------------------------------------------------------------------------------
-// reserve the address range of nfields fields; `eager` fields from the start are mapped right away
-static int slab_map(sdc_ctx* c, LazySlab& sl, int first, int count);
-static int slab_reserve(sdc_ctx* c, LazySlab& sl, size_t field_bytes, int nfields, int eager) {
-    sl.field_bytes = field_bytes;
-    sl.nfields = nfields;
-    sl.handles.assign(nfields, hipMemGenericAllocationHandle_t{});
-    sl.mapped.assign(nfields, 0);
-    int vmm = 0;
-    size_t gran = 0;
-    hipMemAllocationProp prop = {};
-    prop.type = hipMemAllocationTypePinned;
-    prop.location.type = hipMemLocationTypeDevice;
-    prop.location.id = c->device;
-    if (field_bytes >= c->lazy_min_bytes && eager < nfields &&
-        hipDeviceGetAttribute(&vmm, hipDeviceAttributeVirtualMemoryManagementSupported, c->device) == hipSuccess && vmm &&
-        hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) == hipSuccess && gran > 0 &&
-        field_bytes % gran == 0) {
-        void* base = nullptr;
-        if (hipMemAddressReserve(&base, field_bytes * nfields, gran, nullptr, 0) == hipSuccess) {
-            sl.base = static_cast<char*>(base);
-            sl.vmm = true;
-            sl.all_mapped = false;
-            if (getenv("SDC_LAZY_DEBUG"))
-                fprintf(stderr, "[sdcmi] ctx %p: reserved %d fields of %zu bytes at %p .. %p\n", (void*)c, nfields, field_bytes, base,
-                        (void*)(sl.base + field_bytes * nfields));
-            return slab_map(c, sl, 0, eager);
-        }
-    }
-    (void)hipGetLastError();
-    sl.vmm = false;
-    HIPCHK(c, hipMalloc((void**)&sl.base, field_bytes * nfields));
-    HIPCHK(c, hipMemsetAsync(sl.base, 0, field_bytes * nfields, c->stream));
-    std::fill(sl.mapped.begin(), sl.mapped.end(), 1);
-    sl.all_mapped = true;
-    c->bytes += field_bytes * nfields;
+// ---- node fields that are allocated on first touch -------------------------------------------------------------------------
+static int lazy_block(sdc_ctx* c, void** dst, size_t bytes) {
+    if (*dst || bytes == 0) return SDC_OK;
+    HIPCHK(c, hipMalloc(dst, bytes));
+    HIPCHK(c, hipMemsetAsync(*dst, 0, bytes, c->stream));
+    c->bytes += bytes;
     return SDC_OK;
 }
-// fields [first, first + count) become real (zero-filled) memory; no-op for the ones that are
-static int slab_map(sdc_ctx* c, LazySlab& sl, int first, int count) {
-    if (sl.all_mapped) return SDC_OK;
-    hipMemAllocationProp prop = {};
-    prop.type = hipMemAllocationTypePinned;
-    prop.location.type = hipMemLocationTypeDevice;
-    prop.location.id = c->device;
-    hipMemAccessDesc acc = {};
-    acc.location.type = hipMemLocationTypeDevice;
-    acc.location.id = c->device;
-    acc.flags = hipMemAccessFlagsProtReadWrite;
-    for (int f = first; f < first + count && f < sl.nfields; ++f) {
-        if (sl.mapped[f]) continue;
-        char* at = sl.base + (size_t)f * sl.field_bytes;
-        hipError_t e = hipMemCreate(&sl.handles[f], sl.field_bytes, &prop, 0);
-        if (e != hipSuccess)
-            return fail(c, e == hipErrorOutOfMemory ? SDC_ERR_NOMEM : SDC_ERR_HIP, "mapping field %d of a slab (%zu bytes): %s", f,
-                        sl.field_bytes, hipGetErrorString(e));
-        e = hipMemMap(at, sl.field_bytes, 0, sl.handles[f], 0);
-        if (e == hipSuccess) e = hipMemSetAccess(at, sl.field_bytes, &acc, 1);
-        if (e != hipSuccess) {
-            (void)hipMemRelease(sl.handles[f]);
-            return fail(c, SDC_ERR_HIP, "mapping field %d of a slab: %s", f, hipGetErrorString(e));
-        }
-        sl.mapped[f] = 1;
-        c->bytes += sl.field_bytes;
-        if (getenv("SDC_LAZY_DEBUG")) fprintf(stderr, "[sdcmi] ctx %p: mapped field %d at %p\n", (void*)c, f, (void*)at);
-        HIPCHK(c, hipMemsetAsync(at, 0, sl.field_bytes, c->stream));
-    }
-    bool all = true;
-    for (char m : sl.mapped) all = all && m;
-    sl.all_mapped = all;
-    return SDC_OK;
-}
-static void slab_free(LazySlab& sl) {
-    if (!sl.base) return;
-    if (sl.vmm) {
-        for (int f = 0; f < sl.nfields; ++f)
-            if (sl.mapped[f]) {
-                (void)hipMemUnmap(sl.base + (size_t)f * sl.field_bytes, sl.field_bytes);
-                (void)hipMemRelease(sl.handles[f]);
-            }
-        (void)hipMemAddressFree(sl.base, sl.field_bytes * sl.nfields);
-    } else {
-        (void)hipFree(sl.base);
-    }
-    sl.base = nullptr;
+// F (all of it: f[0] included) is about to be read or written
+static inline int need_f0(sdc_ctx* c) {
+    return c->F ? SDC_OK : lazy_block(c, (void**)&c->F, c->N * sizeof(double) * (size_t)(c->M + 1) * c->ncomp);
 }
 // U[1..M] and F are about to be read or written in real space
 static inline int need_nodes(sdc_ctx* c) {
-    if (c->slabU.all_mapped && c->slabF.all_mapped) return SDC_OK;
-    int rc = slab_map(c, c->slabU, 0, c->slabU.nfields);
-    return rc == SDC_OK ? slab_map(c, c->slabF, 0, c->slabF.nfields) : rc;
+    if (c->Un && c->F) return SDC_OK;
+    int rc = lazy_block(c, (void**)&c->Un, c->N * sizeof(double) * (size_t)c->M);
+    if (rc != SDC_OK) return rc;
+    c->U = c->Un - c->N;   // (node index base: U + m N for m >= 1)
+    return need_f0(c);
 }
-// F[0] alone (f(u[0]) is evaluated) / the node spectra S[0..M-2] (an iterate is stored in Fourier space)
-static inline int need_f0(sdc_ctx* c) { return slab_map(c, c->slabF, 0, c->ncomp); }
-static inline int need_node_spectra(sdc_ctx* c) { return slab_map(c, c->slabS, 0, c->slabS.nfields); }
+// the node spectra S[0..M-2] (an iterate is stored in Fourier space)
+static inline int need_node_spectra(sdc_ctx* c) {
+    if (c->Sn || c->M < 2) return SDC_OK;
+    int rc = lazy_block(c, (void**)&c->Sn, sizeof(cd) * c->Nc * (size_t)(c->M - 1));
+    c->S = c->Sn;
+    return rc;
+}
 #define NEED_NODES(c)                      \
     do {                                   \
         int rcn_ = need_nodes(c);          \

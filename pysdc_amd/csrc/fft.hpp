@@ -1,6 +1,8 @@
-// In-register / LDS Stockham FFT building blocks for f64 complex lines of length N = 2^p (2 <= N <= 1024)
-// on gfx950.  One line is spread over P = N/E threads with E = min(16, N) elements per thread; element i of
-// thread j is line index j + i*P.  Every stage reads that same strided set (so loads/stores to global memory
+// In-register / LDS Stockham FFT building blocks for f64 complex lines of length N = 2^p (2 <= N <= 2048) or
+// N = 3 * 2^p (24 .. 768: the even grids the reference accepts that are not powers of two, generic_ND_FD.py:126-129) on
+// gfx950.  One line is spread over P = N/E threads with E = min(16, N) elements per thread (12 for the lengths with a factor
+// 3: radix-4 / radix-2 stages, one radix-3 stage LAST, so that the number of finished sub-transforms NS stays a power of
+// two where an index is reduced by it); element i of thread j is line index j + i*P.  Every stage reads that same strided set (so loads/stores to global memory
 // keep one pattern for all N) and scatters through LDS to the Stockham output position.  Real and imaginary
 // planes go through LDS one after the other, which halves the LDS footprint (N*8 bytes per line).
 #pragma once
@@ -90,6 +92,16 @@ DEVI void bf2(cd& a, cd& b) {
     a = cadd(t, b);
     b = csub(t, b);
 }
+// 3-point DFT: X1 = x0 - (x1 + x2)/2 + DIR i (sqrt 3 / 2)(x1 - x2), X2 its mirror
+template <int DIR>
+DEVI void bf3(cd& a0, cd& a1, cd& a2) {
+    constexpr double h = 0.86602540378443864676;  // sqrt(3) / 2
+    const cd s = cadd(a1, a2), d = mul_dir_i<DIR>(cscale(csub(a1, a2), h));
+    const cd m = cd{a0.x - 0.5 * s.x, a0.y - 0.5 * s.y};
+    a0 = cadd(a0, s);
+    a1 = cadd(m, d);
+    a2 = csub(m, d);
+}
 template <int DIR>
 DEVI void bf4(cd& a0, cd& a1, cd& a2, cd& a3) {
     cd t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = mul_dir_i<DIR>(csub(a1, a3));
@@ -104,6 +116,8 @@ template <int R, int DIR>
 DEVI void dft(cd (&x)[R]) {
     if constexpr (R == 2) {
         bf2<DIR>(x[0], x[1]);
+    } else if constexpr (R == 3) {
+        bf3<DIR>(x[0], x[1], x[2]);
     } else if constexpr (R == 4) {
         bf4<DIR>(x[0], x[1], x[2], x[3]);
     } else if constexpr (R == 8) {
@@ -153,7 +167,13 @@ DEVI void dft(cd (&x)[R]) {
 #ifndef SDC_FFT_E
 #define SDC_FFT_E 16
 #endif
-constexpr int fft_elems(int N) { return N < SDC_FFT_E ? N : SDC_FFT_E; }
+constexpr bool fft_has3(int N) { return N % 3 == 0; }
+constexpr int fft_elems(int N) { return fft_has3(N) ? (N < 12 ? N : 12) : (N < SDC_FFT_E ? N : SDC_FFT_E); }
+// lengths the line transforms handle: 2^p, and 3 * 2^p from 24 on (the thread counts of the kernels want P = N / 12 = 2^q >= 2)
+constexpr bool fft_length_ok(int N) {
+    int m = N % 3 == 0 ? N / 3 : N;
+    return N >= 2 && (m & (m - 1)) == 0 && (N % 3 != 0 || N >= 24);
+}
 
 // LDS index maps (in doubles).  The skew (pos >> 4) breaks the power-of-two strides of the stage-1 scatter.
 // kUnit: doubles between neighbouring (skewed) positions of one column.  A run of positions pos0 + m * d with d a multiple of
@@ -199,7 +219,9 @@ DEVI void fft_butterflies(cd (&r)[EE], int j, const cd* __restrict__ tw) {
             constexpr int step = N / (NS * R);
             const cd w1 = tw_dir<DIR>(tw[k * step]);
             x[1] = cmul(x[1], w1);
-            if constexpr (R > 2) {
+            if constexpr (R == 3) {
+                x[2] = cmul(x[2], cmul(w1, w1));
+            } else if constexpr (R > 2) {
                 const cd w2 = cmul(w1, w1);
                 cd run[4] = {cmul(w2, w2), w1, w2, cmul(w2, w1)};  // w^4, w^1, w^2, w^3
                 x[2] = cmul(x[2], run[2]);
@@ -277,7 +299,11 @@ template <int N, int NS, int DIR, class LAY, bool WAVE, int EE = fft_elems(N)>
 DEVI void fft_stages(cd (&r)[EE], int j, int col, double* lds, const cd* __restrict__ tw) {
     constexpr int REM = N / NS;
     constexpr int RMAX = EE < 16 ? EE : 16;  // a butterfly cannot be wider than the elements a thread holds
-    constexpr int R = REM >= RMAX ? RMAX : REM;
+    // lengths with a factor 3 (12 elements per thread): radix 4 while the power-of-two part lasts, a radix 2 if one is left,
+    // the radix 3 last
+    constexpr int REM2 = fft_has3(N) ? REM / 3 : REM;
+    constexpr int R = fft_has3(N) ? (REM2 >= 4 ? 4 : (REM2 == 2 ? 2 : 3)) : (REM >= RMAX ? RMAX : REM);
+    static_assert(EE % R == 0, "elements per thread must hold whole butterflies");
     fft_butterflies<N, R, NS, DIR, EE>(r, j, tw);
     if constexpr (NS * R < N) {
         fft_exchange<N, R, NS, LAY, WAVE, EE>(r, j, col, lds);

@@ -99,7 +99,7 @@ __global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_fwd(FieldPtr
 #pragma unroll
         for (int i = 0; i < E; ++i) {
             const int k = j + i * P;
-            const double v = lds[LAY::idx(col, (N - k) & (N - 1))];
+            const double v = lds[LAY::idx(col, (N - k) % N)];
             if (part == 0) {
                 A[i].x = 0.5 * (r[i].x + v);
                 B[i].y = -0.5 * (r[i].x - v);

@@ -238,6 +238,34 @@ __global__ void k_axpby(size_t n, double a, const double* __restrict__ x, double
     }
 }
 
+// A box of a field (basic indexing of the reference's ndarray datatype, datatype_classes/mesh.py:12-60: integers and slices
+// per axis): element (i0, i1, i2, i3) of the box lies at field[off + i0 s0 + i1 s1 + i2 s2 + i3 s3] (strides in elements, may be
+// negative) and at compact[((i0 c1 + i1) c2 + i2) c3 + i3].  dir 0: compact <- box, 1: box <- compact, 2: box <- value.
+struct BoxArgs {
+    long long off, s[4];
+    long long c[4];
+    double* field;
+    double* compact;
+    double value;
+    int dir;
+};
+__global__ void k_box(BoxArgs a) {
+    const size_t total = (size_t)(a.c[0] * a.c[1] * a.c[2] * a.c[3]);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        size_t r = i;
+        const long long i3 = (long long)(r % (size_t)a.c[3]);
+        r /= (size_t)a.c[3];
+        const long long i2 = (long long)(r % (size_t)a.c[2]);
+        r /= (size_t)a.c[2];
+        const long long i1 = (long long)(r % (size_t)a.c[1]);
+        const long long i0 = (long long)(r / (size_t)a.c[1]);
+        double* at = a.field + (a.off + i0 * a.s[0] + i1 * a.s[1] + i2 * a.s[2] + i3 * a.s[3]);
+        if (a.dir == 0) a.compact[i] = *at;
+        else if (a.dir == 1) *at = a.compact[i];
+        else *at = a.value;
+    }
+}
+
 __global__ void k_fill(size_t n, double a, double* __restrict__ y) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = a;
 }
@@ -295,7 +323,8 @@ __global__ __launch_bounds__(256) void k_spread(SpreadArgs a) {
 // at hand (kept by the sweep in the U[1..M] slab): r_m changes by the same difference for every node, so the
 // node norms against the new u[0] follow in one pass:  d = new - old, u0 <- new, norms[m] = max |r_m + d|.
 template <int M>
-__global__ __launch_bounds__(256) void k_replace_u0(const double* __restrict__ src, double* __restrict__ U, size_t N,
+__global__ __launch_bounds__(256) void k_replace_u0(const double* __restrict__ src, double* __restrict__ U0,
+                                                    const double* __restrict__ U, size_t N,
                                                     unsigned long long* __restrict__ norms) {
     double nm[M];
 #pragma unroll
@@ -303,9 +332,9 @@ __global__ __launch_bounds__(256) void k_replace_u0(const double* __restrict__ s
     const size_t n2 = N >> 1;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x * blockDim.x) {
         const double2 nw = reinterpret_cast<const double2*>(src)[i];
-        const double2 od = reinterpret_cast<const double2*>(U)[i];
+        const double2 od = reinterpret_cast<const double2*>(U0)[i];
         const double d0 = nw.x - od.x, d1 = nw.y - od.y;
-        reinterpret_cast<double2*>(U)[i] = nw;
+        reinterpret_cast<double2*>(U0)[i] = nw;
 #pragma unroll
         for (int m = 0; m < M; ++m) {
             const double2 r = reinterpret_cast<const double2*>(U + (size_t)(m + 1) * N)[i];

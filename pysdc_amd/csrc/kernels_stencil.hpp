@@ -240,7 +240,8 @@ __global__ __launch_bounds__(256, 4) void k_stencil3d(Stencil3Args a) {
 // u0 + dt sum_j Q[m][j] f_j - u_m (core/sweeper.py:186-199) is formed.  Replaces stencil (10 field passes) +
 // residual (11) by one kernel with 6 reads + 5 writes.
 struct StencilResArgs {
-    const double* U;  // slab: U[0] = u0, U[1..M]
+    const double* U;  // node index base: U + m N = U[m], m = 1..M
+    const double* u0; // u[0] (a block of its own)
     double* F;        // slab (ncomp == 1)
     double wI[3], wE[3];    // implicit operator; explicit stencil operator when ncomp == 2
     double cQ[MAXM][MAXM];  // dt * Q[m+1][j+1]
@@ -338,7 +339,7 @@ __global__ __launch_bounds__(256, (EXPL || M >= 6) ? 2 : 3) void k_stencil3d_res
         }
         nmax[j] = 0.0;
     }
-    u0c = ld_u0_pair(a.U + wrapx(x0) + off);
+    u0c = ld_u0_pair(a.u0 + wrapx(x0) + off);
     const double cI = 3.0 * a.wI[1], cE = EXPL ? 3.0 * a.wE[1] : 0.0;
     const size_t fstep = (size_t)(EXPL ? 2 : 1) * a.N;  // distance between F[j] and F[j+1]
     for (int p = 0; p < a.xchunk; ++p) {
@@ -357,7 +358,7 @@ __global__ __launch_bounds__(256, (EXPL || M >= 6) ? 2 : 3) void k_stencil3d_res
                 nn[j] = *reinterpret_cast<const double2*>(uj + px2 + off);
                 hn[j] = halo_wanted ? halo_load(uj + (AHEAD ? px2 : px1)) : double2{0.0, 0.0};
             }
-            u0n = ld_u0_pair(a.U + px1 + off);
+            u0n = ld_u0_pair(a.u0 + px1 + off);
         }
         const size_t po = (size_t)x * sx + off;
         double2 fv[M];

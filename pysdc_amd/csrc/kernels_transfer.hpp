@@ -209,3 +209,25 @@ __global__ void k_pad_spectrum_2d(const cd* __restrict__ G, cd* __restrict__ T, 
         T[p] = cd{0.5 * (t0.x + t1.x), 0.5 * (t0.y - t1.y)};
     }
 }
+
+// 3-D: the eight corner blocks of fftn(G) go to the eight corners of a zero fine spectrum, real(ifftn) - the 2-D rule of
+// TransferMesh_FFT2D.py:58-77 with one more axis (a field that does not depend on one axis is prolonged plane by plane
+// exactly as mesh_to_mesh_fft2d does it: tests/test_gpu_multilevel.py).  G: coarse half spectrum [nc/2+1][nc][nc].
+__device__ __forceinline__ cd pad3d_T(const cd* __restrict__ G, int nc, int nf, int a, int b, int c) {
+    const int h = nc / 2;
+    const bool ina = a < h || a >= nf - h, inb = b < h || b >= nf - h, inc = c < h || c >= nf - h;
+    if (!ina || !inb || !inc) return cd{0.0, 0.0};
+    const int ca = a < h ? a : a - (nf - nc), cb = b < h ? b : b - (nf - nc), cc = c < h ? c : c - (nf - nc);
+    if (ca <= nc / 2) return G[((size_t)ca * nc + cb) * nc + cc];
+    const cd g = G[((size_t)(nc - ca) * nc + ((nc - cb) % nc)) * nc + ((nc - cc) % nc)];
+    return cd{g.x, -g.y};
+}
+__global__ void k_pad_spectrum_3d(const cd* __restrict__ G, cd* __restrict__ T, int nc, int nf) {
+    const size_t total = (size_t)(nf / 2 + 1) * nf * nf;
+    for (size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x; p < total; p += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(p % nf), b = (int)((p / nf) % nf), a = (int)(p / ((size_t)nf * nf));
+        const cd t0 = pad3d_T(G, nc, nf, a, b, c);
+        const cd t1 = pad3d_T(G, nc, nf, (nf - a) % nf, (nf - b) % nf, (nf - c) % nf);
+        T[p] = cd{0.5 * (t0.x + t1.x), 0.5 * (t0.y - t1.y)};
+    }
+}

@@ -6,7 +6,8 @@
 // van der Pol ensemble: one trajectory per lane (SoA state [2][T])
 // ------------------------------------------------------------------------------------------------------
 struct VdpSweepArgs {
-    double* U;   // slab [(M+1)][2][T]
+    double* U;   // node index base: U + m N = U[m] ([2][T] each), m = 1..M
+    const double* u0;   // u[0] (a block of its own)
     double* F;
     const double* tau;  // or null
     size_t T;
@@ -111,7 +112,7 @@ __global__ VDP_BOUNDS void k_vdp_sweep(VdpSweepArgs a) {
     for (int m = 0; m < M; ++m) nmax[m] = 0.0;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < T; i += (size_t)gridDim.x * blockDim.x) {
         const double mu = a.mu;
-        const double u00 = a.U[i], u01 = a.U[T + i];
+        const double u00 = a.u0[i], u01 = a.u0[T + i];
         // Live state per trajectory: the right-hand sides of all nodes (old ones, replaced node by node by the new ones)
         // and the gathered sums - 4 M doubles.  Node values are NOT kept: the old one of node m is read again when its
         // Newton iteration starts (as the guess), the new ones are read back for the residual (this thread wrote them:
@@ -326,7 +327,7 @@ __global__ __launch_bounds__(256) void k_vdp_sweep_mfma(VdpSweepArgs a) {
         const bool valid = i < T;
         const size_t ii = valid ? i : 0;
         const double mu = a.mu;
-        const double u00 = a.U[ii], u01 = a.U[T + ii];
+        const double u00 = a.u0[ii], u01 = a.u0[T + ii];
         double f0[M], f1[M], g0[M], g1[M], un0[M], un1[M];
 #pragma unroll
         for (int m = 0; m < M; ++m) {

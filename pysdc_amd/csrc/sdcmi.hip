@@ -38,8 +38,9 @@
 // host side
 // ------------------------------------------------------------------------------------------------------
 static int ensure_work(sdc_ctx* c);
-// the FFT kernels transform lines of length 2^p <= 1024 (2048 in 1-D and 2-D)
+// the FFT kernels transform lines of length 2^p <= 1024 (2048 in 1-D and 2-D) and 3 * 2^p from 24 to 768 (fft.hpp)
 static inline bool fourier_ok(const sdc_ctx* c) {
+    if (c->n % 3 == 0) return fft_length_ok(c->n) && c->n <= 768;
     return is_pow2(c->n) && (c->n <= 1024 || (c->n == 2048 && c->ndim <= 2));
 }
 static inline int grid_for(size_t work, int block) {
@@ -66,7 +67,7 @@ static int trail_reset(sdc_ctx* c);
     } while (0)
 static int ensure_u0(sdc_ctx* c) {
     if (c->u0_spec_only) {  // the start value exists as its transform only (sdc_advance after a deferred end value)
-        int rcs = spectrum_to_field(c, c->S0, c->U);
+        int rcs = spectrum_to_field(c, c->S0, c->U0);
         if (rcs != SDC_OK) return rcs;  // (still "spectrum only": nobody reads a half-written U[0])
         c->u0_spec_only = false;
         return SDC_OK;
@@ -74,14 +75,14 @@ static int ensure_u0(sdc_ctx* c) {
     if (c->u0_src) {
         const double* src = c->u0_src;
         c->u0_src = nullptr;
-        HIPCHK(c, hipMemcpyAsync(c->U, src, c->N * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->U0, src, c->N * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     }
     return SDC_OK;
 }
 // nullptr when the start value could not be produced (c->u0_rc, c->err say why): callers go through U0R
 static inline const double* u0r(sdc_ctx* c) {
     if (c->u0_spec_only && (c->u0_rc = ensure_u0(c)) != SDC_OK) return nullptr;
-    return c->u0_src ? c->u0_src : c->U;
+    return c->u0_src ? c->u0_src : c->U0;
 }
 #define U0R(c, var)                        \
     const double* var = u0r(c);            \
@@ -109,7 +110,7 @@ static int materialize_uend(sdc_ctx* c) {
 
 static double* slot_ptr(sdc_ctx* c, int slot, int m, int comp) {
     switch (slot) {
-        case SDC_SLOT_U: return (m >= 0 && m <= c->M) ? c->U + (size_t)m * c->N : nullptr;
+        case SDC_SLOT_U: return m == 0 ? c->U0 : ((m >= 1 && m <= c->M) ? c->U + (size_t)m * c->N : nullptr);
         case SDC_SLOT_F:
             return (m >= 0 && m <= c->M && comp >= 0 && comp < c->ncomp) ? c->F + ((size_t)m * c->ncomp + comp) * c->N
                                                                          : nullptr;
@@ -120,8 +121,11 @@ static double* slot_ptr(sdc_ctx* c, int slot, int m, int comp) {
 }
 
 template <int MODE>
-static int launch_quad(sdc_ctx* c, const QuadArgs& a, const char* name) {
+static int launch_quad(sdc_ctx* c, const QuadArgs& a0, const char* name) {
     NEED_NODES(c);
+    QuadArgs a = a0;   // (the bases as they are NOW: the blocks may have been allocated a moment ago)
+    a.F = c->F;
+    if (a.Usub) a.Usub = c->U;
     LaunchTimer lt(c, name);
     int grid = grid_for(c->N / 2, 256);
     if (MODE >= 1 && grid > 2048) grid = 2048;   // (norms: fewer, longer workgroups - fewer atomics on the M slots)
@@ -230,6 +234,7 @@ static int eval_nodes(sdc_ctx* c, double dt) {
         StencilResArgs a;
         memset(&a, 0, sizeof a);
         a.U = c->U;
+        a.u0 = c->U0;
         a.F = c->F;
         for (int k = 0; k < 3; ++k) {
             a.wI[k] = c->st[0].w[k];
@@ -625,7 +630,7 @@ static int spec_sweep_n(sdc_ctx* c, int nf, SpecArgs& a, const FieldPtrs& p, uns
                         bool spec_only) {
     const int n = c->n;
     const size_t lines = c->ndim == 1 ? 1 : (size_t)(n / 2 + 1) * (c->ndim == 3 ? n : 1);
-    if constexpr (SDC_FUSE_SPECZ && N >= 64 && N <= 1024) {  // fused with the first inverse pass (M <= 5)
+    if constexpr (SDC_FUSE_SPECZ && N >= 64 && N <= 1024 && (N & (N - 1)) == 0) {  // fused with the first inverse pass (M <= 5)
         if (nf <= 5 && !spec_only) {
             {
                 // after a spread predictor all nodes share S0: that launch does not read S (fewer bytes)
@@ -699,7 +704,13 @@ static int spec_sweep_n(sdc_ctx* c, int nf, SpecArgs& a, const FieldPtrs& p, uns
         case 512: return CALL(512);                                                                         \
         case 1024: return CALL(1024);                                                                       \
         case 2048: return CALL(2048);                                                                       \
-        default: return fail(c, SDC_ERR_UNSUPPORTED, "spectral solve needs n = 2^p <= 2048, got %d", (c)->n); \
+        case 24: return CALL(24);                                                                           \
+        case 48: return CALL(48);                                                                           \
+        case 96: return CALL(96);                                                                           \
+        case 192: return CALL(192);                                                                         \
+        case 384: return CALL(384);                                                                         \
+        case 768: return CALL(768);                                                                         \
+        default: return fail(c, SDC_ERR_UNSUPPORTED, "spectral solve needs n = 2^p <= 2048 or 3 * 2^p in 24 .. 768, got %d", (c)->n); \
     }
 
 static int fwd_transform(sdc_ctx* c, int nf, const FieldPtrs& p, cd* dst, size_t fstride) {
@@ -725,7 +736,7 @@ static int spec_residual_n(sdc_ctx* c, SpecArgs& a, unsigned long long* norms) {
     const size_t lines = c->ndim == 1 ? 1 : (size_t)(n / 2 + 1) * (c->ndim == 3 ? n : 1);
     FieldPtrs p0;
     memset(&p0, 0, sizeof p0);
-    if constexpr (SDC_FUSE_SPECZ && N >= 64 && N <= 1024) {
+    if constexpr (SDC_FUSE_SPECZ && N >= 64 && N <= 1024 && (N & (N - 1)) == 0) {
         if (nf <= 5) {
             {
                 LaunchTimer lt(c, pname("spec_z_resid", nf));
@@ -847,6 +858,7 @@ static int store_spectra(sdc_ctx* c, bool last_only) {
     if (!last_only) {
         int rcn = need_node_spectra(c);
         if (rcn != SDC_OK) return rcn;
+        a.S = c->S;
     }
     const int n = c->n;
     const size_t lines = c->ndim == 1 ? 1 : (size_t)(n / 2 + 1) * (c->ndim == 3 ? n : 1);
@@ -967,7 +979,7 @@ static int fft_pipeline(sdc_ctx* c, int nf, const FieldPtrs& p, ZArgs& z, const 
     if (!c->have_stencil[0]) return fail(c, SDC_ERR_STATE, "implicit operator not set (sdc_set_stencil)");
     if (!fourier_ok(c))
         return fail(c, SDC_ERR_UNSUPPORTED,
-                    "spectral solve needs n = 2^p <= 1024 per dimension (<= 2048 in 1-D / 2-D), got %d", c->n);
+                    "spectral solve needs n = 2^p <= 1024 per dimension (<= 2048 in 1-D / 2-D) or 3 * 2^p in 24 .. 768, got %d", c->n);
     {
         int rw = ensure_work(c);
         if (rw != SDC_OK) return rw;
@@ -984,6 +996,12 @@ static int fft_pipeline(sdc_ctx* c, int nf, const FieldPtrs& p, ZArgs& z, const 
         case 512: return fft_pipeline_n<512>(c, nf, p, z, rq, lin);
         case 1024: return fft_pipeline_n<1024>(c, nf, p, z, rq, lin);
         case 2048: return fft_pipeline_n<2048>(c, nf, p, z, rq, lin);
+        case 24: return fft_pipeline_n<24>(c, nf, p, z, rq, lin);
+        case 48: return fft_pipeline_n<48>(c, nf, p, z, rq, lin);
+        case 96: return fft_pipeline_n<96>(c, nf, p, z, rq, lin);
+        case 192: return fft_pipeline_n<192>(c, nf, p, z, rq, lin);
+        case 384: return fft_pipeline_n<384>(c, nf, p, z, rq, lin);
+        case 768: return fft_pipeline_n<768>(c, nf, p, z, rq, lin);
     }
     return fail(c, SDC_ERR_UNSUPPORTED, "n = %d", c->n);
 }
@@ -1212,14 +1230,16 @@ int sdc_ctx_create(sdc_ctx** out, int device, int ndim, int n, int num_nodes, in
         // U[0] is there from the start; U[1..M] and F are mapped when something first touches them in real space (the sweeps
         // that stay in Fourier space never do)
         c->bytes = 0;
-        int rcs = slab_reserve(c, c->slabU, fb, c->M + 1, 1);
-        if (rcs == SDC_OK) rcs = slab_reserve(c, c->slabF, fb, (c->M + 1) * ncomp, 0);
-        if (rcs != SDC_OK) {
-            g_create_err = c->err;
-            return rcs;
+        HIPCHK(nullptr, hipMalloc((void**)&c->U0, fb));
+        HIPCHK(nullptr, hipMemsetAsync(c->U0, 0, fb, c->stream));
+        c->bytes += fb;
+        if (fb < c->lazy_min_bytes) {   // small fields: everything from the start (same blocks, same addressing)
+            int rcs = need_nodes(c);
+            if (rcs != SDC_OK) {
+                g_create_err = c->err;
+                return rcs;
+            }
         }
-        c->U = reinterpret_cast<double*>(c->slabU.base);
-        c->F = reinterpret_cast<double*>(c->slabF.base);
         HIPCHK(nullptr, hipMalloc((void**)&c->UEND, fb));
         HIPCHK(nullptr, hipMalloc((void**)&c->red, sizeof(unsigned long long) * 16));
         HIPCHK(nullptr, hipHostMalloc((void**)&c->red_host, sizeof(unsigned long long) * 16));
@@ -1237,7 +1257,7 @@ int sdc_ctx_create(sdc_ctx** out, int device, int ndim, int n, int num_nodes, in
         HIPCHK(nullptr, hipEventCreate(&c->ev1));
         HIPCHK(nullptr, hipEventCreate(&c->pev0));
         HIPCHK(nullptr, hipEventCreate(&c->pev1));
-        if (is_pow2(n)) {
+        if (is_pow2(n) || fft_length_ok(n)) {
             std::vector<cd> tw(n);
             for (int m = 0; m < n; ++m) {
                 const long double ang = 2.0L * 3.14159265358979323846264338327950288L * (long double)m / (long double)n;
@@ -1264,9 +1284,10 @@ int sdc_ctx_destroy(sdc_ctx* c) {
     (void)flush_x(c);
     comm_free(c);
     (void)hipStreamSynchronize(c->stream);
-    slab_free(c->slabU);
-    slab_free(c->slabF);
-    slab_free(c->slabS);
+    (void)hipFree(c->U0);
+    (void)hipFree(c->Un);
+    (void)hipFree(c->F);
+    (void)hipFree(c->Sn);
     for (cd* b : c->spool_owned) (void)hipFree(b);
     (void)hipFree(c->TAU);
     (void)hipFree(c->UEND);
@@ -1504,18 +1525,21 @@ static int ensure_tau(sdc_ctx* c) {
 }
 
 static int ensure_spec_cache(sdc_ctx* c) {
-    if (!c->S) {
-        // the last node's slot is there from the start (it takes turns with the start value's spectrum); the other node
-        // spectra are mapped when an iterate is first STORED (need_node_spectra) - sweeps that recompute their iterate never do
-        int rcs = slab_reserve(c, c->slabS, sizeof(cd) * c->Nc, c->M, 0);
-        if (rcs == SDC_OK) rcs = slab_map(c, c->slabS, c->M - 1, 1);
-        if (rcs != SDC_OK) return rcs;
-        c->S = reinterpret_cast<cd*>(c->slabS.base);
+    if (!c->Sx) {
+        // the start value's and the last node's spectrum are there from the start (they trade places from step to step); the
+        // other node spectra are allocated when an iterate is first STORED (need_node_spectra) - sweeps that recompute theirs
+        // never do
         HIPCHK(c, hipMalloc((void**)&c->Sx, sizeof(cd) * c->Nc));
         c->S0 = c->Sx;
-        c->SL = c->S + (size_t)(c->M - 1) * c->Nc;
+        c->SL = spool_get(c);   // (its own buffer: it takes turns with the start value's spectrum)
+        if (!c->SL) return SDC_ERR_NOMEM;
         c->bytes += sizeof(cd) * c->Nc;
         c->spec_valid = c->spec0_valid = false;
+        if (sizeof(cd) * c->Nc < c->lazy_min_bytes) {
+            int rcs = need_node_spectra(c);
+            if (rcs != SDC_OK) return rcs;
+        }
+        c->S = c->Sn;
     }
     // the second end-value buffer of sdc_advance, allocated with the cache (not inside a time loop) - unless this is a
     // time-parallel level (keep_rfields / early_uend are switched on before its first sweep): those advance in place only as
@@ -1609,7 +1633,7 @@ int sdc_materialize(sdc_ctx* c, int slot, int m) {
             int rcf = need_f0(c);
             if (rcf != SDC_OK) return rcf;
             c->f0_pending = false;
-            return sdc_eval_f(c, c->U, c->gvals[0], c->F, c->ncomp == 2 ? c->F + c->N : nullptr);
+            return sdc_eval_f(c, c->U0, c->gvals[0], c->F, c->ncomp == 2 ? c->F + c->N : nullptr);
         }
         return SDC_OK;
     }
@@ -1627,7 +1651,7 @@ int sdc_materialize(sdc_ctx* c, int slot, int m) {
     if (slot < 0) ENSURE_U0(c);  // "everything": all of the real-space state is about to be used as it is stored
     if (slot < 0 && c->f0_pending) {
         c->f0_pending = false;
-        int rc0 = sdc_eval_f(c, c->U, c->gvals[0], c->F, c->ncomp == 2 ? c->F + c->N : nullptr);
+        int rc0 = sdc_eval_f(c, c->U0, c->gvals[0], c->F, c->ncomp == 2 ? c->F + c->N : nullptr);
         if (rc0 != SDC_OK) return rc0;
     }
     // a node value that is handed out may be overwritten by the holder: F[1..M] = f(U[1..M]) of the CURRENT node
@@ -1653,7 +1677,7 @@ long long sdc_end_value_generation(sdc_ctx* c) {
     // > 0 while the end value (UEND, or its put-off transform) still IS the last node of the cached iterate, i.e. while
     // sdc_advance could hand it over; changes with every sweep.  A caller that gave a COPY of the end value away can tell
     // later whether the engine still holds exactly that state (pysdc_amd/controller.py: consecutive run() calls).
-    if (!c || !c->S || !c->spec_valid || c->uend_gen < 0 || c->uend_gen != c->spec_gen) return -1;
+    if (!c || !c->Sx || !c->spec_valid || c->uend_gen < 0 || c->uend_gen != c->spec_gen) return -1;
     return c->spec_gen + 1;
 }
 
@@ -2069,7 +2093,7 @@ static int sweep_nodewise(sdc_ctx* c, double dt, bool keep_guess = false) {
     }
     QuadArgs q;
     quad_base(c, q);
-    q.u0 = c->U;
+    q.u0 = c->U0;
     q.tau = c->tau_active ? c->TAU : nullptr;
     for (int m = 0; m < M; ++m) {
         // without keep_guess the old iterate is only a solver guess: its storage takes the right-hand side
@@ -2183,6 +2207,7 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
         VdpSweepArgs a;
         memset(&a, 0, sizeof a);
         a.U = c->U;
+        a.u0 = c->U0;
         a.F = c->F;
         a.tau = c->tau_active ? c->TAU : nullptr;
         a.T = c->N / 2;
@@ -2339,11 +2364,11 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
         // nobody will ask for the residual of this iterate (sdc_set_skip_residual): only the cached transforms move
         const bool spec_only = c->deferred && c->skip_residual && c->ndim >= 2 && M <= 8;
         const bool norms_only = !spec_only && c->deferred && c->fuse_residual && c->ndim >= 2;
+        if (!(spec_only || (norms_only && !c->keep_rfields))) NEED_NODES(c);   // (before their addresses are formed)
         for (int m = 0; m < M; ++m) {
             // norms only: nothing is stored in real space - unless the residual FIELDS are wanted (keep_rfields),
             // which then occupy the U[1..M] slab while the iterate itself lives in the cache
             p.out[m] = (spec_only || (norms_only && !c->keep_rfields)) ? nullptr : c->U + (size_t)(m + 1) * c->N;
-            if (p.out[m]) NEED_NODES(c);
             a.alpha[m] = dt * c->QI[m + 1][m + 1];
             for (int j = 0; j < M; ++j) {
                 a.gI[m][j] = dt * (c->Q[m + 1][j + 1] - c->QI[m + 1][j + 1]);
@@ -2362,7 +2387,7 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
         // lines - 6 instead of 16 spectrum passes.  store_spectra writes the iterate out when somebody needs it.
         bool go = false;
         {
-            const bool fused_z = SDC_FUSE_SPECZ && c->n >= 64 && c->n <= 1024 && M <= 5;
+            const bool fused_z = SDC_FUSE_SPECZ && c->n >= 64 && c->n <= 1024 && is_pow2(c->n) && M <= 5;
             // (with a residual to deliver this pays for a REAL symbol without explicit part - heat: real multipliers, and
             // the modes kz / N - kz of a line share them; complex multipliers cost more than reading the stored iterate:
             // advection-diffusion 512^3 3.2 -> 3.4 ms per launch)
@@ -2373,7 +2398,7 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
             // unstored iterate becomes a function of ALL the start values the slice has had since its predictor - a trail
             // (trail_iterate), kept while their number stays below trail_max; the launch always writes the last node's spectrum
             const bool trail = c->wire_spectral && c->early_uend && c->trail_max > 0 && norms_only && pairs_z && !c->keep_rfields;
-            go = c->virt_max > 0 && (c->deferred || iter_out) && !c->keep_rfields && (!c->early_uend || trail) && c->ndim >= 2 &&
+            go = c->virt_max > 0 && is_pow2(c->n) && (c->deferred || iter_out) && !c->keep_rfields && (!c->early_uend || trail) && c->ndim >= 2 &&
                       c->expl_kind != SDC_EXPL_FORCING &&
                       (spec_only || iter_out || (norms_only && fused_z && a.real_sym && !a.lamE));
             SpecCoef now;
@@ -2486,6 +2511,7 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
         if (!go) {   // the iterate is (about to be) stored in the node spectra
             int rcn = need_node_spectra(c);
             if (rcn != SDC_OK) return rcn;
+            a.S = c->S;
         }
         FLUSH_X(c);   // (norms of the previous iterate that still wait for their last pass: before the slots are cleared)
         if (norms_only) {
@@ -2526,7 +2552,7 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
     // 1. gather u0 + dt (Q - QI) F_impl + dt (Q - QE) F_expl (+ tau) for all nodes into U[1..M]
     QuadArgs q;
     quad_base(c, q);
-    q.u0 = c->U;
+    q.u0 = c->U0;
     q.tau = c->tau_active ? c->TAU : nullptr;
     const bool forcing = c->expl_kind == SDC_EXPL_FORCING;
     for (int m = 0; m < M; ++m) {
@@ -3079,7 +3105,7 @@ int sdc_residual_post_integrals(sdc_ctx* c, double dt, int type, double* const* 
             if (rcm != SDC_OK) return rcm;
             QuadArgs q;
             quad_base(c, q);
-            q.u0 = c->U;
+            q.u0 = c->U0;
             q.tau = c->tau_active ? c->TAU : nullptr;
             q.Usub = c->U;
             q.norms = c->red;
@@ -3204,7 +3230,7 @@ int sdc_end_point(sdc_ctx* c, double dt, int do_coll_update) {
     if (rcm != SDC_OK) return rcm;
     QuadArgs q;
     quad_base(c, q);
-    q.u0 = c->U;
+    q.u0 = c->U0;
     q.tau = c->tau_active ? c->TAU : nullptr;
     q.tau_row0 = c->M - 1;
     q.nout = 1;
@@ -3222,7 +3248,7 @@ int sdc_advance(sdc_ctx* c) {
     c->res_spread = false;
     c->spec_spread = false;
     // UEND is the inverse transform of the last node's spectrum: that spectrum is the transform of the new u[0]
-    const bool handover = c->S && c->spec_valid && c->uend_gen >= 0 && c->uend_gen == c->spec_gen;
+    const bool handover = c->Sx && c->spec_valid && c->uend_gen >= 0 && c->uend_gen == c->spec_gen;
     c->prev_sweeps = (c->spec_valid && c->spec_virtual > 0) ? c->spec_virtual : 0;
     if (handover) STORE_SPECTRA(c, true);  // (SL has to BE there; S0 changes below)
     if (handover) {
@@ -3265,7 +3291,7 @@ int sdc_advance(sdc_ctx* c) {
     }
     c->u0_src = nullptr;  // U[0] is overwritten as a whole
     c->u0_spec_only = false;
-    HIPCHK(c, hipMemcpyAsync(c->U, c->UEND, c->N * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->U0, c->UEND, c->N * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     if (handover) {
         HIPCHK(c, hipMemcpyAsync(c->S0, c->SL, sizeof(cd) * c->Nc, hipMemcpyDeviceToDevice, c->stream));
         c->spec0_valid = true;
@@ -3329,13 +3355,13 @@ int sdc_replace_u0(sdc_ctx* c, const double* src) {
         LaunchTimer lt(c, pname("replace_u0", c->M));
         const int grid = grid_for(c->N / 2, 256);
 #define RCASE(MM) \
-    case MM: hipLaunchKernelGGL((k_replace_u0<MM>), dim3(grid), dim3(256), 0, c->stream, src, c->U, c->N, c->res_dev); break;
+    case MM: hipLaunchKernelGGL((k_replace_u0<MM>), dim3(grid), dim3(256), 0, c->stream, src, c->U0, c->U, c->N, c->res_dev); break;
         switch (c->M) { RCASE(1) RCASE(2) RCASE(3) RCASE(4) RCASE(5) RCASE(6) RCASE(7) RCASE(8) }
 #undef RCASE
         HIPCHK(c, hipGetLastError());
         c->rfields_valid = false;  // the stored fields belong to the old u[0]
     } else {
-        HIPCHK(c, hipMemcpyAsync(c->U, src, c->N * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->U0, src, c->N * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
         c->res_valid = false;
     }
     c->res_spread = false;
@@ -3381,7 +3407,7 @@ void* sdc_end_spectrum(sdc_ctx* c, void* stream) {
     if (!c || !c->have_coeffs) return nullptr;
     const cd* src = nullptr;
     hipEvent_t ev = nullptr;
-    if (c->S && c->spec_valid && c->uend_gen >= 0 && c->uend_gen == c->spec_gen) {
+    if (c->Sx && c->spec_valid && c->uend_gen >= 0 && c->uend_gen == c->spec_gen) {
         if (store_spectra(c, true) != SDC_OK) return nullptr;  // (an iterate that was never stored: now its last node is)
         src = c->SL;
         if (c->sl_ev_recorded) ev = c->sl_ev;
@@ -3538,6 +3564,45 @@ int sdc_vec_axpby(sdc_ctx* c, size_t n, double a, const double* x, double b, con
     return SDC_OK;
 }
 
+int sdc_vec_box(sdc_ctx* c, int ndim, const long long* shape, const long long* start, const long long* step,
+                const long long* count, double* field, double* compact, int direction, double value) {
+    CTX_OR_DEFAULT(c);
+    if (ndim < 1 || ndim > 4 || !shape || !start || !step || !count || !field || direction < 0 || direction > 2 ||
+        (direction != 2 && !compact))
+        return fail(c, SDC_ERR_PARAM, "bad box arguments");
+    BoxArgs a;
+    memset(&a, 0, sizeof a);
+    // right-aligned into four axes; strides of the C-ordered field
+    long long stride = 1, total = 1;
+    for (int d = 0; d < 4; ++d) {
+        a.c[d] = 1;
+        a.s[d] = 0;
+    }
+    for (int d = ndim - 1; d >= 0; --d) {
+        const int q = 4 - ndim + d;
+        if (shape[d] < 1 || count[d] < 0 || step[d] == 0) return fail(c, SDC_ERR_PARAM, "bad box arguments (axis %d)", d);
+        if (count[d] > 0) {
+            const long long last = start[d] + (count[d] - 1) * step[d];
+            if (start[d] < 0 || start[d] >= shape[d] || last < 0 || last >= shape[d])
+                return fail(c, SDC_ERR_PARAM, "index out of bounds on axis %d (size %lld)", d, shape[d]);
+        }
+        a.c[q] = count[d];
+        a.s[q] = step[d] * stride;
+        a.off += start[d] * stride;
+        stride *= shape[d];
+        total *= count[d];
+    }
+    if (total == 0) return SDC_OK;
+    a.field = field;
+    a.compact = compact;
+    a.value = value;
+    a.dir = direction;
+    LaunchTimer lt(c, "box");
+    hipLaunchKernelGGL(k_box, dim3(grid_for((size_t)total, 256)), dim3(256), 0, c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    return SDC_OK;
+}
+
 int sdc_vec_amax(sdc_ctx* c, size_t n, const double* x, double* out) {
     CTX_OR_DEFAULT(c);
     if (!x || !out) return fail(c, SDC_ERR_PARAM, "null pointer");
@@ -3681,10 +3746,10 @@ int sdc_transfer_apply_batch_acc(void* stream, int nfields, int ndim, int n_out,
 
 int sdc_fft_prolong(sdc_ctx* coarse, sdc_ctx* fine, const double* src, double* dst, double factor) {
     if (!coarse || !fine || !src || !dst) return fail(fine, SDC_ERR_PARAM, "null pointer");
-    if (coarse->ndim != fine->ndim || fine->ndim > 2)
-        return fail(fine, SDC_ERR_UNSUPPORTED, "Fourier prolongation is built for 1-D and 2-D grids (got %d-D -> %d-D)",
+    if (coarse->ndim != fine->ndim)
+        return fail(fine, SDC_ERR_UNSUPPORTED, "Fourier prolongation between grids of one dimension (got %d-D -> %d-D)",
                     coarse->ndim, fine->ndim);
-    if (coarse->kind != 0 || fine->kind != 0 || !is_pow2(coarse->n) || !is_pow2(fine->n) || fine->n < coarse->n ||
+    if (coarse->kind != 0 || fine->kind != 0 || !fourier_ok(coarse) || !fourier_ok(fine) || fine->n < coarse->n ||
         coarse->n < 2 || fine->n > 1024)
         return fail(fine, SDC_ERR_UNSUPPORTED, "Fourier prolongation needs n = 2^p <= 1024 on both grids (%d -> %d)",
                     coarse->n, fine->n);
@@ -3709,8 +3774,11 @@ int sdc_fft_prolong(sdc_ctx* coarse, sdc_ctx* fine, const double* src, double* d
         if (fine->ndim == 1)
             hipLaunchKernelGGL(k_pad_spectrum_1d, dim3(grid_for(nf, 256)), dim3(256), 0, fine->stream, coarse->W, fine->W,
                                nc, nf);
-        else
+        else if (fine->ndim == 2)
             hipLaunchKernelGGL(k_pad_spectrum_2d, dim3(grid_for((size_t)(nf / 2 + 1) * nf, 256)), dim3(256), 0,
+                               fine->stream, coarse->W, fine->W, nc, nf);
+        else
+            hipLaunchKernelGGL(k_pad_spectrum_3d, dim3(grid_for((size_t)(nf / 2 + 1) * nf * nf, 256)), dim3(256), 0,
                                fine->stream, coarse->W, fine->W, nc, nf);
     }
     HIPCHK(fine, hipGetLastError());

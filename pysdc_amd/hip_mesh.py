@@ -48,6 +48,21 @@ class device_buffer:
         _check_hip(_hip().hipMemcpy(C.c_void_p(self.ptr), h.ctypes.data_as(C.c_void_p), self.nbytes, 1))
 
 
+def _torch_key(key):
+    """an advanced-indexing key with its arrays on the device"""
+    torch = _torch()
+
+    def conv(k):
+        if isinstance(k, hip_mesh):
+            return k.as_torch().reshape(k.shape)
+        if isinstance(k, (np.ndarray, list)):
+            a = np.asarray(k)
+            return torch.as_tensor(a, device='cuda')
+        return k
+
+    return tuple(conv(k) for k in key) if isinstance(key, tuple) else conv(key)
+
+
 class hip_mesh:
     comm = None
     xp = None
@@ -147,10 +162,73 @@ class hip_mesh:
         torch = _torch()
         return torch.as_tensor(_CAI(self.ptr, self.size, self), device='cuda')
 
-    # ---- assignment ----------------------------------------------------------------------------------
+    # ---- indexing (mesh IS an ndarray, datatype_classes/mesh.py:12-60: u[i], u[..., j], u[1:-1], u[mask]) ------------------
+    @staticmethod
+    def _whole(key):
+        return key is Ellipsis or (isinstance(key, slice) and key == slice(None))
+
+    def _box(self, key):
+        """basic indexing resolved against self.shape: (start, step, count) per axis and the shape of the result (integer
+        axes dropped), or None when the key needs advanced indexing (index arrays, masks, np.newaxis)"""
+        key = key if isinstance(key, tuple) else (key,)
+        if any(not (isinstance(k, (int, np.integer, slice)) or k is Ellipsis) or isinstance(k, (bool, np.bool_)) for k in key):
+            return None
+        if sum(k is Ellipsis for k in key) > 1:
+            raise IndexError("an index can only have a single ellipsis ('...')")
+        nd = len(self.shape)
+        given = sum(k is not Ellipsis for k in key)
+        if given > nd:
+            raise IndexError(f'too many indices for array: array is {nd}-dimensional, but {given} were indexed')
+        full = []
+        for k in key:
+            full += [slice(None)] * (nd - given) if k is Ellipsis else [k]
+        full += [slice(None)] * (nd - len(full))
+        start, step, count, out_shape = [], [], [], []
+        for ax, (k, n) in enumerate(zip(full, self.shape)):
+            if isinstance(k, slice):
+                a, b, c = k.indices(n)
+                cnt = len(range(a, b, c))
+                start.append(a if cnt else 0)
+                step.append(c)
+                count.append(cnt)
+                out_shape.append(cnt)
+            else:
+                i = int(k)
+                if not -n <= i < n:
+                    raise IndexError(f'index {i} is out of bounds for axis {ax} with size {n}')
+                start.append(i % n)
+                step.append(1)
+                count.append(1)
+        return start, step, count, tuple(out_shape)
+
+    def _box_call(self, box, compact_ptr, direction, value=0.0):
+        start, step, count, _ = box
+        nd = len(self.shape)
+        arr = lambda v: (C.c_longlong * nd)(*[int(x) for x in v])   # noqa: E731
+        _chk(L.load().sdc_vec_box(None, nd, arr(self.shape), arr(start), arr(step), arr(count), self.ptr, compact_ptr, direction,
+                                  float(value)))
+
     def __setitem__(self, key, value):
-        if not (key is Ellipsis or (isinstance(key, slice) and key == slice(None))):
-            raise NotImplementedError('hip_mesh supports whole-field assignment only: x[:] = value')
+        if not self._whole(key):
+            box = self._box(key)
+            if box is None:   # index arrays / masks: through a torch view of the same memory
+                t = self.as_torch().reshape(self.shape)
+                t[_torch_key(key)] = value.as_torch().reshape(value.shape) if isinstance(value, hip_mesh) else _torch().as_tensor(
+                    np.asarray(value, dtype=np.float64), device='cuda')
+            elif np.isscalar(value):
+                self._box_call(box, None, 2, value)
+            else:
+                shape = box[3]
+                if isinstance(value, hip_mesh):
+                    if value.shape != shape and value.size != int(np.prod(shape)):
+                        raise DataError(f'could not broadcast input of shape {value.shape} into shape {shape}')
+                    src = value
+                else:
+                    src = hip_mesh((shape if shape else (1,), None, _F64), val=None)
+                    src.set(np.broadcast_to(np.asarray(value, dtype=np.float64), shape if shape else (1,)))
+                self._box_call(box, src.ptr, 1)
+            self._wrote()
+            return
         if isinstance(value, hip_mesh):
             if value.size != self.size:
                 raise DataError(f'size mismatch: {value.size} vs {self.size}')
@@ -163,9 +241,56 @@ class hip_mesh:
         self._wrote()
 
     def __getitem__(self, key):
-        if key is Ellipsis or (isinstance(key, slice) and key == slice(None)):
+        """whole field: the object itself.  Integers / slices: the selected box gathered on the device into a NEW hip_mesh
+        (a copy - where ndarray hands out a view; write through `x[key] = ...`), or a Python float when every axis got an
+        integer.  Index arrays and masks: the same through a torch view of the memory."""
+        if self._whole(key):
             return self
-        raise NotImplementedError('hip_mesh supports whole-field access only; use .get() for host indexing')
+        box = self._box(key)
+        if box is None:
+            t = self.as_torch().reshape(self.shape)[_torch_key(key)]
+            if t.ndim == 0:
+                return float(t.item())
+            out = hip_mesh((tuple(t.shape), None, _F64), val=None)
+            out.as_torch().reshape(t.shape).copy_(t)
+            return out
+        shape = box[3]
+        out = hip_mesh((shape if shape else (1,), None, _F64), val=None)
+        if out.size:
+            self._box_call(box, out.ptr, 0)
+        return out if shape else float(out.get()[0])
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __iter__(self):
+        return (self[i] for i in range(self.shape[0]))
+
+    def reshape(self, *shape):
+        """another shape over the same memory (ndarray.reshape of a contiguous array: a view)"""
+        shape = shape[0] if len(shape) == 1 and not np.isscalar(shape[0]) else shape
+        shape = tuple(int(v) for v in shape)
+        if -1 in shape:
+            known = int(np.prod([v for v in shape if v != -1]))
+            shape = tuple(self.size // max(known, 1) if v == -1 else v for v in shape)
+        if int(np.prod(shape)) != self.size:
+            raise ValueError(f'cannot reshape array of size {self.size} into shape {shape}')
+        return hip_mesh.view(self.ptr, shape, keep=self, on_write=self._on_write, on_access=self._on_access)
+
+    def ravel(self):
+        return self.flatten()
+
+    def max(self):
+        return float(self.as_torch().max().item())
+
+    def min(self):
+        return float(self.as_torch().min().item())
+
+    def sum(self):
+        return float(self.as_torch().sum().item())
+
+    def mean(self):
+        return float(self.as_torch().mean().item())
 
     # ---- arithmetic (mesh.py:49-63: results keep the datatype) ------------------------------------------
     def _new_like(self):

@@ -87,6 +87,7 @@ PROTOTYPES = {
     'sdc_comm_bcast_end_spectrum': (C.c_int, [_vp, C.c_int]),
     'sdc_comm_set_chunk': (C.c_int, [_vp, C.c_size_t]),
     'sdc_comm_set_relay': (C.c_int, [_vp, C.c_int]),
+    'sdc_comm_set_host_share': (C.c_int, [_vp, C.c_double]),
     'sdc_comm_set_format': (C.c_int, [_vp, C.c_int]),
     'sdc_comm_info': (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_ulonglong),
                                 C.POINTER(C.c_ulonglong), C.c_char_p]),
@@ -107,6 +108,8 @@ PROTOTYPES = {
     'sdc_vec_fill': (C.c_int, [_vp, C.c_size_t, C.c_double, _vp]),
     'sdc_vec_axpby': (C.c_int, [_vp, C.c_size_t, C.c_double, _vp, C.c_double, _vp, _vp]),
     'sdc_vec_amax': (C.c_int, [_vp, C.c_size_t, _vp, _dp]),
+    'sdc_vec_box': (C.c_int, [_vp, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong),
+                              C.POINTER(C.c_longlong), _vp, _vp, C.c_int, C.c_double]),
     'sdc_set_problem_vdp': (C.c_int, [_vp, C.c_double, C.c_double, C.c_int]),
     'sdc_set_vdp_block_solver': (C.c_int, [_vp, C.c_int]),
     'sdc_work_counters': (C.c_int, [_vp, C.POINTER(C.c_ulonglong)]),

@@ -157,7 +157,9 @@ class BaseTransfer:
         ef.ptr(Lb.SLOT_U, 1)                      # (node fields that were put off are stored now)
         ec.ptr(Lb.SLOT_U, 1)
         coarse._lists()
-        self._space_batch('R', M + 1, ef.ptr(Lb.SLOT_U, 0), ec.ptr(Lb.SLOT_U, 0))
+        # (u[0] and U[1..M] are blocks of their own inside the engines: two calls, the node fields as one batch)
+        self._space_batch('R', 1, ef.ptr(Lb.SLOT_U, 0), ec.ptr(Lb.SLOT_U, 0))
+        self._space_batch('R', M, ef.ptr(Lb.SLOT_U, 1), ec.ptr(Lb.SLOT_U, 1))
         coarse._u.mark(range(M + 1))
         coarse._touched(Lb.SLOT_U, 0)
         coarse._touched(Lb.SLOT_U, 1)
@@ -575,3 +577,17 @@ class mesh_to_mesh_fft2d(_fourier_transfer):
 
     def _factor(self):
         return self.ratio * 2
+
+
+class mesh_to_mesh_fft3d(_fourier_transfer):
+    """The same in 3-D: restriction by injection, prolongation by copying the eight corner blocks of fftn(G) into a zero fine
+    spectrum and taking the real part of its inverse transform.  The reference's Fourier transfer in three dimensions
+    (transfer_classes/TransferMesh_MPIFFT.py:51-136, `fft_to_fft`) delegates the padded transform to mpi4py_fft, which is
+    not available here; this class extends TransferMesh_FFT2D.py:58-77 by one axis instead - a field that does not depend on
+    one axis is prolonged plane by plane exactly as mesh_to_mesh_fft2d does it, including its factor (2 * ratio there, hence
+    2 * ratio^2 here; both are the interpolating ratio^ndim for ratio 2)."""
+
+    ndim = 3
+
+    def _factor(self):
+        return 2 * self.ratio**2

@@ -54,6 +54,22 @@ class HostLib:
         out._obj.value = float(np.max(np.abs(v))) if not np.isnan(v).any() else float('nan')
         return 0
 
+    def sdc_vec_box(self, ctx, ndim, shape, start, step, count, field, compact, direction, value):
+        shp = [int(shape[d]) for d in range(ndim)]
+        f = _arr(field, int(np.prod(shp))).reshape(shp)
+        cnt = [int(count[d]) for d in range(ndim)]
+        if int(np.prod(cnt)) == 0:
+            return 0
+        key = tuple(np.arange(cnt[d]) * int(step[d]) + int(start[d]) for d in range(ndim))
+        sel = np.ix_(*key)
+        if direction == 0:
+            _arr(compact, int(np.prod(cnt)))[:] = f[sel].reshape(-1)
+        elif direction == 1:
+            f[sel] = _arr(compact, int(np.prod(cnt))).reshape(cnt)
+        else:
+            f[sel] = value
+        return 0
+
     def sdc_last_error(self, ctx):
         return b'host stand-in'
 

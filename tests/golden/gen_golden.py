@@ -11,7 +11,7 @@ own entry points, switched on by environment variables (or call the function aft
 GOLDEN_FFT=1 fft_transfer_main (transfer_fft.npz, runs_ac_fft.npz), GOLDEN_RELAY=1 relay_main (runs_relay.npz),
 GOLDEN_CG=1 cg_main (sweeps_cg.npz), GOLDEN_VDPJ=1 vdp_jacobian_main (vdp_jacobian.npz), GOLDEN_DML=1
 dirichlet_ml_main (transfer_dirichlet.npz, runs_ml_dirichlet.npz), GOLDEN_GUESS=1 guess_main (sweeps_guess.npz), GOLDEN_SKIP=1 skip_main (runs_skip.npz), GOLDEN_RELAY8=1 relay8_main (runs_relay8.npz),
-GOLDEN_BIG3D=1 big3d_main (sweeps_big3d.npz), GOLDEN_CFG5=1 cfg5_main (runs_cfg5.npz), GOLDEN_ML8=1 ml8_main (runs_ml8.npz), GOLDEN_DND=1 dirichlet_nd_main (sweeps_dirichlet_nd.npz, runs_dirichlet_nd.npz), GOLDEN_NSW2=1 nsweeps2_main (runs_nsweeps2.npz), GOLDEN_PIN1024=1 pin1024_main (sweeps_pin1024.npz, 20 minutes), GOLDEN_GMRES=1 gmres_main (sweeps_gmres.npz), GOLDEN_DHO=1 dirichlet_ho_main (sweeps_dirichlet_ho.npz, runs_dirichlet_ho.npz, dirichlet_ho_matrices.npz), GOLDEN_BC=1 boundary_main (boundary_matrices.npz, sweeps_neumann.npz, runs_neumann.npz), GOLDEN_PIN512=1 pin512_main (sweeps_pin512.npz);
+GOLDEN_BIG3D=1 big3d_main (sweeps_big3d.npz), GOLDEN_CFG5=1 cfg5_main (runs_cfg5.npz), GOLDEN_ML8=1 ml8_main (runs_ml8.npz), GOLDEN_DND=1 dirichlet_nd_main (sweeps_dirichlet_nd.npz, runs_dirichlet_nd.npz), GOLDEN_NSW2=1 nsweeps2_main (runs_nsweeps2.npz), GOLDEN_PIN1024=1 pin1024_main (sweeps_pin1024.npz, 20 minutes), GOLDEN_GMRES=1 gmres_main (sweeps_gmres.npz), GOLDEN_DHO=1 dirichlet_ho_main (sweeps_dirichlet_ho.npz, runs_dirichlet_ho.npz, dirichlet_ho_matrices.npz), GOLDEN_BC=1 boundary_main (boundary_matrices.npz, sweeps_neumann.npz, runs_neumann.npz), GOLDEN_PIN512=1 pin512_main (sweeps_pin512.npz), GOLDEN_R3=1 radix3_main (sweeps_radix3.npz, runs_radix3.npz);
 GOLDEN_ML=0 skips the multi-level block.
 
 ``qmat`` (third-party, absent here) is replaced by oracle/qmat_shim, which forwards to
@@ -1110,3 +1110,39 @@ def pin512_main():
 
 if __name__ == '__main__' and os.environ.get('GOLDEN_PIN512', '0') == '1':
     pin512_main()
+
+
+def radix3_main():
+    """even periodic grids that are not powers of two (generic_ND_FD.py:126-129 only asks for even nvars): 96 (1-D), 48^2,
+    24^3 - and 192 in 1-D - with the reference's direct solver (SuperLU).  The engine's line transforms of length 3 * 2^p
+    (csrc/fft.hpp) give these grids the exact Fourier solve: sweeps of heat / advection / IMEX advection-diffusion / forced
+    heat, and runs to a tolerance."""
+    RR = dict(quad_type='RADAU-RIGHT')
+    cases = []
+    for nv, tag in ((96, '1d_96'), (192, '1d_192'), ((48, 48), '2d_48'), ((24, 24, 24), '3d_24')):
+        for order, M, QI, dt in ((2, 5, 'IE', 1e-2), (4, 3, 'LU', 5e-2)):
+            if tag == '3d_24' and order == 4:
+                continue   # (one 24^3 case with five nodes, one with a FAS correction below: the file stays small)
+            cases.append(sweep_case(f'r3_heat{tag}_o{order}_M{M}_{QI}', 'heat_unforced',
+                                    dict(nvars=nv, nu=0.1, freq=2, order=order, bc='periodic'),
+                                    'generic_implicit', dict(num_nodes=M, QI=QI, **RR), dt, nsweeps=2 if tag == '3d_24' else 3))
+    cases.append(sweep_case('r3_adv1d_96', 'advection', dict(nvars=96, c=1.0, freq=2, order=2, stencil_type='center', bc='periodic'),
+                            'generic_implicit', dict(num_nodes=3, QI='LU', **RR), 1e-2))
+    cases.append(sweep_case('r3_advdiff2d_48', 'advdiff', dict(nvars=(48, 48), nu=0.02, c=1.0, freq=2, order=2),
+                            'imex_1st_order', dict(num_nodes=3, QI='IE', QE='EE', **RR), 1e-2))
+    cases.append(sweep_case('r3_forced2d_48', 'heat_forced', dict(nvars=(48, 48), nu=0.1, freq=2),
+                            'imex_1st_order', dict(num_nodes=3, QI='LU', QE='EE', **RR), 2e-2, u0_kind='exact'))
+    cases.append(sweep_case('r3_heat3d_24_tau', 'heat_unforced', dict(nvars=(24, 24, 24), nu=0.1, freq=2),
+                            'generic_implicit', dict(num_nodes=3, QI='IE', **RR), 2e-2, nsweeps=2, tau_seed=7))
+    save('sweeps_radix3.npz', cases)
+    runs = [run_case('r3_run_heat3d_24', 'heat_unforced', dict(nvars=(24, 24, 24), nu=0.1, freq=2), 'generic_implicit',
+                     dict(num_nodes=3, QI='IE', **RR), dict(dt=0.02, restol=1e-9), 20, 0.0, 0.06, seed=3),
+            run_case('r3_run_heat2d_48_P2', 'heat_unforced', dict(nvars=(48, 48), nu=0.1, freq=2), 'generic_implicit',
+                     dict(num_nodes=5, QI='LU', **RR), dict(dt=0.02, restol=1e-10), 30, 0.0, 0.08, num_procs=2, seed=4),
+            run_case('r3_run_forced1d_96', 'heat_forced', dict(nvars=96, nu=0.1, freq=2), 'imex_1st_order',
+                     dict(num_nodes=3, QI='IE', QE='EE', **RR), dict(dt=0.01, restol=1e-9), 30, 0.0, 0.03)]
+    save('runs_radix3.npz', runs)
+
+
+if __name__ == '__main__' and os.environ.get('GOLDEN_R3', '0') == '1':
+    radix3_main()

@@ -176,6 +176,44 @@ def test_lockstep_handover_and_broadcast_between_ranks_on_one_device(P, relay, a
         assert info['mesh_broadcasts'] == (1 if relay and P > 2 else 0)
 
 
+@pytest.mark.parametrize('share,n', [(0.45, 40), (0.9, 24), (0.3, 96)])
+def test_two_ranks_share_the_message_between_the_wire_and_host_memory(share, n):
+    """two ranks: the tail of every lock-step hand-over travels through pinned host memory on helper threads (HostPipe: a ring
+    of slots in shared memory) beside the direct message - several rounds over the same pipe, every value bit for bit; the
+    96^3 field is larger than the ring, so slots are reused within one message"""
+    import os
+
+    from pysdc_amd.comm import DeviceComm
+
+    os.environ['SDC_PIPE_CHUNK'] = '4096' if n == 96 else '1000000'     # (slots of 32 KB: ~65 trips round the ring per message)
+
+    def field(r, k):
+        return np.random.default_rng(10 * k + r).standard_normal((n, n, n))
+
+    def body(r, uid):
+        e = _engine(n=n)
+        comm = DeviceComm(e, 2, r, uid=uid)
+        comm.set_host_share(share)
+        got = []
+        for k in range(4):
+            e.upload(L.SLOT_UEND, 0, field(r, k))
+            e.upload(L.SLOT_U, 0, np.zeros((n, n, n)))
+            comm.handover_post(2)
+            comm.handover_complete()
+            got.append(e.download(L.SLOT_U, 0))
+        comm.sync()
+        comm.close()
+        e.close()
+        return got
+
+    try:
+        res = _thread_ranks(2, body)
+    finally:
+        del os.environ['SDC_PIPE_CHUNK']
+    for k in range(4):
+        assert np.array_equal(res[0][k], np.zeros((n, n, n))) and np.array_equal(res[1][k], field(0, k)), k
+
+
 def test_levels_of_one_rank_share_a_communicator():
     """two levels per rank (fine owns, coarse attaches: PFASST sends on every level, controller_MPI.py:702-768): messages of
     both levels travel over the one communicator in the order they are posted"""
@@ -249,6 +287,36 @@ def test_bench_ranks_on_one_gpu_end_to_end(tmp_path, ranks, n, steps, warmup):
     assert [v for _, v in get_sorted(stats, type='niter')] == [4] * (ranks * (warmup + steps))
     ref, got = ref.get(), np.load(dump)
     assert np.max(np.abs(got - ref)) <= 1e-12 * np.max(np.abs(ref))
+
+
+@pytest.mark.parametrize('forced', [1, 2, 3])
+def test_wire_validation_falls_back_mode_by_mode(forced):
+    """bench.py's validate_wire drops a wire mode that does not reproduce the serial emulation for the next, more conservative
+    one: with the first `forced` modes declared mismatching, the run lands on the following mode (fields on the wire and every
+    hand-over sent; then no two-hop relay either), says so in its line - and ends with ONE JSON error when no mode is left"""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    import bench
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '3', '--n', '64', '--backend', 'gloo', '--same-device', '--steps', '1',
+           '--warmup', '1', '--job-timeout', '600']
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['PYSDC_BENCH_FORCE_WIRE_MISMATCH'] = str(forced)
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=env, cwd=root)
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith('{')]
+    assert lines, (res.returncode, res.stdout[-2000:], res.stderr[-2000:])
+    rec = json.loads(lines[-1])
+    if forced >= len(bench.WIRE_MODES):
+        # (the launcher reports the rank that gave up; the rank's own line - why - is in its output tail)
+        assert res.returncode != 0 and 'error' in rec and 'no wire mode reproduces the serial emulation' in json.dumps(rec), rec
+        return
+    assert res.returncode == 0 and 'error' not in rec, rec
+    assert f'mode: {bench.WIRE_MODES[forced][0]}' in rec['config']['time_parallel'], rec['config']
+    assert rec['n_gpus'] == 3 and rec['finite'] and rec['niter'] == 4
 
 
 def test_bench_reports_a_failed_launch_as_json(tmp_path):

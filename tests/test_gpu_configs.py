@@ -360,3 +360,35 @@ def test_config5_allencahn_256_two_level_vs_2d_reference(name):
     assert float(np.max(np.abs(got - case['uend'][:, :, None]))) < TOL * scale          # every z-plane
     res = [v for _, v in get_sorted(stats, type='residual_post_iteration', sortby='time')]
     np.testing.assert_allclose(res, case['res'], rtol=1e-5, atol=1e-11)
+
+
+@pytest.mark.parametrize('name', list(load_cases('runs_ac_fft.npz')))
+def test_allencahn_3d_runs_with_fourier_transfer_vs_2d_reference(name):
+    """two-level MLSDC / PFASST with the 3-D Fourier space transfer (mesh_to_mesh_fft3d; the reference's own needs mpi4py_fft,
+    TransferMesh_MPIFFT.py:51-136): a z-invariant 32^3 / 16^3 Allen-Cahn run reproduces the reference's 2-D run with
+    mesh_to_mesh_fft2d (tests/golden/runs_ac_fft.npz) in every plane - iteration counts, end value, residuals"""
+    from pysdc_amd.controller import controller_nonMPI
+    from pysdc_amd.stats import get_sorted
+    from pysdc_amd.sweepers import imex_1st_order
+    from pysdc_amd.transfer import mesh_to_mesh_fft3d
+
+    case = load_cases('runs_ac_fft.npz')[name]
+    meta = case['meta']
+    assert meta['transfer'] == 'mesh_to_mesh_fft2d'
+    nf, nc = meta['prob_params']['nvars'][0][0], meta['prob_params']['nvars'][1][0]
+    pp = dict(nvars=[(nf,) * 3, (nc,) * 3], nu=meta['prob_params']['nu'], eps=meta['prob_params']['eps'],
+              radius=meta['prob_params']['radius'])
+    desc = dict(problem_class=_ac3d_class(), problem_params=pp, sweeper_class=imex_1st_order,
+                sweeper_params=dict(meta['sweeper_params']), level_params=dict(meta['level_params']),
+                step_params=dict(maxiter=meta['maxiter']), space_transfer_class=mesh_to_mesh_fft3d, space_transfer_params={})
+    Ctl = controller_nonMPI(meta['num_procs'], dict(logger_level=40, **meta['controller_params']), desc)
+    prob = Ctl.MS[0].levels[0].prob
+    u0 = prob.u_init
+    u0[:] = np.ascontiguousarray(np.broadcast_to(case['u0'][:, :, None], (nf, nf, nf)))
+    uend, stats = Ctl.run(u0, meta['t0'], meta['Tend'])
+    niter = [v for _, v in get_sorted(stats, type='niter', sortby='time')]
+    assert niter == list(case['niter']), (niter, list(case['niter']))
+    scale = float(np.max(np.abs(case['uend'])))
+    assert float(np.max(np.abs(uend.get() - case['uend'][:, :, None]))) < TOL * scale          # every z-plane
+    res = [v for _, v in get_sorted(stats, type='residual_post_iteration', sortby='time')]
+    np.testing.assert_allclose(res, case['res'], rtol=1e-5, atol=1e-11)

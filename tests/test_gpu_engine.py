@@ -24,10 +24,12 @@ def supported(case):
     if pp.get('bc', 'periodic') != 'periodic':
         return False
     n = G.norm_nvars(pp['nvars'])[0]
-    return n & (n - 1) == 0
+    return n & (n - 1) == 0 or (n % 3 == 0 and 24 <= n <= 768 and (n // 3) & (n // 3 - 1) == 0)   # 2^p, 3 * 2^p
 
 
-SWEEP_FILES = ['sweeps_heat.npz', 'sweeps_imex.npz', 'sweeps_adv.npz', 'sweeps_guess.npz', 'sweeps_pin1024.npz']
+# (sweeps_radix3.npz: the even grids the reference accepts that are not powers of two - 96, 192, 48^2, 24^3 with its direct
+# solver - on the engine's line transforms of length 3 * 2^p)
+SWEEP_FILES = ['sweeps_heat.npz', 'sweeps_imex.npz', 'sweeps_adv.npz', 'sweeps_guess.npz', 'sweeps_pin1024.npz', 'sweeps_radix3.npz']
 SWEEP_CASES = [(f, n) for f in SWEEP_FILES for n, c in load_cases(f).items() if supported(c)]
 
 

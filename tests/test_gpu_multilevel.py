@@ -71,6 +71,46 @@ def test_fourier_transfer_kernels(name):
     assert rel_err(T.prolong(G).get(), c['prolonged']) < 1e-13
 
 
+@pytest.mark.parametrize('name', [n for n, c in load_cases('transfer_fft.npz').items() if c['meta']['kind'] != 'fft1d'])
+@pytest.mark.parametrize('axis', [0, 1, 2])
+def test_fourier_transfer_in_3d_is_the_2d_rule_plane_by_plane(name, axis):
+    """mesh_to_mesh_fft3d (the reference's 3-D Fourier transfer needs mpi4py_fft: TransferMesh_MPIFFT.py:51-136) pinned
+    to the reference's 2-D class: a field that does not depend on one axis is restricted / prolonged in every plane across
+    that axis exactly as the golden vectors of mesh_to_mesh_fft2d say - for each of the three axes"""
+    from pysdc_amd.problems import heatNd_unforced
+    from pysdc_amd.transfer import mesh_to_mesh_fft3d
+
+    c = load_cases('transfer_fft.npz')[name]
+    m = c['meta']
+    pf = heatNd_unforced(nvars=(m['nf'],) * 3, nu=0.1, freq=2)
+    pc = heatNd_unforced(nvars=(m['nc'],) * 3, nu=0.1, freq=2)
+    T = mesh_to_mesh_fft3d(pf, pc, {})
+
+    def lift(plane, n):   # the 2-D field repeated along `axis`
+        return np.ascontiguousarray(np.moveaxis(np.broadcast_to(plane, (n,) + plane.shape), 0, axis))
+
+    F, G = pf.u_init, pc.u_init
+    F[:] = lift(c['fine'], m['nf'])
+    G[:] = lift(c['coarse'], m['nc'])
+    assert np.array_equal(T.restrict(F).get(), lift(c['restricted'], m['nc']))
+    got = T.prolong(G).get()
+    assert rel_err(got, lift(c['prolonged'], m['nf'])) < 1e-13
+    # a field that depends on all three axes: against NumPy's fftn with the same corner rule
+    rng = np.random.default_rng(5)
+    g = rng.standard_normal((m['nc'],) * 3)
+    G[:] = g
+    gh = np.fft.fftn(g)
+    h, nf = m['nc'] // 2, m['nf']
+    fh = np.zeros((nf,) * 3, dtype=complex)
+    lo, hi_c, hi_f = slice(0, h), slice(h, None), slice(nf - h, None)
+    for sa in ((lo, lo), (hi_c, hi_f)):
+        for sb in ((lo, lo), (hi_c, hi_f)):
+            for sc in ((lo, lo), (hi_c, hi_f)):
+                fh[sa[1], sb[1], sc[1]] = gh[sa[0], sb[0], sc[0]]
+    want = np.real(np.fft.ifftn(fh)) * 2 * (nf // m['nc']) ** 2
+    assert rel_err(T.prolong(G).get(), want) < 1e-13
+
+
 @pytest.mark.parametrize('name', list(load_cases('transfer_dirichlet.npz')))
 def test_dirichlet_transfer_kernels(name):
     """non-periodic mesh_to_mesh between 1-D dirichlet-zero grids on the device against the reference class."""

@@ -31,7 +31,8 @@ RUNS = ([('runs.npz', n) for n in load_cases('runs.npz')] + [('runs_dirichlet.np
         + [('runs_dirichlet_nd.npz', n) for n in load_cases('runs_dirichlet_nd.npz')]
         + [('runs_dirichlet_ho.npz', n) for n in load_cases('runs_dirichlet_ho.npz')]
         + [('runs_neumann.npz', n) for n in load_cases('runs_neumann.npz')]
-        + [('runs_skip.npz', n) for n in load_cases('runs_skip.npz')])
+        + [('runs_skip.npz', n) for n in load_cases('runs_skip.npz')]
+        + [('runs_radix3.npz', n) for n in load_cases('runs_radix3.npz')])   # grids of 3 * 2^p points: exact Fourier solve too
 
 
 @pytest.mark.parametrize('fname,name', RUNS)

@@ -177,6 +177,9 @@ def test_three_ranks_at_512cubed_match_the_serial_emulation(env):
 
     ref_res = {kind: by_time_and_iter(rstats, kind) for kind in ('residual_post_sweep', 'residual_post_iteration')}
     del C, u0
+    import gc
+
+    gc.collect()                # (three 512^3 levels of the emulation: their engines go before the ranks' ones come)
     torch.cuda.empty_cache()
     saved = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
@@ -212,6 +215,7 @@ def test_three_ranks_at_512cubed_match_the_serial_emulation(env):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+    gc.collect()
     assert not errors, errors[0]
     for r in range(nranks):
         assert rel_err(out[r][0], ref) < 1e-12, r

@@ -97,6 +97,56 @@ def test_reference_hooks_and_convergence_controllers_on_device_datatype(ref):
         assert [v for _, v in ref['get_sorted'](stats, type='niter', sortby='time')] == list(case['niter'])
 
 
+def test_reference_error_hooks_and_a_hook_that_indexes_the_solution(ref):
+    """the stock error-logging hooks (hooks/log_errors.py: abs(u_exact - L.uend), L.u[0] * 1.0) and a user hook that treats the
+    datatype as the ndarray the reference's `mesh` is (datatype_classes/mesh.py:12-60): integer and slice indexing of L.uend and
+    L.u[m], writing through an index - against the golden run"""
+    from pySDC.core.hooks import Hooks
+    from pySDC.implementations.hooks.log_errors import LogGlobalErrorPostStep, LogLocalErrorPostStep
+
+    case = load_cases('runs.npz')['mssdc_P2_jac']
+    meta = case['meta']
+    seen = []
+
+    class Probe(Hooks):
+        def post_step(self, step, level_number):
+            super().post_step(step, level_number)
+            L = step.levels[level_number]
+            L.sweep.compute_end_point()
+            u = L.uend
+            host = u.get()
+            mid = u.shape[0] // 2
+            pt = (3,) * host.ndim
+            assert u[pt] == host[pt] and isinstance(u[pt], float)          # integers on every axis: a number
+            assert np.array_equal(u[-1].get() if host.ndim > 1 else u[-1], host[-1])
+            assert np.array_equal(u[1:-1].get(), host[1:-1]) and u[1:-1].shape == host[1:-1].shape
+            assert np.array_equal(u[::-2].get(), host[::-2]) and np.array_equal(u[..., :mid].get(), host[..., :mid])
+            assert len(u) == len(host) and np.array_equal(np.asarray(L.u[1])[:4], L.u[1][:4].get())
+            w = u * 1.0
+            w[2:5] = 7.0
+            w[0] = -1.0
+            ref_w = host.copy()
+            ref_w[2:5], ref_w[0] = 7.0, -1.0
+            assert np.array_equal(w.get(), ref_w) and np.array_equal(u.get(), host)      # (the copy changed, the level did not)
+            seen.append(float(u[(mid,) * host.ndim]))
+
+    with host_device():
+        C = ref['controller'](2, dict(logger_level=40, hook_class=[LogGlobalErrorPostStep, LogLocalErrorPostStep, Probe],
+                                      mssdc_jac=True), _description(meta))
+        P = C.MS[0].levels[0].prob
+        u0 = P.u_init
+        u0[:] = case['u0']
+        uend, stats = C.run(u0, meta['t0'], meta['Tend'])
+        assert rel_err(uend.get(), case['uend']) < 1e-10
+        eg = ref['get_sorted'](stats, type='e_global_post_step', sortby='time')
+        el = ref['get_sorted'](stats, type='e_local_post_step', sortby='time')
+        assert len(eg) == len(case['niter']) == len(el) == len(seen)
+        t_end, e_end = eg[-1]
+        want = float(np.max(np.abs(P.u_exact(t_end).get() - case['uend'])))
+        assert abs(e_end - want) <= 1e-10 * max(want, 1e-30) + 1e-14
+        assert all(np.isfinite(v) for _, v in el)
+
+
 @pytest.mark.parametrize('name', ['mlsdc_heat2d', 'pfasst_heat2d_P2', 'pfasst_heat2d_P4', 'mlsdc_forced2d', 'pfasst_forced2d_P2',
                                   'mlsdc_heat2d_M53'])
 def test_reference_multilevel_stack_drives_product_classes(ref, name):
