@@ -192,14 +192,17 @@ int sdc_set_keep_residual_fields(sdc_ctx* ctx, int on);
 int sdc_set_early_end_point(sdc_ctx* ctx, int on);
 /* Time-parallel levels that sweep in Fourier space with spectra on the wire (sdc_comm_set_format): how the engine deals
  * with a u[0] that is replaced between sweeps (controller_MPI.py:218-233, :574-583).
- *  trail_sources (default 5, 0 = off): iterates are not stored; a sweep recomputes its iterate from the start values the slice
+ *  trail_sources (default 0 = off; at most 5): iterates are not stored; a sweep recomputes its iterate from the start values the slice
  *    has had since its spread predictor (the sweep is linear: u^k = sum_i C_i(lambda) u0_i per Fourier mode with real node
  *    multipliers), reads those <= trail_sources spectra and writes only the residual lines and the last node's spectrum.
  *    One more start value than that, or sdc_set_virtual_sweeps' limit, and the iterate is stored after all.
  *  defer_last_pass (default 1): the last inverse pass of a sweep's residual waits until the new start value has arrived;
  *    ONE pass over the residual lines then reduces the node norms before AND after the receive (they differ by one field, the
  *    difference of the two start values).  Residuals posted meanwhile (sdc_residual_post) are published by that pass;
- *    a blocking wait, the next sweep or anything else that needs the work spectra runs it at once.
+ *    a blocking wait or anything else that needs the work spectra runs it at once.  When the NEXT sweep arrives while it
+ *    still waits (a fixed number of sweeps: nobody asked), that sweep's z / y launches go first, into a second set of work
+ *    spectra, and the put-off passes follow them: the last node's spectrum is on the wire one launch after the receive and the
+ *    put-off passes run while it travels (2: put off, but never behind the next sweep; 0: every pass at once).
  *  split_send (default 0): a sweep first writes the last node's spectrum by a small launch of its own, so that the message
  *    leaves before the passes put off for the previous iterate and the sweep's own residual passes run. */
 int sdc_set_timeslice_options(sdc_ctx* ctx, int trail_sources, int defer_last_pass, int split_send);

@@ -556,8 +556,8 @@ class controller_dist(_ControllerBase):
                 # iterates recomputed from the start values received so far instead of stored, the last inverse pass of a
                 # residual put off until the new start value is there (one pass then yields the norms before and after the
                 # receive), optionally the last node's spectrum first (include/sdcmi.h: sdc_set_timeslice_options)
-                eng.set_timeslice_options(int(os.environ.get('PYSDC_AMD_TRAIL', '5')),
-                                          os.environ.get('PYSDC_AMD_DEFER_X', '1') != '0',
+                eng.set_timeslice_options(int(os.environ.get('PYSDC_AMD_TRAIL', '0')),
+                                          int(os.environ.get('PYSDC_AMD_DEFER_X', '1')),
                                           os.environ.get('PYSDC_AMD_SPLIT_SEND', '0') != '0')
             # the end value (its spectrum) is produced early so that it can be sent while the residual is reduced -
             # only in lock-step runs, where every posted message is completed before the next sweep (the sweep

@@ -54,6 +54,9 @@ struct PendingX {
     bool has_delta = false;    // ... and u[0] has been replaced since: d_new - d_old is added for the second set of norms
     int nf = 0;
     const cd *d_old = nullptr, *d_new = nullptr;
+    bool d_old_spare = false;          // d_old was kept alive for this pass only: a spare buffer again afterwards
+    cd* work = nullptr;                // the work spectra that hold the residual lines
+    unsigned long long *norms = nullptr, *normsA = nullptr;   // slots of the norms after / before the receive
     std::vector<PendingTicket> tickets;
 };
 
@@ -100,7 +103,7 @@ struct sdc_ctx {
     // Trail (time-parallel levels, spectra on the wire): the iterate after spec_virtual unstored sweeps as a function of the
     // start values the slice has had since its spread predictor - trail_src[0] the block's, trail_src[i] the i-th one received -
     // and of which sweep started from which (vsrc).  trail_ns = 0: no trail (the iterate depends on S0 alone, as in serial runs).
-    int trail_max = 5, trail_ns = 0;
+    int trail_max = 0, trail_ns = 0;   // (0: iterates are stored - measured faster than the recomputing launch, profiles/r05)
     const cd* trail_src[MAXTRAIL] = {};
     unsigned char vsrc[MAXVSWEEPS] = {};
     PendingX xp;
@@ -108,6 +111,14 @@ struct sdc_ctx {
     bool defer_x = true;                      // spectra on the wire: the x pass of a sweep's residual waits for the receive
     bool split_send = false;                  // ... and the last node's spectrum is produced by a launch of its own, first
     bool sl_ev_by_split = false;
+    // ... and when the NEXT sweep arrives while that pass still waits (nobody asked for the numbers: a fixed number of sweeps),
+    // the sweep's z / y launches go first - into a second set of work spectra - and the passes put off for the previous
+    // iterate follow them: the last node's spectrum is final (and on the wire) one z launch after the receive, and the
+    // put-off passes run while the message travels
+    bool pipeline_x = true, hold_flush = false;
+    cd* Wb = nullptr;                         // the other set of work spectra
+    unsigned long long* res_bank[2] = {nullptr, nullptr};   // norm slots: two banks (one per iterate in flight), 16 each
+    int res_bank_now = 0;
     bool wire_spectral = false, rlines_valid = false, sl_ev_recorded = false;
     hipEvent_t sl_ev = nullptr;
     cd* Wend = nullptr;  // spectrum of an end value that is not the cached last node (forward transform of UEND on demand)

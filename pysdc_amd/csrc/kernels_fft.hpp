@@ -723,6 +723,9 @@ struct SpecArgs {
     const cd* src[MAXTRAIL];
     int ns, nsw;
     unsigned char vsrc[MAXVSWEEPS];
+    int scnt[MAXTRAIL];   // sweeps that started from src[i] (consecutive: a start value only changes when one is received)
+    unsigned long long scnt_packed;   // the same, 8 bits per source: the kernel's loop bounds without a load inside its loops
+    double gIrow[MAXM];   // row sums of gI
 };
 
 // one thread per Fourier mode: gather on the cached transforms + node-coupled solve, S updated in place.
@@ -883,86 +886,134 @@ DEVI void trail_iterate(const SpecArgs& a, double lam, size_t base, int p_, int 
         uhi[m] = cd{fma(y[m], shi.x, uhi[m].x), fma(y[m], shi.y, uhi[m].y)};
     }
 }
-// The residual of that iterate against the current start value (the last sweep's), and the last node's value, for K mode
-// pairs of one thread side by side (independent chains: the f64 pipe always has a second one to issue from).  Works on the
-// real node multipliers alone: sweeps come in runs that share a start value (it changes only when one is received), the
-// multipliers of a run are the sum of its chain vectors, and a start value's modes are touched once - when its run is over:
+// The residual of that iterate against the current start value (the last sweep's), and the last node's value, for one mode
+// pair.  Works on the real node multipliers alone: sweeps come in runs that share a start value (it changes only when one is
+// received, so the sweeps of source i are consecutive: a.scnt[i] of them), the multipliers of a run are the sum of its chain
+// vectors, and a start value's modes enter once, when its run is over:
 //   R_m += (delta - G_m + lam sum_q rQ[m][q] G_q) * s,   u_M += G_M * s.
-template <int NF, int K>
-DEVI void trail_residual(const SpecArgs& a, const double (&lam)[K], size_t base, const int (&p_)[K], const bool (&paired)[K], int n,
-                         cd (&rlo)[K][NF], cd (&rhi)[K][NF], cd (&ulo)[K], cd (&uhi)[K]) {
-    double inv[K][NF], x[K][NF], y[K][NF], G[K][NF];
-    const int J = a.nsw, now = a.vsrc[J - 1];
-    int cur = now;
-    cd slo[K], shi[K];
-    const cd* sp = a.src[cur];
+// All start values are fetched before the first multiplication (slo / shi, filled by the caller: the loads of a thread's NEXT
+// pair are in flight while it works on this one).
+#ifndef TRAIL_S
+#define TRAIL_S 5
+#endif
+#define TRAIL_S_NOTE   // start values the in-register variant handles (sdc_set_timeslice_options' default); more: iterates are stored
+// (x, y) <- (T x, T y): one pass over the coefficients for both chains
+template <int NF>
+DEVI void trail_apply2(const SpecArgs& a, double lam, const double (&inv)[NF], double (&x)[NF], double (&y)[NF]) {
+    double ox[NF], oy[NF];
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        slo[k] = sp[base + p_[k]];
-        shi[k] = paired[k] ? sp[base + n - p_[k]] : cd{0.0, 0.0};
-        ulo[k] = uhi[k] = cd{0.0, 0.0};
+    for (int q = 0; q < NF; ++q) {
+        ox[q] = x[q];
+        oy[q] = y[q];
+    }
 #pragma unroll
-        for (int m = 0; m < NF; ++m) {
-            inv[k][m] = fast_rcp(1.0 - a.alpha[m] * lam[k]);
-            y[k][m] = 1.0;
-            G[k][m] = 0.0;
-            rlo[k][m] = rhi[k][m] = cd{0.0, 0.0};
+    for (int m = 0; m < NF; ++m) {
+        double tx = 0.0, ty = 0.0;
+#pragma unroll
+        for (int q = 0; q < NF; ++q) {
+            const double g = a.gI[m][q];
+            tx = fma(g, ox[q], tx);
+            ty = fma(g, oy[q], ty);
         }
+        if (a.coupled) {
 #pragma unroll
-        for (int m = 0; m < NF; ++m) {   // b
-            double t = 0.0;
-            if (a.coupled) {
-#pragma unroll
-                for (int q = 0; q < m; ++q) t = fma(a.cI[m][q], x[k][q], t);
+            for (int q = 0; q < m; ++q) {
+                const double cq = a.cI[m][q];
+                tx = fma(cq, x[q], tx);
+                ty = fma(cq, y[q], ty);
             }
-            x[k][m] = fma(lam[k], t, 1.0) * inv[k][m];
+        }
+        const double li = lam * inv[m];
+        x[m] = li * tx;
+        y[m] = li * ty;
+    }
+}
+template <int NF>
+DEVI void trail_residual(const SpecArgs& a, double lam, const cd (&slo)[TRAIL_S], const cd (&shi)[TRAIL_S], cd (&rlo)[NF],
+                         cd (&rhi)[NF], cd& ulo, cd& uhi) {
+    // The residual of the NEW iterate is  lam dt (Q - QI)(u_new - u_old): the sweep's own equation (generic_implicit.py:75-103)
+    // subtracted from the residual's (core/sweeper.py:186-199).  Per start value only the DIFFERENCE of its node multipliers
+    // between the last two iterates is needed - D_i = x(end of its run) - x(end of the run before it) [+ T^(J-1)(T 1 - 1) for
+    // src[0]]: two chain vectors - and the coefficients are the chain loop's own (no second matrix in scalar registers, no
+    // cancellation of O(1) terms either).  The last node's value needs the last component of the multipliers themselves.
+    double inv[NF], x[NF], z[NF], xp[NF];
+    const int J = a.nsw;
+    ulo = uhi = cd{0.0, 0.0};
+#pragma unroll
+    for (int m = 0; m < NF; ++m) {
+        inv[m] = fast_rcp(1.0 - a.alpha[m] * lam);
+        rlo[m] = rhi[m] = cd{0.0, 0.0};
+        xp[m] = 0.0;
+    }
+#pragma unroll
+    for (int m = 0; m < NF; ++m) {   // x = b,  z = T 1 - 1
+        double tb = 0.0, t1 = a.gIrow[m];
+        if (a.coupled) {
+#pragma unroll
+            for (int q = 0; q < m; ++q) {
+                tb = fma(a.cI[m][q], x[q], tb);
+                t1 = fma(a.cI[m][q], z[q] + 1.0, t1);
+            }
+        }
+        x[m] = fma(lam, tb, 1.0) * inv[m];
+        z[m] = fma(lam * t1, inv[m], -1.0);
+    }
+    double zsum = 1.0;   // last node of T^J 1 = 1 + sum_k (T^k z)_M
+    int s = 0;
+    // (ONE copy of the loop body whatever the number of start values: the launch is bound by its vector instructions, and
+    // unrolled copies spill the coefficient matrix from scalar registers into vector lanes)
+    const unsigned long long counts = a.scnt_packed;
+    for (int i = a.ns - 1; i >= 0; --i) {   // the chain vector x = T^s b belongs to sweep J - 1 - s: the latest source first
+        const int cnt = (int)((counts >> (8 * i)) & 255u);
+        double gM = 0.0;
+        for (int t = 0; t < cnt; ++t) {
+            gM += x[NF - 1];
+            zsum += z[NF - 1];
+            if (t + 1 == cnt) {   // the run of src[i] ends with this chain vector
+                cd sl = slo[0], sh = shi[0];
+#pragma unroll
+                for (int q = 1; q < TRAIL_S; ++q) {   // (selects on a wave-uniform condition: the arrays stay in registers)
+                    const bool hit = i == q;
+                    sl = cd{hit ? slo[q].x : sl.x, hit ? slo[q].y : sl.y};
+                    sh = cd{hit ? shi[q].x : sh.x, hit ? shi[q].y : sh.y};
+                }
+                const double first = i == 0 ? 1.0 : 0.0;
+                double D[NF];
+#pragma unroll
+                for (int m = 0; m < NF; ++m) {
+                    D[m] = fma(first, z[m], x[m] - xp[m]);
+                    xp[m] = x[m];
+                }
+#pragma unroll
+                for (int m = 0; m < NF; ++m) {
+                    double tq = 0.0;
+#pragma unroll
+                    for (int q = 0; q < NF; ++q) tq = fma(a.gI[m][q], D[q], tq);
+                    const double h = lam * tq;
+                    rlo[m] = cd{fma(h, sl.x, rlo[m].x), fma(h, sl.y, rlo[m].y)};
+                    rhi[m] = cd{fma(h, sh.x, rhi[m].x), fma(h, sh.y, rhi[m].y)};
+                }
+                const double gl = fma(first, zsum, gM);
+                ulo = cd{fma(gl, sl.x, ulo.x), fma(gl, sl.y, ulo.y)};
+                uhi = cd{fma(gl, sh.x, uhi.x), fma(gl, sh.y, uhi.y)};
+            }
+            if (++s < J) trail_apply2<NF>(a, lam, inv, x, z);
         }
     }
-    auto close_run = [&](int next) {   // the run of `cur` is complete: its start value enters, the next one's modes are fetched
-        const double one = cur == now ? 1.0 : 0.0;
+}
+template <int NF>
+DEVI void trail_fetch(const SpecArgs& a, size_t base, int p_, int n, bool paired, cd (&slo)[TRAIL_S], cd (&shi)[TRAIL_S]) {
+    // (the partner of an unpaired mode is read from the mode itself and never used: no branch around a load - with one, every
+    // load was waited for in turn; start values that do not exist are not read: a wave-uniform branch)
+    const size_t ilo = base + p_, ihi = base + (paired ? n - p_ : p_);
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-#pragma unroll
-            for (int m = 0; m < NF; ++m) {
-                double t = 0.0;
-#pragma unroll
-                for (int q = 0; q < NF; ++q) t = fma(a.rQ[m][q], G[k][q], t);
-                const double h = fma(lam[k], t, one - G[k][m]);
-                rlo[k][m] = cd{fma(h, slo[k].x, rlo[k][m].x), fma(h, slo[k].y, rlo[k][m].y)};
-                rhi[k][m] = cd{fma(h, shi[k].x, rhi[k][m].x), fma(h, shi[k].y, rhi[k][m].y)};
-            }
-            ulo[k] = cd{fma(G[k][NF - 1], slo[k].x, ulo[k].x), fma(G[k][NF - 1], slo[k].y, ulo[k].y)};
-            uhi[k] = cd{fma(G[k][NF - 1], shi[k].x, uhi[k].x), fma(G[k][NF - 1], shi[k].y, uhi[k].y)};
-        }
-        if (next >= 0) {
-            const cd* sn = a.src[next];
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                slo[k] = sn[base + p_[k]];
-                if (paired[k]) shi[k] = sn[base + n - p_[k]];
-#pragma unroll
-                for (int m = 0; m < NF; ++m) G[k][m] = 0.0;
-            }
-            cur = next;
-        }
-    };
-    for (int s = 0; s < J; ++s) {
-        const int of = a.vsrc[J - 1 - s];   // x = T^s b belongs to sweep J - 1 - s
-        if (of != cur) close_run(of);
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-#pragma unroll
-            for (int m = 0; m < NF; ++m) G[k][m] += x[k][m];
-            trail_apply<NF>(a, lam[k], inv[k], y[k]);
-            if (s + 1 < J) trail_apply<NF>(a, lam[k], inv[k], x[k]);
+    for (int i = 0; i < TRAIL_S; ++i) {
+        if (i < a.ns) {
+            const cd* __restrict__ sp = a.src[i];
+            slo[i] = sp[ilo];
+            shi[i] = sp[ihi];
         }
     }
-    if (cur != 0) close_run(0);
-#pragma unroll
-    for (int k = 0; k < K; ++k)   // y = T^J 1: what is left of the spread predictor's copies of src[0]
-#pragma unroll
-        for (int m = 0; m < NF; ++m) G[k][m] += y[k][m];
-    close_run(-1);
 }
 
 // ... written out: all node spectra or (last_only) only the last one - what store_spectra does for a trail
@@ -1225,9 +1276,6 @@ __global__ __launch_bounds__(256) void k_spec_residual(SpecArgs a, int n, size_t
 #ifndef SDC_SPECZ_VHOIST
 #define SDC_SPECZ_VHOIST 1  // MODE 3: the S0 loads of all chunks are issued before the first chunk is worked on
 #endif
-#ifndef SDC_TRAIL_K2
-#define SDC_TRAIL_K2 0   // 1: two pairs per thread side by side (256 VGPRs and 200 bytes of scratch at five nodes: one at a time it is)
-#endif
 template <int N, bool V = false>
 constexpr int specz_elems() {
     return N == 512 ? 8 : (N == 256 ? SDC_SPECZ_E256 : (N == 1024 ? (V ? SDC_SPECZ_VE1024 : SDC_SPECZ_E1024) : fft_elems(N)));
@@ -1246,7 +1294,7 @@ constexpr int specz_min_waves() { return specz_lines<N, V>() > 1 ? 2 : (V ? SDC_
 template <int N, int NF, int MODE, int EXPL>
 // (several lines per workgroup, N < 1024: the elements a thread takes from the first chunk stay live while it works on
 // the second one - 2 waves / SIMD worth of registers instead of spilling; measured 5.7 -> 4.2 ms at 512^3)
-__global__ __launch_bounds__((specz_threads<N, NF, (MODE >= 3)>()), ((MODE == 6 && N >= 1024) ? 2 : specz_min_waves<N, (MODE >= 3)>()))
+__global__ __launch_bounds__((specz_threads<N, NF, (MODE >= 3)>()), (MODE == 6 ? 2 : specz_min_waves<N, (MODE >= 3)>()))
 void k_spec_z(SpecArgs a, unsigned nlines) {
     constexpr bool RES = MODE >= 1, UPD = MODE <= 1 || MODE >= 3, VIRT = MODE >= 3, TRAIL = MODE == 6, PAIR = MODE >= 4 && !TRAIL,
                    GTAB = MODE == 5, HASE = EXPL == 1, HASP = EXPL == 2;
@@ -1366,48 +1414,49 @@ void k_spec_z(SpecArgs a, unsigned nlines) {
     }
     if constexpr (TRAIL) {
         // MODE 6: the iterate is a function of SEVERAL start values (trail_residual).  All mode pairs of the line are worked on
-        // before anything is handed over - two pairs per thread side by side where the wave has two - through a buffer that
-        // holds the whole line of every field (the transform's exchange planes take its place afterwards).
+        // before anything is handed over, through a buffer that holds the whole line of every field (the transform's exchange
+        // planes take its place afterwards); the start values of a thread's next pair are fetched while it works on this one.
         constexpr int H = N / 2, NI = H + 1, ITT = (NI + NT - 1) / NT;
         const size_t base = (size_t)bid * N;
         double lxy = 0.0;
         if (a.ndim == 3) lxy = a.lamI[bid / N].x + a.lamI[bid % N].x;
         else if (a.ndim == 2) lxy = a.lamI[bid].x;
-        auto work = [&](auto kc, int g) {
-            constexpr int K = decltype(kc)::value;
-            int p_[K];
-            bool mine[K], paired[K];
-            double lam[K];
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                const int p0 = (int)threadIdx.x + (g + k) * NT;
-                mine[k] = ok && p0 < NI;
-                p_[k] = mine[k] ? p0 : H;   // (a lane without a pair of its own follows along on a valid one, stores nothing)
-                paired[k] = p_[k] >= 1 && p_[k] < H;
-                lam[k] = a.lamI[p_[k]].x + lxy;
-            }
-            cd rlo[K][NF], rhi[K][NF], ulo[K], uhi[K];
-            trail_residual<NF, K>(a, lam, base, p_, paired, N, rlo, rhi, ulo, uhi);
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                if (!mine[k]) continue;
-                if (a.store_last) {   // the last node's spectrum: what the wire carries, and the next step's start value
-                    a.SL[base + p_[k]] = ulo[k];
-                    if (paired[k]) a.SL[base + N - p_[k]] = uhi[k];
-                }
-#pragma unroll
-                for (int m = 0; m < NF; ++m) {
-                    rbuf[m * N + p_[k]] = cscale(rlo[k][m], a.invN);
-                    if (paired[k]) rbuf[m * N + N - p_[k]] = cscale(rhi[k][m], a.invN);
-                }
-            }
+        auto pair_of = [&](int g, int& p_, bool& mine, bool& paired) {
+            const int p0 = (int)threadIdx.x + g * NT;
+            mine = ok && p0 < NI;
+            p_ = mine ? p0 : H;   // (a lane without a pair of its own follows along on a valid one, stores nothing)
+            paired = p_ >= 1 && p_ < H;
         };
+        cd slo[2][TRAIL_S], shi[2][TRAIL_S];   // (two sets: the one being worked on, the one being fetched)
+        int pn[2];
+        bool mn[2], prn[2];
+        pair_of(0, pn[0], mn[0], prn[0]);
+        trail_fetch<NF>(a, base, pn[0], N, prn[0], slo[0], shi[0]);
 #pragma unroll
-        for (int g = 0; g < ITT; g += (SDC_TRAIL_K2 ? 2 : 1)) {
-            // (wave-uniform: does any lane of this wave have a second pair in this round?)
-            const bool two = SDC_TRAIL_K2 && g + 1 < ITT && (int)(threadIdx.x & ~63u) + (g + 1) * NT < NI;
-            if (two) work(std::integral_constant<int, 2>{}, g);
-            else if ((int)(threadIdx.x & ~63u) + g * NT < NI) work(std::integral_constant<int, 1>{}, g);
+        for (int g = 0; g < ITT; ++g) {
+            // (wave-uniform: does any lane of this wave have a pair in this round?)
+            if ((int)(threadIdx.x & ~63u) + g * NT < NI) {
+                const int cur = g & 1, nxt = cur ^ 1;
+                const int pc = pn[cur];
+                const bool minec = mn[cur], pairedc = prn[cur];
+                if (g + 1 < ITT && (int)(threadIdx.x & ~63u) + (g + 1) * NT < NI) {
+                    pair_of(g + 1, pn[nxt], mn[nxt], prn[nxt]);
+                    trail_fetch<NF>(a, base, pn[nxt], N, prn[nxt], slo[nxt], shi[nxt]);
+                }
+                cd rlo[NF], rhi[NF], ulo, uhi;
+                trail_residual<NF>(a, a.lamI[pc].x + lxy, slo[cur], shi[cur], rlo, rhi, ulo, uhi);
+                if (minec) {
+                    if (a.store_last) {   // the last node's spectrum: what the wire carries, and the next step's start value
+                        a.SL[base + pc] = ulo;
+                        if (pairedc) a.SL[base + N - pc] = uhi;
+                    }
+#pragma unroll
+                    for (int m = 0; m < NF; ++m) {
+                        rbuf[m * N + pc] = cscale(rlo[m], a.invN);
+                        if (pairedc) rbuf[m * N + N - pc] = cscale(rhi[m], a.invN);
+                    }
+                }
+            }
         }
         __syncthreads();
 #pragma unroll

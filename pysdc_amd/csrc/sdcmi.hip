@@ -441,7 +441,11 @@ static int inverse_tail_n(sdc_ctx* c, int nf, cd* work, const FieldPtrs& p, unsi
             HIPCHK(c, hipGetLastError());
             c->xp.pending = true;
             c->xp.has_delta = false;
+            c->xp.d_old_spare = false;
             c->xp.nf = nf;
+            c->xp.work = work;
+            c->xp.norms = norms;
+            c->xp.normsA = norms + 8;
             c->xp.tickets.clear();
             return SDC_OK;
         }
@@ -592,7 +596,8 @@ static void launch_spec_z_cfg(sdc_ctx* c, SpecArgs& a, size_t lines, int mode, s
     constexpr int SPAN = LPB * N, CH = SPAN > SDC_SPECZ_CH ? SDC_SPECZ_CH : SPAN;
     size_t ldsz = (size_t)LayContig<N>::doubles(NF * LPB) * sizeof(double);
     if ((size_t)NF * CH * sizeof(cd) > ldsz) ldsz = (size_t)NF * CH * sizeof(cd);
-    if (V && a.ns > 0 && (size_t)NF * N * sizeof(cd) > ldsz) ldsz = (size_t)NF * N * sizeof(cd);  // (trail: the whole line of every field)
+    if (V && a.ns > 0) ldsz = std::max(ldsz, (size_t)NF * N * sizeof(cd));  // (trail: the whole line of every field - 80 KB at 1024 x 5: two workgroups per CU, to the byte)
+    if (const char* pad = getenv("SDC_DBG_LDS_PAD")) ldsz += (size_t)atol(pad);   // (experiments: fewer workgroups per CU)
     const dim3 grid((unsigned)((launch_lines + LPB - 1) / LPB)), block(P * LPB * NF);  // (lines: the bound the kernel checks)
     const int expl = a.lamE ? 1 : (a.SP ? 2 : 0);
 #define ZL(M_, E_) hipLaunchKernelGGL((k_spec_z<N, NF, M_, E_>), grid, block, ldsz, c->stream, a, (unsigned)lines)
@@ -868,6 +873,7 @@ static int store_spectra(sdc_ctx* c, bool last_only) {
         a.nsw = c->spec_virtual;
         for (int i = 0; i < c->trail_ns; ++i) a.src[i] = c->trail_src[i];
         memcpy(a.vsrc, c->vsrc, sizeof a.vsrc);
+        for (int k = 0; k < a.nsw; ++k) a.scnt[a.vsrc[k]]++;
         const size_t nitems = lines * (size_t)(n / 2 + 1);
         size_t tb = (nitems + 255) / 256;
         if (tb > SDC_SPEC_GRID) tb = SDC_SPEC_GRID;
@@ -1135,8 +1141,9 @@ static int publish_ticket(sdc_ctx* c, const PendingTicket& t, const unsigned lon
 static int flush_x(sdc_ctx* c) {
     PendingX& xp = c->xp;
     if (!xp.pending) return SDC_OK;
+    if (c->hold_flush) return SDC_OK;   // (a sweep is putting its own launches in front: it calls again when they are queued)
     xp.pending = false;
-    const unsigned long long* before = c->res_dev;
+    const unsigned long long* before = xp.norms;
     FieldPtrs p0;
     memset(&p0, 0, sizeof p0);
     int rc = SDC_OK;
@@ -1147,26 +1154,28 @@ static int flush_x(sdc_ctx* c) {
             spool_put(c, dbuf);
             return SDC_ERR_NOMEM;
         }
-        HIPCHK(c, hipMemsetAsync(c->res_devA, 0, sizeof(unsigned long long) * 8, c->stream));
-#define CALL(NN) joint_norms_n<NN>(c, xp.nf, c->W, xp.d_new, xp.d_old, dbuf, dscr, c->res_dev, c->res_devA)
+        HIPCHK(c, hipMemsetAsync(xp.normsA, 0, sizeof(unsigned long long) * 8, c->stream));
+#define CALL(NN) joint_norms_n<NN>(c, xp.nf, xp.work, xp.d_new, xp.d_old, dbuf, dscr, xp.norms, xp.normsA)
         rc = [&]() -> int { N_DISPATCH(c, CALL) }();
 #undef CALL
         spool_put(c, dbuf);   // (stream-ordered: whoever takes them next works behind these launches)
         spool_put(c, dscr);
-        before = c->res_devA;
-        c->rlines_valid = false;   // W + d is what the current norms describe
+        if (xp.d_old_spare) spool_put(c, xp.d_old);
+        before = xp.normsA;
+        if (xp.work == c->W) c->rlines_valid = false;   // W + d is what the current norms describe
     } else {
-#define CALL(NN) inverse_tail_n<NN>(c, xp.nf, c->W, p0, c->res_dev, true)
+#define CALL(NN) inverse_tail_n<NN>(c, xp.nf, xp.work, p0, xp.norms, true)
         rc = [&]() -> int { N_DISPATCH(c, CALL) }();
 #undef CALL
     }
     if (rc != SDC_OK) return rc;
     for (const PendingTicket& t : xp.tickets) {
-        rc = publish_ticket(c, t, (xp.has_delta && !t.after) ? before : c->res_dev);
+        rc = publish_ticket(c, t, (xp.has_delta && !t.after) ? before : xp.norms);
         if (rc != SDC_OK) return rc;
     }
     xp.tickets.clear();
     xp.has_delta = false;
+    xp.d_old_spare = false;
     xp.d_old = xp.d_new = nullptr;
     return SDC_OK;
 }
@@ -1248,10 +1257,12 @@ int sdc_ctx_create(sdc_ctx** out, int device, int ndim, int n, int num_nodes, in
         HIPCHK(nullptr, hipHostGetDevicePointer((void**)&c->ring_dev, c->ring, 0));
         c->bytes += fb;
         HIPCHK(nullptr, hipMalloc((void**)&c->counters, sizeof(unsigned long long) * 4));
-        HIPCHK(nullptr, hipMalloc((void**)&c->res_dev, sizeof(unsigned long long) * 16));
+        HIPCHK(nullptr, hipMalloc((void**)&c->res_bank[0], sizeof(unsigned long long) * 32));
+        c->res_bank[1] = c->res_bank[0] + 16;
+        c->res_dev = c->res_bank[0];
         c->res_devA = c->res_dev + 8;
         HIPCHK(nullptr, hipMemsetAsync(c->counters, 0, sizeof(unsigned long long) * 4, c->stream));
-        HIPCHK(nullptr, hipMemsetAsync(c->res_dev, 0, sizeof(unsigned long long) * 16, c->stream));
+        HIPCHK(nullptr, hipMemsetAsync(c->res_bank[0], 0, sizeof(unsigned long long) * 32, c->stream));
         HIPCHK(nullptr, hipMemsetAsync(c->UEND, 0, fb, c->stream));
         HIPCHK(nullptr, hipEventCreate(&c->ev0));
         HIPCHK(nullptr, hipEventCreate(&c->ev1));
@@ -1313,7 +1324,8 @@ int sdc_ctx_destroy(sdc_ctx* c) {
     (void)hipFree(c->profile);
     (void)hipFree(c->red);
     (void)hipFree(c->counters);
-    (void)hipFree(c->res_dev);
+    (void)hipFree(c->res_bank[0]);
+    (void)hipFree(c->Wb);
     if (c->red_host) (void)hipHostFree(c->red_host);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -2466,6 +2478,12 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
                     a.nsw = c->spec_virtual;
                     for (int i = 0; i < c->trail_ns; ++i) a.src[i] = c->trail_src[i];
                     memcpy(a.vsrc, c->vsrc, sizeof a.vsrc);
+                    for (int k = 0; k < a.nsw; ++k) a.scnt[a.vsrc[k]]++;
+                    for (int i = 0; i < c->trail_ns; ++i) a.scnt_packed |= (unsigned long long)(a.scnt[i] & 255) << (8 * i);
+                    for (int m = 0; m < M; ++m) {
+                        a.gIrow[m] = 0.0;
+                        for (int j = 0; j < M; ++j) a.gIrow[m] += a.gI[m][j];
+                    }
                     a.store_last = 1;
                     for (int m = 0; m < M; ++m)
                         for (int j = 0; j < M; ++j) a.rQ[m][j] = dt * c->Q[m + 1][j + 1];
@@ -2513,7 +2531,23 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
             if (rcn != SDC_OK) return rcn;
             a.S = c->S;
         }
-        FLUSH_X(c);   // (norms of the previous iterate that still wait for their last pass: before the slots are cleared)
+        // Norms of the previous iterate that still wait for their last pass (time-parallel levels, nobody has asked for the
+        // numbers): this sweep's z / y launches go FIRST - into the other set of work spectra, with the other bank of norm
+        // slots - so that the last node's spectrum is final, and on the wire, one launch after the start value arrived; the
+        // passes that were put off follow and run while the message travels.  Anything else: they run now.
+        const bool pipelined = c->pipeline_x && c->xp.pending && norms_only && c->wire_spectral && c->early_uend && c->defer_x &&
+                               SDC_FUSE_SPECZ && c->n >= 64 && c->n <= 1024 && is_pow2(c->n) && M <= 5;
+        PendingX put_off;
+        if (pipelined) {
+            put_off = c->xp;
+            c->xp = PendingX();
+            std::swap(c->W, c->Wb);   // (the other set is allocated by its first use: ensure_work)
+            c->res_bank_now ^= 1;
+            c->res_dev = c->res_bank[c->res_bank_now];
+            c->res_devA = c->res_dev + 8;
+        } else {
+            FLUSH_X(c);
+        }
         if (norms_only) {
             for (int m = 0; m < M; ++m)
                 for (int j = 0; j < M; ++j) a.rQ[m][j] = dt * c->Q[m + 1][j + 1];
@@ -2521,6 +2555,13 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
         }
         c->spec_gen++;
         int rc0 = spec_sweep(c, M, a, p, norms_only ? c->res_dev : nullptr, spec_only);
+        if (pipelined) {   // (also when the sweep failed: the tickets of the previous iterate are answered)
+            PendingX mine = c->xp;
+            c->xp = put_off;
+            int rcp = flush_x(c);
+            c->xp = mine;
+            if (rc0 == SDC_OK) rc0 = rcp;
+        }
         if (rc0 != SDC_OK) return rc0;
         c->spec_valid = true;
         c->spec_spread = false;
@@ -3306,12 +3347,13 @@ int sdc_advance(sdc_ctx* c) {
 }
 
 int sdc_set_timeslice_options(sdc_ctx* c, int trail_sources, int defer_last_pass, int split_send) {
-    if (!c || trail_sources < 0 || trail_sources > MAXTRAIL)
-        return fail(c, SDC_ERR_PARAM, "trail: 0 .. %d start values", MAXTRAIL);
+    if (!c || trail_sources < 0) return fail(c, SDC_ERR_PARAM, "trail: a number of start values >= 0");
+    if (trail_sources > TRAIL_S) trail_sources = TRAIL_S;   // (what the recomputing launch holds in registers)
     FLUSH_X(c);
     if (trail_sources < c->trail_max) STORE_SPECTRA(c, false);
     c->trail_max = trail_sources;
     c->defer_x = defer_last_pass != 0;
+    c->pipeline_x = defer_last_pass == 1;   // (2: put off, but never behind the next sweep's launches)
     c->split_send = split_send != 0;
     return SDC_OK;
 }
@@ -3455,6 +3497,7 @@ int sdc_replace_u0_spectrum(sdc_ctx* c) {
     if (rcm != SDC_OK) return rcm;
     const bool linear_shift = c->res_valid && c->u_pending && c->spec0_valid && c->spec_valid && !c->tau_active &&
                               c->expl_kind != SDC_EXPL_FORCING;
+    bool keep_old = false;
     if (c->xp.pending && !c->xp.has_delta && linear_shift && c->n >= 64) {
         // the residual lines of the sweep still wait for their last pass: it will reduce the norms before and after this
         // receive in one go (flush_x) - the residual of every node changes by d = new - old (core/sweeper.py:186-199 is linear
@@ -3462,6 +3505,7 @@ int sdc_replace_u0_spectrum(sdc_ctx* c) {
         c->xp.has_delta = true;
         c->xp.d_old = c->S0;
         c->xp.d_new = c->Sin;
+        keep_old = !on_trail;   // (off a trail the old spectrum would become the next inbox: it has to outlive the put-off pass)
     } else {
         FLUSH_X(c);
         const bool fast = c->rlines_valid && linear_shift;
@@ -3485,6 +3529,12 @@ int sdc_replace_u0_spectrum(sdc_ctx* c) {
         cd* next_inbox = spool_get(c);
         if (!next_inbox) return SDC_ERR_NOMEM;
         c->trail_src[c->trail_ns++] = c->Sin;
+        c->S0 = c->Sin;
+        c->Sin = next_inbox;
+    } else if (keep_old) {
+        cd* next_inbox = spool_get(c);
+        if (!next_inbox) return SDC_ERR_NOMEM;
+        c->xp.d_old_spare = true;   // (flush_x hands it back)
         c->S0 = c->Sin;
         c->Sin = next_inbox;
     } else {

@@ -202,9 +202,10 @@ class SweepEngine:
         """leave F[1..M] / the spread copies unwritten until they are read (include/sdcmi.h: sdc_set_deferred)"""
         self._chk(self.lib.sdc_set_deferred(self.ctx, int(bool(on))))
 
-    def set_timeslice_options(self, trail_sources=5, defer_last_pass=True, split_send=False):
-        """how a time-parallel level deals with a u[0] that is replaced between sweeps (include/sdcmi.h)"""
-        self._chk(self.lib.sdc_set_timeslice_options(self.ctx, int(trail_sources), int(bool(defer_last_pass)), int(bool(split_send))))
+    def set_timeslice_options(self, trail_sources=0, defer_last_pass=1, split_send=False):
+        """how a time-parallel level deals with a u[0] that is replaced between sweeps (include/sdcmi.h); defer_last_pass: 0 =
+        every pass at once, 1 = put off and, where nobody asks, run behind the next sweep's first launches, 2 = put off only"""
+        self._chk(self.lib.sdc_set_timeslice_options(self.ctx, int(trail_sources), int(defer_last_pass), int(bool(split_send))))
 
     def set_early_end_point(self, on):
         self._chk(self.lib.sdc_set_early_end_point(self.ctx, int(bool(on))))

@@ -27,6 +27,15 @@ QI[1:, 1:] = QDELTA_GENERATORS['IE'](qGen=c.generator, tLeft=0).genCoeffs()
 out = {}
 copies = int(sys.argv[3]) if len(sys.argv) > 3 else 8       # the "message": that many 8 N byte device copies
 side = torch.cuda.Stream()
+msg_ms = float(os.environ.get('EMU_MSG_MS', '0'))      # spectral variant: the message as a wait of that length on its own stream
+sleep_cycles_per_ms = 0.0
+if msg_ms > 0:
+    torch.cuda._sleep(1000)
+    torch.cuda.synchronize()
+    t_ = time.perf_counter()
+    torch.cuda._sleep(200_000_000)
+    torch.cuda.synchronize()
+    sleep_cycles_per_ms = 200_000_000 / (1e3 * (time.perf_counter() - t_))
 variants = tuple(os.environ.get('EMU_VARIANTS', 'spectral,overlap,fields,recompute').split(','))
 for keep in [dict(spectral='spectral', overlap='overlap', fields=True, recompute=False)[v] for v in variants]:
     e = SweepEngine((n, n, n), M)
@@ -49,8 +58,9 @@ for keep in [dict(spectral='spectral', overlap='overlap', fields=True, recompute
     e.sweep(0.0, dt)                        # warm-up: allocates the spectral cache
     e.residual(dt)
     e.end_point(dt, False)
-    e.replace_u0(inbox.data_ptr())
-    e.residual(dt)
+    if keep != 'spectral':                  # (a FIELD as the new start value: the spectral slice never sees one - it would make
+        e.replace_u0(inbox.data_ptr())      #  the engine store the iterate and allocate the node spectra for nothing)
+        e.residual(dt)
     uend = torch.as_tensor(_CAI(e.ptr(L.SLOT_UEND), e.N, e), device='cuda')
     nspec = 2 * (n // 2 + 1) * n * n
     futures, inbox_free = [], None
@@ -85,6 +95,8 @@ for keep in [dict(spectral='spectral', overlap='overlap', fields=True, recompute
             with torch.cuda.stream(side):   # the message, posted behind the launch that wrote the last node's spectrum only
                 if inbox_free is not None:  # (... and behind the engine's last use of the buffer it lands in: sdc_comm's inbox_free)
                     side.wait_event(inbox_free)
+                if msg_ms > 0:              # a message that takes msg_ms to arrive and uses none of this GPU's bandwidth on the way
+                    torch.cuda._sleep(int(msg_ms * sleep_cycles_per_ms))
                 for _ in range(copies):
                     dst.copy_(src)
             futures.append(e.residual_post(dt))   # IT_FINE: queued; its last pass waits for the receive (defer_last_pass)
@@ -125,7 +137,7 @@ for keep in [dict(spectral='spectral', overlap='overlap', fields=True, recompute
         check = float(torch.max(torch.abs(inbox - uend)))       # the last message is the last end value
     out[{'spectral': 'spectra_on_the_wire', 'overlap': 'overlapped_message', True: 'kept_residual_fields',
          False: 'recomputed_residual'}[keep]] = {
-        'ms_per_iteration': 1e3 * el, 'message_copies': copies, 'options': os.environ.get('EMU_OPTS', '5,1,0') if keep == 'spectral' else None,
+        'ms_per_iteration': 1e3 * el, 'message_copies': copies, 'message_ms': msg_ms, 'options': os.environ.get('EMU_OPTS', '5,1,0') if keep == 'spectral' else None,
         'device_bytes': dev_bytes, 'inbox_minus_uend': check, 'kernels_ms': {k: round(v[0] / v[1], 2) for k, v in prof.items() if v[1]},
         'kernels_ms_per_iteration': {k: round(v[0] / iters, 2) for k, v in prof.items() if v[1]}}
     e.close()

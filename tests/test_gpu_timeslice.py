@@ -84,9 +84,9 @@ def _same(a, b, scale, what):
         assert np.all(np.abs(na - nb) <= 1e-6 * np.abs(nb) + 2e-12 * scale), (what, k, na, nb)
 
 
-# (trail_sources, defer_last_pass, split_send)
-PLAIN = (0, False, False)
-FLOWS = [(5, True, False), (5, True, True), (5, False, False), (0, True, False), (2, True, False), (2, True, True), (8, True, True)]
+# (trail_sources, defer_last_pass: 0 at once / 1 put off, behind the next sweep where possible / 2 put off only, split_send)
+PLAIN = (0, 0, False)
+FLOWS = [(0, 1, False), (0, 2, False), (5, 1, False), (5, 1, True), (5, 0, False), (5, 2, True), (2, 1, False), (2, 1, True), (8, 1, True)]
 
 
 @pytest.mark.parametrize('nvars,M', [((512, 512), 5), ((1024, 1024), 3), ((512, 512, 512), 5)])
@@ -118,7 +118,7 @@ def test_a_slice_that_does_not_receive_every_time():
     for receive in ([False] * iters, [True, True, False, False, True, False], [False, True, True, True, True, True]):
         ref = _slice(nvars, M, PLAIN, iters, dt, blocking=True, receive=receive)
         scale = float(np.max(np.abs(ref['u'])))
-        for opts in ((5, True, False), (5, True, True), (3, True, False)):
+        for opts in ((0, 1, False), (5, 1, False), (5, 1, True), (3, 2, False)):
             got = _slice(nvars, M, opts, iters, dt, receive=receive)
             assert np.max(np.abs(got['u'] - ref['u'])) <= 1e-12 * scale, (receive, opts)
             _same(got['resA'], ref['resA'], scale, (receive, opts, 'A'))
@@ -131,7 +131,7 @@ def test_iterates_that_are_not_stored_leave_the_node_slabs_unmapped():
     nvars, M = (512, 512, 512), 5
     os.environ['SDC_LAZY_MIN_BYTES'] = '1048576'
     try:
-        lean = _slice(nvars, M, (5, True, False), 3, 0.08)
+        lean = _slice(nvars, M, (5, 2, False), 3, 0.08)
         fat = _slice(nvars, M, PLAIN, 3, 0.08, blocking=True)
     finally:
         del os.environ['SDC_LAZY_MIN_BYTES']
@@ -145,7 +145,8 @@ def test_iterates_that_are_not_stored_leave_the_node_slabs_unmapped():
     assert fat['bytes_sweeping'] >= 2 * field + (2 * M + 2) * spec, fat['bytes_sweeping'] / field
 
 
-@pytest.mark.parametrize('env', [{}, {'PYSDC_AMD_SPLIT_SEND': '1'}, {'PYSDC_AMD_TRAIL': '2'}, {'PYSDC_AMD_TRAIL': '0', 'PYSDC_AMD_DEFER_X': '0'}])
+@pytest.mark.parametrize('env', [{}, {'PYSDC_AMD_TRAIL': '5', 'PYSDC_AMD_SPLIT_SEND': '1'}, {'PYSDC_AMD_TRAIL': '2', 'PYSDC_AMD_DEFER_X': '2'},
+                                 {'PYSDC_AMD_DEFER_X': '0'}])
 def test_three_ranks_at_512cubed_match_the_serial_emulation(env):
     """controller_dist, three thread ranks on the one GPU over the shared-memory wire, heat 512^3 (the size from which iterates
     are recomputed from mode pairs), six iterations per block (more start values than a trail of two holds), two blocks with
