@@ -235,10 +235,12 @@ def run_workload(args, world, rank, use_dist, with_stream_reference=True):
         # 1024^3 with M = 5: the sweeps that stay in Fourier space hold ~15 fields of 8.6 GB (U[0], two end-value buffers, M work
         # spectra, the start value's and the last node's spectrum, start / end value objects of the runs; U[1..M], F and the node
         # spectra are mapped only when something touches them in real space - the eager-fields sub-record does: ~31 fields); a
-        # time slice adds the start values of its trail, the spectrum inbox, two spare spectra and the relay staging (~22).  A
-        # GPU that cannot hold it ends the job with an error: the grid is never changed behind the caller's back, so that the
-        # lines of --gpus 1 and --gpus N are always about the same workload
-        need = ((31.0 if args.eager_fields else 17.0) if world == 1 else 23.0) * 8.0 * n**3
+        # time slice adds the start values of its trail, the spectrum inbox, two spare spectra, a second set of M work spectra
+        # (the put-off passes of one iterate run behind the next sweep's first launches) and the relay staging: 215 GB = 25
+        # fields measured by scripts/emulate_timeslice.py, 28 asked for.  A GPU that cannot hold it ends the job with an error:
+        # the grid is never changed behind the caller's back, so that the lines of --gpus 1 and --gpus N are always about the
+        # same workload
+        need = ((31.0 if args.eager_fields else 17.0) if world == 1 else 28.0) * 8.0 * n**3
         free = torch.cuda.mem_get_info()[0]
         if free < need:
             raise MemoryError(f'heat {n}^3 needs {need / 1e9:.0f} GB of HBM on every GPU, {free / 1e9:.0f} GB free on rank {rank} '

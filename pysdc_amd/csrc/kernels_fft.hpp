@@ -897,40 +897,52 @@ DEVI void trail_iterate(const SpecArgs& a, double lam, size_t base, int p_, int 
 #define TRAIL_S 5
 #endif
 #define TRAIL_S_NOTE   // start values the in-register variant handles (sdc_set_timeslice_options' default); more: iterates are stored
-// (x, y) <- (T x, T y): one pass over the coefficients for both chains
+// (x, y) <- (T x, T y): one pass over the coefficients for both chains.  Written column by column - every old value goes into
+// all NF row sums before the next one is touched, and a finished new value into the rows below it at once - so that 2 NF sums
+// advance side by side and the dependent part is two operations per row, not a row's whole sum (the launch has two waves per
+// SIMD: its f64 pipe lives on the independent operations of ONE wave)
+// cf: the sweep's coefficients in LDS - gI[NF][NF], cI[NF][NF], alpha[NF], row sums of gI[NF] - read with one address for the
+// whole wave.  (As kernel arguments they do not fit the scalar registers beside everything else: the launch kept fetching them
+// from the argument segment inside its loops, a wait of the whole wave each time - 7 of its 16 ms.)
 template <int NF>
-DEVI void trail_apply2(const SpecArgs& a, double lam, const double (&inv)[NF], double (&x)[NF], double (&y)[NF]) {
-    double ox[NF], oy[NF];
+struct TrailCoef {
+    static constexpr int GI = 0, CI = NF * NF, AL = 2 * NF * NF, GR = 2 * NF * NF + NF, COUNT = 2 * NF * NF + 2 * NF;
+};
+template <int NF>
+DEVI void trail_apply2(const double* cf, bool coupled, double lam, const double (&inv)[NF], double (&x)[NF], double (&y)[NF]) {
+    using TC = TrailCoef<NF>;
+    double tx[NF], ty[NF];
+#pragma unroll
+    for (int m = 0; m < NF; ++m) tx[m] = ty[m] = 0.0;
 #pragma unroll
     for (int q = 0; q < NF; ++q) {
-        ox[q] = x[q];
-        oy[q] = y[q];
+#pragma unroll
+        for (int m = 0; m < NF; ++m) {
+            const double g = cf[TC::GI + m * NF + q];
+            tx[m] = fma(g, x[q], tx[m]);
+            ty[m] = fma(g, y[q], ty[m]);
+        }
     }
 #pragma unroll
-    for (int m = 0; m < NF; ++m) {
-        double tx = 0.0, ty = 0.0;
+    for (int q = 0; q < NF; ++q) {
+        const double li = lam * inv[q];
+        x[q] = li * tx[q];
+        y[q] = li * ty[q];
+        if (coupled) {
 #pragma unroll
-        for (int q = 0; q < NF; ++q) {
-            const double g = a.gI[m][q];
-            tx = fma(g, ox[q], tx);
-            ty = fma(g, oy[q], ty);
-        }
-        if (a.coupled) {
-#pragma unroll
-            for (int q = 0; q < m; ++q) {
-                const double cq = a.cI[m][q];
-                tx = fma(cq, x[q], tx);
-                ty = fma(cq, y[q], ty);
+            for (int m = q + 1; m < NF; ++m) {
+                const double cq = cf[TC::CI + m * NF + q];
+                tx[m] = fma(cq, x[q], tx[m]);
+                ty[m] = fma(cq, y[q], ty[m]);
             }
         }
-        const double li = lam * inv[m];
-        x[m] = li * tx;
-        y[m] = li * ty;
     }
 }
 template <int NF>
-DEVI void trail_residual(const SpecArgs& a, double lam, const cd (&slo)[TRAIL_S], const cd (&shi)[TRAIL_S], cd (&rlo)[NF],
-                         cd (&rhi)[NF], cd& ulo, cd& uhi) {
+DEVI void trail_residual(const SpecArgs& a, const double* cf, double lam, const cd (&slo)[TRAIL_S], const cd (&shi)[TRAIL_S],
+                         cd (&rlo)[NF], cd (&rhi)[NF], cd& ulo, cd& uhi) {
+    using TC = TrailCoef<NF>;
+    const bool coupled = a.coupled != 0;
     // The residual of the NEW iterate is  lam dt (Q - QI)(u_new - u_old): the sweep's own equation (generic_implicit.py:75-103)
     // subtracted from the residual's (core/sweeper.py:186-199).  Per start value only the DIFFERENCE of its node multipliers
     // between the last two iterates is needed - D_i = x(end of its run) - x(end of the run before it) [+ T^(J-1)(T 1 - 1) for
@@ -941,18 +953,19 @@ DEVI void trail_residual(const SpecArgs& a, double lam, const cd (&slo)[TRAIL_S]
     ulo = uhi = cd{0.0, 0.0};
 #pragma unroll
     for (int m = 0; m < NF; ++m) {
-        inv[m] = fast_rcp(1.0 - a.alpha[m] * lam);
+        inv[m] = fast_rcp(1.0 - cf[TC::AL + m] * lam);
         rlo[m] = rhi[m] = cd{0.0, 0.0};
         xp[m] = 0.0;
     }
 #pragma unroll
     for (int m = 0; m < NF; ++m) {   // x = b,  z = T 1 - 1
-        double tb = 0.0, t1 = a.gIrow[m];
-        if (a.coupled) {
+        double tb = 0.0, t1 = cf[TC::GR + m];
+        if (coupled) {
 #pragma unroll
             for (int q = 0; q < m; ++q) {
-                tb = fma(a.cI[m][q], x[q], tb);
-                t1 = fma(a.cI[m][q], z[q] + 1.0, t1);
+                const double cq = cf[TC::CI + m * NF + q];
+                tb = fma(cq, x[q], tb);
+                t1 = fma(cq, z[q] + 1.0, t1);
             }
         }
         x[m] = fma(lam, tb, 1.0) * inv[m];
@@ -984,12 +997,16 @@ DEVI void trail_residual(const SpecArgs& a, double lam, const cd (&slo)[TRAIL_S]
                     D[m] = fma(first, z[m], x[m] - xp[m]);
                     xp[m] = x[m];
                 }
+                double tq[NF];
+#pragma unroll
+                for (int m = 0; m < NF; ++m) tq[m] = 0.0;
+#pragma unroll
+                for (int q = 0; q < NF; ++q)   // (column by column: NF sums side by side)
+#pragma unroll
+                    for (int m = 0; m < NF; ++m) tq[m] = fma(cf[TC::GI + m * NF + q], D[q], tq[m]);
 #pragma unroll
                 for (int m = 0; m < NF; ++m) {
-                    double tq = 0.0;
-#pragma unroll
-                    for (int q = 0; q < NF; ++q) tq = fma(a.gI[m][q], D[q], tq);
-                    const double h = lam * tq;
+                    const double h = lam * tq[m];
                     rlo[m] = cd{fma(h, sl.x, rlo[m].x), fma(h, sl.y, rlo[m].y)};
                     rhi[m] = cd{fma(h, sh.x, rhi[m].x), fma(h, sh.y, rhi[m].y)};
                 }
@@ -997,7 +1014,7 @@ DEVI void trail_residual(const SpecArgs& a, double lam, const cd (&slo)[TRAIL_S]
                 ulo = cd{fma(gl, sl.x, ulo.x), fma(gl, sl.y, ulo.y)};
                 uhi = cd{fma(gl, sh.x, uhi.x), fma(gl, sh.y, uhi.y)};
             }
-            if (++s < J) trail_apply2<NF>(a, lam, inv, x, z);
+            if (++s < J) trail_apply2<NF>(cf, coupled, lam, inv, x, z);
         }
     }
 }
@@ -1291,10 +1308,26 @@ constexpr int specz_threads() { return specz_lines<N, V>() * (N / specz_elems<N,
 template <int N, bool V>
 constexpr int specz_min_waves() { return specz_lines<N, V>() > 1 ? 2 : (V ? SDC_SPECZ_VWAVES : SDC_SPECZ_WAVES); }
 // EXPL 0: no explicit part, 1: explicit stencil (symbol lamE), 2: u-independent forcing (profile spectrum SP).
+// threads of the trail launch (MODE 6): the node multipliers of the N/2 + 1 mode pairs of a line are the long part of that
+// launch, one pair per thread wants more threads than the NF transforms have (8 waves instead of 5 at 1024 x 5: the
+// waves beyond the transforms' only work on multipliers)
+#ifndef SDC_TRAIL_WIDE
+#define SDC_TRAIL_WIDE 1
+#endif
+#ifndef SDC_TRAIL_WAVES
+#define SDC_TRAIL_WAVES 2   // waves per SIMD the trail launch is compiled for (registers: 256 / 170 / 128)
+#endif
+template <int N, int NF>
+constexpr int trail_threads() {
+    constexpr int nt = specz_threads<N, NF, true>();
+    constexpr int want = ((N / 2 + 1 + 63) / 64) * 64 > 512 ? 512 : ((N / 2 + 1 + 63) / 64) * 64;
+    return (SDC_TRAIL_WIDE && specz_lines<N, true>() == 1 && want > nt) ? want : nt;
+}
 template <int N, int NF, int MODE, int EXPL>
 // (several lines per workgroup, N < 1024: the elements a thread takes from the first chunk stay live while it works on
 // the second one - 2 waves / SIMD worth of registers instead of spilling; measured 5.7 -> 4.2 ms at 512^3)
-__global__ __launch_bounds__((specz_threads<N, NF, (MODE >= 3)>()), (MODE == 6 ? 2 : specz_min_waves<N, (MODE >= 3)>()))
+__global__ __launch_bounds__((MODE == 6 ? trail_threads<N, NF>() : specz_threads<N, NF, (MODE >= 3)>()),
+                             (MODE == 6 ? SDC_TRAIL_WAVES : specz_min_waves<N, (MODE >= 3)>()))
 void k_spec_z(SpecArgs a, unsigned nlines) {
     constexpr bool RES = MODE >= 1, UPD = MODE <= 1 || MODE >= 3, VIRT = MODE >= 3, TRAIL = MODE == 6, PAIR = MODE >= 4 && !TRAIL,
                    GTAB = MODE == 5, HASE = EXPL == 1, HASP = EXPL == 2;
@@ -1416,17 +1449,29 @@ void k_spec_z(SpecArgs a, unsigned nlines) {
         // MODE 6: the iterate is a function of SEVERAL start values (trail_residual).  All mode pairs of the line are worked on
         // before anything is handed over, through a buffer that holds the whole line of every field (the transform's exchange
         // planes take its place afterwards); the start values of a thread's next pair are fetched while it works on this one.
-        constexpr int H = N / 2, NI = H + 1, ITT = (NI + NT - 1) / NT;
+        constexpr int NTT = trail_threads<N, NF>();   // (>= NT: all threads of the workgroup take pairs)
+        constexpr int H = N / 2, NI = H + 1, ITT = (NI + NTT - 1) / NTT;
         const size_t base = (size_t)bid * N;
         double lxy = 0.0;
         if (a.ndim == 3) lxy = a.lamI[bid / N].x + a.lamI[bid % N].x;
         else if (a.ndim == 2) lxy = a.lamI[bid].x;
         auto pair_of = [&](int g, int& p_, bool& mine, bool& paired) {
-            const int p0 = (int)threadIdx.x + g * NT;
+            const int p0 = (int)threadIdx.x + g * NTT;
             mine = ok && p0 < NI;
             p_ = mine ? p0 : H;   // (a lane without a pair of its own follows along on a valid one, stores nothing)
             paired = p_ >= 1 && p_ < H;
         };
+        using TC = TrailCoef<NF>;
+        double* cf = lds + 2 * (size_t)NF * N;   // the sweep's coefficients behind the hand-over buffer (see TrailCoef)
+        if (threadIdx.x < NF * NF) {
+            cf[TC::GI + threadIdx.x] = a.gI[threadIdx.x / NF][threadIdx.x % NF];
+            cf[TC::CI + threadIdx.x] = a.cI[threadIdx.x / NF][threadIdx.x % NF];
+        }
+        if (threadIdx.x < NF) {
+            cf[TC::AL + threadIdx.x] = a.alpha[threadIdx.x];
+            cf[TC::GR + threadIdx.x] = a.gIrow[threadIdx.x];
+        }
+        __syncthreads();
         cd slo[2][TRAIL_S], shi[2][TRAIL_S];   // (two sets: the one being worked on, the one being fetched)
         int pn[2];
         bool mn[2], prn[2];
@@ -1435,16 +1480,28 @@ void k_spec_z(SpecArgs a, unsigned nlines) {
 #pragma unroll
         for (int g = 0; g < ITT; ++g) {
             // (wave-uniform: does any lane of this wave have a pair in this round?)
-            if ((int)(threadIdx.x & ~63u) + g * NT < NI) {
+            if ((int)(threadIdx.x & ~63u) + g * NTT < NI) {
                 const int cur = g & 1, nxt = cur ^ 1;
                 const int pc = pn[cur];
                 const bool minec = mn[cur], pairedc = prn[cur];
-                if (g + 1 < ITT && (int)(threadIdx.x & ~63u) + (g + 1) * NT < NI) {
+                if (g + 1 < ITT && (int)(threadIdx.x & ~63u) + (g + 1) * NTT < NI) {
                     pair_of(g + 1, pn[nxt], mn[nxt], prn[nxt]);
                     trail_fetch<NF>(a, base, pn[nxt], N, prn[nxt], slo[nxt], shi[nxt]);
                 }
                 cd rlo[NF], rhi[NF], ulo, uhi;
-                trail_residual<NF>(a, a.lamI[pc].x + lxy, slo[cur], shi[cur], rlo, rhi, ulo, uhi);
+#ifndef SDC_TRAIL_DBG
+#define SDC_TRAIL_DBG 0   // timing experiments (wrong results): 1 = no multiplier arithmetic, 2 = ... and no line transform
+#endif
+                if constexpr (SDC_TRAIL_DBG >= 1) {
+                    ulo = slo[cur][0];
+                    uhi = shi[cur][0];
+#pragma unroll
+                    for (int m = 0; m < NF; ++m) {
+                        rlo[m] = cadd(slo[cur][m % TRAIL_S], slo[cur][0]);
+                        rhi[m] = cadd(shi[cur][m % TRAIL_S], shi[cur][0]);
+                    }
+                } else
+                trail_residual<NF>(a, cf, a.lamI[pc].x + lxy, slo[cur], shi[cur], rlo, rhi, ulo, uhi);
                 if (minec) {
                     if (a.store_last) {   // the last node's spectrum: what the wire carries, and the next step's start value
                         a.SL[base + pc] = ulo;
@@ -1459,9 +1516,12 @@ void k_spec_z(SpecArgs a, unsigned nlines) {
             }
         }
         __syncthreads();
+        if (f >= NF) return;   // (a wave beyond the transforms': its pairs are handed over, nothing else to do - the line
+                               // transforms below synchronise inside their own waves, P <= 64)
 #pragma unroll
         for (int i = 0; i < E; ++i) r[i] = rbuf[f * N + j + i * P];
-        __syncthreads();
+        // (the exchange planes of the transform alias the hand-over buffer: every transforming wave has read its column first)
+        __builtin_amdgcn_s_barrier();
     }
     constexpr bool HOIST = VIRT && !PAIR && !TRAIL && SDC_SPECZ_VHOIST;
     cd in0all[HOIST ? NCH : 1][ITS];
@@ -1586,7 +1646,7 @@ void k_spec_z(SpecArgs a, unsigned nlines) {
         }
         __syncthreads();  // the next chunk / the exchange planes of the transform overwrite the buffer
     }
-    fft_line<N, +1, LAY, P <= 64, E>(r, j, c, lds, a.tw);
+    if constexpr (!(TRAIL && SDC_TRAIL_DBG >= 2)) fft_line<N, +1, LAY, P <= 64, E>(r, j, c, lds, a.tw);
     if (ok) {
         cd* __restrict__ dst = a.W + f * a.fstride + line * N;
 #pragma unroll

@@ -596,9 +596,10 @@ static void launch_spec_z_cfg(sdc_ctx* c, SpecArgs& a, size_t lines, int mode, s
     constexpr int SPAN = LPB * N, CH = SPAN > SDC_SPECZ_CH ? SDC_SPECZ_CH : SPAN;
     size_t ldsz = (size_t)LayContig<N>::doubles(NF * LPB) * sizeof(double);
     if ((size_t)NF * CH * sizeof(cd) > ldsz) ldsz = (size_t)NF * CH * sizeof(cd);
-    if (V && a.ns > 0) ldsz = std::max(ldsz, (size_t)NF * N * sizeof(cd));  // (trail: the whole line of every field - 80 KB at 1024 x 5: two workgroups per CU, to the byte)
+    if (V && a.ns > 0) ldsz = std::max(ldsz, (size_t)NF * N * sizeof(cd)) + TrailCoef<NF>::COUNT * sizeof(double);  // (trail: the whole line of every field, and the sweep's coefficients)
     if (const char* pad = getenv("SDC_DBG_LDS_PAD")) ldsz += (size_t)atol(pad);   // (experiments: fewer workgroups per CU)
-    const dim3 grid((unsigned)((launch_lines + LPB - 1) / LPB)), block(P * LPB * NF);  // (lines: the bound the kernel checks)
+    // (lines: the bound the kernel checks; the trail launch may use more threads than its transforms have)
+    const dim3 grid((unsigned)((launch_lines + LPB - 1) / LPB)), block((V && a.ns > 0) ? trail_threads<N, NF>() : P * LPB * NF);
     const int expl = a.lamE ? 1 : (a.SP ? 2 : 0);
 #define ZL(M_, E_) hipLaunchKernelGGL((k_spec_z<N, NF, M_, E_>), grid, block, ldsz, c->stream, a, (unsigned)lines)
     if constexpr (V) {  // (iterate recomputed from S0: real symbol, no explicit part - sdc_sweep sees to that)
