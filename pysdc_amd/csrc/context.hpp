@@ -97,6 +97,7 @@ struct sdc_ctx {
     // hold the residual of the current iterate after its z / y inverse passes (the x pass only reduced a norm), which lets
     // a new start value update the node norms by ONE more field through the pipeline instead of M.
     cd* Sin = nullptr;
+    cd* trail_nyq = nullptr;   // [lines][M]: the Nyquist mode's residual of every z line (k_trail_nyq -> k_trail_z)
     // spectrum-sized buffers nobody uses right now (sources of a finished trail, difference spectra, ...) and the ones this
     // context allocated one by one (freed with it)
     std::vector<cd*> spool, spool_owned;

@@ -894,7 +894,7 @@ DEVI void trail_iterate(const SpecArgs& a, double lam, size_t base, int p_, int 
 // All start values are fetched before the first multiplication (slo / shi, filled by the caller: the loads of a thread's NEXT
 // pair are in flight while it works on this one).
 #ifndef TRAIL_S
-#define TRAIL_S 5
+#define TRAIL_S 4
 #endif
 #define TRAIL_S_NOTE   // start values the in-register variant handles (sdc_set_timeslice_options' default); more: iterates are stored
 // (x, y) <- (T x, T y): one pass over the coefficients for both chains.  Written column by column - every old value goes into
@@ -1020,16 +1020,15 @@ DEVI void trail_residual(const SpecArgs& a, const double* cf, double lam, const 
 }
 template <int NF>
 DEVI void trail_fetch(const SpecArgs& a, size_t base, int p_, int n, bool paired, cd (&slo)[TRAIL_S], cd (&shi)[TRAIL_S]) {
-    // (the partner of an unpaired mode is read from the mode itself and never used: no branch around a load - with one, every
-    // load was waited for in turn; start values that do not exist are not read: a wave-uniform branch)
+    // (the partner of an unpaired mode is read from the mode itself and never used, the entries of a.src beyond the trail repeat
+    // its last start value: no branch around a load - with one, the number of loads in flight is not known when the code is
+    // made, and a wait for an earlier load waits for these as well)
     const size_t ilo = base + p_, ihi = base + (paired ? n - p_ : p_);
 #pragma unroll
     for (int i = 0; i < TRAIL_S; ++i) {
-        if (i < a.ns) {
-            const cd* __restrict__ sp = a.src[i];
-            slo[i] = sp[ilo];
-            shi[i] = sp[ihi];
-        }
+        const cd* __restrict__ sp = a.src[i];
+        slo[i] = sp[ilo];
+        shi[i] = sp[ihi];
     }
 }
 
@@ -1308,32 +1307,28 @@ constexpr int specz_threads() { return specz_lines<N, V>() * (N / specz_elems<N,
 template <int N, bool V>
 constexpr int specz_min_waves() { return specz_lines<N, V>() > 1 ? 2 : (V ? SDC_SPECZ_VWAVES : SDC_SPECZ_WAVES); }
 // EXPL 0: no explicit part, 1: explicit stencil (symbol lamE), 2: u-independent forcing (profile spectrum SP).
-// threads of the trail launch (MODE 6): the node multipliers of the N/2 + 1 mode pairs of a line are the long part of that
+// threads of the trail launch (k_trail_z): the node multipliers of the N/2 mode pairs of a line are the long part of that
 // launch, one pair per thread wants more threads than the NF transforms have (8 waves instead of 5 at 1024 x 5: the
 // waves beyond the transforms' only work on multipliers)
-#ifndef SDC_TRAIL_WIDE
-#define SDC_TRAIL_WIDE 1
-#endif
 #ifndef SDC_TRAIL_WAVES
 #define SDC_TRAIL_WAVES 2   // waves per SIMD the trail launch is compiled for (registers: 256 / 170 / 128)
 #endif
 template <int N, int NF>
 constexpr int trail_threads() {
     constexpr int nt = specz_threads<N, NF, true>();
-    constexpr int want = ((N / 2 + 1 + 63) / 64) * 64 > 512 ? 512 : ((N / 2 + 1 + 63) / 64) * 64;
-    return (SDC_TRAIL_WIDE && specz_lines<N, true>() == 1 && want > nt) ? want : nt;
+    constexpr int want = ((N / 2 + 63) / 64) * 64 > 512 ? 512 : ((N / 2 + 63) / 64) * 64;
+    return (specz_lines<N, true>() == 1 && want > nt) ? want : nt;
 }
 template <int N, int NF, int MODE, int EXPL>
 // (several lines per workgroup, N < 1024: the elements a thread takes from the first chunk stay live while it works on
 // the second one - 2 waves / SIMD worth of registers instead of spilling; measured 5.7 -> 4.2 ms at 512^3)
-__global__ __launch_bounds__((MODE == 6 ? trail_threads<N, NF>() : specz_threads<N, NF, (MODE >= 3)>()),
-                             (MODE == 6 ? SDC_TRAIL_WAVES : specz_min_waves<N, (MODE >= 3)>()))
+__global__ __launch_bounds__((specz_threads<N, NF, (MODE >= 3)>()), (specz_min_waves<N, (MODE >= 3)>()))
 void k_spec_z(SpecArgs a, unsigned nlines) {
-    constexpr bool RES = MODE >= 1, UPD = MODE <= 1 || MODE >= 3, VIRT = MODE >= 3, TRAIL = MODE == 6, PAIR = MODE >= 4 && !TRAIL,
+    constexpr bool RES = MODE >= 1, UPD = MODE <= 1 || MODE >= 3, VIRT = MODE >= 3, PAIR = MODE >= 4,
                    GTAB = MODE == 5, HASE = EXPL == 1, HASP = EXPL == 2;
     static_assert(!(VIRT && HASP), "a forced iterate is not a function of the start value alone");
     constexpr int E = specz_elems<N, (MODE >= 3)>(), P = N / E, LPB = specz_lines<N, (MODE >= 3)>();
-    static_assert(!(PAIR || TRAIL) || (LPB == 1 && !HASE), "mode pairs: one line per field and workgroup, real symbol only");
+    static_assert(!PAIR || (LPB == 1 && !HASE), "mode pairs: one line per field and workgroup, real symbol only");
     constexpr int SPAN = LPB * N, CH = SPAN > SDC_SPECZ_CH ? SDC_SPECZ_CH : SPAN, NCH = SPAN / CH, NT = LPB * P * NF;
     constexpr int ITS = (CH + NT - 1) / NT;  // modes per thread and chunk
     using LAY = LayContig<N>;
@@ -1445,85 +1440,7 @@ void k_spec_z(SpecArgs a, unsigned nlines) {
             __syncthreads();
         }
     }
-    if constexpr (TRAIL) {
-        // MODE 6: the iterate is a function of SEVERAL start values (trail_residual).  All mode pairs of the line are worked on
-        // before anything is handed over, through a buffer that holds the whole line of every field (the transform's exchange
-        // planes take its place afterwards); the start values of a thread's next pair are fetched while it works on this one.
-        constexpr int NTT = trail_threads<N, NF>();   // (>= NT: all threads of the workgroup take pairs)
-        constexpr int H = N / 2, NI = H + 1, ITT = (NI + NTT - 1) / NTT;
-        const size_t base = (size_t)bid * N;
-        double lxy = 0.0;
-        if (a.ndim == 3) lxy = a.lamI[bid / N].x + a.lamI[bid % N].x;
-        else if (a.ndim == 2) lxy = a.lamI[bid].x;
-        auto pair_of = [&](int g, int& p_, bool& mine, bool& paired) {
-            const int p0 = (int)threadIdx.x + g * NTT;
-            mine = ok && p0 < NI;
-            p_ = mine ? p0 : H;   // (a lane without a pair of its own follows along on a valid one, stores nothing)
-            paired = p_ >= 1 && p_ < H;
-        };
-        using TC = TrailCoef<NF>;
-        double* cf = lds + 2 * (size_t)NF * N;   // the sweep's coefficients behind the hand-over buffer (see TrailCoef)
-        if (threadIdx.x < NF * NF) {
-            cf[TC::GI + threadIdx.x] = a.gI[threadIdx.x / NF][threadIdx.x % NF];
-            cf[TC::CI + threadIdx.x] = a.cI[threadIdx.x / NF][threadIdx.x % NF];
-        }
-        if (threadIdx.x < NF) {
-            cf[TC::AL + threadIdx.x] = a.alpha[threadIdx.x];
-            cf[TC::GR + threadIdx.x] = a.gIrow[threadIdx.x];
-        }
-        __syncthreads();
-        cd slo[2][TRAIL_S], shi[2][TRAIL_S];   // (two sets: the one being worked on, the one being fetched)
-        int pn[2];
-        bool mn[2], prn[2];
-        pair_of(0, pn[0], mn[0], prn[0]);
-        trail_fetch<NF>(a, base, pn[0], N, prn[0], slo[0], shi[0]);
-#pragma unroll
-        for (int g = 0; g < ITT; ++g) {
-            // (wave-uniform: does any lane of this wave have a pair in this round?)
-            if ((int)(threadIdx.x & ~63u) + g * NTT < NI) {
-                const int cur = g & 1, nxt = cur ^ 1;
-                const int pc = pn[cur];
-                const bool minec = mn[cur], pairedc = prn[cur];
-                if (g + 1 < ITT && (int)(threadIdx.x & ~63u) + (g + 1) * NTT < NI) {
-                    pair_of(g + 1, pn[nxt], mn[nxt], prn[nxt]);
-                    trail_fetch<NF>(a, base, pn[nxt], N, prn[nxt], slo[nxt], shi[nxt]);
-                }
-                cd rlo[NF], rhi[NF], ulo, uhi;
-#ifndef SDC_TRAIL_DBG
-#define SDC_TRAIL_DBG 0   // timing experiments (wrong results): 1 = no multiplier arithmetic, 2 = ... and no line transform
-#endif
-                if constexpr (SDC_TRAIL_DBG >= 1) {
-                    ulo = slo[cur][0];
-                    uhi = shi[cur][0];
-#pragma unroll
-                    for (int m = 0; m < NF; ++m) {
-                        rlo[m] = cadd(slo[cur][m % TRAIL_S], slo[cur][0]);
-                        rhi[m] = cadd(shi[cur][m % TRAIL_S], shi[cur][0]);
-                    }
-                } else
-                trail_residual<NF>(a, cf, a.lamI[pc].x + lxy, slo[cur], shi[cur], rlo, rhi, ulo, uhi);
-                if (minec) {
-                    if (a.store_last) {   // the last node's spectrum: what the wire carries, and the next step's start value
-                        a.SL[base + pc] = ulo;
-                        if (pairedc) a.SL[base + N - pc] = uhi;
-                    }
-#pragma unroll
-                    for (int m = 0; m < NF; ++m) {
-                        rbuf[m * N + pc] = cscale(rlo[m], a.invN);
-                        if (pairedc) rbuf[m * N + N - pc] = cscale(rhi[m], a.invN);
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        if (f >= NF) return;   // (a wave beyond the transforms': its pairs are handed over, nothing else to do - the line
-                               // transforms below synchronise inside their own waves, P <= 64)
-#pragma unroll
-        for (int i = 0; i < E; ++i) r[i] = rbuf[f * N + j + i * P];
-        // (the exchange planes of the transform alias the hand-over buffer: every transforming wave has read its column first)
-        __builtin_amdgcn_s_barrier();
-    }
-    constexpr bool HOIST = VIRT && !PAIR && !TRAIL && SDC_SPECZ_VHOIST;
+    constexpr bool HOIST = VIRT && !PAIR && SDC_SPECZ_VHOIST;
     cd in0all[HOIST ? NCH : 1][ITS];
     if constexpr (HOIST) {
 #pragma unroll
@@ -1536,7 +1453,7 @@ void k_spec_z(SpecArgs a, unsigned nlines) {
             }
     }
 #pragma unroll
-    for (int ch = 0; ch < ((PAIR || TRAIL) ? 0 : NCH); ++ch) {
+    for (int ch = 0; ch < (PAIR ? 0 : NCH); ++ch) {
         // all loads of this chunk first: (NF + 1) * ITS independent 16-byte loads per thread in flight
         cd in0[ITS], inq[ITS][VIRT ? 1 : NF], inp[ITS];
 #pragma unroll
@@ -1646,7 +1563,7 @@ void k_spec_z(SpecArgs a, unsigned nlines) {
         }
         __syncthreads();  // the next chunk / the exchange planes of the transform overwrite the buffer
     }
-    if constexpr (!(TRAIL && SDC_TRAIL_DBG >= 2)) fft_line<N, +1, LAY, P <= 64, E>(r, j, c, lds, a.tw);
+    fft_line<N, +1, LAY, P <= 64, E>(r, j, c, lds, a.tw);
     if (ok) {
         cd* __restrict__ dst = a.W + f * a.fstride + line * N;
 #pragma unroll
@@ -1658,5 +1575,134 @@ void k_spec_z(SpecArgs a, unsigned nlines) {
             dst[j + i * P] = r[i];
 #endif
         }
+    }
+}
+
+// The recomputing z launch of a slice on the trail as a PERSISTENT launch: one workgroup per CU (the hand-over buffer of a line
+// of every field fills half the LDS, its registers the other limit) walks over lines; the start values of its next line are on
+// their way while it works on the multipliers of this one, and the stores of a line drain under the next line's arithmetic.
+// With one line per workgroup and launch the CU's memory pipes idle while the multipliers are made and its ALUs while the line
+// is fetched and stored: 16.9 - 27.9 ms for 1 - 4 replayed sweeps at 1024^3 x 5, of which 8.1 - 12.8 are memory time.
+// The Nyquist mode of every line (item N/2 + 1 of N/2 + 1: a second round of one lane) is made by a launch of its own
+// (k_trail_nyq) and added to the hand-over buffer from a table.
+template <int NF>
+__global__ __launch_bounds__(256) void k_trail_nyq(SpecArgs a, int n, unsigned nlines, cd* __restrict__ nyq) {
+    using TC = TrailCoef<NF>;
+    __shared__ double cf[TC::COUNT];
+    if (threadIdx.x < NF * NF) {
+        cf[TC::GI + threadIdx.x] = a.gI[threadIdx.x / NF][threadIdx.x % NF];
+        cf[TC::CI + threadIdx.x] = a.cI[threadIdx.x / NF][threadIdx.x % NF];
+    }
+    if (threadIdx.x < NF) {
+        cf[TC::AL + threadIdx.x] = a.alpha[threadIdx.x];
+        cf[TC::GR + threadIdx.x] = a.gIrow[threadIdx.x];
+    }
+    __syncthreads();
+    const unsigned line = blockIdx.x * blockDim.x + threadIdx.x;
+    if (line >= nlines) return;
+    const int H = n / 2;
+    double lxy = 0.0;
+    if (a.ndim == 3) lxy = a.lamI[line / n].x + a.lamI[line % n].x;
+    else if (a.ndim == 2) lxy = a.lamI[line].x;
+    const size_t base = (size_t)line * n;
+    cd slo[TRAIL_S], shi[TRAIL_S];
+    trail_fetch<NF>(a, base, H, n, false, slo, shi);
+    cd rlo[NF], rhi[NF], ulo, uhi;
+    trail_residual<NF>(a, cf, a.lamI[H].x + lxy, slo, shi, rlo, rhi, ulo, uhi);
+    if (a.store_last) a.SL[base + H] = ulo;
+#pragma unroll
+    for (int m = 0; m < NF; ++m) nyq[(size_t)line * NF + m] = cscale(rlo[m], a.invN);
+}
+
+template <int N, int NF>
+__global__ __launch_bounds__((trail_threads<N, NF>()), SDC_TRAIL_WAVES)
+void k_trail_z(SpecArgs a, unsigned nlines, const cd* __restrict__ nyq) {
+    constexpr int E = specz_elems<N, true>(), P = N / E, NTT = trail_threads<N, NF>(), H = N / 2;
+    static_assert(specz_lines<N, true>() == 1 && P <= 64 && H <= NTT, "one line per workgroup, one mode pair per thread");
+    using LAY = LayContig<N>;
+    using TC = TrailCoef<NF>;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    cd* rbuf = reinterpret_cast<cd*>(lds);           // [NF][N]: the residual lines handed over to the transforms
+    double* cf = lds + 2 * (size_t)NF * N;           // the sweep's coefficients (see TrailCoef)
+    // the twiddle factors the line transform looks up, in LDS: with one workgroup per CU nobody else's work hides the latency of
+    // a table look-up in L2, and the transform has two dependent ones per line (1.5 of 6.7 us per line at 1024^3)
+    cd* twl = reinterpret_cast<cd*>(cf + ((TC::COUNT + 1) & ~1));
+    static_assert(LAY::doubles(NF) <= 2 * NF * N, "the exchange planes of the transform alias the hand-over buffer");
+    for (int i = threadIdx.x; i < N / 2; i += NTT) twl[i] = a.tw[i];
+    if (threadIdx.x < NF * NF) {
+        cf[TC::GI + threadIdx.x] = a.gI[threadIdx.x / NF][threadIdx.x % NF];
+        cf[TC::CI + threadIdx.x] = a.cI[threadIdx.x / NF][threadIdx.x % NF];
+    }
+    if (threadIdx.x < NF) {
+        cf[TC::AL + threadIdx.x] = a.alpha[threadIdx.x];
+        cf[TC::GR + threadIdx.x] = a.gIrow[threadIdx.x];
+    }
+    __syncthreads();
+    const int c = threadIdx.x / P, j = threadIdx.x % P;   // (c < NF: this wave transforms field c)
+    const bool mine = (int)threadIdx.x < H;
+    const int p_ = mine ? (int)threadIdx.x : H - 1;       // (a lane without a pair follows along on a valid one, stores nothing)
+    const bool paired = p_ >= 1;
+    const double lz = a.lamI[p_].x;
+    cd slo[2][TRAIL_S], shi[2][TRAIL_S];                  // (two sets: the line being worked on, the line being fetched)
+    unsigned line = blockIdx.x;
+    // (what a line needs beside its start values - the symbol of its kx, ky, its Nyquist entries - is asked for one line ahead
+    // and BEFORE the start values of the line after: a wait for these small loads then does not wait for the big ones)
+    // (no branches around these loads: the kx / ky entries of the symbol table exist for every line index below nlines)
+    const double wu = a.ndim >= 2 ? 1.0 : 0.0, wv = a.ndim == 3 ? 1.0 : 0.0;
+    const bool d3 = a.ndim == 3, d2 = a.ndim == 2;
+    const unsigned last = nlines - 1;
+    auto iu_of = [=](unsigned ln) { const unsigned lc = ln < last ? ln : last; return d3 ? lc / N : (d2 ? lc : 0u); };
+    auto iv_of = [=](unsigned ln) { const unsigned lc = ln < last ? ln : last; return d3 ? lc % N : 0u; };
+    auto nyq_of = [=](unsigned ln) {
+        const unsigned lc = ln < last ? ln : last;
+        return nyq[(size_t)lc * NF + ((int)threadIdx.x < NF ? threadIdx.x : 0)];
+    };
+    double lu = a.lamI[iu_of(line)].x, lv = a.lamI[iv_of(line)].x;
+    cd nq = nyq_of(line);
+    if (line < nlines) trail_fetch<NF>(a, (size_t)line * N, p_, N, paired, slo[0], shi[0]);
+    auto step = [&](auto CUR) {
+        constexpr int cur = decltype(CUR)::value, nxt = cur ^ 1;
+        const size_t base = (size_t)line * N;
+        const unsigned nl = line + gridDim.x;
+        const double lxy = wu * lu + wv * lv;
+        const cd nq_cur = nq;
+        lu = a.lamI[iu_of(nl)].x;
+        lv = a.lamI[iv_of(nl)].x;
+        nq = nyq_of(nl);
+        trail_fetch<NF>(a, (size_t)(nl < last ? nl : last) * N, p_, N, paired, slo[nxt], shi[nxt]);   // (past the end: the last line again)
+        cd rlo[NF], rhi[NF], ulo, uhi;
+        trail_residual<NF>(a, cf, lz + lxy, slo[cur], shi[cur], rlo, rhi, ulo, uhi);
+        __syncthreads();   // the transforms of the previous line are done with their exchange planes (first line: cf is there)
+        if (mine) {
+            if (a.store_last) {   // the last node's spectrum: what the wire carries, and the next step's start value
+                a.SL[base + p_] = ulo;
+                if (paired) a.SL[base + N - p_] = uhi;
+            }
+#pragma unroll
+            for (int m = 0; m < NF; ++m) {
+                rbuf[m * N + p_] = cscale(rlo[m], a.invN);
+                if (paired) rbuf[m * N + N - p_] = cscale(rhi[m], a.invN);
+            }
+        }
+        if ((int)threadIdx.x < NF) rbuf[threadIdx.x * N + H] = nq_cur;
+        __syncthreads();
+        cd r[E];
+        if (c < NF) {
+#pragma unroll
+            for (int i = 0; i < E; ++i) r[i] = rbuf[c * N + j + i * P];
+        }
+        __syncthreads();   // (every transforming wave has read its column: the exchange planes may overwrite the buffer)
+        if (c < NF) {      // (the line transforms synchronise inside their own waves, P <= 64: the other waves go on)
+            fft_line<N, +1, LAY, true, E>(r, j, c, lds, twl);
+            cd* __restrict__ dst = a.W + c * a.fstride + base;
+#pragma unroll
+            for (int i = 0; i < E; ++i) dst[j + i * P] = r[i];
+        }
+        line = nl;
+    };
+    while (line < nlines) {
+        step(std::integral_constant<int, 0>{});
+        if (line >= nlines) break;
+        step(std::integral_constant<int, 1>{});
     }
 }

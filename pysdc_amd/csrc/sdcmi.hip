@@ -590,23 +590,51 @@ static int early_end_point_n(sdc_ctx* c, bool norms_only) {
     return SDC_OK;
 }
 
+static int device_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+    }
+    return cus;
+}
+// the trail's z launch: the Nyquist modes of all lines by a small launch of their own, then one persistent workgroup per CU
+template <int N, int NF>
+static void launch_trail_z(sdc_ctx* c, SpecArgs& a, size_t lines) {
+    if (!c->trail_nyq) {
+        const size_t all = c->ndim == 1 ? 1 : (size_t)(c->n / 2 + 1) * (c->ndim == 3 ? c->n : 1);
+        if (hipMalloc((void**)&c->trail_nyq, sizeof(cd) * all * c->M) != hipSuccess) {
+            c->trail_nyq = nullptr;
+            fail(c, SDC_ERR_HIP, "hipMalloc of the trail's Nyquist table");
+            return;
+        }
+        c->bytes += sizeof(cd) * all * c->M;
+    }
+    hipLaunchKernelGGL((k_trail_nyq<NF>), dim3((unsigned)((lines + 255) / 256)), dim3(256), 0, c->stream, a, N, (unsigned)lines, c->trail_nyq);
+    const size_t ldsz = ((size_t)2 * NF * N + ((TrailCoef<NF>::COUNT + 1) & ~1) + N) * sizeof(double);   // hand-over lines, coefficients, N / 2 twiddles
+    const unsigned wgs = (unsigned)std::min<size_t>(lines, (size_t)device_cus());
+    hipLaunchKernelGGL((k_trail_z<N, NF>), dim3(wgs), dim3(trail_threads<N, NF>()), ldsz, c->stream, a, (unsigned)lines, (const cd*)c->trail_nyq);
+}
+
 template <int N, int NF, bool V>
 static void launch_spec_z_cfg(sdc_ctx* c, SpecArgs& a, size_t lines, int mode, size_t launch_lines) {
     constexpr int P = N / specz_elems<N, V>(), LPB = specz_lines<N, V>();
     constexpr int SPAN = LPB * N, CH = SPAN > SDC_SPECZ_CH ? SDC_SPECZ_CH : SPAN;
     size_t ldsz = (size_t)LayContig<N>::doubles(NF * LPB) * sizeof(double);
     if ((size_t)NF * CH * sizeof(cd) > ldsz) ldsz = (size_t)NF * CH * sizeof(cd);
-    if (V && a.ns > 0) ldsz = std::max(ldsz, (size_t)NF * N * sizeof(cd)) + TrailCoef<NF>::COUNT * sizeof(double);  // (trail: the whole line of every field, and the sweep's coefficients)
     if (const char* pad = getenv("SDC_DBG_LDS_PAD")) ldsz += (size_t)atol(pad);   // (experiments: fewer workgroups per CU)
-    // (lines: the bound the kernel checks; the trail launch may use more threads than its transforms have)
-    const dim3 grid((unsigned)((launch_lines + LPB - 1) / LPB)), block((V && a.ns > 0) ? trail_threads<N, NF>() : P * LPB * NF);
+    const dim3 grid((unsigned)((launch_lines + LPB - 1) / LPB)), block(P * LPB * NF);
     const int expl = a.lamE ? 1 : (a.SP ? 2 : 0);
 #define ZL(M_, E_) hipLaunchKernelGGL((k_spec_z<N, NF, M_, E_>), grid, block, ldsz, c->stream, a, (unsigned)lines)
     if constexpr (V) {  // (iterate recomputed from S0: real symbol, no explicit part - sdc_sweep sees to that)
         (void)expl;
         if constexpr (LPB == 1 && SDC_SPECZ_PAIRS) {
             // real symmetric symbol: the modes kz and N - kz of a line share their node multipliers
-            if (a.real_sym && a.ns > 0) ZL(6, 0);
+            if (a.real_sym && a.ns > 0) {
+                if constexpr (N / 2 <= trail_threads<N, NF>()) launch_trail_z<N, NF>(c, a, lines);
+                else fail(c, SDC_ERR_STATE, "no trail launch for lines of this length");   // (sdc_sweep: trails only up to n = 1024)
+            }
             else if (a.real_sym && a.gmode) ZL(5, 0);
             else if (a.real_sym) ZL(4, 0);
             else ZL(3, 0);
@@ -1305,6 +1333,7 @@ int sdc_ctx_destroy(sdc_ctx* c) {
     (void)hipFree(c->UEND);
     (void)hipFree(c->W);
     (void)hipFree(c->W2);
+    (void)hipFree(c->trail_nyq);
     (void)hipFree(c->cgw);
     (void)hipFree(c->bcols);
     (void)hipFree(c->bwts);
@@ -2451,7 +2480,7 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
                     c->trail_src[0] = c->S0;
                 }
             } else if (go && c->spec_valid && c->spec_virtual > 0 && (c->spec_virtual < c->virt_max || table) &&
-                       (c->trail_ns > 0) == trail && (!trail || c->spec_virtual < MAXVSWEEPS) &&
+                       (c->trail_ns > 0) == trail && (!trail || (c->spec_virtual < MAXVSWEEPS && c->trail_ns <= TRAIL_S)) &&
                        memcmp(&now, &c->vcoef, sizeof now) == 0) {
                 a.replay = c->spec_virtual;
                 a.spread = 1;
@@ -2478,6 +2507,9 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
                     a.ns = c->trail_ns;
                     a.nsw = c->spec_virtual;
                     for (int i = 0; i < c->trail_ns; ++i) a.src[i] = c->trail_src[i];
+                    // (the launch fetches TRAIL_S start values whatever their number - a fixed number of loads in flight lets
+                    // it wait for exactly the ones it needs; the entries beyond the trail repeat the last one: cache hits)
+                    for (int i = c->trail_ns; i < MAXTRAIL; ++i) a.src[i] = c->trail_src[c->trail_ns - 1];
                     memcpy(a.vsrc, c->vsrc, sizeof a.vsrc);
                     for (int k = 0; k < a.nsw; ++k) a.scnt[a.vsrc[k]]++;
                     for (int i = 0; i < c->trail_ns; ++i) a.scnt_packed |= (unsigned long long)(a.scnt[i] & 255) << (8 * i);
@@ -3349,7 +3381,9 @@ int sdc_advance(sdc_ctx* c) {
 
 int sdc_set_timeslice_options(sdc_ctx* c, int trail_sources, int defer_last_pass, int split_send) {
     if (!c || trail_sources < 0) return fail(c, SDC_ERR_PARAM, "trail: a number of start values >= 0");
-    if (trail_sources > TRAIL_S) trail_sources = TRAIL_S;   // (what the recomputing launch holds in registers)
+    // (the recomputing launch holds TRAIL_S start values in registers; one more may be on the trail: the one received after the
+    // last sweep of a step, which only the residual against it sees - as a difference of two start values)
+    if (trail_sources > TRAIL_S + 1) trail_sources = TRAIL_S + 1;
     FLUSH_X(c);
     if (trail_sources < c->trail_max) STORE_SPECTRA(c, false);
     c->trail_max = trail_sources;
