@@ -78,10 +78,11 @@ struct sdc_ctx {
     hipStream_t stream = nullptr;
     double *U = nullptr, *F = nullptr, *TAU = nullptr, *UEND = nullptr, *profile = nullptr;
     // The node fields live in blocks of their own that are allocated when something first touches them in real space: U0 = u[0]
-    // (always there), Un = U[1..M], F = F[0..M][ncomp], Sn = the node spectra S[0..M-2] (the last node's has its own buffer).
-    // The sweeps that stay in Fourier space never touch Un, F, Sn - 128 GB at 1024^3 that are simply never allocated.  `U` is
-    // the base the node index counts from: U + m N = U[m] for m >= 1 (Un - N); u[0] is reached through U0 ONLY.
-    double *U0 = nullptr, *Un = nullptr;
+    // (always there), Un = U[1..M], F0 = f[0][ncomp], Fn = f[1..M][ncomp], Sn = the node spectra S[0..M-2] (the last node's has
+    // its own buffer).  The sweeps that stay in Fourier space never touch Un, Fn, Sn - 120 GB at 1024^3 that are simply never
+    // allocated.  `U` / `F` are the bases the node index counts from: U + m N = U[m], F + (m ncomp + comp) N = f[m].comp for
+    // m >= 1 (Un - N, Fn - ncomp N); u[0] and f[0] are reached through U0 / F0 ONLY.
+    double *U0 = nullptr, *Un = nullptr, *F0 = nullptr, *Fn = nullptr;
     cd* Sn = nullptr;
     size_t lazy_min_bytes = (size_t)64 << 20;   // contexts with smaller fields allocate everything at once (SDC_LAZY_MIN_BYTES)
     cd* W = nullptr;
@@ -268,16 +269,19 @@ static int lazy_block(sdc_ctx* c, void** dst, size_t bytes) {
     c->bytes += bytes;
     return SDC_OK;
 }
-// F (all of it: f[0] included) is about to be read or written
+// f[0] is about to be read or written (a block of its own: a run that stays in Fourier space touches f(u0), never f[1..M])
 static inline int need_f0(sdc_ctx* c) {
-    return c->F ? SDC_OK : lazy_block(c, (void**)&c->F, c->N * sizeof(double) * (size_t)(c->M + 1) * c->ncomp);
+    return c->F0 ? SDC_OK : lazy_block(c, (void**)&c->F0, c->N * sizeof(double) * (size_t)c->ncomp);
 }
-// U[1..M] and F are about to be read or written in real space
+// U[1..M] and F (all of it) are about to be read or written in real space
 static inline int need_nodes(sdc_ctx* c) {
-    if (c->Un && c->F) return SDC_OK;
+    if (c->Un && c->Fn && c->F0) return SDC_OK;
     int rc = lazy_block(c, (void**)&c->Un, c->N * sizeof(double) * (size_t)c->M);
     if (rc != SDC_OK) return rc;
     c->U = c->Un - c->N;   // (node index base: U + m N for m >= 1)
+    rc = lazy_block(c, (void**)&c->Fn, c->N * sizeof(double) * (size_t)c->M * c->ncomp);
+    if (rc != SDC_OK) return rc;
+    c->F = c->Fn - (size_t)c->ncomp * c->N;   // (node index base: F + (m ncomp + comp) N for m >= 1; f[0] lives in F0)
     return need_f0(c);
 }
 // the node spectra S[0..M-2] (an iterate is stored in Fourier space)

@@ -112,8 +112,8 @@ static double* slot_ptr(sdc_ctx* c, int slot, int m, int comp) {
     switch (slot) {
         case SDC_SLOT_U: return m == 0 ? c->U0 : ((m >= 1 && m <= c->M) ? c->U + (size_t)m * c->N : nullptr);
         case SDC_SLOT_F:
-            return (m >= 0 && m <= c->M && comp >= 0 && comp < c->ncomp) ? c->F + ((size_t)m * c->ncomp + comp) * c->N
-                                                                         : nullptr;
+            if (m < 0 || m > c->M || comp < 0 || comp >= c->ncomp) return nullptr;
+            return m == 0 ? c->F0 + (size_t)comp * c->N : c->F + ((size_t)m * c->ncomp + comp) * c->N;
         case SDC_SLOT_TAU: return (m >= 0 && m < c->M) ? c->TAU + (size_t)m * c->N : nullptr;
         case SDC_SLOT_UEND: return c->UEND;
         default: return nullptr;
@@ -1326,7 +1326,8 @@ int sdc_ctx_destroy(sdc_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->U0);
     (void)hipFree(c->Un);
-    (void)hipFree(c->F);
+    (void)hipFree(c->Fn);
+    (void)hipFree(c->F0);
     (void)hipFree(c->Sn);
     for (cd* b : c->spool_owned) (void)hipFree(b);
     (void)hipFree(c->TAU);
@@ -1599,7 +1600,7 @@ static int launch_spread(sdc_ctx* c, int guess, double fill_u, double fill_f, bo
     NEED_NODES(c);
     U0R(c, u0p);
     a.u0 = u0p;
-    a.f0 = c->F;
+    a.f0 = c->F0;
     a.profile = c->profile;
     if (c->odd_n && c->profile && c->expl_kind == SDC_EXPL_FORCING) {
         // compact interior fields (sdc_set_odd_interior): the fill needs the profile in THEIR layout - the interior of the
@@ -1639,7 +1640,7 @@ static int materialize(sdc_ctx* c, bool need_u, bool need_f) {
         if (c->f0_pending) {  // the copies are copies of F[0]
             U0R(c, u0p);
             c->f0_pending = false;
-            int rc0 = sdc_eval_f(c, u0p, c->gvals[0], c->F, c->ncomp == 2 ? c->F + c->N : nullptr);
+            int rc0 = sdc_eval_f(c, u0p, c->gvals[0], c->F0, c->ncomp == 2 ? c->F0 + c->N : nullptr);
             if (rc0 != SDC_OK) return rc0;
         }
         c->spread_pending = false;
@@ -1675,7 +1676,7 @@ int sdc_materialize(sdc_ctx* c, int slot, int m) {
             int rcf = need_f0(c);
             if (rcf != SDC_OK) return rcf;
             c->f0_pending = false;
-            return sdc_eval_f(c, c->U0, c->gvals[0], c->F, c->ncomp == 2 ? c->F + c->N : nullptr);
+            return sdc_eval_f(c, c->U0, c->gvals[0], c->F0, c->ncomp == 2 ? c->F0 + c->N : nullptr);
         }
         return SDC_OK;
     }
@@ -1687,13 +1688,13 @@ int sdc_materialize(sdc_ctx* c, int slot, int m) {
         if (!c->f0_pending) return SDC_OK;
         U0R(c, u0p);
         c->f0_pending = false;
-        return sdc_eval_f(c, u0p, c->gvals[0], c->F, c->ncomp == 2 ? c->F + c->N : nullptr);
+        return sdc_eval_f(c, u0p, c->gvals[0], c->F0, c->ncomp == 2 ? c->F0 + c->N : nullptr);
     }
     NEED_NODES(c);
     if (slot < 0) ENSURE_U0(c);  // "everything": all of the real-space state is about to be used as it is stored
     if (slot < 0 && c->f0_pending) {
         c->f0_pending = false;
-        int rc0 = sdc_eval_f(c, c->U0, c->gvals[0], c->F, c->ncomp == 2 ? c->F + c->N : nullptr);
+        int rc0 = sdc_eval_f(c, c->U0, c->gvals[0], c->F0, c->ncomp == 2 ? c->F0 + c->N : nullptr);
         if (rc0 != SDC_OK) return rc0;
     }
     // a node value that is handed out may be overwritten by the holder: F[1..M] = f(U[1..M]) of the CURRENT node
@@ -2080,13 +2081,13 @@ int sdc_predict(sdc_ctx* c, double t, double dt, int guess, double fill_u, doubl
             rc = need_f0(c);
             if (rc != SDC_OK) return rc;
             LaunchTimer lt(c, "vdp_eval");
-            hipLaunchKernelGGL(k_vdp_eval, dim3(grid_for(c->N / 4, 256)), dim3(256), 0, c->stream, u0p, c->F, c->N / 2,
+            hipLaunchKernelGGL(k_vdp_eval, dim3(grid_for(c->N / 4, 256)), dim3(256), 0, c->stream, u0p, c->F0, c->N / 2,
                                c->vdp_mu, c->counters, c->res_dev + 7);
             HIPCHK(c, hipGetLastError());
             f0_max_done = true;
         } else {
             rc = need_f0(c);
-            if (rc == SDC_OK) rc = sdc_eval_f(c, u0p, c->gvals[0], c->F, c->ncomp == 2 ? c->F + c->N : nullptr);
+            if (rc == SDC_OK) rc = sdc_eval_f(c, u0p, c->gvals[0], c->F0, c->ncomp == 2 ? c->F0 + c->N : nullptr);
             if (rc != SDC_OK) return rc;
         }
     }
@@ -2094,8 +2095,8 @@ int sdc_predict(sdc_ctx* c, double t, double dt, int guess, double fill_u, doubl
         // the node copies are not stored until somebody reads them (materialize); only max|f(u0)| is needed now
         if (spread_res && !f0_by_norm && !f0_max_done) {
             LaunchTimer lt(c, "amax");
-            hipLaunchKernelGGL(k_amax_sum, dim3(grid_for(c->N, 256)), dim3(256), 0, c->stream, c->F,
-                               c->ncomp == 2 ? c->F + c->N : nullptr, c->N, c->res_dev + 7);
+            hipLaunchKernelGGL(k_amax_sum, dim3(grid_for(c->N, 256)), dim3(256), 0, c->stream, c->F0,
+                               c->ncomp == 2 ? c->F0 + c->N : nullptr, c->N, c->res_dev + 7);
             HIPCHK(c, hipGetLastError());
         }
         c->spread_pending = true;

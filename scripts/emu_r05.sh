@@ -10,7 +10,7 @@ run() {  # opts copies msg_ms
 import sys, json
 d = json.loads(sys.stdin.read())['spectra_on_the_wire']
 d['kernels_ms'] = {k: v for k, v in d['kernels_ms'].items()}
-print(json.dumps({'options': d['options'], 'message_copies': d['message_copies'], 'message_ms': d['message_ms'], 'ms_per_iteration': round(d['ms_per_iteration'], 2),
+print(json.dumps({'options': d['options'], 'message_copies': d['message_copies'], 'message_ms': d['message_ms'], 'message_ms_measured': d.get('message_ms_measured', 0.0), 'ms_per_iteration': round(d['ms_per_iteration'], 2),
                   'device_GB': round(d['device_bytes'] / 1e9, 1), 'kernels_ms_per_iteration': d['kernels_ms_per_iteration']}))
 " || tail -3 gpurun_out/r05/emu.err
 }

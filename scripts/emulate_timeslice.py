@@ -63,7 +63,7 @@ for keep in [dict(spectral='spectral', overlap='overlap', fields=True, recompute
         e.residual(dt)
     uend = torch.as_tensor(_CAI(e.ptr(L.SLOT_UEND), e.N, e), device='cuda')
     nspec = 2 * (n // 2 + 1) * n * n
-    futures, inbox_free = [], None
+    futures, inbox_free, sleeps = [], None, []
     if keep == 'spectral':
         opts = [int(v) for v in os.environ.get('EMU_OPTS', '5,1,0').split(',')]   # trail sources, deferred last pass, split send
         e.set_timeslice_options(*opts)
@@ -96,7 +96,11 @@ for keep in [dict(spectral='spectral', overlap='overlap', fields=True, recompute
                 if inbox_free is not None:  # (... and behind the engine's last use of the buffer it lands in: sdc_comm's inbox_free)
                     side.wait_event(inbox_free)
                 if msg_ms > 0:              # a message that takes msg_ms to arrive and uses none of this GPU's bandwidth on the way
+                    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    ev[0].record()
                     torch.cuda._sleep(int(msg_ms * sleep_cycles_per_ms))
+                    ev[1].record()
+                    sleeps.append(ev)       # (the spin counts shader clocks, which drop under load: what it took is measured)
                 for _ in range(copies):
                     dst.copy_(src)
             futures.append(e.residual_post(dt))   # IT_FINE: queued; its last pass waits for the receive (defer_last_pass)
@@ -137,7 +141,8 @@ for keep in [dict(spectral='spectral', overlap='overlap', fields=True, recompute
         check = float(torch.max(torch.abs(inbox - uend)))       # the last message is the last end value
     out[{'spectral': 'spectra_on_the_wire', 'overlap': 'overlapped_message', True: 'kept_residual_fields',
          False: 'recomputed_residual'}[keep]] = {
-        'ms_per_iteration': 1e3 * el, 'message_copies': copies, 'message_ms': msg_ms, 'options': os.environ.get('EMU_OPTS', '5,1,0') if keep == 'spectral' else None,
+        'ms_per_iteration': 1e3 * el, 'message_copies': copies, 'message_ms': msg_ms,
+        'message_ms_measured': round(sum(a.elapsed_time(b) for a, b in sleeps[-iters:]) / max(1, len(sleeps[-iters:])), 2) if sleeps else 0.0, 'options': os.environ.get('EMU_OPTS', '5,1,0') if keep == 'spectral' else None,
         'device_bytes': dev_bytes, 'inbox_minus_uend': check, 'kernels_ms': {k: round(v[0] / v[1], 2) for k, v in prof.items() if v[1]},
         'kernels_ms_per_iteration': {k: round(v[0] / iters, 2) for k, v in prof.items() if v[1]}}
     e.close()
