@@ -237,10 +237,11 @@ def run_workload(args, world, rank, use_dist, with_stream_reference=True):
         # spectra are mapped only when something touches them in real space - the eager-fields sub-record does: ~31 fields); a
         # time slice adds the start values of its trail, the spectrum inbox, two spare spectra, a second set of M work spectra
         # (the put-off passes of one iterate run behind the next sweep's first launches) and the relay staging: 215 GB = 25
-        # fields measured by scripts/emulate_timeslice.py, 28 asked for.  A GPU that cannot hold it ends the job with an error:
-        # the grid is never changed behind the caller's back, so that the lines of --gpus 1 and --gpus N are always about the
-        # same workload
-        need = ((31.0 if args.eager_fields else 17.0) if world == 1 else 28.0) * 8.0 * n**3
+        # fields measured by scripts/emulate_timeslice.py.  The second set of work spectra is given up when it does not fit
+        # (sdc_sweep: same numbers, less overlap), so 24 fields are asked for.  A GPU that cannot hold that ends the job with an
+        # error: the grid is never changed behind the caller's back, so that the lines of --gpus 1 and --gpus N are always
+        # about the same workload
+        need = ((31.0 if args.eager_fields else 17.0) if world == 1 else 24.0) * 8.0 * n**3
         free = torch.cuda.mem_get_info()[0]
         if free < need:
             raise MemoryError(f'heat {n}^3 needs {need / 1e9:.0f} GB of HBM on every GPU, {free / 1e9:.0f} GB free on rank {rank} '

@@ -555,14 +555,16 @@ class controller_dist(_ControllerBase):
             if spectra and hasattr(eng, 'set_timeslice_options'):
                 # iterates recomputed from the start values received so far instead of stored, the last inverse pass of a
                 # residual put off until the new start value is there (one pass then yields the norms before and after the
-                # receive) and run behind the next sweep's first launches, the last node's spectrum written first so that
-                # the message leaves 10-17 ms earlier (include/sdcmi.h: sdc_set_timeslice_options).  Measured at 1024^3 per
-                # slice iteration with a 67 ms message: 89.6 ms like this, 105.8 with stored iterates, 120 with every pass
-                # at once (profiles/r05/timeslice_emulation_n1024.json); the engine falls back by itself where a flow
-                # does not apply (small grids, forcing terms, residual fields asked for)
+                # receive) and run behind the next sweep's first launches (include/sdcmi.h: sdc_set_timeslice_options).
+                # Up to four ranks - one or two xGMI links carry the 8 N bytes: 67 ms and more at 1024^3 - the last node's
+                # spectrum is written by a launch of its own first, so that the message leaves 10-17 ms earlier for 7 ms
+                # more device work.  Measured at 1024^3 per slice iteration (profiles/r05/timeslice_emulation_n1024.json):
+                # with a 67 ms message 88.5 ms like this, 98.2 without the split, 103.9 with stored iterates, 117.8 with
+                # every pass at once; with a 33 ms message (8 ranks) 65.8 without the split, 68.3 with it.  The engine
+                # falls back by itself where a flow does not apply (small grids, forcing terms, residual fields asked for)
                 eng.set_timeslice_options(int(os.environ.get('PYSDC_AMD_TRAIL', '5')),
                                           int(os.environ.get('PYSDC_AMD_DEFER_X', '1')),
-                                          os.environ.get('PYSDC_AMD_SPLIT_SEND', '1') != '0')
+                                          os.environ.get('PYSDC_AMD_SPLIT_SEND', '1' if self.size <= 4 else '0') != '0')
             # the end value (its spectrum) is produced early so that it can be sent while the residual is reduced -
             # only in lock-step runs, where every posted message is completed before the next sweep (the sweep
             # overwrites what the message reads), and only with ONE sweep per iteration: with nsweeps > 1 it_fine posts a

@@ -291,10 +291,11 @@ static inline int need_node_spectra(sdc_ctx* c) {
     c->S = c->Sn;
     return rc;
 }
-#define NEED_NODES(c)                      \
-    do {                                   \
-        int rcn_ = need_nodes(c);          \
-        if (rcn_ != SDC_OK) return rcn_;   \
+#define NEED_NODES(c)                                                                                              \
+    do {                                                                                                           \
+        if (!(c)->Un && getenv("SDC_TRACE_LAZY")) fprintf(stderr, "[sdcmi] node fields allocated by %s:%d\n", __func__, __LINE__); \
+        int rcn_ = need_nodes(c);                                                                                  \
+        if (rcn_ != SDC_OK) return rcn_;                                                                           \
     } while (0)
 
 // ---- spare spectra ---------------------------------------------------------------------------------------------------

@@ -1634,7 +1634,8 @@ static int launch_spread(sdc_ctx* c, int guess, double fill_u, double fill_f, bo
 }
 
 // bring deferred real-space state up to date before it is read (or partially overwritten)
-static int materialize(sdc_ctx* c, bool need_u, bool need_f) {
+static int materialize_at(sdc_ctx* c, bool need_u, bool need_f, int line) {
+    if ((need_u || need_f) && !c->Un && getenv("SDC_TRACE_LAZY")) fprintf(stderr, "[sdcmi] materialize called from line %d\n", line);
     if (need_u || need_f) NEED_NODES(c);
     if (c->spread_pending && (need_u || need_f)) {
         if (c->f0_pending) {  // the copies are copies of F[0]
@@ -1660,6 +1661,7 @@ static int materialize(sdc_ctx* c, bool need_u, bool need_f) {
     return SDC_OK;
 }
 
+#define materialize(c, u, f) materialize_at(c, u, f, __LINE__)   // (SDC_TRACE_LAZY: who made the node fields real)
 int sdc_materialize(sdc_ctx* c, int slot, int m) {
     if (!c) return SDC_ERR_PARAM;
     if (slot == SDC_SLOT_UEND) return materialize_uend(c);  // (readers of the end value: views, sends)
@@ -1728,7 +1730,10 @@ void* sdc_slot_ptr(sdc_ctx* c, int slot, int m, int comp) {
     if (!c) return nullptr;
     // whoever asks for the address of a node field is about to read or write it
     if ((slot == SDC_SLOT_U || slot == SDC_SLOT_F) && sdc_materialize(c, slot, m) != SDC_OK) return nullptr;
-    if (((slot == SDC_SLOT_U && m != 0) || (slot == SDC_SLOT_F && m != 0)) && need_nodes(c) != SDC_OK) return nullptr;
+    if ((slot == SDC_SLOT_U && m != 0) || (slot == SDC_SLOT_F && m != 0)) {
+        if (!c->Un && getenv("SDC_TRACE_LAZY")) fprintf(stderr, "[sdcmi] node fields allocated by sdc_slot_ptr(%d, %d)\n", slot, m);
+        if (need_nodes(c) != SDC_OK) return nullptr;
+    }
     if (slot == SDC_SLOT_TAU && ensure_tau(c) != SDC_OK) return nullptr;
     if (slot == SDC_SLOT_UEND) {
         if (materialize_uend(c) != SDC_OK) return nullptr;
@@ -1813,8 +1818,10 @@ int sdc_set_unlocked(sdc_ctx* c, int unlocked) {
 int sdc_set_spectral_reuse(sdc_ctx* c, int on) {
     if (!c) return SDC_ERR_PARAM;
     MATERIALIZE_UEND(c);                    // ... and of a put-off end value
-    int rcm = materialize(c, true, false);  // the cache may be the only holder of U[1..M]
-    if (rcm != SDC_OK) return rcm;
+    if (c->spread_pending || c->u_pending) {   // the cache may be the only holder of U[1..M]
+        int rcm = materialize(c, true, false);
+        if (rcm != SDC_OK) return rcm;
+    }
     c->reuse = on != 0;
     c->spec_valid = c->spec0_valid = c->spec_spread = false;
     return SDC_OK;
@@ -2569,13 +2576,25 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
         // numbers): this sweep's z / y launches go FIRST - into the other set of work spectra, with the other bank of norm
         // slots - so that the last node's spectrum is final, and on the wire, one launch after the start value arrived; the
         // passes that were put off follow and run while the message travels.  Anything else: they run now.
-        const bool pipelined = c->pipeline_x && c->xp.pending && norms_only && c->wire_spectral && c->early_uend && c->defer_x &&
-                               SDC_FUSE_SPECZ && c->n >= 64 && c->n <= 1024 && is_pow2(c->n) && M <= 5;
+        bool pipelined = c->pipeline_x && c->xp.pending && norms_only && c->wire_spectral && c->early_uend && c->defer_x &&
+                         SDC_FUSE_SPECZ && c->n >= 64 && c->n <= 1024 && is_pow2(c->n) && M <= 5;
+        if (pipelined && !c->Wb) {
+            // the second set of work spectra, by its first use; a GPU without room for it (43 GB at 1024^3 x 5) keeps the
+            // put-off passes in front of the sweep from now on - same numbers, less overlap
+            if (hipMalloc((void**)&c->Wb, sizeof(cd) * c->Nc * c->M) == hipSuccess) {
+                c->bytes += sizeof(cd) * c->Nc * c->M;
+            } else {
+                (void)hipGetLastError();
+                c->Wb = nullptr;
+                c->pipeline_x = false;
+                pipelined = false;
+            }
+        }
         PendingX put_off;
         if (pipelined) {
             put_off = c->xp;
             c->xp = PendingX();
-            std::swap(c->W, c->Wb);   // (the other set is allocated by its first use: ensure_work)
+            std::swap(c->W, c->Wb);
             c->res_bank_now ^= 1;
             c->res_dev = c->res_bank[c->res_bank_now];
             c->res_devA = c->res_dev + 8;

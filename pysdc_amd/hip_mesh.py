@@ -78,8 +78,8 @@ class hip_mesh:
         if _ptr is not None:  # non-owning view
             self.shape = tuple(_shape)
             self.size = int(np.prod(self.shape))
-            self.ptr = int(_ptr)
-            return
+            self._p = _ptr if callable(_ptr) else int(_ptr)   # (callable: asked for when the memory is first used - a slab
+            return                                             #  block that nobody touches is never allocated)
         if isinstance(init, hip_mesh):
             self.shape = init.shape
             self.size = init.size
@@ -109,6 +109,8 @@ class hip_mesh:
         if self._on_access is not None:
             self._on_access()
         self._lineage = None  # the raw address leaves this object: it may be written behind our back
+        if callable(self._p):
+            self._p = int(self._p())
         return self._p
 
     @ptr.setter

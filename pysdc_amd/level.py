@@ -116,12 +116,13 @@ class SlabList:
             if self._slot in (Lb.SLOT_U, Lb.SLOT_F):  # node fields may be deferred (sdc_materialize)
                 acc = lambda slot=self._slot, m=m: e.materialize(slot, m)  # noqa: E731
             off = 8 * self._L._view_offset()
+            # (addresses are asked for when a view is first USED: U[1..M] and F[1..M] are blocks of their own that the engine
+            # allocates on first touch - a hook that merely fetches L.u[m] must not cost 86 GB at 1024^3)
+            at = lambda comp, slot=self._slot, m=m: e.ptr(slot, m, comp) + off  # noqa: E731
             if self._imex:
-                self._views[m] = hip_imex_mesh.view(e.ptr(self._slot, m, 0) + off, e.ptr(self._slot, m, 1) + off, shape,
-                                                    keep=e, on_write=cb, on_access=acc)
+                self._views[m] = hip_imex_mesh.view(lambda: at(0), lambda: at(1), shape, keep=e, on_write=cb, on_access=acc)
             else:
-                self._views[m] = hip_mesh.view(e.ptr(self._slot, m, 0) + off, shape, keep=e, on_write=cb,
-                                               on_access=acc)
+                self._views[m] = hip_mesh.view(lambda: at(0), shape, keep=e, on_write=cb, on_access=acc)
         return self._views[m]
 
     def __getitem__(self, m):
