@@ -9,7 +9,15 @@
  *
  * State of one level lives on the device as slabs (f64, C order, spatial index fastest):
  *   U[(M+1)][N]  F[(M+1)][ncomp][N]  TAU[M][N]  UEND[N]        N = n^ndim, M = collocation nodes
- * replacing the reference's Python lists u[], f[], tau[] (pySDC/core/level.py:96-106).
+ * replacing the reference's Python lists u[], f[], tau[] (pySDC/core/level.py:96-106).  u[0] and f[0] always exist; the
+ * blocks U[1..M] and F[1..M] are allocated the first time something reads or writes a node value in real space (contexts
+ * whose fields are smaller than 64 MB allocate everything at once): sdc_slot_ptr() of such a slot makes them real, pointers
+ * handed out earlier stay valid.
+ *
+ * Environment switches the library itself reads: SDC_LAZY_MIN_BYTES (field size from which node blocks are allocated on first
+ * touch; default 64 MB), SDC_TRACE_LAZY=1 (stderr: which entry point made them real), SDC_NO_TRAIL_DZ=1 (time slices: the
+ * difference of two start values always through a launch of its own - A/B runs), SDC_PIPE_CHUNK (doubles per slot of the
+ * host-memory pipe of two-rank runs), SDC_COMM_TIMEOUT (seconds a receive waits).
  */
 #ifndef SDCMI_H
 #define SDCMI_H

@@ -559,8 +559,8 @@ class controller_dist(_ControllerBase):
                 # Up to four ranks - one or two xGMI links carry the 8 N bytes: 67 ms and more at 1024^3 - the last node's
                 # spectrum is written by a launch of its own first, so that the message leaves 10-17 ms earlier for 7 ms
                 # more device work.  Measured at 1024^3 per slice iteration (profiles/r05/timeslice_emulation_n1024.json):
-                # with a 67 ms message 88.5 ms like this, 98.2 without the split, 103.9 with stored iterates, 117.8 with
-                # every pass at once; with a 33 ms message (8 ranks) 65.8 without the split, 68.3 with it.  The engine
+                # with a 67 ms message 89.5 ms like this, 100.2 without the split, 104.2 with stored iterates, 118.3 with
+                # every pass at once; with a 33 ms message (8 ranks) 65.3 without the split, 66.7 with it.  The engine
                 # falls back by itself where a flow does not apply (small grids, forcing terms, residual fields asked for)
                 eng.set_timeslice_options(int(os.environ.get('PYSDC_AMD_TRAIL', '5')),
                                           int(os.environ.get('PYSDC_AMD_DEFER_X', '1')),

@@ -55,6 +55,7 @@ struct PendingX {
     int nf = 0;
     const cd *d_old = nullptr, *d_new = nullptr;
     bool d_old_spare = false;          // d_old was kept alive for this pass only: a spare buffer again afterwards
+    cd* dz = nullptr;                  // d_new - d_old after its z pass already (the next sweep's trail launch made it on the way)
     cd* work = nullptr;                // the work spectra that hold the residual lines
     unsigned long long *norms = nullptr, *normsA = nullptr;   // slots of the norms after / before the receive
     std::vector<PendingTicket> tickets;
@@ -98,6 +99,7 @@ struct sdc_ctx {
     // hold the residual of the current iterate after its z / y inverse passes (the x pass only reduced a norm), which lets
     // a new start value update the node norms by ONE more field through the pipeline instead of M.
     cd* Sin = nullptr;
+    bool dz_written = false;   // the trail launch of the sweep in progress took the difference line along (SpecArgs::dz)
     cd* trail_nyq = nullptr;   // [lines][M]: the Nyquist mode's residual of every z line (k_trail_nyq -> k_trail_z)
     // spectrum-sized buffers nobody uses right now (sources of a finished trail, difference spectra, ...) and the ones this
     // context allocated one by one (freed with it)

@@ -102,6 +102,24 @@ DEVI void bf3(cd& a0, cd& a1, cd& a2) {
     a1 = cadd(m, d);
     a2 = csub(m, d);
 }
+// 5-point DFT (Winograd-style: two mirrored pairs): with s1 = x1 + x4, s2 = x2 + x3, d1 = x1 - x4, d2 = x2 - x3
+//   X1,4 = x0 + c1 s1 + c2 s2  +- DIR i (S1 d1 + S2 d2),   X2,3 = x0 + c2 s1 + c1 s2  +- DIR i (S2 d1 - S1 d2)
+// c_k = cos(2 pi k/5), S_k = sin(2 pi k/5)
+template <int DIR>
+DEVI void bf5(cd& a0, cd& a1, cd& a2, cd& a3, cd& a4) {
+    constexpr double c1 = 0.30901699437494742410, c2 = -0.80901699437494742410;
+    constexpr double S1 = 0.95105651629515357212, S2 = 0.58778525229247312917;
+    const cd s1 = cadd(a1, a4), s2 = cadd(a2, a3), d1 = csub(a1, a4), d2 = csub(a2, a3);
+    const cd m1 = cd{fma(c1, s1.x, fma(c2, s2.x, a0.x)), fma(c1, s1.y, fma(c2, s2.y, a0.y))};
+    const cd m2 = cd{fma(c2, s1.x, fma(c1, s2.x, a0.x)), fma(c2, s1.y, fma(c1, s2.y, a0.y))};
+    const cd e1 = mul_dir_i<DIR>(cd{fma(S1, d1.x, S2 * d2.x), fma(S1, d1.y, S2 * d2.y)});
+    const cd e2 = mul_dir_i<DIR>(cd{fma(S2, d1.x, -S1 * d2.x), fma(S2, d1.y, -S1 * d2.y)});
+    a0 = cadd(a0, cadd(s1, s2));
+    a1 = cadd(m1, e1);
+    a4 = csub(m1, e1);
+    a2 = cadd(m2, e2);
+    a3 = csub(m2, e2);
+}
 template <int DIR>
 DEVI void bf4(cd& a0, cd& a1, cd& a2, cd& a3) {
     cd t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = mul_dir_i<DIR>(csub(a1, a3));
@@ -120,6 +138,8 @@ DEVI void dft(cd (&x)[R]) {
         bf3<DIR>(x[0], x[1], x[2]);
     } else if constexpr (R == 4) {
         bf4<DIR>(x[0], x[1], x[2], x[3]);
+    } else if constexpr (R == 5) {
+        bf5<DIR>(x[0], x[1], x[2], x[3], x[4]);
     } else if constexpr (R == 8) {
         // 8 = 4 (n1) x 2 (n2): x[2*n1 + n2]
         bf4<DIR>(x[0], x[2], x[4], x[6]);
@@ -168,11 +188,17 @@ DEVI void dft(cd (&x)[R]) {
 #define SDC_FFT_E 16
 #endif
 constexpr bool fft_has3(int N) { return N % 3 == 0; }
-constexpr int fft_elems(int N) { return fft_has3(N) ? (N < 12 ? N : 12) : (N < SDC_FFT_E ? N : SDC_FFT_E); }
-// lengths the line transforms handle: 2^p, and 3 * 2^p from 24 on (the thread counts of the kernels want P = N / 12 = 2^q >= 2)
+constexpr bool fft_has5(int N) { return N % 5 == 0; }
+constexpr int fft_odd(int N) { return fft_has3(N) ? 3 : (fft_has5(N) ? 5 : 1); }   // the ONE odd factor a length may have
+constexpr int fft_elems(int N) {
+    return fft_has3(N) ? (N < 12 ? N : 12) : (fft_has5(N) ? (N < 20 ? N : 20) : (N < SDC_FFT_E ? N : SDC_FFT_E));
+}
+// lengths the line transforms handle: 2^p, 3 * 2^p from 24 on and 5 * 2^p from 40 on (the thread counts of the kernels want
+// P = N / 12 resp. N / 20 = 2^q >= 2)
 constexpr bool fft_length_ok(int N) {
-    int m = N % 3 == 0 ? N / 3 : N;
-    return N >= 2 && (m & (m - 1)) == 0 && (N % 3 != 0 || N >= 24);
+    if (N % 15 == 0) return false;
+    int m = N / fft_odd(N);
+    return N >= 2 && (m & (m - 1)) == 0 && (N % 3 != 0 || N >= 24) && (N % 5 != 0 || N >= 40);
 }
 
 // LDS index maps (in doubles).  The skew (pos >> 4) breaks the power-of-two strides of the stage-1 scatter.
@@ -299,10 +325,11 @@ template <int N, int NS, int DIR, class LAY, bool WAVE, int EE = fft_elems(N)>
 DEVI void fft_stages(cd (&r)[EE], int j, int col, double* lds, const cd* __restrict__ tw) {
     constexpr int REM = N / NS;
     constexpr int RMAX = EE < 16 ? EE : 16;  // a butterfly cannot be wider than the elements a thread holds
-    // lengths with a factor 3 (12 elements per thread): radix 4 while the power-of-two part lasts, a radix 2 if one is left,
-    // the radix 3 last
-    constexpr int REM2 = fft_has3(N) ? REM / 3 : REM;
-    constexpr int R = fft_has3(N) ? (REM2 >= 4 ? 4 : (REM2 == 2 ? 2 : 3)) : (REM >= RMAX ? RMAX : REM);
+    // lengths with a factor 3 or 5 (12 / 20 elements per thread): radix 4 while the power-of-two part lasts, a radix 2 if one
+    // is left, the odd radix last
+    constexpr int ODD = fft_odd(N);
+    constexpr int REM2 = REM / ODD;
+    constexpr int R = ODD > 1 ? (REM2 >= 4 ? 4 : (REM2 == 2 ? 2 : ODD)) : (REM >= RMAX ? RMAX : REM);
     static_assert(EE % R == 0, "elements per thread must hold whole butterflies");
     fft_butterflies<N, R, NS, DIR, EE>(r, j, tw);
     if constexpr (NS * R < N) {

@@ -726,6 +726,10 @@ struct SpecArgs {
     int scnt[MAXTRAIL];   // sweeps that started from src[i] (consecutive: a start value only changes when one is received)
     unsigned long long scnt_packed;   // the same, 8 bits per source: the kernel's loop bounds without a load inside its loops
     double gIrow[MAXM];   // row sums of gI
+    // the trail's z launch can transform one more line per z line on the way: src[ns-1] - src[ns-2], the difference of the
+    // last two start values, which the put-off x pass of the PREVIOUS iterate's residual is waiting for (flush_x) - the
+    // launch has both in registers; dz = where it goes (scaled like the residual lines), or null
+    cd* dz;
 };
 
 // one thread per Fourier mode: gather on the cached transforms + node-coupled solve, S updated in place.
@@ -1585,7 +1589,7 @@ void k_spec_z(SpecArgs a, unsigned nlines) {
 // is fetched and stored: 16.9 - 27.9 ms for 1 - 4 replayed sweeps at 1024^3 x 5, of which 8.1 - 12.8 are memory time.
 // The Nyquist mode of every line (item N/2 + 1 of N/2 + 1: a second round of one lane) is made by a launch of its own
 // (k_trail_nyq) and added to the hand-over buffer from a table.
-template <int NF>
+template <int NF, bool DZ>
 __global__ __launch_bounds__(256) void k_trail_nyq(SpecArgs a, int n, unsigned nlines, cd* __restrict__ nyq) {
     using TC = TrailCoef<NF>;
     __shared__ double cf[TC::COUNT];
@@ -1611,23 +1615,26 @@ __global__ __launch_bounds__(256) void k_trail_nyq(SpecArgs a, int n, unsigned n
     trail_residual<NF>(a, cf, a.lamI[H].x + lxy, slo, shi, rlo, rhi, ulo, uhi);
     if (a.store_last) a.SL[base + H] = ulo;
 #pragma unroll
-    for (int m = 0; m < NF; ++m) nyq[(size_t)line * NF + m] = cscale(rlo[m], a.invN);
+    for (int m = 0; m < NF; ++m) nyq[(size_t)line * (NF + DZ) + m] = cscale(rlo[m], a.invN);
+    if constexpr (DZ) nyq[(size_t)line * (NF + 1) + NF] = cscale(csub(a.src[a.ns - 1][base + H], a.src[a.ns - 2][base + H]), a.invN);
 }
 
-template <int N, int NF>
+template <int N, int NF, bool DZ>
 __global__ __launch_bounds__((trail_threads<N, NF>()), SDC_TRAIL_WAVES)
 void k_trail_z(SpecArgs a, unsigned nlines, const cd* __restrict__ nyq) {
+    constexpr int NL = NF + (DZ ? 1 : 0);   // lines handed to the transforms: the residual of every node [+ the difference line]
     constexpr int E = specz_elems<N, true>(), P = N / E, NTT = trail_threads<N, NF>(), H = N / 2;
     static_assert(specz_lines<N, true>() == 1 && P <= 64 && H <= NTT, "one line per workgroup, one mode pair per thread");
     using LAY = LayContig<N>;
     using TC = TrailCoef<NF>;
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    cd* rbuf = reinterpret_cast<cd*>(lds);           // [NF][N]: the residual lines handed over to the transforms
-    double* cf = lds + 2 * (size_t)NF * N;           // the sweep's coefficients (see TrailCoef)
+    cd* rbuf = reinterpret_cast<cd*>(lds);           // [NL][N]: the residual lines handed over to the transforms
+    double* cf = lds + 2 * (size_t)NL * N;           // the sweep's coefficients (see TrailCoef)
     // the twiddle factors the line transform looks up, in LDS: with one workgroup per CU nobody else's work hides the latency of
     // a table look-up in L2, and the transform has two dependent ones per line (1.5 of 6.7 us per line at 1024^3)
     cd* twl = reinterpret_cast<cd*>(cf + ((TC::COUNT + 1) & ~1));
-    static_assert(LAY::doubles(NF) <= 2 * NF * N, "the exchange planes of the transform alias the hand-over buffer");
+    static_assert(LAY::doubles(NL) <= 2 * NL * N && NL * (N / specz_elems<N, true>()) <= trail_threads<N, NF>(),
+                  "the exchange planes of the transform alias the hand-over buffer; one wave per line");
     for (int i = threadIdx.x; i < N / 2; i += NTT) twl[i] = a.tw[i];
     if (threadIdx.x < NF * NF) {
         cf[TC::GI + threadIdx.x] = a.gI[threadIdx.x / NF][threadIdx.x % NF];
@@ -1655,7 +1662,7 @@ void k_trail_z(SpecArgs a, unsigned nlines, const cd* __restrict__ nyq) {
     auto iv_of = [=](unsigned ln) { const unsigned lc = ln < last ? ln : last; return d3 ? lc % N : 0u; };
     auto nyq_of = [=](unsigned ln) {
         const unsigned lc = ln < last ? ln : last;
-        return nyq[(size_t)lc * NF + ((int)threadIdx.x < NF ? threadIdx.x : 0)];
+        return nyq[(size_t)lc * NL + ((int)threadIdx.x < NL ? threadIdx.x : 0)];
     };
     double lu = a.lamI[iu_of(line)].x, lv = a.lamI[iv_of(line)].x;
     cd nq = nyq_of(line);
@@ -1684,17 +1691,32 @@ void k_trail_z(SpecArgs a, unsigned nlines, const cd* __restrict__ nyq) {
                 if (paired) rbuf[m * N + N - p_] = cscale(rhi[m], a.invN);
             }
         }
-        if ((int)threadIdx.x < NF) rbuf[threadIdx.x * N + H] = nq_cur;
+        if constexpr (DZ) {   // the difference of the last two start values: one more line
+            cd dl = slo[cur][0], dh = shi[cur][0], el = slo[cur][0], eh = shi[cur][0];
+#pragma unroll
+            for (int q = 1; q < TRAIL_S; ++q) {   // (selects on wave-uniform conditions: the arrays stay in registers)
+                const bool hn = a.ns - 1 == q, ho = a.ns - 2 == q;
+                dl = cd{hn ? slo[cur][q].x : dl.x, hn ? slo[cur][q].y : dl.y};
+                dh = cd{hn ? shi[cur][q].x : dh.x, hn ? shi[cur][q].y : dh.y};
+                el = cd{ho ? slo[cur][q].x : el.x, ho ? slo[cur][q].y : el.y};
+                eh = cd{ho ? shi[cur][q].x : eh.x, ho ? shi[cur][q].y : eh.y};
+            }
+            if (mine) {
+                rbuf[NF * N + p_] = cscale(csub(dl, el), a.invN);
+                if (paired) rbuf[NF * N + N - p_] = cscale(csub(dh, eh), a.invN);
+            }
+        }
+        if ((int)threadIdx.x < NL) rbuf[threadIdx.x * N + H] = nq_cur;
         __syncthreads();
         cd r[E];
-        if (c < NF) {
+        if (c < NL) {
 #pragma unroll
             for (int i = 0; i < E; ++i) r[i] = rbuf[c * N + j + i * P];
         }
         __syncthreads();   // (every transforming wave has read its column: the exchange planes may overwrite the buffer)
-        if (c < NF) {      // (the line transforms synchronise inside their own waves, P <= 64: the other waves go on)
+        if (c < NL) {      // (the line transforms synchronise inside their own waves, P <= 64: the other waves go on)
             fft_line<N, +1, LAY, true, E>(r, j, c, lds, twl);
-            cd* __restrict__ dst = a.W + c * a.fstride + base;
+            cd* __restrict__ dst = (DZ && c == NF) ? a.dz + base : a.W + c * a.fstride + base;
 #pragma unroll
             for (int i = 0; i < E; ++i) dst[j + i * P] = r[i];
         }

@@ -38,9 +38,11 @@
 // host side
 // ------------------------------------------------------------------------------------------------------
 static int ensure_work(sdc_ctx* c);
-// the FFT kernels transform lines of length 2^p <= 1024 (2048 in 1-D and 2-D) and 3 * 2^p from 24 to 768 (fft.hpp)
+// the FFT kernels transform lines of length 2^p <= 1024 (2048 in 1-D and 2-D), 3 * 2^p from 24 to 768 and 5 * 2^p from 40 to 640
+// (fft.hpp)
 static inline bool fourier_ok(const sdc_ctx* c) {
     if (c->n % 3 == 0) return fft_length_ok(c->n) && c->n <= 768;
+    if (c->n % 5 == 0) return fft_length_ok(c->n) && c->n <= 640;
     return is_pow2(c->n) && (c->n <= 1024 || (c->n == 2048 && c->ndim <= 2));
 }
 static inline int grid_for(size_t work, int block) {
@@ -497,7 +499,7 @@ static int inverse_tail_x_only(sdc_ctx* c, int nf, cd* work, const FieldPtrs& p,
 // (dscr), then ONE x pass over the nf residual fields in `work` that reduces max |r| into normsA and max |r + d| into norms.
 template <int N>
 static int joint_norms_n(sdc_ctx* c, int nf, cd* work, const cd* d_new, const cd* d_old, cd* dbuf, cd* dscr,
-                         unsigned long long* norms, unsigned long long* normsA) {
+                         unsigned long long* norms, unsigned long long* normsA, bool z_done = false) {
     constexpr int E = fft_elems(N), P = N / E, T = N >= 2048 ? 4 : (N == 1024 ? SDC_T1024 : 8), LPB = z_lines_per_block<N>();
     const size_t lds_str = (size_t)LayStrided<N, T>::doubles(T) * sizeof(double);
     const size_t lds_x = (SDC_XWAVE && P == 64) ? (size_t)LayCols<N>::doubles(T) * sizeof(double) : lds_str;
@@ -508,7 +510,7 @@ static int joint_norms_n(sdc_ctx* c, int nf, cd* work, const cd* d_new, const cd
     const ReactEpi none{nullptr, 0, 0, 0, 0.0, 0.0, {}};
     FieldPtrs p;
     memset(&p, 0, sizeof p);
-    {
+    if (!z_done) {   // (done: dbuf holds the difference after its z pass - a trail launch transformed it on the way)
         LaunchTimer lt(c, pname("fft_z_diff", 1));
         const size_t ldsz = (size_t)LayContig<N>::doubles(LPB) * sizeof(double);
         hipLaunchKernelGGL((k_fftz_plain<N, +1>), dim3((unsigned)((lines + LPB - 1) / LPB)), dim3(P * LPB), ldsz, c->stream,
@@ -604,17 +606,30 @@ template <int N, int NF>
 static void launch_trail_z(sdc_ctx* c, SpecArgs& a, size_t lines) {
     if (!c->trail_nyq) {
         const size_t all = c->ndim == 1 ? 1 : (size_t)(c->n / 2 + 1) * (c->ndim == 3 ? c->n : 1);
-        if (hipMalloc((void**)&c->trail_nyq, sizeof(cd) * all * c->M) != hipSuccess) {
+        if (hipMalloc((void**)&c->trail_nyq, sizeof(cd) * all * (c->M + 1)) != hipSuccess) {
             c->trail_nyq = nullptr;
             fail(c, SDC_ERR_HIP, "hipMalloc of the trail's Nyquist table");
             return;
         }
-        c->bytes += sizeof(cd) * all * c->M;
+        c->bytes += sizeof(cd) * all * (c->M + 1);
     }
-    hipLaunchKernelGGL((k_trail_nyq<NF>), dim3((unsigned)((lines + 255) / 256)), dim3(256), 0, c->stream, a, N, (unsigned)lines, c->trail_nyq);
-    const size_t ldsz = ((size_t)2 * NF * N + ((TrailCoef<NF>::COUNT + 1) & ~1) + N) * sizeof(double);   // hand-over lines, coefficients, N / 2 twiddles
     const unsigned wgs = (unsigned)std::min<size_t>(lines, (size_t)device_cus());
-    hipLaunchKernelGGL((k_trail_z<N, NF>), dim3(wgs), dim3(trail_threads<N, NF>()), ldsz, c->stream, a, (unsigned)lines, (const cd*)c->trail_nyq);
+    // (hand-over lines, coefficients, N / 2 twiddles)
+    constexpr size_t lds_tail = (((TrailCoef<NF>::COUNT + 1) & ~1) + N) * sizeof(double);
+    constexpr bool can_dz = (NF + 1) * (N / specz_elems<N, true>()) <= trail_threads<N, NF>() &&
+                            (size_t)2 * (NF + 1) * N * sizeof(double) + lds_tail <= (size_t)160 * 1024;
+    if constexpr (can_dz) {
+        if (a.dz && a.ns >= 2) {   // ... and the difference of the last two start values as one more line (SpecArgs::dz)
+            hipLaunchKernelGGL((k_trail_nyq<NF, true>), dim3((unsigned)((lines + 255) / 256)), dim3(256), 0, c->stream, a, N, (unsigned)lines, c->trail_nyq);
+            hipLaunchKernelGGL((k_trail_z<N, NF, true>), dim3(wgs), dim3(trail_threads<N, NF>()), (size_t)2 * (NF + 1) * N * sizeof(double) + lds_tail,
+                               c->stream, a, (unsigned)lines, (const cd*)c->trail_nyq);
+            c->dz_written = true;
+            return;
+        }
+    }
+    hipLaunchKernelGGL((k_trail_nyq<NF, false>), dim3((unsigned)((lines + 255) / 256)), dim3(256), 0, c->stream, a, N, (unsigned)lines, c->trail_nyq);
+    hipLaunchKernelGGL((k_trail_z<N, NF, false>), dim3(wgs), dim3(trail_threads<N, NF>()), (size_t)2 * NF * N * sizeof(double) + lds_tail, c->stream, a,
+                       (unsigned)lines, (const cd*)c->trail_nyq);
 }
 
 template <int N, int NF, bool V>
@@ -623,7 +638,6 @@ static void launch_spec_z_cfg(sdc_ctx* c, SpecArgs& a, size_t lines, int mode, s
     constexpr int SPAN = LPB * N, CH = SPAN > SDC_SPECZ_CH ? SDC_SPECZ_CH : SPAN;
     size_t ldsz = (size_t)LayContig<N>::doubles(NF * LPB) * sizeof(double);
     if ((size_t)NF * CH * sizeof(cd) > ldsz) ldsz = (size_t)NF * CH * sizeof(cd);
-    if (const char* pad = getenv("SDC_DBG_LDS_PAD")) ldsz += (size_t)atol(pad);   // (experiments: fewer workgroups per CU)
     const dim3 grid((unsigned)((launch_lines + LPB - 1) / LPB)), block(P * LPB * NF);
     const int expl = a.lamE ? 1 : (a.SP ? 2 : 0);
 #define ZL(M_, E_) hipLaunchKernelGGL((k_spec_z<N, NF, M_, E_>), grid, block, ldsz, c->stream, a, (unsigned)lines)
@@ -744,7 +758,12 @@ static int spec_sweep_n(sdc_ctx* c, int nf, SpecArgs& a, const FieldPtrs& p, uns
         case 192: return CALL(192);                                                                         \
         case 384: return CALL(384);                                                                         \
         case 768: return CALL(768);                                                                         \
-        default: return fail(c, SDC_ERR_UNSUPPORTED, "spectral solve needs n = 2^p <= 2048 or 3 * 2^p in 24 .. 768, got %d", (c)->n); \
+        case 40: return CALL(40);                                                                           \
+        case 80: return CALL(80);                                                                           \
+        case 160: return CALL(160);                                                                         \
+        case 320: return CALL(320);                                                                         \
+        case 640: return CALL(640);                                                                         \
+        default: return fail(c, SDC_ERR_UNSUPPORTED, "spectral solve needs n = 2^p <= 2048, 3 * 2^p in 24 .. 768 or 5 * 2^p in 40 .. 640, got %d", (c)->n); \
     }
 
 static int fwd_transform(sdc_ctx* c, int nf, const FieldPtrs& p, cd* dst, size_t fstride) {
@@ -1014,7 +1033,7 @@ static int fft_pipeline(sdc_ctx* c, int nf, const FieldPtrs& p, ZArgs& z, const 
     if (!c->have_stencil[0]) return fail(c, SDC_ERR_STATE, "implicit operator not set (sdc_set_stencil)");
     if (!fourier_ok(c))
         return fail(c, SDC_ERR_UNSUPPORTED,
-                    "spectral solve needs n = 2^p <= 1024 per dimension (<= 2048 in 1-D / 2-D) or 3 * 2^p in 24 .. 768, got %d", c->n);
+                    "spectral solve needs n = 2^p <= 1024 per dimension (<= 2048 in 1-D / 2-D), 3 * 2^p in 24 .. 768 or 5 * 2^p in 40 .. 640, got %d", c->n);
     {
         int rw = ensure_work(c);
         if (rw != SDC_OK) return rw;
@@ -1037,6 +1056,11 @@ static int fft_pipeline(sdc_ctx* c, int nf, const FieldPtrs& p, ZArgs& z, const 
         case 192: return fft_pipeline_n<192>(c, nf, p, z, rq, lin);
         case 384: return fft_pipeline_n<384>(c, nf, p, z, rq, lin);
         case 768: return fft_pipeline_n<768>(c, nf, p, z, rq, lin);
+        case 40: return fft_pipeline_n<40>(c, nf, p, z, rq, lin);
+        case 80: return fft_pipeline_n<80>(c, nf, p, z, rq, lin);
+        case 160: return fft_pipeline_n<160>(c, nf, p, z, rq, lin);
+        case 320: return fft_pipeline_n<320>(c, nf, p, z, rq, lin);
+        case 640: return fft_pipeline_n<640>(c, nf, p, z, rq, lin);
     }
     return fail(c, SDC_ERR_UNSUPPORTED, "n = %d", c->n);
 }
@@ -1177,14 +1201,16 @@ static int flush_x(sdc_ctx* c) {
     memset(&p0, 0, sizeof p0);
     int rc = SDC_OK;
     if (xp.has_delta) {
-        cd* dbuf = spool_get(c);
+        const bool z_done = xp.dz != nullptr;
+        cd* dbuf = z_done ? xp.dz : spool_get(c);
         cd* dscr = dbuf ? spool_get(c) : nullptr;
+        xp.dz = nullptr;
         if (!dbuf || !dscr) {
             spool_put(c, dbuf);
             return SDC_ERR_NOMEM;
         }
         HIPCHK(c, hipMemsetAsync(xp.normsA, 0, sizeof(unsigned long long) * 8, c->stream));
-#define CALL(NN) joint_norms_n<NN>(c, xp.nf, xp.work, xp.d_new, xp.d_old, dbuf, dscr, xp.norms, xp.normsA)
+#define CALL(NN) joint_norms_n<NN>(c, xp.nf, xp.work, xp.d_new, xp.d_old, dbuf, dscr, xp.norms, xp.normsA, z_done)
         rc = [&]() -> int { N_DISPATCH(c, CALL) }();
 #undef CALL
         spool_put(c, dbuf);   // (stream-ordered: whoever takes them next works behind these launches)
@@ -2591,9 +2617,17 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
             }
         }
         PendingX put_off;
+        c->dz_written = false;
         if (pipelined) {
             put_off = c->xp;
             c->xp = PendingX();
+            // the put-off pass waits for the difference of the last two start values: this sweep's trail launch reads both
+            // anyway and transforms the difference line on the way (no fft_z_diff: 4.5 ms at 1024^3 for 1.5 in the launch)
+            if (put_off.has_delta && !put_off.dz && a.ns >= 2 && c->ndim >= 2 && put_off.d_new == a.src[a.ns - 1] &&
+                put_off.d_old == a.src[a.ns - 2] && !getenv("SDC_NO_TRAIL_DZ")) {
+                a.dz = spool_get(c);
+                if (!a.dz) return SDC_ERR_NOMEM;
+            }
             std::swap(c->W, c->Wb);
             c->res_bank_now ^= 1;
             c->res_dev = c->res_bank[c->res_bank_now];
@@ -2610,6 +2644,10 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
         int rc0 = spec_sweep(c, M, a, p, norms_only ? c->res_dev : nullptr, spec_only);
         if (pipelined) {   // (also when the sweep failed: the tickets of the previous iterate are answered)
             PendingX mine = c->xp;
+            if (a.dz) {
+                if (c->dz_written && rc0 == SDC_OK) put_off.dz = a.dz;
+                else spool_put(c, a.dz);   // (a launch that could not take the line along: the difference goes through fft_z_diff)
+            }
             c->xp = put_off;
             int rcp = flush_x(c);
             c->xp = mine;

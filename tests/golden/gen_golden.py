@@ -11,7 +11,7 @@ own entry points, switched on by environment variables (or call the function aft
 GOLDEN_FFT=1 fft_transfer_main (transfer_fft.npz, runs_ac_fft.npz), GOLDEN_RELAY=1 relay_main (runs_relay.npz),
 GOLDEN_CG=1 cg_main (sweeps_cg.npz), GOLDEN_VDPJ=1 vdp_jacobian_main (vdp_jacobian.npz), GOLDEN_DML=1
 dirichlet_ml_main (transfer_dirichlet.npz, runs_ml_dirichlet.npz), GOLDEN_GUESS=1 guess_main (sweeps_guess.npz), GOLDEN_SKIP=1 skip_main (runs_skip.npz), GOLDEN_RELAY8=1 relay8_main (runs_relay8.npz),
-GOLDEN_BIG3D=1 big3d_main (sweeps_big3d.npz), GOLDEN_CFG5=1 cfg5_main (runs_cfg5.npz), GOLDEN_ML8=1 ml8_main (runs_ml8.npz), GOLDEN_DND=1 dirichlet_nd_main (sweeps_dirichlet_nd.npz, runs_dirichlet_nd.npz), GOLDEN_NSW2=1 nsweeps2_main (runs_nsweeps2.npz), GOLDEN_PIN1024=1 pin1024_main (sweeps_pin1024.npz, 20 minutes), GOLDEN_GMRES=1 gmres_main (sweeps_gmres.npz), GOLDEN_DHO=1 dirichlet_ho_main (sweeps_dirichlet_ho.npz, runs_dirichlet_ho.npz, dirichlet_ho_matrices.npz), GOLDEN_BC=1 boundary_main (boundary_matrices.npz, sweeps_neumann.npz, runs_neumann.npz), GOLDEN_PIN512=1 pin512_main (sweeps_pin512.npz), GOLDEN_R3=1 radix3_main (sweeps_radix3.npz, runs_radix3.npz);
+GOLDEN_BIG3D=1 big3d_main (sweeps_big3d.npz), GOLDEN_CFG5=1 cfg5_main (runs_cfg5.npz), GOLDEN_ML8=1 ml8_main (runs_ml8.npz), GOLDEN_DND=1 dirichlet_nd_main (sweeps_dirichlet_nd.npz, runs_dirichlet_nd.npz), GOLDEN_NSW2=1 nsweeps2_main (runs_nsweeps2.npz), GOLDEN_PIN1024=1 pin1024_main (sweeps_pin1024.npz, 20 minutes), GOLDEN_GMRES=1 gmres_main (sweeps_gmres.npz), GOLDEN_DHO=1 dirichlet_ho_main (sweeps_dirichlet_ho.npz, runs_dirichlet_ho.npz, dirichlet_ho_matrices.npz), GOLDEN_BC=1 boundary_main (boundary_matrices.npz, sweeps_neumann.npz, runs_neumann.npz), GOLDEN_PIN512=1 pin512_main (sweeps_pin512.npz), GOLDEN_R3=1 radix3_main (sweeps_radix3.npz, runs_radix3.npz), GOLDEN_R5=1 radix5_main (sweeps_radix5.npz, runs_radix5.npz);
 GOLDEN_ML=0 skips the multi-level block.
 
 ``qmat`` (third-party, absent here) is replaced by oracle/qmat_shim, which forwards to
@@ -1146,3 +1146,31 @@ def radix3_main():
 
 if __name__ == '__main__' and os.environ.get('GOLDEN_R3', '0') == '1':
     radix3_main()
+
+
+def radix5_main():
+    """the same for grids of 5 * 2^p points (line transforms with a radix-5 stage): 80 and 160 (1-D), 40^2; in 3-D the
+    shortest line the engine's kernels take is 40, and a sweep case at 40^3 is 13 MB of node values - the 3-D grid is pinned
+    by the oracle (tests/test_gpu_edges.py), whose Fourier solve the 1-D / 2-D cases of this file pin at these line lengths: the
+    reference's SuperLU needs minutes per solve at 40^3."""
+    RR = dict(quad_type='RADAU-RIGHT')
+    cases = [sweep_case('r5_heat1d_80_o2_M5_IE', 'heat_unforced', dict(nvars=80, nu=0.1, freq=2, order=2, bc='periodic'),
+                        'generic_implicit', dict(num_nodes=5, QI='IE', **RR), 1e-2, nsweeps=3),
+             sweep_case('r5_heat1d_160_o4_M3_LU', 'heat_unforced', dict(nvars=160, nu=0.1, freq=2, order=4, bc='periodic'),
+                        'generic_implicit', dict(num_nodes=3, QI='LU', **RR), 5e-2, nsweeps=3),
+             sweep_case('r5_heat2d_40_o2_M5_IE', 'heat_unforced', dict(nvars=(40, 40), nu=0.1, freq=2, order=2, bc='periodic'),
+                        'generic_implicit', dict(num_nodes=5, QI='IE', **RR), 1e-2, nsweeps=3),
+             sweep_case('r5_adv1d_80', 'advection', dict(nvars=80, c=1.0, freq=2, order=2, stencil_type='center', bc='periodic'),
+                        'generic_implicit', dict(num_nodes=3, QI='LU', **RR), 1e-2),
+             sweep_case('r5_advdiff2d_40', 'advdiff', dict(nvars=(40, 40), nu=0.02, c=1.0, freq=2, order=2),
+                        'imex_1st_order', dict(num_nodes=3, QI='IE', QE='EE', **RR), 1e-2)]
+    save('sweeps_radix5.npz', cases)
+    runs = [run_case('r5_run_heat2d_40', 'heat_unforced', dict(nvars=(40, 40), nu=0.1, freq=2), 'generic_implicit',
+                     dict(num_nodes=3, QI='IE', **RR), dict(dt=0.02, restol=1e-9), 20, 0.0, 0.06, seed=5),
+            run_case('r5_run_forced1d_80', 'heat_forced', dict(nvars=80, nu=0.1, freq=2), 'imex_1st_order',
+                     dict(num_nodes=3, QI='IE', QE='EE', **RR), dict(dt=0.01, restol=1e-9), 30, 0.0, 0.03)]
+    save('runs_radix5.npz', runs)
+
+
+if __name__ == '__main__' and os.environ.get('GOLDEN_R5', '0') == '1':
+    radix5_main()

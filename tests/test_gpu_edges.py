@@ -176,3 +176,34 @@ def test_vdp_ensembles_of_ragged_size(ntraj):
             assert rel_err(U[:, :, i], np.stack(Lo.u)) < TOL, (k, i)
         assert abs(Lv.status.residual - worst) <= 1e-9 * max(worst, 1e-6)
     assert Lv.prob.work_counters['newton'].niter == sum(P.work_counters['newton'].niter for P, _ in refs)
+
+
+@pytest.mark.parametrize('n', [40, 48])
+def test_3d_grids_with_an_odd_factor_fourier_solve_equals_the_krylov_solve(n):
+    """40^3 (5 * 2^3) and 48^3 (3 * 2^4): the reference's direct solver needs minutes per solve there, so the exact Fourier
+    solve of these 3-D grids - line transforms with a radix-5 / radix-3 stage along all three axes - is checked against the
+    device's own conjugate gradients (the reference's other solver_type, generic_ND_FD.py:238-262; pinned by sweeps_cg.npz),
+    which shares no transform code with it.  The 1-D / 2-D goldens of these line lengths come from the reference itself."""
+    from pysdc_amd.controller import controller_nonMPI
+    from pysdc_amd.problems import heatNd_unforced
+    from pysdc_amd.sweepers import generic_implicit
+
+    ends, kernels = {}, {}
+    for solver in ('direct', 'CG'):
+        desc = dict(problem_class=heatNd_unforced,
+                    problem_params=dict(nvars=(n, n, n), nu=0.1, freq=2, solver_type=solver, lintol=1e-13, liniter=2000),
+                    sweeper_class=generic_implicit, sweeper_params=dict(num_nodes=3, quad_type='RADAU-RIGHT', QI='IE'),
+                    level_params=dict(dt=2e-2, restol=1e-9), step_params=dict(maxiter=20))
+        C = controller_nonMPI(1, dict(logger_level=40), desc)
+        P = C.MS[0].levels[0].prob
+        eng = C.MS[0].levels[0].engine
+        eng.profile_enable(True)
+        u0 = P.u_exact(0.0)
+        u0[:] = u0.get() + 0.05 * np.random.default_rng(11).standard_normal((n, n, n))
+        uend, stats = C.run(u0, 0.0, 4e-2)
+        ends[solver] = uend.get()
+        kernels[solver] = set(k.split('[')[0] for k in eng.profile_read())
+    assert any(k.startswith('spec_') or k.startswith('fft_z') for k in kernels['direct']), kernels['direct']
+    assert not any(k.startswith('cg') for k in kernels['direct']), kernels['direct']
+    assert any(k.startswith('cg') for k in kernels['CG']), kernels['CG']
+    assert rel_err(ends['direct'], ends['CG']) < 1e-9

@@ -29,7 +29,7 @@ def supported(case):
 
 # (sweeps_radix3.npz: the even grids the reference accepts that are not powers of two - 96, 192, 48^2, 24^3 with its direct
 # solver - on the engine's line transforms of length 3 * 2^p)
-SWEEP_FILES = ['sweeps_heat.npz', 'sweeps_imex.npz', 'sweeps_adv.npz', 'sweeps_guess.npz', 'sweeps_pin1024.npz', 'sweeps_radix3.npz']
+SWEEP_FILES = ['sweeps_heat.npz', 'sweeps_imex.npz', 'sweeps_adv.npz', 'sweeps_guess.npz', 'sweeps_pin1024.npz', 'sweeps_radix3.npz', 'sweeps_radix5.npz']
 SWEEP_CASES = [(f, n) for f in SWEEP_FILES for n, c in load_cases(f).items() if supported(c)]
 
 

@@ -32,7 +32,8 @@ RUNS = ([('runs.npz', n) for n in load_cases('runs.npz')] + [('runs_dirichlet.np
         + [('runs_dirichlet_ho.npz', n) for n in load_cases('runs_dirichlet_ho.npz')]
         + [('runs_neumann.npz', n) for n in load_cases('runs_neumann.npz')]
         + [('runs_skip.npz', n) for n in load_cases('runs_skip.npz')]
-        + [('runs_radix3.npz', n) for n in load_cases('runs_radix3.npz')])   # grids of 3 * 2^p points: exact Fourier solve too
+        + [('runs_radix3.npz', n) for n in load_cases('runs_radix3.npz')]    # grids of 3 * 2^p points: exact Fourier solve too
+        + [('runs_radix5.npz', n) for n in load_cases('runs_radix5.npz')])   # ... and of 5 * 2^p points
 
 
 @pytest.mark.parametrize('fname,name', RUNS)

@@ -15,7 +15,8 @@ SWEEP_FILES = ['sweeps_heat.npz', 'sweeps_imex.npz', 'sweeps_adv.npz', 'sweeps_v
 SWEEP_CASES = ([(f, n) for f in SWEEP_FILES for n in load_cases(f)]
                + [('sweeps_pin1024.npz', 'pin_heat1d_1024_M5_IE')]   # (its 2-D companion is stored as subsamples: GPU tests)
                # grids of 3 * 2^p points (the 24^3 cases take the sparse LU minutes: they are the GPU suite's)
-               + [('sweeps_radix3.npz', n) for n in load_cases('sweeps_radix3.npz') if '3d_24' not in n])
+               + [('sweeps_radix3.npz', n) for n in load_cases('sweeps_radix3.npz') if '3d_24' not in n]
+               + [('sweeps_radix5.npz', n) for n in load_cases('sweeps_radix5.npz')])
 
 
 @pytest.mark.parametrize('fname,name', SWEEP_CASES)
@@ -63,6 +64,7 @@ RUN_CASES = ([('runs.npz', n) for n in load_cases('runs.npz')] + [('runs_dirichl
              + [('runs_skip.npz', n) for n in load_cases('runs_skip.npz')]
              + [('runs_nsweeps2.npz', n) for n in load_cases('runs_nsweeps2.npz')] + [('sweeps_pin1024.npz', 'pin_heat1d_1024_run')]
              + [('runs_radix3.npz', n) for n in load_cases('runs_radix3.npz') if '3d_24' not in n]
+             + [('runs_radix5.npz', n) for n in load_cases('runs_radix5.npz')]
              + [('runs_relay8.npz', n) for n in load_cases('runs_relay8.npz') if 'alltodone' not in n])  # (run_sdc has no all_to_done)   # skip_residual_computation (core/sweeper.py:176-179)
 
 
