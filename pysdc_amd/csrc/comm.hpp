@@ -319,7 +319,7 @@ struct ShmWire : Wire {
 // through pinned host memory instead: the sender copies chunks into a ring of `depth` slots in POSIX shared memory (registered
 // with the HIP runtime: DMA at the host link's rate), the receiver copies them out as they arrive; both sides run their loop on
 // a helper thread and a stream of their own, beside the RCCL transfer of the head of the message.  With 45 % of the message on
-// this path both finish in ~75 - 80 ms (PCIe Gen5 x16: ~50 GB/s either way).  One-directional: file /dev/shm/<job>.pipe.<src>.<dst>.
+// this path both finish in ~80 ms (measured on one box: 48 GB/s end to end, scripts/probe_host_pipe.py).  One-directional: file /dev/shm/<job>.pipe.<src>.<dst>.
 struct HostPipe {
     struct Head {
         std::atomic<unsigned long long> posted, consumed;
