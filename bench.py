@@ -54,6 +54,8 @@ def _kernel_bytes(name, n, M, ncomp=1):
         'spec_z_res_spread': (1 + 2 * nf) * spec,           # first sweep after a spread predictor: only S0 is read
         'spec_z_spread': (1 + 2 * nf) * spec,
         # iterate recomputed from the transform of u0 (virtual sweeps): S0 in, the residual's transformed lines out
+        # (a time slice on the trail reads one start value per receive more and may write the difference line: not counted -
+        # the fractions of --gpus N lines are on the low side)
         **{f'spec_z_res_v{r}': (1 + nf) * spec for r in ('0', '1', '2', '3', '4', '5', '6', '7+')},
         **{f'spec_z_v{r}': (1 + nf) * spec for r in ('0', '1', '2', '3', '4', '5', '6', '7+')},   # (the iterate itself out)
         # long runs of sweeps: the real node multipliers of a mode pair (nf doubles per two modes) are read from a table,

@@ -602,17 +602,16 @@ static int device_cus() {
     return cus;
 }
 // the trail's z launch: the Nyquist modes of all lines by a small launch of their own, then one persistent workgroup per CU
+// the table the small launch leaves for the big one: M (+ 1) Nyquist entries per z line (allocated by sdc_sweep, which can fail)
+static int ensure_trail_nyq(sdc_ctx* c) {
+    if (c->trail_nyq) return SDC_OK;
+    const size_t all = c->ndim == 1 ? 1 : (size_t)(c->n / 2 + 1) * (c->ndim == 3 ? c->n : 1);
+    HIPCHK(c, hipMalloc((void**)&c->trail_nyq, sizeof(cd) * all * (c->M + 1)));
+    c->bytes += sizeof(cd) * all * (c->M + 1);
+    return SDC_OK;
+}
 template <int N, int NF>
 static void launch_trail_z(sdc_ctx* c, SpecArgs& a, size_t lines) {
-    if (!c->trail_nyq) {
-        const size_t all = c->ndim == 1 ? 1 : (size_t)(c->n / 2 + 1) * (c->ndim == 3 ? c->n : 1);
-        if (hipMalloc((void**)&c->trail_nyq, sizeof(cd) * all * (c->M + 1)) != hipSuccess) {
-            c->trail_nyq = nullptr;
-            fail(c, SDC_ERR_HIP, "hipMalloc of the trail's Nyquist table");
-            return;
-        }
-        c->bytes += sizeof(cd) * all * (c->M + 1);
-    }
     const unsigned wgs = (unsigned)std::min<size_t>(lines, (size_t)device_cus());
     // (hand-over lines, coefficients, N / 2 twiddles)
     constexpr size_t lds_tail = (((TrailCoef<NF>::COUNT + 1) & ~1) + N) * sizeof(double);
@@ -2538,6 +2537,10 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
                 if (c->trail_ns > 0) {
                     // this sweep starts from the current start value: the last one on the trail
                     c->vsrc[c->spec_virtual - 1] = (unsigned char)(c->trail_ns - 1);
+                    {
+                        int rcq = ensure_trail_nyq(c);
+                        if (rcq != SDC_OK) return rcq;
+                    }
                     a.ns = c->trail_ns;
                     a.nsw = c->spec_virtual;
                     for (int i = 0; i < c->trail_ns; ++i) a.src[i] = c->trail_src[i];
