@@ -95,7 +95,8 @@ FLOWS = [(0, 1, False), (0, 2, False), (5, 1, False), (5, 1, True), (5, 0, False
 
 # (1024^2 x 3 and 512^3 x 3: the trail launch has a wave to spare and takes the difference of the last two start values along as
 # one more line - SpecArgs::dz; 512 x 5 fills its workgroup: the difference goes through a launch of its own)
-@pytest.mark.parametrize('nvars,M', [((512, 512), 5), ((1024, 1024), 3), ((512, 512, 512), 5), ((512, 512, 512), 3)])
+@pytest.mark.parametrize('nvars,M', [((512, 512), 5), ((1024, 1024), 3), ((512, 512, 512), 5), ((512, 512, 512), 3),
+                                     ((512, 512), 1), ((512, 512), 2), ((1024, 1024), 4)])   # (every node count the launches are built for)
 def test_every_data_flow_of_a_time_slice_reproduces_stored_iterates(nvars, M):
     dt = 2e-3 * (512.0 / nvars[0]) ** 2 * 40
     iters = 4 if len(nvars) == 3 else 6
