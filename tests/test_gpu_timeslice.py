@@ -240,3 +240,37 @@ def test_three_ranks_at_512cubed_match_the_serial_emulation(env):
             for key, v in mine.items():
                 want = ref_res[kind][key]
                 assert abs(v - want) <= 1e-6 * abs(want) + 1e-13, (r, kind, key, v, want)
+
+
+def test_a_serial_run_through_the_plug_in_classes_never_makes_the_node_fields_real():
+    """controller -> sweeper -> problem classes, hooks that fetch (not read) level fields: a run that stays in Fourier space holds
+    u[0], f[0], two end-value buffers, the work spectra and the spectra of the start value and of the last node - not U[1..M],
+    F[1..M] or the node spectra (86 instead of 232 GB at 1024^3, M = 5); reading one node value allocates them"""
+    from pysdc_amd.controller import controller_nonMPI
+    from pysdc_amd.hooks import Hooks
+    from pysdc_amd.problems import heatNd_unforced
+    from pysdc_amd.sweepers import generic_implicit
+
+    class Fetch(Hooks):
+        def post_iteration(self, step, level_number):
+            L_ = step.levels[level_number]
+            assert len(L_.u) == 4 and L_.u[2] is not None and L_.f[3] is not None      # handed out, not dereferenced
+
+    n, M = 128, 3
+    os.environ['SDC_LAZY_MIN_BYTES'] = '4096'
+    try:
+        desc = dict(problem_class=heatNd_unforced, problem_params=dict(nvars=(n, n, n), nu=0.1, freq=2),
+                    sweeper_class=generic_implicit, sweeper_params=dict(num_nodes=M, quad_type='RADAU-RIGHT', QI='IE'),
+                    level_params=dict(dt=1e-2, restol=-1), step_params=dict(maxiter=4))
+        C = controller_nonMPI(1, dict(logger_level=40, hook_class=[Fetch]), desc)
+        Lv = C.MS[0].levels[0]
+        uend, _ = C.run(Lv.prob.u_exact(0.0), 0.0, 3e-2)
+        field = 8 * n**3
+        spec = field * (n + 2) / n
+        lean = Lv.engine.device_bytes
+        assert lean <= 4.1 * field + (M + 3) * spec, lean / field
+        assert np.all(np.isfinite(uend.get()))
+        _ = Lv.u[2].get()                      # somebody looks at a node value
+        assert Lv.engine.device_bytes >= lean + 2 * M * field
+    finally:
+        del os.environ['SDC_LAZY_MIN_BYTES']
