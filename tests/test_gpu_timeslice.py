@@ -158,7 +158,8 @@ def test_iterates_that_are_not_stored_leave_the_node_slabs_unmapped():
 
 @pytest.mark.parametrize('env', [{}, {'PYSDC_AMD_TRAIL': '0', 'PYSDC_AMD_SPLIT_SEND': '0'}, {'PYSDC_AMD_TRAIL': '2', 'PYSDC_AMD_DEFER_X': '2'},
                                  {'PYSDC_AMD_TRAIL': '0', 'PYSDC_AMD_SPLIT_SEND': '0', 'PYSDC_AMD_DEFER_X': '0'},
-                                 {'PYSDC_AMD_TRAIL': '5', 'PYSDC_AMD_SPLIT_SEND': '0'}])
+                                 {'PYSDC_AMD_TRAIL': '5', 'PYSDC_AMD_SPLIT_SEND': '0', 'PYSDC_AMD_DEFER_X': '1'},   # (eight ranks' default)
+                                 {'PYSDC_AMD_DEFER_X': '1'}])
 def test_three_ranks_at_512cubed_match_the_serial_emulation(env):
     """controller_dist, three thread ranks on the one GPU over the shared-memory wire, heat 512^3 (the size from which iterates
     are recomputed from mode pairs), six iterations per block (more start values than a trail of two holds), two blocks with
