@@ -503,6 +503,8 @@ def run_workload(args, world, rank, use_dist, with_stream_reference=True):
                        'time_parallel': f'{world} time-slice(s), one per GPU, '
                                         + ('two-level PFASST' if (args.workload == 'allencahn' and world > 1) else
                                            f'multi-step SDC ({"Jacobi" if args.mssdc == "jacobi" else "Gauss-Seidel"})')
+                                        + (f'; slice flow (trail, put-off pass, split send) = {tuple(int(v) for v in ctrl.timeslice_flow)}'
+                                           if getattr(ctrl, 'timeslice_flow', None) else '')
                                         + (f'; wire {args.wire}, mode: {getattr(args, "wire_mode", "default")}'
                                            + (f' (64^3 check vs serial emulation: {args.wire_check:.1e})'
                                               if getattr(args, 'wire_check', None) is not None else '') if world > 1 else '')},

@@ -566,9 +566,10 @@ class controller_dist(_ControllerBase):
                 # the pass may as well run first: no second set of work spectra (172 instead of 215 GB), same cycle (90.8 vs
                 # 89.5 ms with a 67 ms message)
                 few = self.size <= 4
-                eng.set_timeslice_options(int(os.environ.get('PYSDC_AMD_TRAIL', '5')),
-                                          int(os.environ.get('PYSDC_AMD_DEFER_X', '2' if few else '1')),
-                                          os.environ.get('PYSDC_AMD_SPLIT_SEND', '1' if few else '0') != '0')
+                self.timeslice_flow = (int(os.environ.get('PYSDC_AMD_TRAIL', '5')),
+                                       int(os.environ.get('PYSDC_AMD_DEFER_X', '2' if few else '1')),
+                                       os.environ.get('PYSDC_AMD_SPLIT_SEND', '1' if few else '0') != '0')
+                eng.set_timeslice_options(*self.timeslice_flow)
             # the end value (its spectrum) is produced early so that it can be sent while the residual is reduced -
             # only in lock-step runs, where every posted message is completed before the next sweep (the sweep
             # overwrites what the message reads), and only with ONE sweep per iteration: with nsweeps > 1 it_fine posts a
