@@ -506,7 +506,7 @@ def run_workload(args, world, rank, use_dist, with_stream_reference=True):
                                         + (f'; slice flow (trail, put-off pass, split send) = {tuple(int(v) for v in ctrl.timeslice_flow)}'
                                            if getattr(ctrl, 'timeslice_flow', None) else '')
                                         + (f'; wire {args.wire}, mode: {getattr(args, "wire_mode", "default")}'
-                                           + (f' (64^3 check vs serial emulation: {args.wire_check:.1e})'
+                                           + (f' (64^3 and 512^2 checks vs serial emulation: {args.wire_check:.1e})'
                                               if getattr(args, 'wire_check', None) is not None else '') if world > 1 else '')},
             'sdc_iters_per_s': units * sweeps_total / el,
             'niter': niter,
@@ -708,7 +708,7 @@ WIRE_MODES = [   # tried in this order until one reproduces the serial emulation
 
 
 def validate_wire(args, torch, dist, rank, world):
-    """Before the 8.6 GB fields exist: the multi-rank run itself on a 64^3 grid - same controller, same wire, same options
+    """Before the 8.6 GB fields exist: the multi-rank run itself on a 64^3 and a 512^2 grid - same controller, same wire, same options
     (spectra on the wire, two-hop relay, skipped first hand-over) - against controller_nonMPI emulating the ranks in this
     process.  The RCCL wire has carried one rank before this job (no multi-GPU box was reachable during development), so a
     mode that does not reproduce the emulation is dropped for the next, more conservative one; the line says which ran.
@@ -719,18 +719,21 @@ def validate_wire(args, torch, dist, rank, world):
     from pysdc_amd.problems import heatNd_unforced
     from pysdc_amd.sweepers import generic_implicit
 
-    n, M, K, blocks = 64, 5, 3, 2
-    dt = 1e-3 * (512.0 / n) ** 2
-    desc = dict(problem_class=heatNd_unforced, problem_params=dict(nvars=(n, n, n), nu=0.1, freq=2, order=2),
-                sweeper_class=generic_implicit, sweeper_params=dict(num_nodes=M, quad_type='RADAU-RIGHT', QI='IE'),
-                level_params=dict(dt=dt, restol=-1.0, nsweeps=1), step_params=dict(maxiter=K))
+    M, blocks = 5, 2
     cpar = dict(logger_level=40, mssdc_jac=args.mssdc == 'jacobi')
-    serial = controller_nonMPI(world, cpar, desc)
-    L0 = serial.MS[0].levels[0]
-    u0 = L0.prob.u_exact(0.0)
-    ref, _ = serial.run(u0, 0.0, blocks * world * dt)
-    ref = ref.get()
-    del serial
+    # two grids: 64^3 (the bench's dimension; iterates stored) and 512^2 with four sweeps per step - the smallest grid on
+    # which a slice recomputes its iterates from the start values it has received (csrc: trail) and puts the last pass of a
+    # residual off, i.e. the data flow of the 1024^3 run itself, at 2 MB per field
+    checks = []
+    for nvars, K in (((64, 64, 64), 3), ((512, 512), 4)):
+        dt = 1e-3 * (512.0 / nvars[0]) ** 2
+        desc = dict(problem_class=heatNd_unforced, problem_params=dict(nvars=nvars, nu=0.1, freq=2, order=2),
+                    sweeper_class=generic_implicit, sweeper_params=dict(num_nodes=M, quad_type='RADAU-RIGHT', QI='IE'),
+                    level_params=dict(dt=dt, restol=-1.0, nsweeps=1), step_params=dict(maxiter=K))
+        serial = controller_nonMPI(world, cpar, desc)
+        ref, _ = serial.run(serial.MS[0].levels[0].prob.u_exact(0.0), 0.0, blocks * world * dt)
+        checks.append((desc, blocks * world * dt, ref.get()))
+        del serial
     last = None
     # (tests: the first so many modes are treated as if they had not reproduced the emulation, so that every fallback - the
     # environment it sets, its restoration, the agreement between the ranks - runs once before a real fabric ever needs it)
@@ -740,10 +743,12 @@ def validate_wire(args, torch, dist, rank, world):
         os.environ.update(env)
         ok = 0
         try:
-            ctrl = controller_dist(dict(cpar, comm_wire=args.wire), desc)
-            got, _ = ctrl.run(ctrl.S.levels[0].prob.u_exact(0.0), 0.0, blocks * world * dt)
-            err = float(np.max(np.abs(got.get() - ref)) / np.max(np.abs(ref)))
-            ctrl.close() if hasattr(ctrl, 'close') else None
+            err = 0.0
+            for desc, tend, ref in checks:
+                ctrl = controller_dist(dict(cpar, comm_wire=args.wire), desc)
+                got, _ = ctrl.run(ctrl.S.levels[0].prob.u_exact(0.0), 0.0, tend)
+                err = max(err, float(np.max(np.abs(got.get() - ref)) / np.max(np.abs(ref))))
+                ctrl.close() if hasattr(ctrl, 'close') else None
             ok = 1 if err <= 1e-10 else 0
             last = f'{name}: differs from the serial emulation by {err:.2e}'
             if idx_mode < forced:

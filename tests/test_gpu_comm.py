@@ -273,7 +273,7 @@ def test_bench_ranks_on_one_gpu_end_to_end(tmp_path, ranks, n, steps, warmup):
     assert len(pr['seconds']) == ranks and pr['sweeps'] == [4 * steps] * ranks and pr['wire'] == 'shm'
     assert rec['niter'] == 4 and rec['finite']
     # the multi-rank path was checked against the serial emulation on a small grid before the run, in its default mode
-    assert 'mode: default (64^3 check vs serial emulation' in rec['config']['time_parallel'], rec['config']
+    assert 'mode: default (64^3 and 512^2 checks vs serial emulation' in rec['config']['time_parallel'], rec['config']
     # the same time steps by the serial controller emulating the ranks
     dt = 1e-3 * (512.0 / n) ** 2
     desc = dict(problem_class=heatNd_unforced, problem_params=dict(nvars=(n, n, n), nu=0.1, freq=2, order=2),
