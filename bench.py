@@ -344,10 +344,11 @@ def run_workload(args, world, rank, use_dist, with_stream_reference=True):
         del spare
     del u0
     sync()
-    eng.profile_enable(True)
+    events = not getattr(args, 'no_kernel_events', False)
+    eng.profile_enable(events)
     coarser = [Lc.engine for Lc in step.levels[1:] if hasattr(Lc, 'engine')]
     for ec in coarser:
-        ec.profile_enable(True)
+        ec.profile_enable(events)
     t0 = time.perf_counter()
     uend, stats = ctrl.run(uend, block * args.warmup, block * (args.warmup + args.steps))
     sync()
@@ -913,6 +914,9 @@ def main():
                     help='--gpus > 1: skip the small-grid run over the wire that is compared with the serial emulation')
     ap.add_argument('--job-timeout', type=float, default=1500.0,
                     help='--gpus > 1 started without a launcher: seconds after which the parent ends the job with an error')
+    ap.add_argument('--no-kernel-events', action='store_true',
+                    help='no HIP events around the launches of the timed region (no kernel table, no roofline): what the '
+                         'event records themselves cost a launch-bound configuration')
     ap.add_argument('--dump-end-value', default=None,
                     help='rank 0 saves the end value of the timed run to this .npy file (tests)')
     args = ap.parse_args()

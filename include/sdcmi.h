@@ -411,6 +411,19 @@ int sdc_transfer_apply_batch(void* stream, int nfields, int ndim, int n_out, int
  * without the pass that adds it (same bits: x + P d either way). */
 int sdc_transfer_apply_batch_acc(void* stream, int nfields, int ndim, int n_out, int n_in, int width, const int* idx,
                                  const double* w, const double* in, double* out, int accumulate);
+/* ... between NESTED periodic grids that differ by a factor of two per axis (n_out = 2 n_in or n_in = 2 n_out), where the host
+ * has checked that every table entry of output row i lies in the window of that row (coarsening: columns 2i-1, 2i, 2i+1
+ * modulo n_in, width 3 - rorder 2; refinement: columns i/2 - width/2 + 1 .. i/2 + width/2 modulo n_in, even rows a single
+ * entry - TransferMesh.py:49-146 with helpers/transfer_helper.py:153-186, periodic / equidist_nested): the three axes in
+ * ONE launch that streams every input once (coarsening) or stages a coarse tile with its halo in LDS (refinement), the
+ * sums nested and accumulated in the order of the separable passes.  The differences FAS forms around a transfer ride
+ * along (core/base_transfer.py:120-147, :196-205): in_minus != NULL transfers in - in_minus (the coarse-grid correction
+ * u_G - uold_G), out_minus != NULL stores result - out_minus (tau = R(Q_F f_F) - Q_G f_G).  Anything the fused launches
+ * do not cover (1-D / 2-D, other widths, grids that are not a multiple of the tile) takes sdc_transfer_apply_batch_acc's
+ * passes and forms the differences with launches of their own: same results. */
+int sdc_transfer_apply_nested(void* stream, int nfields, int ndim, int n_out, int n_in, int width, const int* idx,
+                              const double* w, const double* in, const double* in_minus, double* out,
+                              const double* out_minus, int accumulate);
 
 /* Fourier prolongation between two periodic grids held by two contexts (the levels' engines):
  * mesh_to_mesh_fft (1-D, transfer_classes/TransferMesh_FFT.py:36-57: rfft, low modes + Nyquist copied, irfft,

@@ -156,6 +156,8 @@ struct sdc_ctx {
     int g_from = 8, g_sweeps = 0;
     SpecCoef vcoef;
     cd *tw = nullptr, *lamI = nullptr, *lamE = nullptr;
+    bool sym_table_real = false;   // a symbol table given by the user (sdc_set_symbol, which = 0) whose imaginary parts are all zero ...
+    double sym_absmax = 0.0;       // ... and the largest |entry| of it (the operator's symbol is the sum over the axes)
     bool sym_real[2] = {false, false};  // the stencil is symmetric: its Fourier symbol is real (imaginary parts stored as 0)
     unsigned long long* red = nullptr;  // reduction slots (device)
     unsigned long long* red_host = nullptr;

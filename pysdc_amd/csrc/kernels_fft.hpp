@@ -18,6 +18,13 @@ struct ReactEpi {
     int field, kind, nu;   // field < 0: every field f of the launch, into outs[f]
     double p0, p1;
     double* outs[MAXM];
+    // The implicit part at the value a node solve just produced, without a transform of its own: (1 - alpha A) u = rhs gives
+    // A u = (u - rhs) / alpha (generic_MPIFFT_Laplacian.py:164-211 evaluates it through a second transform round trip).  The
+    // last pass of the solve has u in registers and reads rhs from `rhs` (which may be the field u is written to: every
+    // thread reads its elements before it stores them).  impl_out == null: nothing.  Field 0 of the launch.
+    double* impl_out;
+    const double* rhs;
+    double inv_alpha;
     __host__ __device__ double* target(int f) const { return field < 0 ? outs[f] : (f == field ? out : nullptr); }
 };
 __device__ __forceinline__ double react_value(double v, int kind, double p0, double p1, int nu) {
@@ -37,6 +44,7 @@ struct LinTerms {
     const double* x[2 * MAXM];
     double c[2 * MAXM];
     int n;
+    double* wb;   // != null: the completed field is stored there as well (the right-hand side the last pass of the solve reads again)
 };
 
 // 1-D problems: promote the real line to complex / take the real part back
@@ -80,6 +88,10 @@ __global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_fwd(FieldPtr
                 r[i].x += ck * v.x;
                 r[i].y += ck * v.y;
             }
+        }
+        if (lin.wb) {
+#pragma unroll
+            for (int i = 0; i < E; ++i) *reinterpret_cast<cd*>(lin.wb + (size_t)(j + i * P) * rest + 2 * (size_t)c) = r[i];
         }
     }
     if (double* const eo = epi.target((int)blockIdx.y); eo && ok) {  // reaction term of the field that is being read
@@ -141,7 +153,9 @@ __global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_fwd(FieldPtr
 // field when u[0] is replaced, core/sweeper.py:186-199 is linear in u[0]).  2: max |r| goes to norms2[field] and max |r + d|
 // with d from the scratch to norms[field] - the residual before and after the receive out of one pass over the residual
 // lines (same XCD-aware order as ADD: the nfields workgroups that read one scratch tile follow each other on one XCD).
-template <int N, int T, bool NORM, bool STORE, bool ADD = false, int SCR = 0>
+// IMPL: the implicit part from the solve's own equation rides along (ReactEpi::impl_out; an instantiation of its own, so
+// that the registers it needs are not everybody's).
+template <int N, int T, bool NORM, bool STORE, bool ADD = false, int SCR = 0, bool IMPL = false>
 __global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_inv(FieldPtrs p, const cd* __restrict__ W,
                                                                       size_t fstride, int rest,
                                                                       const cd* __restrict__ tw,
@@ -344,8 +358,27 @@ __global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_inv(FieldPtr
         if ((threadIdx.x & 63) == 0) atomic_max_abs(norms + by, m);
     }
     if constexpr (STORE) {
-        double* __restrict__ out = p.out[by];
+        double* out = p.out[by];   // (no __restrict__: epi.rhs may be this very field)
         if (ok) {
+            if constexpr (IMPL) {
+                if (epi.impl_out && by == 0) {   // A u = (u - rhs) / alpha, four elements at a time (few registers beside r[])
+                    constexpr int CHK = E % 4 == 0 ? 4 : 1;
+#pragma unroll
+                    for (int i0 = 0; i0 < E; i0 += CHK) {
+                        cd q[CHK];
+#pragma unroll
+                        for (int i = 0; i < CHK; ++i)
+                            q[i] = *reinterpret_cast<const cd*>(epi.rhs + (size_t)(j + (i0 + i) * P) * rest + 2 * (size_t)c);
+#pragma unroll
+                        for (int i = 0; i < CHK; ++i) {
+                            __builtin_nontemporal_store((r[i0 + i].x - q[i].x) * epi.inv_alpha,
+                                                        epi.impl_out + (size_t)(j + (i0 + i) * P) * rest + 2 * (size_t)c);
+                            __builtin_nontemporal_store((r[i0 + i].y - q[i].y) * epi.inv_alpha,
+                                                        epi.impl_out + (size_t)(j + (i0 + i) * P) * rest + 2 * (size_t)c + 1);
+                        }
+                    }
+                }
+            }
 #pragma unroll
             for (int i = 0; i < E; ++i)
                 *reinterpret_cast<cd*>(out + (size_t)(j + i * P) * rest + 2 * (size_t)c) = r[i];

@@ -167,6 +167,188 @@ __global__ __launch_bounds__(256) void k_xfer_fused3(XferArgs a, unsigned nfield
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Nested periodic grids, factor two per axis, 3-D, the table entries of every output row inside that row's window (checked
+// by the host, sdc_transfer_apply_nested): one launch per transfer whose HBM traffic is the fields themselves.
+// ------------------------------------------------------------------------------------------------------
+struct NestedArgs {
+    const double* in;
+    const double* in_minus;    // refinement: in - in_minus is transferred (null: in)
+    double* out;
+    const double* out_minus;   // coarsening: result - out_minus is stored (null: result)
+    const int* idx;
+    const double* w;
+    int n_out, n_in, W, accumulate;
+};
+
+// Coarsening with three entries per row (rorder 2: full weighting).  A thread owns the column (j, k) of the coarse grid and
+// walks along i: the fine values 2k, 2k+1 of a row are ONE 16-byte load, 2k-1 comes from the neighbouring lane, so a wave
+// reads whole 1 KB pieces of the fine rows; the plane sum of plane 2i+1 is kept for output i+1.  Per coarse value 2 planes x 3
+// rows are loaded (the rows two neighbouring j share come from the caches); the sums are nested and ordered like the table
+// says - what k_xfer_fused3 and the three separable passes compute.
+//   grid: x = (k blocks) * (n_out / blockDim.y), y = n_out / TI, z = field;  block = (KX, JY), KX a power of two >= 16
+template <int TI>
+__global__ __launch_bounds__(256) void k_restrict3_nested(NestedArgs a, unsigned kx_blocks) {
+    const unsigned n_out = (unsigned)a.n_out, n_in = (unsigned)a.n_in;
+    const unsigned kb = blockIdx.x % kx_blocks, jb = blockIdx.x / kx_blocks;
+    const unsigned k = kb * blockDim.x + threadIdx.x, j = jb * blockDim.y + threadIdx.y;
+    const unsigned i0 = blockIdx.y * TI, o = blockIdx.z;
+    const double* __restrict__ src = a.in + (size_t)o * n_in * n_in * n_in;
+    double wk[3], wj[3];
+    int ck[3];        // which of (left, 2k, 2k+1) entry c reads
+    unsigned rj[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        wk[c] = a.w[(size_t)c * n_out + k];
+        const unsigned ik = (unsigned)a.idx[(size_t)c * n_out + k];
+        ck[c] = ik == 2 * k ? 1 : (ik == 2 * k + 1 ? 2 : 0);
+        wj[c] = a.w[(size_t)c * n_out + j];
+        rj[c] = (unsigned)a.idx[(size_t)c * n_out + j];
+    }
+    const unsigned kl = (2 * k + n_in - 1) % n_in;
+    // (the lane to the left holds column k - 1 of the same row unless this one starts a row or a wave)
+    const bool lane0 = threadIdx.x == 0 || ((threadIdx.y * blockDim.x + threadIdx.x) & 63u) == 0;
+    auto row_sum = [&](const double* __restrict__ row) {
+        const double2 v = *reinterpret_cast<const double2*>(row + 2 * (size_t)k);
+        double left = __shfl_up(v.y, 1);
+        if (lane0) left = row[kl];
+        double acc = 0.0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double val = ck[c] == 1 ? v.x : (ck[c] == 2 ? v.y : left);
+            acc = wk[c] != 0.0 ? acc + wk[c] * val : acc;
+        }
+        return acc;
+    };
+    auto plane_sum = [&](unsigned p) {
+        const double* __restrict__ pl = src + (size_t)p * n_in * n_in;
+        double s[3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) s[b] = row_sum(pl + (size_t)rj[b] * n_in);   // (all three rows in flight)
+        double acc = 0.0;
+#pragma unroll
+        for (int b = 0; b < 3; ++b) acc = wj[b] != 0.0 ? acc + wj[b] * s[b] : acc;
+        return acc;
+    };
+    double tm = plane_sum((2 * i0 + n_in - 1) % n_in);
+#pragma unroll 2
+    for (unsigned ii = 0; ii < (unsigned)TI; ++ii) {
+        const unsigned i = i0 + ii;
+        const double t0 = plane_sum(2 * i), tp = plane_sum(2 * i + 1);
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const double wi = a.w[(size_t)q * n_out + i];
+            const unsigned ip = (unsigned)a.idx[(size_t)q * n_out + i];
+            const double tv = ip == 2 * i ? t0 : (ip == 2 * i + 1 ? tp : tm);
+            acc = wi != 0.0 ? acc + wi * tv : acc;
+        }
+        const size_t q = (((size_t)o * n_out + i) * n_out + j) * n_out + k;
+        if (a.out_minus) acc = acc - a.out_minus[q];
+        a.out[q] = acc;
+        tm = tp;
+    }
+}
+
+// Refinement (iorder = W: even rows copy a coarse value, odd rows interpolate W of them).  A workgroup of 256 threads makes a
+// 16^3 tile of the fine grid from the (8 + W - 1)^3 coarse values it depends on, staged in LDS: contiguous axis first (T1),
+// then the middle one (T2), then the first, whose result is stored or added to what is there (the coarse-grid correction) -
+// the three separable passes with their intermediate fields in LDS instead of HBM.  Thread (jf, kf) of the tile keeps its
+// table rows in registers; the rows of the first axis are uniform over the workgroup.
+//   grid: x = tiles along the contiguous axis, y = tiles along the middle axis, z = tiles along the first axis * fields
+template <int W>
+__global__ __launch_bounds__(256) void k_prolong3_nested(NestedArgs a) {
+    constexpr int TC = 8, TF = 16, HW = TC + W - 1, HL = W / 2 - 1;
+    __shared__ double A[HW * HW * HW > HW * TF * TF ? HW * HW * HW : HW * TF * TF];   // coarse window, later T2[x][jf][kf]
+    __shared__ double T1[HW * HW * TF];                                                 // [x][y][kf]
+    __shared__ double WX[TF * W];   // table rows of the first axis for the 16 fine planes of the tile: weights ...
+    __shared__ int LX[TF * W];      // ... and local window positions
+    const int n_out = a.n_out, n_in = a.n_in;
+    const int tiles = n_in / TC;
+    const int tz = blockIdx.x, ty = blockIdx.y, tx = blockIdx.z % tiles, o = blockIdx.z / tiles;
+    // Even fine indices copy ONE coarse value, odd ones interpolate W: the threads are arranged so that a wave holds rows of
+    // one parity - waves 0, 2 the even kf (first stage) / jf (second, third stage), waves 1, 3 the odd ones - and the entries
+    // with weight zero are skipped by a branch that is uniform over the wave (3.5 LDS reads per value instead of 6).
+    const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63, par = wv & 1;
+    const int kf1 = 2 * (ln & 7) + par, xy1 = (ln >> 3) + 8 * (wv >> 1);        // first stage: 16 (x, y) rows per round
+    const int kf = ln & 15, jf = 2 * ((ln >> 4) + 4 * (wv >> 1)) + par;          // second / third stage, T2 slot jf * 16 + kf
+    const int slot = jf * TF + kf;
+    const double* __restrict__ src = a.in + (size_t)o * n_in * n_in * n_in;
+    const double* __restrict__ sub = a.in_minus ? a.in_minus + (size_t)o * n_in * n_in * n_in : nullptr;
+    // window origin per axis (coarse index of local position 0); every sum below lies in [0, 2 n_in): one conditional
+    // subtraction instead of a division
+    auto wrap = [n_in](int v) { return v >= n_in ? v - n_in : v; };
+    const int ox = wrap(tx * TC - HL + n_in), oy = wrap(ty * TC - HL + n_in), oz = wrap(tz * TC - HL + n_in);
+    for (int e = tid; e < HW * HW * HW; e += 256) {
+        const int z = e % HW, y = (e / HW) % HW, x = e / (HW * HW);
+        const size_t g = ((size_t)wrap(ox + x) * n_in + (size_t)wrap(oy + y)) * n_in + (size_t)wrap(oz + z);
+        double v = src[g];
+        if (sub) v = v - sub[g];
+        A[e] = v;
+    }
+    if (tid < TF * W) {
+        const int fi = tid / W, c = tid % W, ig = tx * TF + fi;
+        WX[tid] = a.w[(size_t)c * n_out + ig];
+        LX[tid] = wrap(a.idx[(size_t)c * n_out + ig] - ox + n_in) * (TF * TF);
+    }
+    // this thread's table rows along the contiguous (kf1) and the middle (jf) axis: weights and LOCAL window positions
+    double wz[W], wy[W];
+    int lz[W], ly[W];
+    {
+        const int kg = tz * TF + kf1, jg = ty * TF + jf;
+#pragma unroll
+        for (int c = 0; c < W; ++c) {
+            wz[c] = a.w[(size_t)c * n_out + kg];
+            lz[c] = wrap(a.idx[(size_t)c * n_out + kg] - oz + n_in);
+            wy[c] = a.w[(size_t)c * n_out + jg];
+            ly[c] = wrap(a.idx[(size_t)c * n_out + jg] - oy + n_in) * TF;
+        }
+    }
+    __syncthreads();
+    for (int xy = xy1; xy < HW * HW; xy += 16) {
+        const double* __restrict__ row = A + xy * HW;
+        double acc = 0.0;
+#pragma unroll
+        for (int c = 0; c < W; ++c)
+            if (wz[c] != 0.0) acc += wz[c] * row[lz[c]];
+        T1[xy * TF + kf1] = acc;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int x = 0; x < HW; ++x) {
+        const double* __restrict__ pl = T1 + x * HW * TF + kf;
+        double acc = 0.0;
+#pragma unroll
+        for (int c = 0; c < W; ++c)
+            if (wy[c] != 0.0) acc += wy[c] * pl[ly[c]];
+        A[x * TF * TF + slot] = acc;   // T2 (the coarse window is not read any more: every thread passed the barrier above)
+    }
+    __syncthreads();
+    double* __restrict__ dst = a.out + (size_t)o * n_out * n_out * n_out +
+                               ((size_t)(tx * TF) * n_out + (size_t)(ty * TF + jf)) * n_out + (size_t)(tz * TF + kf);
+    const size_t plane = (size_t)n_out * n_out;
+    // (the fine values the tile is added to are fetched before the sums: their latency hides behind the LDS reads)
+    double old[TF];
+    if (a.accumulate) {
+#pragma unroll
+        for (int fi = 0; fi < TF; ++fi) old[fi] = dst[fi * plane];
+    }
+#pragma unroll
+    for (int fi = 0; fi < TF; ++fi) {
+        double acc = 0.0;
+#pragma unroll
+        for (int c = 0; c < W; ++c) {
+            // (the row of the first axis is the same for the whole workgroup: scalar weight, scalar branch)
+            const double wl = WX[fi * W + c];
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)__double2loint(wl));
+            const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)__double2hiint(wl));
+            const double wi = __hiloint2double((int)hi, (int)lo);
+            if (wi != 0.0) acc += wi * A[__builtin_amdgcn_readfirstlane(LX[fi * W + c]) + slot];
+        }
+        dst[fi * plane] = a.accumulate ? old[fi] + acc : acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // Fourier prolongation (mesh_to_mesh_fft, TransferMesh_FFT.py:36-57; mesh_to_mesh_fft2d,
 // TransferMesh_FFT2D.py:58-77): the coarse spectrum is copied into the low modes of a fine spectrum.  The
 // reference's index conventions are kept as they are, including where the coarse Nyquist mode ends up.

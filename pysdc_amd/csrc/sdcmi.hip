@@ -313,6 +313,9 @@ struct ReactReq {
     int where = 0, field = 0;   // field < 0: of every field of the pipeline, into outs[f]
     double* out = nullptr;
     double* outs[MAXM] = {};
+    double* impl_out = nullptr;      // the implicit part at the solution of field 0 from the solve's own equation (ReactEpi)
+    const double* rhs = nullptr;
+    double inv_alpha = 0.0;
 };
 template <int N>
 static int fft_pipeline_n(sdc_ctx* c, int nf, const FieldPtrs& p, ZArgs& z, const ReactReq& rq = ReactReq(),
@@ -320,7 +323,10 @@ static int fft_pipeline_n(sdc_ctx* c, int nf, const FieldPtrs& p, ZArgs& z, cons
     const ReactEpi none{nullptr, 0, 0, 0, 0.0, 0.0, {}};
     ReactEpi epi{rq.out, rq.field, c->react_kind, c->react_nu, c->react_p0, c->react_p1, {}};
     for (int f = 0; f < MAXM; ++f) epi.outs[f] = rq.outs[f];
-    const bool can = c->ndim >= 2 && (rq.out != nullptr || rq.field < 0);  // (1-D lines go through k_promote / k_realpart: the caller launches k_reaction)
+    epi.impl_out = rq.impl_out;
+    epi.rhs = rq.rhs;
+    epi.inv_alpha = rq.inv_alpha;
+    const bool can = c->ndim >= 2 && (rq.out != nullptr || rq.field < 0 || rq.impl_out != nullptr);  // (1-D lines go through k_promote / k_realpart: the caller launches k_reaction)
     constexpr int E = fft_elems(N), P = N / E;
     constexpr int T = N >= 2048 ? 4 : (N == 1024 ? SDC_T1024 : 8);  // complex columns per strided tile (128-byte row segments up to N = 1024)
     const size_t lds_str = (size_t)LayStrided<N, T>::doubles(T) * sizeof(double);
@@ -344,7 +350,7 @@ static int fft_pipeline_n(sdc_ctx* c, int nf, const FieldPtrs& p, ZArgs& z, cons
         {
             LaunchTimer lt(c, pname("fft_x_fwd", nfi));
             hipLaunchKernelGGL((k_fftx_fwd<N, T>), dim3(tiles, nfi), dim3(P * T), lds_str, c->stream, p, c->W, c->Nc,
-                               rest, c->tw, (can && rq.where == 1) ? epi : none, lin ? *lin : LinTerms{{}, {}, 0});
+                               rest, c->tw, (can && rq.where == 1) ? epi : none, lin ? *lin : LinTerms{{}, {}, 0, nullptr});
         }
         if (c->ndim == 3) {
             LaunchTimer lt(c, pname("fft_y_fwd", nfi));
@@ -375,8 +381,12 @@ static int fft_pipeline_n(sdc_ctx* c, int nf, const FieldPtrs& p, ZArgs& z, cons
                                c->stream, c->W, c->Nc, c->tw);
         }
         LaunchTimer lt(c, pname("fft_x_inv", nf));
-        hipLaunchKernelGGL((k_fftx_inv<N, T, false, true>), dim3(tiles, nf), dim3(P * T), lds_str, c->stream, p, c->W, c->Nc,
-                           rest, c->tw, nullptr, nullptr, 1, (can && rq.where == 2) ? epi : none);
+        if (can && rq.where == 2 && rq.impl_out)
+            hipLaunchKernelGGL((k_fftx_inv<N, T, false, true, false, 0, true>), dim3(tiles, nf), dim3(P * T), lds_str, c->stream, p,
+                               c->W, c->Nc, rest, c->tw, nullptr, nullptr, 1, epi);
+        else
+            hipLaunchKernelGGL((k_fftx_inv<N, T, false, true>), dim3(tiles, nf), dim3(P * T), lds_str, c->stream, p, c->W, c->Nc,
+                               rest, c->tw, nullptr, nullptr, 1, (can && rq.where == 2) ? epi : none);
     }
     HIPCHK(c, hipGetLastError());
     return SDC_OK;
@@ -1517,7 +1527,16 @@ int sdc_set_symbol(sdc_ctx* c, int which, const double* table) {
     HIPCHK(c, hipMemcpyAsync(*dst, table, sizeof(cd) * c->n, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->have_stencil[which] = true;
-    if (which == 0) c->spectral_op = true;
+    if (which == 0) {
+        c->spectral_op = true;
+        c->sym_table_real = true;
+        c->sym_absmax = 0.0;
+        for (int k = 0; k < c->n; ++k) {
+            if (table[2 * k + 1] != 0.0) c->sym_table_real = false;
+            const double m = hypot(table[2 * k], table[2 * k + 1]);
+            if (m > c->sym_absmax) c->sym_absmax = m;
+        }
+    }
     c->spec_valid = c->spec0_valid = false;
     c->g_sweeps = 0;  // (multipliers of another symbol)
     return SDC_OK;
@@ -2219,6 +2238,34 @@ static int sweep_nodewise(sdc_ctx* c, double dt, bool keep_guess = false) {
                 hipLaunchKernelGGL(k_lincomb, dim3(grid_for(c->N / 2, 256)), dim3(256), 0, c->stream, la);
                 HIPCHK(c, hipGetLastError());
             }
+        }
+#ifndef SDC_IMPL_FROM_SOLVE
+#define SDC_IMPL_FROM_SOLVE 1
+#endif
+        // ... and when the symbol is real and alpha |symbol|max >= 1, the implicit part at the new value is (u - rhs) / alpha:
+        // the solve's own equation, evaluated by the last pass as it writes u - ONE spectrum through the z / y passes instead
+        // of two (rounding error eps |u| / alpha <= eps |symbol|max |u|: that of the transformed evaluation).  The first pass
+        // stores the completed right-hand side where the last one reads it.
+        const bool impl_from_solve = SDC_IMPL_FROM_SOLVE && shared_fwd && c->ndim >= 2 && c->sym_table_real && alpha > 0.0 &&
+                                     alpha * c->sym_absmax * c->ndim >= 1.0 && (!imex || c->expl_kind == SDC_EXPL_REACTION);
+        if (impl_from_solve) {
+            FieldPtrs p1;
+            memset(&p1, 0, sizeof p1);
+            ZArgs z1;
+            memset(&z1, 0, sizeof z1);
+            p1.in[0] = rhs;
+            p1.out[0] = um;
+            z1.alpha[0] = alpha;
+            ReactReq rq1;
+            rq1.where = 2;
+            if (imex) rq1.out = c->F + ((size_t)(m + 1) * c->ncomp + 1) * c->N;
+            rq1.impl_out = c->F + ((size_t)(m + 1) * c->ncomp) * c->N;
+            rq1.rhs = rhs;
+            rq1.inv_alpha = 1.0 / alpha;
+            if (lin.n) lin.wb = rhs;
+            rc = fft_pipeline(c, 1, p1, z1, rq1, lin.n ? &lin : nullptr);
+            if (rc != SDC_OK) return rc;
+            continue;
         }
         if (shared_fwd) {
             // operator given by its symbol: the solve and the evaluation of the implicit part at the new value share
@@ -3885,6 +3932,96 @@ int sdc_transfer_apply_batch_acc(void* stream, int nfields, int ndim, int n_out,
         }
         dims[axis] = n_out;
         src = a.out;
+    }
+    HIPCHK(nullptr, hipGetLastError());
+    return SDC_OK;
+}
+
+int sdc_transfer_apply_nested(void* stream, int nfields, int ndim, int n_out, int n_in, int width, const int* idx,
+                              const double* w, const double* in, const double* in_minus, double* out,
+                              const double* out_minus, int accumulate) {
+    if (nfields < 1 || ndim < 1 || ndim > 3 || n_out < 1 || n_in < 1 || width < 1 || !idx || !w || !in || !out)
+        return fail(nullptr, SDC_ERR_PARAM, "bad transfer arguments");
+#ifndef SDC_XFER_NESTED
+#define SDC_XFER_NESTED 1
+#endif
+    hipStream_t st = (hipStream_t)stream;
+    NestedArgs a;
+    memset(&a, 0, sizeof a);
+    a.in = in;
+    a.in_minus = in_minus;
+    a.out = out;
+    a.out_minus = out_minus;
+    a.idx = idx;
+    a.w = w;
+    a.n_out = n_out;
+    a.n_in = n_in;
+    a.W = width;
+    a.accumulate = accumulate;
+    const bool aligned = (((uintptr_t)in | (uintptr_t)out) & 15) == 0;
+    // (threads along k: the largest power of two that divides n_out, at most 256)
+    unsigned kx = (unsigned)(n_out & -n_out);
+    if (kx > 256u) kx = 256u;
+    const unsigned jy = kx ? 256u / kx : 1u;
+    if (SDC_XFER_NESTED && ndim == 3 && n_in == 2 * n_out && width == 3 && !accumulate && !in_minus && kx >= 16 &&
+        (unsigned)n_out % jy == 0 && n_out % 8 == 0 && nfields <= 65535 && aligned) {
+        // coarse planes a thread walks over: the longer the walk, the fewer fine planes are read twice (1 + 1 / (2 TI)) - but the
+        // launch wants a few thousand workgroups
+        const unsigned kx_blocks = (unsigned)n_out / kx;
+        const size_t per_plane = (size_t)kx_blocks * ((unsigned)n_out / jy) * (size_t)nfields;
+        const int TI = per_plane * (n_out / 8) >= 4096 ? 8 : (per_plane * (n_out / 4) >= 4096 ? 4 : 2);
+        const dim3 g(kx_blocks * ((unsigned)n_out / jy), (unsigned)n_out / TI, (unsigned)nfields), blk(kx, jy);
+        if (TI == 8) hipLaunchKernelGGL((k_restrict3_nested<8>), g, blk, 0, st, a, kx_blocks);
+        else if (TI == 4) hipLaunchKernelGGL((k_restrict3_nested<4>), g, blk, 0, st, a, kx_blocks);
+        else hipLaunchKernelGGL((k_restrict3_nested<2>), g, blk, 0, st, a, kx_blocks);
+        HIPCHK(nullptr, hipGetLastError());
+        return SDC_OK;
+    }
+    if (SDC_XFER_NESTED && ndim == 3 && n_out == 2 * n_in && !out_minus && n_in % 8 == 0 && n_in >= 2 * (8 + width) &&
+        (width == 2 || width == 4 || width == 6 || width == 8) && (size_t)(n_in / 8) * nfields <= 65535) {
+        const unsigned tiles = (unsigned)n_in / 8;
+        const dim3 g(tiles, tiles, tiles * (unsigned)nfields), blk(256);
+        switch (width) {
+        case 2: hipLaunchKernelGGL((k_prolong3_nested<2>), g, blk, 0, st, a); break;
+        case 4: hipLaunchKernelGGL((k_prolong3_nested<4>), g, blk, 0, st, a); break;
+        case 6: hipLaunchKernelGGL((k_prolong3_nested<6>), g, blk, 0, st, a); break;
+        default: hipLaunchKernelGGL((k_prolong3_nested<8>), g, blk, 0, st, a); break;
+        }
+        HIPCHK(nullptr, hipGetLastError());
+        return SDC_OK;
+    }
+    // everything else: the separable passes, the differences by launches of their own (a scratch field per host thread)
+    size_t len_in = (size_t)nfields, len_out = (size_t)nfields;
+    for (int d = 0; d < ndim; ++d) {
+        len_in *= (size_t)n_in;
+        len_out *= (size_t)n_out;
+    }
+    struct Tmp {
+        double* p = nullptr;
+        size_t len = 0;
+        ~Tmp() {
+            if (p) (void)hipFree(p);
+        }
+    };
+    static thread_local Tmp tmp;
+    const double* src = in;
+    if (in_minus) {
+        if (tmp.len < len_in) {
+            if (tmp.p) (void)hipFree(tmp.p);
+            tmp.p = nullptr;
+            tmp.len = 0;
+            if (hipMalloc((void**)&tmp.p, len_in * sizeof(double)) != hipSuccess)
+                return fail(nullptr, SDC_ERR_NOMEM, "transfer scratch allocation failed");
+            tmp.len = len_in;
+        }
+        hipLaunchKernelGGL(k_axpby, dim3(grid_for(len_in, 256)), dim3(256), 0, st, len_in, 1.0, in, -1.0, in_minus, tmp.p);
+        src = tmp.p;
+    }
+    int rc = sdc_transfer_apply_batch_acc(stream, nfields, ndim, n_out, n_in, width, idx, w, src, out, accumulate);
+    if (rc != SDC_OK) return rc;
+    if (out_minus) {
+        if (accumulate) return fail(nullptr, SDC_ERR_PARAM, "out_minus and accumulate exclude each other");
+        hipLaunchKernelGGL(k_axpby, dim3(grid_for(len_out, 256)), dim3(256), 0, st, len_out, 1.0, out, -1.0, out_minus, out);
     }
     HIPCHK(nullptr, hipGetLastError());
     return SDC_OK;

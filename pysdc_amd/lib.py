@@ -116,6 +116,7 @@ PROTOTYPES = {
     'sdc_transfer_apply_batch': (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     'sdc_transfer_apply_batch_acc': (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int]),
     'sdc_transfer_apply': (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
+    'sdc_transfer_apply_nested': (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int]),
     'sdc_odd_mirror': (C.c_int, [_vp, _vp, C.c_int]),
     'sdc_set_odd_interior': (C.c_int, [_vp, C.c_int]),
     'sdc_odd_extend': (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int]),

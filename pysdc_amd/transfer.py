@@ -143,9 +143,17 @@ class BaseTransfer:
         except (AttributeError, IndexError, TypeError):
             return False
 
-    def _space_batch(self, key, nfields, src_ptr, dst_ptr, accumulate=False):
+    def _space_batch(self, key, nfields, src_ptr, dst_ptr, accumulate=False, src_minus=None, dst_minus=None):
+        """nfields fields through the space transfer; src_minus: the difference src - src_minus is transferred, dst_minus:
+        result - dst_minus is stored (the differences of core/base_transfer.py:120-147 / :196-205 without fields and launches
+        of their own where the tables have the nested structure, sdc_transfer_apply_nested)"""
         sp = self.space_transfer
         idx, w, width, (n_out, n_in) = sp._tab[key]
+        if sp._nested.get(key):
+            Lb.check(Lb.load().sdc_transfer_apply_nested(None, nfields, sp.ndim, n_out, n_in, width, idx.ptr, w.ptr, src_ptr,
+                                                         src_minus, dst_ptr, dst_minus, int(accumulate)), None)
+            return
+        assert src_minus is None and dst_minus is None
         Lb.check(Lb.load().sdc_transfer_apply_batch_acc(None, nfields, sp.ndim, n_out, n_in, width, idx.ptr, w.ptr, src_ptr,
                                                         dst_ptr, int(accumulate)), None)
 
@@ -167,12 +175,6 @@ class BaseTransfer:
         self._refresh_f_nodes(coarse, list(range(1, M + 1)))
         quad_coarse = coarse.sweep.integrate()    # M fields, one behind the other (checked: a user's integrate() need not)
         quad_fine = fine.sweep.integrate()
-        on_coarse = hip_mesh(((M * nc,), None, np.dtype('float64')), val=None)
-        if self._one_buffer(quad_fine, 8 * ef.N):
-            self._space_batch('R', M, quad_fine[0].ptr, on_coarse.ptr)
-        else:
-            for k in range(M):
-                self._space_batch('R', 1, quad_fine[k].ptr, on_coarse.ptr + 8 * k * nc)
         if not self._one_buffer(quad_coarse, 8 * nc):
             packed = hip_mesh(((M * nc,), None, np.dtype('float64')), val=None)
             for k in range(M):
@@ -183,7 +185,17 @@ class BaseTransfer:
             coarse._activate_tau()
         tau = hip_mesh.view(ec.ptr(Lb.SLOT_TAU, 0), (M * nc,), keep=ec)
         qc = hip_mesh.view(quad_coarse[0].ptr, (M * nc,), keep=quad_coarse[0])
-        tau._axpby(1.0, on_coarse, -1.0, qc, tau)
+        if self._one_buffer(quad_fine, 8 * ef.N) and self.space_transfer._nested.get('R'):
+            # tau = R(Q_F f_F) - Q_G f_G leaves the restriction's launch as that difference
+            self._space_batch('R', M, quad_fine[0].ptr, tau.ptr, dst_minus=qc.ptr)
+        else:
+            on_coarse = hip_mesh(((M * nc,), None, np.dtype('float64')), val=None)
+            if self._one_buffer(quad_fine, 8 * ef.N):
+                self._space_batch('R', M, quad_fine[0].ptr, on_coarse.ptr)
+            else:
+                for k in range(M):
+                    self._space_batch('R', 1, quad_fine[k].ptr, on_coarse.ptr + 8 * k * nc)
+            tau._axpby(1.0, on_coarse, -1.0, qc, tau)
         if fine.tau[0] is not None:               # a correction the fine level itself received from above travels down too
             carried = hip_mesh(((M * nc,), None, np.dtype('float64')), val=None)
             self._space_batch('R', M, ef.ptr(Lb.SLOT_TAU, 0), carried.ptr)
@@ -209,10 +221,15 @@ class BaseTransfer:
         uold = getattr(self, '_uold_batch', None)
         if uold is None or any(coarse.uold[n] is None or coarse.uold[n].ptr != uold.ptr + 8 * (n - 1) * nc for n in range(1, M + 1)):
             return False
-        diff = hip_mesh(((M * nc,), None, np.dtype('float64')), val=None)
-        diff._axpby(1.0, hip_mesh.view(ec.ptr(Lb.SLOT_U, 1), (M * nc,), keep=ec), -1.0, uold, diff)
-        # u_F[m] += P diff[m]: the last pass of the prolongation adds its result to the node values where they lie
-        self._space_batch('P', M, diff.ptr, ef.ptr(Lb.SLOT_U, 1), accumulate=True)
+        if self.space_transfer._nested.get('P'):
+            # u_F[m] += P (u_G[m] - uold_G[m]): the difference is formed as the coarse tile is staged, the sum as the fine
+            # tile is stored - one launch, no field for either
+            self._space_batch('P', M, ec.ptr(Lb.SLOT_U, 1), ef.ptr(Lb.SLOT_U, 1), accumulate=True, src_minus=uold.ptr)
+        else:
+            diff = hip_mesh(((M * nc,), None, np.dtype('float64')), val=None)
+            diff._axpby(1.0, hip_mesh.view(ec.ptr(Lb.SLOT_U, 1), (M * nc,), keep=ec), -1.0, uold, diff)
+            # u_F[m] += P diff[m]: the last pass of the prolongation adds its result to the node values where they lie
+            self._space_batch('P', M, diff.ptr, ef.ptr(Lb.SLOT_U, 1), accumulate=True)
         fine._touched(Lb.SLOT_U, 1)
         self._refresh_f_nodes(fine, list(range(1, M + 1)))
         return True
@@ -380,7 +397,23 @@ def _row_tables(M):
     return np.ascontiguousarray(idx.T), np.ascontiguousarray(w.T), width
 
 
+def _rows_in_window(M, first):
+    """do the non-zero columns of every row r of the dense 1-D operator M lie in first(r, width) .. + width - 1 (modulo the
+    number of columns), width = the widest row?"""
+    n_rows, n_cols = M.shape
+    width = max(1, int(np.max(np.count_nonzero(M, axis=1))))
+    if n_cols < 2 * width:
+        return False
+    for r in range(n_rows):
+        cols = np.nonzero(M[r])[0]
+        if len(cols) and np.any((cols - first(r, width)) % n_cols >= width):
+            return False
+    return True
+
+
 class mesh_to_mesh:
+    _nested = {}
+
     def __init__(self, fine_prob, coarse_prob, params):
         self.params = _SpacePars(params)
         self.logger = logging.getLogger('space-transfer')
@@ -422,9 +455,17 @@ class mesh_to_mesh:
             for key, Mx in (('P', P), ('R', R)):
                 idx, w, width = _row_tables(Mx)
                 self._tab[key] = (device_buffer(idx), device_buffer(w), width, Mx.shape)
+            # nested periodic grids in 3-D: do all entries of every row lie in that row's window?  (what the one-launch
+            # transfers of sdc_transfer_apply_nested assume; everything else takes the separable passes)
+            self._nested = {'P': periodic and self.ndim == 3 and _rows_in_window(P, lambda r, wd: r // 2 - wd // 2 + 1),
+                            'R': periodic and self.ndim == 3 and _rows_in_window(R, lambda r, wd: 2 * r - 1)}
 
     def _apply(self, key, src, dst):
         idx, w, width, (n_out, n_in) = self._tab[key]
+        if self._nested.get(key):
+            Lb.check(Lb.load().sdc_transfer_apply_nested(None, 1, self.ndim, n_out, n_in, width, idx.ptr, w.ptr, src.ptr, None,
+                                                         dst.ptr, None, 0), None)
+            return
         Lb.check(Lb.load().sdc_transfer_apply(None, self.ndim, n_out, n_in, width, idx.ptr, w.ptr, src.ptr, dst.ptr), None)
 
     def _restrict(self, fine, coarse):
@@ -452,8 +493,12 @@ class mesh_to_mesh:
         shape = out_init[0] if not np.isscalar(out_init[0]) else (int(out_init[0]),)
         osize = int(np.prod(shape))
         buf = hip_mesh(((len(fields) * osize,), None, np.dtype('float64')), val=None)
-        Lb.check(Lb.load().sdc_transfer_apply_batch(None, len(fields), self.ndim, n_out, n_in, width, idx.ptr, w.ptr,
-                                                    ptrs[0], buf.ptr), None)
+        if self._nested.get(key):
+            Lb.check(Lb.load().sdc_transfer_apply_nested(None, len(fields), self.ndim, n_out, n_in, width, idx.ptr, w.ptr,
+                                                         ptrs[0], None, buf.ptr, None, 0), None)
+        else:
+            Lb.check(Lb.load().sdc_transfer_apply_batch(None, len(fields), self.ndim, n_out, n_in, width, idx.ptr, w.ptr,
+                                                        ptrs[0], buf.ptr), None)
         return [hip_mesh.view(buf.ptr + 8 * k * osize, shape, keep=buf) for k in range(len(fields))]
 
     def restrict_many(self, fields):

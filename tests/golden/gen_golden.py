@@ -1174,3 +1174,33 @@ def radix5_main():
 
 if __name__ == '__main__' and os.environ.get('GOLDEN_R5', '0') == '1':
     radix5_main()
+
+
+def transfer3d_main():
+    """mesh_to_mesh in 3-D on grids the one-launch transfers of round 6 take (sdc_transfer_apply_nested: restriction with
+    full weighting streamed once, prolongation through an LDS tile): 64^3 <-> 32^3 with iorder 6 / rorder 2 (BASELINE config
+    5's orders) and iorder 4.  The fields hold small integers so that the file stays small."""
+    from pySDC.implementations.transfer_classes.TransferMesh import mesh_to_mesh
+
+    out = {}
+    for tag, n, io, ro in (('64_io6', 64, 6, 2), ('64_io4', 64, 4, 2), ('64_io2', 64, 2, 2), ('48_io8', 48, 8, 2)):
+        nf, nc = (n,) * 3, (n // 2,) * 3
+        pf = heatNd_unforced(nvars=nf, nu=0.1, freq=2, bc='periodic')
+        pc = heatNd_unforced(nvars=nc, nu=0.1, freq=2, bc='periodic')
+        T = mesh_to_mesh(pf, pc, dict(iorder=io, rorder=ro, periodic=True))
+        rng = np.random.default_rng(11)
+        F = pf.dtype_u(pf.init)
+        F[:] = rng.integers(-8, 9, size=nf).astype(float)
+        G = pc.dtype_u(pc.init)
+        G[:] = rng.integers(-8, 9, size=nc).astype(float)
+        out[f'transfer3d_{tag}/fine'] = np.asarray(F).astype(np.int8)
+        out[f'transfer3d_{tag}/coarse'] = np.asarray(G).astype(np.int8)
+        out[f'transfer3d_{tag}/restricted'] = np.asarray(T.restrict(F)).copy()
+        out[f'transfer3d_{tag}/prolonged'] = np.asarray(T.prolong(G)).copy()
+        out[f'transfer3d_{tag}/meta'] = np.array(json.dumps(dict(name=f'transfer3d_{tag}', nf=list(nf), nc=list(nc), iorder=io, rorder=ro)))
+    np.savez_compressed(os.path.join(OUT, 'transfer3d.npz'), **out)
+    print('transfer3d.npz', os.path.getsize(os.path.join(OUT, 'transfer3d.npz')) // 1024, 'KiB')
+
+
+if __name__ == '__main__' and os.environ.get('GOLDEN_T3D', '0') == '1':
+    transfer3d_main()

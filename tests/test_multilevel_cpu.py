@@ -25,6 +25,15 @@ def test_space_transfer_oracle_vs_golden():
         assert rel_err(T.prolong(c['coarse']), c['prolonged']) < 1e-15, name
 
 
+def test_space_transfer_oracle_vs_golden_3d_64():
+    """the grids the one-launch transfers take (tests/test_gpu_transfer_nested.py): 64^3 <-> 32^3, 48^3 <-> 24^3"""
+    for name, c in load_cases('transfer3d.npz').items():
+        m = c['meta']
+        T = O.MeshToMesh(_tup(m['nf']), _tup(m['nc']), m['iorder'], m['rorder'])
+        assert rel_err(T.restrict(c['fine'].astype(float)), c['restricted']) < 1e-15, name
+        assert rel_err(T.prolong(c['coarse'].astype(float)), c['prolonged']) < 1e-15, name
+
+
 def test_fourier_transfer_oracle_vs_golden():
     """mesh_to_mesh_fft / mesh_to_mesh_fft2d restated in the oracle against vectors of the reference classes."""
     for name, c in load_cases('transfer_fft.npz').items():
