@@ -344,21 +344,36 @@ def run_workload(args, world, rank, use_dist, with_stream_reference=True):
         del spare
     del u0
     sync()
-    events = not getattr(args, 'no_kernel_events', False)
-    eng.profile_enable(events)
+    # HIP events around every launch of the timed region give the kernel table (roofline).  A configuration made of ~75
+    # launches of 10 - 300 us per iteration (the two-level Allen-Cahn run) pays ~10 us per launch for them - a tenth of its
+    # wall time: there the timed region runs WITHOUT events and the same steps run once more WITH them for the table
+    # (`kernel_events`: 'timed region' | 'second run of the same steps' | 'none'; the second run's wall time is reported too).
+    events_mode = getattr(args, 'kernel_events', None) or ('separate' if args.workload == 'allencahn' else 'timed')
+    if getattr(args, 'no_kernel_events', False):
+        events_mode = 'none'
     coarser = [Lc.engine for Lc in step.levels[1:] if hasattr(Lc, 'engine')]
-    for ec in coarser:
-        ec.profile_enable(events)
+
+    def set_events(on):
+        eng.profile_enable(on)
+        for ec in coarser:
+            ec.profile_enable(on)
+
+    set_events(events_mode == 'timed')
     t0 = time.perf_counter()
     uend, stats = ctrl.run(uend, block * args.warmup, block * (args.warmup + args.steps))
     sync()
     el = time.perf_counter() - t0
+    el_events = None
+    if events_mode == 'separate':
+        set_events(True)
+        t1 = time.perf_counter()
+        uend2, _ = ctrl.run(uend, block * (args.warmup + args.steps), block * (args.warmup + 2 * args.steps))
+        sync()
+        el_events = time.perf_counter() - t1
+        del uend2
     prof = eng.profile_read()
-    eng.profile_enable(False)
-    prof_coarse = []
-    for ec in coarser:
-        prof_coarse.append((ec.n, ec.profile_read()))
-        ec.profile_enable(False)
+    prof_coarse = [(ec.n, ec.profile_read()) for ec in coarser]
+    set_events(False)
 
     el_own = el
     elt = torch.tensor([el], dtype=torch.float64)   # (host tensor: the process group is gloo)
@@ -518,6 +533,8 @@ def run_workload(args, world, rank, use_dist, with_stream_reference=True):
             'roofline': roof, 'roofline_sweep': roof_sweep, 'kernels': kern, 'finite': finite,
             'device_bytes_per_gpu': eng.device_bytes,
             'params': {'M': M, 'dt': dt, 'n': n}, 'restol': args.restol,
+            'kernel_events': {'timed': 'timed region', 'separate': 'second run of the same steps', 'none': 'none'}[events_mode],
+            'ms_per_step_with_events': (1e3 * el_events / args.steps) if el_events is not None else None,
         }
         if per_rank is not None:
             out['per_rank'] = per_rank
@@ -594,6 +611,8 @@ def compact_sub(r):
          'kernel': roof.get('kernel'), 'bound': roof.get('bound'), 'frac': roof.get('frac'), 'sweep_frac': rs.get('frac')}
     if len(set(r['niter'])) > 1 or r.get('restol', -1) > 0:
         c['niter'] = r['niter'][:8]
+    if r.get('ms_per_step_with_events') is not None:   # (timed without HIP events; the kernel table from a second run with them)
+        c['ms_per_step_with_events'] = r['ms_per_step_with_events']
     return _r(c, 4)
 
 
@@ -914,6 +933,11 @@ def main():
                     help='--gpus > 1: skip the small-grid run over the wire that is compared with the serial emulation')
     ap.add_argument('--job-timeout', type=float, default=1500.0,
                     help='--gpus > 1 started without a launcher: seconds after which the parent ends the job with an error')
+    ap.add_argument('--kernel-events', default=None, choices=['timed', 'separate'],
+                    help="HIP events around every launch: 'timed' = inside the timed region (default; the headline's roofline "
+                         "is measured there), 'separate' = the timed region runs without them and the same steps run once "
+                         'more with them for the kernel table (default for --workload allencahn, whose ~75 short launches '
+                         'per iteration pay a tenth of their wall time for the events)')
     ap.add_argument('--no-kernel-events', action='store_true',
                     help='no HIP events around the launches of the timed region (no kernel table, no roofline): what the '
                          'event records themselves cost a launch-bound configuration')

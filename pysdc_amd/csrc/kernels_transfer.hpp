@@ -189,7 +189,14 @@ struct NestedArgs {
 template <int TI>
 __global__ __launch_bounds__(256) void k_restrict3_nested(NestedArgs a, unsigned kx_blocks) {
     const unsigned n_out = (unsigned)a.n_out, n_in = (unsigned)a.n_in;
-    const unsigned kb = blockIdx.x % kx_blocks, jb = blockIdx.x / kx_blocks;
+#ifndef SDC_XFER_XCD
+#define SDC_XFER_XCD 1
+#endif
+    // Workgroups are handed to the 8 XCDs round robin (x fastest): with the plain order the two workgroups that share a fine
+    // row sit on different XCDs and each L2 fetches it.  Every XCD takes a contiguous eighth of the j blocks instead.
+    unsigned bxs = blockIdx.x;
+    if (SDC_XFER_XCD && (gridDim.x & 7u) == 0) bxs = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const unsigned kb = bxs % kx_blocks, jb = bxs / kx_blocks;
     const unsigned k = kb * blockDim.x + threadIdx.x, j = jb * blockDim.y + threadIdx.y;
     const unsigned i0 = blockIdx.y * TI, o = blockIdx.z;
     const double* __restrict__ src = a.in + (size_t)o * n_in * n_in * n_in;
@@ -229,8 +236,11 @@ __global__ __launch_bounds__(256) void k_restrict3_nested(NestedArgs a, unsigned
         for (int b = 0; b < 3; ++b) acc = wj[b] != 0.0 ? acc + wj[b] * s[b] : acc;
         return acc;
     };
+#ifndef SDC_RESTRICT_UNROLL
+#define SDC_RESTRICT_UNROLL 1
+#endif
     double tm = plane_sum((2 * i0 + n_in - 1) % n_in);
-#pragma unroll 2
+#pragma unroll SDC_RESTRICT_UNROLL
     for (unsigned ii = 0; ii < (unsigned)TI; ++ii) {
         const unsigned i = i0 + ii;
         const double t0 = plane_sum(2 * i), tp = plane_sum(2 * i + 1);
@@ -250,28 +260,36 @@ __global__ __launch_bounds__(256) void k_restrict3_nested(NestedArgs a, unsigned
 }
 
 // Refinement (iorder = W: even rows copy a coarse value, odd rows interpolate W of them).  A workgroup of 256 threads makes a
-// 16^3 tile of the fine grid from the (8 + W - 1)^3 coarse values it depends on, staged in LDS: contiguous axis first (T1),
-// then the middle one (T2), then the first, whose result is stored or added to what is there (the coarse-grid correction) -
-// the three separable passes with their intermediate fields in LDS instead of HBM.  Thread (jf, kf) of the tile keeps its
-// table rows in registers; the rows of the first axis are uniform over the workgroup.
+// 16^3 tile of the fine grid from the (8 + W - 1)^3 coarse values it depends on, staged in LDS.  The window is worked off
+// plane by plane along the first axis: contiguous axis (T1: one plane of (8 + W - 1) x 16 values in LDS, two buffers), then
+// the middle axis, whose result - one value per thread (jf, kf) and plane - stays in REGISTERS; the first axis then is a sum
+// over a thread's own registers, stored or added to what is there (the coarse-grid correction).  The three separable passes
+// with their intermediate fields on chip; 21 KB of LDS per workgroup, so that five or six of them share a CU and the
+// read-modify-write of one tile runs behind the sums of the others.
+// Even fine indices copy ONE coarse value, odd ones interpolate W: the threads are arranged so that a wave holds rows of one
+// parity and skips the entries with weight zero by a branch that is uniform over the wave.  Sums along the contiguous and
+// the middle axis run in table order; along the first axis in the order of the window (the table's order except where the
+// window wraps around the periodic seam - the same terms).
 //   grid: x = tiles along the contiguous axis, y = tiles along the middle axis, z = tiles along the first axis * fields
 template <int W>
 __global__ __launch_bounds__(256) void k_prolong3_nested(NestedArgs a) {
     constexpr int TC = 8, TF = 16, HW = TC + W - 1, HL = W / 2 - 1;
-    __shared__ double A[HW * HW * HW > HW * TF * TF ? HW * HW * HW : HW * TF * TF];   // coarse window, later T2[x][jf][kf]
-    __shared__ double T1[HW * HW * TF];                                                 // [x][y][kf]
-    __shared__ double WX[TF * W];   // table rows of the first axis for the 16 fine planes of the tile: weights ...
-    __shared__ int LX[TF * W];      // ... and local window positions
+    __shared__ double A[HW * HW * HW];     // coarse window [x][y][z]
+    __shared__ double T1[2][HW * TF];      // one x plane after the contiguous axis: [y][kf]
+    __shared__ double WX[TF * W];          // rows of the first axis for the 16 fine planes of the tile, by window slot
     const int n_out = a.n_out, n_in = a.n_in;
     const int tiles = n_in / TC;
-    const int tz = blockIdx.x, ty = blockIdx.y, tx = blockIdx.z % tiles, o = blockIdx.z / tiles;
-    // Even fine indices copy ONE coarse value, odd ones interpolate W: the threads are arranged so that a wave holds rows of
-    // one parity - waves 0, 2 the even kf (first stage) / jf (second, third stage), waves 1, 3 the odd ones - and the entries
-    // with weight zero are skipped by a branch that is uniform over the wave (3.5 LDS reads per value instead of 6).
+    int tz = blockIdx.x, ty = blockIdx.y;
+    if (SDC_XFER_XCD && ((gridDim.x * gridDim.y) & 7u) == 0) {   // every XCD a contiguous eighth of the (ty, tz) tiles of a slab
+        const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y, per = (gridDim.x * gridDim.y) >> 3;
+        const unsigned l2 = (lin & 7u) * per + (lin >> 3);
+        tz = (int)(l2 % gridDim.x);
+        ty = (int)(l2 / gridDim.x);
+    }
+    const int tx = blockIdx.z % tiles, o = blockIdx.z / tiles;
     const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63, par = wv & 1;
-    const int kf1 = 2 * (ln & 7) + par, xy1 = (ln >> 3) + 8 * (wv >> 1);        // first stage: 16 (x, y) rows per round
-    const int kf = ln & 15, jf = 2 * ((ln >> 4) + 4 * (wv >> 1)) + par;          // second / third stage, T2 slot jf * 16 + kf
-    const int slot = jf * TF + kf;
+    const int kf1 = 2 * (ln & 7) + par, y1 = (ln >> 3) + 8 * (wv >> 1);          // first stage: row y1 (< HW) of the plane
+    const int kf = ln & 15, jf = 2 * ((ln >> 4) + 4 * (wv >> 1)) + par;          // second / third stage
     const double* __restrict__ src = a.in + (size_t)o * n_in * n_in * n_in;
     const double* __restrict__ sub = a.in_minus ? a.in_minus + (size_t)o * n_in * n_in * n_in : nullptr;
     // window origin per axis (coarse index of local position 0); every sum below lies in [0, 2 n_in): one conditional
@@ -285,11 +303,7 @@ __global__ __launch_bounds__(256) void k_prolong3_nested(NestedArgs a) {
         if (sub) v = v - sub[g];
         A[e] = v;
     }
-    if (tid < TF * W) {
-        const int fi = tid / W, c = tid % W, ig = tx * TF + fi;
-        WX[tid] = a.w[(size_t)c * n_out + ig];
-        LX[tid] = wrap(a.idx[(size_t)c * n_out + ig] - ox + n_in) * (TF * TF);
-    }
+    if (tid < TF * W) WX[tid] = 0.0;
     // this thread's table rows along the contiguous (kf1) and the middle (jf) axis: weights and LOCAL window positions
     double wz[W], wy[W];
     int lz[W], ly[W];
@@ -303,32 +317,44 @@ __global__ __launch_bounds__(256) void k_prolong3_nested(NestedArgs a) {
             ly[c] = wrap(a.idx[(size_t)c * n_out + jg] - oy + n_in) * TF;
         }
     }
-    __syncthreads();
-    for (int xy = xy1; xy < HW * HW; xy += 16) {
-        const double* __restrict__ row = A + xy * HW;
-        double acc = 0.0;
+    double* __restrict__ dst = a.out + (size_t)o * n_out * n_out * n_out +
+                               ((size_t)(tx * TF) * n_out + (size_t)(ty * TF + jf)) * n_out + (size_t)(tz * TF + kf);
+    const size_t plane = (size_t)n_out * n_out;
+#ifndef SDC_PROLONG_OLD_LATE
+#define SDC_PROLONG_OLD_LATE 0
+#endif
+    // (the fine values the tile is added to are fetched now: their latency hides behind everything below)
+    double old[TF];
+    if (!SDC_PROLONG_OLD_LATE && a.accumulate) {
 #pragma unroll
-        for (int c = 0; c < W; ++c)
-            if (wz[c] != 0.0) acc += wz[c] * row[lz[c]];
-        T1[xy * TF + kf1] = acc;
+        for (int fi = 0; fi < TF; ++fi) old[fi] = dst[fi * plane];
     }
     __syncthreads();
+    if (tid < TF * W) {   // entry c of fine plane fi sits in window slot (local position) - fi / 2
+        const int fi = tid / W, c = tid % W, ig = tx * TF + fi;
+        const double w = a.w[(size_t)c * n_out + ig];
+        if (w != 0.0) WX[fi * W + wrap(a.idx[(size_t)c * n_out + ig] - ox + n_in) - (fi >> 1)] = w;
+    }
+    double t2[HW];
 #pragma unroll
     for (int x = 0; x < HW; ++x) {
-        const double* __restrict__ pl = T1 + x * HW * TF + kf;
+        if (y1 < HW) {
+            const double* __restrict__ row = A + (x * HW + y1) * HW;
+            double acc = 0.0;
+#pragma unroll
+            for (int c = 0; c < W; ++c)
+                if (wz[c] != 0.0) acc += wz[c] * row[lz[c]];
+            T1[x & 1][y1 * TF + kf1] = acc;
+        }
+        __syncthreads();   // (two buffers: plane x + 1 is written while stragglers still read plane x - never plane x + 2)
+        const double* __restrict__ pl = T1[x & 1] + kf;
         double acc = 0.0;
 #pragma unroll
         for (int c = 0; c < W; ++c)
             if (wy[c] != 0.0) acc += wy[c] * pl[ly[c]];
-        A[x * TF * TF + slot] = acc;   // T2 (the coarse window is not read any more: every thread passed the barrier above)
+        t2[x] = acc;
     }
-    __syncthreads();
-    double* __restrict__ dst = a.out + (size_t)o * n_out * n_out * n_out +
-                               ((size_t)(tx * TF) * n_out + (size_t)(ty * TF + jf)) * n_out + (size_t)(tz * TF + kf);
-    const size_t plane = (size_t)n_out * n_out;
-    // (the fine values the tile is added to are fetched before the sums: their latency hides behind the LDS reads)
-    double old[TF];
-    if (a.accumulate) {
+    if (SDC_PROLONG_OLD_LATE && a.accumulate) {
 #pragma unroll
         for (int fi = 0; fi < TF; ++fi) old[fi] = dst[fi * plane];
     }
@@ -336,13 +362,13 @@ __global__ __launch_bounds__(256) void k_prolong3_nested(NestedArgs a) {
     for (int fi = 0; fi < TF; ++fi) {
         double acc = 0.0;
 #pragma unroll
-        for (int c = 0; c < W; ++c) {
+        for (int p = 0; p < W; ++p) {
             // (the row of the first axis is the same for the whole workgroup: scalar weight, scalar branch)
-            const double wl = WX[fi * W + c];
+            const double wl = WX[fi * W + p];
             const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)__double2loint(wl));
             const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)__double2hiint(wl));
             const double wi = __hiloint2double((int)hi, (int)lo);
-            if (wi != 0.0) acc += wi * A[__builtin_amdgcn_readfirstlane(LX[fi * W + c]) + slot];
+            if (wi != 0.0) acc += wi * t2[(fi >> 1) + p];
         }
         dst[fi * plane] = a.accumulate ? old[fi] + acc : acc;
     }

@@ -180,6 +180,16 @@ class DeviceBacked:
         self._uend_view = None
         self._res_cache = None
         self.integrals_wanted = False   # set by a BaseTransfer whose fine level this is: compute_residual brings integrate() along
+        # change counters of u[0] and f[0] (every path that writes them bumps): lets a transfer recognise a start value it has
+        # restricted already (serial MLSDC restricts the same u[0] in every iteration of a step, core/base_transfer.py:113-118)
+        self._tok_u0 = 0
+        self._tok_f0 = 0
+
+    def _bump(self, u0=False, f0=False):
+        if u0:
+            self._tok_u0 = getattr(self, '_tok_u0', 0) + 1
+        if f0:
+            self._tok_f0 = getattr(self, '_tok_f0', 0) + 1
 
     def settle_residual(self):
         """a residual that was put off (LevelStatus: evaluated when read) is evaluated NOW: the state it belongs to - u[0] in
@@ -248,6 +258,7 @@ class DeviceBacked:
         """device state was written outside the engine's own sweep calls: drop the cached residual and tell
         the engine which cached transforms are stale (include/sdcmi.h: sdc_invalidate_spectra)."""
         self._res_cache = None
+        self._bump(u0=slot is None or (slot == Lb.SLOT_U and m == 0), f0=slot is None or (slot == Lb.SLOT_F and m == 0))
         e = self._engine_obj
         if e is None:
             return
@@ -329,6 +340,7 @@ class ForeignLevelState(DeviceBacked):
                 continue
             sl.invalidate()
             self._res_cache = None
+            self._bump(True, True)
             if name == 'tau' and self._engine_obj is not None:
                 self._engine_obj.set_tau_active(False)
             for m, v in enumerate(cur):
@@ -429,16 +441,19 @@ class Level(DeviceBacked):
         self.engine.replace_u0(src.ptr)
         self._u.mark([0])
         self._res_cache = None
+        self._bump(u0=True)
 
     def received_u0(self):
         """the engine has taken a new u[0] from its communicator (sdc_comm_*: inbox -> sdc_replace_u0 inside the library)"""
         self._lists()
         self._u.mark([0])
         self._res_cache = None
+        self._bump(u0=True)
 
     def refresh_f0(self):
         """f[0] = f(u[0]) after u[0] was replaced (controller_MPI.py:233, controller_nonMPI.py:284).  Nothing on
         the sweep path reads f[0]; an engine-backed problem evaluates it when it is asked for."""
+        self._bump(f0=True)
         if getattr(self.prob, 'fused', False) and self._engine_obj is not None:
             Lb.check(self._engine_obj.lib.sdc_defer_f0(self._engine_obj.ctx), self._engine_obj.ctx)
             self._f.mark([0])
@@ -451,6 +466,7 @@ class Level(DeviceBacked):
         self.engine.advance()
         self._u.mark([0])
         self._res_cache = None
+        self._bump(True, True)
         self._uend_valid = False  # (the end-value buffer of the finished step now holds this step's start value)
 
     def start_from_wire(self):
@@ -459,6 +475,7 @@ class Level(DeviceBacked):
         self.engine.start_from_spectrum()
         self._u.mark([0])
         self._res_cache = None
+        self._bump(True, True)
         self._uend_valid = False
 
     def reset_level(self, reset_status=True):
@@ -477,6 +494,7 @@ class Level(DeviceBacked):
         self.residual = [None] * M
         self.increment = [None] * M
         self._res_cache = None
+        self._bump(True, True)
         if reset_status:
             self.status = LevelStatus()
 

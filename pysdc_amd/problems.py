@@ -625,6 +625,7 @@ class _SpectralLaplacianIMEX(Problem):
     dtype_f = hip_imex_mesh
     ncomp = 2
     fused = True  # the engine sweeps node by node on the device (nonlinear explicit part: sdc_sweep -> sweep_nodewise)
+    rhs_autonomous = True   # eval_f(u, t) does not depend on t (a transfer may keep f(u[0]) of a start value it has seen)
 
     def _symbol(self):
         n = self.nvars[0]

@@ -185,6 +185,8 @@ class Sweeper:
             D.u.mark(range(M + 1))
             D.f.mark(range(M + 1))
             D._res_cache = None
+            if hasattr(D, '_bump'):
+                D._bump(f0=True)
         else:
             return self._predict_generic()
         L.status.unlocked = True
