@@ -49,7 +49,9 @@ enum sdc_expl_kind {
     SDC_EXPL_NONE = 0,    /* fully implicit problem (generic_implicit) */
     SDC_EXPL_STENCIL = 1, /* f.expl = B u with a periodic FD stencil (advection part of config 3) */
     SDC_EXPL_FORCING = 2, /* f.expl = P(x) g(t), independent of u (heatNd_forced, HeatEquation_ND_FD.py:162-204) */
-    SDC_EXPL_REACTION = 3 /* f.expl = pointwise nonlinear function of u (Allen-Cahn); swept node by node */
+    SDC_EXPL_REACTION = 3, /* f.expl = pointwise nonlinear function of u (Allen-Cahn); swept node by node */
+    SDC_EXPL_SYMBOL = 4    /* f.expl = B u with B given by its Fourier symbol (sdc_set_symbol which = 1): the explicit advection
+                            * part -c d/dx of AdvectionDiffusionEquation_1D_FFT.py:82-87 beside the implicit diffusion symbol */
 };
 
 /* ---- context ----------------------------------------------------------------------------------------- */
@@ -73,8 +75,11 @@ int sdc_set_coeffs(sdc_ctx* ctx, const double* Qmat, const double* QI, const dou
 int sdc_set_stencil(sdc_ctx* ctx, int which, int npts, const int* offsets, const double* weights);
 /* Implicit (which = 0) / explicit (1) operator given directly by its 1-D Fourier symbol, n complex values
  * (re, im interleaved); the N-D symbol is the sum over the axes.  Used for the pseudo-spectral Laplacian
- * -(2 pi k / L)^2 of AllenCahn_2D_FFT.py:84-93 / generic_MPIFFT_Laplacian.py:113-124; eval_f then applies the
- * operator through the FFT pipeline instead of a stencil. */
+ * -(2 pi k / L)^2 of AllenCahn_2D_FFT.py:84-93 / generic_MPIFFT_Laplacian.py:113-124 and for the operators nu d2/dx2
+ * (implicit) and -c d/dx (explicit, which = 1: sets SDC_EXPL_SYMBOL; needs the implicit symbol too) of
+ * AdvectionDiffusionEquation_1D_FFT.py:63-72; eval_f then applies the operator(s) through the FFT pipeline instead of a
+ * stencil.  The table covers ALL n modes of the complex transform the engine uses (k and n - k conjugate for a real
+ * operator); like numpy's irfft the result is the real part, so the imaginary part a Nyquist entry produces is dropped. */
 int sdc_set_symbol(sdc_ctx* ctx, int which, const double* table);
 /* Pointwise explicit term (SDC_EXPL_REACTION): kind 1: p0 * u * (1 - u^nu)  (AllenCahn_2D_FFT.py:140-141, p0 =
  * 1/eps^2); kind 2: p0 * u (1-u)(1-2u) - p1 * u (1-u)  (AllenCahn_MPIFFT.py:83-85, p0 = -2/eps^2, p1 = 6 dw). */

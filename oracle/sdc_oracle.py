@@ -1080,3 +1080,77 @@ class AllenCahnND:
         r2 = (X[0] - 0.5) ** 2 + (X[1] - 0.5) ** 2 if self.init_type == 'circle' else sum((Xi - 0.5) ** 2 for Xi in X)
         return np.broadcast_to(0.5 * (1.0 + np.tanh((self.radius - np.sqrt(r2)) / (np.sqrt(2) * self.eps))),
                                self.nvars).copy()
+
+
+# ----------------------------------------------------------------------------------------------
+# pseudo-spectral advection-diffusion in 1-D (problem_classes/AdvectionDiffusionEquation_1D_FFT.py)
+# ----------------------------------------------------------------------------------------------
+class AdvDiff1DIMEX:
+    """AdvectionDiffusionEquation_1D_FFT.py:52-164: ddx = i kx, lap = -kx^2 on the rfft layout (:63-72), eval_f with the
+    diffusion part implicit and the advection part explicit (:74-97), solve_system (:99-124), u_exact (:126-164)."""
+
+    imex = True
+
+    def __init__(self, nvars=256, c=1.0, freq=-1, nu=0.02, L=1.0):
+        self.nvars, self.c, self.freq, self.nu, self.L = (int(nvars),), c, freq, nu, L
+        self.ndim = 1
+        n = int(nvars)
+        self.xvalues = np.array([i * L / n - L / 2.0 for i in range(n)])
+        kx = np.zeros(n // 2 + 1)
+        for i in range(0, len(kx)):
+            kx[i] = 2 * np.pi / L * i
+        self.ddx = kx * 1j
+        self.lap = -(kx**2)
+        self.work_counters = {'rhs': _Counter()}
+
+    def u_init(self):
+        return np.zeros(self.nvars)
+
+    def f_init(self):
+        return np.zeros((2,) + self.nvars)
+
+    def eval_f(self, u, t):
+        f = self.f_init()
+        tmp_u = np.fft.rfft(u)
+        f[0][:] = np.fft.irfft(self.nu * self.lap * tmp_u)
+        f[1][:] = np.fft.irfft(-self.c * self.ddx * tmp_u)
+        self.work_counters['rhs']()
+        return f
+
+    def solve_system(self, rhs, factor, u0, t):
+        return np.fft.irfft(np.fft.rfft(rhs) / (1.0 - self.nu * factor * self.lap))
+
+    def u_exact(self, t):
+        n = self.nvars[0]
+        me = np.zeros(n)
+        if self.freq > 0:
+            omega = 2.0 * np.pi * self.freq
+            me[:] = np.sin(omega * (self.xvalues - self.c * t)) * np.exp(-t * self.nu * omega**2)
+        elif self.freq == 0:
+            np.random.seed(1)
+            me[:] = np.random.rand(n)
+        else:
+            t00 = 0.08
+            nbox = int(np.ceil(np.sqrt(4.0 * self.nu * (t00 + t) * 37.0 / (self.L**2))))
+            for k in range(-nbox, nbox + 1):
+                for i in range(n):
+                    x = self.xvalues[i] - self.c * t + k * self.L
+                    me[i] += np.sqrt(t00) / np.sqrt(t00 + t) * np.exp(-(x**2) / (4.0 * self.nu * (t00 + t)))
+        return me
+
+
+class AdvDiff1DImplicit(AdvDiff1DIMEX):
+    """AdvectionDiffusionEquation_1D_FFT.py:167-238: both parts implicit; eval_f never counts (:203 names the counter without
+    calling it)."""
+
+    imex = False
+
+    def f_init(self):
+        return np.zeros(self.nvars)
+
+    def eval_f(self, u, t):
+        tmp_u = np.fft.rfft(u)
+        return np.fft.irfft(self.nu * self.lap * tmp_u - self.c * self.ddx * tmp_u)
+
+    def solve_system(self, rhs, factor, u0, t):
+        return np.fft.irfft(np.fft.rfft(rhs) / (1.0 - factor * (self.nu * self.lap - self.c * self.ddx)))

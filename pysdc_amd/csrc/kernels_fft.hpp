@@ -561,7 +561,9 @@ struct ZArgs {
     double invN;
     int nf, ndim, coupled;
     int apply;  // 1: multiply by the symbol (operator application) instead of dividing by 1 - alpha*symbol
-    int dup;    // 1: two fields out of ONE input (field 0): the solution and the operator applied to it
+    int dup;    // 1: several fields out of ONE input (field 0).  Solve (apply = 0): the solution, the implicit operator applied
+                // to it and - nf = 3 - the explicit operator (lamE) applied to it; apply = 1, nf = 2: the implicit and the
+                // explicit operator applied to the input (eval_f of a problem whose two parts are given by their symbols)
 };
 
 // forward FFT along the contiguous axis, node-coupled implicit solve in Fourier space, inverse FFT.
@@ -630,7 +632,13 @@ __global__ __launch_bounds__(z_lines_per_block<N>() * (N / fft_elems(N)) * MAXM,
                         }
                     }
                     const double al = a.alpha[m];
-                    if (a.dup && m == 1) u[m] = cmul(u[0], lam);  // the operator applied to the solution
+                    // The operators applied to the SOLUTION act on the real field the inverse transform makes of it: its modes 0
+                    // and N/2 are real (numpy's irfft drops their imaginary parts; a symbol with an odd derivative is not real at
+                    // N/2 - AdvectionDiffusionEquation_1D_FFT.py:227-238 followed by :203-207).  1-D lines only (in more
+                    // dimensions the caller evaluates through real space when the symbol is complex).
+                    if (a.dup && !a.apply && m == 1 && a.ndim == 1 && (kz == 0 || 2 * kz == N)) u[0].y = 0.0;
+                    if (a.dup && m == 1) u[m] = a.apply ? cmul(acc, mu) : cmul(u[0], lam);  // (every column of a dup launch holds field 0's line)
+                    else if (a.dup && m == 2) u[m] = cmul(u[0], mu);
                     else u[m] = a.apply ? cmul(acc, lam) : cmul(acc, cinv_fast(cd{1.0 - al * lam.x, -al * lam.y}));
                     buf[(m * LPB + ll) * CH + kk] = cscale(u[m], a.invN);
                 }

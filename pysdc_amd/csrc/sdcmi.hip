@@ -38,6 +38,9 @@
 // host side
 // ------------------------------------------------------------------------------------------------------
 static int ensure_work(sdc_ctx* c);
+// work spectra a context holds: one per node - in 1-D (lines: next to nothing) at least three, so that a problem whose two
+// parts are given by symbols gets its solution and both parts out of one transform whatever the number of nodes
+static inline int work_fields(const sdc_ctx* c) { return c->ndim == 1 && c->M < 3 ? 3 : c->M; }
 // the FFT kernels transform lines of length 2^p <= 1024 (2048 in 1-D and 2-D), 3 * 2^p from 24 to 768 and 5 * 2^p from 40 to 640
 // (fft.hpp)
 static inline bool fourier_ok(const sdc_ctx* c) {
@@ -335,6 +338,7 @@ static int fft_pipeline_n(sdc_ctx* c, int nf, const FieldPtrs& p, ZArgs& z, cons
     z.fstride = c->Nc;
     z.tw = c->tw;
     z.lamI = c->lamI;
+    if (z.dup && c->expl_kind == SDC_EXPL_SYMBOL) z.lamE = c->lamE;   // (the explicit operator rides along: ZArgs::dup)
     z.nf = nf;
     z.ndim = c->ndim;
     z.invN = 1.0 / (double)c->N;
@@ -1527,6 +1531,10 @@ int sdc_set_symbol(sdc_ctx* c, int which, const double* table) {
     HIPCHK(c, hipMemcpyAsync(*dst, table, sizeof(cd) * c->n, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->have_stencil[which] = true;
+    if (which == 1) {
+        if (c->ncomp != 2) return fail(c, SDC_ERR_PARAM, "explicit part needs ncomp == 2");
+        c->expl_kind = SDC_EXPL_SYMBOL;
+    }
     if (which == 0) {
         c->spectral_op = true;
         c->sym_table_real = true;
@@ -1554,7 +1562,7 @@ int sdc_set_reaction(sdc_ctx* c, int kind, double p0, double p1, int nu) {
 }
 
 int sdc_set_expl_kind(sdc_ctx* c, int kind) {
-    if (!c || kind < 0 || kind > 3) return fail(c, SDC_ERR_PARAM, "bad explicit kind");
+    if (!c || kind < 0 || kind > 4) return fail(c, SDC_ERR_PARAM, "bad explicit kind");
     if (kind != SDC_EXPL_NONE && c->ncomp != 2) return fail(c, SDC_ERR_PARAM, "explicit part needs ncomp == 2");
     c->expl_kind = kind;
     return SDC_OK;
@@ -1596,8 +1604,9 @@ static int ensure_work(sdc_ctx* c) {
     FLUSH_X(c);               // (residual lines that still wait for their last pass)
     c->rlines_valid = false;  // whoever asks for the work spectra is about to overwrite them (a sweep says so again afterwards)
     if (!c->W) {
-        HIPCHK(c, hipMalloc((void**)&c->W, sizeof(cd) * c->Nc * c->M));
-        c->bytes += sizeof(cd) * c->Nc * c->M;
+        const int nw = work_fields(c);
+        HIPCHK(c, hipMalloc((void**)&c->W, sizeof(cd) * c->Nc * nw));
+        c->bytes += sizeof(cd) * c->Nc * nw;
     }
     return SDC_OK;
 }
@@ -1978,7 +1987,15 @@ int sdc_eval_f(sdc_ctx* c, const double* u, double g_t, double* f_impl, double* 
                 rq.out = f_expl;
                 react_done = true;
             }
-            int rc0 = fft_pipeline(c, 1, p, z, rq);
+            int nfe = 1;
+            if (f_expl && c->expl_kind == SDC_EXPL_SYMBOL) {   // both parts from ONE forward transform
+                if (!c->lamE) return fail(c, SDC_ERR_STATE, "explicit symbol not set (sdc_set_symbol which=1)");
+                if (work_fields(c) < 2) return fail(c, SDC_ERR_UNSUPPORTED, "two work spectra needed (num_nodes >= 2)");
+                p.out[1] = f_expl;
+                z.dup = 1;
+                nfe = 2;
+            }
+            int rc0 = fft_pipeline(c, nfe, p, z, rq);
             if (rc0 != SDC_OK) return rc0;
         } else {
             const double* in1[1] = {u};
@@ -2206,7 +2223,10 @@ static int sweep_nodewise(sdc_ctx* c, double dt, bool keep_guess = false) {
         const double alpha = dt * c->QI[m + 1][m + 1];
         // operator given by its symbol, direct solve: solve and implicit evaluation share one forward transform - and the
         // terms of the nodes before this one are added by that transform's first pass as it reads the gathered field
-        const bool shared_fwd = c->spectral_op && !keep_guess && c->solver_kind == 0 && c->M >= 2;  // (two work spectra needed)
+        // (a complex symbol in more than one dimension: solve and evaluation each go through real space - the projection onto
+        // real fields between them is part of the result, see k_fftz_solve)
+        const bool shared_fwd = c->spectral_op && !keep_guess && c->solver_kind == 0 && work_fields(c) >= 2 &&  // (two work spectra needed)
+                                (c->ndim == 1 || (c->sym_table_real && c->expl_kind != SDC_EXPL_SYMBOL));
         const bool rhs_on_the_way = shared_fwd && c->ndim >= 2 && SDC_FUSE_NODE_RHS;
         LinTerms lin;
         memset(&lin, 0, sizeof lin);
@@ -2279,16 +2299,36 @@ static int sweep_nodewise(sdc_ctx* c, double dt, bool keep_guess = false) {
             p2.out[1] = c->F + ((size_t)(m + 1) * c->ncomp) * c->N;
             z2.alpha[0] = alpha;
             z2.dup = 1;
-            if (imex && c->expl_kind != SDC_EXPL_REACTION)
-                return fail(c, SDC_ERR_UNSUPPORTED, "explicit part of a symbol-only operator must be a reaction term");
+            const bool esym = imex && c->expl_kind == SDC_EXPL_SYMBOL;
+            if (imex && c->expl_kind != SDC_EXPL_REACTION && !esym)
+                return fail(c, SDC_ERR_UNSUPPORTED, "explicit part of a symbol-only operator must be a reaction term or a symbol");
+            if (esym && work_fields(c) < 3) {
+                // (fewer than three work spectra: solve + implicit part now, the explicit operator by an evaluation of its own)
+                rc = fft_pipeline(c, 2, p2, z2, ReactReq(), lin.n ? &lin : nullptr);
+                if (rc == SDC_OK) {
+                    FieldPtrs pe;
+                    memset(&pe, 0, sizeof pe);
+                    ZArgs ze;
+                    memset(&ze, 0, sizeof ze);
+                    pe.in[0] = um;
+                    pe.out[0] = p2.out[1];   // (the implicit part once more: same bits) ...
+                    pe.out[1] = c->F + ((size_t)(m + 1) * c->ncomp + 1) * c->N;   // ... and the explicit one
+                    ze.apply = 1;
+                    ze.dup = 1;
+                    rc = fft_pipeline(c, 2, pe, ze);
+                }
+                if (rc != SDC_OK) return rc;
+                continue;
+            }
+            if (esym) p2.out[2] = c->F + ((size_t)(m + 1) * c->ncomp + 1) * c->N;
             ReactReq rq2;
-            if (imex && c->ndim >= 2) {  // f_expl(u_m) leaves the last inverse pass together with u_m
+            if (imex && !esym && c->ndim >= 2) {  // f_expl(u_m) leaves the last inverse pass together with u_m
                 rq2.where = 2;
                 rq2.out = c->F + ((size_t)(m + 1) * c->ncomp + 1) * c->N;
             }
-            rc = fft_pipeline(c, 2, p2, z2, rq2, lin.n ? &lin : nullptr);
+            rc = fft_pipeline(c, esym ? 3 : 2, p2, z2, rq2, lin.n ? &lin : nullptr);
             if (rc != SDC_OK) return rc;
-            if (imex && rq2.where == 0) {
+            if (imex && !esym && rq2.where == 0) {
                 LaunchTimer lt(c, "reaction");
                 hipLaunchKernelGGL(k_reaction, dim3(grid_for(c->N, 256)), dim3(256), 0, c->stream, um,
                                    c->F + ((size_t)(m + 1) * c->ncomp + 1) * c->N, c->N, c->react_kind, c->react_p0,

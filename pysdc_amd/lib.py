@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get('PYSDC_AMD_LIB') or os.path.join(_HERE, 'libsdcmi.so')
 SLOT_U, SLOT_F, SLOT_TAU, SLOT_UEND, SLOT_WORK = 0, 1, 2, 3, 4
 RES_TYPES = {'full_abs': 0, 'last_abs': 1, 'full_rel': 2, 'last_rel': 3}
 GUESS = {'spread': 0, 'copy': 1, 'zero': 2, 'random': 3}
-EXPL_NONE, EXPL_STENCIL, EXPL_FORCING, EXPL_REACTION = 0, 1, 2, 3
+EXPL_NONE, EXPL_STENCIL, EXPL_FORCING, EXPL_REACTION, EXPL_SYMBOL = 0, 1, 2, 3, 4
 
 ERR_PARAM, ERR_HIP, ERR_STATE, ERR_UNSUPPORTED, ERR_NOMEM, ERR_NEWTON, ERR_COMM = -1, -2, -3, -4, -5, -6, -7
 

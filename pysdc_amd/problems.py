@@ -754,3 +754,121 @@ class allencahn_imex(_SpectralLaplacianIMEX):
             raise NotImplementedError(f'init_type {self.init_type!r}')
         me = 0.5 * (1.0 + np.tanh((self.radius - np.sqrt(r2)) / (np.sqrt(2) * self.eps)))
         return self._from_host(np.broadcast_to(me, self.nvars))
+
+
+class advectiondiffusion1d_imex(Problem):
+    """pySDC/implementations/problem_classes/AdvectionDiffusionEquation_1D_FFT.py:9-164:  u_t = -c u_x + nu u_xx on
+    [-L/2, L/2), periodic, pseudo-spectral; diffusion implicit, advection explicit.  The reference works on the half spectrum
+    of numpy's rfft / irfft; the engine transforms the promoted complex line, so both operators are handed over as symbols on
+    all n modes (mode n - k the conjugate of mode k) - irfft's rule that the imaginary part a Nyquist entry produces is dropped
+    is the engine's "real part" (include/sdcmi.h: sdc_set_symbol).  SURVEY 2.1: the IMEX parity anchor."""
+
+    dtype_u = hip_mesh
+    dtype_f = hip_imex_mesh
+    ncomp = 2
+    fused = True            # sdc_sweep runs the node loop on the device (sweep_nodewise: solve, A u and B u from one transform)
+    rhs_autonomous = True
+
+    def __init__(self, nvars=256, c=1.0, freq=-1, nu=0.02, L=1.0):
+        super().__init__(init=(nvars, None, np.dtype('float64')))
+        self._makeAttributeAndRegister('nvars', 'c', 'freq', 'nu', 'L', localVars=locals(), readOnly=True)
+        if (self.nvars) % 2 != 0:
+            raise ProblemError('setup requires nvars = 2^p')
+        if not L_fft_ok(int(nvars)):
+            raise ProblemError(f'the line transforms of the engine take n = 2^p (<= 2048), 3 * 2^p (24 .. 768) and 5 * 2^p (40 .. 640), '
+                               f'got nvars = {nvars}')
+        self.xvalues = np.array([i * self.L / self.nvars - self.L / 2.0 for i in range(self.nvars)])
+        kx = np.zeros(self.init[0] // 2 + 1)
+        for i in range(0, len(kx)):
+            kx[i] = 2 * np.pi / self.L * i
+        self.ddx = kx * 1j
+        self.lap = -(kx**2)
+        self.work_counters['rhs'] = WorkCounter()
+        self.engine_nvars = (int(nvars),)
+
+    def _full(self, half):
+        """a symbol given on the modes 0 .. n/2 of rfft continued to all n modes of the complex transform"""
+        n = int(self.nvars)
+        full = np.empty(n, dtype=complex)
+        full[: n // 2 + 1] = half
+        full[n // 2 + 1:] = np.conj(half[1: n // 2][::-1])
+        return full
+
+    def configure_engine(self, engine):
+        engine.set_symbol(0, self._full(self.nu * self.lap + 0j))
+        engine.set_symbol(1, self._full(-self.c * self.ddx))
+
+    @classmethod
+    def get_default_sweeper_class(cls):
+        from pysdc_amd.sweepers import imex_1st_order
+
+        return imex_1st_order
+
+    def eval_f(self, u, t):
+        f = self._out_f()
+        self.engine.eval_f(u.ptr, 0.0, f.impl.ptr, f.expl.ptr)
+        self.work_counters['rhs']()
+        return f
+
+    def solve_system(self, rhs, factor, u0, t):
+        me = self._out_u()
+        self.engine.solve(rhs.ptr, float(factor), me.ptr)
+        return me
+
+    def _from_host(self, values):
+        sol = self._out_u()
+        sol[:] = values
+        return sol
+
+    def u_exact(self, t):
+        """AdvectionDiffusionEquation_1D_FFT.py:130-164 (host arithmetic of the reference, result on the device)"""
+        me = np.zeros(self.nvars)
+        if self.freq > 0:
+            omega = 2.0 * np.pi * self.freq
+            me[:] = np.sin(omega * (self.xvalues - self.c * t)) * np.exp(-t * self.nu * omega**2)
+        elif self.freq == 0:
+            np.random.seed(1)
+            me[:] = np.random.rand(self.nvars)
+        else:
+            t00 = 0.08
+            if self.nu > 0:
+                nbox = int(np.ceil(np.sqrt(4.0 * self.nu * (t00 + t) * 37.0 / (self.L**2))))
+                for k in range(-nbox, nbox + 1):
+                    for i in range(self.init[0]):
+                        x = self.xvalues[i] - self.c * t + k * self.L
+                        me[i] += np.sqrt(t00) / np.sqrt(t00 + t) * np.exp(-(x**2) / (4.0 * self.nu * (t00 + t)))
+            else:
+                raise ProblemError('There is no exact solution implemented for negative frequency and negative nu!')
+        return self._from_host(me)
+
+
+class advectiondiffusion1d_implicit(advectiondiffusion1d_imex):
+    """AdvectionDiffusionEquation_1D_FFT.py:167-238: the same equation with both parts implicit - one complex symbol
+    nu lap - c ddx that is applied (eval_f) and inverted (solve_system).  Like the reference's eval_f (:203, a statement
+    without a call) the 'rhs' counter is never incremented."""
+
+    dtype_f = hip_mesh
+    ncomp = 1
+
+    def configure_engine(self, engine):
+        engine.set_symbol(0, self._full(self.nu * self.lap - self.c * self.ddx))
+
+    @classmethod
+    def get_default_sweeper_class(cls):
+        from pysdc_amd.sweepers import generic_implicit
+
+        return generic_implicit
+
+    def eval_f(self, u, t):
+        f = self._out_f()
+        self.engine.eval_f(u.ptr, 0.0, f.ptr)
+        return f
+
+
+def L_fft_ok(n):
+    """line lengths the engine's Stockham kernels take (csrc/fft.hpp: fft_length_ok), up to 2048"""
+    if n < 2 or n > 2048 or n % 15 == 0:
+        return False
+    odd = 3 if n % 3 == 0 else (5 if n % 5 == 0 else 1)
+    m = n // odd
+    return (m & (m - 1)) == 0 and (odd != 3 or 24 <= n <= 768) and (odd != 5 or 40 <= n <= 640)

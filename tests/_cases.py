@@ -35,6 +35,10 @@ def make_oracle_problem(prob, pp):
         return O.AdvectionDiffusionIMEX(**pp)
     if prob == 'vanderpol':
         return O.VanDerPol(**pp)
+    if prob == 'ad1d_imex':
+        return O.AdvDiff1DIMEX(**pp)
+    if prob == 'ad1d_implicit':
+        return O.AdvDiff1DImplicit(**pp)
     if prob == 'allencahn2d':
         return O.AllenCahn2D(**pp)
     if prob == 'allencahnNd':

@@ -11,7 +11,7 @@ own entry points, switched on by environment variables (or call the function aft
 GOLDEN_FFT=1 fft_transfer_main (transfer_fft.npz, runs_ac_fft.npz), GOLDEN_RELAY=1 relay_main (runs_relay.npz),
 GOLDEN_CG=1 cg_main (sweeps_cg.npz), GOLDEN_VDPJ=1 vdp_jacobian_main (vdp_jacobian.npz), GOLDEN_DML=1
 dirichlet_ml_main (transfer_dirichlet.npz, runs_ml_dirichlet.npz), GOLDEN_GUESS=1 guess_main (sweeps_guess.npz), GOLDEN_SKIP=1 skip_main (runs_skip.npz), GOLDEN_RELAY8=1 relay8_main (runs_relay8.npz),
-GOLDEN_BIG3D=1 big3d_main (sweeps_big3d.npz), GOLDEN_CFG5=1 cfg5_main (runs_cfg5.npz), GOLDEN_ML8=1 ml8_main (runs_ml8.npz), GOLDEN_DND=1 dirichlet_nd_main (sweeps_dirichlet_nd.npz, runs_dirichlet_nd.npz), GOLDEN_NSW2=1 nsweeps2_main (runs_nsweeps2.npz), GOLDEN_PIN1024=1 pin1024_main (sweeps_pin1024.npz, 20 minutes), GOLDEN_GMRES=1 gmres_main (sweeps_gmres.npz), GOLDEN_DHO=1 dirichlet_ho_main (sweeps_dirichlet_ho.npz, runs_dirichlet_ho.npz, dirichlet_ho_matrices.npz), GOLDEN_BC=1 boundary_main (boundary_matrices.npz, sweeps_neumann.npz, runs_neumann.npz), GOLDEN_PIN512=1 pin512_main (sweeps_pin512.npz), GOLDEN_R3=1 radix3_main (sweeps_radix3.npz, runs_radix3.npz), GOLDEN_R5=1 radix5_main (sweeps_radix5.npz, runs_radix5.npz);
+GOLDEN_BIG3D=1 big3d_main (sweeps_big3d.npz), GOLDEN_CFG5=1 cfg5_main (runs_cfg5.npz), GOLDEN_ML8=1 ml8_main (runs_ml8.npz), GOLDEN_DND=1 dirichlet_nd_main (sweeps_dirichlet_nd.npz, runs_dirichlet_nd.npz), GOLDEN_NSW2=1 nsweeps2_main (runs_nsweeps2.npz), GOLDEN_PIN1024=1 pin1024_main (sweeps_pin1024.npz, 20 minutes), GOLDEN_GMRES=1 gmres_main (sweeps_gmres.npz), GOLDEN_DHO=1 dirichlet_ho_main (sweeps_dirichlet_ho.npz, runs_dirichlet_ho.npz, dirichlet_ho_matrices.npz), GOLDEN_BC=1 boundary_main (boundary_matrices.npz, sweeps_neumann.npz, runs_neumann.npz), GOLDEN_PIN512=1 pin512_main (sweeps_pin512.npz), GOLDEN_R3=1 radix3_main (sweeps_radix3.npz, runs_radix3.npz), GOLDEN_R5=1 radix5_main (sweeps_radix5.npz, runs_radix5.npz), GOLDEN_T3D=1 transfer3d_main (transfer3d.npz), GOLDEN_AD1D=1 ad1d_main (sweeps_ad1d.npz, runs_ad1d.npz);
 GOLDEN_ML=0 skips the multi-level block.
 
 ``qmat`` (third-party, absent here) is replaced by oracle/qmat_shim, which forwards to
@@ -1204,3 +1204,39 @@ def transfer3d_main():
 
 if __name__ == '__main__' and os.environ.get('GOLDEN_T3D', '0') == '1':
     transfer3d_main()
+
+
+def ad1d_main():
+    """AdvectionDiffusionEquation_1D_FFT.py: advectiondiffusion1d_imex (the IMEX parity anchor, 8c G2) and
+    advectiondiffusion1d_implicit - sweeps from random start values and runs to a tolerance at N = 64 / 256."""
+    from pySDC.implementations.problem_classes.AdvectionDiffusionEquation_1D_FFT import (advectiondiffusion1d_imex,
+                                                                                         advectiondiffusion1d_implicit)
+
+    PROBS['ad1d_imex'] = advectiondiffusion1d_imex
+    PROBS['ad1d_implicit'] = advectiondiffusion1d_implicit
+    RR = dict(quad_type='RADAU-RIGHT')
+    cases = []
+    for n in (64, 256):
+        for M, QI, dt in ((3, 'LU', 1e-2), (5, 'IE', 5e-3)):
+            cases.append(sweep_case(f'ad1d_imex_{n}_M{M}_{QI}', 'ad1d_imex', dict(nvars=n, c=1.0, freq=2, nu=0.02),
+                                    'imex_1st_order', dict(num_nodes=M, QI=QI, QE='EE', **RR), dt))
+            cases.append(sweep_case(f'ad1d_impl_{n}_M{M}_{QI}', 'ad1d_implicit', dict(nvars=n, c=1.0, freq=2, nu=0.02),
+                                    'generic_implicit', dict(num_nodes=M, QI=QI, **RR), dt))
+    cases.append(sweep_case('ad1d_imex_96_M3_tau', 'ad1d_imex', dict(nvars=96, c=0.5, freq=-1, nu=0.02), 'imex_1st_order',
+                            dict(num_nodes=3, QI='LU', QE='EE', **RR), 1e-2, tau_seed=5, u0_kind='exact'))
+    cases.append(sweep_case('ad1d_imex_64_M2_gauss', 'ad1d_imex', dict(nvars=64, c=1.0, freq=-1, nu=0.02, L=2.0), 'imex_1st_order',
+                            dict(num_nodes=2, QI='IE', QE='EE', quad_type='GAUSS'), 1e-2, u0_kind='exact'))
+    save('sweeps_ad1d.npz', cases)
+    runs = [run_case('ad1d_imex_run_256', 'ad1d_imex', dict(nvars=256, c=1.0, freq=-1, nu=0.02), 'imex_1st_order',
+                     dict(num_nodes=3, QI='LU', QE='EE', **RR), dict(dt=0.02, restol=1e-10), 50, 0.0, 0.1),
+            run_case('ad1d_imex_run_64_P2', 'ad1d_imex', dict(nvars=64, c=1.0, freq=2, nu=0.02), 'imex_1st_order',
+                     dict(num_nodes=3, QI='LU', QE='EE', **RR), dict(dt=0.01, restol=1e-9), 50, 0.0, 0.04, num_procs=2),
+            run_case('ad1d_impl_run_256', 'ad1d_implicit', dict(nvars=256, c=1.0, freq=4, nu=0.02), 'generic_implicit',
+                     dict(num_nodes=5, QI='LU', **RR), dict(dt=0.02, restol=1e-10), 50, 0.0, 0.1),
+            run_case('ad1d_impl_run_64_rand', 'ad1d_implicit', dict(nvars=64, c=1.0, freq=0, nu=0.02), 'generic_implicit',
+                     dict(num_nodes=3, QI='IE', **RR), dict(dt=0.005, restol=1e-9), 50, 0.0, 0.02)]
+    save('runs_ad1d.npz', runs)
+
+
+if __name__ == '__main__' and os.environ.get('GOLDEN_AD1D', '0') == '1':
+    ad1d_main()

@@ -11,7 +11,7 @@ from tests._cases import load_cases, make_oracle_problem, make_oracle_coll, rel_
 TOL = 1e-13
 
 SWEEP_FILES = ['sweeps_heat.npz', 'sweeps_imex.npz', 'sweeps_adv.npz', 'sweeps_vdp.npz', 'sweeps_ac.npz', 'sweeps_cg.npz', 'sweeps_gmres.npz', 'sweeps_guess.npz',
-               'sweeps_dirichlet_nd.npz', 'sweeps_dirichlet_ho.npz', 'sweeps_neumann.npz']
+               'sweeps_dirichlet_nd.npz', 'sweeps_dirichlet_ho.npz', 'sweeps_neumann.npz', 'sweeps_ad1d.npz']
 SWEEP_CASES = ([(f, n) for f in SWEEP_FILES for n in load_cases(f)]
                + [('sweeps_pin1024.npz', 'pin_heat1d_1024_M5_IE')]   # (its 2-D companion is stored as subsamples: GPU tests)
                # grids of 3 * 2^p points (the 24^3 cases take the sparse LU minutes: they are the GPU suite's)
@@ -65,6 +65,7 @@ RUN_CASES = ([('runs.npz', n) for n in load_cases('runs.npz')] + [('runs_dirichl
              + [('runs_nsweeps2.npz', n) for n in load_cases('runs_nsweeps2.npz')] + [('sweeps_pin1024.npz', 'pin_heat1d_1024_run')]
              + [('runs_radix3.npz', n) for n in load_cases('runs_radix3.npz') if '3d_24' not in n]
              + [('runs_radix5.npz', n) for n in load_cases('runs_radix5.npz')]
+             + [('runs_ad1d.npz', n) for n in load_cases('runs_ad1d.npz')]   # AdvectionDiffusionEquation_1D_FFT.py, both classes
              + [('runs_relay8.npz', n) for n in load_cases('runs_relay8.npz') if 'alltodone' not in n])  # (run_sdc has no all_to_done)   # skip_residual_computation (core/sweeper.py:176-179)
 
 
