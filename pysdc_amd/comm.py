@@ -49,6 +49,44 @@ def torch_host_bcast(uid, root=0, group=None, dist=None):
     return box[0]
 
 
+def ranks_share_host_memory(rank, host_bcast, host_all_ok):
+    """do all ranks see the same /dev/shm?  The pinned-host second path of two-rank hand-overs (sdc_comm_set_host_share) is a
+    ring in POSIX shared memory: it only exists between ranks of ONE host.  Rank 0 creates a small file holding a nonce and
+    ships name and nonce with `host_bcast(obj_or_None) -> obj`; every rank looks for it; `host_all_ok(flag) -> bool` tells
+    whether all of them found it.  Both calls are collective and are made by every rank whatever happens locally (a rank
+    that cannot create or read the file says 'no' in the second one); a failure of the calls themselves means 'no'."""
+    import os
+    import secrets
+
+    created, probe = None, (None, None)
+    if rank == 0:
+        try:
+            name, nonce = f'/dev/shm/pysdc_amd.probe.{os.getpid()}.{secrets.token_hex(8)}', secrets.token_hex(16)
+            with open(name, 'w') as f:
+                f.write(nonce)
+            created, probe = name, (name, nonce)
+        except OSError:
+            pass
+    try:
+        name, nonce = host_bcast(probe if rank == 0 else None)
+        mine = False
+        if name:
+            try:
+                with open(name) as f:
+                    mine = f.read() == nonce
+            except OSError:
+                pass
+        return bool(host_all_ok(mine))
+    except Exception:  # noqa: BLE001  (the host group itself failed: the path stays off)
+        return False
+    finally:
+        if created:
+            try:
+                os.unlink(created)
+            except OSError:
+                pass
+
+
 class DeviceComm:
     """one time rank's end of the communicator, bound to one level's SweepEngine.  The fine level owns the
     communicator (``DeviceComm(engine, P, r, ...)``); the coarser levels of the same rank share it (``attach``)."""

@@ -187,6 +187,7 @@ class controller_nonMPI(_ControllerBase):
             block = [self.MS[p] for p in live]
             while not self.pfasst(block):
                 pass
+            _refuse_restart(block)
             tail = block[-1]
             uend = tail.levels[0].uend
             start, nxt = self._schedule(start[live[-1]] + tail.dt, Tend)
@@ -372,6 +373,16 @@ class controller_nonMPI(_ControllerBase):
             S.levels[0].sweep.update_nodes()
 
 
+def _refuse_restart(steps):
+    """a finished block whose step asks to be restarted (S.status.restart: set by a subclassed sweeper, a hook or a
+    convergence controller of the reference, controller_nonMPI.py:150-163) - these controllers have no restart logic
+    (core/convergence_controller.py lives with the reference): say so instead of going on with a step that was rejected"""
+    for S in steps:
+        if getattr(S.status, 'restart', False):
+            raise ControllerError(f'step at t = {S.time} asks to be restarted (status.restart): the controllers of this package do '
+                                  'not restart steps - hand the description to the reference\'s controller (INTEGRATION.md, route 1)')
+
+
 _FROM_WIRE = object()   # restart_block: u[0] is the spectrum this rank's communicator received
 
 
@@ -455,12 +466,29 @@ class controller_dist(_ControllerBase):
             owner.set_relay(self.relay)
             if self.size == 2:
                 # two ranks: one xGMI link would carry the whole message - a share of it goes through pinned host memory
-                # beside it (include/sdcmi.h: sdc_comm_set_host_share)
-                owner.set_host_share(float(os.environ.get('PYSDC_AMD_HOST_SHARE', '0.45')))
+                # beside it (include/sdcmi.h: sdc_comm_set_host_share).  That path is a ring in /dev/shm: only between ranks
+                # that have been SEEN to share it (a probe file found by both) - two ranks on two hosts keep the wire alone
+                share = float(os.environ.get('PYSDC_AMD_HOST_SHARE', '0.45'))
+                if share > 0.0 and not self._ranks_share_host():
+                    share = 0.0
+                self.host_share = share
+                owner.set_host_share(share)
             if self.p2p_chunk > 0:
                 owner.set_chunk(self.p2p_chunk)
             self._comms = [owner] + [DeviceComm.attach(L.engine, owner) for L in self.S.levels[1:]]
         return self._comms
+
+    def _ranks_share_host(self):
+        from pysdc_amd.comm import ranks_share_host_memory, torch_host_bcast
+
+        def all_ok(flag):
+            import torch
+
+            t = torch.tensor([1.0 if flag else 0.0], dtype=torch.float64)
+            self.dist.all_reduce(t, group=self.host_comm)     # (sum over the ranks)
+            return int(round(float(t.item()))) == self.size
+
+        return ranks_share_host_memory(self.rank, lambda obj: torch_host_bcast(obj, 0, self.host_comm, self.dist), all_ok)
 
     @property
     def two_hop_calls(self):
@@ -588,6 +616,7 @@ class controller_dist(_ControllerBase):
             if active:
                 while not S.status.done:
                     self.pfasst(num_active)
+                _refuse_restart([S])
             # end value of the block travels from its last active rank to everybody (controller_MPI.py:125-130)
             root = num_active - 1
             time = time + dt * num_active

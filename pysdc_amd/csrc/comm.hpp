@@ -320,45 +320,57 @@ struct ShmWire : Wire {
 // with the HIP runtime: DMA at the host link's rate), the receiver copies them out as they arrive; both sides run their loop on
 // a helper thread and a stream of their own, beside the RCCL transfer of the head of the message.  With 45 % of the message on
 // this path both finish in ~80 ms (measured on one box: 48 GB/s end to end, scripts/probe_host_pipe.py).  One-directional: file /dev/shm/<job>.pipe.<src>.<dst>.
+// The ring is made ONCE per communicator and direction, its slots sized for the largest message the context can send (a field
+// or a half spectrum) - the piece a hand-over sends per slot (`chunk`) is a logical length inside them, so a change of the
+// message kind or of the share never re-opens the file (two ranks re-opening on their own could end up on different files).
+// The file's name is dropped as soon as BOTH ends have mapped it (a counter in its header; the second to attach unlinks - the
+// mapping outlives the name), or by the only end that ever opened it when that end goes away.
 struct HostPipe {
     struct Head {
         std::atomic<unsigned long long> posted, consumed;
-        char pad[48];
+        std::atomic<unsigned> attached;   // ends that have mapped the file
+        char pad[44];
     };
     static_assert(sizeof(Head) == 64, "pipe header");
     std::string path;
     int fd = -1;
     unsigned char* base = nullptr;
-    size_t map_bytes = 0, chunk = 0;   // chunk: doubles per slot
+    size_t map_bytes = 0, cap = 0;     // cap: doubles per slot
     int depth = 2;
-    bool device = true, registered = false, creator = false;
+    bool device = true, registered = false, named = false;
     hipStream_t stream = nullptr;
-    double timeout_s = 120.0;
+    double timeout_s = 0.0;            // <= 0: wait for ever, like a receive on the wire (SDC_COMM_TIMEOUT > 0 bounds both)
     Head* head() const { return reinterpret_cast<Head*>(base); }
-    double* slot(unsigned long long k) const { return reinterpret_cast<double*>(base + sizeof(Head)) + (size_t)(k % (unsigned)depth) * chunk; }
+    double* slot(unsigned long long k) const { return reinterpret_cast<double*>(base + sizeof(Head)) + (size_t)(k % (unsigned)depth) * cap; }
     ~HostPipe() {
         if (stream) {
             (void)hipStreamSynchronize(stream);
             (void)hipStreamDestroy(stream);
         }
         if (base) {
+            if (named && head()->attached.load(std::memory_order_acquire) < 2) shm_unlink(path.c_str());   // (nobody else ever came)
             if (registered) (void)hipHostUnregister(base);
             munmap(base, map_bytes);
         }
         if (fd >= 0) close(fd);
-        if (!path.empty()) shm_unlink(path.c_str());
     }
-    int open(sdc_ctx* c, const std::string& job, int src, int dst, size_t chunk_doubles, bool on_device) {
+    int open(sdc_ctx* c, const std::string& job, int src, int dst, size_t slot_doubles, bool on_device) {
         path = "/" + job + ".pipe." + std::to_string(src) + "." + std::to_string(dst);
-        chunk = chunk_doubles;
+        cap = slot_doubles;
         device = on_device;
+        if (const char* t = getenv("SDC_COMM_TIMEOUT")) timeout_s = atof(t);
         fd = shm_open(path.c_str(), O_CREAT | O_RDWR, 0600);
         if (fd < 0) return fail(c, SDC_ERR_COMM, "shm_open(%s): %s", path.c_str(), strerror(errno));
-        map_bytes = sizeof(Head) + (size_t)depth * chunk * sizeof(double);
+        named = true;
+        map_bytes = sizeof(Head) + (size_t)depth * cap * sizeof(double);
         if (ftruncate(fd, (off_t)map_bytes) != 0) return fail(c, SDC_ERR_COMM, "ftruncate(%s): %s", path.c_str(), strerror(errno));
         void* m = mmap(nullptr, map_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
         if (m == MAP_FAILED) return fail(c, SDC_ERR_COMM, "mmap(%s): %s", path.c_str(), strerror(errno));
         base = static_cast<unsigned char*>(m);
+        if (head()->attached.fetch_add(1, std::memory_order_acq_rel) + 1 >= 2) {   // both ends hold the mapping: the name can go
+            shm_unlink(path.c_str());
+            named = false;
+        }
         if (device) {
             registered = hipHostRegister(base, map_bytes, hipHostRegisterDefault) == hipSuccess;   // (pageable copies still work)
             if (!registered) (void)hipGetLastError();
@@ -372,15 +384,16 @@ struct HostPipe {
         for (unsigned spin = 0; !ready(); ++spin) {
             if (spin < 4000) sched_yield();
             else usleep(20);
-            if ((spin & 1023) == 1023 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) {
+            if (timeout_s > 0.0 && (spin & 1023) == 1023 &&
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) {
                 *err = std::string("host pipe ") + path + ": " + what + " timed out";
                 return SDC_ERR_COMM;
             }
         }
         return SDC_OK;
     }
-    // host loops (helper threads): n doubles from / to a buffer of the pipe's kind, chunk by chunk
-    int send(const double* buf, size_t n, std::string* err) {
+    // host loops (helper threads): n doubles from / to a buffer of the pipe's kind, `chunk` (<= cap) of them per slot
+    int send(const double* buf, size_t n, size_t chunk, std::string* err) {
         Head* h = head();
         for (size_t o = 0; o < n; o += chunk) {
             const size_t len = std::min(chunk, n - o);
@@ -401,7 +414,7 @@ struct HostPipe {
         }
         return SDC_OK;
     }
-    int recv(double* buf, size_t n, std::string* err) {
+    int recv(double* buf, size_t n, size_t chunk, std::string* err) {
         Head* h = head();
         for (size_t o = 0; o < n; o += chunk) {
             const size_t len = std::min(chunk, n - o);
@@ -856,41 +869,48 @@ extern "C" int sdc_comm_handover_post(sdc_ctx* c, int nactive) {
     } else {
         // two ranks: the tail of the message through pinned host memory, on helper threads, beside the direct transfer
         size_t n_host = 0;
-        if (nactive == 2 && cs->host_share > 0.0 && n >= 4096) {
+        // (only messages of tens of megabytes: below that the helper threads and the per-slot synchronisation cost more than the
+        // share of the link they free - SDC_PIPE_MIN_BYTES, default 32 MB; tests lower it)
+        size_t min_bytes = (size_t)32 << 20;
+        if (const char* pm = getenv("SDC_PIPE_MIN_BYTES")) min_bytes = strtoull(pm, nullptr, 10);
+        if (nactive == 2 && cs->host_share > 0.0 && n * sizeof(double) >= min_bytes && n >= 1024) {
             n_host = ((size_t)((double)n * cs->host_share) / 512) * 512;
             size_t slot_doubles = (size_t)16 << 20;   // 128 MB slots (SDC_PIPE_CHUNK: doubles per slot, for tests)
             if (const char* pc = getenv("SDC_PIPE_CHUNK")) slot_doubles = std::max<size_t>(512, strtoull(pc, nullptr, 10));
-            const size_t chunk = std::min<size_t>(n_host, slot_doubles);
+            // slots sized ONCE for the largest message of this context (a field or a half spectrum), whatever travels now
+            const size_t cap = std::min<size_t>(slot_doubles, ((std::max<size_t>(c->N, 2 * c->Nc) + 511) / 512) * 512);
             if ((rc = join_helpers(c, cs)) != SDC_OK) return rc;
             if (!cs->pipe_ready) HIPCHK(c, hipEventCreateWithFlags(&cs->pipe_ready, hipEventDisableTiming));
             // (whatever the message stream waits for - the end value complete, the inbox free - the pipes wait for too)
             HIPCHK(c, hipEventRecord(cs->pipe_ready, w->stream));
             if (sending) {
-                if (!cs->pipe_out || cs->pipe_out->chunk != chunk) {
+                if (!cs->pipe_out) {
                     cs->pipe_out.reset(new HostPipe);
-                    if ((rc = cs->pipe_out->open(c, cs->job, r, r + 1, chunk, true)) != SDC_OK) return rc;
+                    if ((rc = cs->pipe_out->open(c, cs->job, r, r + 1, cap, true)) != SDC_OK) return rc;
                 }
                 HIPCHK(c, hipStreamWaitEvent(cs->pipe_out->stream, cs->pipe_ready, 0));
                 HostPipe* pp = cs->pipe_out.get();
+                const size_t chunk = std::min<size_t>(std::max<size_t>(n_host, 512), pp->cap);   // (the ring's own slot size)
                 const double* from = src + (n - n_host);
                 const int dev = c->device;
-                cs->helper_out = std::thread([cs, pp, from, n_host, dev] {
+                cs->helper_out = std::thread([cs, pp, from, n_host, chunk, dev] {
                     (void)hipSetDevice(dev);
-                    cs->helper_rc_out = pp->send(from, n_host, &cs->helper_err_out);
+                    cs->helper_rc_out = pp->send(from, n_host, chunk, &cs->helper_err_out);
                 });
             }
             if (receiving) {
-                if (!cs->pipe_in || cs->pipe_in->chunk != chunk) {
+                if (!cs->pipe_in) {
                     cs->pipe_in.reset(new HostPipe);
-                    if ((rc = cs->pipe_in->open(c, cs->job, r - 1, r, chunk, true)) != SDC_OK) return rc;
+                    if ((rc = cs->pipe_in->open(c, cs->job, r - 1, r, cap, true)) != SDC_OK) return rc;
                 }
                 HIPCHK(c, hipStreamWaitEvent(cs->pipe_in->stream, cs->pipe_ready, 0));
                 HostPipe* pp = cs->pipe_in.get();
+                const size_t chunk = std::min<size_t>(std::max<size_t>(n_host, 512), pp->cap);
                 double* to = dst + (n - n_host);
                 const int dev = c->device;
-                cs->helper_in = std::thread([cs, pp, to, n_host, dev] {
+                cs->helper_in = std::thread([cs, pp, to, n_host, chunk, dev] {
                     (void)hipSetDevice(dev);
-                    cs->helper_rc_in = pp->recv(to, n_host, &cs->helper_err_in);
+                    cs->helper_rc_in = pp->recv(to, n_host, chunk, &cs->helper_err_in);
                 });
             }
             cs->host_path_calls++;

@@ -119,7 +119,7 @@ struct sdc_ctx {
     // the sweep's z / y launches go first - into a second set of work spectra - and the passes put off for the previous
     // iterate follow them: the last node's spectrum is final (and on the wire) one z launch after the receive, and the
     // put-off passes run while the message travels
-    bool pipeline_x = true, hold_flush = false;
+    bool pipeline_x = true;
     cd* Wb = nullptr;                         // the other set of work spectra
     unsigned long long* res_bank[2] = {nullptr, nullptr};   // norm slots: two banks (one per iterate in flight), 16 each
     int res_bank_now = 0;

@@ -113,13 +113,18 @@ static int materialize_uend(sdc_ctx* c) {
         if (rcv_ != SDC_OK) return rcv_;   \
     } while (0)
 
+// (U / F are node-index bases that point N resp. ncomp N values BEFORE their blocks Un / Fn - index 0 through them is not
+// memory of this context - and every block may still be unallocated (need_nodes / need_f0): null then, never base + offset)
 static double* slot_ptr(sdc_ctx* c, int slot, int m, int comp) {
     switch (slot) {
-        case SDC_SLOT_U: return m == 0 ? c->U0 : ((m >= 1 && m <= c->M) ? c->U + (size_t)m * c->N : nullptr);
+        case SDC_SLOT_U:
+            if (m == 0) return c->U0;
+            return (m >= 1 && m <= c->M && c->Un) ? c->U + (size_t)m * c->N : nullptr;
         case SDC_SLOT_F:
             if (m < 0 || m > c->M || comp < 0 || comp >= c->ncomp) return nullptr;
-            return m == 0 ? c->F0 + (size_t)comp * c->N : c->F + ((size_t)m * c->ncomp + comp) * c->N;
-        case SDC_SLOT_TAU: return (m >= 0 && m < c->M) ? c->TAU + (size_t)m * c->N : nullptr;
+            if (m == 0) return c->F0 ? c->F0 + (size_t)comp * c->N : nullptr;
+            return c->Fn ? c->F + ((size_t)m * c->ncomp + comp) * c->N : nullptr;
+        case SDC_SLOT_TAU: return (m >= 0 && m < c->M && c->TAU) ? c->TAU + (size_t)m * c->N : nullptr;
         case SDC_SLOT_UEND: return c->UEND;
         default: return nullptr;
     }
@@ -1207,7 +1212,6 @@ static int publish_ticket(sdc_ctx* c, const PendingTicket& t, const unsigned lon
 static int flush_x(sdc_ctx* c) {
     PendingX& xp = c->xp;
     if (!xp.pending) return SDC_OK;
-    if (c->hold_flush) return SDC_OK;   // (a sweep is putting its own launches in front: it calls again when they are queued)
     xp.pending = false;
     const unsigned long long* before = xp.norms;
     FieldPtrs p0;
@@ -1219,13 +1223,14 @@ static int flush_x(sdc_ctx* c) {
         cd* dscr = dbuf ? spool_get(c) : nullptr;
         xp.dz = nullptr;
         if (!dbuf || !dscr) {
-            spool_put(c, dbuf);
-            return SDC_ERR_NOMEM;
-        }
-        HIPCHK(c, hipMemsetAsync(xp.normsA, 0, sizeof(unsigned long long) * 8, c->stream));
+            rc = SDC_ERR_NOMEM;   // (spool_get has left the message)
+        } else if (hipMemsetAsync(xp.normsA, 0, sizeof(unsigned long long) * 8, c->stream) != hipSuccess) {
+            rc = fail(c, SDC_ERR_HIP, "hipMemsetAsync of the norm slots failed");
+        } else {
 #define CALL(NN) joint_norms_n<NN>(c, xp.nf, xp.work, xp.d_new, xp.d_old, dbuf, dscr, xp.norms, xp.normsA, z_done)
-        rc = [&]() -> int { N_DISPATCH(c, CALL) }();
+            rc = [&]() -> int { N_DISPATCH(c, CALL) }();
 #undef CALL
+        }
         spool_put(c, dbuf);   // (stream-ordered: whoever takes them next works behind these launches)
         spool_put(c, dscr);
         if (xp.d_old_spare) spool_put(c, xp.d_old);
@@ -1236,16 +1241,22 @@ static int flush_x(sdc_ctx* c) {
         rc = [&]() -> int { N_DISPATCH(c, CALL) }();
 #undef CALL
     }
-    if (rc != SDC_OK) return rc;
+    if (rc != SDC_OK) {
+        // the numbers could not be made: whoever holds a ticket of this pass reads NaN (all bits set) - never a record of an
+        // older residual, never a wait without end - and the caller gets the error
+        (void)hipMemsetAsync(xp.norms, 0xFF, sizeof(unsigned long long) * 8, c->stream);
+        if (xp.has_delta) (void)hipMemsetAsync(xp.normsA, 0xFF, sizeof(unsigned long long) * 8, c->stream);
+        (void)hipGetLastError();
+    }
     for (const PendingTicket& t : xp.tickets) {
-        rc = publish_ticket(c, t, (xp.has_delta && !t.after) ? before : xp.norms);
-        if (rc != SDC_OK) return rc;
+        const int rcp = publish_ticket(c, t, (xp.has_delta && !t.after) ? before : xp.norms);
+        if (rc == SDC_OK) rc = rcp;
     }
     xp.tickets.clear();
     xp.has_delta = false;
     xp.d_old_spare = false;
     xp.d_old = xp.d_new = nullptr;
-    return SDC_OK;
+    return rc;
 }
 
 // the trail of unstored sweeps is over (its iterate was stored, or its state is gone): the start values it depended on -
@@ -1787,6 +1798,7 @@ void* sdc_slot_ptr(sdc_ctx* c, int slot, int m, int comp) {
         if (!c->Un && getenv("SDC_TRACE_LAZY")) fprintf(stderr, "[sdcmi] node fields allocated by sdc_slot_ptr(%d, %d)\n", slot, m);
         if (need_nodes(c) != SDC_OK) return nullptr;
     }
+    if (slot == SDC_SLOT_F && m == 0 && need_f0(c) != SDC_OK) return nullptr;
     if (slot == SDC_SLOT_TAU && ensure_tau(c) != SDC_OK) return nullptr;
     if (slot == SDC_SLOT_UEND) {
         if (materialize_uend(c) != SDC_OK) return nullptr;

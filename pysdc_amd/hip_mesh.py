@@ -211,6 +211,9 @@ class hip_mesh:
                                   float(value)))
 
     def __setitem__(self, key, value):
+        if getattr(self, '_strided_copy', False):
+            raise DataError('this field is the COPY a strided index of a device field returned (ndarray would have handed out '
+                            'a view): write through the field itself, x[key] = value')
         if not self._whole(key):
             box = self._box(key)
             if box is None:   # index arrays / masks: through a torch view of the same memory
@@ -257,10 +260,34 @@ class hip_mesh:
             out.as_torch().reshape(t.shape).copy_(t)
             return out
         shape = box[3]
+        off = self._contiguous_offset(box)
+        if off is not None and shape and int(np.prod(shape)):
+            # a box that is ONE contiguous piece of memory (leading-axis integers / unit-step slices, whole trailing axes): a
+            # view, like ndarray's - `v = u[1:-1]; v[:] = x` and `u[0][...] = x` write the field itself
+            return hip_mesh.view(self.ptr + 8 * off, shape, keep=self, on_write=self._on_write, on_access=self._on_access)
         out = hip_mesh((shape if shape else (1,), None, _F64), val=None)
         if out.size:
             self._box_call(box, out.ptr, 0)
+        if shape:
+            out._strided_copy = True   # (where ndarray hands out a strided view: writes through it would be lost - they raise)
         return out if shape else float(out.get()[0])
+
+    def _contiguous_offset(self, box):
+        """element offset of the box when it is one contiguous piece of this (C-ordered) field, else None"""
+        start, step, count, _ = box
+        if any(c > 1 and st != 1 for st, c in zip(step, count)):
+            return None
+        nd = len(self.shape)
+        ax = nd - 1
+        while ax >= 0 and start[ax] == 0 and count[ax] == self.shape[ax]:   # whole trailing axes
+            ax -= 1
+        if any(count[a] != 1 for a in range(ax)):   # at most ONE partial axis; everything before it a single index
+            return None
+        off, stride = 0, 1
+        for a in range(nd - 1, -1, -1):
+            off += start[a] * stride
+            stride *= self.shape[a]
+        return off
 
     def __len__(self):
         return self.shape[0]

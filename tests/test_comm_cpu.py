@@ -67,3 +67,23 @@ def test_a_missing_peer_times_out_with_an_error():
     for f in os.listdir('/dev/shm'):
         if f.startswith(f'sdcmi.lonely{os.getpid()}'):
             os.unlink(os.path.join('/dev/shm', f))
+
+
+def test_same_host_probe_of_the_pinned_host_path():
+    """the pinned-host share of two-rank hand-overs is switched on only between ranks that have been seen to share /dev/shm
+    (pysdc_amd/controller.py: _ranks_share_host): the probe file is found by a rank of this host, not by one that looks for it
+    somewhere else; any failure on the way means 'no'"""
+    import os
+
+    from pysdc_amd.comm import ranks_share_host_memory
+
+    assert ranks_share_host_memory(0, lambda obj: obj, lambda flag: flag) is True
+    assert ranks_share_host_memory(0, lambda obj: ('/dev/shm/pysdc_amd.probe.none', obj[1]), lambda flag: flag) is False
+    assert ranks_share_host_memory(0, lambda obj: (obj[0], 'another nonce'), lambda flag: flag) is False
+    assert ranks_share_host_memory(1, lambda obj: ('/dev/shm/pysdc_amd.probe.none', 'x'), lambda flag: flag) is False
+
+    def broken(obj):
+        raise RuntimeError('no host group')
+
+    assert ranks_share_host_memory(0, broken, lambda flag: flag) is False
+    assert not [f for f in os.listdir('/dev/shm') if f.startswith('pysdc_amd.probe.')]

@@ -186,6 +186,7 @@ def test_two_ranks_share_the_message_between_the_wire_and_host_memory(share, n):
     from pysdc_amd.comm import DeviceComm
 
     os.environ['SDC_PIPE_CHUNK'] = '4096' if n == 96 else '1000000'     # (slots of 32 KB: ~65 trips round the ring per message)
+    os.environ['SDC_PIPE_MIN_BYTES'] = '0'                              # (the path is for messages of tens of MB by default)
 
     def field(r, k):
         return np.random.default_rng(10 * k + r).standard_normal((n, n, n))
@@ -210,6 +211,7 @@ def test_two_ranks_share_the_message_between_the_wire_and_host_memory(share, n):
         res = _thread_ranks(2, body)
     finally:
         del os.environ['SDC_PIPE_CHUNK']
+        del os.environ['SDC_PIPE_MIN_BYTES']
     for k in range(4):
         assert np.array_equal(res[0][k], np.zeros((n, n, n))) and np.array_equal(res[1][k], field(0, k)), k
 

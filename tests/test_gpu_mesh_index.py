@@ -32,7 +32,13 @@ def test_basic_indexing_equals_numpy(shape):
             assert isinstance(got, float) and got == want, key
         else:
             assert got.shape == want.shape and np.array_equal(got.get(), want), key
-            assert got.ptr != m.ptr            # a copy (ndarray hands out a view: documented difference)
+            # one contiguous piece of memory (leading integers / unit-step slices, whole trailing axes): a view like ndarray's;
+            # anything strided: a copy that refuses to be written through
+            base = np.shares_memory(want, h) and want.flags['C_CONTIGUOUS'] and want.size > 0
+            assert (got.ptr == m.ptr + (want.__array_interface__['data'][0] - h.__array_interface__['data'][0])) == bool(base), key
+            if not base and want.size:
+                with pytest.raises(Exception):
+                    got[:] = 0.0
     assert len(m) == shape[0] and [np.array_equal(np.asarray(r), h[i]) for i, r in enumerate(m)] == [True] * shape[0]
     with pytest.raises(IndexError):
         m[(shape[0],) + (0,) * (len(shape) - 1)]
@@ -62,6 +68,25 @@ def test_assignment_through_an_index_equals_numpy(shape):
             h[key] = 2.0 * val
             m[key] = dev
             assert np.array_equal(m.get(), h), key
+
+
+def test_contiguous_indices_are_views_like_ndarray():
+    """`v = u[1:-1]; v[:] = x` and `u[0][...] = x` write the field itself (datatype_classes/mesh.py: the reference's mesh IS an
+    ndarray), also through a view into a level's slab - where the write reaches the engine"""
+    m, h = _mesh((9, 8, 10), 4)
+    v = m[1:-1]
+    v[:] = 2.5
+    h[1:-1] = 2.5
+    assert np.array_equal(m.get(), h)
+    m[0][...] = -1.0
+    h[0][...] = -1.0
+    m[3, 2][4:7] = 9.0
+    h[3, 2][4:7] = 9.0
+    row = m[5, 1:3]
+    row += row
+    h[5, 1:3] += h[5, 1:3]
+    assert np.array_equal(m.get(), h)
+    assert np.array_equal(np.asarray(m), h) and np.array(m).shape == h.shape    # one bulk copy (__array__), not one call per element
 
 
 def test_index_arrays_masks_reductions_and_reshape():

@@ -83,3 +83,25 @@ def test_level_status_with_a_residual_that_is_on_its_way():
     # a thunk (work not queued yet) is deferred, evaluated on the first read and replaced by its number
     st.residual = lambda: 7.0
     assert st.residual_is_deferred() and st.residual == 7.0 and not st.residual_is_deferred()
+
+
+def test_a_step_that_asks_for_a_restart_is_refused_loudly():
+    """S.status.restart set by a hook (what a convergence controller of the reference or a subclassed sweeper would do,
+    controller_nonMPI.py:150-163): the package's own controllers have no restart logic and say so"""
+    from pysdc_amd.errors import ControllerError
+    from pysdc_amd.hooks import Hooks
+
+    class AskForRestart(Hooks):
+        def post_step(self, step, level_number):
+            step.status.restart = True
+
+    case = load_cases('runs.npz')['config1']
+    meta = case['meta']
+    with host_device():
+        from pysdc_amd.controller import controller_nonMPI
+
+        C = controller_nonMPI(1, dict(logger_level=40, hook_class=[AskForRestart]), _description(meta))
+        u0 = C.MS[0].levels[0].prob.u_init
+        u0[:] = case['u0']
+        with pytest.raises(ControllerError, match='restart'):
+            C.run(u0, meta['t0'], meta['Tend'])
