@@ -94,8 +94,10 @@ def _kernel_bytes(name, n, M, ncomp=1):
     return b / groups if b is not None else None
 
 
-def _cpu_sample(sample_n, M, dt_ref_n, target_n, nsweeps):
-    """one bounded sample of the oracle (NumPy/SciPy restatement of the reference's path, oracle/sdc_oracle.py): heat 3-D
+def _cpu_sample(sample_n, M, dt_ref_n, target_n, nsweeps, solver='CG'):
+    """(solver='fft': the same sweep with the oracle's exact Fourier solve, oracle.spectral_solve - the algorithm of the GPU
+    path - instead of the reference's CG)
+    one bounded sample of the oracle (NumPy/SciPy restatement of the reference's path, oracle/sdc_oracle.py): heat 3-D
     sample_n^3, M nodes, 1 time step = nsweeps sweeps, CG(rtol 1e-12) like the reference's feasible 3-D configuration
     (BASELINE.md 3), same dt*nu/dx^2 stiffness as the GPU workload.  Runs in a child interpreter (no GPU, no torch)."""
     import numpy as np
@@ -111,24 +113,31 @@ def _cpu_sample(sample_n, M, dt_ref_n, target_n, nsweeps):
     nv = (sample_n,) * 3
     dt = dt_ref_n * (target_n / sample_n) ** 2
     t0 = time.perf_counter()
-    prob = O.HeatUnforced(nv, 0.1, 2, solver_type='CG', lintol=1e-12)
+    if solver == 'fft':
+        class HeatFourierSolve(O.HeatUnforced):
+            def solve_system(self, rhs, factor, u0, t):
+                return O.spectral_solve(self, rhs, factor)
+
+        prob = HeatFourierSolve(nv, 0.1, 2)
+    else:
+        prob = O.HeatUnforced(nv, 0.1, 2, solver_type='CG', lintol=1e-12)
     setup = time.perf_counter() - t0
     u0 = init_field(nv, 2, 1e-3, 0)
     t0 = time.perf_counter()
     O.run_sdc(lambda: O.Level(prob, coll, dt, restol=-1.0), u0, 0.0, dt, maxiter=nsweeps)
     el = time.perf_counter() - t0
-    return {'n': sample_n, 'seconds': el, 'setup_seconds': setup, 'sweeps': nsweeps,
-            'cg_iterations': prob.work_counters['CG'].niter}
+    return {'n': sample_n, 'seconds': el, 'setup_seconds': setup, 'sweeps': nsweeps, 'solver': solver,
+            'cg_iterations': prob.work_counters['CG'].niter if 'CG' in prob.work_counters else 0}
 
 
-def _spawn_cpu_sample(sample_n, M, dt_ref_n, target_n, nsweeps):
+def _spawn_cpu_sample(sample_n, M, dt_ref_n, target_n, nsweeps, solver='CG'):
     """a fresh interpreter per sample (a child process, never an exec of this one: the GPU is initialised here);
     single-threaded BLAS / OpenMP so that `cores` means what it says"""
     import subprocess
 
     env = dict(os.environ, OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1', MKL_NUM_THREADS='1', HIP_VISIBLE_DEVICES='')
     code = (f'import sys, json; sys.path.insert(0, {ROOT!r}); import bench; '
-            f'print(json.dumps(bench._cpu_sample({sample_n}, {M}, {dt_ref_n!r}, {target_n}, {nsweeps})))')
+            f'print(json.dumps(bench._cpu_sample({sample_n}, {M}, {dt_ref_n!r}, {target_n}, {nsweeps}, {solver!r})))')
     return subprocess.Popen([sys.executable, '-c', code], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env,
                             cwd='/tmp')
 
@@ -157,6 +166,8 @@ class CpuBaseline:
         self.big_n, self.mid_n = big_n, mid_n
         self.r64 = _collect(_spawn_cpu_sample(64, M, dt_ref_n, target_n, nsweeps))   # alone on the host
         self.big = _spawn_cpu_sample(big_n, M, dt_ref_n, target_n, 1) if big_n else None   # collected in finish()
+        # the SAME algorithm as the GPU path beside it: one oracle sweep with the exact Fourier solve, one core, big_n^3
+        self.big_fft = _spawn_cpu_sample(big_n, M, dt_ref_n, target_n, 1, 'fft') if big_n else None
 
     def finish(self):
         M, nsweeps, target = self.M, self.nsweeps, self.target
@@ -185,8 +196,54 @@ class CpuBaseline:
         if rbig is not None:
             out['one_core'] = {'value': 1.0 / (rbig['seconds'] * nsweeps) * sc(self.big_n), 'n': self.big_n,
                                'seconds_per_sweep': rbig['seconds'], 'cg_iterations': rbig['cg_iterations']}
-        detail = {'r64': self.r64, 'big': rbig, 'mid': rs, 'mid_wall_seconds': wall}
+        # same algorithm (Fourier solve): all cores = concurrent copies of one sweep at mid_n^3, one core = one sweep at big_n^3
+        same, rsf, rbf = None, None, None
+        try:
+            procs = [_spawn_cpu_sample(self.mid_n, M, self.dt, target, 1, 'fft') for _ in range(self.workers)]
+            rsf = [_collect(p) for p in procs]
+            slow_f = max(r['seconds'] for r in rsf)
+            same = {'value': self.workers / (slow_f * nsweeps) * sc(self.mid_n), 'unit': 'time-steps/s', 'cores': self.workers,
+                    'n': self.mid_n, 'seconds_per_sweep': slow_f,
+                    'note': "oracle sweep with its exact Fourier solve (numpy rfftn, one thread per copy): the GPU path's "
+                            'algorithm, not the CG of the reference\'s feasible 3-D configuration'}
+            if self.big_fft is not None:
+                rbf = _collect(self.big_fft, timeout=600)
+                same['one_core'] = {'value': 1.0 / (rbf['seconds'] * nsweeps) * sc(self.big_n), 'n': self.big_n,
+                                    'seconds_per_sweep': rbf['seconds']}
+        except Exception as e:  # noqa: BLE001  (never takes the line down)
+            same = same or {'error': repr(e)[:120]}
+        out['same_algorithm'] = same
+        detail = {'r64': self.r64, 'big': rbig, 'mid': rs, 'mid_wall_seconds': wall, 'mid_fft': rsf, 'big_fft': rbf}
         return out, detail
+
+
+def allencahn_ref2d_extruded():
+    """--ac-variant ref2d: the product's 3-D pseudo-spectral two-level problem carrying the reaction term and the start value of
+    the REFERENCE's 2-D class (AllenCahn_2D_FFT.py:140-141 1/eps^2 u (1 - u^nu); :171-174 the circle on [-L/2, L/2]^2),
+    constant along z - every z-plane then evolves exactly like the reference's allencahn2d_imex, whose golden two-level runs
+    (tests/golden/runs_cfg5.npz: MLSDC, and PFASST on 8 processes) pin iteration counts and end value of BASELINE config 5."""
+    import numpy as np
+
+    from pysdc_amd.problems import allencahn_imex
+
+    class allencahn2d_extruded(allencahn_imex):
+        def __init__(self, nvars=None, nu=2, eps=0.04, radius=0.25):
+            super().__init__(nvars=nvars, eps=eps, radius=radius)
+            self._nu2d = nu
+
+        def configure_engine(self, engine):
+            engine.set_symbol(0, self._symbol())
+            engine.set_reaction(1, 1.0 / self.eps**2, 0.0, int(self._nu2d))
+
+        def u_exact(self, t, **kwargs):
+            assert t == 0, 'ERROR: u_exact only valid for t=0'
+            n = self.nvars[0]
+            x = np.array([i * self.L / n - self.L / 2.0 for i in range(n)])
+            xv, yv = np.meshgrid(x, x, indexing='ij')
+            plane = np.tanh((self.radius - np.sqrt(xv**2 + yv**2)) / (np.sqrt(2) * self.eps))
+            return self._from_host(np.ascontiguousarray(np.broadcast_to(plane[:, :, None], self.nvars)))
+
+    return allencahn2d_extruded
 
 
 def stream_reference(torch, eng, nbytes=1 << 32):
@@ -275,14 +332,16 @@ def run_workload(args, world, rank, use_dist, with_stream_reference=True):
         ncomp = 2
         M = 3
         dt = 1e-3
-        desc = dict(problem_class=allencahn_imex,
-                    problem_params=dict(nvars=[(n, n, n), (n // 2, n // 2, n // 2)], eps=0.04, radius=0.25,
-                                        init_type='sphere'),
+        ref2d = getattr(args, 'ac_variant', 'sphere') == 'ref2d'
+        desc = dict(problem_class=allencahn_ref2d_extruded() if ref2d else allencahn_imex,
+                    problem_params=(dict(nvars=[(n, n, n), (n // 2, n // 2, n // 2)], nu=2, eps=0.04, radius=0.25) if ref2d else
+                                    dict(nvars=[(n, n, n), (n // 2, n // 2, n // 2)], eps=0.04, radius=0.25, init_type='sphere')),
                     sweeper_class=imex_1st_order,
                     sweeper_params=dict(num_nodes=M, quad_type='RADAU-RIGHT', QI='LU', QE='EE'),
                     level_params=dict(dt=dt, restol=args.restol, nsweeps=1), step_params=dict(maxiter=K),
                     space_transfer_class=mesh_to_mesh, space_transfer_params=dict(iorder=6, rorder=2, periodic=True))
-        wl = (f'allencahn_imex {n}^3 / {n // 2}^3 (pseudo-spectral, eps=0.04, sphere), two-level '
+        wl = ((f'allencahn2d_imex extruded along z (reference reaction term and circle, z-invariant) {n}^3 / {n // 2}^3, two-level '
+               if ref2d else f'allencahn_imex {n}^3 / {n // 2}^3 (pseudo-spectral, eps=0.04, sphere), two-level ') +
               f'{"PFASST" if world > 1 else "MLSDC"}, M={M} RADAU-RIGHT on both levels, QI=LU, QE=EE, '
               f'mesh_to_mesh iorder 6 / rorder 2')
         unit = 'time-steps/s'
@@ -321,7 +380,12 @@ def run_workload(args, world, rank, use_dist, with_stream_reference=True):
         eng.set_virtual_sweeps(args.virtual_sweeps)
     if args.multiplier_table is not None and hasattr(eng, 'set_multiplier_table'):
         eng.set_multiplier_table(args.multiplier_table)
-    if args.workload in ('vdp', 'allencahn'):
+    if args.workload == 'allencahn' and getattr(args, 'start_plane_file', None):
+        # (tests: a 2-D start value extruded along z - e.g. the perturbed circle a golden run of the reference started from)
+        plane = np.load(args.start_plane_file)
+        u0 = L.prob.u_init
+        u0[:] = np.ascontiguousarray(np.broadcast_to(plane[:, :, None], tuple(L.prob.nvars)))
+    elif args.workload in ('vdp', 'allencahn'):
         u0 = L.prob.u_exact(0.0)
     else:
         # synthetic input on the device: sin mode (freq 2) + 1e-3 * seeded noise
@@ -439,6 +503,8 @@ def run_workload(args, world, rank, use_dist, with_stream_reference=True):
                     traffic /= int(dom[0][dom[0].index('/') + 1:-1])
             roof = {'kernel': dom[0], 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                     'frac': ach / HBM_PEAK_GBS, 'traffic': traffic,
+                    'traffic_source': ('profiles/traffic.json: rocprofv3 --pmc passes of this kernel run by the builder '
+                                       '(scripts/profile_bench.sh), not measured in this run') if traffic is not None else None,
                     'algorithmic_bytes_per_launch': kernel_bytes(dom[0], n, M),
                     'ms_per_launch': dom[1][0] / dom[1][1],
                     'stream_reference_gbs': stream_reference(torch, eng) if with_stream_reference else None}
@@ -522,7 +588,7 @@ def run_workload(args, world, rank, use_dist, with_stream_reference=True):
                                         + (f'; slice flow (trail, put-off pass, split send) = {tuple(int(v) for v in ctrl.timeslice_flow)}'
                                            if getattr(ctrl, 'timeslice_flow', None) else '')
                                         + (f'; wire {args.wire}, mode: {getattr(args, "wire_mode", "default")}'
-                                           + (f' (64^3 and 512^2 checks vs serial emulation: {args.wire_check:.1e})'
+                                           + (f' ({"64^3 / 32^3 two-level" if args.workload == "allencahn" else "64^3 and 512^2"} checks vs serial emulation: {args.wire_check:.1e})'
                                               if getattr(args, 'wire_check', None) is not None else '') if world > 1 else '')},
             'sdc_iters_per_s': units * sweeps_total / el,
             'niter': niter,
@@ -631,7 +697,7 @@ def compact_line(out, subs=None, cpu=None, details_path=None, sustained=None):
     line['finite'] = out['finite']
     if roof:
         line['roofline'] = {k: roof.get(k) for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic',
-                                                     'algorithmic_bytes_per_launch', 'ms_per_launch')}
+                                                     'traffic_source', 'algorithmic_bytes_per_launch', 'ms_per_launch')}
     else:
         line['roofline'] = None
     if rs:
@@ -736,20 +802,35 @@ def validate_wire(args, torch, dist, rank, world):
     import numpy as np
 
     from pysdc_amd.controller import controller_nonMPI, controller_dist
-    from pysdc_amd.problems import heatNd_unforced
-    from pysdc_amd.sweepers import generic_implicit
+    from pysdc_amd.problems import heatNd_unforced, allencahn_imex
+    from pysdc_amd.sweepers import generic_implicit, imex_1st_order
+    from pysdc_amd.transfer import mesh_to_mesh
 
     M, blocks = 5, 2
     cpar = dict(logger_level=40, mssdc_jac=args.mssdc == 'jacobi')
+    if args.workload == 'allencahn':
+        cpar['predict_type'] = 'pfasst_burnin'
     # two grids: 64^3 (the bench's dimension; iterates stored) and 512^2 with four sweeps per step - the smallest grid on
     # which a slice recomputes its iterates from the start values it has received (csrc: trail) and puts the last pass of a
     # residual off, i.e. the data flow of the 1024^3 run itself, at 2 MB per field
     checks = []
-    for nvars, K in (((64, 64, 64), 3), ((512, 512), 4)):
-        dt = 1e-3 * (512.0 / nvars[0]) ** 2
-        desc = dict(problem_class=heatNd_unforced, problem_params=dict(nvars=nvars, nu=0.1, freq=2, order=2),
-                    sweeper_class=generic_implicit, sweeper_params=dict(num_nodes=M, quad_type='RADAU-RIGHT', QI='IE'),
-                    level_params=dict(dt=dt, restol=-1.0, nsweeps=1), step_params=dict(maxiter=K))
+    if args.workload == 'allencahn':
+        # the two-level flow of config 5 (PFASST with burn-in: fine and coarse hand-overs, FAS transfers between them) at
+        # 64^3 / 32^3, a fixed number of iterations and one to a tolerance (the `done` chain, controller_MPI.py:574-807)
+        plan = [(dict(problem_class=allencahn_imex,
+                      problem_params=dict(nvars=[(64, 64, 64), (32, 32, 32)], eps=0.04, radius=0.25, init_type='sphere'),
+                      sweeper_class=imex_1st_order, sweeper_params=dict(num_nodes=3, quad_type='RADAU-RIGHT', QI='LU', QE='EE'),
+                      level_params=dict(dt=1e-3, restol=restol, nsweeps=1), step_params=dict(maxiter=K),
+                      space_transfer_class=mesh_to_mesh, space_transfer_params=dict(iorder=6, rorder=2, periodic=True)), 1e-3)
+                for restol, K in ((-1.0, 3), (1e-7, 50))]
+    else:
+        plan = []
+        for nvars, K in (((64, 64, 64), 3), ((512, 512), 4)):
+            dt = 1e-3 * (512.0 / nvars[0]) ** 2
+            plan.append((dict(problem_class=heatNd_unforced, problem_params=dict(nvars=nvars, nu=0.1, freq=2, order=2),
+                              sweeper_class=generic_implicit, sweeper_params=dict(num_nodes=M, quad_type='RADAU-RIGHT', QI='IE'),
+                              level_params=dict(dt=dt, restol=-1.0, nsweeps=1), step_params=dict(maxiter=K)), dt))
+    for desc, dt in plan:
         serial = controller_nonMPI(world, cpar, desc)
         ref, _ = serial.run(serial.MS[0].levels[0].prob.u_exact(0.0), 0.0, blocks * world * dt)
         checks.append((desc, blocks * world * dt, ref.get()))
@@ -933,6 +1014,13 @@ def main():
                     help='--gpus > 1: skip the small-grid run over the wire that is compared with the serial emulation')
     ap.add_argument('--job-timeout', type=float, default=1500.0,
                     help='--gpus > 1 started without a launcher: seconds after which the parent ends the job with an error')
+    ap.add_argument('--ac-variant', default='sphere', choices=['sphere', 'ref2d'],
+                    help="--workload allencahn: 'sphere' = allencahn_imex with a sphere (the bench default); 'ref2d' = the reference's "
+                         '2-D allencahn2d_imex extruded along z (its reaction term and circle), whose golden runs pin config 5 '
+                         '(tests/golden/runs_cfg5.npz): with --restol 1e-8 --steps 1 --warmup 0 --gpus 8 the run IS the golden '
+                         'PFASST case')
+    ap.add_argument('--start-plane-file', default=None,
+                    help='--workload allencahn: .npy file with a 2-D start value, extruded along z (tests: the start value of a golden run)')
     ap.add_argument('--kernel-events', default=None, choices=['timed', 'separate'],
                     help="HIP events around every launch: 'timed' = inside the timed region (default; the headline's roofline "
                          "is measured there), 'separate' = the timed region runs without them and the same steps run once "

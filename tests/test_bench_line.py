@@ -18,7 +18,8 @@ def _record(title=None, world=1, steps=20, bad=False):
     x = float('nan') if bad else 15.2345678901234
     kern = {f'kernel_number_{i}[5]': {'ms_per_launch': x, 'launches': 80, 'gbs': 5000.123456789} for i in range(40)}
     roof = {'kernel': 'spec_z_res_v0[5]', 'bound': 'hbm', 'achieved': 5655.123456789 if not bad else float('inf'), 'peak': 8000.0,
-            'unit': 'GB/s', 'frac': 0.7068904320987, 'traffic': 86105972736.0, 'algorithmic_bytes_per_launch': 86067118080.0,
+            'unit': 'GB/s', 'frac': 0.7068904320987, 'traffic': 86105972736.0, 'traffic_source': 'p' * 150,
+            'algorithmic_bytes_per_launch': 86067118080.0,
             'ms_per_launch': x, 'stream_reference_gbs': {'fill': 5600.0, 'amax': 5500.0, 'copy': 4800.0}}
     rs = {'bound': 'hbm', 'peak': 8000.0, 'unit': 'GB/s', 'ms_per_sweep': 37.4123456789, 'bytes_moved_per_sweep': 180741996544.0,
           'achieved': 4831.123456789, 'frac': 0.60389, 'floor_bytes_per_sweep': 137438953472.0, 'achieved_on_floor': 3673.6,
@@ -42,7 +43,9 @@ def _record(title=None, world=1, steps=20, bad=False):
 def _cpu():
     return {'value': 1.2345678e-3, 'unit': 'time-steps/s', 'cores': 32, 'kind': 'port', 'sample': 's' * 200,
             'one_core_64_dof_scaled': 8.56e-5,
-            'one_core': {'value': 4.9e-5, 'n': 256, 'seconds_per_sweep': 78.5455453, 'cg_iterations': 406}}
+            'one_core': {'value': 4.9e-5, 'n': 256, 'seconds_per_sweep': 78.5455453, 'cg_iterations': 406},
+            'same_algorithm': {'value': 2.3456789e-2, 'unit': 'time-steps/s', 'cores': 32, 'n': 128, 'seconds_per_sweep': 4.123456,
+                               'note': 'n' * 180, 'one_core': {'value': 1.1e-3, 'n': 256, 'seconds_per_sweep': 35.123456}}}
 
 
 def _strict(line):
@@ -52,6 +55,9 @@ def _strict(line):
 
 def test_headline_line_with_every_sub_record_fits_and_parses():
     subs = [_record(title=t) for t, _ in bench.SUB_PLAN] + [{'title': 'x' * 100, 'error': 'e' * 1000}]
+    for r in subs:
+        if r['title'].startswith('cfg5'):
+            r['ms_per_step_with_events'] = 18.123456789
     subs[2]['niter'] = [43, 32]
     subs[2]['restol'] = 1e-10
     line = json.dumps(bench.compact_line(_record(), subs, _cpu(), 'gpurun_out/bench_details.json', _record(steps=20)),
@@ -67,6 +73,9 @@ def test_headline_line_with_every_sub_record_fits_and_parses():
     assert rec['roofline']['bound'] == 'hbm' and 0 < rec['roofline']['frac'] < 1
     assert rec['roofline']['traffic'] and rec['roofline']['algorithmic_bytes_per_launch'] and rec['roofline']['ms_per_launch']
     assert {'value', 'unit', 'cores', 'kind', 'sample'} <= set(rec['cpu_baseline']) and len(rec['cpu_baseline']['sample']) <= 200
+    assert rec['cpu_baseline']['same_algorithm']['one_core']['n'] == 256 and rec['roofline']['traffic_source']
+    sub5 = [x for x in rec['sub'] if x['title'].startswith('cfg5')][0]
+    assert 'ms_per_step_with_events' in sub5     # (timed without HIP events, the kernel table from a second run with them)
     assert {'frac', 'frac_on_floor'} <= set(rec['roofline_sweep'])
     assert len(rec['sub']) == len(bench.SUB_PLAN) + 1 and all(len(s['title']) <= 40 for s in rec['sub'])
     assert rec['niter'] == 4 and rec['sub'][2]['niter'] == [43, 32]

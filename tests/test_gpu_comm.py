@@ -291,6 +291,45 @@ def test_bench_ranks_on_one_gpu_end_to_end(tmp_path, ranks, n, steps, warmup):
     assert np.max(np.abs(got - ref)) <= 1e-12 * np.max(np.abs(ref))
 
 
+def test_bench_config5_pfasst_on_eight_ranks_is_the_golden_run(tmp_path):
+    """BASELINE config 5 verbatim through `bench.py --workload allencahn --gpus 8` (eight rank processes on GPU 0 over the
+    shared-memory wire: launcher, rendezvous, the two-level wire validation against the serial emulation, controller_dist's
+    PFASST with burn-in - fine and coarse hand-overs, the `done` chain): with the reference's 2-D reaction term and circle
+    extruded along z (--ac-variant ref2d) and restol 1e-8 the run IS the golden 8-process PFASST case of the reference
+    (tests/golden/runs_cfg5.npz: cfg5_ac2d_pfasst_P8) - iteration counts of every rank bit-exact, the end value in every
+    z-plane <= 1e-10 (what controller_nonMPI(8) reproduces in tests/test_gpu_configs.py)"""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    from tests._cases import load_cases
+
+    import torch
+
+    if torch.cuda.mem_get_info()[0] < 60e9:
+        pytest.skip('not enough HBM for eight two-level slices')
+    case = load_cases('runs_cfg5.npz')['cfg5_ac2d_pfasst_P8']
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dump, start = str(tmp_path / 'uend.npy'), str(tmp_path / 'u0.npy')
+    np.save(start, case['u0'])        # (the reference's circle with the seeded perturbation the golden run started from)
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--workload', 'allencahn', '--ac-variant', 'ref2d', '--gpus', '8',
+           '--backend', 'gloo', '--same-device', '--restol', '1e-8', '--steps', '1', '--warmup', '0', '--dump-end-value', dump,
+           '--start-plane-file', start, '--job-timeout', '900']
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200, env=env, cwd=root)
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith('{')]
+    assert res.returncode == 0 and lines, (res.returncode, res.stdout[-2000:], res.stderr[-2000:])
+    rec = json.loads(lines[-1])
+    assert 'error' not in rec, rec
+    assert rec['n_gpus'] == 8 and rec['finite'] and 'two-level PFASST' in rec['config']['time_parallel']
+    assert 'mode: default (64^3 / 32^3 two-level checks vs serial emulation' in rec['config']['time_parallel'], rec['config']
+    assert rec['per_rank']['sweeps'] == [int(v) for v in case['niter']] == [7, 7, 8, 8, 8, 9, 9, 9]
+    got = np.load(dump)
+    scale = float(np.max(np.abs(case['uend'])))
+    assert got.shape == (256, 256, 256) and float(np.max(np.abs(got - case['uend'][:, :, None]))) < 1e-10 * scale
+
+
 @pytest.mark.parametrize('forced', [1, 2, 3])
 def test_wire_validation_falls_back_mode_by_mode(forced):
     """bench.py's validate_wire drops a wire mode that does not reproduce the serial emulation for the next, more conservative
