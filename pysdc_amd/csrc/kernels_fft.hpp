@@ -1199,14 +1199,15 @@ __global__ __launch_bounds__(256) void k_spec_point(SpecArgs a, int n, size_t nm
 // (last_only) only the last one
 template <int NF>
 __global__ __launch_bounds__(256) void k_spec_store(SpecArgs a, int n, size_t nmodes, int nsweeps) {
-    const int lg = 31 - __builtin_clz(n);  // (n = 2^p on every path that gets here)
+    const bool p2 = (n & (n - 1)) == 0;    // (lines of 3 * 2^p / 5 * 2^p modes divide; the rest shifts)
+    const int lg = 31 - __builtin_clz(n);
     for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < nmodes; g += (size_t)gridDim.x * blockDim.x) {
-        const int kz = (int)(g & (size_t)(n - 1));
-        const size_t ln = g >> lg;
+        const int kz = p2 ? (int)(g & (size_t)(n - 1)) : (int)(g % (size_t)n);
+        const size_t ln = p2 ? g >> lg : g / (size_t)n;
         cd lam = a.lamI[kz], mu = cd{0.0, 0.0};
         if (a.lamE) mu = a.lamE[kz];
         if (a.ndim == 3) {
-            const int kx = (int)(ln >> lg), ky = (int)(ln & (size_t)(n - 1));
+            const int kx = p2 ? (int)(ln >> lg) : (int)(ln / (size_t)n), ky = p2 ? (int)(ln & (size_t)(n - 1)) : (int)(ln % (size_t)n);
             lam = cadd(lam, cadd(a.lamI[kx], a.lamI[ky]));
             if (a.lamE) mu = cadd(mu, cadd(a.lamE[kx], a.lamE[ky]));
         } else if (a.ndim == 2) {
@@ -1227,14 +1228,15 @@ __global__ __launch_bounds__(256) void k_spec_store(SpecArgs a, int n, size_t nm
 // thread per pair (p, n - p), p in [0, n/2); the thread with p = 0 also takes the unpaired mode n/2.
 template <int NF>
 __global__ __launch_bounds__(256) void k_spec_store_pairs(SpecArgs a, int n, size_t npairs, int nsweeps) {
+    const bool p2 = (n & (n - 1)) == 0;
     const int lg = 31 - __builtin_clz(n);
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < npairs; idx += (size_t)gridDim.x * blockDim.x) {
-        const int p_ = (int)(idx & (size_t)(n / 2 - 1));
-        const size_t ln = idx >> (lg - 1);
+        const int p_ = p2 ? (int)(idx & (size_t)(n / 2 - 1)) : (int)(idx % (size_t)(n / 2));
+        const size_t ln = p2 ? idx >> (lg - 1) : idx / (size_t)(n / 2);
         double lxy = 0.0;
-        if (a.ndim == 3) lxy = a.lamI[ln >> lg].x + a.lamI[ln & (size_t)(n - 1)].x;
+        if (a.ndim == 3) lxy = p2 ? a.lamI[ln >> lg].x + a.lamI[ln & (size_t)(n - 1)].x : a.lamI[ln / (size_t)n].x + a.lamI[ln % (size_t)n].x;
         else if (a.ndim == 2) lxy = a.lamI[ln].x;
-        const size_t base = ln << lg;
+        const size_t base = ln * (size_t)n;
         const size_t ilo = base + p_, ihi = base + (p_ ? n - p_ : n / 2);
         const cd lo = a.S0[ilo], hi = a.S0[ihi];
         double g[NF];
@@ -1349,6 +1351,13 @@ constexpr int specz_lines() {
 
 template <int N, int NF, bool V>
 constexpr int specz_threads() { return specz_lines<N, V>() * (N / specz_elems<N, V>()) * NF; }
+// modes handed through LDS at a time: the largest divisor of the workgroup's span (lines x N) that is no more than SDC_SPECZ_CH
+// (512 for the powers of two; 384 for spans of 768 = lines of 3 * 2^p, 320 for spans of 1280 = lines of 5 * 2^p)
+constexpr int specz_chunk(int span) {
+    int ch = span > SDC_SPECZ_CH ? SDC_SPECZ_CH : span;
+    while (span % ch) --ch;
+    return ch;
+}
 template <int N, bool V>
 constexpr int specz_min_waves() { return specz_lines<N, V>() > 1 ? 2 : (V ? SDC_SPECZ_VWAVES : SDC_SPECZ_WAVES); }
 // EXPL 0: no explicit part, 1: explicit stencil (symbol lamE), 2: u-independent forcing (profile spectrum SP).
@@ -1374,7 +1383,7 @@ void k_spec_z(SpecArgs a, unsigned nlines) {
     static_assert(!(VIRT && HASP), "a forced iterate is not a function of the start value alone");
     constexpr int E = specz_elems<N, (MODE >= 3)>(), P = N / E, LPB = specz_lines<N, (MODE >= 3)>();
     static_assert(!PAIR || (LPB == 1 && !HASE), "mode pairs: one line per field and workgroup, real symbol only");
-    constexpr int SPAN = LPB * N, CH = SPAN > SDC_SPECZ_CH ? SDC_SPECZ_CH : SPAN, NCH = SPAN / CH, NT = LPB * P * NF;
+    constexpr int SPAN = LPB * N, CH = specz_chunk(SPAN), NCH = SPAN / CH, NT = LPB * P * NF;
     constexpr int ITS = (CH + NT - 1) / NT;  // modes per thread and chunk
     using LAY = LayContig<N>;
     extern __shared__ __attribute__((aligned(16))) double lds[];

@@ -653,13 +653,26 @@ static void launch_trail_z(sdc_ctx* c, SpecArgs& a, size_t lines) {
 template <int N, int NF, bool V>
 static void launch_spec_z_cfg(sdc_ctx* c, SpecArgs& a, size_t lines, int mode, size_t launch_lines) {
     constexpr int P = N / specz_elems<N, V>(), LPB = specz_lines<N, V>();
-    constexpr int SPAN = LPB * N, CH = SPAN > SDC_SPECZ_CH ? SDC_SPECZ_CH : SPAN;
+    constexpr int SPAN = LPB * N, CH = specz_chunk(SPAN);
     size_t ldsz = (size_t)LayContig<N>::doubles(NF * LPB) * sizeof(double);
     if ((size_t)NF * CH * sizeof(cd) > ldsz) ldsz = (size_t)NF * CH * sizeof(cd);
     const dim3 grid((unsigned)((launch_lines + LPB - 1) / LPB)), block(P * LPB * NF);
     const int expl = a.lamE ? 1 : (a.SP ? 2 : 0);
 #define ZL(M_, E_) hipLaunchKernelGGL((k_spec_z<N, NF, M_, E_>), grid, block, ldsz, c->stream, a, (unsigned)lines)
-    if constexpr (V) {  // (iterate recomputed from S0: real symbol, no explicit part - sdc_sweep sees to that)
+    if constexpr (V && (N & (N - 1)) != 0) {
+        // lines of 3 * 2^p / 5 * 2^p modes: the recomputing launches only (mode pairs where a line fills a workgroup: 768) -
+        // no trail, no multiplier table, and stored iterates take the pointwise launch (spec_sweep_n)
+        (void)expl;
+        (void)mode;
+        if constexpr (LPB == 1 && SDC_SPECZ_PAIRS) {
+            if (a.real_sym && !a.ns && !a.gmode) ZL(4, 0);
+            else if (!a.ns && !a.gmode) ZL(3, 0);
+            else fail(c, SDC_ERR_STATE, "no trail / table launch for lines of this length");
+        } else {
+            if (!a.ns && !a.gmode) ZL(3, 0);
+            else fail(c, SDC_ERR_STATE, "no trail / table launch for lines of this length");
+        }
+    } else if constexpr (V) {  // (iterate recomputed from S0: real symbol, no explicit part - sdc_sweep sees to that)
         (void)expl;
         if constexpr (LPB == 1 && SDC_SPECZ_PAIRS) {
             // real symmetric symbol: the modes kz and N - kz of a line share their node multipliers
@@ -671,13 +684,16 @@ static void launch_spec_z_cfg(sdc_ctx* c, SpecArgs& a, size_t lines, int mode, s
             else if (a.real_sym) ZL(4, 0);
             else ZL(3, 0);
         } else ZL(3, 0);
-    } else {
+    } else if constexpr ((N & (N - 1)) == 0) {
 #define ZM(E_)                   \
     if (mode == 0) ZL(0, E_);    \
     else if (mode == 1) ZL(1, E_); \
     else ZL(2, E_);
         if (expl == 1) { ZM(1) } else if (expl == 2) { ZM(2) } else { ZM(0) }
 #undef ZM
+    } else {
+        (void)expl;
+        fail(c, SDC_ERR_STATE, "stored iterates of lines of this length take the pointwise launch");
     }
 #undef ZL
 }
@@ -696,8 +712,10 @@ static int spec_sweep_n(sdc_ctx* c, int nf, SpecArgs& a, const FieldPtrs& p, uns
                         bool spec_only) {
     const int n = c->n;
     const size_t lines = c->ndim == 1 ? 1 : (size_t)(n / 2 + 1) * (c->ndim == 3 ? n : 1);
-    if constexpr (SDC_FUSE_SPECZ && N >= 64 && N <= 1024 && (N & (N - 1)) == 0) {  // fused with the first inverse pass (M <= 5)
-        if (nf <= 5 && !spec_only) {
+    constexpr bool kPow2 = (N & (N - 1)) == 0;
+    if constexpr (SDC_FUSE_SPECZ && N >= 64 && N <= 1024) {  // fused with the first inverse pass (M <= 5)
+        // (lines of 3 * 2^p / 5 * 2^p modes: only the launches that recompute the iterate - a.virt - exist)
+        if (nf <= 5 && !spec_only && (kPow2 || a.virt)) {
             {
                 // after a spread predictor all nodes share S0: that launch does not read S (fewer bytes)
                 static const char* const vnames[] = {"spec_z_res_v0", "spec_z_res_v1", "spec_z_res_v2", "spec_z_res_v3",
@@ -2562,19 +2580,21 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
         bool go = false;
         {
             const bool fused_z = SDC_FUSE_SPECZ && c->n >= 64 && c->n <= 1024 && is_pow2(c->n) && M <= 5;
+            // the launches that recompute the iterate exist for lines of 3 * 2^p / 5 * 2^p modes from 80 on as well (round 6)
+            const bool virt_z = fused_z || (SDC_FUSE_SPECZ && c->n >= 80 && c->n <= 768 && fourier_ok(c) && M <= 5);
             // (with a residual to deliver this pays for a REAL symbol without explicit part - heat: real multipliers, and
             // the modes kz / N - kz of a line share them; complex multipliers cost more than reading the stored iterate:
             // advection-diffusion 512^3 3.2 -> 3.4 ms per launch)
             // (a sweep that stores the node values - eager fields - hands the iterate itself to the transform: mode pairs only)
-            const bool pairs_z = SDC_SPECZ_PAIRS && fused_z && c->n >= 512 && a.real_sym && !a.lamE;
+            const bool pairs_z = SDC_SPECZ_PAIRS && virt_z && (is_pow2(c->n) ? c->n >= 512 : c->n == 768) && a.real_sym && !a.lamE;
             const bool iter_out = !spec_only && !norms_only && pairs_z;
             // Time-parallel levels (spectra on the wire, the end value wanted early): u[0] is replaced between the sweeps, so the
             // unstored iterate becomes a function of ALL the start values the slice has had since its predictor - a trail
             // (trail_iterate), kept while their number stays below trail_max; the launch always writes the last node's spectrum
-            const bool trail = c->wire_spectral && c->early_uend && c->trail_max > 0 && norms_only && pairs_z && !c->keep_rfields;
-            go = c->virt_max > 0 && is_pow2(c->n) && (c->deferred || iter_out) && !c->keep_rfields && (!c->early_uend || trail) && c->ndim >= 2 &&
+            const bool trail = c->wire_spectral && c->early_uend && c->trail_max > 0 && norms_only && pairs_z && is_pow2(c->n) && !c->keep_rfields;
+            go = c->virt_max > 0 && (is_pow2(c->n) || virt_z) && (c->deferred || iter_out) && !c->keep_rfields && (!c->early_uend || trail) && c->ndim >= 2 &&
                       c->expl_kind != SDC_EXPL_FORCING &&
-                      (spec_only || iter_out || (norms_only && fused_z && a.real_sym && !a.lamE));
+                      (spec_only || iter_out || (norms_only && virt_z && a.real_sym && !a.lamE));
             SpecCoef now;
             memset(&now, 0, sizeof now);
             memcpy(now.gI, a.gI, sizeof now.gI);
@@ -2587,7 +2607,7 @@ int sdc_sweep(sdc_ctx* c, double t, double dt) {
             now.has_e = a.lamE ? 1 : 0;
             // the multiplier table takes over where replaying gets dearer than 2 M doubles of traffic per mode pair - if the
             // replayed sweeps get that far (virt_max) and the table can be had
-            bool table = go && !trail && pairs_z && !spec_only && c->g_from > 0 && c->virt_max > c->g_from && c->spec_virtual >= c->g_from;
+            bool table = go && !trail && pairs_z && is_pow2(c->n) && !spec_only && c->g_from > 0 && c->virt_max > c->g_from && c->spec_virtual >= c->g_from;
             if (table && !c->Gm) {
                 const size_t glines = (size_t)(c->n / 2 + 1) * (c->ndim == 3 ? c->n : 1);
                 const size_t gbytes = sizeof(double) * glines * (size_t)M * (size_t)(c->n / 2 + 1);

@@ -31,10 +31,10 @@ json.dump(summary, open(f'{out}/pmc_summary.json', 'w'), indent=1)
 NAMES = [(r'k_spec_z<\d+, \d+, 5, \d+>', 'spec_z_res_tab'), (r'k_spec_z<\d+, \d+, [34], \d+>', 'spec_z_res_v0'), (r'k_spec_store', 'spec_store'),
          (r'k_spec_z<\d+, \d+, 1, \d+>', 'spec_z_res'), (r'k_spec_z<\d+, \d+, 0, \d+>', 'spec_z'),
          (r'k_ffty<\d+, \d+, 1>', 'fft_y_inv'), (r'k_ffty<\d+, \d+, -1>', 'fft_y_fwd'),
-         (r'k_fftx_inv<\d+, \d+, true, false, false, 2>', 'fft_x_norm2'), (r'k_fftx_inv<\d+, \d+, false, false, false, 1>', 'fft_x_scr'),
-         (r'k_fftx_inv<\d+, \d+, true, false(, false)?(, 0)?>', 'fft_x_norm'), (r'k_fftx_norm_half', 'fft_x_norm'),
-         (r'k_fftx_inv<\d+, \d+, true, false, true(, 0)?>', 'fft_x_norm_add'),
-         (r'k_fftx_inv<\d+, \d+, false, true(, false)?(, 0)?>', 'fft_x_inv'), (r'k_fftx_inv<\d+, \d+, true, true(, false)?(, 0)?>', 'fft_x_inv_norm'),
+         (r'k_fftx_inv<\d+, \d+, true, false, false, 2(, false)?>', 'fft_x_norm2'), (r'k_fftx_inv<\d+, \d+, false, false, false, 1(, false)?>', 'fft_x_scr'),
+         (r'k_fftx_inv<\d+, \d+, true, false(, false)?(, 0)?(, false)?>', 'fft_x_norm'), (r'k_fftx_norm_half', 'fft_x_norm'),
+         (r'k_fftx_inv<\d+, \d+, true, false, true(, 0)?(, false)?>', 'fft_x_norm_add'),
+         (r'k_fftx_inv<\d+, \d+, false, true(, false)?(, 0)?(, false)?>', 'fft_x_inv'), (r'k_fftx_inv<\d+, \d+, true, true(, false)?(, 0)?(, false)?>', 'fft_x_inv_norm'),
          (r'k_trail_z<', 'trail_z'), (r'k_trail_store<', 'trail_store'), (r'k_trail_nyq<', 'trail_nyq'),
          (r'k_fftx_fwd', 'fft_x_fwd'), (r'k_fftz_plain<\d+, 1, true>', 'fft_z_sym'), (r'k_fftz_plain<\d+, 1(, false)?>', 'fft_z_inv'),
          (r'k_fftz_plain<\d+, -1(, false)?>', 'fft_z_fwd'),
