@@ -14,12 +14,23 @@ cnt = collections.defaultdict(int)
 for f in glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"]
-        if not any(s in k for s in ("k_spec_z", "k_ffty<1024, 8, 1>", "k_fftx_inv<1024, 8, true, false")):
+        if not any(s in k for s in ("k_spec_z", "k_ffty<1024, 8, 1>", "k_fftx_inv<1024, 8, true, false", "k_restrict3", "k_prolong3")):
             continue
         res[k[:40]][row["Counter_Name"]] += float(row["Counter_Value"] or 0)
         if row["Counter_Name"] == "SQ_WAVE_CYCLES":
             cnt[k[:40]] += 1
 out = {k: {"dispatches": cnt[k], **{c: v / max(cnt[k], 1) for c, v in d.items()}} for k, d in res.items()}
+json.dump(out, open("$OUT/sq_summary.json", "w"), indent=1)
+# resident waves per SIMD, MEASURED: SQ_WAVE_CYCLES counts quad-cycles summed over all waves, SQ_BUSY_CYCLES cycles summed over
+# the 32 shader engines (8 XCDs x 4) for the time the launch was on the chip; 1024 SIMDs:
+#   waves / SIMD = 4 SQ_WAVE_CYCLES / (SQ_BUSY_CYCLES / 32 * 1024) = SQ_WAVE_CYCLES / (8 SQ_BUSY_CYCLES)
+# and the share of the launch's duration a SIMD's vector ALU / a CU's LDS pipe was busy (ACTIVE_INST_* in quad-cycles):
+#   VALU: 4 SQ_ACTIVE_INST_VALU / (SQ_BUSY_CYCLES / 32 * 1024),  LDS (one pipe per CU): 4 SQ_ACTIVE_INST_LDS / (SQ_BUSY_CYCLES / 32 * 256)
+for k, d in out.items():
+    if d.get("SQ_BUSY_CYCLES"):
+        d["resident_waves_per_simd"] = d.get("SQ_WAVE_CYCLES", 0.0) / (8.0 * d["SQ_BUSY_CYCLES"])
+        d["valu_busy_share_of_simd"] = d.get("SQ_ACTIVE_INST_VALU", 0.0) / (8.0 * d["SQ_BUSY_CYCLES"])
+        d["lds_busy_share_of_cu_pipe"] = d.get("SQ_ACTIVE_INST_LDS", 0.0) / (2.0 * d["SQ_BUSY_CYCLES"])
 json.dump(out, open("$OUT/sq_summary.json", "w"), indent=1)
 for k, d in out.items():
     w = d.get("SQ_WAVE_CYCLES", 1)
