@@ -212,9 +212,15 @@ struct LayContig {  // lines are separate: [col][pos]
     DEVI static int idx(int col, int pos) { return col * kLine + pos + (pos >> 4); }
     static constexpr int doubles(int cols) { return cols * kLine; }
 };
+#ifndef SDC_LAYCOLS_PAD
+#define SDC_LAYCOLS_PAD 4
+#endif
 template <int N>
-struct LayCols {  // like LayContig, with the columns 16 dwords apart modulo the 64 banks (8 columns written by one wave)
-    static constexpr int kLine = N + (N >> 4) + 8;
+struct LayCols {  // like LayContig, with the columns 8 dwords apart modulo the 64 banks: the LDS serves 16 lanes (128 bytes) per
+                  // cycle, and the 16 lanes of a group hold 8 columns x 2 consecutive rows when the unpacked line is written -
+                  // 8 x 4 dwords side by side.  (16 dwords apart, rounds 2 - 5: columns c and c + 4 shared their banks - the
+                  // norm-only x pass kept the CU's LDS pipe busy 96 % of its time, a third of that in conflicts: round 6)
+    static constexpr int kLine = N + (N >> 4) + SDC_LAYCOLS_PAD;
     static constexpr int kUnit = 1;
     DEVI static int idx(int col, int pos) { return col * kLine + pos + (pos >> 4); }
     static constexpr int doubles(int cols) { return cols * kLine; }
