@@ -577,9 +577,23 @@ constexpr int z_lines_per_block() {
     return P >= 64 ? 1 : 64 / P;
 }
 
+// elements per thread of the node-solve launch: lines of 64 .. 256 modes take 8 instead of 16 - twice the waves, two thirds of
+// the registers: with 16 a 128^3 level launches ONE wave per SIMD (26 -> ?? us) and a 256^3 level holds three per SIMD
+#ifndef SDC_ZSOLVE_E
+#define SDC_ZSOLVE_E 8
+#endif
 template <int N>
-__global__ __launch_bounds__(z_lines_per_block<N>() * (N / fft_elems(N)) * MAXM, 3) void k_fftz_solve(ZArgs a, unsigned nlines) {
-    constexpr int E = fft_elems(N), P = N / E, LPB = z_lines_per_block<N>();
+constexpr int zsolve_elems() {
+    return ((N & (N - 1)) == 0 && N >= 64 && N <= 256 && SDC_ZSOLVE_E < fft_elems(N)) ? SDC_ZSOLVE_E : fft_elems(N);
+}
+template <int N>
+constexpr int zsolve_lines() {
+    constexpr int P = N / zsolve_elems<N>();
+    return P >= 64 ? 1 : 64 / P;
+}
+template <int N>
+__global__ __launch_bounds__(zsolve_lines<N>() * (N / zsolve_elems<N>()) * MAXM, 3) void k_fftz_solve(ZArgs a, unsigned nlines) {
+    constexpr int E = zsolve_elems<N>(), P = N / E, LPB = zsolve_lines<N>();
     constexpr int NCH = E == 16 ? 2 : 1;  // the solve buffer holds N/NCH modes per column at a time
     constexpr int CH = N / NCH, ECH = E / NCH;
     using LAY = LayContig<N>;
@@ -593,7 +607,7 @@ __global__ __launch_bounds__(z_lines_per_block<N>() * (N / fft_elems(N)) * MAXM,
     cd r[E];
 #pragma unroll
     for (int i = 0; i < E; ++i) r[i] = ok ? Win[j + i * P] : cd{0.0, 0.0};
-    fft_line<N, -1, LAY, (N / fft_elems(N)) <= 64>(r, j, c, lds, a.tw);
+    fft_line<N, -1, LAY, (P <= 64), E>(r, j, c, lds, a.tw);
     __syncthreads();  // the solve buffer aliases other waves' exchange planes (and all loads of a shared line are done)
 
     cd* buf = reinterpret_cast<cd*>(lds);  // [column][CH]
@@ -653,7 +667,7 @@ __global__ __launch_bounds__(z_lines_per_block<N>() * (N / fft_elems(N)) * MAXM,
     // through the whole kernel for reuse in the inverse
     int j2 = j;
     asm volatile("" : "+v"(j2));
-    fft_line<N, +1, LAY, (N / fft_elems(N)) <= 64>(r, j2, c, lds, a.tw);
+    fft_line<N, +1, LAY, (P <= 64), E>(r, j2, c, lds, a.tw);
     if (ok) {
 #pragma unroll
         for (int i = 0; i < E; ++i) Wl[j2 + i * P] = r[i];

@@ -370,12 +370,12 @@ static int fft_pipeline_n(sdc_ctx* c, int nf, const FieldPtrs& p, ZArgs& z, cons
     }
     {
         LaunchTimer lt(c, pname("fft_z_solve", nf));
-        constexpr int LPB = z_lines_per_block<N>();
-        constexpr int NCH = fft_elems(N) == 16 ? 2 : 1;
+        constexpr int LPB = zsolve_lines<N>(), PZ = N / zsolve_elems<N>();
+        constexpr int NCH = zsolve_elems<N>() == 16 ? 2 : 1;
         size_t ldsz = (size_t)LayContig<N>::doubles(nf * LPB) * sizeof(double);  // FFT exchange planes
         const size_t solve_sz = (size_t)nf * LPB * (N / NCH) * sizeof(cd);         // node-coupling buffer
         if (solve_sz > ldsz) ldsz = solve_sz;
-        hipLaunchKernelGGL((k_fftz_solve<N>), dim3((unsigned)((lines + LPB - 1) / LPB)), dim3(P * LPB * nf), ldsz,
+        hipLaunchKernelGGL((k_fftz_solve<N>), dim3((unsigned)((lines + LPB - 1) / LPB)), dim3(PZ * LPB * nf), ldsz,
                            c->stream, z, (unsigned)lines);
     }
     if (c->ndim == 1) {
