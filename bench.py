@@ -846,6 +846,9 @@ def validate_wire(args, torch, dist, rank, world):
     # environment it sets, its restoration, the agreement between the ranks - runs once before a real fabric ever needs it)
     forced = int(os.environ.get('PYSDC_BENCH_FORCE_WIRE_MISMATCH', '0'))
     for idx_mode, (name, env) in enumerate(WIRE_MODES):
+        # (the pinned-host share of two-rank hand-overs is for messages of tens of MB: on the small grids of this check it is
+        # switched on for every message, so that the full-size run is not its first use)
+        env = dict(env, SDC_PIPE_MIN_BYTES='0')
         saved = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
         ok = 0
@@ -865,6 +868,10 @@ def validate_wire(args, torch, dist, rank, world):
         t = torch.tensor([ok], dtype=torch.int32)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)     # every rank must agree, and every rank takes the same branch
         if int(t.item()) == 1:
+            if saved.get('SDC_PIPE_MIN_BYTES') is None:      # (the mode's own settings stay for the run; this one was the check's)
+                os.environ.pop('SDC_PIPE_MIN_BYTES', None)
+            else:
+                os.environ['SDC_PIPE_MIN_BYTES'] = saved['SDC_PIPE_MIN_BYTES']
             return name, err
         for k, v in saved.items():
             if v is None:
