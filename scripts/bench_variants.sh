@@ -7,3 +7,11 @@ try:
     d=json.loads(l); print('$args', '->', round(d['value'],3), d['unit'], 'finite', d.get('finite'), 'niter', d.get('niter'))
 except Exception as e: print('$args', 'FAILED', l[:300])"
 done
+for args in "--workload allencahn --n 128" "--workload allencahn --n 128 --kernel-events timed" "--workload allencahn --n 64 --ac-variant ref2d --restol 1e-8" "--n 768" "--n 640 --eager-fields" "--n 96"; do
+  python bench.py $args --steps 3 --warmup 1 --no-cpu-baseline --no-extras --details-file gpurun_out/v.json 2>&1 | tail -1 | python -c "
+import sys,json
+l=sys.stdin.read().strip()
+try:
+    d=json.loads(l); print('$args', '->', round(d['value'],3), d['unit'], 'finite', d.get('finite'), 'niter', d.get('niter'))
+except Exception as e: print('$args', 'FAILED', l[:300])"
+done
