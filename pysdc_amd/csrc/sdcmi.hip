@@ -1293,7 +1293,7 @@ static int trail_reset(sdc_ctx* c) {
 
 extern "C" {
 
-int sdc_version(void) { return 102; }  // 101: sdc_work_counters writes out[5]; 102: residual post / wait, batched eval_f, accumulating transfer; sdc_set_pipeline_groups gone
+int sdc_version(void) { return 103; }  // 101: sdc_work_counters writes out[5]; 102: residual post / wait, batched eval_f, accumulating transfer; sdc_set_pipeline_groups gone; 103: sdc_transfer_apply_nested, SDC_EXPL_SYMBOL (sdc_set_symbol which = 1)
 
 int sdc_init_field(sdc_ctx* c, double* dst, const int* freq, double amp, unsigned long long seed) {
     if (!c || !dst || !freq) return fail(c, SDC_ERR_PARAM, "null pointer");
