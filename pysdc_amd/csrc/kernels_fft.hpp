@@ -582,9 +582,13 @@ constexpr int z_lines_per_block() {
 #ifndef SDC_ZSOLVE_E
 #define SDC_ZSOLVE_E 8
 #endif
+#ifndef SDC_ZSOLVE_E_SMALL
+#define SDC_ZSOLVE_E_SMALL SDC_ZSOLVE_E   // ... of lines of 64 / 128 modes
+#endif
 template <int N>
 constexpr int zsolve_elems() {
-    return ((N & (N - 1)) == 0 && N >= 64 && N <= 256 && SDC_ZSOLVE_E < fft_elems(N)) ? SDC_ZSOLVE_E : fft_elems(N);
+    constexpr int want = N <= 128 ? SDC_ZSOLVE_E_SMALL : SDC_ZSOLVE_E;
+    return ((N & (N - 1)) == 0 && N >= 64 && N <= 256 && want < fft_elems(N)) ? want : fft_elems(N);
 }
 template <int N>
 constexpr int zsolve_lines() {
