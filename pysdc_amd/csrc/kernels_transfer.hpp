@@ -186,8 +186,11 @@ struct NestedArgs {
 // rows are loaded (the rows two neighbouring j share come from the caches); the sums are nested and ordered like the table
 // says - what k_xfer_fused3 and the three separable passes compute.
 //   grid: x = (k blocks) * (n_out / blockDim.y), y = n_out / TI, z = field;  block = (KX, JY), KX a power of two >= 16
+#ifndef SDC_RESTRICT_THREADS
+#define SDC_RESTRICT_THREADS 256
+#endif
 template <int TI>
-__global__ __launch_bounds__(256) void k_restrict3_nested(NestedArgs a, unsigned kx_blocks) {
+__global__ __launch_bounds__(SDC_RESTRICT_THREADS) void k_restrict3_nested(NestedArgs a, unsigned kx_blocks) {
     const unsigned n_out = (unsigned)a.n_out, n_in = (unsigned)a.n_in;
 #ifndef SDC_XFER_XCD
 #define SDC_XFER_XCD 1
@@ -215,7 +218,11 @@ __global__ __launch_bounds__(256) void k_restrict3_nested(NestedArgs a, unsigned
     // (the lane to the left holds column k - 1 of the same row unless this one starts a row or a wave)
     const bool lane0 = threadIdx.x == 0 || ((threadIdx.y * blockDim.x + threadIdx.x) & 63u) == 0;
     auto row_sum = [&](const double* __restrict__ row) {
-        const double2 v = *reinterpret_cast<const double2*>(row + 2 * (size_t)k);
+#ifndef SDC_RESTRICT_NT
+#define SDC_RESTRICT_NT 0
+#endif
+        const double2* __restrict__ pv = reinterpret_cast<const double2*>(row + 2 * (size_t)k);
+        const double2 v = SDC_RESTRICT_NT ? double2{__builtin_nontemporal_load(&pv->x), __builtin_nontemporal_load(&pv->y)} : *pv;
         double left = __shfl_up(v.y, 1);
         if (lane0) left = row[kl];
         double acc = 0.0;
@@ -325,9 +332,12 @@ __global__ __launch_bounds__(256) void k_prolong3_nested(NestedArgs a) {
 #endif
     // (the fine values the tile is added to are fetched now: their latency hides behind everything below)
     double old[TF];
+#ifndef SDC_PROLONG_NT
+#define SDC_PROLONG_NT 3   // nontemporal load / store of the fine tile that is added to (bit 0 / 1): 272 -> 240 us at 3 x 128^3 -> 256^3
+#endif
     if (!SDC_PROLONG_OLD_LATE && a.accumulate) {
 #pragma unroll
-        for (int fi = 0; fi < TF; ++fi) old[fi] = dst[fi * plane];
+        for (int fi = 0; fi < TF; ++fi) old[fi] = (SDC_PROLONG_NT & 1) ? __builtin_nontemporal_load(dst + fi * plane) : dst[fi * plane];
     }
     __syncthreads();
     if (tid < TF * W) {   // entry c of fine plane fi sits in window slot (local position) - fi / 2
@@ -370,7 +380,9 @@ __global__ __launch_bounds__(256) void k_prolong3_nested(NestedArgs a) {
             const double wi = __hiloint2double((int)hi, (int)lo);
             if (wi != 0.0) acc += wi * t2[(fi >> 1) + p];
         }
-        dst[fi * plane] = a.accumulate ? old[fi] + acc : acc;
+        const double res = a.accumulate ? old[fi] + acc : acc;
+        if (SDC_PROLONG_NT & 2) __builtin_nontemporal_store(res, dst + fi * plane);
+        else dst[fi * plane] = res;
     }
 }
 

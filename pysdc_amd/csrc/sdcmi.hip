@@ -4041,9 +4041,9 @@ int sdc_transfer_apply_nested(void* stream, int nfields, int ndim, int n_out, in
         // launch wants a few thousand workgroups
         const unsigned kx_blocks = (unsigned)n_out / kx;
         const size_t per_plane = (size_t)kx_blocks * ((unsigned)n_out / jy) * (size_t)nfields;
-        // (measured at 3 x 256^3 -> 128^3, scripts/probes/xfer_nested_probe.hip: TI = 4: 133 us, 8: 146, 16: 172 - few, long
-        // workgroups leave CUs idle at the end)
-        const int TI = per_plane * (n_out / 8) >= 16384 ? 8 : (per_plane * (n_out / 4) >= 4096 ? 4 : 2);
+        // (measured at 3 x 256^3 -> 128^3, scripts/probes/xfer_nested_probe.hip: TI = 1: 146 us, 2: 125, 4: 133 - 139, 8: 146,
+        // 16: 172 - few, long workgroups leave CUs idle at the end; rows per workgroup 1 / 2 / 4 / 8: 138 / 138 / 153 / 156)
+        const int TI = per_plane * (n_out / 8) >= 65536 ? 8 : (per_plane * (n_out / 4) >= 16384 ? 4 : 2);
         const dim3 g(kx_blocks * ((unsigned)n_out / jy), (unsigned)n_out / TI, (unsigned)nfields), blk(kx, jy);
         if (TI == 8) hipLaunchKernelGGL((k_restrict3_nested<8>), g, blk, 0, st, a, kx_blocks);
         else if (TI == 4) hipLaunchKernelGGL((k_restrict3_nested<4>), g, blk, 0, st, a, kx_blocks);

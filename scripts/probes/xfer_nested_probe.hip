@@ -45,7 +45,10 @@ int main() {
             CK(hipEventRecord(e0, 0));
             if (which == 0) {
                 a.in = fine; a.in_minus = nullptr; a.out = cout_; a.out_minus = cold; a.idx = dri; a.w = drw; a.n_out = nc; a.n_in = nf; a.W = 3; a.accumulate = 0;
-                const unsigned kx = 128, jy = 2;
+#ifndef PROBE_JY
+#define PROBE_JY 2
+#endif
+                const unsigned kx = 128, jy = PROBE_JY;
                 hipLaunchKernelGGL((k_restrict3_nested<PROBE_TI>), dim3(nc / jy, nc / PROBE_TI, K), dim3(kx, jy), 0, 0, a, 1u);
             } else {
                 a.in = coarse; a.in_minus = cold; a.out = fine; a.out_minus = nullptr; a.idx = dpi; a.w = dpw; a.n_out = nf; a.n_in = nc; a.W = W; a.accumulate = 1;
