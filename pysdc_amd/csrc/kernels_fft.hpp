@@ -74,17 +74,28 @@ __global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_fwd(FieldPtr
     const int c = blockIdx.x * T + col;
     const bool ok = c < ncol;
     const double* __restrict__ in = p.in[blockIdx.y];
+#ifndef SDC_XFWD_NT
+#define SDC_XFWD_NT 1   // bit 0: nontemporal loads of the fields read (round 6, 256^3: the node right-hand sides with their terms 153 -> 130 us;
+                        // neutral at 1024^3), bit 1: nontemporal stores of the spectrum (a loss: the next pass reads it)
+#endif
+    auto ldf = [](const double* q) {
+#if SDC_XFWD_NT & 1
+        return cd{__builtin_nontemporal_load(q), __builtin_nontemporal_load(q + 1)};
+#else
+        return *reinterpret_cast<const cd*>(q);
+#endif
+    };
     cd r[E];
 #pragma unroll
     for (int i = 0; i < E; ++i)
-        r[i] = ok ? *reinterpret_cast<const cd*>(in + (size_t)(j + i * P) * rest + 2 * (size_t)c) : cd{0.0, 0.0};
+        r[i] = ok ? ldf(in + (size_t)(j + i * P) * rest + 2 * (size_t)c) : cd{0.0, 0.0};
     if (lin.n > 0 && blockIdx.y == 0 && ok) {   // (same accumulation order as k_lincomb: base, then term by term)
         for (int k = 0; k < lin.n; ++k) {
             const double* __restrict__ xk = lin.x[k];
             const double ck = lin.c[k];
 #pragma unroll
             for (int i = 0; i < E; ++i) {
-                const cd v = *reinterpret_cast<const cd*>(xk + (size_t)(j + i * P) * rest + 2 * (size_t)c);
+                const cd v = ldf(xk + (size_t)(j + i * P) * rest + 2 * (size_t)c);
                 r[i].x += ck * v.x;
                 r[i].y += ck * v.y;
             }
@@ -128,8 +139,15 @@ __global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_fwd(FieldPtr
         const int k = j + i * P;
         if (ok && k <= N / 2) {
             cd* dst = Wf + (size_t)k * rest + 2 * (size_t)c;
+#if SDC_XFWD_NT & 2
+            __builtin_nontemporal_store(A[i].x, &dst[0].x);
+            __builtin_nontemporal_store(A[i].y, &dst[0].y);
+            __builtin_nontemporal_store(B[i].x, &dst[1].x);
+            __builtin_nontemporal_store(B[i].y, &dst[1].y);
+#else
             dst[0] = A[i];
             dst[1] = B[i];
+#endif
         }
     }
 }
@@ -228,8 +246,16 @@ __global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_inv(FieldPtr
         const int k = j + i * P;
         if (ok && k <= N / 2) {
             const cd* src = Wf + (size_t)k * rest + 2 * (size_t)c;
-            A[i] = src[0];
-            B[i] = src[1];
+#ifndef SDC_XINV_LD_NT
+#define SDC_XINV_LD_NT 0   // nontemporal loads of the spectra in the launches that STORE real fields
+#endif
+            if constexpr (STORE && SDC_XINV_LD_NT) {
+                A[i] = cd{__builtin_nontemporal_load(&src[0].x), __builtin_nontemporal_load(&src[0].y)};
+                B[i] = cd{__builtin_nontemporal_load(&src[1].x), __builtin_nontemporal_load(&src[1].y)};
+            } else {
+                A[i] = src[0];
+                B[i] = src[1];
+            }
             if constexpr (ADD) {
                 const cd* s2 = add + (size_t)k * rest + 2 * (size_t)c;
                 A[i] = cadd(A[i], s2[0]);
@@ -379,15 +405,24 @@ __global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_inv(FieldPtr
                     }
                 }
             }
+#ifndef SDC_XINV_NT
+#define SDC_XINV_NT 0   // nontemporal stores of the real fields
+#endif
+            auto stf = [](double* q, cd v) {
+#if SDC_XINV_NT
+                __builtin_nontemporal_store(v.x, q);
+                __builtin_nontemporal_store(v.y, q + 1);
+#else
+                *reinterpret_cast<cd*>(q) = v;
+#endif
+            };
 #pragma unroll
-            for (int i = 0; i < E; ++i)
-                *reinterpret_cast<cd*>(out + (size_t)(j + i * P) * rest + 2 * (size_t)c) = r[i];
+            for (int i = 0; i < E; ++i) stf(out + (size_t)(j + i * P) * rest + 2 * (size_t)c, r[i]);
             if (double* const eo = epi.target(by)) {  // reaction term of the field that is being written
 #pragma unroll
                 for (int i = 0; i < E; ++i)
-                    *reinterpret_cast<cd*>(eo + (size_t)(j + i * P) * rest + 2 * (size_t)c) =
-                        cd{react_value(r[i].x, epi.kind, epi.p0, epi.p1, epi.nu),
-                           react_value(r[i].y, epi.kind, epi.p0, epi.p1, epi.nu)};
+                    stf(eo + (size_t)(j + i * P) * rest + 2 * (size_t)c,
+                        cd{react_value(r[i].x, epi.kind, epi.p0, epi.p1, epi.nu), react_value(r[i].y, epi.kind, epi.p0, epi.p1, epi.nu)});
             }
         }
     }
@@ -608,9 +643,18 @@ __global__ __launch_bounds__(zsolve_lines<N>() * (N / zsolve_elems<N>()) * MAXM,
     const bool ok = line < nlines;
     cd* __restrict__ Wl = a.W + f * a.fstride + line * N;
     const cd* __restrict__ Win = a.dup ? a.W + line * N : Wl;  // dup: every field starts from field 0's line
+#ifndef SDC_ZSOLVE_NT
+#define SDC_ZSOLVE_NT 0   // bit 0: nontemporal loads, bit 1: nontemporal stores of the lines
+#endif
     cd r[E];
 #pragma unroll
-    for (int i = 0; i < E; ++i) r[i] = ok ? Win[j + i * P] : cd{0.0, 0.0};
+    for (int i = 0; i < E; ++i) {
+#if SDC_ZSOLVE_NT & 1
+        r[i] = ok ? cd{__builtin_nontemporal_load(&Win[j + i * P].x), __builtin_nontemporal_load(&Win[j + i * P].y)} : cd{0.0, 0.0};
+#else
+        r[i] = ok ? Win[j + i * P] : cd{0.0, 0.0};
+#endif
+    }
     fft_line<N, -1, LAY, (P <= 64), E>(r, j, c, lds, a.tw);
     __syncthreads();  // the solve buffer aliases other waves' exchange planes (and all loads of a shared line are done)
 
@@ -674,7 +718,14 @@ __global__ __launch_bounds__(zsolve_lines<N>() * (N / zsolve_elems<N>()) * MAXM,
     fft_line<N, +1, LAY, (P <= 64), E>(r, j2, c, lds, a.tw);
     if (ok) {
 #pragma unroll
-        for (int i = 0; i < E; ++i) Wl[j2 + i * P] = r[i];
+        for (int i = 0; i < E; ++i) {
+#if SDC_ZSOLVE_NT & 2
+            __builtin_nontemporal_store(r[i].x, &Wl[j2 + i * P].x);
+            __builtin_nontemporal_store(r[i].y, &Wl[j2 + i * P].y);
+#else
+            Wl[j2 + i * P] = r[i];
+#endif
+        }
     }
 }
 

@@ -75,6 +75,25 @@ __device__ inline void block_max_to_slots(unsigned long long* slots, const doubl
 // out[mo] = u0 + sum_j cI[mo][j] F_impl[j] (+ cE[mo][j] F_expl[j]) (+ tau[mo]) (- U[mo+1], max-norm)
 // MODE 0: the sums are stored; 1: node norms of the residual only; 2: the norms AND the bare quadrature sums (out[mo]): the
 // residual of a fine level and the integrals its restriction asks for next (core/base_transfer.py:120-127) in one pass over F
+#ifndef SDC_QUAD_NT
+#define SDC_QUAD_NT 3   // bit 0: nontemporal loads of F, bit 1: nontemporal stores of the sums (round 6, 256^3 x 3 nodes: residual +
+                        // integrals 351 -> 310 us, gather 265 -> 245, integrate 226 -> 197; 1024^3: 16.4 -> 16.2 ms)
+#endif
+__device__ __forceinline__ double2 quad_ld(const double2* p) {
+#if SDC_QUAD_NT & 1
+    return double2{__builtin_nontemporal_load(&p->x), __builtin_nontemporal_load(&p->y)};
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void quad_st(double2* p, double2 v) {
+#if SDC_QUAD_NT & 2
+    __builtin_nontemporal_store(v.x, &p->x);
+    __builtin_nontemporal_store(v.y, &p->y);
+#else
+    *p = v;
+#endif
+}
 template <int M, int NCOMP, int MODE>
 __global__ __launch_bounds__(256) void k_quad(QuadArgs a) {
     const size_t n2 = a.N >> 1;
@@ -85,8 +104,8 @@ __global__ __launch_bounds__(256) void k_quad(QuadArgs a) {
         double2 fi[M], fe[M];
 #pragma unroll
         for (int j = 0; j < M; ++j) {
-            fi[j] = reinterpret_cast<const double2*>(a.F + ((size_t)(j + 1) * NCOMP) * a.N)[i];
-            if (NCOMP == 2) fe[j] = reinterpret_cast<const double2*>(a.F + ((size_t)(j + 1) * NCOMP + 1) * a.N)[i];
+            fi[j] = quad_ld(reinterpret_cast<const double2*>(a.F + ((size_t)(j + 1) * NCOMP) * a.N) + i);
+            if (NCOMP == 2) fe[j] = quad_ld(reinterpret_cast<const double2*>(a.F + ((size_t)(j + 1) * NCOMP + 1) * a.N) + i);
         }
         double2 u0 = a.u0 ? reinterpret_cast<const double2*>(a.u0)[i] : double2{0.0, 0.0};
 #pragma unroll
@@ -104,7 +123,7 @@ __global__ __launch_bounds__(256) void k_quad(QuadArgs a) {
                         acc.y += a.cI[mo][j] * fi[j].y;
                     }
                 }
-                if (MODE == 2) reinterpret_cast<double2*>(a.out[mo])[i] = acc;   // the quadrature alone: what integrate() returns
+                if (MODE == 2) quad_st(reinterpret_cast<double2*>(a.out[mo]) + i, acc);   // the quadrature alone: what integrate() returns
                 acc.x += u0.x;
                 acc.y += u0.y;
                 if (a.tau) {
@@ -113,7 +132,7 @@ __global__ __launch_bounds__(256) void k_quad(QuadArgs a) {
                     acc.y += t.y;
                 }
                 if (MODE == 0) {
-                    reinterpret_cast<double2*>(a.out[mo])[i] = acc;
+                    quad_st(reinterpret_cast<double2*>(a.out[mo]) + i, acc);
                 } else {
                     double2 us = reinterpret_cast<const double2*>(a.Usub + (size_t)(mo + 1) * a.N)[i];
                     double r0 = fabs(acc.x - us.x), r1 = fabs(acc.y - us.y);
