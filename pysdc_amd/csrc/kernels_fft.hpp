@@ -748,9 +748,18 @@ __global__ __launch_bounds__(z_lines_per_block<N>() * (N / fft_elems(N)) * MAXM,
     const size_t base = f * fstride + line * N;
     cd r[E];
     // (source field `one` may live outside the strided block: the last node's spectrum, SpecArgs::SL)
+#ifndef SDC_ZPLAIN_NT
+#define SDC_ZPLAIN_NT 0   // bit 0: nontemporal loads, bit 1: nontemporal stores of the lines
+#endif
     const cd* __restrict__ in = (f == one) ? src_one + line * N : src + base;
 #pragma unroll
-    for (int i = 0; i < E; ++i) r[i] = ok ? in[j + i * P] : cd{0.0, 0.0};
+    for (int i = 0; i < E; ++i) {
+#if SDC_ZPLAIN_NT & 1
+        r[i] = ok ? cd{__builtin_nontemporal_load(&in[j + i * P].x), __builtin_nontemporal_load(&in[j + i * P].y)} : cd{0.0, 0.0};
+#else
+        r[i] = ok ? in[j + i * P] : cd{0.0, 0.0};
+#endif
+    }
     if (sub) {  // the difference of two spectra is transformed (sub may be the destination: every thread reads its own modes first)
 #pragma unroll
         for (int i = 0; i < E; ++i)
@@ -783,7 +792,14 @@ __global__ __launch_bounds__(z_lines_per_block<N>() * (N / fft_elems(N)) * MAXM,
     fft_line<N, DIR, LAY, (N / fft_elems(N)) <= 64>(r, j, c, lds, tw);
     if (ok) {
 #pragma unroll
-        for (int i = 0; i < E; ++i) dst[base + j + i * P] = r[i];
+        for (int i = 0; i < E; ++i) {
+#if SDC_ZPLAIN_NT & 2
+            __builtin_nontemporal_store(r[i].x, &dst[base + j + i * P].x);
+            __builtin_nontemporal_store(r[i].y, &dst[base + j + i * P].y);
+#else
+            dst[base + j + i * P] = r[i];
+#endif
+        }
     }
 }
 
@@ -1481,9 +1497,17 @@ void k_spec_z(SpecArgs a, unsigned nlines) {
             const int p_ = threadIdx.x + it * NT;
             lo[it] = hi[it] = cd{0.0, 0.0};
             lz[it] = 0.0;
+#ifndef SDC_SPECZ_LD_NT
+#define SDC_SPECZ_LD_NT 0   // nontemporal loads of the start-value modes (read once per launch)
+#endif
             if (p_ < NI && ok) {
+#if SDC_SPECZ_LD_NT
+                lo[it] = cd{__builtin_nontemporal_load(&a.S0[base + p_].x), __builtin_nontemporal_load(&a.S0[base + p_].y)};
+                if (p_ >= 1 && p_ < N / 2) hi[it] = cd{__builtin_nontemporal_load(&a.S0[base + N - p_].x), __builtin_nontemporal_load(&a.S0[base + N - p_].y)};
+#else
                 lo[it] = a.S0[base + p_];
                 if (p_ >= 1 && p_ < N / 2) hi[it] = a.S0[base + N - p_];
+#endif
                 lz[it] = a.lamI[p_].x;
             }
         }
