@@ -247,9 +247,10 @@ __global__ __launch_bounds__((N / fft_elems(N)) * T, 4) void k_fftx_inv(FieldPtr
         if (ok && k <= N / 2) {
             const cd* src = Wf + (size_t)k * rest + 2 * (size_t)c;
 #ifndef SDC_XINV_LD_NT
-#define SDC_XINV_LD_NT 0   // nontemporal loads of the spectra in the launches that STORE real fields
+#define SDC_XINV_LD_NT 1   // nontemporal loads of the spectra in the launches that STORE real fields, lines up to 256 modes
+                           // (config 5: -1 % per step; at 1024^3 the store pass LOSES 13 %: the spectra are long gone from the caches there)
 #endif
-            if constexpr (STORE && SDC_XINV_LD_NT) {
+            if constexpr (STORE && SDC_XINV_LD_NT && N <= 256) {
                 A[i] = cd{__builtin_nontemporal_load(&src[0].x), __builtin_nontemporal_load(&src[0].y)};
                 B[i] = cd{__builtin_nontemporal_load(&src[1].x), __builtin_nontemporal_load(&src[1].y)};
             } else {
