@@ -41,6 +41,12 @@ static int ensure_work(sdc_ctx* c);
 // work spectra a context holds: one per node - in 1-D (lines: next to nothing) at least three, so that a problem whose two
 // parts are given by symbols gets its solution and both parts out of one transform whatever the number of nodes
 static inline int work_fields(const sdc_ctx* c) { return c->ndim == 1 && c->M < 3 ? 3 : c->M; }
+// complex columns per tile of the strided passes (x and y): 128-byte row segments up to N = 1024, 64-byte ones at 2048
+#ifndef SDC_TSMALL
+#define SDC_TSMALL 16   // ... of lines of up to 256 modes: 256-byte row segments (round 6, config 5: +1 - 2 %; 32: the same; 4: -22 %)
+#endif
+template <int N>
+constexpr int strided_cols() { return N >= 2048 ? 4 : (N == 1024 ? SDC_T1024 : (N <= 256 && (N & (N - 1)) == 0 ? SDC_TSMALL : 8)); }
 // the FFT kernels transform lines of length 2^p <= 1024 (2048 in 1-D and 2-D), 3 * 2^p from 24 to 768 and 5 * 2^p from 40 to 640
 // (fft.hpp)
 static inline bool fourier_ok(const sdc_ctx* c) {
@@ -336,7 +342,7 @@ static int fft_pipeline_n(sdc_ctx* c, int nf, const FieldPtrs& p, ZArgs& z, cons
     epi.inv_alpha = rq.inv_alpha;
     const bool can = c->ndim >= 2 && (rq.out != nullptr || rq.field < 0 || rq.impl_out != nullptr);  // (1-D lines go through k_promote / k_realpart: the caller launches k_reaction)
     constexpr int E = fft_elems(N), P = N / E;
-    constexpr int T = N >= 2048 ? 4 : (N == 1024 ? SDC_T1024 : 8);  // complex columns per strided tile (128-byte row segments up to N = 1024)
+    constexpr int T = strided_cols<N>();  // complex columns per strided tile (128-byte row segments up to N = 1024)
     const size_t lds_str = (size_t)LayStrided<N, T>::doubles(T) * sizeof(double);
     const int n = c->n;
     z.W = c->W;
@@ -404,7 +410,7 @@ static int fft_pipeline_n(sdc_ctx* c, int nf, const FieldPtrs& p, ZArgs& z, cons
 // forward transform of nf real fields into fully transformed spectra dst[f] (dst + f*fstride)
 template <int N>
 static int fwd_transform_n(sdc_ctx* c, int nf, const FieldPtrs& p, cd* dst, size_t fstride) {
-    constexpr int E = fft_elems(N), P = N / E, T = N >= 2048 ? 4 : (N == 1024 ? SDC_T1024 : 8), LPB = z_lines_per_block<N>();
+    constexpr int E = fft_elems(N), P = N / E, T = strided_cols<N>(), LPB = z_lines_per_block<N>();
     const size_t lds_str = (size_t)LayStrided<N, T>::doubles(T) * sizeof(double);
     const int n = c->n;
     size_t lines;
@@ -439,7 +445,7 @@ static int fwd_transform_n(sdc_ctx* c, int nf, const FieldPtrs& p, cd* dst, size
 template <int N>
 static int inverse_tail_n(sdc_ctx* c, int nf, cd* work, const FieldPtrs& p, unsigned long long* norms, bool y_done = false,
                           bool defer_x = false) {
-    constexpr int E = fft_elems(N), P = N / E, T = N >= 2048 ? 4 : (N == 1024 ? SDC_T1024 : 8);
+    constexpr int E = fft_elems(N), P = N / E, T = strided_cols<N>();
     const size_t lds_str = (size_t)LayStrided<N, T>::doubles(T) * sizeof(double);
     // (the norm-only pass with one wave per column keeps the columns apart in LDS: a few more bytes)
     const size_t lds_x = (SDC_XWAVE && P == 64) ? (size_t)LayCols<N>::doubles(T) * sizeof(double) : lds_str;
@@ -500,7 +506,7 @@ static int inverse_tail_n(sdc_ctx* c, int nf, cd* work, const FieldPtrs& p, unsi
 // only the last (x) pass, norm-only, of fields that went through the other passes already, plus one more field `add`
 template <int N>
 static int inverse_tail_x_only(sdc_ctx* c, int nf, cd* work, const FieldPtrs& p, unsigned long long* norms, const cd* add) {
-    constexpr int E = fft_elems(N), P = N / E, T = N >= 2048 ? 4 : (N == 1024 ? SDC_T1024 : 8);
+    constexpr int E = fft_elems(N), P = N / E, T = strided_cols<N>();
     const size_t lds_str = (SDC_XWAVE && P == 64) ? (size_t)LayCols<N>::doubles(T) * sizeof(double)
                                                   : (size_t)LayStrided<N, T>::doubles(T) * sizeof(double);
     const int rest = (int)(c->N / c->n);
@@ -519,7 +525,7 @@ static int inverse_tail_x_only(sdc_ctx* c, int nf, cd* work, const FieldPtrs& p,
 template <int N>
 static int joint_norms_n(sdc_ctx* c, int nf, cd* work, const cd* d_new, const cd* d_old, cd* dbuf, cd* dscr,
                          unsigned long long* norms, unsigned long long* normsA, bool z_done = false) {
-    constexpr int E = fft_elems(N), P = N / E, T = N >= 2048 ? 4 : (N == 1024 ? SDC_T1024 : 8), LPB = z_lines_per_block<N>();
+    constexpr int E = fft_elems(N), P = N / E, T = strided_cols<N>(), LPB = z_lines_per_block<N>();
     const size_t lds_str = (size_t)LayStrided<N, T>::doubles(T) * sizeof(double);
     const size_t lds_x = (SDC_XWAVE && P == 64) ? (size_t)LayCols<N>::doubles(T) * sizeof(double) : lds_str;
     const int n = c->n;
@@ -1208,7 +1214,7 @@ static int residual_shift_n(sdc_ctx* c, cd* dbuf, const cd* newS0, const cd* old
     }
     HIPCHK(c, hipGetLastError());
     if (c->ndim == 3) {
-        constexpr int E = fft_elems(N), PS = N / E, T = N >= 2048 ? 4 : (N == 1024 ? SDC_T1024 : 8);
+        constexpr int E = fft_elems(N), PS = N / E, T = strided_cols<N>();
         const size_t lds_str = (size_t)LayStrided<N, T>::doubles(T) * sizeof(double);
         LaunchTimer lt(c, pname("fft_y_inv", 1));
         hipLaunchKernelGGL((k_ffty<N, T, +1>), dim3((n + T - 1) / T, n / 2 + 1, 1), dim3(PS * T), lds_str, c->stream, dbuf,

@@ -9,7 +9,7 @@ import json
 try:
     d=json.load(open("gpurun_out/acvar_$tag.details.json"))["headline"]
     k=d["kernels"]
-    print("$tag", round(d["value"],2), "steps/s", round(d["ms_per_step"],3), "ms/step", {n:round(v["ms_per_launch"]*1e3,1) for n,v in k.items() if n.startswith(("fft_y","fft_z_solve","fft_x_inv"))})
+    print("$tag", round(d["value"],2), "steps/s", round(d["ms_per_step"],3), "ms/step", {n:round(v["ms_per_launch"]*1e3,1) for n,v in k.items() if n.startswith(("fft_y","fft_x"))})
 except Exception as e:
     print("$tag failed", e)
 PY
