@@ -45,8 +45,11 @@ static inline int work_fields(const sdc_ctx* c) { return c->ndim == 1 && c->M < 
 #ifndef SDC_TSMALL
 #define SDC_TSMALL 16   // ... of lines of up to 256 modes: 256-byte row segments (round 6, config 5: +1 - 2 %; 32: the same; 4: -22 %)
 #endif
+#ifndef SDC_T512
+#define SDC_T512 8
+#endif
 template <int N>
-constexpr int strided_cols() { return N >= 2048 ? 4 : (N == 1024 ? SDC_T1024 : (N <= 256 && (N & (N - 1)) == 0 ? SDC_TSMALL : 8)); }
+constexpr int strided_cols() { return N >= 2048 ? 4 : (N == 1024 ? SDC_T1024 : (N == 512 ? SDC_T512 : (N <= 256 && (N & (N - 1)) == 0 ? SDC_TSMALL : 8))); }
 // the FFT kernels transform lines of length 2^p <= 1024 (2048 in 1-D and 2-D), 3 * 2^p from 24 to 768 and 5 * 2^p from 40 to 640
 // (fft.hpp)
 static inline bool fourier_ok(const sdc_ctx* c) {
